@@ -1,0 +1,254 @@
+"""TEST INFRASTRUCTURE -- golden-vector generator.  Run ONLY in the build container:
+
+    python oracle/make_golden.py            # writes tests/golden/*.npz, *.json
+
+Imports the real reference from /root/reference (via oracle/ref_import.py + oracle/shims),
+loads formula weights (paif_amd/synthetic.py), feeds formula inputs and stores the reference's
+outputs as small fixtures.  The fixtures hold DATA only (inputs are regenerated from the
+formulas; expected outputs are stored); no reference source travels.  The reference has no
+tests/fixtures of its own, so these outputs of the reference itself are
+what pins the oracle and the HIP path.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from oracle import ref_import  # noqa: E402
+from oracle import paif_oracle as O  # noqa: E402
+from paif_amd import synthetic as S  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+PRIMITIVES = [  # the [probe] list of SURVEY.md 8(a) O7 + the shipped genotype
+    "Denseblocks_3_1", "DilConv_3_2", "ECAattention_3", "Residualblocks_7_1",
+    "SPAattention_3", "SepConv_3_1", "SepConv_5_1", "DilConv_5_1",
+    "Denseblocks_5_2", "Denseblocks_7_1", "Residualblocks_3_2", "Residualblocks_5_2",
+]
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def npy(x):
+    return x.detach().cpu().numpy()
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote %-28s %8.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+def build_model(R, backbone, cls="Network_MM_Searched"):
+    with ref_import.quiet():
+        if cls == "Network_MM_Searched":
+            m = R["mfa"].Network_MM_Searched(32, O.FUSION_AT, None, None, backbone, num_classes=9)
+        else:
+            fus = R["mfa"].Network_Fusion_Searched(32, None, O.FUSION_AT)
+            m = R["mfa"].Network_MM_CompModel(fus, None, None, backbone, 9, 256, None)
+    m.eval()
+    S.load_formula_weights(m)
+    return m
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    R = ref_import.load()
+    mfa, ops = R["mfa"], R["ops"]
+    torch.manual_seed(0)
+
+    # ---- G-a: every primitive, forward + input gradient under loss = sum(y * r) -------------
+    x_np = S.make_smooth_feature(11, 1, 32, 24, 32)
+    r_np = S.make_feature(12, (1, 32, 24, 32))
+    out = {}
+    for prim in PRIMITIVES:
+        with ref_import.quiet():
+            op = mfa.MixedOp(32, prim)
+        op.eval()
+        S.load_formula_weights(op, salt=PRIMITIVES.index(prim) + 1)
+        x = t(x_np).requires_grad_(True)
+        y = op(x)
+        (y * t(r_np)).sum().backward()
+        out[prim + ".y"] = npy(y)
+        out[prim + ".dx"] = npy(x.grad)
+    save("ga_primitives", **out)
+
+    # ---- G-b: guided filter (r=4, both eps) + fp64 variant documenting the fp32 noise floor --
+    from guided_filter_pytorch.guided_filter import GuidedFilter
+
+    y_np = S.make_smooth_feature(21, 1, 32, 24, 32)
+    guide = t(y_np).max(1, keepdim=True)[0] - t(y_np).min(1, keepdim=True)[0]
+    out = {}
+    for eps in (1e-3, 1e-4):
+        out["lf_eps%g" % eps] = npy(GuidedFilter(4, eps)(guide, t(y_np)))
+        out["lf64_eps%g" % eps] = npy(GuidedFilter(4, eps)(guide.double(), t(y_np).double())).astype(np.float32)
+    save("gb_guided_filter", **out)
+
+    # ---- G-c: fusion net with intermediates ------------------------------------------------
+    with ref_import.quiet():
+        fus = mfa.Network_Fusion_Searched(32, None, O.FUSION_AT)
+    fus.eval()
+    S.load_formula_weights(fus)
+    inter = {}
+    hooks = [
+        fus.stem_1.register_forward_hook(lambda m, i, o: inter.__setitem__("fir", npy(o))),
+        fus.stem_2.register_forward_hook(lambda m, i, o: inter.__setitem__("fvis", npy(o))),
+        fus.decompation.conv1x1_lf.register_forward_hook(lambda m, i, o: inter.__setitem__("lf", npy(o))),
+        fus.decompation.conv1x1_hf.register_forward_hook(lambda m, i, o: inter.__setitem__("hf", npy(o))),
+        fus.decompation.chain.register_forward_hook(lambda m, i, o: inter.__setitem__("lf_re", npy(o))),
+        fus.decompation.chain2.register_forward_hook(lambda m, i, o: inter.__setitem__("hf_re", npy(o))),
+        fus.decompation.register_forward_hook(
+            lambda m, i, o: inter.update(ir_feature=npy(o[0]), vis_feature=npy(o[1]))),
+        fus.spa.register_forward_hook(lambda m, i, o: inter.__setitem__("scale", npy(o))),
+        fus.chain.register_forward_hook(lambda m, i, o: inter.__setitem__("feature2", npy(o))),
+    ]
+    ir, vis, _ = S.make_batch(1, 48, 64)
+    ycc = mfa.RGB2YCrCb(t(vis))
+    with torch.no_grad():
+        fused = fus(t(ir), ycc[:, 0:1])
+    keep = {k: inter[k] for k in ("fir", "lf", "hf", "lf_re", "ir_feature", "vis_feature", "scale", "feature2")}
+    save("gc_fusion_48x64", fused=npy(fused), **keep)
+    for h in hooks:
+        h.remove()
+    ir, vis, _ = S.make_batch(2, 64, 96)
+    ycc = mfa.RGB2YCrCb(t(vis))
+    irt = t(ir).requires_grad_(True)
+    yt = ycc[:, 0:1].clone().requires_grad_(True)
+    fused = fus(irt, yt)
+    rr = S.make_feature(31, tuple(fused.shape))
+    (fused * t(rr)).sum().backward()
+    save("gc_fusion_2x64x96", fused=npy(fused), d_ir=npy(irt.grad), d_y=npy(yt.grad))
+
+    # ---- G-d: colour transforms + clamp / batch-global min-max / normalise ------------------
+    m0 = build_model(R, "mit_b0")
+    ir, vis, _ = S.make_batch(2, 64, 96)
+    with torch.no_grad():
+        ycc = mfa.RGB2YCrCb(t(vis))
+        rgb = mfa.YCrCb2RGB(ycc)
+    # seg_in is internal to forward(): capture it as the input of denoise_net
+    cap = {}
+    h = m0.denoise_net.register_forward_pre_hook(lambda m, i: cap.__setitem__("seg_in", npy(i[0])))
+    with torch.no_grad():
+        f2, s2 = m0(t(ir), t(vis))
+        seg_in_b2 = cap["seg_in"].copy()
+        f1, s1 = m0(t(ir[:1]), t(vis[:1]))
+        seg_in_b1 = cap["seg_in"].copy()
+    h.remove()
+    save("gd_colour_glue", ycc=npy(ycc), rgb=npy(rgb), seg_in_b2=seg_in_b2, seg_in_b1=seg_in_b1,
+         logits_b2=npy(s2), logits_b1=npy(s1))
+
+    # ---- G-e: WeTr mit_b0 / mit_b3 at 64x96: stage outputs + logits -------------------------
+    for bb in ("mit_b0", "mit_b3"):
+        m = m0 if bb == "mit_b0" else build_model(R, bb)
+        x = t(seg_in_b2)
+        xg = x.clone().requires_grad_(True)
+        feats = m.denoise_net.encoder(xg)
+        logits = m.denoise_net.decoder(feats)
+        rr = S.make_feature(41, tuple(logits.shape))
+        (logits * t(rr)).sum().backward()
+        save("ge_wetr_%s" % bb, c1=npy(feats[0]), c2=npy(feats[1]), c3=npy(feats[2]), c4=npy(feats[3]),
+             logits=npy(logits), dx=npy(xg.grad))
+        if bb == "mit_b3":
+            m3 = m
+
+    # ---- G-i: state_dict layouts -------------------------------------------------------------
+    for bb, m in (("mit_b0", m0), ("mit_b3", m3)):
+        layout = {k: list(v.shape) for k, v in m.state_dict().items()}
+        with open(os.path.join(OUT, "gi_state_dict_%s.json" % bb), "w") as f:
+            json.dump(layout, f, indent=0, sort_keys=True)
+    mc = build_model(R, "mit_b0", cls="Network_MM_CompModel")
+    assert list(mc.state_dict().keys()) == list(m0.state_dict().keys())
+
+    # ---- G-f: full model, config 1 (4 x 64x96 here; 4 x 480x640 is timed, not stored) and
+    #           ONE 480x640 pair through mit_b3 -------------------------------------------------
+    ir, vis, lab = S.make_batch(4, 64, 96)
+    with torch.no_grad():
+        f, s = m3(t(ir), t(vis))
+        up = torch.nn.functional.interpolate(s, size=lab.shape[1:], mode="bilinear", align_corners=False)
+        pred = up.argmax(1)
+    from oracle.paif_oracle import confusion_matrix
+
+    conf = confusion_matrix(lab, npy(pred))
+    prec, rec, iou = R["util"].compute_results(conf)
+    save("gf_model_b3_4x64x96", fused=npy(f), logits=npy(s), pred=npy(pred).astype(np.uint8), conf=conf,
+         precision=prec, recall=rec, iou=iou)
+    ir, vis, lab = S.make_batch(1, 480, 640)
+    with torch.no_grad():
+        f, s = m3(t(ir), t(vis))
+        up = torch.nn.functional.interpolate(s, size=lab.shape[1:], mode="bilinear", align_corners=False)
+        pred = up.argmax(1)
+    save("gf_model_b3_1x480x640", fused=npy(f).astype(np.float32), logits=npy(s),
+         pred=npy(pred).astype(np.uint8))
+
+    # ---- G-g: attack_both (3 iters, mit_b0, 2 x 64x96), PGD / segPGD / cosPGD ------------------
+    ir, vis, lab = S.make_batch(2, 64, 96)
+    eps, alpha = 8 / 255.0, 2 / 255.0
+    for way in ("PGD", "segPGD", "cosPGD"):
+        # the reference draws delta0 from the global RNG (attack/attack.py:434,439): pin the seed,
+        # replay the same draws here and store them so both sides start from the same point.
+        torch.manual_seed(1234)
+        d0_ir = torch.zeros_like(t(ir)).uniform_(-eps, eps)
+        d0_vis = torch.zeros_like(t(vis)).uniform_(-eps, eps)
+        rec_maps = []
+
+        def recording_model(a, b, _m=m0, _rec=rec_maps):
+            fz, sg = _m(a, b)
+            _rec.append(sg.detach().clone())
+            return fz, sg
+
+        for p_ in m0.parameters():
+            p_.grad = None
+        torch.manual_seed(1234)
+        with torch.no_grad():
+            d_ir, d_vis = R["attack"].attack_both(recording_model, t(vis), t(ir), t(lab), epsilon=eps, alpha=alpha,
+                                                  attack_iters=3, attack_loss="l_seg", attack_way=way)
+        crit = R["attack"].Seg_loss()
+        losses = []
+        for i, sg in enumerate(rec_maps):
+            outp = torch.nn.functional.interpolate(sg, size=lab.shape[1:], mode="bilinear", align_corners=False)
+            losses.append(float(O.attack_loss_value(outp, t(lab), way, i, 3)))
+            if way == "PGD":
+                assert abs(losses[-1] - float(crit(outp, t(lab)))) < 1e-7
+        save("gg_attack_%s" % way, d0_ir=npy(d0_ir), d0_vis=npy(d0_vis), delta_ir=npy(d_ir), delta_vis=npy(d_vis),
+             gsum_sign_ir=np.sign(npy(d_ir.grad)).astype(np.int8), gsum_sign_vis=np.sign(npy(d_vis.grad)).astype(np.int8),
+             gsum_ir=npy(d_ir.grad), gsum_vis=npy(d_vis.grad), losses=np.array(losses))
+
+    # ---- G-h: losses, metrics, schedule --------------------------------------------------------
+    logits = S.make_feature(51, (2, 9, 24, 32), -3, 3)
+    lab_s = S.make_label(3, 24, 32)[None].repeat(2, 0)
+    lg = t(logits).requires_grad_(True)
+    l_seg = R["attack"].Seg_loss()(lg, t(lab_s))
+    l_seg.backward()
+    a = S.make_smooth_feature(52, 2, 1, 32, 40)
+    b = S.make_smooth_feature(53, 2, 1, 32, 40)
+    l_ssim = R["ssim"].ssim(t(a), t(b))
+    l_fus = R["loss"].Fusionloss_grad2()(t(a), t(a), t(a), t(b))
+    conf = np.arange(81).reshape(9, 9) % 7
+    conf[:, 4] = 0
+    conf[4, :] = 0  # an empty class -> NaN
+    prec, rec, iou = R["util"].compute_results(conf)
+    opt = R["optimizer"].PolyWarmupAdamW([torch.nn.Parameter(torch.zeros(1))], lr=8e-5, weight_decay=0.01,
+                                         betas=(0.9, 0.999), warmup_iter=3000, max_iter=160000, warmup_ratio=1e-5,
+                                         power=1.0)
+    lrs = []
+    for step in (0, 1, 2999, 3000, 80000, 159999):
+        opt.global_step = step
+        opt.param_groups[0]["params"][0].grad = torch.zeros(1)
+        opt.step()
+        lrs.append(opt.param_groups[0]["lr"])
+    save("gh_losses_metrics", seg_loss=np.array(float(l_seg)), seg_loss_dlogits=npy(lg.grad),
+         ssim=np.array(float(l_ssim)), fusionloss_grad2=np.array(float(l_fus)), conf=conf, precision=prec,
+         recall=rec, iou=iou, lr_steps=np.array([0, 1, 2999, 3000, 80000, 159999]), lrs=np.array(lrs))
+    print("done")
+
+
+if __name__ == "__main__":
+    main()

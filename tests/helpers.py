@@ -1,0 +1,53 @@
+"""Shared helpers for the parity tests (formula weights -> oracle state_dict etc.)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from paif_amd import synthetic as S
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+PRIMITIVES = [
+    "Denseblocks_3_1", "DilConv_3_2", "ECAattention_3", "Residualblocks_7_1",
+    "SPAattention_3", "SepConv_3_1", "SepConv_5_1", "DilConv_5_1",
+    "Denseblocks_5_2", "Denseblocks_7_1", "Residualblocks_3_2", "Residualblocks_5_2",
+]
+
+
+def layout(backbone):
+    with open(os.path.join(GOLDEN, "gi_state_dict_%s.json" % backbone)) as f:
+        return {k: tuple(v) for k, v in json.load(f).items()}
+
+
+def formula_sd(shapes, salt=0, prefix_filter=None, strip=None):
+    """key->torch tensor from the name-keyed formula; optionally keep only keys with a prefix
+    (and strip it) -- the formula is always evaluated on the FULL key name the generator used."""
+    out = {}
+    for k, shp in shapes.items():
+        if prefix_filter and not k.startswith(prefix_filter):
+            continue
+        kk = k[len(strip):] if strip else k
+        out[kk] = torch.from_numpy(S.formula_tensor(kk if strip else k, shp, salt))
+    return out
+
+
+def model_sd(backbone):
+    return formula_sd(layout(backbone))
+
+
+def fusion_sd():
+    """Stand-alone Network_Fusion_Searched state_dict (keys without the enhance_net. prefix)."""
+    shapes = {k[len("enhance_net."):]: v for k, v in layout("mit_b0").items() if k.startswith("enhance_net.")}
+    return formula_sd(shapes)
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def maxabs(a, b):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    return float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64))))
