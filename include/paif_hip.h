@@ -1,0 +1,156 @@
+/* paif_hip.h -- C ABI of libpaif_hip.so: hand-written gfx950 (MI355X, CDNA4) kernels for the PAIF
+ * hot path (fusion-net forward -> colour glue -> SegFormer -> PGD inner loop).
+ *
+ * The reference (LiuZhu-CV/PAIF) has NO native interface: every op below replaces an implicit
+ * ATen/cuDNN call made by a torch nn.Module.  Each entry point cites the reference site it
+ * replaces (file:line under the reference root).  Contract:
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers unless noted;
+ *   - asynchronous on `stream` (a hipStream_t passed as void*); never allocates / frees / syncs;
+ *   - returns 0 on success, a negative PAIF_E* code on bad arguments, or the positive hipError_t of
+ *     a failed launch; paif_last_error() gives a thread-local message;
+ *   - re-entrant, no global mutable state (autograd calls backward bodies from its own thread).
+ * Activations are float32 NHWC ("channels-last": [B,H,W,C]) unless a parameter says otherwise.
+ */
+#ifndef PAIF_HIP_H
+#define PAIF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PAIF_ABI_VERSION 1
+#define PAIF_EINVAL (-1)   /* bad argument (null pointer, unsupported size) */
+#define PAIF_ENOSUP (-2)   /* combination not built (kernel size / dilation / channels) */
+
+typedef void* paif_stream_t; /* hipStream_t */
+
+int paif_version(void);
+const char* paif_last_error(void);
+/* number of CUs of the current device (grid sizing on the host side); <0 on error */
+int paif_device_cus(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Colour transforms and the fusion->segmentation glue
+ * ------------------------------------------------------------------------------------------- */
+
+/* RGB2YCrCb, core/model_fusion_auto.py:69-92.  rgb, ycc: NCHW [B,3,H,W]. */
+int paif_rgb2ycrcb_fwd(const float* rgb, float* ycc, int B, int H, int W, paif_stream_t stream);
+
+/* cat(fused, Cr, Cb) -> YCrCb2RGB -> clamp[0,1]  (core/model_fusion_auto.py:715-720) with per-block
+ * min/max partials for the batch-global min-max that follows (:721-723).
+ *   fused NCHW [B,1,H,W]; ycc NCHW [B,3,H,W] (Cr,Cb read); rgb_out NCHW [B,3,H,W];
+ *   minmax_partial: [2 * paif_minmax_blocks(B,H,W)] floats (mins then maxs). */
+int paif_minmax_blocks(int B, int H, int W);
+int paif_recompose_clamp_fwd(const float* fused, const float* ycc, float* rgb_out, float* minmax_partial,
+                             int B, int H, int W, paif_stream_t stream);
+/* (x - min)/(max - min) * 255, then per channel (x - mean[c]) / std[c]   (:721-727), in place allowed.
+ * Reduces the partials itself (every block re-reduces them in a fixed order: deterministic).
+ * minmax_out (optional, 2 floats): the global min and max. */
+int paif_minmax_normalize_fwd(const float* rgb, const float* minmax_partial, int npartial, float* out,
+                              float* minmax_out, int B, int H, int W, paif_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fusion network (Network_Fusion_Searched, core/model_fusion_auto.py:599-635)
+ * ------------------------------------------------------------------------------------------- */
+
+/* stem_1 / stem_2: Conv2d(1,32,3,pad 1,no bias) + PReLU (:607-614) fused with Cell_Decom.get_residue
+ * (max_c - min_c, :517-521).  img: 1-channel planes [H,W], image b at img + b*img_bstride floats
+ * (so a channel-0 view of an NCHW [B,3,H,W] tensor needs no copy); w [32,1,3,3]; prelu: 1 float on
+ * device; feat NHWC [B,H,W,32]; guide [B,H,W] (may be NULL). */
+int paif_stem_fwd(const float* img, size_t img_bstride, const float* w, const float* prelu, float* feat, float* guide,
+                  int B, int H, int W, paif_stream_t stream);
+/* Cell_Decom.get_residue on an existing NHWC [B,H,W,32] map (:517-521): guide = max_c - min_c. */
+int paif_channel_residue_fwd(const float* x, float* guide, int B, int H, int W, paif_stream_t stream);
+
+/* Guided filter r=4, 1-channel guide, 32-channel target, for BOTH eps of Cell_Decom.decomposition
+ * (:522-535; third-party guided_filter_pytorch.GuidedFilter, see oracle/shims).
+ * Stage 1: per-channel linear coefficients.  ab: [4][B,H,W,32] = A(eps0), b(eps0), A(eps1), b(eps1).
+ * Stage 2: LF_e = box(A_e)/N * guide + box(b_e)/N.  lf: [2][B,H,W,32].
+ * Box sums are direct 9x9 border-clipped window sums (fp32), not cumsum differences.
+ * Returns PAIF_EINVAL when H <= 9 or W <= 9 (the package asserts h,w > 2r+1). */
+int paif_guided_filter_ab_fwd(const float* guide, const float* y, float* ab, float eps0, float eps1,
+                              int B, int H, int W, paif_stream_t stream);
+int paif_guided_filter_lf_fwd(const float* guide, const float* ab, float* lf, int B, int H, int W,
+                              paif_stream_t stream);
+
+/* Dense k x k convolution, stride 1, "same" zero padding (pad = dil*(k-1)/2), Cout <= 32, inputs =
+ * virtual concat of up to 3 NHWC sources of `cin` channels each, fp32 MFMA (v_mfma_f32_32x32x2_f32)
+ * implicit GEMM with an LDS-staged halo tile.  Replaces BasicConv / nn.Conv2d inside
+ * ResidualDenseBlock (operations_m.py:435-449), ResidualModule (:451-464), ECABasicBlock (:368-393),
+ * DilConv's 1x1 (:501), Cell_Decom.conv1x1_* (core/model_fusion_auto.py:501-502), stem_out.0 (:616).
+ *
+ *   y   = act( conv(in_act(src...)) * scale[c] + shift[c] )        scale/shift NULL -> 1 / 0
+ *   out = y * alpha + res[0] + res[1] + res[2]                      res NULL -> skipped
+ *   pool_partial (optional): [paif_conv2d_blocks(B,H,W)][32] per-block channel sums of `out`
+ *                            (ECA's AdaptiveAvgPool2d, operations_m.py:358)
+ */
+typedef struct {
+  const float* src[3];   /* NHWC [B,H,W,cin] each */
+  int nsrc;              /* 1..3 */
+  int cin;               /* channels per source: 32 or 16 */
+  const float* wpk;      /* packed by paif_pack_conv_weight */
+  int kh;                /* 1,3,5,7 */
+  int dil;               /* 1,2 */
+  int in_act;            /* 0 none, 1 PReLU(in_prelu) on every source, 2 ReLU */
+  const float* in_prelu; /* 1 float on device */
+  const float* scale;    /* [cout] or NULL */
+  const float* shift;    /* [cout] or NULL */
+  int act;               /* 0 none, 1 PReLU(prelu), 2 ReLU */
+  const float* prelu;    /* 1 float on device */
+  float alpha;
+  const float* res[3];   /* NHWC [B,H,W,cout] or NULL */
+  float* out;            /* NHWC [B,H,W,cout] */
+  int cout;              /* 32 or 16 */
+  float* pool_partial;   /* optional */
+} paif_conv_desc;
+
+int paif_conv2d_blocks(int B, int H, int W);
+int paif_conv2d_fwd(const paif_conv_desc* d, int B, int H, int W, paif_stream_t stream);
+/* w: torch layout [cout, nsrc*cin, kh, kh]; wpk: paif_conv_wpk_floats(...) floats.
+ * Layout wpk[src][tap][cin/8][64 lanes][4]: lane (h = lane>>5, n = lane&31) holds
+ * w[n][src*cin + 8*o + 4*h + i][tap], i = 0..3 -- the B operand of four consecutive MFMAs. */
+size_t paif_conv_wpk_floats(int nsrc, int cin, int kh);
+int paif_pack_conv_weight(const float* w, float* wpk, int cout, int nsrc, int cin, int kh, paif_stream_t stream);
+/* Cell_Decom's 1x1 over cat[LF1,LF2,x-LF1,x-LF2] (core/model_fusion_auto.py:512-513) folded to a 1x1
+ * over [x, LF1, LF2]: (Wh1+Wh2) x + (Wl1-Wh1) LF1 + (Wl2-Wh2) LF2.  w [32,128,1,1] -> wpk for nsrc=3. */
+int paif_pack_decomp1x1_weight(const float* w, float* wpk, paif_stream_t stream);
+/* eval-mode BatchNorm folded to scale/shift: scale = g/sqrt(var+eps), shift = b - mean*scale. */
+int paif_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                 float* scale, float* shift, int C, paif_stream_t stream);
+
+/* Depthwise k x k conv (groups = C = 32), optional ReLU on the input: DilConv / SepConv,
+ * operations_m.py:499-500, 514-515.  x, out NHWC [B,H,W,32]; w [32,1,k,k]. */
+int paif_dwconv_fwd(const float* x, const float* w, float* out, int k, int dil, int in_relu,
+                    int B, int H, int W, paif_stream_t stream);
+
+/* ChannelPool(ir, vis) + spatial_attn_layer_M + blend (core/model_fusion_auto.py:1352-1368, 631-632):
+ * pool: comp NHWC [B,H,W,4] = (max_c ir, mean_c ir, max_c vis, mean_c vis);
+ * blend: scale = sigmoid(conv5x5(comp)); agg = scale*ir + (1-scale)*vis.  w [1,4,5,5];
+ * scale_out [B,H,W] optional. */
+int paif_channel_pool2_fwd(const float* ir, const float* vis, float* comp, int B, int H, int W, paif_stream_t stream);
+int paif_spa_blend_fwd(const float* comp, const float* w, const float* ir, const float* vis, float* agg,
+                       float* scale_out, int B, int H, int W, paif_stream_t stream);
+
+/* eca_layer tail + ECABasicBlock residual (operations_m.py:353-367, 390-392):
+ * mean[b][c] = sum over that image's conv blocks of pool_partial / (H*W);
+ * s = sigmoid(conv1d_k(mean)) over channels (zero padded); out = PReLU(o*s + r).
+ * w1d [1,1,k]. */
+int paif_eca_finish_fwd(const float* o, const float* r, const float* pool_partial, const float* w1d, int k,
+                        const float* prelu, float* gate /* [B,32] out: the sigmoid gates */, float* out,
+                        int B, int H, int W, paif_stream_t stream);
+
+/* stem_out.1 + .2 + tanh (core/model_fusion_auto.py:617-619,634): Conv2d(16,1,3,pad 1) -> PReLU -> tanh.
+ * x NHWC [B,H,W,16]; w [1,16,3,3]; fused [B,H,W]. */
+int paif_tail_fwd(const float* x, const float* w, const float* prelu, float* fused, int B, int H, int W,
+                  paif_stream_t stream);
+
+/* plain elementwise a + b (Cell_Chain's residual when it cannot be fused, :445); n floats. */
+int paif_add_fwd(const float* a, const float* b, float* out, size_t n, paif_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PAIF_HIP_H */

@@ -1,0 +1,84 @@
+"""ctypes binding of libpaif_hip.so (C ABI: include/paif_hip.h).
+
+The library is REQUIRED: there is no CPU or eager-PyTorch fallback anywhere in paif_amd.  If the
+shared object is missing or a symbol is absent, importing an op raises immediately.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_size_t, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libpaif_hip.so")
+
+F = c_void_p  # device pointer
+
+
+class ConvDesc(Structure):
+    """paif_conv_desc (include/paif_hip.h)."""
+
+    _fields_ = [
+        ("src", F * 3), ("nsrc", c_int), ("cin", c_int), ("wpk", F), ("kh", c_int), ("dil", c_int),
+        ("in_act", c_int), ("in_prelu", F), ("scale", F), ("shift", F), ("act", c_int), ("prelu", F),
+        ("alpha", c_float), ("res", F * 3), ("out", F), ("cout", c_int), ("pool_partial", F),
+    ]
+
+
+# name -> (restype, argtypes); every symbol declared in include/paif_hip.h
+SIGNATURES = {
+    "paif_version": (c_int, []),
+    "paif_last_error": (c_char_p, []),
+    "paif_device_cus": (c_int, []),
+    "paif_rgb2ycrcb_fwd": (c_int, [F, F, c_int, c_int, c_int, F]),
+    "paif_minmax_blocks": (c_int, [c_int, c_int, c_int]),
+    "paif_recompose_clamp_fwd": (c_int, [F, F, F, F, c_int, c_int, c_int, F]),
+    "paif_minmax_normalize_fwd": (c_int, [F, F, c_int, F, F, c_int, c_int, c_int, F]),
+    "paif_stem_fwd": (c_int, [F, c_size_t, F, F, F, F, c_int, c_int, c_int, F]),
+    "paif_channel_residue_fwd": (c_int, [F, F, c_int, c_int, c_int, F]),
+    "paif_guided_filter_ab_fwd": (c_int, [F, F, F, c_float, c_float, c_int, c_int, c_int, F]),
+    "paif_guided_filter_lf_fwd": (c_int, [F, F, F, c_int, c_int, c_int, F]),
+    "paif_conv2d_blocks": (c_int, [c_int, c_int, c_int]),
+    "paif_conv2d_fwd": (c_int, [POINTER(ConvDesc), c_int, c_int, c_int, F]),
+    "paif_conv_wpk_floats": (c_size_t, [c_int, c_int, c_int]),
+    "paif_pack_conv_weight": (c_int, [F, F, c_int, c_int, c_int, c_int, F]),
+    "paif_pack_decomp1x1_weight": (c_int, [F, F, F]),
+    "paif_bn_fold": (c_int, [F, F, F, F, c_float, F, F, c_int, F]),
+    "paif_dwconv_fwd": (c_int, [F, F, F, c_int, c_int, c_int, c_int, c_int, c_int, F]),
+    "paif_channel_pool2_fwd": (c_int, [F, F, F, c_int, c_int, c_int, F]),
+    "paif_spa_blend_fwd": (c_int, [F, F, F, F, F, F, c_int, c_int, c_int, F]),
+    "paif_eca_finish_fwd": (c_int, [F, F, F, F, c_int, F, F, F, c_int, c_int, c_int, F]),
+    "paif_tail_fwd": (c_int, [F, F, F, F, c_int, c_int, c_int, F]),
+    "paif_add_fwd": (c_int, [F, F, F, c_size_t, F]),
+}
+
+_lib = None
+
+
+class PaifLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (once).  Fails loudly -- never falls back to another implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PaifLibraryError(
+            "libpaif_hip.so not found at %s -- build it with `python -m paif_amd.build` "
+            "(hipcc --offload-arch=gfx950).  paif_amd has no CPU/eager fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise PaifLibraryError("libpaif_hip.so does not export %s (stale build?)" % name) from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().paif_last_error()
+        raise RuntimeError("%s failed (code %d): %s" % (what, rc, msg.decode() if msg else "?"))

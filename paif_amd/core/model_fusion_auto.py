@@ -1,0 +1,208 @@
+"""Fusion network, NAS cell containers and the composite fusion+segmentation models --
+MI355X-native counterparts of the reference's core/model_fusion_auto.py classes that are on the hot
+path (F1-F8, G1, S1).  Same names, constructor signatures and state_dict keys;
+forward() bodies launch the hand-written gfx950 kernels of libpaif_hip.so.
+
+Not reproduced (out of scope, never constructed by either entry script): DRDB, Fusion_Network*,
+SKFF, the GAN pieces, Network_MM_TARDAL/UMF/Base/Auto, the *_showfeatures variants.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..operations_m import OPS, BasicConv, Conv2dParams, PReLUParams, _HipOp, _PackCache
+
+
+# ---------------------------------------------------------------------------------------------
+# colour transforms (reference: core/model_fusion_auto.py:69-111)
+# ---------------------------------------------------------------------------------------------
+def RGB2YCrCb(input_im):
+    """core/model_fusion_auto.py:69-92.  [B,3,H,W] -> [B,3,H,W] (Y, Cr, Cb)."""
+    ops.require_no_grad(input_im)
+    return ops.rgb2ycrcb(input_im)
+
+
+def YCrCb2RGB(input_im):
+    """core/model_fusion_auto.py:94-111 -- on the path only inside the fusion->seg glue, where it is
+    fused with the clamp and the min/max pass (ops.seg_input_from_fused)."""
+    raise NotImplementedError("YCrCb2RGB is fused into the glue kernel (paif_recompose_clamp_fwd); "
+                              "a stand-alone kernel is not built")
+
+
+class MixedOp(nn.Module):
+    """core/model_fusion_auto.py:397-415.  'Name_k' iff the name contains lowercase 'attention', else
+    'Name_k_d' (IndexError on a missing field, KeyError on an unknown name -- as in the reference)."""
+
+    def __init__(self, C, primitive):
+        super().__init__()
+        self._ops = nn.ModuleList()
+        kernel = 3
+        dilation = 1
+        if primitive.find('attention') != -1:
+            name = primitive.split('_')[0]
+            kernel = int(primitive.split('_')[1])
+        else:
+            name = primitive.split('_')[0]
+            kernel = int(primitive.split('_')[1])
+            dilation = int(primitive.split('_')[2])
+        self._op = OPS[name](C, kernel, dilation, False)
+
+    def forward(self, x):
+        return self._op(x)
+
+    def forward_nhwc(self, x, res=()):
+        return self._op.forward_nhwc(x, res)
+
+
+class Cell_Chain(_HipOp):
+    """core/model_fusion_auto.py:418-445: inp + ops(inp).  The outer residual (and any residuals the
+    caller adds on top) ride in the last op's conv epilogue."""
+
+    def __init__(self, C, type, concat):
+        super().__init__()
+        op_names, indices = zip(*type)
+        self._compile(C, op_names, indices, concat)
+
+    def _compile(self, C, op_names, indices, concat):
+        assert len(op_names) == len(indices)
+        self._steps = len(op_names)
+        self._concat = concat
+        self.multiplier = len(concat)
+        self._ops = nn.ModuleList()
+        for name, index in zip(op_names, indices):
+            self._ops += [MixedOp(C, name)]
+        self._indices = indices
+
+    def forward_nhwc(self, inp, res=()):
+        s1 = inp
+        for i in range(self._steps):
+            last = i == self._steps - 1
+            s1 = self._ops[i].forward_nhwc(s1, ((inp,) + tuple(res)) if last else ())
+        return s1
+
+
+class Cell_Decom(nn.Module):
+    """core/model_fusion_auto.py:492-535.  Guided-filter decomposition (r=4, eps 1e-3 / 1e-4) of both
+    streams, the two 128->32 1x1 convs (folded to 96->32 over [x, LF1, LF2]: HF = x - LF is never
+    materialised), the two chains and the outer residuals."""
+
+    def __init__(self, C, types, concat):
+        super().__init__()
+        self._C = C
+        self.radiux = [4]
+        self.eps_list = [0.001, 0.0001]
+        self._ops_1 = nn.ModuleList()
+        self._ops_2 = nn.ModuleList()
+        self.conv1x1_lf = Conv2dParams(C * 4, C, kernel_size=1, bias=True)
+        self.conv1x1_hf = Conv2dParams(C * 4, C, kernel_size=1, bias=True)
+        self._steps = len(concat)
+        self.relu = PReLUParams()  # unused in the reference too, but serialised (decompation.relu.weight)
+        self.chain = Cell_Chain(C, types[0], concat)
+        self.chain2 = Cell_Chain(C, types[1], concat)
+        self._packs = _PackCache()
+        if C != 32:
+            raise NotImplementedError("the HIP kernels are built for C = 32 (the only width either entry script uses)")
+
+    def get_residue(self, tensor):
+        return ops.to_nchw_view(ops.channel_residue(ops.to_nhwc(tensor)).unsqueeze(-1))
+
+    def decomposition_nhwc(self, x, guide=None):
+        """-> lf [2,B,H,W,32] (LF for eps 1e-3, 1e-4)."""
+        if guide is None:
+            guide = ops.channel_residue(x)
+        return ops.guided_filter_pair(guide, x, tuple(self.eps_list))
+
+    def decomposition(self, x, C=None):
+        """API parity with the reference: returns (LF [B,2C,H,W], HF [B,2C,H,W])."""
+        raise NotImplementedError("HF = x - LF is folded into the 1x1 conv; use decomposition_nhwc for the LF maps")
+
+    def forward_nhwc(self, fir, fvis, g_ir=None, g_vis=None):
+        lf_ir = self.decomposition_nhwc(fir, g_ir)
+        lf_vis = self.decomposition_nhwc(fvis, g_vis)
+        w_lf = self._packs.get("lf", [self.conv1x1_lf.weight], lambda: ops.pack_decomp1x1_weight(self.conv1x1_lf.weight))
+        w_hf = self._packs.get("hf", [self.conv1x1_hf.weight], lambda: ops.pack_decomp1x1_weight(self.conv1x1_hf.weight))
+        lf = ops.conv2d([fir, lf_ir[0], lf_ir[1]], w_lf, 1, 1, shift=self.conv1x1_lf.bias)
+        hf = ops.conv2d([fvis, lf_vis[0], lf_vis[1]], w_hf, 1, 1, shift=self.conv1x1_hf.bias)
+        ir_feature = self.chain.forward_nhwc(lf, (fir,))      # lf_re + inp_ir
+        vis_feature = self.chain2.forward_nhwc(hf, (fvis,))   # hf_re + inp_vis
+        return ir_feature, vis_feature
+
+    def forward(self, inp_ir, inp_vis):
+        ops.require_no_grad(inp_ir, inp_vis)
+        with torch.no_grad():
+            a, b = self.forward_nhwc(ops.to_nhwc(inp_ir), ops.to_nhwc(inp_vis))
+        return ops.to_nchw_view(a), ops.to_nchw_view(b)
+
+
+class ChannelPool(nn.Module):
+    """core/model_fusion_auto.py:1352-1355 (2-argument form)."""
+
+    def forward(self, ir, vis):
+        ops.require_no_grad(ir, vis)
+        return ops.to_nchw_view(ops.channel_pool2(ops.to_nhwc(ir), ops.to_nhwc(vis)))
+
+
+class spatial_attn_layer_M(nn.Module):
+    """core/model_fusion_auto.py:1358-1368: sigmoid(conv5x5 4->1 (ChannelPool(ir, vis)))."""
+
+    def __init__(self, kernel_size=5):
+        super().__init__()
+        if kernel_size != 5:
+            raise NotImplementedError("spatial_attn_layer_M: only the 5x5 kernel of the reference is built")
+        self.compress = ChannelPool()
+        self.spatial = BasicConv(4, 1, kernel_size, relu=False)
+
+    def blend_nhwc(self, ir, vis, want_scale=False):
+        comp = ops.channel_pool2(ir, vis)
+        return ops.spa_blend(comp, self.spatial.conv.weight, ir, vis, want_scale)
+
+    def forward(self, ir, vis):
+        ops.require_no_grad(ir, vis)
+        with torch.no_grad():
+            _, scale = self.blend_nhwc(ops.to_nhwc(ir), ops.to_nhwc(vis), want_scale=True)
+        return scale.unsqueeze(1)
+
+
+class Network_Fusion_Searched(nn.Module):
+    """core/model_fusion_auto.py:599-640."""
+
+    def __init__(self, C, criterion, genotype_feature, steps=4, multiplier=3):
+        super().__init__()
+        self._C = C
+        self._criterion = criterion
+        self._steps = steps
+        self._multiplier = multiplier
+        self._genotype = genotype_feature
+        self.stem_1 = nn.Sequential(Conv2dParams(1, C, 3, padding=1, bias=False), PReLUParams())
+        self.stem_2 = nn.Sequential(Conv2dParams(1, C, 3, padding=1, bias=False), PReLUParams())
+        self.stem_out = nn.Sequential(
+            Conv2dParams(C, C // 2, 3, padding=1, bias=False),
+            Conv2dParams(C // 2, 1, 3, padding=1, bias=False),
+            PReLUParams(),
+        )
+        self.tanh = nn.Tanh()
+        self.spa = spatial_attn_layer_M()
+        self.decompation = Cell_Decom(C, [self._genotype.normal_1, self._genotype.normal_2], self._genotype.normal_1_concat)
+        self.chain = Cell_Chain(C, self._genotype.normal_3, self._genotype.normal_1_concat)
+        self._packs = _PackCache()
+
+    def forward(self, ir, vis, inter=None):
+        ops.require_no_grad(ir, vis)
+        with torch.no_grad():
+            vis = vis[:, 0:1, :, :]
+            ir = ir[:, 0:1, :, :]
+            fir, g_ir = ops.stem(ir, self.stem_1[0].weight, self.stem_1[1].weight)
+            fvis, g_vis = ops.stem(vis, self.stem_2[0].weight, self.stem_2[1].weight)
+            ir_feature, vis_feature = self.decompation.forward_nhwc(fir, fvis, g_ir, g_vis)
+            agg = self.spa.blend_nhwc(ir_feature, vis_feature)
+            feature2 = self.chain.forward_nhwc(agg)
+            w0 = self._packs.get("so0", [self.stem_out[0].weight], lambda: ops.pack_conv_weight(self.stem_out[0].weight, 1, 32, 3))
+            t16 = ops.conv2d([feature2], w0, 3, 1, cout=16)
+            out = ops.tail(t16, self.stem_out[1].weight, self.stem_out[2].weight)
+            if inter is not None:
+                inter.update(fir=fir, fvis=fvis, ir_feature=ir_feature, vis_feature=vis_feature, agg=agg, feature2=feature2)
+        return out
+
+    def _loss(self, ir, vis, mask):
+        logits = self(ir, vis)
+        return self._criterion(ir, vis, logits, mask)

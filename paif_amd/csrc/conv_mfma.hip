@@ -1,0 +1,355 @@
+// Dense k x k convolution (stride 1, same padding, Cout <= 32) as an fp32 implicit GEMM on the
+// gfx950 matrix cores: v_mfma_f32_32x32x2_f32 (exact f32 = a k-ordered fmaf chain, 64 FLOP/clk/SIMD).
+//
+//   GEMM view per workgroup:  M = 8 rows x 32 columns of output pixels (8 "segments" of 32 px),
+//                             N = 32 output channels, K = kh*kh*cin per source, sources looped.
+//   A operand (pixels x k): halo tile of one NHWC source staged in LDS, pixel stride padded to
+//       cin+4 dwords so that a wave's ds_read_b128 (4 consecutive channels per lane, 16-lane groups)
+//       is bank-conflict-free ((36*p) mod 64 and (20*p) mod 64 hit 16 distinct 4-bank slots).
+//   B operand (k x cout): pre-packed weights, one float4 per lane per (tap, channel-octet), read
+//       straight from global memory (<= 200 KB per layer, L2 resident), prefetched one tap ahead.
+//   One ds_read_b128 + a quarter of a global_load_dwordx4 feed 4 MFMAs (256 cycles of matrix pipe).
+//   D (32 px x 32 cout per segment): lane (h = lane>>5, n = lane&31) holds cout n of pixels
+//       (r&3) + 8*(r>>2) + 4*h, r = 0..15 -> every store instruction writes two full 128-B NHWC lines.
+//   Epilogue fused: per-channel affine (folded BN / bias), PReLU/ReLU, alpha, up to 3 residual
+//       tensors, optional per-block channel sums (ECA average pool).
+//
+// Replaces: operations_m.py BasicConv / nn.Conv2d inside ResidualDenseBlock (:435-449),
+// ResidualModule (:451-464), ECABasicBlock (:368-393), DilConv's 1x1 (:501);
+// core/model_fusion_auto.py conv1x1_lf/hf (:501-502), stem_out.0 (:616).
+#include "paif_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int TH = 8;    // tile rows  (one segment per row)
+constexpr int TW = 32;   // tile cols  (= MFMA M)
+constexpr int NTHREADS = 256;
+constexpr int SEGS_PER_WAVE = TH / 4;
+
+struct ConvArgs {
+  const float* src[3];
+  const float* res[3];
+  const float4* wpk;
+  const float* in_prelu;
+  const float* scale;
+  const float* shift;
+  const float* prelu;
+  float* out;
+  float* pool_partial;
+  float alpha;
+  int nsrc, in_act, act, cout;
+  int B, H, W, tilesX, tilesY, nblk;
+};
+
+// Fused epilogue of one wave: y = act(acc*scale+shift)*alpha (+res0 +res1 +res2), NHWC store.
+// FULL = interior tile with cout == 32: no per-element predicates, so the compiler can issue all
+// residual loads of a segment, then all stores, without intervening waits.
+template <bool FULL>
+__device__ __forceinline__ float epilogue(const ConvArgs& a, const f32x16 (&acc)[SEGS_PER_WAVE], int b, int y0, int x0,
+                                          int wave, int h, int n) {
+  const bool nvalid = FULL || n < a.cout;
+  float sc = 1.f, sh = 0.f, slope = 0.f;
+  if (nvalid) {
+    if (a.scale) sc = a.scale[n];
+    if (a.shift) sh = a.shift[n];
+  }
+  if (a.act == 1) slope = *a.prelu;
+  const int nres = a.res[0] ? (a.res[1] ? (a.res[2] ? 3 : 2) : 1) : 0;  // residuals are packed from index 0
+  float psum = 0.f;
+#pragma unroll
+  for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) {
+    const int y = y0 + wave * SEGS_PER_WAVE + sg;
+    const bool rowok = FULL || (nvalid && y < a.H);
+    const size_t rowbase = ((size_t)(b * a.H + y) * a.W + x0 + 4 * h) * a.cout + n;
+    float r0[16], r1[16], r2[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dx = (r & 3) + 8 * (r >> 2);
+      const bool ok = FULL || (rowok && x0 + dx + 4 * h < a.W);
+      const size_t o = rowbase + (size_t)dx * a.cout;
+      r0[r] = (nres > 0 && ok) ? a.res[0][o] : 0.f;
+      r1[r] = (nres > 1 && ok) ? a.res[1][o] : 0.f;
+      r2[r] = (nres > 2 && ok) ? a.res[2][o] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dx = (r & 3) + 8 * (r >> 2);
+      const bool ok = FULL || (rowok && x0 + dx + 4 * h < a.W);
+      float v = acc[sg][r] * sc + sh;
+      if (a.act == 1) v = paif::prelu_f(v, slope);
+      else if (a.act == 2) v = fmaxf(v, 0.f);
+      v *= a.alpha;
+      if (nres > 0) v += r0[r];
+      if (nres > 1) v += r1[r];
+      if (nres > 2) v += r2[r];
+      if (ok) {
+        a.out[rowbase + (size_t)dx * a.cout] = v;
+        psum += v;
+      }
+    }
+  }
+  return psum;
+}
+
+template <int KH, int DIL, int CIN>
+__global__ __launch_bounds__(NTHREADS, 3) void conv_mfma_f32(ConvArgs a) {
+  constexpr int P = DIL * (KH - 1) / 2;
+  constexpr int TWH = TW + 2 * P;
+  constexpr int THH = TH + 2 * P;
+  constexpr int PS = CIN + 4;          // pixel stride in dwords
+  constexpr int QPP = CIN / 4;         // float4 per pixel
+  constexpr int NO = CIN / 8;          // channel octets
+  constexpr int NTAP = KH * KH;
+  extern __shared__ __align__(16) float lds[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int h = lane >> 5;
+  const int p = lane & 31;
+
+  const int tile_id = paif::xcd_remap(blockIdx.x, a.nblk);  // (b, ty, tx) row-major
+  int t = tile_id;
+  const int tx = t % a.tilesX;
+  t /= a.tilesX;
+  const int ty = t % a.tilesY;
+  const int b = t / a.tilesY;
+  const int x0 = tx * TW, y0 = ty * TH;
+
+  f32x16 acc[SEGS_PER_WAVE];
+#pragma unroll
+  for (int s = 0; s < SEGS_PER_WAVE; ++s)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+
+  float in_slope = 0.f;
+  if (a.in_act == 1) in_slope = *a.in_prelu;
+
+  // per-lane LDS read base (dwords): pixel (row = wave*SEGS + s, col = p), channel offset 4*h
+  int abase[SEGS_PER_WAVE];
+#pragma unroll
+  for (int s = 0; s < SEGS_PER_WAVE; ++s) abase[s] = ((wave * SEGS_PER_WAVE + s) * TWH + p) * PS + 4 * h;
+
+  for (int s = 0; s < a.nsrc; ++s) {
+    if (s > 0) __syncthreads();  // all waves finished reading the previous tile
+    // ---- stage the halo tile of source s: THH x TWH pixels x CIN channels, zero padded ----------
+    const float* src = a.src[s];
+    // loads are issued UB at a time before the first LDS write so that UB global loads are in flight
+    // per lane (one-at-a-time staging is latency-bound: ~1 us per dependent HBM load)
+    constexpr int TOTAL = THH * TWH * QPP;
+    constexpr int NIT = (TOTAL + NTHREADS - 1) / NTHREADS;
+    constexpr int UB = 6;
+#pragma unroll
+    for (int i0 = 0; i0 < NIT; i0 += UB) {
+      float4 v[UB];
+      int dst[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int idx = tid + (i0 + u) * NTHREADS;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        dst[u] = -1;
+        if (i0 + u < NIT && idx < TOTAL) {
+          const int pix = idx / QPP, q = idx - pix * QPP;
+          const int tyy = pix / TWH, txx = pix - tyy * TWH;
+          const int gy = y0 - P + tyy, gx = x0 - P + txx;
+          dst[u] = pix * PS + q * 4;
+          if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+            v[u] = *reinterpret_cast<const float4*>(src + ((size_t)(b * a.H + gy) * a.W + gx) * CIN + q * 4);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        if (dst[u] >= 0) {
+          float4 t4 = v[u];
+          if (a.in_act == 1) {
+            t4.x = paif::prelu_f(t4.x, in_slope); t4.y = paif::prelu_f(t4.y, in_slope);
+            t4.z = paif::prelu_f(t4.z, in_slope); t4.w = paif::prelu_f(t4.w, in_slope);
+          } else if (a.in_act == 2) {
+            t4.x = fmaxf(t4.x, 0.f); t4.y = fmaxf(t4.y, 0.f); t4.z = fmaxf(t4.z, 0.f); t4.w = fmaxf(t4.w, 0.f);
+          }
+          *reinterpret_cast<float4*>(lds + dst[u]) = t4;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- K loop: taps x channel octets, B prefetched one tap ahead -----------------------------
+    const float4* wsrc = a.wpk + (size_t)s * NTAP * NO * 64 + lane;
+    float4 bcur[NO], bnxt[NO];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) bcur[o] = wsrc[o * 64];
+#pragma unroll 1
+    for (int tap = 0; tap < NTAP; ++tap) {
+      if (tap + 1 < NTAP) {
+#pragma unroll
+        for (int o = 0; o < NO; ++o) bnxt[o] = wsrc[((tap + 1) * NO + o) * 64];
+      }
+      const int dy = tap / KH, dx = tap - dy * KH;
+      const int toff = (dy * DIL * TWH + dx * DIL) * PS;
+#pragma unroll
+      for (int o = 0; o < NO; ++o) {
+#pragma unroll
+        for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) {
+          const float4 av = *reinterpret_cast<const float4*>(lds + abase[sg] + toff + 8 * o);
+          acc[sg] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bcur[o].x, acc[sg], 0, 0, 0);
+          acc[sg] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bcur[o].y, acc[sg], 0, 0, 0);
+          acc[sg] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bcur[o].z, acc[sg], 0, 0, 0);
+          acc[sg] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bcur[o].w, acc[sg], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int o = 0; o < NO; ++o) bcur[o] = bnxt[o];
+    }
+  }
+
+  // ---- epilogue --------------------------------------------------------------------------------
+  const bool full = (y0 + TH <= a.H) && (x0 + TW <= a.W) && (a.cout == 32);  // block-uniform
+  float psum;
+  if (full) psum = epilogue<true>(a, acc, b, y0, x0, wave, h, p);
+  else psum = epilogue<false>(a, acc, b, y0, x0, wave, h, p);
+  if (a.pool_partial) {
+    // lanes (h=0,n) and (h=1,n) -> one value per channel per wave, then across the 4 waves via LDS
+    psum += __shfl_xor(psum, 32);
+    __syncthreads();  // tile no longer needed
+    if (lane < 32) lds[wave * 32 + lane] = psum;
+    __syncthreads();
+    if (tid < 32) a.pool_partial[(size_t)tile_id * 32 + tid] = lds[tid] + lds[32 + tid] + lds[64 + tid] + lds[96 + tid];
+  }
+}
+
+template <int KH, int DIL, int CIN>
+int launch(const ConvArgs& a, hipStream_t st) {
+  constexpr int P = DIL * (KH - 1) / 2;
+  constexpr size_t lds_bytes = (size_t)(TH + 2 * P) * (TW + 2 * P) * (CIN + 4) * 4;
+  static_assert(lds_bytes <= 160 * 1024, "tile does not fit LDS");
+  if (lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_f32<KH, DIL, CIN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) {
+      paif::set_error("conv2d: cannot raise dynamic LDS to %zu: %s", lds_bytes, hipGetErrorString(e));
+      return (int)e;
+    }
+  }
+  hipLaunchKernelGGL((conv_mfma_f32<KH, DIL, CIN>), dim3(a.nblk), dim3(NTHREADS), lds_bytes, st, a);
+  PAIF_LAUNCH_CHECK("conv2d");
+  return 0;
+}
+
+__global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wpk, int cout, int nsrc, int cin,
+                                   int kh) {
+  const int ntap = kh * kh, no = cin / 8;
+  const int total = nsrc * ntap * no * 256;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int i = idx & 3, lane = (idx >> 2) & 63;
+    int rest = idx >> 8;
+    const int o = rest % no; rest /= no;
+    const int tap = rest % ntap;
+    const int s = rest / ntap;
+    const int n = lane & 31, h = lane >> 5;
+    const int c = s * cin + 8 * o + 4 * h + i;
+    wpk[idx] = (n < cout) ? w[((size_t)n * (nsrc * cin) + c) * ntap + tap] : 0.f;
+  }
+}
+
+// w [32][128] over cat[LF1, LF2, x-LF1, x-LF2]  ->  1x1 over sources (x, LF1, LF2)
+__global__ void pack_decomp1x1_kernel(const float* __restrict__ w, float* __restrict__ wpk) {
+  const int total = 3 * 4 * 256;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int i = idx & 3, lane = (idx >> 2) & 63;
+    const int o = (idx >> 8) & 3, s = idx >> 10;
+    const int n = lane & 31, h = lane >> 5;
+    const int c = 8 * o + 4 * h + i;
+    const float* wn = w + n * 128;
+    float v;
+    if (s == 0) v = wn[64 + c] + wn[96 + c];
+    else if (s == 1) v = wn[c] - wn[64 + c];
+    else v = wn[32 + c] - wn[96 + c];
+    wpk[idx] = v;
+  }
+}
+
+__global__ void bn_fold_kernel(const float* g, const float* bta, const float* mean, const float* var, float eps,
+                               float* scale, float* shift, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    const float s = g[c] / sqrtf(var[c] + eps);
+    scale[c] = s;
+    shift[c] = bta[c] - mean[c] * s;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int paif_conv2d_blocks(int B, int H, int W) { return B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW); }
+
+size_t paif_conv_wpk_floats(int nsrc, int cin, int kh) { return (size_t)nsrc * kh * kh * (cin / 8) * 256; }
+
+int paif_conv2d_fwd(const paif_conv_desc* d, int B, int H, int W, paif_stream_t stream) {
+  PAIF_REQUIRE(d && d->out && d->wpk, PAIF_EINVAL, "conv2d: null descriptor/out/wpk");
+  PAIF_REQUIRE(d->nsrc >= 1 && d->nsrc <= 3, PAIF_EINVAL, "conv2d: nsrc=%d", d->nsrc);
+  for (int s = 0; s < d->nsrc; ++s) PAIF_REQUIRE(d->src[s], PAIF_EINVAL, "conv2d: src[%d] null", s);
+  PAIF_REQUIRE(d->cout == 32 || d->cout == 16, PAIF_ENOSUP, "conv2d: cout=%d", d->cout);
+  PAIF_REQUIRE(B > 0 && H > 0 && W > 0, PAIF_EINVAL, "conv2d: empty shape %dx%dx%d", B, H, W);
+  PAIF_REQUIRE(d->in_act != 1 || d->in_prelu, PAIF_EINVAL, "conv2d: in_act=PReLU without slope");
+  PAIF_REQUIRE(d->act != 1 || d->prelu, PAIF_EINVAL, "conv2d: act=PReLU without slope");
+  ConvArgs a;
+  for (int s = 0; s < 3; ++s) {
+    a.src[s] = s < d->nsrc ? d->src[s] : nullptr;
+    a.res[s] = d->res[s];
+  }
+  a.wpk = reinterpret_cast<const float4*>(d->wpk);
+  a.in_prelu = d->in_prelu; a.scale = d->scale; a.shift = d->shift; a.prelu = d->prelu;
+  a.out = d->out; a.pool_partial = d->pool_partial; a.alpha = d->alpha;
+  a.nsrc = d->nsrc; a.in_act = d->in_act; a.act = d->act; a.cout = d->cout;
+  a.B = B; a.H = H; a.W = W;
+  a.tilesX = (W + TW - 1) / TW; a.tilesY = (H + TH - 1) / TH; a.nblk = B * a.tilesX * a.tilesY;
+  hipStream_t st = paif::as_stream(stream);
+  PAIF_REQUIRE(d->cin == 32 || d->cin == 16, PAIF_ENOSUP, "conv2d: cin=%d", d->cin);
+  const int key = d->kh * 100 + d->dil * 10 + (d->cin == 32 ? 0 : 1);
+  switch (key) {
+    case 110: return launch<1, 1, 32>(a, st);
+    case 310: return launch<3, 1, 32>(a, st);
+    case 320: return launch<3, 2, 32>(a, st);
+    case 510: return launch<5, 1, 32>(a, st);
+    case 520: return launch<5, 2, 32>(a, st);
+    case 710: return launch<7, 1, 32>(a, st);
+    case 720: return launch<7, 2, 32>(a, st);
+    case 311: return launch<3, 1, 16>(a, st);
+    default: break;
+  }
+  paif::set_error("conv2d: kernel %dx%d dil %d cin %d not built", d->kh, d->kh, d->dil, d->cin);
+  return PAIF_ENOSUP;
+}
+
+int paif_pack_conv_weight(const float* w, float* wpk, int cout, int nsrc, int cin, int kh, paif_stream_t stream) {
+  PAIF_REQUIRE(w && wpk, PAIF_EINVAL, "pack_conv_weight: null pointer");
+  PAIF_REQUIRE(cout >= 1 && cout <= 32 && nsrc >= 1 && nsrc <= 3 && (cin == 32 || cin == 16) && kh >= 1 && kh <= 7,
+               PAIF_ENOSUP, "pack_conv_weight: cout=%d nsrc=%d cin=%d kh=%d", cout, nsrc, cin, kh);
+  const int total = (int)paif_conv_wpk_floats(nsrc, cin, kh);
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((total + 255) / 256), dim3(256), 0, paif::as_stream(stream), w, wpk, cout,
+                     nsrc, cin, kh);
+  PAIF_LAUNCH_CHECK("pack_conv_weight");
+  return 0;
+}
+
+int paif_pack_decomp1x1_weight(const float* w, float* wpk, paif_stream_t stream) {
+  PAIF_REQUIRE(w && wpk, PAIF_EINVAL, "pack_decomp1x1_weight: null pointer");
+  hipLaunchKernelGGL(pack_decomp1x1_kernel, dim3(12), dim3(256), 0, paif::as_stream(stream), w, wpk);
+  PAIF_LAUNCH_CHECK("pack_decomp1x1_weight");
+  return 0;
+}
+
+int paif_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, float* scale,
+                 float* shift, int C, paif_stream_t stream) {
+  PAIF_REQUIRE(gamma && beta && mean && var && scale && shift && C > 0, PAIF_EINVAL, "bn_fold: bad arguments");
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 63) / 64), dim3(64), 0, paif::as_stream(stream), gamma, beta, mean, var,
+                     eps, scale, shift, C);
+  PAIF_LAUNCH_CHECK("bn_fold");
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,529 @@
+// HBM-bound kernels of the fusion network and of the fusion->segmentation glue (gfx950).
+// Layout: NHWC fp32, one float4 (4 channels) per lane, 8 lanes per pixel -> a wave64 load/store
+// touches 8 pixels x 128 B = 1 KiB contiguous.  Channel reductions (max/min/mean over the 32
+// channels of a pixel) are 8-lane shuffle reductions; grid-wide reductions are two-pass and
+// deterministic (per-block partials reduced in a fixed order, no float atomics).
+#include <stdarg.h>
+
+#include "paif_common.h"
+
+namespace paif {
+static thread_local char g_err[256] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+}  // namespace paif
+
+namespace {
+
+constexpr int MAXGRID = 256 * 8;  // memory-bound kernels: cap the grid and grid-stride (guide, G11)
+
+inline int grid_for(size_t work_items, int per_block) {
+  size_t g = (work_items + per_block - 1) / per_block;
+  if (g > (size_t)MAXGRID) g = MAXGRID;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ---------------------------------------------------------------------------------------------
+// RGB -> YCrCb, NCHW planes (core/model_fusion_auto.py:69-92)
+// ---------------------------------------------------------------------------------------------
+__global__ void rgb2ycrcb_kernel(const float* __restrict__ rgb, float* __restrict__ ycc, int B, size_t HW) {
+  const size_t total = (size_t)B * HW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = i / HW, px = i - b * HW;
+    const float* s = rgb + b * 3 * HW + px;
+    const float R = s[0], G = s[HW], Bl = s[2 * HW];
+    // written exactly as the reference's expression tree (left-to-right adds, no re-association)
+    const float Y = __fadd_rn(__fadd_rn(__fmul_rn(0.299f, R), __fmul_rn(0.587f, G)), __fmul_rn(0.114f, Bl));
+    const float Cr = __fadd_rn(__fmul_rn(__fsub_rn(R, Y), 0.713f), 0.5f);
+    const float Cb = __fadd_rn(__fmul_rn(__fsub_rn(Bl, Y), 0.564f), 0.5f);
+    float* d = ycc + b * 3 * HW + px;
+    d[0] = Y; d[HW] = Cr; d[2 * HW] = Cb;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// stem: 3x3 conv 1->32 (no bias) + PReLU, fused with the guide max_c - min_c
+// thread = (pixel, channel quad); 8 lanes of a pixel read the same 9 taps (broadcast from L1)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                   const float* __restrict__ prelu, float* __restrict__ feat,
+                                                   float* __restrict__ guide, int B, int H, int W,
+                                                   size_t img_bstride) {
+  const int q = threadIdx.x & 7;
+  float wr[4][9];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wr[c][k] = w[(4 * q + c) * 9 + k];
+  const float slope = *prelu;
+  const size_t npix = (size_t)B * H * W;
+  for (size_t pix = (size_t)blockIdx.x * 32 + (threadIdx.x >> 3); pix < npix; pix += (size_t)gridDim.x * 32) {
+    const int x = (int)(pix % W);
+    const size_t rowid = pix / W;
+    const int y = (int)(rowid % H);
+    const float* base = img + ((rowid - y) / H) * img_bstride;  // image start (batch stride in floats)
+    float v[9];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int yy = y + dy - 1, xx = x + dx - 1;
+        v[dy * 3 + dx] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? base[(size_t)yy * W + xx] : 0.f;
+      }
+    float o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) s = fmaf(v[k], wr[c][k], s);
+      o[c] = paif::prelu_f(s, slope);
+    }
+    *reinterpret_cast<float4*>(feat + pix * 32 + q * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    if (guide) {
+      float mx = fmaxf(fmaxf(o[0], o[1]), fmaxf(o[2], o[3]));
+      float mn = fminf(fminf(o[0], o[1]), fminf(o[2], o[3]));
+#pragma unroll
+      for (int m = 1; m < 8; m <<= 1) {
+        mx = fmaxf(mx, __shfl_xor(mx, m));
+        mn = fminf(mn, __shfl_xor(mn, m));
+      }
+      if (q == 0) guide[pix] = mx - mn;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// depthwise k x k (groups = 32), optional ReLU on the input; taps come from L1/L2 (each float4 is
+// re-read by the k*k neighbouring pixels' threads of the same or an adjacent wave).
+// ---------------------------------------------------------------------------------------------
+template <int K, int DIL>
+__global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     float* __restrict__ out, int in_relu, int B, int H, int W) {
+  constexpr int P = DIL * (K - 1) / 2;
+  const int q = threadIdx.x & 7;
+  float wr[4][K * K];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int k = 0; k < K * K; ++k) wr[c][k] = w[(4 * q + c) * K * K + k];
+  const size_t npix = (size_t)B * H * W;
+  for (size_t pix = (size_t)blockIdx.x * 32 + (threadIdx.x >> 3); pix < npix; pix += (size_t)gridDim.x * 32) {
+    const int xx0 = (int)(pix % W);
+    const size_t rowid = pix / W;
+    const int yy0 = (int)(rowid % H);
+    const float* base = x + (rowid - yy0) * W * 32 + q * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int dy = 0; dy < K; ++dy) {
+      const int yy = yy0 + dy * DIL - P;
+      if (yy < 0 || yy >= H) continue;
+#pragma unroll
+      for (int dx = 0; dx < K; ++dx) {
+        const int xx = xx0 + dx * DIL - P;
+        if (xx < 0 || xx >= W) continue;
+        float4 v = *reinterpret_cast<const float4*>(base + ((size_t)yy * W + xx) * 32);
+        if (in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        const int k = dy * K + dx;
+        acc.x = fmaf(v.x, wr[0][k], acc.x); acc.y = fmaf(v.y, wr[1][k], acc.y);
+        acc.z = fmaf(v.z, wr[2][k], acc.z); acc.w = fmaf(v.w, wr[3][k], acc.w);
+      }
+    }
+    *reinterpret_cast<float4*>(out + pix * 32 + q * 4) = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ChannelPool(ir, vis): (max_c ir, mean_c ir, max_c vis, mean_c vis) -> float4 per pixel
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void channel_pool2_kernel(const float* __restrict__ ir, const float* __restrict__ vis,
+                                                            float* __restrict__ comp, size_t npix) {
+  const int q = threadIdx.x & 7;
+  for (size_t pix = (size_t)blockIdx.x * 32 + (threadIdx.x >> 3); pix < npix; pix += (size_t)gridDim.x * 32) {
+    const float4 a = *reinterpret_cast<const float4*>(ir + pix * 32 + q * 4);
+    const float4 b = *reinterpret_cast<const float4*>(vis + pix * 32 + q * 4);
+    float mxa = fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), sa = (a.x + a.y) + (a.z + a.w);
+    float mxb = fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)), sb = (b.x + b.y) + (b.z + b.w);
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) {
+      mxa = fmaxf(mxa, __shfl_xor(mxa, m)); sa += __shfl_xor(sa, m);
+      mxb = fmaxf(mxb, __shfl_xor(mxb, m)); sb += __shfl_xor(sb, m);
+    }
+    if (q == 0) *reinterpret_cast<float4*>(comp + pix * 4) = make_float4(mxa, sa * (1.0f / 32.0f), mxb, sb * (1.0f / 32.0f));
+  }
+}
+
+// Cell_Decom.get_residue on an existing feature map: max_c - min_c
+__global__ __launch_bounds__(256) void channel_residue_kernel(const float* __restrict__ x, float* __restrict__ g, size_t npix) {
+  const int q = threadIdx.x & 7;
+  for (size_t pix = (size_t)blockIdx.x * 32 + (threadIdx.x >> 3); pix < npix; pix += (size_t)gridDim.x * 32) {
+    const float4 a = *reinterpret_cast<const float4*>(x + pix * 32 + q * 4);
+    float mx = fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), mn = fminf(fminf(a.x, a.y), fminf(a.z, a.w));
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) {
+      mx = fmaxf(mx, __shfl_xor(mx, m));
+      mn = fminf(mn, __shfl_xor(mn, m));
+    }
+    if (q == 0) g[pix] = mx - mn;
+  }
+}
+
+// scale = sigmoid(conv5x5 4->1 (comp)); agg = scale*ir + (1-scale)*vis
+__global__ __launch_bounds__(256) void spa_blend_kernel(const float* __restrict__ comp, const float* __restrict__ w,
+                                                        const float* __restrict__ ir, const float* __restrict__ vis,
+                                                        float* __restrict__ agg, float* __restrict__ scale_out, int B,
+                                                        int H, int W) {
+  __shared__ float ws[100];
+  if (threadIdx.x < 100) ws[threadIdx.x] = w[threadIdx.x];  // [1][4][5][5]
+  __syncthreads();
+  const int q = threadIdx.x & 7;
+  const size_t npix = (size_t)B * H * W;
+  for (size_t pix = (size_t)blockIdx.x * 32 + (threadIdx.x >> 3); pix < npix; pix += (size_t)gridDim.x * 32) {
+    const int x0 = (int)(pix % W);
+    const size_t rowid = pix / W;
+    const int y0 = (int)(rowid % H);
+    const float* cbase = comp + (rowid - y0) * W * 4;
+    // 25 taps split over the 8 lanes of the pixel: lane q takes taps q, q+8, q+16, (q+24)
+    float s = 0.f;
+    for (int tap = q; tap < 25; tap += 8) {
+      const int dy = tap / 5, dx = tap - dy * 5;
+      const int yy = y0 + dy - 2, xx = x0 + dx - 2;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+        const float4 c = *reinterpret_cast<const float4*>(cbase + ((size_t)yy * W + xx) * 4);
+        s = fmaf(c.x, ws[tap], s); s = fmaf(c.y, ws[25 + tap], s);
+        s = fmaf(c.z, ws[50 + tap], s); s = fmaf(c.w, ws[75 + tap], s);
+      }
+    }
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) s += __shfl_xor(s, m);
+    const float sc = 1.0f / (1.0f + expf(-s));
+    const float4 a = *reinterpret_cast<const float4*>(ir + pix * 32 + q * 4);
+    const float4 b = *reinterpret_cast<const float4*>(vis + pix * 32 + q * 4);
+    const float om = 1.0f - sc;
+    float4 o;
+    o.x = __fadd_rn(__fmul_rn(sc, a.x), __fmul_rn(om, b.x));
+    o.y = __fadd_rn(__fmul_rn(sc, a.y), __fmul_rn(om, b.y));
+    o.z = __fadd_rn(__fmul_rn(sc, a.z), __fmul_rn(om, b.z));
+    o.w = __fadd_rn(__fmul_rn(sc, a.w), __fmul_rn(om, b.w));
+    *reinterpret_cast<float4*>(agg + pix * 32 + q * 4) = o;
+    if (scale_out && q == 0) scale_out[pix] = sc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ECA tail: mean over HxW from the conv's per-tile partials -> conv1d(k) over channels -> sigmoid
+//           -> out = PReLU(o * s[c] + r)
+// ---------------------------------------------------------------------------------------------
+__global__ void eca_scale_kernel(const float* __restrict__ partial, const float* __restrict__ w1d, int k, int tiles_per_img,
+                                 float inv_hw, float* __restrict__ s_out) {
+  // one block (64 threads) per image; thread c < 32 reduces its channel in tile order (deterministic)
+  __shared__ float mean[32];
+  const int b = blockIdx.x, c = threadIdx.x;
+  if (c < 32) {
+    float s = 0.f;
+    const float* p = partial + (size_t)b * tiles_per_img * 32 + c;
+    for (int t = 0; t < tiles_per_img; ++t) s += p[(size_t)t * 32];
+    mean[c] = s * inv_hw;
+  }
+  __syncthreads();
+  if (c < 32) {
+    float y = 0.f;
+    const int pad = (k - 1) / 2;
+    for (int j = 0; j < k; ++j) {
+      const int cc = c + j - pad;
+      if (cc >= 0 && cc < 32) y = fmaf(mean[cc], w1d[j], y);
+    }
+    s_out[b * 32 + c] = 1.0f / (1.0f + expf(-y));
+  }
+}
+
+__global__ __launch_bounds__(256) void eca_apply_kernel(const float* __restrict__ o, const float* __restrict__ r,
+                                                        const float* __restrict__ s, const float* __restrict__ prelu,
+                                                        float* __restrict__ out, size_t pix_per_img, size_t npix) {
+  const int q = threadIdx.x & 7;
+  const float slope = *prelu;
+  for (size_t pix = (size_t)blockIdx.x * 32 + (threadIdx.x >> 3); pix < npix; pix += (size_t)gridDim.x * 32) {
+    const size_t b = pix / pix_per_img;
+    const float4 sv = *reinterpret_cast<const float4*>(s + b * 32 + q * 4);
+    const float4 ov = *reinterpret_cast<const float4*>(o + pix * 32 + q * 4);
+    const float4 rv = *reinterpret_cast<const float4*>(r + pix * 32 + q * 4);
+    float4 v;
+    v.x = paif::prelu_f(__fadd_rn(__fmul_rn(ov.x, sv.x), rv.x), slope);
+    v.y = paif::prelu_f(__fadd_rn(__fmul_rn(ov.y, sv.y), rv.y), slope);
+    v.z = paif::prelu_f(__fadd_rn(__fmul_rn(ov.z, sv.z), rv.z), slope);
+    v.w = paif::prelu_f(__fadd_rn(__fmul_rn(ov.w, sv.w), rv.w), slope);
+    *reinterpret_cast<float4*>(out + pix * 32 + q * 4) = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// tail: 3x3 conv 16->1 + PReLU + tanh.  x NHWC16; 4 lanes per pixel (one float4 each), taps from L1.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                   const float* __restrict__ prelu, float* __restrict__ fused, int B, int H,
+                                                   int W) {
+  const int q = threadIdx.x & 3;
+  float wr[4][9];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wr[c][k] = w[(4 * q + c) * 9 + k];  // w[0][cin][3][3]
+  const float slope = *prelu;
+  const size_t npix = (size_t)B * H * W;
+  for (size_t pix = (size_t)blockIdx.x * 64 + (threadIdx.x >> 2); pix < npix; pix += (size_t)gridDim.x * 64) {
+    const int x0 = (int)(pix % W);
+    const size_t rowid = pix / W;
+    const int y0 = (int)(rowid % H);
+    const float* base = x + (rowid - y0) * W * 16 + q * 4;
+    float s = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int yy = y0 + dy - 1;
+      if (yy < 0 || yy >= H) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int xx = x0 + dx - 1;
+        if (xx < 0 || xx >= W) continue;
+        const float4 v = *reinterpret_cast<const float4*>(base + ((size_t)yy * W + xx) * 16);
+        const int k = dy * 3 + dx;
+        s = fmaf(v.x, wr[0][k], s); s = fmaf(v.y, wr[1][k], s); s = fmaf(v.z, wr[2][k], s); s = fmaf(v.w, wr[3][k], s);
+      }
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    if (q == 0) fused[pix] = tanhf(paif::prelu_f(s, slope));
+  }
+}
+
+__global__ void add_kernel(const float4* __restrict__ a, const float4* __restrict__ b, float4* __restrict__ o, size_t n4,
+                           const float* at, const float* bt, float* ot, size_t tail) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 x = a[i], y = b[i];
+    o[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < tail) ot[threadIdx.x] = at[threadIdx.x] + bt[threadIdx.x];
+}
+
+// ---------------------------------------------------------------------------------------------
+// glue: cat(fused,Cr,Cb) -> YCrCb2RGB -> clamp -> partial min/max ; then normalise
+// ---------------------------------------------------------------------------------------------
+constexpr int MM_BLOCK_PIX = 2048;  // pixels per block (fixed: the partial count is part of the ABI)
+
+__global__ __launch_bounds__(256) void recompose_clamp_kernel(const float* __restrict__ fused, const float* __restrict__ ycc,
+                                                              float* __restrict__ rgb, float* __restrict__ partial, int nblk,
+                                                              int B, size_t HW) {
+  const size_t total = (size_t)B * HW;
+  const size_t start = (size_t)blockIdx.x * MM_BLOCK_PIX;
+  float mn = INFINITY, mx = -INFINITY;
+  for (size_t i = start + threadIdx.x; i < start + MM_BLOCK_PIX && i < total; i += 256) {
+    const size_t b = i / HW, px = i - b * HW;
+    const float Y = fused[i];
+    const float cr = __fadd_rn(ycc[(b * 3 + 1) * HW + px], -0.5f);
+    const float cb = __fadd_rn(ycc[(b * 3 + 2) * HW + px], -0.5f);
+    const float y0 = __fadd_rn(Y, 0.0f);
+    // (im_flat + bias).mm(mat), mat rows: [1,1,1], [1.403,-0.714,0], [0,-0.344,1.773]; k-ordered fma chain
+    float R = fmaf(cb, 0.0f, fmaf(cr, 1.403f, y0 * 1.0f));
+    float G = fmaf(cb, -0.344f, fmaf(cr, -0.714f, y0 * 1.0f));
+    float Bl = fmaf(cb, 1.773f, fmaf(cr, 0.0f, y0 * 1.0f));
+    R = fminf(fmaxf(R, 0.f), 1.f); G = fminf(fmaxf(G, 0.f), 1.f); Bl = fminf(fmaxf(Bl, 0.f), 1.f);
+    rgb[(b * 3 + 0) * HW + px] = R; rgb[(b * 3 + 1) * HW + px] = G; rgb[(b * 3 + 2) * HW + px] = Bl;
+    mn = fminf(mn, fminf(R, fminf(G, Bl)));
+    mx = fmaxf(mx, fmaxf(R, fmaxf(G, Bl)));
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, m));
+    mx = fmaxf(mx, __shfl_xor(mx, m));
+  }
+  __shared__ float smn[4], smx[4];
+  if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x] = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+    partial[nblk + blockIdx.x] = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+  }
+}
+
+__global__ __launch_bounds__(256) void minmax_normalize_kernel(const float* __restrict__ rgb, const float* __restrict__ partial,
+                                                               int npartial, float* __restrict__ out,
+                                                               float* __restrict__ minmax_out, int B, size_t HW) {
+  // every block reduces the (small) partial array itself: min/max are order-independent -> exact
+  float mn = INFINITY, mx = -INFINITY;
+  for (int i = threadIdx.x; i < npartial; i += 256) {
+    mn = fminf(mn, partial[i]);
+    mx = fmaxf(mx, partial[npartial + i]);
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, m));
+    mx = fmaxf(mx, __shfl_xor(mx, m));
+  }
+  __shared__ float smn[4], smx[4];
+  if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  mn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+  mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+  if (minmax_out && blockIdx.x == 0 && threadIdx.x == 0) { minmax_out[0] = mn; minmax_out[1] = mx; }
+  const float range = mx - mn;
+  const size_t total = (size_t)B * 3 * HW;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (int)((i / HW) % 3);
+    const float mean = c == 0 ? 123.675f : (c == 1 ? 116.28f : 103.53f);
+    const float sd = c == 0 ? 58.395f : (c == 1 ? 57.12f : 57.375f);
+    float v = __fdiv_rn(__fsub_rn(rgb[i], mn), range);
+    v = __fmul_rn(v, 255.0f);
+    out[i] = __fdiv_rn(__fsub_rn(v, mean), sd);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int paif_version(void) { return PAIF_ABI_VERSION; }
+const char* paif_last_error(void) { return paif::g_err; }
+
+int paif_device_cus(void) {
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+    paif::set_error("device_cus: no HIP device");
+    return PAIF_EINVAL;
+  }
+  return prop.multiProcessorCount;
+}
+
+int paif_rgb2ycrcb_fwd(const float* rgb, float* ycc, int B, int H, int W, paif_stream_t stream) {
+  PAIF_REQUIRE(rgb && ycc && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "rgb2ycrcb: bad arguments");
+  const size_t HW = (size_t)H * W;
+  hipLaunchKernelGGL(rgb2ycrcb_kernel, dim3(grid_for(B * HW, 256)), dim3(256), 0, paif::as_stream(stream), rgb, ycc, B, HW);
+  PAIF_LAUNCH_CHECK("rgb2ycrcb");
+  return 0;
+}
+
+int paif_stem_fwd(const float* img, size_t img_bstride, const float* w, const float* prelu, float* feat, float* guide,
+                  int B, int H, int W, paif_stream_t stream) {
+  PAIF_REQUIRE(img && w && prelu && feat && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "stem: bad arguments");
+  PAIF_REQUIRE(img_bstride >= (size_t)H * W, PAIF_EINVAL, "stem: batch stride %zu < H*W", img_bstride);
+  hipLaunchKernelGGL(stem_kernel, dim3(grid_for((size_t)B * H * W, 32)), dim3(256), 0, paif::as_stream(stream), img, w,
+                     prelu, feat, guide, B, H, W, img_bstride);
+  PAIF_LAUNCH_CHECK("stem");
+  return 0;
+}
+
+int paif_dwconv_fwd(const float* x, const float* w, float* out, int k, int dil, int in_relu, int B, int H, int W,
+                    paif_stream_t stream) {
+  PAIF_REQUIRE(x && w && out && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "dwconv: bad arguments");
+  const dim3 g(grid_for((size_t)B * H * W, 32)), blk(256);
+  hipStream_t st = paif::as_stream(stream);
+  const int key = k * 10 + dil;
+  switch (key) {
+    case 31: hipLaunchKernelGGL((dwconv_kernel<3, 1>), g, blk, 0, st, x, w, out, in_relu, B, H, W); break;
+    case 32: hipLaunchKernelGGL((dwconv_kernel<3, 2>), g, blk, 0, st, x, w, out, in_relu, B, H, W); break;
+    case 51: hipLaunchKernelGGL((dwconv_kernel<5, 1>), g, blk, 0, st, x, w, out, in_relu, B, H, W); break;
+    case 52: hipLaunchKernelGGL((dwconv_kernel<5, 2>), g, blk, 0, st, x, w, out, in_relu, B, H, W); break;
+    case 71: hipLaunchKernelGGL((dwconv_kernel<7, 1>), g, blk, 0, st, x, w, out, in_relu, B, H, W); break;
+    case 72: hipLaunchKernelGGL((dwconv_kernel<7, 2>), g, blk, 0, st, x, w, out, in_relu, B, H, W); break;
+    default:
+      paif::set_error("dwconv: kernel %d dil %d not built", k, dil);
+      return PAIF_ENOSUP;
+  }
+  PAIF_LAUNCH_CHECK("dwconv");
+  return 0;
+}
+
+int paif_channel_pool2_fwd(const float* ir, const float* vis, float* comp, int B, int H, int W, paif_stream_t stream) {
+  PAIF_REQUIRE(ir && vis && comp && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "channel_pool2: bad arguments");
+  const size_t npix = (size_t)B * H * W;
+  hipLaunchKernelGGL(channel_pool2_kernel, dim3(grid_for(npix, 32)), dim3(256), 0, paif::as_stream(stream), ir, vis, comp,
+                     npix);
+  PAIF_LAUNCH_CHECK("channel_pool2");
+  return 0;
+}
+
+int paif_channel_residue_fwd(const float* x, float* guide, int B, int H, int W, paif_stream_t stream) {
+  PAIF_REQUIRE(x && guide && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "channel_residue: bad arguments");
+  const size_t npix = (size_t)B * H * W;
+  hipLaunchKernelGGL(channel_residue_kernel, dim3(grid_for(npix, 32)), dim3(256), 0, paif::as_stream(stream), x, guide, npix);
+  PAIF_LAUNCH_CHECK("channel_residue");
+  return 0;
+}
+
+int paif_spa_blend_fwd(const float* comp, const float* w, const float* ir, const float* vis, float* agg, float* scale_out,
+                       int B, int H, int W, paif_stream_t stream) {
+  PAIF_REQUIRE(comp && w && ir && vis && agg && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "spa_blend: bad arguments");
+  hipLaunchKernelGGL(spa_blend_kernel, dim3(grid_for((size_t)B * H * W, 32)), dim3(256), 0, paif::as_stream(stream), comp,
+                     w, ir, vis, agg, scale_out, B, H, W);
+  PAIF_LAUNCH_CHECK("spa_blend");
+  return 0;
+}
+
+int paif_eca_finish_fwd(const float* o, const float* r, const float* pool_partial, const float* w1d, int k,
+                        const float* prelu, float* gate, float* out, int B, int H, int W, paif_stream_t stream) {
+  PAIF_REQUIRE(o && r && pool_partial && w1d && prelu && gate && out && B > 0 && H > 0 && W > 0, PAIF_EINVAL,
+               "eca_finish: bad arguments");
+  PAIF_REQUIRE(k >= 1 && k <= 9 && (k & 1), PAIF_ENOSUP, "eca_finish: k=%d", k);
+  hipStream_t st = paif::as_stream(stream);
+  const int tiles_per_img = paif_conv2d_blocks(1, H, W);
+  float* s = gate;
+  hipLaunchKernelGGL(eca_scale_kernel, dim3(B), dim3(64), 0, st, pool_partial, w1d, k, tiles_per_img,
+                     1.0f / ((float)H * (float)W), s);
+  PAIF_LAUNCH_CHECK("eca_scale");
+  const size_t npix = (size_t)B * H * W;
+  hipLaunchKernelGGL(eca_apply_kernel, dim3(grid_for(npix, 32)), dim3(256), 0, st, o, r, s, prelu, out, (size_t)H * W, npix);
+  PAIF_LAUNCH_CHECK("eca_apply");
+  return 0;
+}
+
+int paif_tail_fwd(const float* x, const float* w, const float* prelu, float* fused, int B, int H, int W,
+                  paif_stream_t stream) {
+  PAIF_REQUIRE(x && w && prelu && fused && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "tail: bad arguments");
+  hipLaunchKernelGGL(tail_kernel, dim3(grid_for((size_t)B * H * W, 64)), dim3(256), 0, paif::as_stream(stream), x, w, prelu,
+                     fused, B, H, W);
+  PAIF_LAUNCH_CHECK("tail");
+  return 0;
+}
+
+int paif_add_fwd(const float* a, const float* b, float* out, size_t n, paif_stream_t stream) {
+  PAIF_REQUIRE(a && b && out, PAIF_EINVAL, "add: null pointer");
+  if (n == 0) return 0;
+  const size_t n4 = n / 4, tail = n - n4 * 4;
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(n4 ? n4 : 1, 256)), dim3(256), 0, paif::as_stream(stream),
+                     reinterpret_cast<const float4*>(a), reinterpret_cast<const float4*>(b), reinterpret_cast<float4*>(out), n4,
+                     a + n4 * 4, b + n4 * 4, out + n4 * 4, tail);
+  PAIF_LAUNCH_CHECK("add");
+  return 0;
+}
+
+int paif_minmax_blocks(int B, int H, int W) {
+  const size_t total = (size_t)B * H * W;
+  return (int)((total + MM_BLOCK_PIX - 1) / MM_BLOCK_PIX);
+}
+
+int paif_recompose_clamp_fwd(const float* fused, const float* ycc, float* rgb_out, float* minmax_partial, int B, int H,
+                             int W, paif_stream_t stream) {
+  PAIF_REQUIRE(fused && ycc && rgb_out && minmax_partial && B > 0 && H > 0 && W > 0, PAIF_EINVAL,
+               "recompose_clamp: bad arguments");
+  const int nblk = paif_minmax_blocks(B, H, W);
+  hipLaunchKernelGGL(recompose_clamp_kernel, dim3(nblk), dim3(256), 0, paif::as_stream(stream), fused, ycc, rgb_out,
+                     minmax_partial, nblk, B, (size_t)H * W);
+  PAIF_LAUNCH_CHECK("recompose_clamp");
+  return 0;
+}
+
+int paif_minmax_normalize_fwd(const float* rgb, const float* minmax_partial, int npartial, float* out, float* minmax_out,
+                              int B, int H, int W, paif_stream_t stream) {
+  PAIF_REQUIRE(rgb && minmax_partial && out && npartial > 0 && B > 0 && H > 0 && W > 0, PAIF_EINVAL,
+               "minmax_normalize: bad arguments");
+  const size_t HW = (size_t)H * W;
+  hipLaunchKernelGGL(minmax_normalize_kernel, dim3(grid_for((size_t)B * 3 * HW, 256)), dim3(256), 0, paif::as_stream(stream),
+                     rgb, minmax_partial, npartial, out, minmax_out, B, HW);
+  PAIF_LAUNCH_CHECK("minmax_normalize");
+  return 0;
+}
+
+}  // extern "C"

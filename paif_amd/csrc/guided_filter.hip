@@ -1,0 +1,205 @@
+// Guided filter (radius 4, 1-channel guide, 32-channel NHWC target), both eps of
+// Cell_Decom.decomposition (core/model_fusion_auto.py:522-535; third-party
+// guided_filter_pytorch.GuidedFilter -- algorithm per oracle/shims/guided_filter_pytorch).
+//
+// HBM-bound.  Row-streaming separable 9x9 box sums:
+//   workgroup = 32 loaded columns (24 output columns + 4 halo each side) x 8 channel quads;
+//   it walks down a segment of rows keeping the last 9 rows in REGISTERS (static ring, loop
+//   unrolled by 9) -> vertical 9-term sums are direct (no running add/subtract drift);
+//   the vertical sums of one row go to LDS (double-buffered by row parity, one barrier per row)
+//   and each thread adds its 9 horizontal neighbours.
+// Box sums are exact border-clipped window sums; N = (#valid rows) x (#valid cols).
+// fp32 throughout (SURVEY.md section 7 hard part 1: A = cov/(var+eps) with eps = 1e-4).
+#include "paif_common.h"
+
+namespace {
+
+constexpr int R = 4;
+constexpr int K = 2 * R + 1;   // 9
+constexpr int NCOL = 32;       // loaded columns per workgroup
+constexpr int OCOL = NCOL - 2 * R;  // 24 output columns
+constexpr int ROWS_PER_SEG = 60;
+
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4fma(float s, float4 a, float4 c) {
+  return make_float4(fmaf(s, a.x, c.x), fmaf(s, a.y, c.y), fmaf(s, a.z, c.z), fmaf(s, a.w, c.w));
+}
+
+// ---- stage 1: A_e = cov/(var+eps_e), b_e = mean_y - A_e*mean_g ---------------------------------
+__global__ __launch_bounds__(256) void gf_ab_kernel(const float* __restrict__ guide, const float* __restrict__ y,
+                                                    float* __restrict__ ab, float eps0, float eps1, int B, int H, int W,
+                                                    int nstrip, int nseg) {
+  __shared__ float4 sy[2][NCOL][8];
+  __shared__ float4 sgy[2][NCOL][8];
+  __shared__ float2 sg[2][NCOL];
+  const int q = threadIdx.x & 7, xi = threadIdx.x >> 3;
+  int t = blockIdx.x;
+  const int strip = t % nstrip; t /= nstrip;
+  const int seg = t % nseg;
+  const int b = t / nseg;
+  const int col = strip * OCOL - R + xi;          // image column of this thread
+  const bool colin = col >= 0 && col < W;
+  const int ybeg = seg * ROWS_PER_SEG, yend = min(H, ybeg + ROWS_PER_SEG);
+  const size_t img = (size_t)b * H * W;
+  const size_t plane = (size_t)B * H * W * 32;
+
+  float4 ry[K];
+  float rg[K];
+  const int r0 = ybeg - R, r1 = yend + R;  // rows streamed: [r0, r1)
+  for (int rr = r0; rr < r1; rr += K) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int row = rr + k;
+      if (row >= r1) break;  // block-uniform
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      float g = 0.f;
+      if (colin && row >= 0 && row < H) {
+        const size_t px = img + (size_t)row * W + col;
+        v = *reinterpret_cast<const float4*>(y + px * 32 + q * 4);
+        g = guide[px];
+      }
+      ry[k] = v;
+      rg[k] = g;
+      const int orow = row - R;  // output row whose 9-row window is now complete
+      if (orow < ybeg) continue;  // block-uniform (ring not full yet)
+      float4 vy = make_float4(0.f, 0.f, 0.f, 0.f), vgy = vy;
+      float vg = 0.f, vgg = 0.f;
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        vy = f4add(vy, ry[j]);
+        vgy = f4fma(rg[j], ry[j], vgy);
+        vg += rg[j];
+        vgg = fmaf(rg[j], rg[j], vgg);
+      }
+      const int buf = orow & 1;
+      sy[buf][xi][q] = vy;
+      sgy[buf][xi][q] = vgy;
+      if (q == 0) sg[buf][xi] = make_float2(vg, vgg);
+      __syncthreads();
+      if (xi >= R && xi < NCOL - R && col < W) {
+        float4 by = make_float4(0.f, 0.f, 0.f, 0.f), bgy = by;
+        float bg = 0.f, bgg = 0.f;
+#pragma unroll
+        for (int j = -R; j <= R; ++j) {
+          by = f4add(by, sy[buf][xi + j][q]);
+          bgy = f4add(bgy, sgy[buf][xi + j][q]);
+          const float2 gg = sg[buf][xi + j];
+          bg += gg.x;
+          bgg += gg.y;
+        }
+        const int cy = min(orow + R, H - 1) - max(orow - R, 0) + 1;
+        const int cx = min(col + R, W - 1) - max(col - R, 0) + 1;
+        const float n = (float)(cy * cx);
+        const float mg = bg / n;
+        const float var = bgg / n - mg * mg;
+        const float4 my = make_float4(by.x / n, by.y / n, by.z / n, by.w / n);
+        const float4 cov = make_float4(bgy.x / n - mg * my.x, bgy.y / n - mg * my.y, bgy.z / n - mg * my.z,
+                                       bgy.w / n - mg * my.w);
+        const size_t o = (img + (size_t)orow * W + col) * 32 + q * 4;
+        const float d0 = var + eps0, d1 = var + eps1;
+        const float4 A0 = make_float4(cov.x / d0, cov.y / d0, cov.z / d0, cov.w / d0);
+        const float4 A1 = make_float4(cov.x / d1, cov.y / d1, cov.z / d1, cov.w / d1);
+        *reinterpret_cast<float4*>(ab + o) = A0;
+        *reinterpret_cast<float4*>(ab + plane + o) =
+            make_float4(my.x - A0.x * mg, my.y - A0.y * mg, my.z - A0.z * mg, my.w - A0.w * mg);
+        *reinterpret_cast<float4*>(ab + 2 * plane + o) = A1;
+        *reinterpret_cast<float4*>(ab + 3 * plane + o) =
+            make_float4(my.x - A1.x * mg, my.y - A1.y * mg, my.z - A1.z * mg, my.w - A1.w * mg);
+      }
+    }
+  }
+}
+
+// ---- stage 2: LF_e = box(A_e)/N * g + box(b_e)/N ; blockIdx.y = e -------------------------------
+__global__ __launch_bounds__(256) void gf_lf_kernel(const float* __restrict__ guide, const float* __restrict__ ab,
+                                                    float* __restrict__ lf, int B, int H, int W, int nstrip, int nseg) {
+  __shared__ float4 sa[2][NCOL][8];
+  __shared__ float4 sb[2][NCOL][8];
+  const int q = threadIdx.x & 7, xi = threadIdx.x >> 3;
+  int t = blockIdx.x;
+  const int strip = t % nstrip; t /= nstrip;
+  const int seg = t % nseg;
+  const int b = t / nseg;
+  const int e = blockIdx.y;
+  const int col = strip * OCOL - R + xi;
+  const bool colin = col >= 0 && col < W;
+  const int ybeg = seg * ROWS_PER_SEG, yend = min(H, ybeg + ROWS_PER_SEG);
+  const size_t img = (size_t)b * H * W;
+  const size_t plane = (size_t)B * H * W * 32;
+  const float* Ap = ab + (size_t)(2 * e) * plane;
+  const float* Bp = ab + (size_t)(2 * e + 1) * plane;
+  float* out = lf + (size_t)e * plane;
+
+  float4 ra[K], rb[K];
+  const int r0 = ybeg - R, r1 = yend + R;
+  for (int rr = r0; rr < r1; rr += K) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int row = rr + k;
+      if (row >= r1) break;
+      float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+      if (colin && row >= 0 && row < H) {
+        const size_t o = (img + (size_t)row * W + col) * 32 + q * 4;
+        va = *reinterpret_cast<const float4*>(Ap + o);
+        vb = *reinterpret_cast<const float4*>(Bp + o);
+      }
+      ra[k] = va;
+      rb[k] = vb;
+      const int orow = row - R;
+      if (orow < ybeg) continue;
+      float4 ua = make_float4(0.f, 0.f, 0.f, 0.f), ub = ua;
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        ua = f4add(ua, ra[j]);
+        ub = f4add(ub, rb[j]);
+      }
+      const int buf = orow & 1;
+      sa[buf][xi][q] = ua;
+      sb[buf][xi][q] = ub;
+      __syncthreads();
+      if (xi >= R && xi < NCOL - R && col < W) {
+        float4 ba = make_float4(0.f, 0.f, 0.f, 0.f), bb = ba;
+#pragma unroll
+        for (int j = -R; j <= R; ++j) {
+          ba = f4add(ba, sa[buf][xi + j][q]);
+          bb = f4add(bb, sb[buf][xi + j][q]);
+        }
+        const int cy = min(orow + R, H - 1) - max(orow - R, 0) + 1;
+        const int cx = min(col + R, W - 1) - max(col - R, 0) + 1;
+        const float n = (float)(cy * cx);
+        const size_t px = img + (size_t)orow * W + col;
+        const float g = guide[px];
+        *reinterpret_cast<float4*>(out + px * 32 + q * 4) =
+            make_float4(fmaf(ba.x / n, g, bb.x / n), fmaf(ba.y / n, g, bb.y / n), fmaf(ba.z / n, g, bb.z / n),
+                        fmaf(ba.w / n, g, bb.w / n));
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int paif_guided_filter_ab_fwd(const float* guide, const float* y, float* ab, float eps0, float eps1, int B, int H, int W,
+                              paif_stream_t stream) {
+  PAIF_REQUIRE(guide && y && ab && B > 0, PAIF_EINVAL, "guided_filter_ab: bad arguments");
+  PAIF_REQUIRE(H > 2 * R + 1 && W > 2 * R + 1, PAIF_EINVAL, "guided_filter: H,W must exceed 2r+1 = %d (got %dx%d)", K, H, W);
+  const int nstrip = (W + OCOL - 1) / OCOL, nseg = (H + ROWS_PER_SEG - 1) / ROWS_PER_SEG;
+  hipLaunchKernelGGL(gf_ab_kernel, dim3(B * nstrip * nseg), dim3(256), 0, paif::as_stream(stream), guide, y, ab, eps0, eps1,
+                     B, H, W, nstrip, nseg);
+  PAIF_LAUNCH_CHECK("guided_filter_ab");
+  return 0;
+}
+
+int paif_guided_filter_lf_fwd(const float* guide, const float* ab, float* lf, int B, int H, int W, paif_stream_t stream) {
+  PAIF_REQUIRE(guide && ab && lf && B > 0, PAIF_EINVAL, "guided_filter_lf: bad arguments");
+  PAIF_REQUIRE(H > 2 * R + 1 && W > 2 * R + 1, PAIF_EINVAL, "guided_filter: H,W must exceed 2r+1 = %d (got %dx%d)", K, H, W);
+  const int nstrip = (W + OCOL - 1) / OCOL, nseg = (H + ROWS_PER_SEG - 1) / ROWS_PER_SEG;
+  hipLaunchKernelGGL(gf_lf_kernel, dim3(B * nstrip * nseg, 2), dim3(256), 0, paif::as_stream(stream), guide, ab, lf, B, H,
+                     W, nstrip, nseg);
+  PAIF_LAUNCH_CHECK("guided_filter_lf");
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,340 @@
+"""NAS-cell primitive operators -- MI355X-native counterparts of the reference's operations_m.py.
+
+Same class names, constructor signatures, OPS registry, sub-module names and state_dict keys as
+the reference (operations_m.py:9-18, 114-145, 340-393, 435-525), so a reference checkpoint loads
+with strict=True and `OPS[name](C, kernel, dilation, affine)` is a drop-in.  forward(x) takes and
+returns [B,C,H,W] tensors like the reference; the arithmetic runs in the hand-written gfx950
+kernels of libpaif_hip.so (paif_amd/csrc), in NHWC (= torch channels_last) internally.
+
+There is NO torch/eager fallback: the parameter-holder modules below raise if ever called.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+# ---------------------------------------------------------------------------------------------
+# parameter holders: same constructors / init / state_dict keys as the torch layers the reference
+# uses, but never executed -- the HIP kernels read their tensors.
+# ---------------------------------------------------------------------------------------------
+class _NeverCalled:
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("%s is a parameter holder; the HIP path must be used" % type(self).__name__)
+
+
+class Conv2dParams(_NeverCalled, nn.Conv2d):
+    pass
+
+
+class Conv1dParams(_NeverCalled, nn.Conv1d):
+    pass
+
+
+class BatchNormParams(_NeverCalled, nn.BatchNorm2d):
+    pass
+
+
+class PReLUParams(_NeverCalled, nn.PReLU):
+    pass
+
+
+class LinearParams(_NeverCalled, nn.Linear):
+    pass
+
+
+class LayerNormParams(_NeverCalled, nn.LayerNorm):
+    pass
+
+
+class _PackCache:
+    """Packed-weight cache keyed on (data_ptr, version, device) of the source parameter(s)."""
+
+    def __init__(self):
+        self._store = {}
+
+    def get(self, name, params, builder):
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in params)
+        hit = self._store.get(name)
+        if hit is None or hit[0] != key:
+            hit = (key, builder())
+            self._store[name] = hit
+        return hit[1]
+
+
+def _pad_for(k, d):
+    # operations_m.py:121-132 -- anything outside the table gets padding 0 in the reference, which would
+    # change the output size; the HIP conv is "same"-padded, so refuse other combinations.
+    table = {(3, 1): 1, (3, 2): 2, (5, 1): 2, (5, 2): 4, (7, 1): 3, (7, 2): 6, (1, 1): 0}
+    if (k, d) not in table:
+        raise NotImplementedError("BasicConv kernel %d dilation %d is outside the reference's padding table" % (k, d))
+    return table[(k, d)]
+
+
+class _HipOp(nn.Module):
+    """Base: NCHW boundary <-> NHWC body."""
+
+    def __init__(self):
+        super().__init__()
+        self._packs = _PackCache()
+
+    def forward(self, x):
+        ops.require_no_grad(x)
+        with torch.no_grad():
+            return ops.to_nchw_view(self.forward_nhwc(ops.to_nhwc(x)))
+
+    def forward_nhwc(self, x, res=()):
+        raise NotImplementedError
+
+    @staticmethod
+    def _add_res(y, res):
+        for r in res:
+            y = ops.add(y, r)
+        return y
+
+
+class BasicConv(_HipOp):
+    """operations_m.py:114-145.  On the hot path always relu=False, bn=False, bias=False."""
+
+    def __init__(self, in_planes, out_planes, kernel_size, dilation=1, groups=1, relu=True, bn=False, bias=False):
+        super().__init__()
+        padding = _pad_for(kernel_size, dilation)
+        self.out_channels = out_planes
+        self.kernel_size, self.dilation, self.groups = kernel_size, dilation, groups
+        self.conv = Conv2dParams(in_planes, out_planes, kernel_size=kernel_size, stride=1, padding=padding,
+                                 dilation=dilation, groups=groups, bias=bias)
+        self.bn = BatchNormParams(out_planes, eps=1e-5, momentum=0.01, affine=True) if bn else None
+        self.relu = PReLUParams() if relu else None
+        if bias:
+            raise NotImplementedError("BasicConv(bias=True) is never used by the reference path")
+
+    def wpk(self, nsrc, cin):
+        return self._packs.get("w", [self.conv.weight], lambda: ops.pack_conv_weight(self.conv.weight, nsrc, cin, self.kernel_size))
+
+    def forward_nhwc(self, x, res=()):
+        C = x.shape[-1]
+        if self.groups == C and self.groups == self.conv.out_channels and self.groups > 1:
+            y = ops.dwconv(x, self.conv.weight, self.kernel_size, self.dilation, in_relu=False)
+            if self.bn is not None or self.relu is not None:
+                raise NotImplementedError("depthwise BasicConv with bn/relu")
+            return self._add_res(y, res)
+        if self.groups != 1:
+            raise NotImplementedError("grouped BasicConv other than depthwise")
+        if C not in (32, 64, 96) or self.conv.out_channels != 32:
+            raise NotImplementedError("BasicConv %d->%d: the HIP conv is built for 32-channel NAS cells" % (C, self.conv.out_channels))
+        nsrc = C // 32
+        srcs = [x] if nsrc == 1 else [x[..., 32 * i:32 * (i + 1)].contiguous() for i in range(nsrc)]
+        scale = shift = None
+        if self.bn is not None:
+            scale, shift = _bn_scale_shift(self.bn, self._packs)
+        act, slope = (ops.ACT_PRELU, self.relu.weight) if self.relu is not None else (ops.ACT_NONE, None)
+        return ops.conv2d(srcs, self.wpk(nsrc, 32), self.kernel_size, self.dilation, scale=scale, shift=shift, act=act,
+                          prelu=slope, res=res)
+
+
+def conv3x3(in_planes, out_planes, stride=1):
+    """operations_m.py:283-284."""
+    return Conv2dParams(in_planes, out_planes, kernel_size=3, stride=stride, padding=1, bias=False)
+
+
+class ResidualDenseBlock(_HipOp):
+    """operations_m.py:435-449: x1=P(c1 x); x2=P(c2 [x,x1]); x3=P(c3 [x,x1,x2]); x3*0.333333 + x.
+    The concatenations are virtual (the conv kernel walks up to three NHWC sources)."""
+
+    def __init__(self, in_channels, kernel_size, dialtions=1, bias=False):
+        super().__init__()
+        self.k, self.d = kernel_size, dialtions
+        self.conv1 = BasicConv(in_channels, in_channels, kernel_size, dilation=dialtions, relu=False)
+        self.conv2 = BasicConv(in_channels * 2, in_channels, kernel_size, dilation=dialtions, relu=False)
+        self.conv3 = BasicConv(in_channels * 3, in_channels, kernel_size, dilation=dialtions, relu=False)
+        self.lrelu = PReLUParams()
+
+    def forward_nhwc(self, x, res=()):
+        a = self.lrelu.weight
+        k, d = self.k, self.d
+        x1 = ops.conv2d([x], self.conv1.wpk(1, 32), k, d, act=ops.ACT_PRELU, prelu=a)
+        x2 = ops.conv2d([x, x1], self.conv2.wpk(2, 32), k, d, act=ops.ACT_PRELU, prelu=a)
+        return ops.conv2d([x, x1, x2], self.conv3.wpk(3, 32), k, d, act=ops.ACT_PRELU, prelu=a, alpha=0.333333,
+                          res=(x,) + tuple(res))
+
+
+class ResidualModule(_HipOp):
+    """operations_m.py:451-464: conv kxk -> conv3x3 dil2 -> conv1x1 -> BN -> PReLU; + x."""
+
+    def __init__(self, in_channels, kernel_size, dialtions=1, bias=False):
+        super().__init__()
+        self.k, self.d = kernel_size, dialtions
+        self.op = nn.Sequential(
+            BasicConv(in_channels, in_channels, kernel_size, dilation=dialtions, relu=False),
+            Conv2dParams(in_channels, in_channels, kernel_size=3, stride=1, padding=2, dilation=2, bias=False),
+            Conv2dParams(in_channels, in_channels, kernel_size=1, padding=0, bias=False),
+            BatchNormParams(in_channels),
+            PReLUParams(),
+        )
+
+    def forward_nhwc(self, x, res=()):
+        op = self.op
+        t1 = ops.conv2d([x], op[0].wpk(1, 32), self.k, self.d)
+        w2 = self._packs.get("w2", [op[1].weight], lambda: ops.pack_conv_weight(op[1].weight, 1, 32, 3))
+        t2 = ops.conv2d([t1], w2, 3, 2)
+        w3 = self._packs.get("w3", [op[2].weight], lambda: ops.pack_conv_weight(op[2].weight, 1, 32, 1))
+        scale, shift = _bn_scale_shift(op[3], self._packs)
+        return ops.conv2d([t2], w3, 1, 1, scale=scale, shift=shift, act=ops.ACT_PRELU, prelu=op[4].weight,
+                          res=(x,) + tuple(res))
+
+
+class DilConv(_HipOp):
+    """operations_m.py:494-506: ReLU -> depthwise kxk dil d -> conv1x1 -> BN(affine); + x."""
+
+    def __init__(self, C_in, C_out, kernel_size, dilation, affine=True):
+        super().__init__()
+        self.k, self.d = kernel_size, dilation
+        self.op = nn.Sequential(
+            nn.ReLU(inplace=False),
+            BasicConv(C_in, C_out, kernel_size, dilation=dilation, relu=False, groups=C_in),
+            Conv2dParams(C_in, C_out, kernel_size=1, padding=0, bias=False),
+            BatchNormParams(C_out, affine=affine),
+        )
+
+    def forward_nhwc(self, x, res=()):
+        op = self.op
+        t = ops.dwconv(x, op[1].conv.weight, self.k, self.d, in_relu=True)
+        w = self._packs.get("w", [op[2].weight], lambda: ops.pack_conv_weight(op[2].weight, 1, 32, 1))
+        scale, shift = _bn_scale_shift(op[3], self._packs)
+        return ops.conv2d([t], w, 1, 1, scale=scale, shift=shift, res=(x,) + tuple(res))
+
+
+def _bn_scale_shift(bn, cache=None, name="bn"):
+    """Eval-mode BatchNorm folded to per-channel scale/shift (cached on parameter/buffer versions)."""
+    if bn.training:
+        raise NotImplementedError("train-mode BatchNorm (batch statistics) is part of the training step, not built yet; call .eval()")
+
+    def build():
+        if bn.affine:
+            return ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+        one = torch.ones_like(bn.running_mean)
+        return ops.bn_fold(one, torch.zeros_like(one), bn.running_mean, bn.running_var, bn.eps)
+
+    if cache is None:
+        return build()
+    keys = [bn.running_mean, bn.running_var] + ([bn.weight, bn.bias] if bn.affine else [])
+    return cache.get(name, keys, build)
+
+
+class SepConv(_HipOp):
+    """operations_m.py:509-525 (no residual)."""
+
+    def __init__(self, C_in, C_out, kernel_size, stride, padding, affine=True):
+        super().__init__()
+        if stride != 1 or padding != kernel_size // 2:
+            raise NotImplementedError("SepConv is only reachable with stride 1, padding k//2 (OPS registry)")
+        self.k = kernel_size
+        self.op = nn.Sequential(
+            nn.ReLU(inplace=False),
+            Conv2dParams(C_in, C_in, kernel_size=kernel_size, stride=stride, padding=padding, groups=C_in, bias=False),
+            Conv2dParams(C_in, C_in, kernel_size=1, padding=0, bias=False),
+            BatchNormParams(C_in, affine=affine),
+            nn.ReLU(inplace=False),
+            Conv2dParams(C_in, C_in, kernel_size=kernel_size, stride=1, padding=padding, groups=C_in, bias=False),
+            Conv2dParams(C_in, C_out, kernel_size=1, padding=0, bias=False),
+            BatchNormParams(C_out, affine=affine),
+        )
+
+    def forward_nhwc(self, x, res=()):
+        op = self.op
+        t = ops.dwconv(x, op[1].weight, self.k, 1, in_relu=True)
+        w1 = self._packs.get("w1", [op[2].weight], lambda: ops.pack_conv_weight(op[2].weight, 1, 32, 1))
+        s1, b1 = _bn_scale_shift(op[3], self._packs, 'bn1')
+        t = ops.conv2d([t], w1, 1, 1, scale=s1, shift=b1, act=ops.ACT_RELU)
+        t = ops.dwconv(t, op[5].weight, self.k, 1, in_relu=False)
+        w2 = self._packs.get("w2", [op[6].weight], lambda: ops.pack_conv_weight(op[6].weight, 1, 32, 1))
+        s2, b2 = _bn_scale_shift(op[7], self._packs, 'bn2')
+        return ops.conv2d([t], w2, 1, 1, scale=s2, shift=b2, res=res)
+
+
+class eca_layer(nn.Module):
+    """operations_m.py:340-367 (parameter holder for the Conv1d over channels; the arithmetic is fused
+    into ECABasicBlock's kernels)."""
+
+    def __init__(self, channel, c_out, stride, k_size=3):
+        super().__init__()
+        self.k_size = k_size
+        self.conv = Conv1dParams(1, 1, kernel_size=k_size, padding=(k_size - 1) // 2, bias=False)
+
+    def forward(self, x):
+        raise NotImplementedError("eca_layer runs fused inside ECABasicBlock (conv2 epilogue pool + eca_finish kernel)")
+
+
+class ECABasicBlock(_HipOp):
+    """operations_m.py:368-393: r=conv3x3(x); o=BasicConv_k(PReLU(r)); o=o*sigmoid(conv1d(avgpool o)); PReLU(o+r).
+    The residual is conv1's output, not the block input."""
+
+    def __init__(self, inplanes, planes, kernel=3, dilation=1, stride=1, reduction=64, with_norm=False):
+        super().__init__()
+        if with_norm:
+            raise NotImplementedError("ECABasicBlock(with_norm=True) is never constructed by the reference")
+        self.with_norm = with_norm
+        self.k = kernel
+        self.conv1 = conv3x3(inplanes, planes, stride)
+        self.conv2 = BasicConv(inplanes, inplanes, kernel, relu=False)
+        self.se = eca_layer(planes, planes, stride, k_size=kernel)
+        self.relu = PReLUParams()
+
+    def forward_nhwc(self, x, res=()):
+        a = self.relu.weight
+        w1 = self._packs.get("w1", [self.conv1.weight], lambda: ops.pack_conv_weight(self.conv1.weight, 1, 32, 3))
+        r = ops.conv2d([x], w1, 3, 1)
+        o, partial = ops.conv2d([r], self.conv2.wpk(1, 32), self.k, 1, in_act=ops.ACT_PRELU, in_prelu=a, pool=True)
+        out = ops.eca_finish(o, r, partial, self.se.conv.weight, self.k, a)
+        return self._add_res(out, res)
+
+
+class Spatial_BasicBlock(_HipOp):
+    """operations_m.py:179-204 (SPAattention): in the search space, not in the shipped genotype.
+    Constructible (state_dict parity); its fused kernels are a SURVEY.md 8(f) rank-1 follow-up."""
+
+    def __init__(self, inplanes, planes, kernel=3, dilation=1, stride=1, reduction=64, with_norm=False):
+        super().__init__()
+        self.k = kernel
+        self.conv1 = conv3x3(inplanes, planes, stride)
+        self.conv2 = BasicConv(inplanes, inplanes, kernel, relu=False)
+        self.se = spatial_attn_layer(kernel)
+        self.relu = PReLUParams()
+
+    def forward_nhwc(self, x, res=()):
+        raise NotImplementedError("SPAattention HIP kernels are not built yet (SURVEY.md 8(f) rank 1)")
+
+
+class ChannelPool(nn.Module):
+    """operations_m.py:148-150 (1-argument form, only inside spatial_attn_layer)."""
+
+    def forward(self, x):
+        raise NotImplementedError("ChannelPool(1-arg) is only reachable through SPAattention (not built yet)")
+
+
+class spatial_attn_layer(nn.Module):
+    """operations_m.py:153-164 (parameter holder)."""
+
+    def __init__(self, kernel_size=5):
+        super().__init__()
+        self.compress = ChannelPool()
+        self.spatial = BasicConv(2, 1, kernel_size, relu=False)
+
+    def forward(self, x):
+        raise NotImplementedError("spatial_attn_layer is only reachable through SPAattention (not built yet)")
+
+
+def _selfpath(*a, **k):
+    raise NotImplementedError("SelAttention/SelfPath is unreachable from MixedOp in the reference (SURVEY.md 8(a) F4)")
+
+
+# operations_m.py:9-18
+OPS = {
+    'Denseblocks': lambda C, kernel, dialtion, affine: ResidualDenseBlock(C, kernel, dialtion),
+    'Residualblocks': lambda C, kernel, dialtion, affine: ResidualModule(C, kernel, dialtion),
+    'ECAattention': lambda C, kernel, dialtion, affine: ECABasicBlock(C, C, kernel, dialtion),
+    'SPAattention': lambda C, kernel, dialtion, affine: Spatial_BasicBlock(C, C, kernel, dialtion),
+    'DilConv': lambda C, kernel, dialtion, affine: DilConv(C, C, kernel, dialtion),
+    'SepConv': lambda C, kernel, dialtion, affine: SepConv(C, C, kernel, 1, kernel // 2),
+    'SelAttention': lambda C, kernel, dialtion, affine: _selfpath(),
+}

@@ -1,0 +1,228 @@
+"""Thin host wrappers: torch CUDA tensors -> raw pointers -> libpaif_hip.so (include/paif_hip.h).
+
+torch is used for device memory (caching allocator) and the current HIP stream only; every
+arithmetic op runs in a hand-written gfx950 kernel.  Internal activation layout is NHWC
+([B,H,W,C] contiguous float32).  `to_nhwc` / `to_nchw_view` convert at the module boundary:
+an NHWC tensor viewed as [B,C,H,W] is exactly torch's channels_last format, so the reference's
+NCHW operator API is kept without copies between our own ops.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_PRELU, ACT_RELU = 0, 1, 2
+
+
+def lib():
+    return _lib.load()
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    """Device pointer of a dense float32 CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("paif_amd ops need CUDA(HIP) tensors; got a %s tensor -- there is no CPU path" % t.device)
+    if t.dtype != torch.float32:
+        raise TypeError("expected float32, got %s" % t.dtype)
+    if not t.is_contiguous():
+        raise RuntimeError("expected a dense (contiguous) tensor, got strides %s for shape %s" % (t.stride(), tuple(t.shape)))
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def require_no_grad(*tensors):
+    """Round-1 scope: forward kernels only.  Fail loudly rather than silently dropping gradients."""
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        raise NotImplementedError(
+            "paif_amd: backward (input-gradient) HIP kernels are not built yet; run under torch.no_grad(). "
+            "There is deliberately no autograd/eager fallback.")
+
+
+def to_nhwc(x):
+    """[B,C,H,W] (any strides) -> dense [B,H,W,C]; free when x is already channels_last."""
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def to_nchw_view(x):
+    """dense [B,H,W,C] -> [B,C,H,W] view (channels_last strides), no copy."""
+    return x.permute(0, 3, 1, 2)
+
+
+# ---------------------------------------------------------------------------------------------
+# colour / glue
+# ---------------------------------------------------------------------------------------------
+def rgb2ycrcb(rgb):
+    rgb = rgb.contiguous()
+    B, C, H, W = rgb.shape
+    assert C == 3
+    out = torch.empty_like(rgb)
+    _lib.check(lib().paif_rgb2ycrcb_fwd(_p(rgb), _p(out), B, H, W, _stream()), "rgb2ycrcb")
+    return out
+
+
+def seg_input_from_fused(fused, ycc, return_minmax=False):
+    """fused [B,1,H,W], ycc [B,3,H,W] -> normalised SegFormer input [B,3,H,W] (batch-global min-max)."""
+    fused = fused.contiguous()
+    ycc = ycc.contiguous()
+    B, _, H, W = ycc.shape
+    L = lib()
+    nblk = L.paif_minmax_blocks(B, H, W)
+    partial = torch.empty(2 * nblk, device=ycc.device, dtype=torch.float32)
+    rgb = torch.empty_like(ycc)
+    _lib.check(L.paif_recompose_clamp_fwd(_p(fused), _p(ycc), _p(rgb), _p(partial), B, H, W, _stream()), "recompose_clamp")
+    mm = torch.empty(2, device=ycc.device, dtype=torch.float32)
+    _lib.check(L.paif_minmax_normalize_fwd(_p(rgb), _p(partial), nblk, _p(rgb), _p(mm), B, H, W, _stream()),
+               "minmax_normalize")
+    return (rgb, mm) if return_minmax else rgb
+
+
+# ---------------------------------------------------------------------------------------------
+# fusion network pieces (all NHWC)
+# ---------------------------------------------------------------------------------------------
+def stem(img, w, prelu, want_guide=True):
+    """img: [B,1,H,W] or a channel-0 view of [B,C,H,W] (dense planes, arbitrary batch stride)."""
+    B, _, H, W = img.shape
+    if img.stride(3) != 1 or img.stride(2) != W:
+        img = img.contiguous()
+    bstride = img.stride(0) if B > 1 else H * W
+    feat = torch.empty((B, H, W, 32), device=img.device, dtype=torch.float32)
+    guide = torch.empty((B, H, W), device=img.device, dtype=torch.float32) if want_guide else None
+    if img.dtype != torch.float32 or not img.is_cuda:
+        raise RuntimeError("stem: need a float32 CUDA tensor")
+    _lib.check(lib().paif_stem_fwd(ctypes.c_void_p(img.data_ptr()), bstride, _p(w), _p(prelu), _p(feat), _p(guide),
+                                   B, H, W, _stream()), "stem")
+    return feat, guide
+
+
+def channel_residue(x):
+    B, H, W, C = x.shape
+    assert C == 32
+    g = torch.empty((B, H, W), device=x.device, dtype=torch.float32)
+    _lib.check(lib().paif_channel_residue_fwd(_p(x), _p(g), B, H, W, _stream()), "channel_residue")
+    return g
+
+
+def guided_filter_pair(guide, y, eps=(0.001, 0.0001)):
+    """Returns lf [2,B,H,W,32] for the two eps (r = 4).  AssertionError if H or W <= 9, like the
+    reference's guided_filter_pytorch."""
+    B, H, W, C = y.shape
+    assert C == 32
+    assert H > 9 and W > 9, "guided filter needs H, W > 2r+1 = 9"
+    ab = torch.empty((4, B, H, W, 32), device=y.device, dtype=torch.float32)
+    lf = torch.empty((2, B, H, W, 32), device=y.device, dtype=torch.float32)
+    L = lib()
+    _lib.check(L.paif_guided_filter_ab_fwd(_p(guide), _p(y), _p(ab), eps[0], eps[1], B, H, W, _stream()), "guided_filter_ab")
+    _lib.check(L.paif_guided_filter_lf_fwd(_p(guide), _p(ab), _p(lf), B, H, W, _stream()), "guided_filter_lf")
+    return lf
+
+
+def pack_conv_weight(w, nsrc, cin, kh):
+    """w: [cout, nsrc*cin, kh, kh] -> packed MFMA B-operand stream."""
+    cout = w.shape[0]
+    assert tuple(w.shape) == (cout, nsrc * cin, kh, kh), (tuple(w.shape), nsrc, cin, kh)
+    L = lib()
+    wpk = torch.empty(L.paif_conv_wpk_floats(nsrc, cin, kh), device=w.device, dtype=torch.float32)
+    _lib.check(L.paif_pack_conv_weight(_p(w.detach().contiguous()), _p(wpk), cout, nsrc, cin, kh, _stream()), "pack_conv_weight")
+    return wpk
+
+
+def pack_decomp1x1_weight(w):
+    assert tuple(w.shape) == (32, 128, 1, 1)
+    L = lib()
+    wpk = torch.empty(L.paif_conv_wpk_floats(3, 32, 1), device=w.device, dtype=torch.float32)
+    _lib.check(L.paif_pack_decomp1x1_weight(_p(w.detach().contiguous()), _p(wpk), _stream()), "pack_decomp1x1_weight")
+    return wpk
+
+
+def bn_fold(weight, bias, mean, var, eps):
+    C = weight.shape[0]
+    scale = torch.empty(C, device=weight.device, dtype=torch.float32)
+    shift = torch.empty(C, device=weight.device, dtype=torch.float32)
+    _lib.check(lib().paif_bn_fold(_p(weight.detach()), _p(bias.detach()), _p(mean), _p(var), eps, _p(scale), _p(shift), C, _stream()),
+               "bn_fold")
+    return scale, shift
+
+
+def conv2d(srcs, wpk, kh, dil=1, cin=32, cout=32, in_act=ACT_NONE, in_prelu=None, scale=None, shift=None,
+           act=ACT_NONE, prelu=None, alpha=1.0, res=(), pool=False):
+    """Dense conv over the virtual concat of `srcs` (NHWC).  Returns out (and the per-tile pool partials)."""
+    B, H, W, C = srcs[0].shape
+    assert C == cin and 1 <= len(srcs) <= 3
+    res = [r for r in res if r is not None]
+    extra = res[3:]
+    res = res[:3]
+    out = torch.empty((B, H, W, cout), device=srcs[0].device, dtype=torch.float32)
+    L = lib()
+    d = _lib.ConvDesc()
+    for i in range(3):
+        d.src[i] = _p(srcs[i]) if i < len(srcs) else None
+        d.res[i] = _p(res[i]) if i < len(res) else None
+    for r in res:
+        assert tuple(r.shape) == (B, H, W, cout)
+    d.nsrc, d.cin, d.wpk, d.kh, d.dil = len(srcs), cin, _p(wpk), kh, dil
+    d.in_act, d.in_prelu = in_act, _p(in_prelu)
+    d.scale, d.shift = _p(scale), _p(shift)
+    d.act, d.prelu, d.alpha = act, _p(prelu), alpha
+    d.out, d.cout = _p(out), cout
+    partial = None
+    if pool:
+        partial = torch.empty((L.paif_conv2d_blocks(B, H, W), 32), device=out.device, dtype=torch.float32)
+    d.pool_partial = _p(partial)
+    _lib.check(L.paif_conv2d_fwd(ctypes.byref(d), B, H, W, _stream()), "conv2d")
+    for r in extra:  # more than 3 fused residuals: plain adds
+        out = add(out, r)
+    return (out, partial) if pool else out
+
+
+def dwconv(x, w, k, dil, in_relu):
+    B, H, W, C = x.shape
+    assert C == 32
+    out = torch.empty_like(x)
+    _lib.check(lib().paif_dwconv_fwd(_p(x), _p(w.detach().contiguous()), _p(out), k, dil, int(in_relu), B, H, W, _stream()), "dwconv")
+    return out
+
+
+def channel_pool2(ir, vis):
+    B, H, W, _ = ir.shape
+    comp = torch.empty((B, H, W, 4), device=ir.device, dtype=torch.float32)
+    _lib.check(lib().paif_channel_pool2_fwd(_p(ir), _p(vis), _p(comp), B, H, W, _stream()), "channel_pool2")
+    return comp
+
+
+def spa_blend(comp, w, ir, vis, want_scale=False):
+    B, H, W, _ = ir.shape
+    agg = torch.empty_like(ir)
+    scale = torch.empty((B, H, W), device=ir.device, dtype=torch.float32) if want_scale else None
+    _lib.check(lib().paif_spa_blend_fwd(_p(comp), _p(w.detach().contiguous()), _p(ir), _p(vis), _p(agg), _p(scale), B, H, W, _stream()),
+               "spa_blend")
+    return (agg, scale) if want_scale else agg
+
+
+def eca_finish(o, r, partial, w1d, k, prelu):
+    B, H, W, _ = o.shape
+    out = torch.empty_like(o)
+    gate = torch.empty((B, 32), device=o.device, dtype=torch.float32)
+    _lib.check(lib().paif_eca_finish_fwd(_p(o), _p(r), _p(partial), _p(w1d.detach().contiguous()), k, _p(prelu), _p(gate), _p(out),
+                                         B, H, W, _stream()), "eca_finish")
+    return out
+
+
+def tail(x16, w, prelu):
+    B, H, W, C = x16.shape
+    assert C == 16
+    fused = torch.empty((B, 1, H, W), device=x16.device, dtype=torch.float32)
+    _lib.check(lib().paif_tail_fwd(_p(x16), _p(w.detach().contiguous()), _p(prelu), _p(fused), B, H, W, _stream()), "tail")
+    return fused
+
+
+def add(a, b):
+    assert a.shape == b.shape
+    out = torch.empty_like(a)
+    _lib.check(lib().paif_add_fwd(_p(a), _p(b), _p(out), a.numel(), _stream()), "add")
+    return out

@@ -1,0 +1,163 @@
+"""GPU parity tests (through the C ABI): fusion-network kernels vs the golden vectors captured from the
+reference and vs the CPU oracle on the same seeded inputs.
+
+Tolerances (fp32 kernels): max-abs <= 1e-4 on fused / O(1) activations relative to the
+tensor's scale; guided-filter LF <= 2e-4 (the reference's own fp32-vs-fp64 floor on LF is ~1e-4: its
+cumsum box filter is LESS accurate than the direct window sums used here)."""
+import numpy as np
+import pytest
+import torch
+
+from paif_amd import synthetic as S
+from tests import helpers as Hh
+from tests.helpers import t, maxabs
+
+pytestmark = pytest.mark.gpu
+
+HIP_PRIMS = [p for p in Hh.PRIMITIVES if not p.startswith("SPAattention")]
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _scale(a):
+    return max(1.0, float(np.abs(a).max()))
+
+
+@pytest.mark.parametrize("prim", HIP_PRIMS)
+def test_primitive_forward(golden, prim):
+    from paif_amd.core.model_fusion_auto import MixedOp
+
+    g = golden("ga_primitives")
+    op = MixedOp(32, prim).eval()
+    S.load_formula_weights(op, salt=Hh.PRIMITIVES.index(prim) + 1)
+    op = op.to(_dev())
+    x = t(S.make_smooth_feature(11, 1, 32, 24, 32)).to(_dev())
+    with torch.no_grad():
+        y = op(x)
+    assert tuple(y.shape) == (1, 32, 24, 32)
+    assert maxabs(y.cpu(), g[prim + ".y"]) <= 1e-4 * _scale(g[prim + ".y"])
+
+
+def test_primitive_vs_oracle_ragged_size():
+    """Edge tiles: H, W not multiples of the 8x32 conv tile; compared with the CPU oracle."""
+    from oracle import paif_oracle as O
+    from paif_amd.core.model_fusion_auto import MixedOp
+    from tests.test_oracle_golden import op_sd
+
+    x = t(S.make_smooth_feature(77, 2, 32, 21, 45))
+    for prim in ("Denseblocks_3_1", "Residualblocks_7_1", "DilConv_3_2", "ECAattention_3"):
+        op = MixedOp(32, prim).eval()
+        S.load_formula_weights(op, salt=Hh.PRIMITIVES.index(prim) + 1)
+        with torch.no_grad():
+            y = op.to(_dev())(x.to(_dev())).cpu()
+            ref = O.mixed_op(x, op_sd(prim), "", prim)
+        assert maxabs(y, ref) <= 1e-4 * _scale(ref.numpy()), prim
+
+
+def test_guided_filter(golden):
+    from paif_amd import ops
+
+    g = golden("gb_guided_filter")
+    y = t(S.make_smooth_feature(21, 1, 32, 24, 32)).to(_dev())
+    ynhwc = ops.to_nhwc(y)
+    guide = ops.channel_residue(ynhwc)
+    lf = ops.guided_filter_pair(guide, ynhwc)
+    for i, eps in enumerate((1e-3, 1e-4)):
+        mine = lf[i].permute(0, 3, 1, 2).cpu()
+        # vs the reference's fp32 run AND vs its fp64 run (we must be at least as close to fp64 as it is)
+        assert maxabs(mine, g["lf_eps%g" % eps]) <= 2e-4
+        floor = maxabs(g["lf_eps%g" % eps], g["lf64_eps%g" % eps])
+        assert maxabs(mine, g["lf64_eps%g" % eps]) <= max(2.0 * floor, 2e-5)
+    with pytest.raises(AssertionError):
+        ops.guided_filter_pair(torch.zeros(1, 9, 20, device=_dev()), torch.zeros(1, 9, 20, 32, device=_dev()))
+
+
+def _fusion_net():
+    from oracle.paif_oracle import FUSION_AT
+    from paif_amd.core.model_fusion_auto import Network_Fusion_Searched
+
+    net = Network_Fusion_Searched(32, None, FUSION_AT).eval()
+    S.load_formula_weights(net)
+    return net.to(_dev())
+
+
+def test_fusion_state_dict_layout():
+    net = _fusion_net()
+    want = {k[len("enhance_net."):]: v for k, v in Hh.layout("mit_b0").items() if k.startswith("enhance_net.")}
+    got = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert got == want
+
+
+def test_fusion_net_intermediates(golden):
+    from paif_amd import ops
+
+    g = golden("gc_fusion_48x64")
+    net = _fusion_net()
+    ir, vis, _ = S.make_batch(1, 48, 64)
+    ycc = ops.rgb2ycrcb(t(vis).to(_dev()))
+    inter = {}
+    with torch.no_grad():
+        fused = net(t(ir).to(_dev()), ycc[:, 0:1], inter=inter)
+    for k in ("fir", "ir_feature", "vis_feature", "feature2"):
+        got = inter[k].permute(0, 3, 1, 2).cpu()
+        assert maxabs(got, g[k]) <= 1e-4 * _scale(g[k]), k
+    assert maxabs(fused.cpu(), g["fused"]) <= 1e-4
+
+
+def test_fusion_net_b2(golden):
+    from paif_amd import ops
+
+    g = golden("gc_fusion_2x64x96")
+    net = _fusion_net()
+    ir, vis, _ = S.make_batch(2, 64, 96)
+    ycc = ops.rgb2ycrcb(t(vis).to(_dev()))
+    with torch.no_grad():
+        fused = net(t(ir).to(_dev()), ycc)  # 3-channel input: forward slices channel 0 itself (:626-627)
+    assert maxabs(fused.cpu(), g["fused"]) <= 1e-4
+
+
+def test_colour_glue_and_batch_coupling(golden):
+    from paif_amd import ops
+
+    g = golden("gd_colour_glue")
+    net = _fusion_net()
+    ir, vis, _ = S.make_batch(2, 64, 96)
+    ycc = ops.rgb2ycrcb(t(vis).to(_dev()))
+    assert maxabs(ycc.cpu(), g["ycc"]) <= 1e-6
+    for B, key in ((2, "b2"), (1, "b1")):
+        with torch.no_grad():
+            fused = net(t(ir[:B]).to(_dev()), ycc[:B].contiguous())
+            seg_in = ops.seg_input_from_fused(fused, ycc[:B].contiguous())
+        assert maxabs(seg_in.cpu(), g["seg_in_" + key]) <= 5e-4  # |values| up to ~2.6; x255/std amplifies 1e-4 by ~4.4
+
+
+def test_fusion_full_size_480x640(golden):
+    """BASELINE config-2 shape (one pair): fused image against the reference's own output."""
+    from paif_amd import ops
+
+    g = golden("gf_model_b3_1x480x640")
+    net = _fusion_net()
+    ir, vis, _ = S.make_batch(1, 480, 640)
+    ycc = ops.rgb2ycrcb(t(vis).to(_dev()))
+    with torch.no_grad():
+        fused = net(t(ir).to(_dev()), ycc)
+    assert maxabs(fused.cpu(), g["fused"]) <= 1e-4
+
+
+def test_requires_grad_fails_loudly():
+    net = _fusion_net()
+    x = torch.zeros(1, 1, 16, 32, device=_dev(), requires_grad=True)
+    with pytest.raises(NotImplementedError):
+        net(x, x)
+
+
+def test_unknown_and_malformed_primitives():
+    from paif_amd.core.model_fusion_auto import MixedOp
+
+    with pytest.raises(KeyError):
+        MixedOp(32, "Nope_3_1")
+    with pytest.raises(IndexError):
+        MixedOp(32, "DilConv_3")
