@@ -185,8 +185,16 @@ def main():
         f, s = m3(t(ir), t(vis))
         up = torch.nn.functional.interpolate(s, size=lab.shape[1:], mode="bilinear", align_corners=False)
         pred = up.argmax(1)
+    # the same pair through the reference in float64: documents the reference's own fp32 noise floor at
+    # full size (its cumsum box filter loses ~1e-4..1e-3 towards the far image edges)
+    m3.double()
+    torch.set_default_dtype(torch.float64)  # YCrCb2RGB builds its matrix with torch.tensor(...) (:96-100)
+    with torch.no_grad():
+        f64, s64 = m3(t(ir).double(), t(vis).double())
+    torch.set_default_dtype(torch.float32)
+    m3.float()
     save("gf_model_b3_1x480x640", fused=npy(f).astype(np.float32), logits=npy(s),
-         pred=npy(pred).astype(np.uint8))
+         pred=npy(pred).astype(np.uint8), fused64=npy(f64).astype(np.float32), logits64=npy(s64).astype(np.float32))
 
     # ---- G-g: attack_both (3 iters, mit_b0, 2 x 64x96), PGD / segPGD / cosPGD ------------------
     ir, vis, lab = S.make_batch(2, 64, 96)

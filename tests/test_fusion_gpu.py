@@ -75,12 +75,15 @@ def test_guided_filter(golden):
         ops.guided_filter_pair(torch.zeros(1, 9, 20, device=_dev()), torch.zeros(1, 9, 20, 32, device=_dev()))
 
 
-def _fusion_net():
+def _fusion_net(prefix=""):
+    """prefix='enhance_net.' gives the weights the fusion net has INSIDE the composite model's goldens
+    (the formula is keyed on the full state_dict key)."""
     from oracle.paif_oracle import FUSION_AT
     from paif_amd.core.model_fusion_auto import Network_Fusion_Searched
 
     net = Network_Fusion_Searched(32, None, FUSION_AT).eval()
-    S.load_formula_weights(net)
+    sd = {k: t(S.formula_tensor(prefix + k, tuple(v.shape))).to(v.dtype) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd, strict=True)
     return net.to(_dev())
 
 
@@ -123,7 +126,7 @@ def test_colour_glue_and_batch_coupling(golden):
     from paif_amd import ops
 
     g = golden("gd_colour_glue")
-    net = _fusion_net()
+    net = _fusion_net("enhance_net.")
     ir, vis, _ = S.make_batch(2, 64, 96)
     ycc = ops.rgb2ycrcb(t(vis).to(_dev()))
     assert maxabs(ycc.cpu(), g["ycc"]) <= 1e-6
@@ -139,12 +142,18 @@ def test_fusion_full_size_480x640(golden):
     from paif_amd import ops
 
     g = golden("gf_model_b3_1x480x640")
-    net = _fusion_net()
+    net = _fusion_net("enhance_net.")
     ir, vis, _ = S.make_batch(1, 480, 640)
     ycc = ops.rgb2ycrcb(t(vis).to(_dev()))
     with torch.no_grad():
         fused = net(t(ir).to(_dev()), ycc)
-    assert maxabs(fused.cpu(), g["fused"]) <= 1e-4
+    # At full size the reference's OWN fp32 run is ~1e-4 away from its fp64 run (cumsum box filter error
+    # grows towards the far image edges).  The HIP path (direct window sums) must be (a) at least as
+    # close to the fp64 result as the reference's fp32 run is, and (b) within 2x that floor of the fp32 run.
+    floor = maxabs(g["fused"], g["fused64"])
+    assert floor < 5e-4
+    assert maxabs(fused.cpu(), g["fused64"]) <= max(floor, 2e-5)
+    assert maxabs(fused.cpu(), g["fused"]) <= 2.0 * floor + 2e-5
 
 
 def test_requires_grad_fails_loudly():
