@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""bench.py -- fused image-pairs/sec at 480x640, bs=8 per GPU (BASELINE.json metric).
+
+Workload (BASELINE.json configs[1]): the fusion-network forward pass -- RGB2YCrCb + Network_Fusion_Searched
+(= Network_MM_SearchedFusion.forward_fusion, reference core/model_fusion_auto.py:1157-1160) -- on a batch of
+8 synthetic 480x640 IR/visible pairs per GPU, inputs resident in HBM, hand-written gfx950 kernels through
+the C ABI.  One process per GPU; replicas only (no data-path collective: the path is per-sample).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement): value = whole-job pairs/s, plus
+  roofline     -- dominant kernel (3x3 fp32-MFMA conv), HIP-event timed on its launch stream inside the timed region
+  cpu_baseline -- the CPU oracle (torch fp32 port of the reference) on the host cores, bounded sample, rank 0, N=1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+H, W, B_PER_GPU = 480, 640, 8
+MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: "Peak FP32 (matrix) 157.3 TFLOPS"
+DOMINANT = "conv_mfma_f32<3,1,32>"  # 3x3 dense convs: 76 % of the fusion FLOPs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)  # RCCL; used for the barrier + max-over-ranks only
+
+    from oracle.paif_oracle import FUSION_AT  # genotype constant only (test infrastructure is not on the timed path)
+    from paif_amd import ops, synthetic as S
+    from paif_amd.core.model_fusion_auto import Network_Fusion_Searched
+
+    net = Network_Fusion_Searched(32, None, FUSION_AT).eval()
+    S.load_formula_weights(net)          # formula weights: no checkpoint exists (reference README.md:34-37)
+    net = net.to(dev)
+    ir_np, vis_np, _ = S.make_batch(B_PER_GPU, H, W, start=rank * B_PER_GPU)   # this rank's shard
+    ir = torch.from_numpy(ir_np).to(dev)
+    vis = torch.from_numpy(vis_np).to(dev)
+
+    def step():
+        with torch.no_grad():
+            ycc = ops.rgb2ycrcb(vis)
+            return net(ir, ycc)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    timer = ops.KernelTimer(lambda tag: tag == DOMINANT)
+    barrier()
+    ops.TIMER = timer
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.TIMER = None
+    assert torch.isfinite(out).all()
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        pairs = B_PER_GPU * world * args.steps
+        n, ms, flops, nbytes = timer.summary()[DOMINANT]
+        achieved = flops / (ms * 1e-3) / 1e12
+        res = {
+            "metric": "fused image-pairs/sec at 480x640 bs=8 per GPU (fusion-net forward)",
+            "value": pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: fusion-net forward (RGB2YCrCb + Network_Fusion_Searched, C=32, shipped genotype), "
+                                   "480x640, bs=8/GPU, fp32 storage + fp32 MFMA", "batch_per_gpu": B_PER_GPU,
+                       "parallelism": "replicas x%d (no data-path collective)" % world},
+            "roofline": {"kernel": DOMINANT, "bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                         "launches": n, "avg_launch_ms": ms / n, "algorithmic_gflop_per_launch": flops / n / 1e9,
+                         "algorithmic_mb_per_launch": nbytes / n / 1e6},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(ir_np, vis_np)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def host_cores():
+    """CPUs this process may actually use: min(affinity mask, cgroup cpu.max quota).  (The GPU box shows
+    256 logical CPUs but runs the job under a 16-CPU cgroup quota; 256 threads there thrash.)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(ir_np, vis_np):
+    """The CPU oracle (fp32 torch port of the reference's path) on the host cores: same workload, bounded
+    sample = 1 pair per forward, 1 warm-up + 3 timed forwards (~10-20 s)."""
+    from oracle import paif_oracle as O
+    from paif_amd import synthetic as S
+    from paif_amd.core.model_fusion_auto import Network_Fusion_Searched
+
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    net = Network_Fusion_Searched(32, None, O.FUSION_AT)
+    S.load_formula_weights(net)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    ir, vis = torch.from_numpy(ir_np[:1]), torch.from_numpy(vis_np[:1])
+
+    def fwd():
+        with torch.no_grad():
+            ycc = O.rgb2ycrcb(vis)
+            return O.fusion_forward(ir, ycc[:, 0:1], sd)
+
+    fwd()
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        fwd()
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": 1.0 / dt, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle fusion forward, B=1 480x640 fp32, 1 warm-up + %d timed forwards, torch %s CPU" % (reps, torch.__version__)}
+
+
+if __name__ == "__main__":
+    main()

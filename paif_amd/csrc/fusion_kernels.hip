@@ -218,19 +218,26 @@ __global__ __launch_bounds__(256) void spa_blend_kernel(const float* __restrict_
 // ECA tail: mean over HxW from the conv's per-tile partials -> conv1d(k) over channels -> sigmoid
 //           -> out = PReLU(o * s[c] + r)
 // ---------------------------------------------------------------------------------------------
-__global__ void eca_scale_kernel(const float* __restrict__ partial, const float* __restrict__ w1d, int k, int tiles_per_img,
-                                 float inv_hw, float* __restrict__ s_out) {
-  // one block (64 threads) per image; thread c < 32 reduces its channel in tile order (deterministic)
+__global__ __launch_bounds__(1024) void eca_scale_kernel(const float* __restrict__ partial, const float* __restrict__ w1d, int k,
+                                                         int tiles_per_img, float inv_hw, float* __restrict__ s_out) {
+  // one block per image: thread (part = tid>>5, c = tid&31) sums tiles part, part+32, ... then the 32 parts
+  // are added in a fixed order -> deterministic (no float atomics)
+  __shared__ float part_sum[32][32];
   __shared__ float mean[32];
-  const int b = blockIdx.x, c = threadIdx.x;
-  if (c < 32) {
-    float s = 0.f;
-    const float* p = partial + (size_t)b * tiles_per_img * 32 + c;
-    for (int t = 0; t < tiles_per_img; ++t) s += p[(size_t)t * 32];
-    mean[c] = s * inv_hw;
+  const int b = blockIdx.x, c = threadIdx.x & 31, part = threadIdx.x >> 5;
+  float s = 0.f;
+  const float* p = partial + (size_t)b * tiles_per_img * 32 + c;
+  for (int t = part; t < tiles_per_img; t += 32) s += p[(size_t)t * 32];
+  part_sum[part][c] = s;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) tot += part_sum[i][c];
+    mean[c] = tot * inv_hw;
   }
   __syncthreads();
-  if (c < 32) {
+  if (threadIdx.x < 32) {
     float y = 0.f;
     const int pad = (k - 1) / 2;
     for (int j = 0; j < k; ++j) {
@@ -470,7 +477,7 @@ int paif_eca_finish_fwd(const float* o, const float* r, const float* pool_partia
   hipStream_t st = paif::as_stream(stream);
   const int tiles_per_img = paif_conv2d_blocks(1, H, W);
   float* s = gate;
-  hipLaunchKernelGGL(eca_scale_kernel, dim3(B), dim3(64), 0, st, pool_partial, w1d, k, tiles_per_img,
+  hipLaunchKernelGGL(eca_scale_kernel, dim3(B), dim3(1024), 0, st, pool_partial, w1d, k, tiles_per_img,
                      1.0f / ((float)H * (float)W), s);
   PAIF_LAUNCH_CHECK("eca_scale");
   const size_t npix = (size_t)B * H * W;

@@ -19,6 +19,40 @@ def lib():
     return _lib.load()
 
 
+class KernelTimer:
+    """HIP-event timing of selected kernel launches on the CURRENT stream (the stream every paif_amd
+    kernel is launched on).  Used by bench.py for the live roofline figure; off by default."""
+
+    def __init__(self, match):
+        self.match = match          # predicate on the kernel tag
+        self.records = []           # (tag, start_event, end_event, flops, bytes)
+
+    def start(self, tag):
+        if not self.match(tag):
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def stop(self, tag, e0, flops, nbytes):
+        if e0 is None:
+            return
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.records.append((tag, e0, e1, flops, nbytes))
+
+    def summary(self):
+        """-> dict tag -> (launches, total_ms, total_flops, total_bytes); call after a synchronize."""
+        out = {}
+        for tag, e0, e1, fl, nb in self.records:
+            n, ms, f, b = out.get(tag, (0, 0.0, 0, 0))
+            out[tag] = (n + 1, ms + e0.elapsed_time(e1), f + fl, b + nb)
+        return out
+
+
+TIMER = None  # set to a KernelTimer to instrument launches
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -174,7 +208,13 @@ def conv2d(srcs, wpk, kh, dil=1, cin=32, cout=32, in_act=ACT_NONE, in_prelu=None
     if pool:
         partial = torch.empty((L.paif_conv2d_blocks(B, H, W), 32), device=out.device, dtype=torch.float32)
     d.pool_partial = _p(partial)
+    tag = "conv_mfma_f32<%d,%d,%d>" % (kh, dil, cin)
+    e0 = TIMER.start(tag) if TIMER is not None else None
     _lib.check(L.paif_conv2d_fwd(ctypes.byref(d), B, H, W, _stream()), "conv2d")
+    if e0 is not None:
+        px = B * H * W
+        # algorithmic work: 2*K*cout FLOP per output pixel; each source map read once, output written once
+        TIMER.stop(tag, e0, 2 * px * kh * kh * cin * len(srcs) * cout, 4 * px * (cin * len(srcs) + cout * (1 + len(res))))
     for r in extra:  # more than 3 fused residuals: plain adds
         out = add(out, r)
     return (out, partial) if pool else out
