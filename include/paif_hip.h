@@ -150,6 +150,53 @@ int paif_tail_fwd(const float* x, const float* w, const float* prelu, float* fus
 /* plain elementwise a + b (Cell_Chain's residual when it cannot be fused, :445); n floats. */
 int paif_add_fwd(const float* a, const float* b, float* out, size_t n, paif_stream_t stream);
 
+
+/* ---------------------------------------------------------------------------------------------
+ * Segmentation network: MixTransformer encoder + SegFormer head (core/mix_transformer.py,
+ * core/segformer_head.py).  Token tensors [B,N,C] (N = H*W row-major) are NHWC images.
+ * ------------------------------------------------------------------------------------------- */
+
+/* C[M,N] = act( (A[M,K] . W[N,K]^T) * scale[n] + shift[n] ) + res[M,N]  -- fp32 MFMA GEMM.
+ * nn.Linear (core/mix_transformer.py:22-25,66-69; core/segformer_head.py:19), the 1x1 convs of the head
+ * (core/segformer_head.py:50-57; scale/shift = folded BatchNorm or bias) and every strided conv after
+ * paif_im2col_fwd (OverlapPatchEmbed.proj core/mix_transformer.py:168, Attention.sr :74).
+ * lda/ldc/ldres: row strides in floats; K % 32 == 0; scale/shift/res may be NULL;
+ * act: 0 none, 1 GELU (erf), 2 ReLU. */
+int paif_gemm_fwd(const float* A, int lda, const float* W, const float* scale, const float* shift, int act,
+                  const float* res, int ldres, float* C, int ldc, int M, int N, int K, paif_stream_t stream);
+
+/* nn.LayerNorm over the last dim (core/mix_transformer.py:75,122,127,172,232-253). x,y [M,C]; C % 4 == 0. */
+int paif_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, int M, int C, float eps,
+                       paif_stream_t stream);
+
+/* im2col of an NHWC [B,H,W,Cin] map for a k x k conv with stride/pad: col [B*OH*OW, Kpad],
+ * column index (ky*k + kx)*Cin + c, zero padded up to Kpad; OH = (H + 2*pad - k)/stride + 1. */
+int paif_im2col_fwd(const float* x, float* col, int B, int H, int W, int Cin, int k, int stride, int pad, int Kpad,
+                    paif_stream_t stream);
+/* conv weight [Cout,Cin,k,k] -> GEMM weight [Cout,Kpad] in the im2col column order. */
+int paif_pack_conv_gemm_weight(const float* w, float* out, int Cout, int Cin, int k, int Kpad, paif_stream_t stream);
+
+/* Mlp: DWConv (3x3 depthwise, bias) + GELU on NHWC tokens (core/mix_transformer.py:48-49,376-387).
+ * x,y [B,H,W,C]; w [C,1,3,3]; bias [C]; C % 4 == 0. */
+int paif_dwconv3_bias_gelu_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int C,
+                               paif_stream_t stream);
+
+/* Attention (core/mix_transformer.py:93-115) after the q / kv linears: q [B,N,C], kv [B,Nk,2C]
+ * (k = channels [0,C), v = [C,2C), head hd at offset hd*(C/heads)), out [B,N,C];
+ * softmax(q k^T * (C/heads)^-0.5) v per head, fused, K and V resident in LDS.
+ * PAIF_ENOSUP when Nk*(C/heads)*8 B > 160 KiB or the head dim is not 32/64. */
+int paif_sr_attention_fwd(const float* q, const float* kv, float* out, int B, int N, int Nk, int C, int heads,
+                          paif_stream_t stream);
+
+/* F.interpolate(mode='bilinear', align_corners=False) of NHWC x [B,IH,IW,C] written into channels
+ * [coff, coff+C) of out [B,OH,OW,ldo] -- the head's upsample + torch.cat (core/segformer_head.py:66-77). */
+int paif_resize_bilinear_into_fwd(const float* x, float* out, int B, int IH, int IW, int C, int OH, int OW, int ldo,
+                                  int coff, paif_stream_t stream);
+
+/* layout changes at the module boundary (3-channel input, 9-channel logits): [B,HW,C] <-> [B,C,HW]. */
+int paif_nhwc_to_nchw_fwd(const float* x, float* y, int B, int HW, int C, paif_stream_t stream);
+int paif_nchw_to_nhwc_fwd(const float* x, float* y, int B, int HW, int C, paif_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

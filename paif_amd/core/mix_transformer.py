@@ -1,0 +1,261 @@
+"""MixTransformer (MiT-B0..B5) encoder -- MI355X-native counterpart of the reference's
+core/mix_transformer.py (NVIDIA SegFormer code).  Same classes, constructor arguments, init and
+state_dict keys; forward bodies launch the gfx950 kernels (fp32 MFMA GEMM, fused SR attention, LayerNorm,
+depthwise-conv+GELU).  Tokens [B,N,C] are NHWC images, so the encoder never transposes.
+
+Inference only for now: DropPath is identity in eval (core/mix_transformer.py:126; timm semantics) and
+train-mode forward raises until the training kernels exist.
+"""
+import math
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..operations_m import Conv2dParams, LayerNormParams, LinearParams, _PackCache
+
+
+def to_2tuple(x):
+    return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+
+
+def _init_weights(m):
+    """core/mix_transformer.py:29-43 (identical in every class there)."""
+    if isinstance(m, nn.Linear):
+        nn.init.trunc_normal_(m.weight, std=.02)
+        if m.bias is not None:
+            nn.init.constant_(m.bias, 0)
+    elif isinstance(m, nn.LayerNorm):
+        nn.init.constant_(m.bias, 0)
+        nn.init.constant_(m.weight, 1.0)
+    elif isinstance(m, nn.Conv2d):
+        fan_out = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+        fan_out //= m.groups
+        m.weight.data.normal_(0, math.sqrt(2.0 / fan_out))
+        if m.bias is not None:
+            m.bias.data.zero_()
+
+
+class DropPath(nn.Module):
+    """Stochastic depth (timm.models.layers.DropPath): identity when p == 0 or in eval."""
+
+    def __init__(self, drop_prob=0.0):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        raise NotImplementedError("train-mode DropPath belongs to the training step (not built yet)")
+
+
+class DWConv(nn.Module):
+    """core/mix_transformer.py:376-387 (parameter holder; fused with GELU in Mlp)."""
+
+    def __init__(self, dim=768):
+        super().__init__()
+        self.dwconv = Conv2dParams(dim, dim, 3, 1, 1, bias=True, groups=dim)
+
+
+class Mlp(nn.Module):
+    """core/mix_transformer.py:18-53: fc1 -> DWConv -> GELU -> fc2 (drop = 0)."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        if act_layer is not nn.GELU or drop != 0.:
+            raise NotImplementedError("Mlp: only GELU / drop=0 (every mit_b* config)")
+        self.fc1 = LinearParams(in_features, hidden_features)
+        self.dwconv = DWConv(hidden_features)
+        self.act = act_layer()
+        self.fc2 = LinearParams(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+        self.apply(_init_weights)
+
+    def forward_tokens(self, x, H, W, res):
+        """x [B,N,C] -> fc2(gelu(dwconv(fc1 x))) + res."""
+        B, N, _ = x.shape
+        hid = ops.gemm(x, self.fc1.weight, shift=self.fc1.bias)
+        hid = ops.dwconv3_bias_gelu(hid.view(B, H, W, -1), self.dwconv.dwconv.weight, self.dwconv.dwconv.bias).view(B, N, -1)
+        return ops.gemm(hid, self.fc2.weight, shift=self.fc2.bias, res=res)
+
+
+class Attention(nn.Module):
+    """core/mix_transformer.py:56-115: spatial-reduction attention."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0., sr_ratio=1):
+        super().__init__()
+        assert dim % num_heads == 0, f"dim {dim} should be divided by num_heads {num_heads}."
+        if qk_scale is not None or attn_drop != 0. or proj_drop != 0.:
+            raise NotImplementedError("Attention: qk_scale / dropout are unused by every mit_b* config")
+        self.dim = dim
+        self.num_heads = num_heads
+        head_dim = dim // num_heads
+        self.scale = head_dim ** -0.5
+        self.q = LinearParams(dim, dim, bias=qkv_bias)
+        self.kv = LinearParams(dim, dim * 2, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = LinearParams(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+        self.sr_ratio = sr_ratio
+        if sr_ratio > 1:
+            self.sr = Conv2dParams(dim, dim, kernel_size=sr_ratio, stride=sr_ratio)
+            self.norm = LayerNormParams(dim)
+        self._packs = _PackCache()
+        self.apply(_init_weights)
+
+    def forward_tokens(self, x, H, W, res):
+        """x = norm1(tokens) [B,N,C]; returns proj(attn) + res."""
+        B, N, C = x.shape
+        q = ops.gemm(x, self.q.weight, shift=self.q.bias)
+        if self.sr_ratio > 1:
+            sr = self.sr_ratio
+            wsr = self._packs.get("sr", [self.sr.weight], lambda: ops.pack_conv_gemm_weight(self.sr.weight))
+            col = ops.im2col(x.view(B, H, W, C), sr, sr, 0, wsr.shape[1])
+            x_ = ops.gemm(col.view(B, -1, wsr.shape[1]), wsr, shift=self.sr.bias)
+            x_ = ops.layernorm(x_, self.norm.weight, self.norm.bias, self.norm.eps)
+        else:
+            x_ = x
+        kv = ops.gemm(x_, self.kv.weight, shift=self.kv.bias)
+        o = ops.sr_attention(q, kv, self.num_heads)
+        return ops.gemm(o, self.proj.weight, shift=self.proj.bias, res=res)
+
+
+class Block(nn.Module):
+    """core/mix_transformer.py:118-155."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop=0., attn_drop=0.,
+                 drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm, sr_ratio=1):
+        super().__init__()
+        self.norm1 = _make_norm(norm_layer, dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop,
+                              proj_drop=drop, sr_ratio=sr_ratio)
+        self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
+        self.norm2 = _make_norm(norm_layer, dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+        self.apply(_init_weights)
+
+    def forward_tokens(self, x, H, W):
+        if self.training and isinstance(self.drop_path, DropPath) and self.drop_path.drop_prob > 0:
+            raise NotImplementedError("train-mode DropPath belongs to the training step (not built yet); call .eval()")
+        x = self.attn.forward_tokens(ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps), H, W, res=x)
+        x = self.mlp.forward_tokens(ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps), H, W, res=x)
+        return x
+
+
+def _make_norm(norm_layer, dim):
+    """norm_layer is nn.LayerNorm or partial(nn.LayerNorm, eps=...) in the reference; keep eps, hold params."""
+    probe = norm_layer(dim)
+    if not isinstance(probe, nn.LayerNorm):
+        raise NotImplementedError("only LayerNorm norm layers")
+    return LayerNormParams(dim, eps=probe.eps)
+
+
+class OverlapPatchEmbed(nn.Module):
+    """core/mix_transformer.py:158-198: strided conv (im2col + MFMA GEMM) + LayerNorm."""
+
+    def __init__(self, img_size=224, patch_size=7, stride=4, in_chans=3, embed_dim=768):
+        super().__init__()
+        img_size = to_2tuple(img_size)
+        patch_size = to_2tuple(patch_size)
+        self.img_size = img_size
+        self.patch_size = patch_size
+        self.stride = stride
+        self.H, self.W = img_size[0] // patch_size[0], img_size[1] // patch_size[1]
+        self.num_patches = self.H * self.W
+        self.proj = Conv2dParams(in_chans, embed_dim, kernel_size=patch_size, stride=stride,
+                                 padding=(patch_size[0] // 2, patch_size[1] // 2))
+        self.norm = LayerNormParams(embed_dim)
+        self._packs = _PackCache()
+        self.apply(_init_weights)
+
+    def forward_nhwc(self, x):
+        """x NHWC [B,H,W,Cin] -> tokens [B, OH*OW, D], OH, OW."""
+        k = self.patch_size[0]
+        w = self._packs.get("w", [self.proj.weight], lambda: ops.pack_conv_gemm_weight(self.proj.weight))
+        col = ops.im2col(x, k, self.stride, k // 2, w.shape[1])
+        B, OH, OW, _ = col.shape
+        t = ops.gemm(col.view(B, OH * OW, -1), w, shift=self.proj.bias)
+        return ops.layernorm(t, self.norm.weight, self.norm.bias, self.norm.eps), OH, OW
+
+
+class MixVisionTransformer(nn.Module):
+    """core/mix_transformer.py:201-375."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dims=[64, 128, 256, 512],
+                 num_heads=[1, 2, 4, 8], mlp_ratios=[4, 4, 4, 4], qkv_bias=False, qk_scale=None, drop_rate=0.,
+                 attn_drop_rate=0., drop_path_rate=0., norm_layer=nn.LayerNorm,
+                 depths=[3, 4, 6, 3], sr_ratios=[8, 4, 2, 1]):
+        super().__init__()
+        self.num_classes = num_classes
+        self.depths = depths
+        self.embed_dims = embed_dims
+        self.patch_embed1 = OverlapPatchEmbed(img_size=img_size, patch_size=7, stride=4, in_chans=in_chans, embed_dim=embed_dims[0])
+        self.patch_embed2 = OverlapPatchEmbed(img_size=img_size // 4, patch_size=3, stride=2, in_chans=embed_dims[0], embed_dim=embed_dims[1])
+        self.patch_embed3 = OverlapPatchEmbed(img_size=img_size // 8, patch_size=3, stride=2, in_chans=embed_dims[1], embed_dim=embed_dims[2])
+        self.patch_embed4 = OverlapPatchEmbed(img_size=img_size // 16, patch_size=3, stride=2, in_chans=embed_dims[2], embed_dim=embed_dims[3])
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths))]
+        cur = 0
+        for s in range(4):
+            blocks = nn.ModuleList([Block(
+                dim=embed_dims[s], num_heads=num_heads[s], mlp_ratio=mlp_ratios[s], qkv_bias=qkv_bias, qk_scale=qk_scale,
+                drop=drop_rate, attn_drop=attn_drop_rate, drop_path=dpr[cur + i], norm_layer=norm_layer,
+                sr_ratio=sr_ratios[s]) for i in range(depths[s])])
+            setattr(self, "block%d" % (s + 1), blocks)
+            setattr(self, "norm%d" % (s + 1), _make_norm(norm_layer, embed_dims[s]))
+            cur += depths[s]
+        self.apply(_init_weights)
+
+    def reset_drop_path(self, drop_path_rate):
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(self.depths))]
+        cur = 0
+        for s in range(4):
+            for i in range(self.depths[s]):
+                getattr(self, "block%d" % (s + 1))[i].drop_path.drop_prob = dpr[cur + i]
+            cur += self.depths[s]
+
+    def freeze_patch_emb(self):
+        self.patch_embed1.requires_grad = False
+
+    def forward_features_nhwc(self, x):
+        """x NHWC [B,H,W,3] -> 4 NHWC stage outputs [B,H/4,W/4,D0] ... [B,H/32,W/32,D3]."""
+        outs = []
+        B = x.shape[0]
+        for s in range(4):
+            t, H, W = getattr(self, "patch_embed%d" % (s + 1)).forward_nhwc(x)
+            for blk in getattr(self, "block%d" % (s + 1)):
+                t = blk.forward_tokens(t, H, W)
+            n = getattr(self, "norm%d" % (s + 1))
+            t = ops.layernorm(t, n.weight, n.bias, n.eps)
+            x = t.view(B, H, W, -1)
+            outs.append(x)
+        return outs
+
+    def forward_features(self, x):
+        ops.require_no_grad(x)
+        with torch.no_grad():
+            xin = ops.nchw_to_nhwc(x)
+            return [ops.to_nchw_view(o) for o in self.forward_features_nhwc(xin)]
+
+    def forward(self, x):
+        return self.forward_features(x)
+
+
+def _mit(embed_dims, depths):
+    def ctor(self, **kwargs):
+        MixVisionTransformer.__init__(
+            self, patch_size=4, embed_dims=embed_dims, num_heads=[1, 2, 5, 8], mlp_ratios=[4, 4, 4, 4], qkv_bias=True,
+            norm_layer=partial(nn.LayerNorm, eps=1e-6), depths=depths, sr_ratios=[8, 4, 2, 1], drop_rate=0.0,
+            drop_path_rate=0.1)
+    return ctor
+
+
+# core/mix_transformer.py:389-433
+mit_b0 = type("mit_b0", (MixVisionTransformer,), {"__init__": _mit([32, 64, 160, 256], [2, 2, 2, 2])})
+mit_b1 = type("mit_b1", (MixVisionTransformer,), {"__init__": _mit([64, 128, 320, 512], [2, 2, 2, 2])})
+mit_b2 = type("mit_b2", (MixVisionTransformer,), {"__init__": _mit([64, 128, 320, 512], [3, 4, 6, 3])})
+mit_b3 = type("mit_b3", (MixVisionTransformer,), {"__init__": _mit([64, 128, 320, 512], [3, 4, 18, 3])})
+mit_b4 = type("mit_b4", (MixVisionTransformer,), {"__init__": _mit([64, 128, 320, 512], [3, 8, 27, 3])})
+mit_b5 = type("mit_b5", (MixVisionTransformer,), {"__init__": _mit([64, 128, 320, 512], [3, 6, 40, 3])})

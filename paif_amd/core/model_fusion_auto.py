@@ -206,3 +206,146 @@ class Network_Fusion_Searched(nn.Module):
     def _loss(self, ir, vis, mask):
         logits = self(ir, vis)
         return self._criterion(ir, vis, logits, mask)
+
+
+# ---------------------------------------------------------------------------------------------
+# segmentation network wrapper + composite models
+# ---------------------------------------------------------------------------------------------
+from . import mix_transformer  # noqa: E402
+from .segformer_head import SegFormerHead  # noqa: E402
+
+
+class WeTr(nn.Module):
+    """core/model_fusion_auto.py:9-68: MiT encoder + SegFormer head (+ a dead `classifier`, :66, whose result
+    the reference discards: it is kept as a parameter for state_dict parity and never evaluated)."""
+
+    def __init__(self, backbone, num_classes=20, embedding_dim=256, pretrained=None):
+        super().__init__()
+        self.num_classes = num_classes
+        self.embedding_dim = embedding_dim
+        self.backbone = backbone
+        self.feature_strides = [4, 8, 16, 32]
+        self.encoder = getattr(mix_transformer, backbone)()
+        self.in_channels = self.encoder.embed_dims
+        if pretrained:
+            self.initialize()
+        self.decoder = SegFormerHead(feature_strides=self.feature_strides, in_channels=self.in_channels,
+                                     embedding_dim=self.embedding_dim, num_classes=self.num_classes)
+        self.classifier = Conv2dParams(in_channels=self.in_channels[-1], out_channels=self.num_classes, kernel_size=1, bias=False)
+
+    def initialize(self):
+        """core/model_fusion_auto.py:22-26,32-36: load 'pretrained/<backbone>.pth' minus the ImageNet head."""
+        state_dict = torch.load('pretrained/' + self.backbone + '.pth')
+        state_dict.pop('head.weight')
+        state_dict.pop('head.bias')
+        self.encoder.load_state_dict(state_dict)
+
+    def get_param_groups(self):
+        """core/model_fusion_auto.py:44-60."""
+        param_groups = [[], [], []]
+        for name, param in list(self.encoder.named_parameters()):
+            if "norm" in name:
+                param_groups[1].append(param)
+            else:
+                param_groups[0].append(param)
+        for param in list(self.decoder.parameters()):
+            param_groups[2].append(param)
+        param_groups[2].append(self.classifier.weight)
+        return param_groups
+
+    def forward_nhwc(self, x):
+        """x NHWC [B,H,W,3] (normalised) -> logits NHWC [B,H/4,W/4,num_classes]."""
+        return self.decoder.forward_nhwc(self.encoder.forward_features_nhwc(x))
+
+    def forward(self, x):
+        ops.require_no_grad(x)
+        with torch.no_grad():
+            return ops.nhwc_to_nchw(self.forward_nhwc(ops.nchw_to_nhwc(x)))
+
+
+class _CompositeBase(nn.Module):
+    """Shared body of Network_MM_CompModel (:698-806) and Network_MM_Searched (:1029-1137)."""
+
+    mean = [123.675, 116.28, 103.53]
+    std = [58.395, 57.12, 57.375]
+
+    def _setup(self, f_loss, segloss):
+        self.fusion_nums = 2
+        self.seg_nums = 2
+        self.fusion_channel = 48
+        self.seg_channel = 64
+        self._criterion = f_loss
+        self.seg_loss = segloss
+
+    def forward(self, ir, vis):
+        """-> (fused [B,1,H,W] in tanh range, seg_map [B,num_classes,H/4,W/4]); :712-729 / :1043-1060."""
+        ops.require_no_grad(ir, vis)
+        with torch.no_grad():
+            ycc = ops.rgb2ycrcb(vis)
+            fused = self.enhance_net.forward(ir[:, 0:1, :, :], ycc)
+            seg_in = ops.seg_input_from_fused(fused, ycc)   # clamp, BATCH-GLOBAL min-max, x255, mean/std
+            seg_map = self.denoise_net(seg_in)
+        return fused, seg_map
+
+    def forward_fusion(self, ir, vis):
+        ops.require_no_grad(ir, vis)
+        with torch.no_grad():
+            return self.enhance_net.forward(ir[:, 0:1, :, :], ops.rgb2ycrcb(vis))
+
+    def forward_object(self, ir, vis):
+        raise NotImplementedError("forward_object (second min-max on the fused plane, :743-772) is only used by _detection_loss; not built")
+
+    def _loss(self, *a, **k):
+        raise NotImplementedError("training losses need the backward kernels (config 5; not built yet)")
+
+    _loss_coupled = _fusion_loss_lower = _fusion_loss = _fusion_loss_wogan = _detection_loss = _loss
+
+    def enhance_net_parameters(self):
+        return self.enhance_net.parameters()
+
+    def denoise_net_parameters(self):
+        return self.denoise_net.parameters()
+
+
+class Network_MM_CompModel(_CompositeBase):
+    """core/model_fusion_auto.py:698-806."""
+
+    def __init__(self, model, f_loss, segloss, backbone, num_classes=20, embedding_dim=256, pretrained=None):
+        super().__init__()
+        self._setup(f_loss, segloss)
+        self.enhance_net = model
+        self.denoise_net = WeTr(backbone, num_classes, embedding_dim, pretrained)
+
+
+class Network_MM_Searched(_CompositeBase):
+    """core/model_fusion_auto.py:1029-1137."""
+
+    def __init__(self, C, genotype, f_loss, segloss, backbone, num_classes=20, embedding_dim=256, pretrained=None):
+        super().__init__()
+        self._setup(f_loss, segloss)
+        self.enhance_net = Network_Fusion_Searched(C, f_loss, genotype)
+        self.denoise_net = WeTr(backbone, num_classes, embedding_dim, pretrained)
+
+
+class Network_MM_SearchedFusion(nn.Module):
+    """core/model_fusion_auto.py:1141-1188 (fusion only)."""
+
+    def __init__(self, C, genotype, f_loss):
+        super().__init__()
+        self.fusion_nums = 2
+        self.seg_nums = 2
+        self.fusion_channel = 48
+        self.seg_channel = 64
+        self._criterion = f_loss
+        self.enhance_net = Network_Fusion_Searched(C, f_loss, genotype)
+        self.denoise_net = None
+
+    def forward(self, ir, vis):
+        ops.require_no_grad(ir, vis)
+        with torch.no_grad():
+            return self.enhance_net.forward(ir, ops.rgb2ycrcb(vis))
+
+    forward_fusion = forward
+
+    def enhance_net_parameters(self):
+        return self.enhance_net.parameters()

@@ -1,0 +1,76 @@
+"""SegFormer all-MLP decode head -- MI355X-native counterpart of the reference's core/segformer_head.py.
+Same classes and state_dict keys (`linear_fuse.{conv.weight, bn.*}` follow mmcv.cnn.ConvModule's naming;
+semantics per oracle/shims/mmcv: conv without bias -> BatchNorm -> ReLU)."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..operations_m import BatchNormParams, Conv2dParams, LinearParams, _PackCache, _bn_scale_shift
+
+
+class MLP(nn.Module):
+    """core/segformer_head.py:13-24."""
+
+    def __init__(self, input_dim=2048, embed_dim=768):
+        super().__init__()
+        self.proj = LinearParams(input_dim, embed_dim)
+
+
+class ConvModule(nn.Module):
+    """Parameter holder with mmcv.cnn.ConvModule's sub-module names (conv, bn, activate)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, norm_cfg=None):
+        super().__init__()
+        self.conv = Conv2dParams(in_channels, out_channels, kernel_size, bias=(norm_cfg is None))
+        self.with_norm = norm_cfg is not None
+        if self.with_norm:
+            self.bn = BatchNormParams(out_channels)
+        self.activate = nn.ReLU(inplace=True)
+
+
+class SegFormerHead(nn.Module):
+    """core/segformer_head.py:27-82."""
+
+    def __init__(self, feature_strides=None, in_channels=128, embedding_dim=256, num_classes=20, **kwargs):
+        super().__init__()
+        self.in_channels = in_channels
+        self.num_classes = num_classes
+        assert len(feature_strides) == len(self.in_channels)
+        assert min(feature_strides) == feature_strides[0]
+        self.feature_strides = feature_strides
+        c1_in, c2_in, c3_in, c4_in = self.in_channels
+        self.embedding_dim = embedding_dim
+        self.linear_c4 = MLP(input_dim=c4_in, embed_dim=embedding_dim)
+        self.linear_c3 = MLP(input_dim=c3_in, embed_dim=embedding_dim)
+        self.linear_c2 = MLP(input_dim=c2_in, embed_dim=embedding_dim)
+        self.linear_c1 = MLP(input_dim=c1_in, embed_dim=embedding_dim)
+        self.dropout = nn.Dropout2d(0.1)
+        self.linear_fuse = ConvModule(in_channels=embedding_dim * 4, out_channels=embedding_dim, kernel_size=1,
+                                      norm_cfg=dict(type='BN', requires_grad=True))
+        self.linear_pred = Conv2dParams(embedding_dim, self.num_classes, kernel_size=1)
+        self._packs = _PackCache()
+
+    def forward_nhwc(self, feats):
+        """feats: 4 NHWC maps -> logits NHWC [B,H/4,W/4,num_classes]."""
+        if self.training:
+            raise NotImplementedError("train-mode head (Dropout2d, BatchNorm batch statistics) is not built yet; call .eval()")
+        c1, c2, c3, c4 = feats
+        B, H1, W1, _ = c1.shape
+        E = self.embedding_dim
+        cat = torch.empty((B, H1, W1, 4 * E), device=c1.device, dtype=torch.float32)
+        # concat order [_c4, _c3, _c2, _c1] (core/segformer_head.py:77)
+        for i, (c, lin) in enumerate(((c4, self.linear_c4), (c3, self.linear_c3), (c2, self.linear_c2))):
+            y = ops.gemm(c, lin.proj.weight, shift=lin.proj.bias)
+            ops.resize_bilinear_into(y, cat, i * E)
+        ops.gemm(c1, self.linear_c1.proj.weight, shift=self.linear_c1.proj.bias, out=cat, col_offset=3 * E)
+        scale, shift = _bn_scale_shift(self.linear_fuse.bn, self._packs)
+        fw = self.linear_fuse.conv.weight.view(E, 4 * E)
+        x = ops.gemm(cat, fw, scale=scale, shift=shift, act=ops.ACT_RELU)
+        pw = self.linear_pred.weight.view(self.num_classes, E)
+        return ops.gemm(x, pw, shift=self.linear_pred.bias)
+
+    def forward(self, x):
+        ops.require_no_grad(*x)
+        with torch.no_grad():
+            out = self.forward_nhwc([ops.to_nhwc(t) for t in x])
+            return ops.nhwc_to_nchw(out)

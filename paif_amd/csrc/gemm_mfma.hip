@@ -1,0 +1,128 @@
+// fp32 GEMM on the gfx950 matrix cores for the SegFormer linears / 1x1 convs / im2col'ed convs:
+//   C[M,N] = epilogue( A[M,K] . W[N,K]^T )         (torch nn.Linear / F.linear weight layout)
+// v_mfma_f32_32x32x2_f32: exact f32 (k-ordered fmaf chain) at the fp32 vector rate.
+//
+//   workgroup tile 128 (M) x 64 (N) x 32 (K), 4 waves, wave w owns rows [32w, 32w+32) x all 64 columns
+//   (2 accumulator tiles).  A and W tiles staged in LDS with row stride 36 dwords (conflict-free
+//   ds_read_b128, see conv_mfma.hip); one b128 A-read + two b128 W-reads feed 8 MFMAs.
+//   D layout: lane (h, n) holds column n of rows (r&3)+8(r>>2)+4h -> each store writes 128-B row segments.
+//   Epilogue: y = acc*scale[n] + shift[n] (bias or folded BN; NULL -> 1/0), GELU(erf)/ReLU, + res[m, n].
+//   K must be a multiple of 32 (callers pad); M, N arbitrary (masked).
+//
+// Replaces nn.Linear in core/mix_transformer.py (Mlp :22-25, Attention :66-69, :74 sr conv via im2col),
+// core/segformer_head.py MLP.proj (:19), linear_fuse 1x1 conv + BN + ReLU (:50-55), linear_pred (:57),
+// OverlapPatchEmbed.proj via im2col (core/mix_transformer.py:168-169).
+#include "paif_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 64, BK = 32, LDS_STRIDE = BK + 4;
+
+struct GemmArgs {
+  const float* A; const float* W; const float* scale; const float* shift; const float* res; float* C;
+  int M, N, K, lda, ldc, ldres, act;
+  int tilesN, nblk;
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__global__ __launch_bounds__(256, 2) void gemm_mfma_f32(GemmArgs a) {
+  __shared__ __align__(16) float sA[BM * LDS_STRIDE];
+  __shared__ __align__(16) float sW[BN * LDS_STRIDE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p = lane & 31;
+  // consecutive workgroups share the same rows of A (same m-tile, different n-tile) -> L2 reuse of A
+  const int tn = blockIdx.x % a.tilesN, tm = blockIdx.x / a.tilesN;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // staging map: A tile = 128 rows x 8 float4 -> 4 per thread; W tile = 64 rows x 8 float4 -> 2 per thread
+  const int srow = tid >> 3, sq = tid & 7;
+  const int abase = (wave * 32 + p) * LDS_STRIDE + 4 * h;
+  const int wbase = p * LDS_STRIDE + 4 * h;
+
+  for (int k0 = 0; k0 < a.K; k0 += BK) {
+    float4 va[4], vw[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + srow + 32 * i;
+      va[i] = (m < a.M) ? *reinterpret_cast<const float4*>(a.A + (size_t)m * a.lda + k0 + sq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int n = n0 + srow + 32 * i;
+      vw[i] = (n < a.N) ? *reinterpret_cast<const float4*>(a.W + (size_t)n * a.K + k0 + sq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (k0 > 0) __syncthreads();  // previous tile fully consumed
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(sA + (srow + 32 * i) * LDS_STRIDE + sq * 4) = va[i];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(sW + (srow + 32 * i) * LDS_STRIDE + sq * 4) = vw[i];
+    __syncthreads();
+#pragma unroll
+    for (int o = 0; o < BK / 8; ++o) {
+      const float4 av = *reinterpret_cast<const float4*>(sA + abase + 8 * o);
+      const float4 w0 = *reinterpret_cast<const float4*>(sW + wbase + 8 * o);
+      const float4 w1 = *reinterpret_cast<const float4*>(sW + wbase + 32 * LDS_STRIDE + 8 * o);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, w0.x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, w1.x, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, w0.y, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, w1.y, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, w0.z, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, w1.z, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, w0.w, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, w1.w, acc[1], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue ----
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int n = n0 + 32 * t + p;
+    if (n >= a.N) continue;
+    const float sc = a.scale ? a.scale[n] : 1.f;
+    const float sh = a.shift ? a.shift[n] : 0.f;
+    float rv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      rv[r] = (a.res && m < a.M) ? a.res[(size_t)m * a.ldres + n] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (m < a.M) {
+        float v = acc[t][r] * sc + sh;
+        if (a.act == 1) v = gelu_erf(v);
+        else if (a.act == 2) v = fmaxf(v, 0.f);
+        if (a.res) v += rv[r];
+        a.C[(size_t)m * a.ldc + n] = v;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int paif_gemm_fwd(const float* A, int lda, const float* W, const float* scale, const float* shift, int act,
+                             const float* res, int ldres, float* C, int ldc, int M, int N, int K, paif_stream_t stream) {
+  PAIF_REQUIRE(A && W && C, PAIF_EINVAL, "gemm: null pointer");
+  PAIF_REQUIRE(M > 0 && N > 0 && K > 0, PAIF_EINVAL, "gemm: empty shape %dx%dx%d", M, N, K);
+  PAIF_REQUIRE(K % 32 == 0, PAIF_ENOSUP, "gemm: K=%d must be a multiple of 32 (pad the operands)", K);
+  PAIF_REQUIRE(lda >= K && ldc >= N && (lda % 4) == 0, PAIF_EINVAL, "gemm: bad leading dimensions lda=%d ldc=%d", lda, ldc);
+  PAIF_REQUIRE(act >= 0 && act <= 2, PAIF_EINVAL, "gemm: act=%d", act);
+  GemmArgs a;
+  a.A = A; a.W = W; a.scale = scale; a.shift = shift; a.res = res; a.C = C;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldres = res ? ldres : 0; a.act = act;
+  a.tilesN = (N + BN - 1) / BN;
+  a.nblk = a.tilesN * ((M + BM - 1) / BM);
+  hipLaunchKernelGGL(gemm_mfma_f32, dim3(a.nblk), dim3(256), 0, paif::as_stream(stream), a);
+  PAIF_LAUNCH_CHECK("gemm");
+  return 0;
+}

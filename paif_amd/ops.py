@@ -266,3 +266,104 @@ def add(a, b):
     out = torch.empty_like(a)
     _lib.check(lib().paif_add_fwd(_p(a), _p(b), _p(out), a.numel(), _stream()), "add")
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# segmentation network (token tensors [B,N,C] = NHWC)
+# ---------------------------------------------------------------------------------------------
+def gemm(a, w, scale=None, shift=None, act=ACT_NONE, res=None, out=None, out_cols=None, col_offset=0):
+    """a [..., K] (dense) x w [N, K]^T -> [..., N].  scale/shift per output column (bias = shift).
+    `out` (+col_offset) lets a caller write into a channel slice of a wider row-major buffer."""
+    K = a.shape[-1]
+    N = w.shape[0]
+    assert w.shape[1] == K, (tuple(w.shape), K)
+    M = a.numel() // K
+    if out is None:
+        out = torch.empty(a.shape[:-1] + (N,), device=a.device, dtype=torch.float32)
+        ldc, cptr = N, _p(out)
+    else:
+        ldc = out.shape[-1]
+        assert out.is_contiguous() and col_offset + N <= ldc
+        cptr = ctypes.c_void_p(out.data_ptr() + 4 * col_offset)
+    if res is not None:
+        assert res.shape[-1] == N and res.numel() == M * N
+    tag = "gemm_mfma_f32"
+    e0 = TIMER.start(tag) if TIMER is not None else None
+    _lib.check(lib().paif_gemm_fwd(_p(a), K, _p(w), _p(scale), _p(shift), act, _p(res), N, cptr, ldc, M, N, K, _stream()), "gemm")
+    if e0 is not None:
+        TIMER.stop(tag, e0, 2 * M * N * K, 4 * (M * K + N * K + M * N * (2 if res is not None else 1)))
+    return out
+
+
+def layernorm(x, weight, bias, eps):
+    C = x.shape[-1]
+    y = torch.empty_like(x)
+    _lib.check(lib().paif_layernorm_fwd(_p(x), _p(weight), _p(bias), _p(y), x.numel() // C, C, eps, _stream()), "layernorm")
+    return y
+
+
+def conv_out_size(n, k, stride, pad):
+    return (n + 2 * pad - k) // stride + 1
+
+
+def im2col(x, k, stride, pad, kpad):
+    """x NHWC [B,H,W,Cin] -> [B, OH, OW, kpad]."""
+    B, H, W, Cin = x.shape
+    OH, OW = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
+    col = torch.empty((B, OH, OW, kpad), device=x.device, dtype=torch.float32)
+    _lib.check(lib().paif_im2col_fwd(_p(x), _p(col), B, H, W, Cin, k, stride, pad, kpad, _stream()), "im2col")
+    return col
+
+
+def pack_conv_gemm_weight(w):
+    """[Cout,Cin,k,k] -> [Cout,Kpad] (Kpad = k*k*Cin rounded up to a multiple of 32)."""
+    Cout, Cin, k, k2 = w.shape
+    assert k == k2
+    kpad = (k * k * Cin + 31) // 32 * 32
+    out = torch.empty((Cout, kpad), device=w.device, dtype=torch.float32)
+    _lib.check(lib().paif_pack_conv_gemm_weight(_p(w.detach().contiguous()), _p(out), Cout, Cin, k, kpad, _stream()), "pack_conv_gemm_weight")
+    return out
+
+
+def dwconv3_bias_gelu(x, w, bias):
+    B, H, W, C = x.shape
+    y = torch.empty_like(x)
+    _lib.check(lib().paif_dwconv3_bias_gelu_fwd(_p(x), _p(w.detach().contiguous()), _p(bias), _p(y), B, H, W, C, _stream()), "dwconv3_bias_gelu")
+    return y
+
+
+def sr_attention(q, kv, heads):
+    """q [B,N,C], kv [B,Nk,2C] -> [B,N,C]."""
+    B, N, C = q.shape
+    Nk = kv.shape[1]
+    assert kv.shape[2] == 2 * C
+    out = torch.empty_like(q)
+    tag = "sr_attention"
+    e0 = TIMER.start(tag) if TIMER is not None else None
+    _lib.check(lib().paif_sr_attention_fwd(_p(q), _p(kv), _p(out), B, N, Nk, C, heads, _stream()), "sr_attention")
+    if e0 is not None:
+        TIMER.stop(tag, e0, 4 * B * N * Nk * C, 4 * (2 * B * N * C + 2 * B * Nk * C))
+    return out
+
+
+def resize_bilinear_into(x, out, coff):
+    """x NHWC [B,IH,IW,C] -> bilinear (align_corners=False) into out[B,OH,OW,coff:coff+C]."""
+    B, IH, IW, C = x.shape
+    _, OH, OW, ldo = out.shape
+    _lib.check(lib().paif_resize_bilinear_into_fwd(_p(x), _p(out), B, IH, IW, C, OH, OW, ldo, coff, _stream()), "resize_bilinear_into")
+    return out
+
+
+def nhwc_to_nchw(x):
+    B, H, W, C = x.shape
+    y = torch.empty((B, C, H, W), device=x.device, dtype=torch.float32)
+    _lib.check(lib().paif_nhwc_to_nchw_fwd(_p(x), _p(y), B, H * W, C, _stream()), "nhwc_to_nchw")
+    return y
+
+
+def nchw_to_nhwc(x):
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    y = torch.empty((B, H, W, C), device=x.device, dtype=torch.float32)
+    _lib.check(lib().paif_nchw_to_nhwc_fwd(_p(x), _p(y), B, H * W, C, _stream()), "nchw_to_nhwc")
+    return y
