@@ -27,7 +27,8 @@ import torch  # noqa: E402
 
 H, W, B_PER_GPU = 480, 640, 8
 MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: "Peak FP32 (matrix) 157.3 TFLOPS"
-DOMINANT = "conv_mfma_f32<3,1,32>"  # 3x3 dense convs: 76 % of the fusion FLOPs
+HBM_PEAK_GBS = 8000.0             # same guide: "HBM3E peak BW 8.0 TB/s spec" (6.29 TB/s measured float4 copy)
+# dominant kernel = the 3x3 dense convs: 76 % of the fusion FLOPs
 
 
 def main():
@@ -36,6 +37,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--conv-precision", choices=["f32", "bf16x3"], default="bf16x3",
+                    help="arithmetic of the dense convs: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs, fp32 accumulate)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -57,6 +60,8 @@ def main():
     from paif_amd import ops, synthetic as S
     from paif_amd.core.model_fusion_auto import Network_Fusion_Searched
 
+    ops.set_conv_precision(args.conv_precision)
+    DOMINANT = "conv_mfma_%s<3,1,32>" % args.conv_precision
     net = Network_Fusion_Searched(32, None, FUSION_AT).eval()
     S.load_formula_weights(net)          # formula weights: no checkpoint exists (reference README.md:34-37)
     net = net.to(dev)
@@ -95,19 +100,29 @@ def main():
     if rank == 0:
         pairs = B_PER_GPU * world * args.steps
         n, ms, flops, nbytes = timer.summary()[DOMINANT]
-        achieved = flops / (ms * 1e-3) / 1e12
+        tflops = flops / (ms * 1e-3) / 1e12
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        if args.conv_precision == "f32":
+            # exact-fp32 MFMA: compute-bound (intensity 72-108 FLOP/B against 157.3 TF / 8 TB/s = 19.7 FLOP/B)
+            roof = {"kernel": DOMINANT, "bound": "mfma", "achieved": tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": tflops / MFMA_F32_PEAK_TFLOPS}
+        else:
+            # split-bf16: 3 bf16 MFMA passes -> effective matrix peak 2500/3 = 833 TF algorithmic; at 72-108 FLOP/B
+            # (fp32 storage) the HBM roof binds (833e12 / 8e12 = 104 FLOP/B)
+            roof = {"kernel": DOMINANT, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": gbs / HBM_PEAK_GBS, "algorithmic_tflops": tflops}
+        roof.update({"traffic": None, "launches": n, "avg_launch_ms": ms / n, "algorithmic_gflop_per_launch": flops / n / 1e9,
+                     "algorithmic_mb_per_launch": nbytes / n / 1e6})
         res = {
             "metric": "fused image-pairs/sec at 480x640 bs=8 per GPU (fusion-net forward)",
             "value": pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.conv_precision == "f32" else "f32 storage; conv products as split-bf16 (3x bf16 MFMA, f32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": "configs[1]: fusion-net forward (RGB2YCrCb + Network_Fusion_Searched, C=32, shipped genotype), "
-                                   "480x640, bs=8/GPU, fp32 storage + fp32 MFMA", "batch_per_gpu": B_PER_GPU,
+                                   "480x640, bs=8/GPU, fp32 storage, conv precision %s" % args.conv_precision, "batch_per_gpu": B_PER_GPU,
                        "parallelism": "replicas x%d (no data-path collective)" % world},
-            "roofline": {"kernel": DOMINANT, "bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                         "launches": n, "avg_launch_ms": ms / n, "algorithmic_gflop_per_launch": flops / n / 1e9,
-                         "algorithmic_mb_per_launch": nbytes / n / 1e6},
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(ir_np, vis_np)

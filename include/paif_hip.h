@@ -105,7 +105,11 @@ typedef struct {
   float* out;            /* NHWC [B,H,W,cout] */
   int cout;              /* 32 or 16 */
   float* pool_partial;   /* optional */
+  int precision;         /* PAIF_CONV_F32 (exact fp32 MFMA) or PAIF_CONV_BF16X3 (split-bf16, ~1e-5 rel.);
+                            wpk must have been packed for the same precision */
 } paif_conv_desc;
+#define PAIF_CONV_F32 0
+#define PAIF_CONV_BF16X3 1
 
 int paif_conv2d_blocks(int B, int H, int W);
 int paif_conv2d_fwd(const paif_conv_desc* d, int B, int H, int W, paif_stream_t stream);
@@ -114,6 +118,10 @@ int paif_conv2d_fwd(const paif_conv_desc* d, int B, int H, int W, paif_stream_t 
  * w[n][src*cin + 8*o + 4*h + i][tap], i = 0..3 -- the B operand of four consecutive MFMAs. */
 size_t paif_conv_wpk_floats(int nsrc, int cin, int kh);
 int paif_pack_conv_weight(const float* w, float* wpk, int cout, int nsrc, int cin, int kh, paif_stream_t stream);
+/* Same weights for precision = PAIF_CONV_BF16X3 (cin = 32 only): each value split into bf16 hi + bf16 lo,
+ * wpk[src][tap][k16][hi|lo][64 lanes][8 bf16] (same size in bytes as the fp32 packing). */
+int paif_pack_conv_weight_bf16x3(const float* w, float* wpk, int cout, int nsrc, int kh, paif_stream_t stream);
+int paif_pack_decomp1x1_weight_bf16x3(const float* w, float* wpk, paif_stream_t stream);
 /* Cell_Decom's 1x1 over cat[LF1,LF2,x-LF1,x-LF2] (core/model_fusion_auto.py:512-513) folded to a 1x1
  * over [x, LF1, LF2]: (Wh1+Wh2) x + (Wl1-Wh1) LF1 + (Wl2-Wh2) LF2.  w [32,128,1,1] -> wpk for nsrc=3. */
 int paif_pack_decomp1x1_weight(const float* w, float* wpk, paif_stream_t stream);
@@ -184,8 +192,9 @@ int paif_dwconv3_bias_gelu_fwd(const float* x, const float* w, const float* bias
 /* Attention (core/mix_transformer.py:93-115) after the q / kv linears: q [B,N,C], kv [B,Nk,2C]
  * (k = channels [0,C), v = [C,2C), head hd at offset hd*(C/heads)), out [B,N,C];
  * softmax(q k^T * (C/heads)^-0.5) v per head, fused, K and V resident in LDS.
+ * lse (optional, [B,heads,N]): log-sum-exp of the scaled scores per query, saved for the backward pass.
  * PAIF_ENOSUP when Nk*(C/heads)*8 B > 160 KiB or the head dim is not 32/64. */
-int paif_sr_attention_fwd(const float* q, const float* kv, float* out, int B, int N, int Nk, int C, int heads,
+int paif_sr_attention_fwd(const float* q, const float* kv, float* out, float* lse, int B, int N, int Nk, int C, int heads,
                           paif_stream_t stream);
 
 /* F.interpolate(mode='bilinear', align_corners=False) of NHWC x [B,IH,IW,C] written into channels
@@ -196,6 +205,52 @@ int paif_resize_bilinear_into_fwd(const float* x, float* out, int B, int IH, int
 /* layout changes at the module boundary (3-channel input, 9-channel logits): [B,HW,C] <-> [B,C,HW]. */
 int paif_nhwc_to_nchw_fwd(const float* x, float* y, int B, int HW, int C, paif_stream_t stream);
 int paif_nchw_to_nhwc_fwd(const float* x, float* y, int B, int HW, int C, paif_stream_t stream);
+/* NCHW [B,C,HW] -> NHWC [B,HW,CP], channels [C,CP) zero (pads dlogits to the GEMM's K % 32 == 0). */
+int paif_nchw_to_nhwc_pad_fwd(const float* x, float* y, int B, int HW, int C, int CP, paif_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Input-gradient (dgrad) entry points for the PGD inner loop (attack/attack.py:443-512: loss.backward()
+ * then sign of delta.grad).  Only d(loss)/d(input) is produced; parameter gradients are not.
+ * GEMM / dense-conv dgrads reuse paif_gemm_fwd / paif_conv2d_fwd with transposed weights.
+ * ------------------------------------------------------------------------------------------- */
+
+/* paif_gemm_fwd with a prologue on A: A'[m,k] = A[m,k] * (a_mask[m,k] > 0) * a_scale[k]  (a_mask / a_scale
+ * may be NULL).  Backward of ReLU(BN(.)) in front of a dgrad GEMM (core/segformer_head.py:50-55). */
+int paif_gemm_masked_fwd(const float* A, int lda, const float* a_mask, const float* a_scale, const float* W,
+                         const float* scale, const float* shift, int act, const float* res, int ldres, float* C,
+                         int ldc, int M, int N, int K, paif_stream_t stream);
+/* w [N,K] -> wt [K,Npad] (zero padded): weight operand of the dgrad GEMM dA = dC . W. */
+int paif_transpose_pad_fwd(const float* w, float* wt, int N, int K, int Npad, paif_stream_t stream);
+
+/* LayerNorm backward w.r.t. x: dx = rstd*(g - mean(g) - xhat*mean(g*xhat)), g = dy*gamma; + add (optional). */
+int paif_layernorm_bwd_input(const float* x, const float* gamma, const float* dy, const float* add, float* dx,
+                             int M, int C, float eps, paif_stream_t stream);
+/* backward of paif_dwconv3_bias_gelu_fwd w.r.t. x (tmp: scratch of x's size). */
+int paif_dwconv3_bias_gelu_bwd_input(const float* x, const float* w, const float* bias, const float* dy, float* tmp,
+                                     float* dx, int B, int H, int W, int C, paif_stream_t stream);
+/* adjoint of paif_im2col_fwd: dx [B,H,W,Cin] from dcol [B*OH*OW,Kpad]. */
+int paif_col2im_fwd(const float* dcol, float* dx, int B, int H, int W, int Cin, int k, int stride, int pad, int Kpad,
+                    paif_stream_t stream);
+/* adjoint of paif_resize_bilinear_into_fwd: dx [B,IH,IW,C] from channels [coff,coff+C) of dout [B,OH,OW,ldo]. */
+int paif_resize_bilinear_adjoint_fwd(const float* dout, float* dx, int B, int IH, int IW, int C, int OH, int OW,
+                                     int ldo, int coff, paif_stream_t stream);
+/* backward of paif_sr_attention_fwd: dq [B,N,C], dkv [B,Nk,2C] from dout, the saved output o and lse.
+ * delta [B,heads,N] scratch/out; dkv_partial: paif_sr_attention_bwd_chunks(B,N,heads) * B*Nk*2C floats. */
+int paif_sr_attention_bwd_chunks(int B, int N, int heads);
+int paif_sr_attention_bwd_input(const float* q, const float* kv, const float* o, const float* dout, const float* lse,
+                                float* delta, float* dq, float* dkv, float* dkv_partial, int B, int N, int Nk, int C,
+                                int heads, paif_stream_t stream);
+
+/* Seg_loss on bilinearly upsampled logits (attack/attack.py:103-114,446-448; F.interpolate align_corners=False
+ * + CrossEntropyLoss(ignore_index), mean over valid pixels).  logits NHWC [B,IH,IW,C]; label int64 [B,OH,OW].
+ * fwd: partial = 2*paif_upsample_ce_blocks floats of scratch; loss_count[0] = loss, [1] = #valid pixels.
+ * bwd: dfull [B,OH,OW,CP] = gscale[0] * (softmax - onehot) on valid pixels (CP >= C, CP % 4 == 0, zero padded);
+ *      gscale = dloss/count on device; follow with paif_resize_bilinear_adjoint_fwd to get dlogits. */
+int paif_upsample_ce_blocks(int B, int OH, int OW);
+int paif_upsample_ce_fwd(const float* logits, const long long* label, float* partial, float* loss_count, int B, int IH,
+                         int IW, int C, int OH, int OW, int ignore_index, paif_stream_t stream);
+int paif_upsample_ce_bwd(const float* logits, const long long* label, const float* gscale, float* dfull, int B, int IH,
+                         int IW, int C, int OH, int OW, int ignore_index, int CP, paif_stream_t stream);
 
 #ifdef __cplusplus
 }

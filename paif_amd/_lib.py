@@ -20,6 +20,7 @@ class ConvDesc(Structure):
         ("src", F * 3), ("nsrc", c_int), ("cin", c_int), ("wpk", F), ("kh", c_int), ("dil", c_int),
         ("in_act", c_int), ("in_prelu", F), ("scale", F), ("shift", F), ("act", c_int), ("prelu", F),
         ("alpha", c_float), ("res", F * 3), ("out", F), ("cout", c_int), ("pool_partial", F),
+        ("precision", c_int),
     ]
 
 
@@ -41,6 +42,8 @@ SIGNATURES = {
     "paif_conv_wpk_floats": (c_size_t, [c_int, c_int, c_int]),
     "paif_pack_conv_weight": (c_int, [F, F, c_int, c_int, c_int, c_int, F]),
     "paif_pack_decomp1x1_weight": (c_int, [F, F, F]),
+    "paif_pack_conv_weight_bf16x3": (c_int, [F, F, c_int, c_int, c_int, F]),
+    "paif_pack_decomp1x1_weight_bf16x3": (c_int, [F, F, F]),
     "paif_bn_fold": (c_int, [F, F, F, F, c_float, F, F, c_int, F]),
     "paif_dwconv_fwd": (c_int, [F, F, F, c_int, c_int, c_int, c_int, c_int, c_int, F]),
     "paif_channel_pool2_fwd": (c_int, [F, F, F, c_int, c_int, c_int, F]),
@@ -53,10 +56,22 @@ SIGNATURES = {
     "paif_im2col_fwd": (c_int, [F, F, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, F]),
     "paif_pack_conv_gemm_weight": (c_int, [F, F, c_int, c_int, c_int, c_int, F]),
     "paif_dwconv3_bias_gelu_fwd": (c_int, [F, F, F, F, c_int, c_int, c_int, c_int, F]),
-    "paif_sr_attention_fwd": (c_int, [F, F, F, c_int, c_int, c_int, c_int, c_int, F]),
+    "paif_sr_attention_fwd": (c_int, [F, F, F, F, c_int, c_int, c_int, c_int, c_int, F]),
     "paif_resize_bilinear_into_fwd": (c_int, [F, F, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, F]),
     "paif_nhwc_to_nchw_fwd": (c_int, [F, F, c_int, c_int, c_int, F]),
     "paif_nchw_to_nhwc_fwd": (c_int, [F, F, c_int, c_int, c_int, F]),
+    "paif_nchw_to_nhwc_pad_fwd": (c_int, [F, F, c_int, c_int, c_int, c_int, F]),
+    "paif_gemm_masked_fwd": (c_int, [F, c_int, F, F, F, F, F, c_int, F, c_int, F, c_int, c_int, c_int, c_int, F]),
+    "paif_transpose_pad_fwd": (c_int, [F, F, c_int, c_int, c_int, F]),
+    "paif_layernorm_bwd_input": (c_int, [F, F, F, F, F, c_int, c_int, c_float, F]),
+    "paif_dwconv3_bias_gelu_bwd_input": (c_int, [F, F, F, F, F, F, c_int, c_int, c_int, c_int, F]),
+    "paif_col2im_fwd": (c_int, [F, F, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, F]),
+    "paif_resize_bilinear_adjoint_fwd": (c_int, [F, F, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, F]),
+    "paif_sr_attention_bwd_chunks": (c_int, [c_int, c_int, c_int]),
+    "paif_sr_attention_bwd_input": (c_int, [F, F, F, F, F, F, F, F, F, c_int, c_int, c_int, c_int, c_int, F]),
+    "paif_upsample_ce_blocks": (c_int, [c_int, c_int, c_int]),
+    "paif_upsample_ce_fwd": (c_int, [F, F, F, F, c_int, c_int, c_int, c_int, c_int, c_int, c_int, F]),
+    "paif_upsample_ce_bwd": (c_int, [F, F, F, F, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, F]),
 }
 
 _lib = None

@@ -72,14 +72,28 @@ class Mlp(nn.Module):
         self.act = act_layer()
         self.fc2 = LinearParams(hidden_features, out_features)
         self.drop = nn.Dropout(drop)
+        self._packs = _PackCache()
         self.apply(_init_weights)
 
-    def forward_tokens(self, x, H, W, res):
+    def forward_tokens(self, x, H, W, res, tape=None):
         """x [B,N,C] -> fc2(gelu(dwconv(fc1 x))) + res."""
         B, N, _ = x.shape
-        hid = ops.gemm(x, self.fc1.weight, shift=self.fc1.bias)
-        hid = ops.dwconv3_bias_gelu(hid.view(B, H, W, -1), self.dwconv.dwconv.weight, self.dwconv.dwconv.bias).view(B, N, -1)
+        hid1 = ops.gemm(x, self.fc1.weight, shift=self.fc1.bias)
+        hid = ops.dwconv3_bias_gelu(hid1.view(B, H, W, -1), self.dwconv.dwconv.weight, self.dwconv.dwconv.bias).view(B, N, -1)
+        if tape is not None:
+            tape.update(hid1=hid1, H=H, W=W)
         return ops.gemm(hid, self.fc2.weight, shift=self.fc2.bias, res=res)
+
+    def backward_tokens(self, dy, tape):
+        """dy = d/d(fc2 output) -> d/d(x) (input gradient only)."""
+        B, N, _ = dy.shape
+        H, W = tape["H"], tape["W"]
+        fc2t = self._packs.get("fc2T", [self.fc2.weight], lambda: ops.transpose_pad(self.fc2.weight))
+        fc1t = self._packs.get("fc1T", [self.fc1.weight], lambda: ops.transpose_pad(self.fc1.weight))
+        d_h2 = ops.gemm(dy, fc2t)
+        d_h1 = ops.dwconv3_bias_gelu_bwd(tape["hid1"].view(B, H, W, -1), self.dwconv.dwconv.weight, self.dwconv.dwconv.bias,
+                                         d_h2.view(B, H, W, -1)).view(B, N, -1)
+        return ops.gemm(d_h1, fc1t)
 
 
 class Attention(nn.Module):
@@ -106,21 +120,45 @@ class Attention(nn.Module):
         self._packs = _PackCache()
         self.apply(_init_weights)
 
-    def forward_tokens(self, x, H, W, res):
+    def forward_tokens(self, x, H, W, res, tape=None):
         """x = norm1(tokens) [B,N,C]; returns proj(attn) + res."""
         B, N, C = x.shape
         q = ops.gemm(x, self.q.weight, shift=self.q.bias)
+        x_sr = None
         if self.sr_ratio > 1:
             sr = self.sr_ratio
             wsr = self._packs.get("sr", [self.sr.weight], lambda: ops.pack_conv_gemm_weight(self.sr.weight))
             col = ops.im2col(x.view(B, H, W, C), sr, sr, 0, wsr.shape[1])
-            x_ = ops.gemm(col.view(B, -1, wsr.shape[1]), wsr, shift=self.sr.bias)
-            x_ = ops.layernorm(x_, self.norm.weight, self.norm.bias, self.norm.eps)
+            x_sr = ops.gemm(col.view(B, -1, wsr.shape[1]), wsr, shift=self.sr.bias)
+            x_ = ops.layernorm(x_sr, self.norm.weight, self.norm.bias, self.norm.eps)
         else:
             x_ = x
         kv = ops.gemm(x_, self.kv.weight, shift=self.kv.bias)
-        o = ops.sr_attention(q, kv, self.num_heads)
+        if tape is None:
+            o = ops.sr_attention(q, kv, self.num_heads)
+        else:
+            o, lse = ops.sr_attention(q, kv, self.num_heads, want_lse=True)
+            tape.update(q=q, kv=kv, o=o, lse=lse, x_sr=x_sr, H=H, W=W)
         return ops.gemm(o, self.proj.weight, shift=self.proj.bias, res=res)
+
+    def backward_tokens(self, dy, tape):
+        """dy = d/d(proj output) -> d/d(x) where x = norm1(tokens) (input gradient only)."""
+        B, N, C = dy.shape
+        H, W = tape["H"], tape["W"]
+        pt = self._packs.get("projT", [self.proj.weight], lambda: ops.transpose_pad(self.proj.weight))
+        qt = self._packs.get("qT", [self.q.weight], lambda: ops.transpose_pad(self.q.weight))
+        kvt = self._packs.get("kvT", [self.kv.weight], lambda: ops.transpose_pad(self.kv.weight))
+        d_o = ops.gemm(dy, pt)
+        dq, dkv = ops.sr_attention_bwd(tape["q"], tape["kv"], tape["o"], d_o, tape["lse"], self.num_heads)
+        d_xkv = ops.gemm(dkv, kvt)
+        if self.sr_ratio > 1:
+            sr = self.sr_ratio
+            wsr = self._packs.get("sr", [self.sr.weight], lambda: ops.pack_conv_gemm_weight(self.sr.weight))
+            wsrt = self._packs.get("srT", [self.sr.weight], lambda: ops.transpose_pad(wsr))
+            d_sr = ops.layernorm_bwd(tape["x_sr"], self.norm.weight, d_xkv, self.norm.eps)
+            d_col = ops.gemm(d_sr, wsrt)
+            d_xkv = ops.col2im(d_col, B, H, W, C, sr, sr, 0).view(B, N, C)
+        return ops.gemm(dq, qt, res=d_xkv)
 
 
 class Block(nn.Module):
@@ -137,12 +175,23 @@ class Block(nn.Module):
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
         self.apply(_init_weights)
 
-    def forward_tokens(self, x, H, W):
+    def forward_tokens(self, x, H, W, tape=None):
         if self.training and isinstance(self.drop_path, DropPath) and self.drop_path.drop_prob > 0:
             raise NotImplementedError("train-mode DropPath belongs to the training step (not built yet); call .eval()")
-        x = self.attn.forward_tokens(ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps), H, W, res=x)
-        x = self.mlp.forward_tokens(ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps), H, W, res=x)
-        return x
+        t_attn = t_mlp = None
+        if tape is not None:
+            t_attn, t_mlp = {}, {}
+        x1 = self.attn.forward_tokens(ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps), H, W, res=x, tape=t_attn)
+        x2 = self.mlp.forward_tokens(ops.layernorm(x1, self.norm2.weight, self.norm2.bias, self.norm2.eps), H, W, res=x1, tape=t_mlp)
+        if tape is not None:
+            tape.append(dict(x=x, x1=x1, attn=t_attn, mlp=t_mlp))
+        return x2
+
+    def backward_tokens(self, d_x2, t):
+        d_ln2 = self.mlp.backward_tokens(d_x2, t["mlp"])
+        d_x1 = ops.layernorm_bwd(t["x1"], self.norm2.weight, d_ln2, self.norm2.eps, add=d_x2)
+        d_ln1 = self.attn.backward_tokens(d_x1, t["attn"])
+        return ops.layernorm_bwd(t["x"], self.norm1.weight, d_ln1, self.norm1.eps, add=d_x1)
 
 
 def _make_norm(norm_layer, dim):
@@ -171,14 +220,26 @@ class OverlapPatchEmbed(nn.Module):
         self._packs = _PackCache()
         self.apply(_init_weights)
 
-    def forward_nhwc(self, x):
+    def forward_nhwc(self, x, tape=None):
         """x NHWC [B,H,W,Cin] -> tokens [B, OH*OW, D], OH, OW."""
         k = self.patch_size[0]
         w = self._packs.get("w", [self.proj.weight], lambda: ops.pack_conv_gemm_weight(self.proj.weight))
         col = ops.im2col(x, k, self.stride, k // 2, w.shape[1])
         B, OH, OW, _ = col.shape
         t = ops.gemm(col.view(B, OH * OW, -1), w, shift=self.proj.bias)
+        if tape is not None:
+            tape.append(dict(pre=t, in_shape=tuple(x.shape)))
         return ops.layernorm(t, self.norm.weight, self.norm.bias, self.norm.eps), OH, OW
+
+    def backward_nhwc(self, d_tok, t):
+        """d/d(tokens after the norm) -> d/d(input map) NHWC."""
+        k = self.patch_size[0]
+        B, H, W, Cin = t["in_shape"]
+        w = self._packs.get("w", [self.proj.weight], lambda: ops.pack_conv_gemm_weight(self.proj.weight))
+        wt = self._packs.get("wT", [self.proj.weight], lambda: ops.transpose_pad(w))
+        d_pre = ops.layernorm_bwd(t["pre"], self.norm.weight, d_tok, self.norm.eps)
+        d_col = ops.gemm(d_pre, wt)
+        return ops.col2im(d_col, B, H, W, Cin, k, self.stride, k // 2)
 
 
 class MixVisionTransformer(nn.Module):
@@ -219,19 +280,39 @@ class MixVisionTransformer(nn.Module):
     def freeze_patch_emb(self):
         self.patch_embed1.requires_grad = False
 
-    def forward_features_nhwc(self, x):
-        """x NHWC [B,H,W,3] -> 4 NHWC stage outputs [B,H/4,W/4,D0] ... [B,H/32,W/32,D3]."""
+    def forward_features_nhwc(self, x, tape=None):
+        """x NHWC [B,H,W,3] -> 4 NHWC stage outputs [B,H/4,W/4,D0] ... [B,H/32,W/32,D3].
+        tape (list): filled with what the input-gradient pass needs (one dict per stage)."""
         outs = []
         B = x.shape[0]
         for s in range(4):
-            t, H, W = getattr(self, "patch_embed%d" % (s + 1)).forward_nhwc(x)
+            st = None if tape is None else dict(pe=[], blocks=[])
+            t, H, W = getattr(self, "patch_embed%d" % (s + 1)).forward_nhwc(x, None if st is None else st["pe"])
             for blk in getattr(self, "block%d" % (s + 1)):
-                t = blk.forward_tokens(t, H, W)
+                t = blk.forward_tokens(t, H, W, None if st is None else st["blocks"])
             n = getattr(self, "norm%d" % (s + 1))
+            if st is not None:
+                st.update(pre_norm=t, H=H, W=W)
+                tape.append(st)
             t = ops.layernorm(t, n.weight, n.bias, n.eps)
             x = t.view(B, H, W, -1)
             outs.append(x)
         return outs
+
+    def backward_features_nhwc(self, d_feats, tape):
+        """d/d(4 stage outputs, NHWC) -> d/d(input) NHWC [B,H,W,3]."""
+        d_next = None
+        for s in (3, 2, 1, 0):
+            st = tape[s]
+            d_out = d_feats[s] if d_next is None else ops.add(d_feats[s].contiguous(), d_next)
+            B = d_out.shape[0]
+            n = getattr(self, "norm%d" % (s + 1))
+            d_t = ops.layernorm_bwd(st["pre_norm"], n.weight, d_out.reshape(B, st["H"] * st["W"], -1), n.eps)
+            blocks = getattr(self, "block%d" % (s + 1))
+            for i in range(len(blocks) - 1, -1, -1):
+                d_t = blocks[i].backward_tokens(d_t, st["blocks"][i])
+            d_next = getattr(self, "patch_embed%d" % (s + 1)).backward_nhwc(d_t, st["pe"][0])
+        return d_next
 
     def forward_features(self, x):
         ops.require_no_grad(x)

@@ -253,14 +253,44 @@ class WeTr(nn.Module):
         param_groups[2].append(self.classifier.weight)
         return param_groups
 
-    def forward_nhwc(self, x):
+    def forward_nhwc(self, x, tape=None):
         """x NHWC [B,H,W,3] (normalised) -> logits NHWC [B,H/4,W/4,num_classes]."""
-        return self.decoder.forward_nhwc(self.encoder.forward_features_nhwc(x))
+        enc_tape = None if tape is None else []
+        head_tape = None if tape is None else {}
+        out = self.decoder.forward_nhwc(self.encoder.forward_features_nhwc(x, enc_tape), head_tape)
+        if tape is not None:
+            tape.update(enc=enc_tape, head=head_tape)
+        return out
+
+    def backward_nhwc(self, d_logits32, tape):
+        """d/d(logits) as NHWC [B,H/4,W/4,32] (zero padded) -> d/d(input) NHWC [B,H,W,3]."""
+        d_feats = self.decoder.backward_nhwc(d_logits32, tape["head"])
+        return self.encoder.backward_features_nhwc(d_feats, tape["enc"])
 
     def forward(self, x):
-        ops.require_no_grad(x)
+        if torch.is_grad_enabled() and x.requires_grad:
+            return _WeTrFn.apply(x, self)
         with torch.no_grad():
             return ops.nhwc_to_nchw(self.forward_nhwc(ops.nchw_to_nhwc(x)))
+
+
+class _WeTrFn(torch.autograd.Function):
+    """Input-gradient autograd node of WeTr: hand-written reverse pass, no parameter gradients (the PGD loop
+    only consumes d loss / d input)."""
+
+    @staticmethod
+    def forward(ctx, x, module):
+        tape = {}
+        out = ops.nhwc_to_nchw(module.forward_nhwc(ops.nchw_to_nhwc(x.detach()), tape))
+        ctx.tape, ctx.module = tape, module
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        d32 = ops.nchw_to_nhwc_pad(d_out, 32)
+        d_x = ctx.module.backward_nhwc(d32, ctx.tape)
+        ctx.tape = None
+        return ops.nhwc_to_nchw(d_x), None
 
 
 class _CompositeBase(nn.Module):

@@ -50,7 +50,7 @@ class SegFormerHead(nn.Module):
         self.linear_pred = Conv2dParams(embedding_dim, self.num_classes, kernel_size=1)
         self._packs = _PackCache()
 
-    def forward_nhwc(self, feats):
+    def forward_nhwc(self, feats, tape=None):
         """feats: 4 NHWC maps -> logits NHWC [B,H/4,W/4,num_classes]."""
         if self.training:
             raise NotImplementedError("train-mode head (Dropout2d, BatchNorm batch statistics) is not built yet; call .eval()")
@@ -66,8 +66,31 @@ class SegFormerHead(nn.Module):
         scale, shift = _bn_scale_shift(self.linear_fuse.bn, self._packs)
         fw = self.linear_fuse.conv.weight.view(E, 4 * E)
         x = ops.gemm(cat, fw, scale=scale, shift=shift, act=ops.ACT_RELU)
+        if tape is not None:
+            tape.update(x=x, shapes=[tuple(c.shape) for c in feats])
         pw = self.linear_pred.weight.view(self.num_classes, E)
         return ops.gemm(x, pw, shift=self.linear_pred.bias)
+
+    def backward_nhwc(self, d_logits, tape):
+        """d_logits NHWC [B,H/4,W/4,32] (channels >= num_classes zero) -> [d_c1, d_c2, d_c3, d_c4] NHWC."""
+        E = self.embedding_dim
+        pw = self.linear_pred.weight.view(self.num_classes, E)
+        fw = self.linear_fuse.conv.weight.view(E, 4 * E)
+        pwt = self._packs.get("predT", [self.linear_pred.weight], lambda: ops.transpose_pad(pw))     # [E, 32]
+        fwt = self._packs.get("fuseT", [self.linear_fuse.conv.weight], lambda: ops.transpose_pad(fw))  # [4E, E]
+        scale, _ = _bn_scale_shift(self.linear_fuse.bn, self._packs)
+        assert d_logits.shape[-1] == pwt.shape[1]
+        d_x = ops.gemm(d_logits, pwt)                                           # [B,H1,W1,E]
+        d_cat = ops.gemm(d_x, fwt, a_mask=tape["x"], a_scale=scale)             # through ReLU and the folded BN
+        grads = [None] * 4
+        for i, (idx, lin) in enumerate(((3, self.linear_c4), (2, self.linear_c3), (1, self.linear_c2))):
+            _, h, w, _ = tape["shapes"][idx]
+            d_y = ops.resize_bilinear_adjoint(d_cat, i * E, E, h, w)
+            lt = self._packs.get("linT%d" % idx, [lin.proj.weight], lambda lin=lin: ops.transpose_pad(lin.proj.weight))
+            grads[idx] = ops.gemm(d_y, lt)
+        l1t = self._packs.get("linT0", [self.linear_c1.proj.weight], lambda: ops.transpose_pad(self.linear_c1.proj.weight))
+        grads[0] = ops.gemm(d_cat, l1t, a_cols=(3 * E, E))
+        return grads
 
     def forward(self, x):
         ops.require_no_grad(*x)

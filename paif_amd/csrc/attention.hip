@@ -19,7 +19,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct AttnArgs {
-  const float* q; const float* kv; float* out;
+  const float* q; const float* kv; float* out; float* lse;
   int B, N, Nk, C, heads;
   float scale;
 };
@@ -114,6 +114,7 @@ __global__ __launch_bounds__(256) void sr_attention_kernel(AttnArgs a) {
   }
 
   // ---- normalise and store: lane (h, j) holds dims 32*dt + 8*g + 4*h + (0..3) of query j ----
+  if (a.lse && h == 0 && q0 + p < a.N) a.lse[((size_t)b * a.heads + hd) * a.N + q0 + p] = m_run + logf(l_run);
   if (q0 + p < a.N) {
     const float inv = 1.0f / l_run;
     float* orow = a.out + ((size_t)b * a.N + q0 + p) * C + hd * D;
@@ -149,13 +150,13 @@ int launch_attn(const AttnArgs& a, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int paif_sr_attention_fwd(const float* q, const float* kv, float* out, int B, int N, int Nk, int C, int heads,
-                                     paif_stream_t stream) {
+extern "C" int paif_sr_attention_fwd(const float* q, const float* kv, float* out, float* lse, int B, int N, int Nk, int C,
+                                     int heads, paif_stream_t stream) {
   PAIF_REQUIRE(q && kv && out && B > 0 && N > 0 && Nk > 0 && heads > 0, PAIF_EINVAL, "sr_attention: bad arguments");
   PAIF_REQUIRE(C % heads == 0, PAIF_EINVAL, "sr_attention: C=%d not divisible by heads=%d", C, heads);
   const int D = C / heads;
   AttnArgs a;
-  a.q = q; a.kv = kv; a.out = out; a.B = B; a.N = N; a.Nk = Nk; a.C = C; a.heads = heads;
+  a.q = q; a.kv = kv; a.out = out; a.lse = lse; a.B = B; a.N = N; a.Nk = Nk; a.C = C; a.heads = heads;
   a.scale = 1.0f / sqrtf((float)D);
   hipStream_t st = paif::as_stream(stream);
   if (D == 64) return launch_attn<64>(a, st);

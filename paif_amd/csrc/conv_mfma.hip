@@ -219,6 +219,209 @@ __global__ __launch_bounds__(NTHREADS, 3) void conv_mfma_f32(ConvArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Split-bf16 ("bf16x3") variant: every fp32 operand x is split into hi = bf16(x) and lo = bf16(x - hi)
+// and the product is formed as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation
+// (the dropped lo*lo term is 2^-16 relative to the product).  3 bf16 MFMAs of K=16 replace 8 fp32 MFMAs of
+// K=2: 5.3x less matrix-pipe time at ~1e-5 relative accuracy, which keeps the fp32 parity tolerance while
+// moving the k x k convs from the fp32-MFMA roof to (nearly) the HBM roof.
+//   LDS pixel record (144 B): 32 x bf16 hi | 32 x bf16 lo | 16 B pad (conflict-free ds_read_b128);
+//   A fragment: lane (p = pixel, hh) reads 8 consecutive channels (16 B) of its pixel: channels 16*ks + 8*hh + j;
+//   B fragment: packed weights, lane (n = cout, hh) holds w[n][16*ks + 8*hh + j][tap], hi and lo streams.
+// ---------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  const __bf16 x = (__bf16)a, y = (__bf16)b;
+  return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+}
+
+template <int KH, int DIL>
+__global__ __launch_bounds__(NTHREADS, 3) void conv_mfma_bf16x3(ConvArgs a) {
+  constexpr int CIN = 32;
+  constexpr int P = DIL * (KH - 1) / 2;
+  constexpr int TWH = TW + 2 * P;
+  constexpr int THH = TH + 2 * P;
+  constexpr int PSB = 144;             // pixel record in bytes
+  constexpr int QPP = CIN / 4;
+  constexpr int NKS = CIN / 16;        // K=16 steps per tap
+  constexpr int NTAP = KH * KH;
+  extern __shared__ __align__(16) float lds[];
+  char* ldsb = reinterpret_cast<char*>(lds);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int hh = lane >> 5;
+  const int p = lane & 31;
+
+  const int tile_id = paif::xcd_remap(blockIdx.x, a.nblk);
+  int t = tile_id;
+  const int tx = t % a.tilesX;
+  t /= a.tilesX;
+  const int ty = t % a.tilesY;
+  const int b = t / a.tilesY;
+  const int x0 = tx * TW, y0 = ty * TH;
+
+  f32x16 acc[SEGS_PER_WAVE];
+#pragma unroll
+  for (int s = 0; s < SEGS_PER_WAVE; ++s)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+
+  float in_slope = 0.f;
+  if (a.in_act == 1) in_slope = *a.in_prelu;
+
+  int abase[SEGS_PER_WAVE];
+#pragma unroll
+  for (int s = 0; s < SEGS_PER_WAVE; ++s) abase[s] = ((wave * SEGS_PER_WAVE + s) * TWH + p) * PSB + 16 * hh;
+
+  for (int s = 0; s < a.nsrc; ++s) {
+    if (s > 0) __syncthreads();
+    const float* src = a.src[s];
+    constexpr int TOTAL = THH * TWH * QPP;
+    constexpr int NIT = (TOTAL + NTHREADS - 1) / NTHREADS;
+    constexpr int UB = 6;
+#pragma unroll
+    for (int i0 = 0; i0 < NIT; i0 += UB) {
+      float4 v[UB];
+      int dst[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int idx = tid + (i0 + u) * NTHREADS;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        dst[u] = -1;
+        if (i0 + u < NIT && idx < TOTAL) {
+          const int pix = idx / QPP, q = idx - pix * QPP;
+          const int tyy = pix / TWH, txx = pix - tyy * TWH;
+          const int gy = y0 - P + tyy, gx = x0 - P + txx;
+          dst[u] = pix * PSB + q * 8;
+          if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+            v[u] = *reinterpret_cast<const float4*>(src + ((size_t)(b * a.H + gy) * a.W + gx) * CIN + q * 4);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        if (dst[u] >= 0) {
+          float4 t4 = v[u];
+          if (a.in_act == 1) {
+            t4.x = paif::prelu_f(t4.x, in_slope); t4.y = paif::prelu_f(t4.y, in_slope);
+            t4.z = paif::prelu_f(t4.z, in_slope); t4.w = paif::prelu_f(t4.w, in_slope);
+          } else if (a.in_act == 2) {
+            t4.x = fmaxf(t4.x, 0.f); t4.y = fmaxf(t4.y, 0.f); t4.z = fmaxf(t4.z, 0.f); t4.w = fmaxf(t4.w, 0.f);
+          }
+          const __bf16 hx = (__bf16)t4.x, hy = (__bf16)t4.y, hz = (__bf16)t4.z, hw = (__bf16)t4.w;
+          uint2 hi, lo;
+          hi.x = (unsigned)__builtin_bit_cast(unsigned short, hx) | ((unsigned)__builtin_bit_cast(unsigned short, hy) << 16);
+          hi.y = (unsigned)__builtin_bit_cast(unsigned short, hz) | ((unsigned)__builtin_bit_cast(unsigned short, hw) << 16);
+          lo.x = pack_bf16(t4.x - (float)hx, t4.y - (float)hy);
+          lo.y = pack_bf16(t4.z - (float)hz, t4.w - (float)hw);
+          *reinterpret_cast<uint2*>(ldsb + dst[u]) = hi;
+          *reinterpret_cast<uint2*>(ldsb + dst[u] + 64) = lo;
+        }
+      }
+    }
+    __syncthreads();
+
+    const uint4* wsrc = reinterpret_cast<const uint4*>(a.wpk) + (size_t)s * NTAP * NKS * 2 * 64 + lane;
+    uint4 bcur[NKS * 2], bnxt[NKS * 2];
+#pragma unroll
+    for (int i = 0; i < NKS * 2; ++i) bcur[i] = wsrc[i * 64];
+#pragma unroll 1
+    for (int tap = 0; tap < NTAP; ++tap) {
+      if (tap + 1 < NTAP) {
+#pragma unroll
+        for (int i = 0; i < NKS * 2; ++i) bnxt[i] = wsrc[((tap + 1) * NKS * 2 + i) * 64];
+      }
+      const int dy = tap / KH, dx = tap - dy * KH;
+      const int toff = (dy * DIL * TWH + dx * DIL) * PSB;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, bcur[2 * ks]);
+        const bf16x8 bl = __builtin_bit_cast(bf16x8, bcur[2 * ks + 1]);
+#pragma unroll
+        for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) {
+          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ldsb + abase[sg] + toff + 32 * ks);
+          const bf16x8 al = *reinterpret_cast<const bf16x8*>(ldsb + abase[sg] + toff + 64 + 32 * ks);
+          acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[sg], 0, 0, 0);
+          acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[sg], 0, 0, 0);
+          acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[sg], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NKS * 2; ++i) bcur[i] = bnxt[i];
+    }
+  }
+
+  const bool full = (y0 + TH <= a.H) && (x0 + TW <= a.W) && (a.cout == 32);
+  float psum;
+  if (full) psum = epilogue<true>(a, acc, b, y0, x0, wave, hh, p);
+  else psum = epilogue<false>(a, acc, b, y0, x0, wave, hh, p);
+  if (a.pool_partial) {
+    psum += __shfl_xor(psum, 32);
+    __syncthreads();
+    if (lane < 32) lds[wave * 32 + lane] = psum;
+    __syncthreads();
+    if (tid < 32) a.pool_partial[(size_t)tile_id * 32 + tid] = lds[tid] + lds[32 + tid] + lds[64 + tid] + lds[96 + tid];
+  }
+}
+
+template <int KH, int DIL>
+int launch_bf16x3(const ConvArgs& a, hipStream_t st) {
+  constexpr int P = DIL * (KH - 1) / 2;
+  constexpr size_t lds_bytes = (size_t)(TH + 2 * P) * (TW + 2 * P) * 144;
+  static_assert(lds_bytes <= 160 * 1024, "tile does not fit LDS");
+  if (lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_bf16x3<KH, DIL>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) {
+      paif::set_error("conv2d(bf16x3): cannot raise dynamic LDS to %zu: %s", lds_bytes, hipGetErrorString(e));
+      return (int)e;
+    }
+  }
+  hipLaunchKernelGGL((conv_mfma_bf16x3<KH, DIL>), dim3(a.nblk), dim3(NTHREADS), lds_bytes, st, a);
+  PAIF_LAUNCH_CHECK("conv2d(bf16x3)");
+  return 0;
+}
+
+// w [cout][nsrc*32][kh][kh] fp32 -> wpk[src][tap][ks][hi|lo][64 lanes][8 bf16]
+__global__ void pack_weight_bf16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpk, int cout, int nsrc,
+                                          int kh) {
+  const int ntap = kh * kh;
+  const int total = nsrc * ntap * 2 * 2 * 64 * 8;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int j = idx & 7, lane = (idx >> 3) & 63, part = (idx >> 9) & 1, ks = (idx >> 10) & 1;
+    int rest = idx >> 11;
+    const int tap = rest % ntap;
+    const int s = rest / ntap;
+    const int n = lane & 31, hh = lane >> 5;
+    const int c = s * 32 + 16 * ks + 8 * hh + j;
+    const float v = (n < cout) ? w[((size_t)n * (nsrc * 32) + c) * ntap + tap] : 0.f;
+    const __bf16 hi = (__bf16)v;
+    const __bf16 out = part == 0 ? hi : (__bf16)(v - (float)hi);
+    wpk[idx] = __builtin_bit_cast(unsigned short, out);
+  }
+}
+
+// decomposition 1x1 (see pack_decomp1x1_kernel) in the bf16x3 stream layout
+__global__ void pack_decomp1x1_bf16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpk) {
+  const int total = 3 * 2 * 2 * 64 * 8;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int j = idx & 7, lane = (idx >> 3) & 63, part = (idx >> 9) & 1, ks = (idx >> 10) & 1, s = idx >> 11;
+    const int n = lane & 31, hh = lane >> 5;
+    const int c = 16 * ks + 8 * hh + j;
+    const float* wn = w + n * 128;
+    float v;
+    if (s == 0) v = wn[64 + c] + wn[96 + c];
+    else if (s == 1) v = wn[c] - wn[64 + c];
+    else v = wn[32 + c] - wn[96 + c];
+    const __bf16 hi = (__bf16)v;
+    const __bf16 out = part == 0 ? hi : (__bf16)(v - (float)hi);
+    wpk[idx] = __builtin_bit_cast(unsigned short, out);
+  }
+}
+
 template <int KH, int DIL, int CIN>
 int launch(const ConvArgs& a, hipStream_t st) {
   constexpr int P = DIL * (KH - 1) / 2;
@@ -309,7 +512,22 @@ int paif_conv2d_fwd(const paif_conv_desc* d, int B, int H, int W, paif_stream_t 
   a.tilesX = (W + TW - 1) / TW; a.tilesY = (H + TH - 1) / TH; a.nblk = B * a.tilesX * a.tilesY;
   hipStream_t st = paif::as_stream(stream);
   PAIF_REQUIRE(d->cin == 32 || d->cin == 16, PAIF_ENOSUP, "conv2d: cin=%d", d->cin);
+  PAIF_REQUIRE(d->precision == PAIF_CONV_F32 || d->precision == PAIF_CONV_BF16X3, PAIF_EINVAL, "conv2d: precision=%d", d->precision);
   const int key = d->kh * 100 + d->dil * 10 + (d->cin == 32 ? 0 : 1);
+  if (d->precision == PAIF_CONV_BF16X3) {
+    switch (key) {
+      case 110: return launch_bf16x3<1, 1>(a, st);
+      case 310: return launch_bf16x3<3, 1>(a, st);
+      case 320: return launch_bf16x3<3, 2>(a, st);
+      case 510: return launch_bf16x3<5, 1>(a, st);
+      case 520: return launch_bf16x3<5, 2>(a, st);
+      case 710: return launch_bf16x3<7, 1>(a, st);
+      case 720: return launch_bf16x3<7, 2>(a, st);
+      default: break;
+    }
+    paif::set_error("conv2d(bf16x3): kernel %dx%d dil %d cin %d not built", d->kh, d->kh, d->dil, d->cin);
+    return PAIF_ENOSUP;
+  }
   switch (key) {
     case 110: return launch<1, 1, 32>(a, st);
     case 310: return launch<3, 1, 32>(a, st);
@@ -323,6 +541,25 @@ int paif_conv2d_fwd(const paif_conv_desc* d, int B, int H, int W, paif_stream_t 
   }
   paif::set_error("conv2d: kernel %dx%d dil %d cin %d not built", d->kh, d->kh, d->dil, d->cin);
   return PAIF_ENOSUP;
+}
+
+int paif_pack_conv_weight_bf16x3(const float* w, float* wpk, int cout, int nsrc, int kh, paif_stream_t stream) {
+  PAIF_REQUIRE(w && wpk, PAIF_EINVAL, "pack_conv_weight_bf16x3: null pointer");
+  PAIF_REQUIRE(cout >= 1 && cout <= 32 && nsrc >= 1 && nsrc <= 3 && kh >= 1 && kh <= 7, PAIF_ENOSUP,
+               "pack_conv_weight_bf16x3: cout=%d nsrc=%d kh=%d", cout, nsrc, kh);
+  const int total = nsrc * kh * kh * 2048;
+  hipLaunchKernelGGL(pack_weight_bf16x3_kernel, dim3((total + 255) / 256), dim3(256), 0, paif::as_stream(stream), w,
+                     reinterpret_cast<unsigned short*>(wpk), cout, nsrc, kh);
+  PAIF_LAUNCH_CHECK("pack_conv_weight_bf16x3");
+  return 0;
+}
+
+int paif_pack_decomp1x1_weight_bf16x3(const float* w, float* wpk, paif_stream_t stream) {
+  PAIF_REQUIRE(w && wpk, PAIF_EINVAL, "pack_decomp1x1_weight_bf16x3: null pointer");
+  hipLaunchKernelGGL(pack_decomp1x1_bf16x3_kernel, dim3(24), dim3(256), 0, paif::as_stream(stream), w,
+                     reinterpret_cast<unsigned short*>(wpk));
+  PAIF_LAUNCH_CHECK("pack_decomp1x1_weight_bf16x3");
+  return 0;
 }
 
 int paif_pack_conv_weight(const float* w, float* wpk, int cout, int nsrc, int cin, int kh, paif_stream_t stream) {

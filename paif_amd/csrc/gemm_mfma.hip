@@ -22,6 +22,7 @@ constexpr int BM = 128, BN = 64, BK = 32, LDS_STRIDE = BK + 4;
 
 struct GemmArgs {
   const float* A; const float* W; const float* scale; const float* shift; const float* res; float* C;
+  const float* a_mask; const float* a_scale;
   int M, N, K, lda, ldc, ldres, act;
   int tilesN, nblk;
 };
@@ -53,6 +54,15 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32(GemmArgs a) {
     for (int i = 0; i < 4; ++i) {
       const int m = m0 + srow + 32 * i;
       va[i] = (m < a.M) ? *reinterpret_cast<const float4*>(a.A + (size_t)m * a.lda + k0 + sq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a.a_mask && m < a.M) {  // dgrad prologue: ReLU mask and per-column scale (folded BatchNorm)
+        const float4 mk = *reinterpret_cast<const float4*>(a.a_mask + (size_t)m * a.lda + k0 + sq * 4);
+        va[i].x = mk.x > 0.f ? va[i].x : 0.f; va[i].y = mk.y > 0.f ? va[i].y : 0.f;
+        va[i].z = mk.z > 0.f ? va[i].z : 0.f; va[i].w = mk.w > 0.f ? va[i].w : 0.f;
+      }
+      if (a.a_scale) {
+        const float4 sc4 = *reinterpret_cast<const float4*>(a.a_scale + k0 + sq * 4);
+        va[i].x *= sc4.x; va[i].y *= sc4.y; va[i].z *= sc4.z; va[i].w *= sc4.w;
+      }
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -110,14 +120,25 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32(GemmArgs a) {
 
 }  // namespace
 
+extern "C" int paif_gemm_masked_fwd(const float* A, int lda, const float* a_mask, const float* a_scale, const float* W,
+                                    const float* scale, const float* shift, int act, const float* res, int ldres, float* C,
+                                    int ldc, int M, int N, int K, paif_stream_t stream);
+
 extern "C" int paif_gemm_fwd(const float* A, int lda, const float* W, const float* scale, const float* shift, int act,
                              const float* res, int ldres, float* C, int ldc, int M, int N, int K, paif_stream_t stream) {
+  return paif_gemm_masked_fwd(A, lda, nullptr, nullptr, W, scale, shift, act, res, ldres, C, ldc, M, N, K, stream);
+}
+
+extern "C" int paif_gemm_masked_fwd(const float* A, int lda, const float* a_mask, const float* a_scale, const float* W,
+                                    const float* scale, const float* shift, int act, const float* res, int ldres, float* C,
+                                    int ldc, int M, int N, int K, paif_stream_t stream) {
   PAIF_REQUIRE(A && W && C, PAIF_EINVAL, "gemm: null pointer");
   PAIF_REQUIRE(M > 0 && N > 0 && K > 0, PAIF_EINVAL, "gemm: empty shape %dx%dx%d", M, N, K);
   PAIF_REQUIRE(K % 32 == 0, PAIF_ENOSUP, "gemm: K=%d must be a multiple of 32 (pad the operands)", K);
   PAIF_REQUIRE(lda >= K && ldc >= N && (lda % 4) == 0, PAIF_EINVAL, "gemm: bad leading dimensions lda=%d ldc=%d", lda, ldc);
   PAIF_REQUIRE(act >= 0 && act <= 2, PAIF_EINVAL, "gemm: act=%d", act);
   GemmArgs a;
+  a.a_mask = a_mask; a.a_scale = a_scale;
   a.A = A; a.W = W; a.scale = scale; a.shift = shift; a.res = res; a.C = C;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldres = res ? ldres : 0; a.act = act;
   a.tilesN = (N + BN - 1) / BN;

@@ -329,3 +329,24 @@ int paif_nchw_to_nhwc_fwd(const float* x, float* y, int B, int HW, int C, paif_s
 }
 
 }  // extern "C"
+
+// NCHW [B,C,HW] -> NHWC [B,HW,CP] with zero padding of channels [C,CP) (dlogits entering the dgrad GEMM)
+namespace {
+__global__ void nchw_to_nhwc_pad_kernel(const float* __restrict__ x, float* __restrict__ y, int B, size_t HW, int C, int CP) {
+  const size_t total = (size_t)B * HW * CP;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % CP);
+    const size_t t = i / CP;
+    const size_t px = t % HW, b = t / HW;
+    y[i] = c < C ? x[(b * C + c) * HW + px] : 0.f;
+  }
+}
+}  // namespace
+
+extern "C" int paif_nchw_to_nhwc_pad_fwd(const float* x, float* y, int B, int HW, int C, int CP, paif_stream_t stream) {
+  PAIF_REQUIRE(x && y && B > 0 && HW > 0 && C > 0 && CP >= C, PAIF_EINVAL, "nchw_to_nhwc_pad: bad arguments");
+  hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel, dim3(grid_for((size_t)B * HW * CP, 256)), dim3(256), 0, paif::as_stream(stream), x, y, B,
+                     (size_t)HW, C, CP);
+  PAIF_LAUNCH_CHECK("nchw_to_nhwc_pad");
+  return 0;
+}

@@ -54,7 +54,7 @@ class _PackCache:
         self._store = {}
 
     def get(self, name, params, builder):
-        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in params)
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in params) + (ops.CONFIG["conv_precision"],)
         hit = self._store.get(name)
         if hit is None or hit[0] != key:
             hit = (key, builder())

@@ -13,6 +13,29 @@ import torch
 from . import _lib
 
 ACT_NONE, ACT_PRELU, ACT_RELU = 0, 1, 2
+ACT_GELU = 1  # paif_gemm_fwd's act code 1 is GELU (the conv's code 1 is PReLU)
+
+# Arithmetic of the dense k x k convs (cin = 32):
+#   "f32"    -- v_mfma_f32_32x32x2_f32, bit-exact fp32 products (parity ~1e-6 vs the fp32 reference)
+#   "bf16x3" -- split-bf16: hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate
+#               (~1e-5 relative; 5.3x less matrix-pipe time -> the convs become HBM-bound)
+CONFIG = {"conv_precision": "bf16x3"}
+_PREC_CODE = {"f32": 0, "bf16x3": 1}
+
+
+def set_conv_precision(mode):
+    if mode not in _PREC_CODE:
+        raise ValueError("conv precision must be one of %s" % sorted(_PREC_CODE))
+    CONFIG["conv_precision"] = mode
+
+
+class PackedWeight:
+    """Packed MFMA B-operand stream + the precision it was packed for."""
+
+    __slots__ = ("data", "precision")
+
+    def __init__(self, data, precision):
+        self.data, self.precision = data, precision
 
 
 def lib():
@@ -156,22 +179,34 @@ def guided_filter_pair(guide, y, eps=(0.001, 0.0001)):
     return lf
 
 
-def pack_conv_weight(w, nsrc, cin, kh):
-    """w: [cout, nsrc*cin, kh, kh] -> packed MFMA B-operand stream."""
+def pack_conv_weight(w, nsrc, cin, kh, precision=None):
+    """w: [cout, nsrc*cin, kh, kh] -> packed MFMA B-operand stream (PackedWeight)."""
     cout = w.shape[0]
     assert tuple(w.shape) == (cout, nsrc * cin, kh, kh), (tuple(w.shape), nsrc, cin, kh)
+    precision = precision or CONFIG["conv_precision"]
+    if cin != 32:
+        precision = "f32"  # the split-bf16 kernel is built for 32-channel sources
     L = lib()
     wpk = torch.empty(L.paif_conv_wpk_floats(nsrc, cin, kh), device=w.device, dtype=torch.float32)
-    _lib.check(L.paif_pack_conv_weight(_p(w.detach().contiguous()), _p(wpk), cout, nsrc, cin, kh, _stream()), "pack_conv_weight")
-    return wpk
+    wc = w.detach().contiguous()
+    if precision == "bf16x3":
+        _lib.check(L.paif_pack_conv_weight_bf16x3(_p(wc), _p(wpk), cout, nsrc, kh, _stream()), "pack_conv_weight_bf16x3")
+    else:
+        _lib.check(L.paif_pack_conv_weight(_p(wc), _p(wpk), cout, nsrc, cin, kh, _stream()), "pack_conv_weight")
+    return PackedWeight(wpk, precision)
 
 
-def pack_decomp1x1_weight(w):
+def pack_decomp1x1_weight(w, precision=None):
     assert tuple(w.shape) == (32, 128, 1, 1)
+    precision = precision or CONFIG["conv_precision"]
     L = lib()
     wpk = torch.empty(L.paif_conv_wpk_floats(3, 32, 1), device=w.device, dtype=torch.float32)
-    _lib.check(L.paif_pack_decomp1x1_weight(_p(w.detach().contiguous()), _p(wpk), _stream()), "pack_decomp1x1_weight")
-    return wpk
+    wc = w.detach().contiguous()
+    if precision == "bf16x3":
+        _lib.check(L.paif_pack_decomp1x1_weight_bf16x3(_p(wc), _p(wpk), _stream()), "pack_decomp1x1_weight_bf16x3")
+    else:
+        _lib.check(L.paif_pack_decomp1x1_weight(_p(wc), _p(wpk), _stream()), "pack_decomp1x1_weight")
+    return PackedWeight(wpk, precision)
 
 
 def bn_fold(weight, bias, mean, var, eps):
@@ -199,7 +234,8 @@ def conv2d(srcs, wpk, kh, dil=1, cin=32, cout=32, in_act=ACT_NONE, in_prelu=None
         d.res[i] = _p(res[i]) if i < len(res) else None
     for r in res:
         assert tuple(r.shape) == (B, H, W, cout)
-    d.nsrc, d.cin, d.wpk, d.kh, d.dil = len(srcs), cin, _p(wpk), kh, dil
+    d.nsrc, d.cin, d.wpk, d.kh, d.dil = len(srcs), cin, _p(wpk.data), kh, dil
+    d.precision = _PREC_CODE[wpk.precision]
     d.in_act, d.in_prelu = in_act, _p(in_prelu)
     d.scale, d.shift = _p(scale), _p(shift)
     d.act, d.prelu, d.alpha = act, _p(prelu), alpha
@@ -208,7 +244,7 @@ def conv2d(srcs, wpk, kh, dil=1, cin=32, cout=32, in_act=ACT_NONE, in_prelu=None
     if pool:
         partial = torch.empty((L.paif_conv2d_blocks(B, H, W), 32), device=out.device, dtype=torch.float32)
     d.pool_partial = _p(partial)
-    tag = "conv_mfma_f32<%d,%d,%d>" % (kh, dil, cin)
+    tag = "conv_mfma_%s<%d,%d,%d>" % (wpk.precision, kh, dil, cin)
     e0 = TIMER.start(tag) if TIMER is not None else None
     _lib.check(L.paif_conv2d_fwd(ctypes.byref(d), B, H, W, _stream()), "conv2d")
     if e0 is not None:
@@ -271,13 +307,23 @@ def add(a, b):
 # ---------------------------------------------------------------------------------------------
 # segmentation network (token tensors [B,N,C] = NHWC)
 # ---------------------------------------------------------------------------------------------
-def gemm(a, w, scale=None, shift=None, act=ACT_NONE, res=None, out=None, out_cols=None, col_offset=0):
-    """a [..., K] (dense) x w [N, K]^T -> [..., N].  scale/shift per output column (bias = shift).
-    `out` (+col_offset) lets a caller write into a channel slice of a wider row-major buffer."""
-    K = a.shape[-1]
+def gemm(a, w, scale=None, shift=None, act=ACT_NONE, res=None, out=None, out_cols=None, col_offset=0,
+         a_cols=None, a_mask=None, a_scale=None):
+    """a [..., K] x w [N, K]^T -> [..., N].  scale/shift per output column (bias = shift).
+    `out` (+col_offset) writes into a channel slice of a wider row-major buffer;
+    `a_cols=(c0, K)` reads a column slice of a wider dense `a` (row stride a.shape[-1]);
+    `a_mask`/`a_scale`: dgrad prologue A' = A * (mask > 0) * a_scale[k]."""
     N = w.shape[0]
+    lda = a.shape[-1]
+    if a_cols is None:
+        K, aptr = lda, _p(a)
+    else:
+        _p(a)
+        c0, K = a_cols
+        assert c0 % 4 == 0 and c0 + K <= lda
+        aptr = ctypes.c_void_p(a.data_ptr() + 4 * c0)
     assert w.shape[1] == K, (tuple(w.shape), K)
-    M = a.numel() // K
+    M = a.numel() // lda
     if out is None:
         out = torch.empty(a.shape[:-1] + (N,), device=a.device, dtype=torch.float32)
         ldc, cptr = N, _p(out)
@@ -287,12 +333,103 @@ def gemm(a, w, scale=None, shift=None, act=ACT_NONE, res=None, out=None, out_col
         cptr = ctypes.c_void_p(out.data_ptr() + 4 * col_offset)
     if res is not None:
         assert res.shape[-1] == N and res.numel() == M * N
+    if a_mask is not None:
+        assert a_cols is None and a_mask.shape == a.shape
     tag = "gemm_mfma_f32"
     e0 = TIMER.start(tag) if TIMER is not None else None
-    _lib.check(lib().paif_gemm_fwd(_p(a), K, _p(w), _p(scale), _p(shift), act, _p(res), N, cptr, ldc, M, N, K, _stream()), "gemm")
+    _lib.check(lib().paif_gemm_masked_fwd(aptr, lda, _p(a_mask), _p(a_scale), _p(w), _p(scale), _p(shift), act, _p(res), N, cptr,
+                                          ldc, M, N, K, _stream()), "gemm")
     if e0 is not None:
         TIMER.stop(tag, e0, 2 * M * N * K, 4 * (M * K + N * K + M * N * (2 if res is not None else 1)))
     return out
+
+
+def transpose_pad(w2d, npad=None):
+    """w [N,K] -> [K,Npad] (zero padded to a multiple of 32): the dgrad GEMM's weight operand."""
+    N, K = w2d.shape
+    npad = npad or (N + 31) // 32 * 32
+    wt = torch.empty((K, npad), device=w2d.device, dtype=torch.float32)
+    _lib.check(lib().paif_transpose_pad_fwd(_p(w2d.detach().contiguous()), _p(wt), N, K, npad, _stream()), "transpose_pad")
+    return wt
+
+
+def layernorm_bwd(x, weight, dy, eps, add=None):
+    C = x.shape[-1]
+    dx = torch.empty_like(x)
+    _lib.check(lib().paif_layernorm_bwd_input(_p(x), _p(weight), _p(dy), _p(add), _p(dx), x.numel() // C, C, eps, _stream()),
+               "layernorm_bwd")
+    return dx
+
+
+def dwconv3_bias_gelu_bwd(x, w, bias, dy):
+    B, H, W, C = x.shape
+    tmp = torch.empty_like(x)
+    dx = torch.empty_like(x)
+    _lib.check(lib().paif_dwconv3_bias_gelu_bwd_input(_p(x), _p(w.detach().contiguous()), _p(bias), _p(dy), _p(tmp), _p(dx), B, H, W, C,
+                                                      _stream()), "dwconv3_bias_gelu_bwd")
+    return dx
+
+
+def col2im(dcol, B, H, W, Cin, k, stride, pad):
+    kpad = dcol.shape[-1]
+    dx = torch.empty((B, H, W, Cin), device=dcol.device, dtype=torch.float32)
+    _lib.check(lib().paif_col2im_fwd(_p(dcol), _p(dx), B, H, W, Cin, k, stride, pad, kpad, _stream()), "col2im")
+    return dx
+
+
+def resize_bilinear_adjoint(dout, coff, C, IH, IW):
+    """dout [B,OH,OW,ldo] -> dx [B,IH,IW,C] (adjoint of resize_bilinear_into on channels [coff,coff+C))."""
+    B, OH, OW, ldo = dout.shape
+    dx = torch.empty((B, IH, IW, C), device=dout.device, dtype=torch.float32)
+    _lib.check(lib().paif_resize_bilinear_adjoint_fwd(_p(dout), _p(dx), B, IH, IW, C, OH, OW, ldo, coff, _stream()),
+               "resize_bilinear_adjoint")
+    return dx
+
+
+def sr_attention_bwd(q, kv, o, dout, lse, heads):
+    B, N, C = q.shape
+    Nk = kv.shape[1]
+    L = lib()
+    nchunk = L.paif_sr_attention_bwd_chunks(B, N, heads)
+    delta = torch.empty((B, heads, N), device=q.device, dtype=torch.float32)
+    dq = torch.empty_like(q)
+    dkv = torch.empty_like(kv)
+    partial = torch.empty((nchunk, B, Nk, 2 * C), device=q.device, dtype=torch.float32)
+    _lib.check(L.paif_sr_attention_bwd_input(_p(q), _p(kv), _p(o), _p(dout.contiguous()), _p(lse), _p(delta), _p(dq), _p(dkv), _p(partial),
+                                             B, N, Nk, C, heads, _stream()), "sr_attention_bwd")
+    return dq, dkv
+
+
+def nchw_to_nhwc_pad(x, cp):
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    y = torch.empty((B, H, W, cp), device=x.device, dtype=torch.float32)
+    _lib.check(lib().paif_nchw_to_nhwc_pad_fwd(_p(x), _p(y), B, H * W, C, cp, _stream()), "nchw_to_nhwc_pad")
+    return y
+
+
+def upsample_ce_fwd(logits, label, ignore_index=255):
+    """logits NHWC [B,IH,IW,C], label int64 [B,OH,OW] -> tensor [2] = (mean NLL over valid px, #valid)."""
+    B, IH, IW, C = logits.shape
+    _, OH, OW = label.shape
+    assert label.dtype == torch.int64 and label.is_cuda and label.is_contiguous()
+    L = lib()
+    nblk = L.paif_upsample_ce_blocks(B, OH, OW)
+    partial = torch.empty(2 * nblk, device=logits.device, dtype=torch.float32)
+    out = torch.empty(2, device=logits.device, dtype=torch.float32)
+    _lib.check(L.paif_upsample_ce_fwd(_p(logits), ctypes.c_void_p(label.data_ptr()), _p(partial), _p(out), B, IH, IW, C, OH, OW,
+                                      ignore_index, _stream()), "upsample_ce_fwd")
+    return out
+
+
+def upsample_ce_bwd(logits, label, gscale, cp=32, ignore_index=255):
+    """-> dlogits NHWC [B,IH,IW,cp] (channels >= C zero); gscale: 1-element device tensor = dloss / count."""
+    B, IH, IW, C = logits.shape
+    _, OH, OW = label.shape
+    dfull = torch.empty((B, OH, OW, cp), device=logits.device, dtype=torch.float32)
+    _lib.check(lib().paif_upsample_ce_bwd(_p(logits), ctypes.c_void_p(label.data_ptr()), _p(gscale), _p(dfull), B, IH, IW, C, OH, OW,
+                                          ignore_index, cp, _stream()), "upsample_ce_bwd")
+    return resize_bilinear_adjoint(dfull, 0, cp, IH, IW)
 
 
 def layernorm(x, weight, bias, eps):
@@ -332,18 +469,19 @@ def dwconv3_bias_gelu(x, w, bias):
     return y
 
 
-def sr_attention(q, kv, heads):
-    """q [B,N,C], kv [B,Nk,2C] -> [B,N,C]."""
+def sr_attention(q, kv, heads, want_lse=False):
+    """q [B,N,C], kv [B,Nk,2C] -> [B,N,C] (and the per-query log-sum-exp [B,heads,N] for the backward)."""
     B, N, C = q.shape
     Nk = kv.shape[1]
     assert kv.shape[2] == 2 * C
     out = torch.empty_like(q)
+    lse = torch.empty((B, heads, N), device=q.device, dtype=torch.float32) if want_lse else None
     tag = "sr_attention"
     e0 = TIMER.start(tag) if TIMER is not None else None
-    _lib.check(lib().paif_sr_attention_fwd(_p(q), _p(kv), _p(out), B, N, Nk, C, heads, _stream()), "sr_attention")
+    _lib.check(lib().paif_sr_attention_fwd(_p(q), _p(kv), _p(out), _p(lse), B, N, Nk, C, heads, _stream()), "sr_attention")
     if e0 is not None:
         TIMER.stop(tag, e0, 4 * B * N * Nk * C, 4 * (2 * B * N * C + 2 * B * Nk * C))
-    return out
+    return (out, lse) if want_lse else out
 
 
 def resize_bilinear_into(x, out, coff):

@@ -101,9 +101,27 @@ def full():
     return r + "  | B=8 fwd %.2f ms -> %.1f pairs/s" % (dt * 1e3, 8 / dt)
 
 
+def full64():
+    from oracle.paif_oracle import FUSION_AT
+    from paif_amd.core.model_fusion_auto import Network_Fusion_Searched
+    net = Network_Fusion_Searched(32, None, FUSION_AT).eval()
+    sd = {k: t(S.formula_tensor("enhance_net." + k, tuple(v.shape))).to(v.dtype) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd); net = net.to(dev)
+    g = G("gf_model_b3_1x480x640")
+    ir, vis, _ = S.make_batch(1, 480, 640)
+    ycc = ops.rgb2ycrcb(t(vis).to(dev))
+    with torch.no_grad():
+        fused = net(t(ir).to(dev), ycc)
+    return "fused vs ref32 %.2e vs ref64 %.2e (ref floor %.2e)" % (maxabs(fused.cpu(), g["fused"]), maxabs(fused.cpu(), g["fused64"]), maxabs(g["fused"], g["fused64"]))
+
+
 if __name__ == "__main__":
     print(torch.cuda.get_device_name(0), "lib", ops.lib().paif_version(), "CUs", ops.lib().paif_device_cus())
-    prims()
-    run("guided filter", gf)
-    run("fusion 48x64", fusion)
-    run("fusion 480x640 + timing", full)
+    for prec in ("f32", "bf16x3"):
+        ops.set_conv_precision(prec)
+        print("=== conv precision", prec, flush=True)
+        prims()
+        run("guided filter", gf)
+        run("fusion 48x64", fusion)
+        run("fusion 480x640 weights", full64)
+        run("fusion 480x640 + timing", full)

@@ -83,3 +83,73 @@ if __name__ == "__main__":
     run("wetr mit_b3", b3)
     if "m" in holder:
         run("full 480x640", lambda: full(holder["m"]))
+
+
+def wetr_bwd(bb):
+    m = Network_MM_Searched(32, O.FUSION_AT, None, None, bb, num_classes=9).eval(); S.load_formula_weights(m); m = m.to(dev)
+    g = G("ge_wetr_" + bb)
+    x = t(G("gd_colour_glue")["seg_in_b2"]).to(dev).requires_grad_(True)
+    logits = m.denoise_net(x)
+    r = t(S.make_feature(41, tuple(logits.shape))).to(dev)
+    (logits * r).sum().backward()
+    d = (x.grad.cpu() - t(g["dx"])).abs()
+    return "logits %.1e dx maxabs %.2e (scale %.2e) rel-l2 %.2e" % (maxabs(logits.detach().cpu(), g["logits"]), float(d.max()), float(np.abs(g["dx"]).max()),
+        float(torch.linalg.norm(x.grad.cpu() - t(g["dx"])) / torch.linalg.norm(t(g["dx"]))))
+
+
+def unit_bwd():
+    out = []
+    # layernorm bwd
+    x = torch.randn(50, 320, requires_grad=True); g_ = torch.randn(320); be = torch.randn(320); dy = torch.randn(50, 320); add = torch.randn(50, 320)
+    torch.nn.functional.layer_norm(x, (320,), g_, be, 1e-6).backward(dy)
+    got = ops.layernorm_bwd(x.detach().to(dev), g_.to(dev), dy.to(dev), 1e-6, add=add.to(dev)).cpu()
+    out.append("ln_bwd %.1e" % maxabs(got, x.grad + add))
+    # dwconv gelu bwd
+    x = torch.randn(2, 9, 11, 64, requires_grad=True); w = torch.randn(64, 1, 3, 3); b = torch.randn(64); dy = torch.randn(2, 9, 11, 64)
+    y = torch.nn.functional.gelu(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w, b, 1, 1, 1, 64)).permute(0, 2, 3, 1)
+    y.backward(dy)
+    got = ops.dwconv3_bias_gelu_bwd(x.detach().to(dev), w.to(dev), b.to(dev), dy.to(dev)).cpu()
+    out.append("dwgelu_bwd %.1e" % maxabs(got, x.grad))
+    # attention bwd
+    for (B, N, Nk, C, heads) in [(2, 200, 45, 128, 2), (1, 130, 300, 64, 1), (2, 96, 6, 64, 2)]:
+        q = torch.randn(B, N, C, requires_grad=True); kv = torch.randn(B, Nk, 2 * C, requires_grad=True); do = torch.randn(B, N, C)
+        hd = C // heads
+        qq = q.view(B, N, heads, hd).permute(0, 2, 1, 3)
+        kk = kv.view(B, Nk, 2, heads, hd).permute(2, 0, 3, 1, 4)
+        ref = (((qq @ kk[0].transpose(-2, -1)) * hd ** -0.5).softmax(-1) @ kk[1]).transpose(1, 2).reshape(B, N, C)
+        ref.backward(do)
+        o, lse = ops.sr_attention(q.detach().to(dev), kv.detach().to(dev), heads, want_lse=True)
+        dq, dkv = ops.sr_attention_bwd(q.detach().to(dev), kv.detach().to(dev), o, do.to(dev), lse, heads)
+        out.append("attn_bwd(%d,%d,%d,%d) dq %.1e dkv %.1e" % (N, Nk, C, heads, maxabs(dq.cpu(), q.grad), maxabs(dkv.cpu(), kv.grad)))
+    # im2col / col2im adjoint, resize adjoint
+    x = torch.randn(2, 13, 17, 8, requires_grad=True)
+    col = torch.nn.functional.unfold(x.permute(0, 3, 1, 2), 3, 1, 1, 2)  # [B, C*9, L]
+    dcol_ref = torch.randn_like(col)
+    col.backward(dcol_ref)
+    # our column order is (ky,kx,c); unfold's is (c,ky,kx)
+    OH, OW = ops.conv_out_size(13, 3, 2, 1), ops.conv_out_size(17, 3, 2, 1)
+    dc = dcol_ref.view(2, 8, 9, OH * OW).permute(0, 3, 2, 1).reshape(2, OH, OW, 72).contiguous()
+    got = ops.col2im(dc.to(dev), 2, 13, 17, 8, 3, 2, 1).cpu()
+    out.append("col2im %.1e" % maxabs(got, x.grad))
+    x = torch.randn(2, 5, 7, 8, requires_grad=True)
+    up = torch.nn.functional.interpolate(x.permute(0, 3, 1, 2), size=(20, 28), mode="bilinear", align_corners=False)
+    dd = torch.randn(2, 20, 28, 16)
+    up.backward(dd[..., 8:].permute(0, 3, 1, 2))
+    got = ops.resize_bilinear_adjoint(dd.to(dev), 8, 8, 5, 7).cpu()
+    out.append("resize_adj %.1e" % maxabs(got, x.grad))
+    # upsample + CE
+    lg = torch.randn(2, 6, 8, 9, requires_grad=True); lab = torch.randint(0, 9, (2, 24, 32)); lab[0, :3] = 255
+    up = torch.nn.functional.interpolate(lg.permute(0, 3, 1, 2), size=(24, 32), mode="bilinear", align_corners=False)
+    loss = torch.nn.functional.cross_entropy(up, lab, ignore_index=255)
+    loss.backward()
+    lc = ops.upsample_ce_fwd(lg.detach().to(dev), lab.to(dev))
+    gs = (1.0 / lc[1:2]).contiguous()
+    dl = ops.upsample_ce_bwd(lg.detach().to(dev), lab.to(dev), gs, cp=32).cpu()
+    out.append("ce loss %.1e dlogits %.1e pad %.1e" % (abs(float(lc[0]) - float(loss)), maxabs(dl[..., :9], lg.grad), float(dl[..., 9:].abs().max())))
+    return " ".join(out)
+
+
+if __name__ == "__main__":
+    run("unit_bwd", unit_bwd)
+    run("wetr_bwd mit_b0", lambda: wetr_bwd("mit_b0"))
+    run("wetr_bwd mit_b3", lambda: wetr_bwd("mit_b3"))
