@@ -107,7 +107,15 @@ typedef struct {
   float* pool_partial;   /* optional */
   int precision;         /* PAIF_CONV_F32 (exact fp32 MFMA) or PAIF_CONV_BF16X3 (split-bf16, ~1e-5 rel.);
                             wpk must have been packed for the same precision */
+  /* ---- backward-pass support (all optional / zero for a plain forward) ---- */
+  float* aux_out;        /* forward: also store the pre-activation z = conv*scale+shift (saved for dgrad) */
+  const float* in_aux;   /* dgrad staging, in_act 3/4: the saved pre-activation of the layer being back-propagated */
+  const float* in_scale; /* in_act 3/4/5: per-input-channel factor (that layer's folded BN scale) or NULL */
+  float in_alpha;        /* in_act 3/4/5: scalar factor (that layer's alpha) */
+  const float* epi_aux;  /* epi_dact: tensor gating the output */
+  int epi_dact;          /* 0 none; 1: out *= (epi_aux >= 0 ? 1 : *prelu); 2: out *= (epi_aux > 0), before residuals */
 } paif_conv_desc;
+/* in_act: 0 none, 1 PReLU, 2 ReLU, 3 src*in_alpha*in_scale[c]*(in_aux>=0?1:*in_prelu), 4 ...*(in_aux>0), 5 src*in_alpha*in_scale[c] */
 #define PAIF_CONV_F32 0
 #define PAIF_CONV_BF16X3 1
 
@@ -148,12 +156,14 @@ int paif_spa_blend_fwd(const float* comp, const float* w, const float* ir, const
  * w1d [1,1,k]. */
 int paif_eca_finish_fwd(const float* o, const float* r, const float* pool_partial, const float* w1d, int k,
                         const float* prelu, float* gate /* [B,32] out: the sigmoid gates */, float* out,
+                        float* u_out /* optional: pre-activation o*gate + r, saved for the backward pass */,
                         int B, int H, int W, paif_stream_t stream);
 
 /* stem_out.1 + .2 + tanh (core/model_fusion_auto.py:617-619,634): Conv2d(16,1,3,pad 1) -> PReLU -> tanh.
  * x NHWC [B,H,W,16]; w [1,16,3,3]; fused [B,H,W]. */
-int paif_tail_fwd(const float* x, const float* w, const float* prelu, float* fused, int B, int H, int W,
-                  paif_stream_t stream);
+int paif_tail_fwd(const float* x, const float* w, const float* prelu, float* fused,
+                  float* z_out /* optional: conv output before PReLU/tanh, saved for the backward pass */,
+                  int B, int H, int W, paif_stream_t stream);
 
 /* plain elementwise a + b (Cell_Chain's residual when it cannot be fused, :445); n floats. */
 int paif_add_fwd(const float* a, const float* b, float* out, size_t n, paif_stream_t stream);
@@ -251,6 +261,62 @@ int paif_upsample_ce_fwd(const float* logits, const long long* label, float* par
                          int IW, int C, int OH, int OW, int ignore_index, paif_stream_t stream);
 int paif_upsample_ce_bwd(const float* logits, const long long* label, const float* gscale, float* dfull, int B, int IH,
                          int IW, int C, int OH, int OW, int ignore_index, int CP, paif_stream_t stream);
+
+/* ---- fusion-network dgrad helpers (dense-conv dgrads go through paif_conv2d_fwd with these weights and the
+ * in_act 3/4/5, epi_dact hooks of paif_conv_desc) ---- */
+/* forward w [Co,Ctot,k,k] -> dgrad weight w.r.t. source channels [coff,coff+cs): wt [cs,Co,k,k],
+ * wt[n][c][ky][kx] = w[c][coff+n][k-1-ky][k-1-kx]  (pack it with paif_pack_conv_weight*, nsrc = 1). */
+int paif_conv_weight_dgrad(const float* w, float* wt, int Co, int Ctot, int k, int coff, int cs, paif_stream_t stream);
+/* Cell_Decom 1x1 [32,128,1,1] -> folded ordinary weight [32,96,1,1] over [x, LF1, LF2]. */
+int paif_fold_decomp1x1_weight(const float* w, float* wf, paif_stream_t stream);
+/* backward of paif_tail_fwd w.r.t. x (NHWC16). */
+int paif_tail_bwd_input(const float* dfused, const float* fused, const float* z, const float* w, const float* prelu,
+                        float* dt16, int B, int H, int W, paif_stream_t stream);
+/* backward of paif_stem_fwd w.r.t. the 1-channel image (PReLU slope must be >= 0: sign(feat) = sign(pre-act)). */
+int paif_stem_bwd_input(const float* dfeat, const float* feat, const float* w, const float* prelu, float* dimg,
+                        int B, int H, int W, paif_stream_t stream);
+/* depthwise dgrad: out = dwconv(dt; rotated w) * (aux > 0) + add   (aux, add optional). */
+int paif_dwconv_bwd_input(const float* dt, const float* w, const float* aux, const float* add, float* out, int k, int dil,
+                          int B, int H, int W, paif_stream_t stream);
+/* backward of paif_eca_finish_fwd: d_o, d_r from dout; partial: B*paif_eca_bwd_blocks(H,W)*32 floats, coef: B*32. */
+int paif_eca_bwd_blocks(int H, int W);
+int paif_eca_bwd_input(const float* dout, const float* u, const float* o, const float* gate, const float* w1d, int k,
+                       const float* prelu, float* partial, float* coef, float* d_o, float* d_r, int B, int H, int W,
+                       paif_stream_t stream);
+/* backward of paif_channel_pool2_fwd + paif_spa_blend_fwd: d_ir, d_vis (+ optional add_*); dpre: [B,H,W] scratch. */
+int paif_spa_blend_bwd_input(const float* dagg, const float* w, const float* ir, const float* vis, const float* s,
+                             const float* add_ir, const float* add_vis, float* dpre, float* d_ir, float* d_vis,
+                             int B, int H, int W, paif_stream_t stream);
+/* backward of the guided-filter pair (+ get_residue): dlf [2][B,H,W,32] -> dy [B,H,W,32] (guide gradient routed to
+ * the arg-max/arg-min channels; + optional add).  gstat [B,H,W,2], t_my/t_mgy [B,H,W,32], t_g [B,H,W,4]: scratch. */
+int paif_guided_filter_bwd_input(const float* guide, const float* y, const float* ab, const float* dlf, float eps0,
+                                 float eps1, const float* add, float* gstat, float* t_my, float* t_mgy, float* t_g,
+                                 float* dy, int B, int H, int W, paif_stream_t stream);
+
+/* ---- glue backward + PGD update ---- */
+/* backward of paif_recompose_clamp_fwd + paif_minmax_normalize_fwd: dseg NCHW [B,3,H,W] -> dfused [B,H,W]
+ * (+ optional dfused_direct), dcrcb [B,2,H,W].  minmax: the 2 floats paif_minmax_normalize_fwd wrote.
+ * torch semantics: clamp passes gradient where 0 <= r <= 1; min/max gradients are spread evenly over equal elements.
+ * partial: 4 * paif_glue_bwd_blocks floats. */
+int paif_glue_bwd_blocks(int B, int H, int W);
+int paif_glue_bwd_input(const float* dseg, const float* fused, const float* ycc, const float* minmax,
+                        const float* dfused_direct, float* partial, float* dfused, float* dcrcb, int B, int H, int W,
+                        paif_stream_t stream);
+/* backward of paif_rgb2ycrcb_fwd: (dY [B,H,W], dcrcb [B,2,H,W]) -> dvis NCHW [B,3,H,W]. */
+int paif_rgb2ycrcb_bwd_input(const float* dY, const float* dcrcb, float* dvis, int B, int H, int W, paif_stream_t stream);
+/* attack/attack.py:504-512: delta <- clamp(clamp(delta + alpha*sign(grad_sum), -eps, eps), 0 - X, 1 - X), in place. */
+int paif_pgd_step(float* delta, const float* grad_sum, const float* X, float alpha, float eps, size_t n,
+                  paif_stream_t stream);
+/* y += a*x (the never-zeroed delta.grad of the reference's attack loop accumulates, attack/attack.py:501). */
+int paif_axpy(float* y, const float* x, float a, size_t n, paif_stream_t stream);
+
+/* ---- evaluation harness (test_original.py:180,206-211; robust_test.py:181-212) ---- */
+/* F.interpolate(bilinear, align_corners=False) to [OH,OW] + argmax over classes: logits NHWC [B,IH,IW,C] -> pred int64 [B,OH,OW]. */
+int paif_upsample_argmax_fwd(const float* logits, long long* pred, int B, int IH, int IW, int C, int OH, int OW,
+                             paif_stream_t stream);
+/* conf[l*ncls + p] += #pixels with label l and prediction p (uint64, pairs outside [0,ncls) dropped) -- accumulates. */
+int paif_confusion_matrix_accum(const long long* label, const long long* pred, unsigned long long* conf, size_t n, int ncls,
+                                paif_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,8 @@ class ConvDesc(Structure):
         ("src", F * 3), ("nsrc", c_int), ("cin", c_int), ("wpk", F), ("kh", c_int), ("dil", c_int),
         ("in_act", c_int), ("in_prelu", F), ("scale", F), ("shift", F), ("act", c_int), ("prelu", F),
         ("alpha", c_float), ("res", F * 3), ("out", F), ("cout", c_int), ("pool_partial", F),
-        ("precision", c_int),
+        ("precision", c_int), ("aux_out", F), ("in_aux", F), ("in_scale", F), ("in_alpha", c_float), ("epi_aux", F),
+        ("epi_dact", c_int),
     ]
 
 
@@ -48,8 +49,8 @@ SIGNATURES = {
     "paif_dwconv_fwd": (c_int, [F, F, F, c_int, c_int, c_int, c_int, c_int, c_int, F]),
     "paif_channel_pool2_fwd": (c_int, [F, F, F, c_int, c_int, c_int, F]),
     "paif_spa_blend_fwd": (c_int, [F, F, F, F, F, F, c_int, c_int, c_int, F]),
-    "paif_eca_finish_fwd": (c_int, [F, F, F, F, c_int, F, F, F, c_int, c_int, c_int, F]),
-    "paif_tail_fwd": (c_int, [F, F, F, F, c_int, c_int, c_int, F]),
+    "paif_eca_finish_fwd": (c_int, [F, F, F, F, c_int, F, F, F, F, c_int, c_int, c_int, F]),
+    "paif_tail_fwd": (c_int, [F, F, F, F, F, c_int, c_int, c_int, F]),
     "paif_add_fwd": (c_int, [F, F, F, c_size_t, F]),
     "paif_gemm_fwd": (c_int, [F, c_int, F, F, F, c_int, F, c_int, F, c_int, c_int, c_int, c_int, F]),
     "paif_layernorm_fwd": (c_int, [F, F, F, F, c_int, c_int, c_float, F]),
@@ -71,6 +72,22 @@ SIGNATURES = {
     "paif_sr_attention_bwd_input": (c_int, [F, F, F, F, F, F, F, F, F, c_int, c_int, c_int, c_int, c_int, F]),
     "paif_upsample_ce_blocks": (c_int, [c_int, c_int, c_int]),
     "paif_upsample_ce_fwd": (c_int, [F, F, F, F, c_int, c_int, c_int, c_int, c_int, c_int, c_int, F]),
+    "paif_conv_weight_dgrad": (c_int, [F, F, c_int, c_int, c_int, c_int, c_int, F]),
+    "paif_fold_decomp1x1_weight": (c_int, [F, F, F]),
+    "paif_tail_bwd_input": (c_int, [F, F, F, F, F, F, c_int, c_int, c_int, F]),
+    "paif_stem_bwd_input": (c_int, [F, F, F, F, F, c_int, c_int, c_int, F]),
+    "paif_dwconv_bwd_input": (c_int, [F, F, F, F, F, c_int, c_int, c_int, c_int, c_int, F]),
+    "paif_eca_bwd_blocks": (c_int, [c_int, c_int]),
+    "paif_eca_bwd_input": (c_int, [F, F, F, F, F, c_int, F, F, F, F, F, c_int, c_int, c_int, F]),
+    "paif_spa_blend_bwd_input": (c_int, [F, F, F, F, F, F, F, F, F, F, c_int, c_int, c_int, F]),
+    "paif_guided_filter_bwd_input": (c_int, [F, F, F, F, c_float, c_float, F, F, F, F, F, F, c_int, c_int, c_int, F]),
+    "paif_upsample_argmax_fwd": (c_int, [F, F, c_int, c_int, c_int, c_int, c_int, c_int, F]),
+    "paif_confusion_matrix_accum": (c_int, [F, F, F, c_size_t, c_int, F]),
+    "paif_glue_bwd_blocks": (c_int, [c_int, c_int, c_int]),
+    "paif_glue_bwd_input": (c_int, [F, F, F, F, F, F, F, F, c_int, c_int, c_int, F]),
+    "paif_rgb2ycrcb_bwd_input": (c_int, [F, F, F, c_int, c_int, c_int, F]),
+    "paif_pgd_step": (c_int, [F, F, F, c_float, c_float, c_size_t, F]),
+    "paif_axpy": (c_int, [F, F, c_float, c_size_t, F]),
     "paif_upsample_ce_bwd": (c_int, [F, F, F, F, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, F]),
 }
 

@@ -50,13 +50,18 @@ class MixedOp(nn.Module):
     def forward(self, x):
         return self._op(x)
 
-    def forward_nhwc(self, x, res=()):
-        return self._op.forward_nhwc(x, res)
+    def forward_nhwc(self, x, res=(), tape=None):
+        return self._op.forward_nhwc(x, res, tape)
+
+    def backward_nhwc(self, g, t):
+        return self._op.backward_nhwc(g, t)
 
 
 class Cell_Chain(_HipOp):
     """core/model_fusion_auto.py:418-445: inp + ops(inp).  The outer residual (and any residuals the
     caller adds on top) ride in the last op's conv epilogue."""
+
+    _tape_is_list = True
 
     def __init__(self, C, type, concat):
         super().__init__()
@@ -73,12 +78,19 @@ class Cell_Chain(_HipOp):
             self._ops += [MixedOp(C, name)]
         self._indices = indices
 
-    def forward_nhwc(self, inp, res=()):
+    def forward_nhwc(self, inp, res=(), tape=None):
         s1 = inp
         for i in range(self._steps):
             last = i == self._steps - 1
-            s1 = self._ops[i].forward_nhwc(s1, ((inp,) + tuple(res)) if last else ())
+            s1 = self._ops[i].forward_nhwc(s1, ((inp,) + tuple(res)) if last else (), tape)
         return s1
+
+    def backward_nhwc(self, g, tape):
+        """g = d/d(chain output) -> d/d(inp).  `tape`: this chain's entries in forward order (one per op)."""
+        d = g
+        for i in range(self._steps - 1, -1, -1):
+            d = self._ops[i].backward_nhwc(d, tape[i])
+        return ops.add(d, g)   # the chain's own residual: out = inp + ops(inp)
 
 
 class Cell_Decom(nn.Module):
@@ -106,26 +118,54 @@ class Cell_Decom(nn.Module):
     def get_residue(self, tensor):
         return ops.to_nchw_view(ops.channel_residue(ops.to_nhwc(tensor)).unsqueeze(-1))
 
-    def decomposition_nhwc(self, x, guide=None):
+    def decomposition_nhwc(self, x, guide=None, want_ab=False):
         """-> lf [2,B,H,W,32] (LF for eps 1e-3, 1e-4)."""
         if guide is None:
             guide = ops.channel_residue(x)
-        return ops.guided_filter_pair(guide, x, tuple(self.eps_list))
+        return ops.guided_filter_pair(guide, x, tuple(self.eps_list), want_ab=want_ab)
 
     def decomposition(self, x, C=None):
         """API parity with the reference: returns (LF [B,2C,H,W], HF [B,2C,H,W])."""
         raise NotImplementedError("HF = x - LF is folded into the 1x1 conv; use decomposition_nhwc for the LF maps")
 
-    def forward_nhwc(self, fir, fvis, g_ir=None, g_vis=None):
-        lf_ir = self.decomposition_nhwc(fir, g_ir)
-        lf_vis = self.decomposition_nhwc(fvis, g_vis)
+    def forward_nhwc(self, fir, fvis, g_ir=None, g_vis=None, tape=None):
+        if g_ir is None:
+            g_ir = ops.channel_residue(fir)
+        if g_vis is None:
+            g_vis = ops.channel_residue(fvis)
+        if tape is None:
+            lf_ir = self.decomposition_nhwc(fir, g_ir)
+            lf_vis = self.decomposition_nhwc(fvis, g_vis)
+        else:
+            lf_ir, ab_ir = self.decomposition_nhwc(fir, g_ir, want_ab=True)
+            lf_vis, ab_vis = self.decomposition_nhwc(fvis, g_vis, want_ab=True)
         w_lf = self._packs.get("lf", [self.conv1x1_lf.weight], lambda: ops.pack_decomp1x1_weight(self.conv1x1_lf.weight))
         w_hf = self._packs.get("hf", [self.conv1x1_hf.weight], lambda: ops.pack_decomp1x1_weight(self.conv1x1_hf.weight))
         lf = ops.conv2d([fir, lf_ir[0], lf_ir[1]], w_lf, 1, 1, shift=self.conv1x1_lf.bias)
         hf = ops.conv2d([fvis, lf_vis[0], lf_vis[1]], w_hf, 1, 1, shift=self.conv1x1_hf.bias)
-        ir_feature = self.chain.forward_nhwc(lf, (fir,))      # lf_re + inp_ir
-        vis_feature = self.chain2.forward_nhwc(hf, (fvis,))   # hf_re + inp_vis
+        t1 = None if tape is None else []
+        t2 = None if tape is None else []
+        ir_feature = self.chain.forward_nhwc(lf, (fir,), t1)      # lf_re + inp_ir
+        vis_feature = self.chain2.forward_nhwc(hf, (fvis,), t2)   # hf_re + inp_vis
+        if tape is not None:
+            tape.update(fir=fir, fvis=fvis, g_ir=g_ir, g_vis=g_vis, ab_ir=ab_ir, ab_vis=ab_vis, chain=t1, chain2=t2)
         return ir_feature, vis_feature
+
+    def _stream_backward(self, d_feat, chain, chain_tape, conv, name, feat, guide, ab):
+        """One stream: d/d(ir_feature) -> d/d(stem feature)."""
+        d_l = chain.backward_nhwc(d_feat, chain_tape)                        # through chain(lf) (+ its residual)
+        wf = self._packs.get("fold_" + name, [conv.weight], lambda: ops.fold_decomp1x1_weight(conv.weight))
+        dg = lambda s: self._packs.get("dg_%s%d" % (name, s), [conv.weight], lambda: ops.pack_conv_dgrad_weight(wf, 32 * s, 32))
+        d_x = ops.conv2d([d_l], dg(0), 1, 1, res=(d_feat,))                  # x term of the folded 1x1 + the outer "+ inp"
+        dlf = torch.empty((2,) + tuple(feat.shape), device=feat.device, dtype=torch.float32)
+        ops.conv2d([d_l], dg(1), 1, 1, out=dlf[0])
+        ops.conv2d([d_l], dg(2), 1, 1, out=dlf[1])
+        return ops.guided_filter_bwd(guide, feat, ab, dlf, tuple(self.eps_list), add=d_x)
+
+    def backward_nhwc(self, d_ir_feature, d_vis_feature, t):
+        d_fir = self._stream_backward(d_ir_feature, self.chain, t["chain"], self.conv1x1_lf, "lf", t["fir"], t["g_ir"], t["ab_ir"])
+        d_fvis = self._stream_backward(d_vis_feature, self.chain2, t["chain2"], self.conv1x1_hf, "hf", t["fvis"], t["g_vis"], t["ab_vis"])
+        return d_fir, d_fvis
 
     def forward(self, inp_ir, inp_vis):
         ops.require_no_grad(inp_ir, inp_vis)
@@ -155,6 +195,9 @@ class spatial_attn_layer_M(nn.Module):
     def blend_nhwc(self, ir, vis, want_scale=False):
         comp = ops.channel_pool2(ir, vis)
         return ops.spa_blend(comp, self.spatial.conv.weight, ir, vis, want_scale)
+
+    def blend_backward_nhwc(self, d_agg, ir, vis, scale):
+        return ops.spa_blend_bwd(d_agg, self.spatial.conv.weight, ir, vis, scale)
 
     def forward(self, ir, vis):
         ops.require_no_grad(ir, vis)
@@ -187,25 +230,81 @@ class Network_Fusion_Searched(nn.Module):
         self._packs = _PackCache()
 
     def forward(self, ir, vis, inter=None):
-        ops.require_no_grad(ir, vis)
+        if torch.is_grad_enabled() and (ir.requires_grad or vis.requires_grad):
+            return _FusionFn.apply(ir, vis, self)
         with torch.no_grad():
-            vis = vis[:, 0:1, :, :]
-            ir = ir[:, 0:1, :, :]
-            fir, g_ir = ops.stem(ir, self.stem_1[0].weight, self.stem_1[1].weight)
-            fvis, g_vis = ops.stem(vis, self.stem_2[0].weight, self.stem_2[1].weight)
-            ir_feature, vis_feature = self.decompation.forward_nhwc(fir, fvis, g_ir, g_vis)
+            return self.forward_impl(ir, vis, inter=inter)
+
+    def forward_impl(self, ir, vis, inter=None, tape=None):
+        """ir, vis: [B,>=1,H,W] (channel 0 is used, :626-627).  tape (dict): filled for the input-gradient pass."""
+        vis = vis[:, 0:1, :, :]
+        ir = ir[:, 0:1, :, :]
+        fir, g_ir = ops.stem(ir, self.stem_1[0].weight, self.stem_1[1].weight)
+        fvis, g_vis = ops.stem(vis, self.stem_2[0].weight, self.stem_2[1].weight)
+        t_dec = None if tape is None else {}
+        ir_feature, vis_feature = self.decompation.forward_nhwc(fir, fvis, g_ir, g_vis, t_dec)
+        t_chain = None if tape is None else []
+        if tape is None:
             agg = self.spa.blend_nhwc(ir_feature, vis_feature)
-            feature2 = self.chain.forward_nhwc(agg)
-            w0 = self._packs.get("so0", [self.stem_out[0].weight], lambda: ops.pack_conv_weight(self.stem_out[0].weight, 1, 32, 3))
-            t16 = ops.conv2d([feature2], w0, 3, 1, cout=16)
+        else:
+            agg, scale = self.spa.blend_nhwc(ir_feature, vis_feature, want_scale=True)
+        feature2 = self.chain.forward_nhwc(agg, (), t_chain)
+        w0 = self._packs.get("so0", [self.stem_out[0].weight], lambda: ops.pack_conv_weight(self.stem_out[0].weight, 1, 32, 3))
+        t16 = ops.conv2d([feature2], w0, 3, 1, cout=16)
+        if tape is None:
             out = ops.tail(t16, self.stem_out[1].weight, self.stem_out[2].weight)
-            if inter is not None:
-                inter.update(fir=fir, fvis=fvis, ir_feature=ir_feature, vis_feature=vis_feature, agg=agg, feature2=feature2)
+        else:
+            out, z = ops.tail(t16, self.stem_out[1].weight, self.stem_out[2].weight, save=True)
+            tape.update(dec=t_dec, chain=t_chain, ir_feature=ir_feature, vis_feature=vis_feature, scale=scale, fused=out, z=z)
+        if inter is not None:
+            inter.update(fir=fir, fvis=fvis, ir_feature=ir_feature, vis_feature=vis_feature, agg=agg, feature2=feature2)
         return out
+
+    def backward_impl(self, d_fused, tape):
+        """d/d(fused) [B,1,H,W] -> (d/d(ir), d/d(vis channel 0)) as [B,1,H,W] each."""
+        from ..operations_m import check_positive_slope
+        for prm, what in ((self.stem_1[1].weight, "stem_1"), (self.stem_2[1].weight, "stem_2")):
+            check_positive_slope(prm, what)
+        d_t16 = ops.tail_bwd(d_fused, tape["fused"], tape["z"], self.stem_out[1].weight, self.stem_out[2].weight)
+        w0t = self._packs.get("so0T", [self.stem_out[0].weight], lambda: ops.pack_conv_dgrad_weight(self.stem_out[0].weight, 0, 32))
+        d_feat2 = ops.conv2d([d_t16], w0t, 3, 1, cin=16, cout=32)
+        d_agg = self.chain.backward_nhwc(d_feat2, tape["chain"])
+        d_irf, d_visf = self.spa.blend_backward_nhwc(d_agg, tape["ir_feature"], tape["vis_feature"], tape["scale"])
+        d_fir, d_fvis = self.decompation.backward_nhwc(d_irf, d_visf, tape["dec"])
+        t = tape["dec"]
+        d_ir = ops.stem_bwd(d_fir, t["fir"], self.stem_1[0].weight, self.stem_1[1].weight)
+        d_y = ops.stem_bwd(d_fvis, t["fvis"], self.stem_2[0].weight, self.stem_2[1].weight)
+        return d_ir, d_y
 
     def _loss(self, ir, vis, mask):
         logits = self(ir, vis)
         return self._criterion(ir, vis, logits, mask)
+
+
+class _FusionFn(torch.autograd.Function):
+    """Input-gradient autograd node of the fusion network (hand-written reverse pass; no parameter grads)."""
+
+    @staticmethod
+    def forward(ctx, ir, vis, module):
+        tape = {}
+        out = module.forward_impl(ir.detach(), vis.detach(), tape=tape)
+        ctx.tape, ctx.module = tape, module
+        ctx.shapes = (tuple(ir.shape), tuple(vis.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, d_fused):
+        d_ir1, d_y1 = ctx.module.backward_impl(d_fused.contiguous(), ctx.tape)
+        ctx.tape = None
+        outs = []
+        for g1, shp in ((d_ir1, ctx.shapes[0]), (d_y1, ctx.shapes[1])):
+            if shp[1] == 1:
+                outs.append(g1)
+            else:  # forward used channel 0 only: zero gradient for the others
+                full = torch.zeros(shp, device=g1.device, dtype=g1.dtype)
+                full[:, 0:1] = g1
+                outs.append(full)
+        return outs[0], outs[1], None
 
 
 # ---------------------------------------------------------------------------------------------
@@ -309,13 +408,38 @@ class _CompositeBase(nn.Module):
 
     def forward(self, ir, vis):
         """-> (fused [B,1,H,W] in tanh range, seg_map [B,num_classes,H/4,W/4]); :712-729 / :1043-1060."""
-        ops.require_no_grad(ir, vis)
+        if torch.is_grad_enabled() and (ir.requires_grad or vis.requires_grad):
+            return _CompositeFn.apply(ir, vis, self)
         with torch.no_grad():
             ycc = ops.rgb2ycrcb(vis)
-            fused = self.enhance_net.forward(ir[:, 0:1, :, :], ycc)
+            fused = self.enhance_net.forward_impl(ir[:, 0:1, :, :], ycc)
             seg_in = ops.seg_input_from_fused(fused, ycc)   # clamp, BATCH-GLOBAL min-max, x255, mean/std
             seg_map = self.denoise_net(seg_in)
         return fused, seg_map
+
+    # ---- taped forward / hand-written reverse pass (input gradients only) -------------------------
+    def forward_taped(self, ir, vis):
+        """-> (fused [B,1,H,W], logits NHWC [B,H/4,W/4,ncls], tape)."""
+        tape = dict(fus={}, seg={}, ir_shape=tuple(ir.shape))
+        ycc = ops.rgb2ycrcb(vis)
+        fused = self.enhance_net.forward_impl(ir[:, 0:1, :, :], ycc, tape=tape["fus"])
+        seg_in, mm = ops.seg_input_from_fused(fused, ycc, return_minmax=True)
+        logits = self.denoise_net.forward_nhwc(ops.nchw_to_nhwc(seg_in), tape["seg"])
+        tape.update(ycc=ycc, fused=fused, minmax=mm)
+        return fused, logits, tape
+
+    def backward_taped(self, d_logits32, tape, d_fused=None):
+        """d/d(logits) NHWC [B,H/4,W/4,32] (zero padded) [+ d/d(fused)] -> (d/d(ir) [B,Cir,H,W], d/d(vis) [B,3,H,W])."""
+        d_seg_in = ops.nhwc_to_nchw(self.denoise_net.backward_nhwc(d_logits32, tape["seg"]))
+        d_f, dcrcb = ops.glue_bwd(d_seg_in, tape["fused"], tape["ycc"], tape["minmax"], d_fused)
+        d_ir1, d_y = self.enhance_net.backward_impl(d_f, tape["fus"])
+        d_vis = ops.rgb2ycrcb_bwd(d_y, dcrcb)
+        shp = tape["ir_shape"]
+        if shp[1] != 1:   # forward used channel 0 only
+            full = torch.zeros(shp, device=d_ir1.device, dtype=d_ir1.dtype)
+            full[:, 0:1] = d_ir1
+            d_ir1 = full
+        return d_ir1, d_vis
 
     def forward_fusion(self, ir, vis):
         ops.require_no_grad(ir, vis)
@@ -335,6 +459,24 @@ class _CompositeBase(nn.Module):
 
     def denoise_net_parameters(self):
         return self.denoise_net.parameters()
+
+
+class _CompositeFn(torch.autograd.Function):
+    """Input-gradient autograd node of the composite model: lets the reference's own attack code
+    (`loss.backward()` on F.interpolate(seg_map) + CrossEntropyLoss, attack/attack.py:445-501) drive the HIP reverse pass."""
+
+    @staticmethod
+    def forward(ctx, ir, vis, module):
+        fused, logits, tape = module.forward_taped(ir.detach(), vis.detach())
+        ctx.tape, ctx.module = tape, module
+        return fused, ops.nhwc_to_nchw(logits)
+
+    @staticmethod
+    def backward(ctx, d_fused, d_seg):
+        d32 = ops.nchw_to_nhwc_pad(d_seg, 32)
+        d_ir, d_vis = ctx.module.backward_taped(d32, ctx.tape, d_fused.contiguous())
+        ctx.tape = None
+        return d_ir, d_vis, None
 
 
 class Network_MM_CompModel(_CompositeBase):

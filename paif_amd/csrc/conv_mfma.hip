@@ -38,15 +38,52 @@ struct ConvArgs {
   const float* prelu;
   float* out;
   float* pool_partial;
-  float alpha;
-  int nsrc, in_act, act, cout;
+  float* aux_out;          // optional: pre-activation z = acc*scale+shift (saved for the backward pass)
+  const float* in_aux;     // in_act 3/4: pre-activation of the layer whose gradient is being propagated
+  const float* in_scale;   // in_act 3/4/5: per-input-channel factor (folded BN scale of that layer) or NULL
+  const float* epi_aux;    // epi_dact: tensor whose sign gates the output (d PReLU / d ReLU)
+  float alpha, in_alpha;
+  int nsrc, in_act, act, cout, epi_dact;
   int B, H, W, tilesX, tilesY, nblk;
 };
+
+// Transform applied to a staged float4 (channels 4q..4q+3 of one pixel):
+//   0 none | 1 PReLU(slope) | 2 ReLU                                   (forward pre-activations)
+//   3 v * in_alpha * in_scale[c] * (aux >= 0 ? 1 : slope)              (dgrad through PReLU(BN(.))*alpha)
+//   4 v * in_alpha * in_scale[c] * (aux > 0)                           (dgrad through ReLU)
+//   5 v * in_alpha * in_scale[c]                                       (dgrad through an affine only)
+template <bool HOOKS>
+__device__ __forceinline__ float4 stage_xform(const ConvArgs& a, float4 v, float4 aux, float slope, int q) {
+  if (a.in_act == 0) return v;
+  if (a.in_act == 1) {
+    v.x = paif::prelu_f(v.x, slope); v.y = paif::prelu_f(v.y, slope);
+    v.z = paif::prelu_f(v.z, slope); v.w = paif::prelu_f(v.w, slope);
+    return v;
+  }
+  if (a.in_act == 2) {
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    return v;
+  }
+  if (!HOOKS) return v;
+  float4 f = make_float4(a.in_alpha, a.in_alpha, a.in_alpha, a.in_alpha);
+  if (a.in_scale) {
+    const float4 s4 = *reinterpret_cast<const float4*>(a.in_scale + q * 4);
+    f.x *= s4.x; f.y *= s4.y; f.z *= s4.z; f.w *= s4.w;
+  }
+  if (a.in_act == 3) {
+    f.x *= aux.x >= 0.f ? 1.f : slope; f.y *= aux.y >= 0.f ? 1.f : slope;
+    f.z *= aux.z >= 0.f ? 1.f : slope; f.w *= aux.w >= 0.f ? 1.f : slope;
+  } else if (a.in_act == 4) {
+    f.x *= aux.x > 0.f ? 1.f : 0.f; f.y *= aux.y > 0.f ? 1.f : 0.f;
+    f.z *= aux.z > 0.f ? 1.f : 0.f; f.w *= aux.w > 0.f ? 1.f : 0.f;
+  }
+  return make_float4(v.x * f.x, v.y * f.y, v.z * f.z, v.w * f.w);
+}
 
 // Fused epilogue of one wave: y = act(acc*scale+shift)*alpha (+res0 +res1 +res2), NHWC store.
 // FULL = interior tile with cout == 32: no per-element predicates, so the compiler can issue all
 // residual loads of a segment, then all stores, without intervening waits.
-template <bool FULL>
+template <bool FULL, bool HOOKS>
 __device__ __forceinline__ float epilogue(const ConvArgs& a, const f32x16 (&acc)[SEGS_PER_WAVE], int b, int y0, int x0,
                                           int wave, int h, int n) {
   const bool nvalid = FULL || n < a.cout;
@@ -55,7 +92,7 @@ __device__ __forceinline__ float epilogue(const ConvArgs& a, const f32x16 (&acc)
     if (a.scale) sc = a.scale[n];
     if (a.shift) sh = a.shift[n];
   }
-  if (a.act == 1) slope = *a.prelu;
+  if (a.act == 1 || (HOOKS && a.epi_dact == 1)) slope = *a.prelu;
   const int nres = a.res[0] ? (a.res[1] ? (a.res[2] ? 3 : 2) : 1) : 0;  // residuals are packed from index 0
   float psum = 0.f;
 #pragma unroll
@@ -63,7 +100,7 @@ __device__ __forceinline__ float epilogue(const ConvArgs& a, const f32x16 (&acc)
     const int y = y0 + wave * SEGS_PER_WAVE + sg;
     const bool rowok = FULL || (nvalid && y < a.H);
     const size_t rowbase = ((size_t)(b * a.H + y) * a.W + x0 + 4 * h) * a.cout + n;
-    float r0[16], r1[16], r2[16];
+    float r0[16], r1[16], r2[16], ea[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int dx = (r & 3) + 8 * (r >> 2);
@@ -72,15 +109,19 @@ __device__ __forceinline__ float epilogue(const ConvArgs& a, const f32x16 (&acc)
       r0[r] = (nres > 0 && ok) ? a.res[0][o] : 0.f;
       r1[r] = (nres > 1 && ok) ? a.res[1][o] : 0.f;
       r2[r] = (nres > 2 && ok) ? a.res[2][o] : 0.f;
+      ea[r] = (HOOKS && a.epi_dact && ok) ? a.epi_aux[o] : 0.f;
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int dx = (r & 3) + 8 * (r >> 2);
       const bool ok = FULL || (rowok && x0 + dx + 4 * h < a.W);
       float v = acc[sg][r] * sc + sh;
+      if (HOOKS && a.aux_out && ok) a.aux_out[rowbase + (size_t)dx * a.cout] = v;
       if (a.act == 1) v = paif::prelu_f(v, slope);
       else if (a.act == 2) v = fmaxf(v, 0.f);
       v *= a.alpha;
+      if (HOOKS && a.epi_dact == 1) v *= ea[r] >= 0.f ? 1.f : slope;      // d PReLU (slope = *prelu)
+      else if (HOOKS && a.epi_dact == 2) v *= ea[r] > 0.f ? 1.f : 0.f;    // d ReLU
       if (nres > 0) v += r0[r];
       if (nres > 1) v += r1[r];
       if (nres > 2) v += r2[r];
@@ -93,8 +134,8 @@ __device__ __forceinline__ float epilogue(const ConvArgs& a, const f32x16 (&acc)
   return psum;
 }
 
-template <int KH, int DIL, int CIN>
-__global__ __launch_bounds__(NTHREADS, 3) void conv_mfma_f32(ConvArgs a) {
+template <int KH, int DIL, int CIN, bool HOOKS>
+__global__ __launch_bounds__(NTHREADS, HOOKS ? 2 : 3) void conv_mfma_f32(ConvArgs a) {
   constexpr int P = DIL * (KH - 1) / 2;
   constexpr int TWH = TW + 2 * P;
   constexpr int THH = TH + 2 * P;
@@ -125,7 +166,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void conv_mfma_f32(ConvArgs a) {
     for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
 
   float in_slope = 0.f;
-  if (a.in_act == 1) in_slope = *a.in_prelu;
+  if (a.in_act == 1 || (HOOKS && a.in_act == 3)) in_slope = *a.in_prelu;
 
   // per-lane LDS read base (dwords): pixel (row = wave*SEGS + s, col = p), channel offset 4*h
   int abase[SEGS_PER_WAVE];
@@ -140,35 +181,33 @@ __global__ __launch_bounds__(NTHREADS, 3) void conv_mfma_f32(ConvArgs a) {
     // per lane (one-at-a-time staging is latency-bound: ~1 us per dependent HBM load)
     constexpr int TOTAL = THH * TWH * QPP;
     constexpr int NIT = (TOTAL + NTHREADS - 1) / NTHREADS;
-    constexpr int UB = 6;
+    constexpr int UB = HOOKS ? 3 : 6;
 #pragma unroll
     for (int i0 = 0; i0 < NIT; i0 += UB) {
-      float4 v[UB];
+      float4 v[UB], xa[UB];
       int dst[UB];
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
         const int idx = tid + (i0 + u) * NTHREADS;
         v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        xa[u] = v[u];
         dst[u] = -1;
         if (i0 + u < NIT && idx < TOTAL) {
           const int pix = idx / QPP, q = idx - pix * QPP;
           const int tyy = pix / TWH, txx = pix - tyy * TWH;
           const int gy = y0 - P + tyy, gx = x0 - P + txx;
           dst[u] = pix * PS + q * 4;
-          if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-            v[u] = *reinterpret_cast<const float4*>(src + ((size_t)(b * a.H + gy) * a.W + gx) * CIN + q * 4);
+          if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+            const size_t go = ((size_t)(b * a.H + gy) * a.W + gx) * CIN + q * 4;
+            v[u] = *reinterpret_cast<const float4*>(src + go);
+            if (HOOKS && (a.in_act == 3 || a.in_act == 4)) xa[u] = *reinterpret_cast<const float4*>(a.in_aux + go);
+          }
         }
       }
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
         if (dst[u] >= 0) {
-          float4 t4 = v[u];
-          if (a.in_act == 1) {
-            t4.x = paif::prelu_f(t4.x, in_slope); t4.y = paif::prelu_f(t4.y, in_slope);
-            t4.z = paif::prelu_f(t4.z, in_slope); t4.w = paif::prelu_f(t4.w, in_slope);
-          } else if (a.in_act == 2) {
-            t4.x = fmaxf(t4.x, 0.f); t4.y = fmaxf(t4.y, 0.f); t4.z = fmaxf(t4.z, 0.f); t4.w = fmaxf(t4.w, 0.f);
-          }
+          const float4 t4 = stage_xform<HOOKS>(a, v[u], xa[u], in_slope, (dst[u] % PS) >> 2);
           *reinterpret_cast<float4*>(lds + dst[u]) = t4;
         }
       }
@@ -207,8 +246,8 @@ __global__ __launch_bounds__(NTHREADS, 3) void conv_mfma_f32(ConvArgs a) {
   // ---- epilogue --------------------------------------------------------------------------------
   const bool full = (y0 + TH <= a.H) && (x0 + TW <= a.W) && (a.cout == 32);  // block-uniform
   float psum;
-  if (full) psum = epilogue<true>(a, acc, b, y0, x0, wave, h, p);
-  else psum = epilogue<false>(a, acc, b, y0, x0, wave, h, p);
+  if (full) psum = epilogue<true, HOOKS>(a, acc, b, y0, x0, wave, h, p);
+  else psum = epilogue<false, HOOKS>(a, acc, b, y0, x0, wave, h, p);
   if (a.pool_partial) {
     // lanes (h=0,n) and (h=1,n) -> one value per channel per wave, then across the 4 waves via LDS
     psum += __shfl_xor(psum, 32);
@@ -237,8 +276,8 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
   return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
 }
 
-template <int KH, int DIL>
-__global__ __launch_bounds__(NTHREADS, 3) void conv_mfma_bf16x3(ConvArgs a) {
+template <int KH, int DIL, bool HOOKS>
+__global__ __launch_bounds__(NTHREADS, HOOKS ? 2 : 3) void conv_mfma_bf16x3(ConvArgs a) {
   constexpr int CIN = 32;
   constexpr int P = DIL * (KH - 1) / 2;
   constexpr int TWH = TW + 2 * P;
@@ -271,7 +310,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void conv_mfma_bf16x3(ConvArgs a) {
     for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
 
   float in_slope = 0.f;
-  if (a.in_act == 1) in_slope = *a.in_prelu;
+  if (a.in_act == 1 || (HOOKS && a.in_act == 3)) in_slope = *a.in_prelu;
 
   int abase[SEGS_PER_WAVE];
 #pragma unroll
@@ -282,35 +321,33 @@ __global__ __launch_bounds__(NTHREADS, 3) void conv_mfma_bf16x3(ConvArgs a) {
     const float* src = a.src[s];
     constexpr int TOTAL = THH * TWH * QPP;
     constexpr int NIT = (TOTAL + NTHREADS - 1) / NTHREADS;
-    constexpr int UB = 6;
+    constexpr int UB = HOOKS ? 3 : 6;
 #pragma unroll
     for (int i0 = 0; i0 < NIT; i0 += UB) {
-      float4 v[UB];
+      float4 v[UB], xa[UB];
       int dst[UB];
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
         const int idx = tid + (i0 + u) * NTHREADS;
         v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        xa[u] = v[u];
         dst[u] = -1;
         if (i0 + u < NIT && idx < TOTAL) {
           const int pix = idx / QPP, q = idx - pix * QPP;
           const int tyy = pix / TWH, txx = pix - tyy * TWH;
           const int gy = y0 - P + tyy, gx = x0 - P + txx;
           dst[u] = pix * PSB + q * 8;
-          if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-            v[u] = *reinterpret_cast<const float4*>(src + ((size_t)(b * a.H + gy) * a.W + gx) * CIN + q * 4);
+          if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+            const size_t go = ((size_t)(b * a.H + gy) * a.W + gx) * CIN + q * 4;
+            v[u] = *reinterpret_cast<const float4*>(src + go);
+            if (HOOKS && (a.in_act == 3 || a.in_act == 4)) xa[u] = *reinterpret_cast<const float4*>(a.in_aux + go);
+          }
         }
       }
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
         if (dst[u] >= 0) {
-          float4 t4 = v[u];
-          if (a.in_act == 1) {
-            t4.x = paif::prelu_f(t4.x, in_slope); t4.y = paif::prelu_f(t4.y, in_slope);
-            t4.z = paif::prelu_f(t4.z, in_slope); t4.w = paif::prelu_f(t4.w, in_slope);
-          } else if (a.in_act == 2) {
-            t4.x = fmaxf(t4.x, 0.f); t4.y = fmaxf(t4.y, 0.f); t4.z = fmaxf(t4.z, 0.f); t4.w = fmaxf(t4.w, 0.f);
-          }
+          const float4 t4 = stage_xform<HOOKS>(a, v[u], xa[u], in_slope, (dst[u] % PSB) >> 3);
           const __bf16 hx = (__bf16)t4.x, hy = (__bf16)t4.y, hz = (__bf16)t4.z, hw = (__bf16)t4.w;
           uint2 hi, lo;
           hi.x = (unsigned)__builtin_bit_cast(unsigned short, hx) | ((unsigned)__builtin_bit_cast(unsigned short, hy) << 16);
@@ -356,8 +393,8 @@ __global__ __launch_bounds__(NTHREADS, 3) void conv_mfma_bf16x3(ConvArgs a) {
 
   const bool full = (y0 + TH <= a.H) && (x0 + TW <= a.W) && (a.cout == 32);
   float psum;
-  if (full) psum = epilogue<true>(a, acc, b, y0, x0, wave, hh, p);
-  else psum = epilogue<false>(a, acc, b, y0, x0, wave, hh, p);
+  if (full) psum = epilogue<true, HOOKS>(a, acc, b, y0, x0, wave, hh, p);
+  else psum = epilogue<false, HOOKS>(a, acc, b, y0, x0, wave, hh, p);
   if (a.pool_partial) {
     psum += __shfl_xor(psum, 32);
     __syncthreads();
@@ -367,22 +404,29 @@ __global__ __launch_bounds__(NTHREADS, 3) void conv_mfma_bf16x3(ConvArgs a) {
   }
 }
 
-template <int KH, int DIL>
-int launch_bf16x3(const ConvArgs& a, hipStream_t st) {
+template <int KH, int DIL, bool HOOKS>
+int launch_bf16x3_h(const ConvArgs& a, hipStream_t st) {
   constexpr int P = DIL * (KH - 1) / 2;
   constexpr size_t lds_bytes = (size_t)(TH + 2 * P) * (TW + 2 * P) * 144;
   static_assert(lds_bytes <= 160 * 1024, "tile does not fit LDS");
   if (lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_bf16x3<KH, DIL>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_bf16x3<KH, DIL, HOOKS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) {
       paif::set_error("conv2d(bf16x3): cannot raise dynamic LDS to %zu: %s", lds_bytes, hipGetErrorString(e));
       return (int)e;
     }
   }
-  hipLaunchKernelGGL((conv_mfma_bf16x3<KH, DIL>), dim3(a.nblk), dim3(NTHREADS), lds_bytes, st, a);
+  hipLaunchKernelGGL((conv_mfma_bf16x3<KH, DIL, HOOKS>), dim3(a.nblk), dim3(NTHREADS), lds_bytes, st, a);
   PAIF_LAUNCH_CHECK("conv2d(bf16x3)");
   return 0;
+}
+
+static inline bool needs_hooks(const ConvArgs& a) { return a.in_act >= 3 || a.aux_out || a.epi_dact; }
+
+template <int KH, int DIL>
+int launch_bf16x3(const ConvArgs& a, hipStream_t st) {
+  return needs_hooks(a) ? launch_bf16x3_h<KH, DIL, true>(a, st) : launch_bf16x3_h<KH, DIL, false>(a, st);
 }
 
 // w [cout][nsrc*32][kh][kh] fp32 -> wpk[src][tap][ks][hi|lo][64 lanes][8 bf16]
@@ -422,22 +466,27 @@ __global__ void pack_decomp1x1_bf16x3_kernel(const float* __restrict__ w, unsign
   }
 }
 
-template <int KH, int DIL, int CIN>
-int launch(const ConvArgs& a, hipStream_t st) {
+template <int KH, int DIL, int CIN, bool HOOKS>
+int launch_h(const ConvArgs& a, hipStream_t st) {
   constexpr int P = DIL * (KH - 1) / 2;
   constexpr size_t lds_bytes = (size_t)(TH + 2 * P) * (TW + 2 * P) * (CIN + 4) * 4;
   static_assert(lds_bytes <= 160 * 1024, "tile does not fit LDS");
   if (lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_f32<KH, DIL, CIN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_f32<KH, DIL, CIN, HOOKS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) {
       paif::set_error("conv2d: cannot raise dynamic LDS to %zu: %s", lds_bytes, hipGetErrorString(e));
       return (int)e;
     }
   }
-  hipLaunchKernelGGL((conv_mfma_f32<KH, DIL, CIN>), dim3(a.nblk), dim3(NTHREADS), lds_bytes, st, a);
+  hipLaunchKernelGGL((conv_mfma_f32<KH, DIL, CIN, HOOKS>), dim3(a.nblk), dim3(NTHREADS), lds_bytes, st, a);
   PAIF_LAUNCH_CHECK("conv2d");
   return 0;
+}
+
+template <int KH, int DIL, int CIN>
+int launch(const ConvArgs& a, hipStream_t st) {
+  return needs_hooks(a) ? launch_h<KH, DIL, CIN, true>(a, st) : launch_h<KH, DIL, CIN, false>(a, st);
 }
 
 __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wpk, int cout, int nsrc, int cin,
@@ -508,6 +557,14 @@ int paif_conv2d_fwd(const paif_conv_desc* d, int B, int H, int W, paif_stream_t 
   a.in_prelu = d->in_prelu; a.scale = d->scale; a.shift = d->shift; a.prelu = d->prelu;
   a.out = d->out; a.pool_partial = d->pool_partial; a.alpha = d->alpha;
   a.nsrc = d->nsrc; a.in_act = d->in_act; a.act = d->act; a.cout = d->cout;
+  a.aux_out = d->aux_out; a.in_aux = d->in_aux; a.in_scale = d->in_scale; a.in_alpha = d->in_alpha;
+  a.epi_aux = d->epi_aux; a.epi_dact = d->epi_dact;
+  PAIF_REQUIRE(d->in_act >= 0 && d->in_act <= 5, PAIF_EINVAL, "conv2d: in_act=%d", d->in_act);
+  PAIF_REQUIRE(!(d->in_act == 3 || d->in_act == 4) || (d->in_aux && d->nsrc == 1), PAIF_EINVAL,
+               "conv2d: in_act=%d needs in_aux and a single source", d->in_act);
+  PAIF_REQUIRE(d->in_act != 3 || d->in_prelu, PAIF_EINVAL, "conv2d: in_act=3 without slope");
+  PAIF_REQUIRE(d->epi_dact >= 0 && d->epi_dact <= 2 && (!d->epi_dact || d->epi_aux), PAIF_EINVAL, "conv2d: epi_dact=%d", d->epi_dact);
+  PAIF_REQUIRE(d->epi_dact != 1 || d->prelu, PAIF_EINVAL, "conv2d: epi_dact=PReLU without slope");
   a.B = B; a.H = H; a.W = W;
   a.tilesX = (W + TW - 1) / TW; a.tilesY = (H + TH - 1) / TH; a.nblk = B * a.tilesX * a.tilesY;
   hipStream_t st = paif::as_stream(stream);

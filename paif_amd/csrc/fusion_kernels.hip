@@ -250,7 +250,8 @@ __global__ __launch_bounds__(1024) void eca_scale_kernel(const float* __restrict
 
 __global__ __launch_bounds__(256) void eca_apply_kernel(const float* __restrict__ o, const float* __restrict__ r,
                                                         const float* __restrict__ s, const float* __restrict__ prelu,
-                                                        float* __restrict__ out, size_t pix_per_img, size_t npix) {
+                                                        float* __restrict__ out, float* __restrict__ u_out, size_t pix_per_img,
+                                                        size_t npix) {
   const int q = threadIdx.x & 7;
   const float slope = *prelu;
   for (size_t pix = (size_t)blockIdx.x * 32 + (threadIdx.x >> 3); pix < npix; pix += (size_t)gridDim.x * 32) {
@@ -258,12 +259,12 @@ __global__ __launch_bounds__(256) void eca_apply_kernel(const float* __restrict_
     const float4 sv = *reinterpret_cast<const float4*>(s + b * 32 + q * 4);
     const float4 ov = *reinterpret_cast<const float4*>(o + pix * 32 + q * 4);
     const float4 rv = *reinterpret_cast<const float4*>(r + pix * 32 + q * 4);
-    float4 v;
-    v.x = paif::prelu_f(__fadd_rn(__fmul_rn(ov.x, sv.x), rv.x), slope);
-    v.y = paif::prelu_f(__fadd_rn(__fmul_rn(ov.y, sv.y), rv.y), slope);
-    v.z = paif::prelu_f(__fadd_rn(__fmul_rn(ov.z, sv.z), rv.z), slope);
-    v.w = paif::prelu_f(__fadd_rn(__fmul_rn(ov.w, sv.w), rv.w), slope);
-    *reinterpret_cast<float4*>(out + pix * 32 + q * 4) = v;
+    float4 u4;
+    u4.x = __fadd_rn(__fmul_rn(ov.x, sv.x), rv.x); u4.y = __fadd_rn(__fmul_rn(ov.y, sv.y), rv.y);
+    u4.z = __fadd_rn(__fmul_rn(ov.z, sv.z), rv.z); u4.w = __fadd_rn(__fmul_rn(ov.w, sv.w), rv.w);
+    if (u_out) *reinterpret_cast<float4*>(u_out + pix * 32 + q * 4) = u4;
+    *reinterpret_cast<float4*>(out + pix * 32 + q * 4) =
+        make_float4(paif::prelu_f(u4.x, slope), paif::prelu_f(u4.y, slope), paif::prelu_f(u4.z, slope), paif::prelu_f(u4.w, slope));
   }
 }
 
@@ -271,8 +272,8 @@ __global__ __launch_bounds__(256) void eca_apply_kernel(const float* __restrict_
 // tail: 3x3 conv 16->1 + PReLU + tanh.  x NHWC16; 4 lanes per pixel (one float4 each), taps from L1.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                   const float* __restrict__ prelu, float* __restrict__ fused, int B, int H,
-                                                   int W) {
+                                                   const float* __restrict__ prelu, float* __restrict__ fused,
+                                                   float* __restrict__ z_out, int B, int H, int W) {
   const int q = threadIdx.x & 3;
   float wr[4][9];
 #pragma unroll
@@ -302,7 +303,10 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ x, 
     }
     s += __shfl_xor(s, 1);
     s += __shfl_xor(s, 2);
-    if (q == 0) fused[pix] = tanhf(paif::prelu_f(s, slope));
+    if (q == 0) {
+      fused[pix] = tanhf(paif::prelu_f(s, slope));
+      if (z_out) z_out[pix] = s;
+    }
   }
 }
 
@@ -470,7 +474,7 @@ int paif_spa_blend_fwd(const float* comp, const float* w, const float* ir, const
 }
 
 int paif_eca_finish_fwd(const float* o, const float* r, const float* pool_partial, const float* w1d, int k,
-                        const float* prelu, float* gate, float* out, int B, int H, int W, paif_stream_t stream) {
+                        const float* prelu, float* gate, float* out, float* u_out, int B, int H, int W, paif_stream_t stream) {
   PAIF_REQUIRE(o && r && pool_partial && w1d && prelu && gate && out && B > 0 && H > 0 && W > 0, PAIF_EINVAL,
                "eca_finish: bad arguments");
   PAIF_REQUIRE(k >= 1 && k <= 9 && (k & 1), PAIF_ENOSUP, "eca_finish: k=%d", k);
@@ -481,16 +485,16 @@ int paif_eca_finish_fwd(const float* o, const float* r, const float* pool_partia
                      1.0f / ((float)H * (float)W), s);
   PAIF_LAUNCH_CHECK("eca_scale");
   const size_t npix = (size_t)B * H * W;
-  hipLaunchKernelGGL(eca_apply_kernel, dim3(grid_for(npix, 32)), dim3(256), 0, st, o, r, s, prelu, out, (size_t)H * W, npix);
+  hipLaunchKernelGGL(eca_apply_kernel, dim3(grid_for(npix, 32)), dim3(256), 0, st, o, r, s, prelu, out, u_out, (size_t)H * W, npix);
   PAIF_LAUNCH_CHECK("eca_apply");
   return 0;
 }
 
-int paif_tail_fwd(const float* x, const float* w, const float* prelu, float* fused, int B, int H, int W,
+int paif_tail_fwd(const float* x, const float* w, const float* prelu, float* fused, float* z_out, int B, int H, int W,
                   paif_stream_t stream) {
   PAIF_REQUIRE(x && w && prelu && fused && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "tail: bad arguments");
   hipLaunchKernelGGL(tail_kernel, dim3(grid_for((size_t)B * H * W, 64)), dim3(256), 0, paif::as_stream(stream), x, w, prelu,
-                     fused, B, H, W);
+                     fused, z_out, B, H, W);
   PAIF_LAUNCH_CHECK("tail");
   return 0;
 }

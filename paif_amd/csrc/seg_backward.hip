@@ -417,3 +417,67 @@ int paif_transpose_pad_fwd(const float* w, float* wt, int N, int K, int Npad, pa
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// evaluation harness kernels (test_original.py:180,207-211): bilinear upsample + argmax, confusion matrix
+// ---------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void upsample_argmax_kernel(const float* __restrict__ logits, long long* __restrict__ pred, int B,
+                                                              int IH, int IW, int C, int OH, int OW) {
+  const size_t total = (size_t)B * OH * OW;
+  const float sy = (float)IH / (float)OH, sx = (float)IW / (float)OW;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ox = (int)(i % OW);
+    size_t t = i / OW;
+    const int oy = (int)(t % OH);
+    const int b = (int)(t / OH);
+    int y0, y1, x0, x1; float ly, lx;
+    src_index(sy, oy, IH, y0, y1, ly);
+    src_index(sx, ox, IW, x0, x1, lx);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float* p00 = logits + (((size_t)b * IH + y0) * IW + x0) * C;
+    const float* p01 = logits + (((size_t)b * IH + y0) * IW + x1) * C;
+    const float* p10 = logits + (((size_t)b * IH + y1) * IW + x0) * C;
+    const float* p11 = logits + (((size_t)b * IH + y1) * IW + x1) * C;
+    float best = -INFINITY; int bi = 0;
+    for (int c = 0; c < C; ++c) {
+      const float v = hy * (hx * p00[c] + lx * p01[c]) + ly * (hx * p10[c] + lx * p11[c]);
+      if (v > best) { best = v; bi = c; }   // first maximum, like torch.argmax
+    }
+    pred[i] = bi;
+  }
+}
+
+// rows = true class, cols = predicted; pairs with a class outside [0, n) are dropped (sklearn labels=0..n-1)
+__global__ void confusion_kernel(const long long* __restrict__ label, const long long* __restrict__ pred,
+                                 unsigned long long* __restrict__ conf, size_t n, int ncls) {
+  __shared__ unsigned int local[32 * 32];
+  for (int i = threadIdx.x; i < ncls * ncls; i += blockDim.x) local[i] = 0;
+  __syncthreads();
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const long long l = label[i], p = pred[i];
+    if (l >= 0 && l < ncls && p >= 0 && p < ncls) atomicAdd(&local[l * ncls + p], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < ncls * ncls; i += blockDim.x)
+    if (local[i]) atomicAdd(&conf[i], (unsigned long long)local[i]);   // integer atomics: order-independent, exact
+}
+}  // namespace
+
+extern "C" int paif_upsample_argmax_fwd(const float* logits, long long* pred, int B, int IH, int IW, int C, int OH, int OW,
+                                        paif_stream_t stream) {
+  PAIF_REQUIRE(logits && pred && B > 0 && IH > 0 && IW > 0 && C > 0 && OH > 0 && OW > 0, PAIF_EINVAL, "upsample_argmax: bad arguments");
+  hipLaunchKernelGGL(upsample_argmax_kernel, dim3(grid_for((size_t)B * OH * OW, 256)), dim3(256), 0, paif::as_stream(stream), logits, pred,
+                     B, IH, IW, C, OH, OW);
+  PAIF_LAUNCH_CHECK("upsample_argmax");
+  return 0;
+}
+
+extern "C" int paif_confusion_matrix_accum(const long long* label, const long long* pred, unsigned long long* conf, size_t n, int ncls,
+                                           paif_stream_t stream) {
+  PAIF_REQUIRE(label && pred && conf && ncls > 0 && ncls <= 32, PAIF_EINVAL, "confusion_matrix: bad arguments (ncls <= 32)");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(confusion_kernel, dim3(grid_for(n, 256)), dim3(256), 0, paif::as_stream(stream), label, pred, conf, n, ncls);
+  PAIF_LAUNCH_CHECK("confusion_matrix");
+  return 0;
+}

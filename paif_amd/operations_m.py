@@ -71,6 +71,19 @@ def _pad_for(k, d):
     return table[(k, d)]
 
 
+_slope_checked = {}
+
+
+def check_positive_slope(param, what):
+    """Backward kernels that read the sign of a PReLU OUTPUT (instead of a saved pre-activation) need a
+    non-negative slope.  One host sync per parameter version."""
+    key = (param.data_ptr(), param._version)
+    if _slope_checked.get(id(param)) != key:
+        if float(param.detach().min()) < 0.0:
+            raise NotImplementedError("%s: negative PReLU slope is not supported by the backward kernels" % what)
+        _slope_checked[id(param)] = key
+
+
 class _HipOp(nn.Module):
     """Base: NCHW boundary <-> NHWC body."""
 
@@ -79,18 +92,45 @@ class _HipOp(nn.Module):
         self._packs = _PackCache()
 
     def forward(self, x):
-        ops.require_no_grad(x)
+        if torch.is_grad_enabled() and x.requires_grad:
+            return _OpFn.apply(x, self)
         with torch.no_grad():
             return ops.to_nchw_view(self.forward_nhwc(ops.to_nhwc(x)))
 
-    def forward_nhwc(self, x, res=()):
+    def forward_nhwc(self, x, res=(), tape=None):
         raise NotImplementedError
+
+    def backward_nhwc(self, g, tape):
+        """g = d/d(output) -> d/d(x), INCLUDING the op's own residual path when it has one."""
+        raise NotImplementedError("%s: backward kernels not built" % type(self).__name__)
+
+    def _dgrad_w(self, name, w, coff=0, cs=32):
+        return self._packs.get("dg_" + name, [w], lambda: ops.pack_conv_dgrad_weight(w, coff, cs))
 
     @staticmethod
     def _add_res(y, res):
         for r in res:
             y = ops.add(y, r)
         return y
+
+
+class _OpFn(torch.autograd.Function):
+    """Input-gradient autograd node of one NAS-cell operator (hand-written reverse pass, no parameter grads)."""
+
+    @staticmethod
+    def forward(ctx, x, module):
+        tape = []
+        y = module.forward_nhwc(ops.to_nhwc(x.detach()), (), tape)
+        # single ops record one entry; containers (Cell_Chain) consume the whole list
+        ctx.entry = tape if getattr(module, "_tape_is_list", False) else tape[0]
+        ctx.module = module
+        return ops.to_nchw_view(y)
+
+    @staticmethod
+    def backward(ctx, g):
+        d = ctx.module.backward_nhwc(ops.to_nhwc(g), ctx.entry)
+        ctx.entry = None
+        return ops.to_nchw_view(d), None
 
 
 class BasicConv(_HipOp):
@@ -111,7 +151,9 @@ class BasicConv(_HipOp):
     def wpk(self, nsrc, cin):
         return self._packs.get("w", [self.conv.weight], lambda: ops.pack_conv_weight(self.conv.weight, nsrc, cin, self.kernel_size))
 
-    def forward_nhwc(self, x, res=()):
+    def forward_nhwc(self, x, res=(), tape=None):
+        if tape is not None:
+            raise NotImplementedError("BasicConv used stand-alone has no backward; it is differentiated inside its parent op")
         C = x.shape[-1]
         if self.groups == C and self.groups == self.conv.out_channels and self.groups > 1:
             y = ops.dwconv(x, self.conv.weight, self.kernel_size, self.dilation, in_relu=False)
@@ -149,13 +191,32 @@ class ResidualDenseBlock(_HipOp):
         self.conv3 = BasicConv(in_channels * 3, in_channels, kernel_size, dilation=dialtions, relu=False)
         self.lrelu = PReLUParams()
 
-    def forward_nhwc(self, x, res=()):
+    def forward_nhwc(self, x, res=(), tape=None):
         a = self.lrelu.weight
         k, d = self.k, self.d
         x1 = ops.conv2d([x], self.conv1.wpk(1, 32), k, d, act=ops.ACT_PRELU, prelu=a)
         x2 = ops.conv2d([x, x1], self.conv2.wpk(2, 32), k, d, act=ops.ACT_PRELU, prelu=a)
-        return ops.conv2d([x, x1, x2], self.conv3.wpk(3, 32), k, d, act=ops.ACT_PRELU, prelu=a, alpha=0.333333,
-                          res=(x,) + tuple(res))
+        if tape is None:
+            return ops.conv2d([x, x1, x2], self.conv3.wpk(3, 32), k, d, act=ops.ACT_PRELU, prelu=a, alpha=0.333333,
+                              res=(x,) + tuple(res))
+        out, z3 = ops.conv2d([x, x1, x2], self.conv3.wpk(3, 32), k, d, act=ops.ACT_PRELU, prelu=a, alpha=0.333333,
+                             res=(x,) + tuple(res), want_aux=True)
+        tape.append(dict(x1=x1, x2=x2, z3=z3))
+        return out
+
+    def backward_nhwc(self, g, t):
+        a = self.lrelu.weight
+        check_positive_slope(a, "ResidualDenseBlock")   # x1, x2 are PReLU outputs: their sign is the pre-activation's
+        k, d = self.k, self.d
+        w1, w2, w3 = self.conv1.conv.weight, self.conv2.conv.weight, self.conv3.conv.weight
+        hook3 = dict(in_act=ops.IN_DPRELU, in_aux=t["z3"], in_alpha=0.333333, in_prelu=a)
+        d_x = ops.conv2d([g], self._dgrad_w("c3s0", w3, 0), k, d, res=(g,), **hook3)
+        d_x1 = ops.conv2d([g], self._dgrad_w("c3s1", w3, 32), k, d, **hook3)
+        d_x2 = ops.conv2d([g], self._dgrad_w("c3s2", w3, 64), k, d, **hook3)
+        hook2 = dict(in_act=ops.IN_DPRELU, in_aux=t["x2"], in_prelu=a)
+        d_x = ops.conv2d([d_x2], self._dgrad_w("c2s0", w2, 0), k, d, res=(d_x,), **hook2)
+        d_x1 = ops.conv2d([d_x2], self._dgrad_w("c2s1", w2, 32), k, d, res=(d_x1,), **hook2)
+        return ops.conv2d([d_x1], self._dgrad_w("c1", w1, 0), k, d, res=(d_x,), in_act=ops.IN_DPRELU, in_aux=t["x1"], in_prelu=a)
 
 
 class ResidualModule(_HipOp):
@@ -172,15 +233,27 @@ class ResidualModule(_HipOp):
             PReLUParams(),
         )
 
-    def forward_nhwc(self, x, res=()):
+    def forward_nhwc(self, x, res=(), tape=None):
         op = self.op
         t1 = ops.conv2d([x], op[0].wpk(1, 32), self.k, self.d)
         w2 = self._packs.get("w2", [op[1].weight], lambda: ops.pack_conv_weight(op[1].weight, 1, 32, 3))
         t2 = ops.conv2d([t1], w2, 3, 2)
         w3 = self._packs.get("w3", [op[2].weight], lambda: ops.pack_conv_weight(op[2].weight, 1, 32, 1))
         scale, shift = _bn_scale_shift(op[3], self._packs)
-        return ops.conv2d([t2], w3, 1, 1, scale=scale, shift=shift, act=ops.ACT_PRELU, prelu=op[4].weight,
-                          res=(x,) + tuple(res))
+        kw = dict(scale=scale, shift=shift, act=ops.ACT_PRELU, prelu=op[4].weight, res=(x,) + tuple(res))
+        if tape is None:
+            return ops.conv2d([t2], w3, 1, 1, **kw)
+        out, z = ops.conv2d([t2], w3, 1, 1, want_aux=True, **kw)
+        tape.append(dict(z=z))
+        return out
+
+    def backward_nhwc(self, g, t):
+        op = self.op
+        scale, _ = _bn_scale_shift(op[3], self._packs)
+        d_t2 = ops.conv2d([g], self._dgrad_w("c1x1", op[2].weight), 1, 1, in_act=ops.IN_DPRELU, in_aux=t["z"], in_scale=scale,
+                          in_prelu=op[4].weight)
+        d_t1 = ops.conv2d([d_t2], self._dgrad_w("c3d2", op[1].weight), 3, 2)
+        return ops.conv2d([d_t1], self._dgrad_w("ck", op[0].conv.weight), self.k, self.d, res=(g,))
 
 
 class DilConv(_HipOp):
@@ -196,12 +269,20 @@ class DilConv(_HipOp):
             BatchNormParams(C_out, affine=affine),
         )
 
-    def forward_nhwc(self, x, res=()):
+    def forward_nhwc(self, x, res=(), tape=None):
         op = self.op
         t = ops.dwconv(x, op[1].conv.weight, self.k, self.d, in_relu=True)
         w = self._packs.get("w", [op[2].weight], lambda: ops.pack_conv_weight(op[2].weight, 1, 32, 1))
         scale, shift = _bn_scale_shift(op[3], self._packs)
+        if tape is not None:
+            tape.append(dict(x=x))
         return ops.conv2d([t], w, 1, 1, scale=scale, shift=shift, res=(x,) + tuple(res))
+
+    def backward_nhwc(self, g, t):
+        op = self.op
+        scale, _ = _bn_scale_shift(op[3], self._packs)
+        d_t = ops.conv2d([g], self._dgrad_w("c1x1", op[2].weight), 1, 1, in_act=ops.IN_SCALE, in_scale=scale)
+        return ops.dwconv_bwd(d_t, op[1].conv.weight, self.k, self.d, aux=t["x"], add=g)
 
 
 def _bn_scale_shift(bn, cache=None, name="bn"):
@@ -240,7 +321,9 @@ class SepConv(_HipOp):
             BatchNormParams(C_out, affine=affine),
         )
 
-    def forward_nhwc(self, x, res=()):
+    def forward_nhwc(self, x, res=(), tape=None):
+        if tape is not None:
+            raise NotImplementedError("SepConv backward kernels are not built (not in the shipped genotype)")
         op = self.op
         t = ops.dwconv(x, op[1].weight, self.k, 1, in_relu=True)
         w1 = self._packs.get("w1", [op[2].weight], lambda: ops.pack_conv_weight(op[2].weight, 1, 32, 1))
@@ -280,13 +363,24 @@ class ECABasicBlock(_HipOp):
         self.se = eca_layer(planes, planes, stride, k_size=kernel)
         self.relu = PReLUParams()
 
-    def forward_nhwc(self, x, res=()):
+    def forward_nhwc(self, x, res=(), tape=None):
         a = self.relu.weight
         w1 = self._packs.get("w1", [self.conv1.weight], lambda: ops.pack_conv_weight(self.conv1.weight, 1, 32, 3))
         r = ops.conv2d([x], w1, 3, 1)
         o, partial = ops.conv2d([r], self.conv2.wpk(1, 32), self.k, 1, in_act=ops.ACT_PRELU, in_prelu=a, pool=True)
-        out = ops.eca_finish(o, r, partial, self.se.conv.weight, self.k, a)
+        if tape is None:
+            out = ops.eca_finish(o, r, partial, self.se.conv.weight, self.k, a)
+        else:
+            out, u, gate = ops.eca_finish(o, r, partial, self.se.conv.weight, self.k, a, save=True)
+            tape.append(dict(r=r, o=o, u=u, gate=gate))
         return self._add_res(out, res)
+
+    def backward_nhwc(self, g, t):
+        a = self.relu.weight
+        d_o, d_r = ops.eca_bwd(g, t["u"], t["o"], t["gate"], self.se.conv.weight, self.k, a)
+        # o = conv2(PReLU(r)):  d_r += conv2^T(d_o) * PReLU'(r)
+        d_r = ops.conv2d([d_o], self._dgrad_w("c2", self.conv2.conv.weight), self.k, 1, epi_dact=1, epi_aux=t["r"], prelu=a, res=(d_r,))
+        return ops.conv2d([d_r], self._dgrad_w("c1", self.conv1.weight), 3, 1)
 
 
 class Spatial_BasicBlock(_HipOp):
@@ -301,7 +395,7 @@ class Spatial_BasicBlock(_HipOp):
         self.se = spatial_attn_layer(kernel)
         self.relu = PReLUParams()
 
-    def forward_nhwc(self, x, res=()):
+    def forward_nhwc(self, x, res=(), tape=None):
         raise NotImplementedError("SPAattention HIP kernels are not built yet (SURVEY.md 8(f) rank 1)")
 
 

@@ -165,9 +165,9 @@ def channel_residue(x):
     return g
 
 
-def guided_filter_pair(guide, y, eps=(0.001, 0.0001)):
-    """Returns lf [2,B,H,W,32] for the two eps (r = 4).  AssertionError if H or W <= 9, like the
-    reference's guided_filter_pytorch."""
+def guided_filter_pair(guide, y, eps=(0.001, 0.0001), want_ab=False):
+    """Returns lf [2,B,H,W,32] for the two eps (r = 4) (and the coefficient maps ab [4,B,H,W,32] for the
+    backward pass).  AssertionError if H or W <= 9, like the reference's guided_filter_pytorch."""
     B, H, W, C = y.shape
     assert C == 32
     assert H > 9 and W > 9, "guided filter needs H, W > 2r+1 = 9"
@@ -176,7 +176,7 @@ def guided_filter_pair(guide, y, eps=(0.001, 0.0001)):
     L = lib()
     _lib.check(L.paif_guided_filter_ab_fwd(_p(guide), _p(y), _p(ab), eps[0], eps[1], B, H, W, _stream()), "guided_filter_ab")
     _lib.check(L.paif_guided_filter_lf_fwd(_p(guide), _p(ab), _p(lf), B, H, W, _stream()), "guided_filter_lf")
-    return lf
+    return (lf, ab) if want_ab else lf
 
 
 def pack_conv_weight(w, nsrc, cin, kh, precision=None):
@@ -218,15 +218,24 @@ def bn_fold(weight, bias, mean, var, eps):
     return scale, shift
 
 
+IN_DPRELU, IN_DRELU, IN_SCALE = 3, 4, 5   # dgrad staging modes of paif_conv_desc.in_act
+
+
 def conv2d(srcs, wpk, kh, dil=1, cin=32, cout=32, in_act=ACT_NONE, in_prelu=None, scale=None, shift=None,
-           act=ACT_NONE, prelu=None, alpha=1.0, res=(), pool=False):
-    """Dense conv over the virtual concat of `srcs` (NHWC).  Returns out (and the per-tile pool partials)."""
+           act=ACT_NONE, prelu=None, alpha=1.0, res=(), pool=False, want_aux=False, in_aux=None, in_scale=None,
+           in_alpha=1.0, epi_dact=0, epi_aux=None, out=None):
+    """Dense conv over the virtual concat of `srcs` (NHWC).  Returns out (and the per-tile pool partials /
+    the saved pre-activation when asked).  in_act 3/4/5 + in_aux/in_scale/in_alpha and epi_dact/epi_aux are the
+    activation-derivative hooks used when the same kernel runs a dgrad (include/paif_hip.h)."""
     B, H, W, C = srcs[0].shape
     assert C == cin and 1 <= len(srcs) <= 3
     res = [r for r in res if r is not None]
     extra = res[3:]
     res = res[:3]
-    out = torch.empty((B, H, W, cout), device=srcs[0].device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((B, H, W, cout), device=srcs[0].device, dtype=torch.float32)
+    else:
+        assert tuple(out.shape) == (B, H, W, cout) and out.is_contiguous()
     L = lib()
     d = _lib.ConvDesc()
     for i in range(3):
@@ -244,6 +253,9 @@ def conv2d(srcs, wpk, kh, dil=1, cin=32, cout=32, in_act=ACT_NONE, in_prelu=None
     if pool:
         partial = torch.empty((L.paif_conv2d_blocks(B, H, W), 32), device=out.device, dtype=torch.float32)
     d.pool_partial = _p(partial)
+    aux = torch.empty_like(out) if want_aux else None
+    d.aux_out, d.in_aux, d.in_scale, d.in_alpha = _p(aux), _p(in_aux), _p(in_scale), in_alpha
+    d.epi_aux, d.epi_dact = _p(epi_aux), epi_dact
     tag = "conv_mfma_%s<%d,%d,%d>" % (wpk.precision, kh, dil, cin)
     e0 = TIMER.start(tag) if TIMER is not None else None
     _lib.check(L.paif_conv2d_fwd(ctypes.byref(d), B, H, W, _stream()), "conv2d")
@@ -253,7 +265,26 @@ def conv2d(srcs, wpk, kh, dil=1, cin=32, cout=32, in_act=ACT_NONE, in_prelu=None
         TIMER.stop(tag, e0, 2 * px * kh * kh * cin * len(srcs) * cout, 4 * px * (cin * len(srcs) + cout * (1 + len(res))))
     for r in extra:  # more than 3 fused residuals: plain adds
         out = add(out, r)
+    if pool and want_aux:
+        return out, partial, aux
+    if want_aux:
+        return out, aux
     return (out, partial) if pool else out
+
+
+def pack_conv_dgrad_weight(w, coff, cs, precision=None):
+    """Forward weight w [Co, Ctot, k, k] -> packed weights of the dgrad conv w.r.t. source channels
+    [coff, coff+cs): a k x k conv with cin = Co, cout = cs, rotated taps."""
+    Co, Ctot, k, _ = w.shape
+    wt = torch.empty((cs, Co, k, k), device=w.device, dtype=torch.float32)
+    _lib.check(lib().paif_conv_weight_dgrad(_p(w.detach().contiguous()), _p(wt), Co, Ctot, k, coff, cs, _stream()), "conv_weight_dgrad")
+    return pack_conv_weight(wt, 1, Co, k, precision)
+
+
+def fold_decomp1x1_weight(w):
+    wf = torch.empty((32, 96, 1, 1), device=w.device, dtype=torch.float32)
+    _lib.check(lib().paif_fold_decomp1x1_weight(_p(w.detach().contiguous()), _p(wf), _stream()), "fold_decomp1x1_weight")
+    return wf
 
 
 def dwconv(x, w, k, dil, in_relu):
@@ -280,21 +311,78 @@ def spa_blend(comp, w, ir, vis, want_scale=False):
     return (agg, scale) if want_scale else agg
 
 
-def eca_finish(o, r, partial, w1d, k, prelu):
+def eca_finish(o, r, partial, w1d, k, prelu, save=False):
     B, H, W, _ = o.shape
     out = torch.empty_like(o)
     gate = torch.empty((B, 32), device=o.device, dtype=torch.float32)
+    u = torch.empty_like(o) if save else None
     _lib.check(lib().paif_eca_finish_fwd(_p(o), _p(r), _p(partial), _p(w1d.detach().contiguous()), k, _p(prelu), _p(gate), _p(out),
-                                         B, H, W, _stream()), "eca_finish")
+                                         _p(u), B, H, W, _stream()), "eca_finish")
+    return (out, u, gate) if save else out
+
+
+def eca_bwd(dout, u, o, gate, w1d, k, prelu):
+    B, H, W, _ = o.shape
+    L = lib()
+    partial = torch.empty((B, L.paif_eca_bwd_blocks(H, W), 32), device=o.device, dtype=torch.float32)
+    coef = torch.empty((B, 32), device=o.device, dtype=torch.float32)
+    d_o, d_r = torch.empty_like(o), torch.empty_like(o)
+    _lib.check(L.paif_eca_bwd_input(_p(dout), _p(u), _p(o), _p(gate), _p(w1d.detach().contiguous()), k, _p(prelu), _p(partial), _p(coef),
+                                    _p(d_o), _p(d_r), B, H, W, _stream()), "eca_bwd")
+    return d_o, d_r
+
+
+def spa_blend_bwd(dagg, w, ir, vis, s, add_ir=None, add_vis=None):
+    B, H, W, _ = ir.shape
+    dpre = torch.empty((B, H, W), device=ir.device, dtype=torch.float32)
+    d_ir, d_vis = torch.empty_like(ir), torch.empty_like(vis)
+    _lib.check(lib().paif_spa_blend_bwd_input(_p(dagg), _p(w.detach().contiguous()), _p(ir), _p(vis), _p(s), _p(add_ir), _p(add_vis),
+                                              _p(dpre), _p(d_ir), _p(d_vis), B, H, W, _stream()), "spa_blend_bwd")
+    return d_ir, d_vis
+
+
+def dwconv_bwd(dt, w, k, dil, aux=None, add=None):
+    B, H, W, _ = dt.shape
+    out = torch.empty_like(dt)
+    _lib.check(lib().paif_dwconv_bwd_input(_p(dt), _p(w.detach().contiguous()), _p(aux), _p(add), _p(out), k, dil, B, H, W, _stream()),
+               "dwconv_bwd")
     return out
 
 
-def tail(x16, w, prelu):
+def guided_filter_bwd(guide, y, ab, dlf, eps=(0.001, 0.0001), add=None):
+    B, H, W, _ = y.shape
+    dev = y.device
+    gstat = torch.empty((B, H, W, 2), device=dev, dtype=torch.float32)
+    t_my, t_mgy = torch.empty_like(y), torch.empty_like(y)
+    t_g = torch.empty((B, H, W, 4), device=dev, dtype=torch.float32)
+    dy = torch.empty_like(y)
+    _lib.check(lib().paif_guided_filter_bwd_input(_p(guide), _p(y), _p(ab), _p(dlf), eps[0], eps[1], _p(add), _p(gstat), _p(t_my),
+                                                  _p(t_mgy), _p(t_g), _p(dy), B, H, W, _stream()), "guided_filter_bwd")
+    return dy
+
+
+def stem_bwd(dfeat, feat, w, prelu):
+    B, H, W, _ = feat.shape
+    dimg = torch.empty((B, 1, H, W), device=feat.device, dtype=torch.float32)
+    _lib.check(lib().paif_stem_bwd_input(_p(dfeat), _p(feat), _p(w.detach().contiguous()), _p(prelu), _p(dimg), B, H, W, _stream()), "stem_bwd")
+    return dimg
+
+
+def tail_bwd(dfused, fused, z, w, prelu):
+    B, _, H, W = fused.shape
+    dt16 = torch.empty((B, H, W, 16), device=fused.device, dtype=torch.float32)
+    _lib.check(lib().paif_tail_bwd_input(_p(dfused.contiguous()), _p(fused), _p(z), _p(w.detach().contiguous()), _p(prelu), _p(dt16), B, H, W,
+                                         _stream()), "tail_bwd")
+    return dt16
+
+
+def tail(x16, w, prelu, save=False):
     B, H, W, C = x16.shape
     assert C == 16
     fused = torch.empty((B, 1, H, W), device=x16.device, dtype=torch.float32)
-    _lib.check(lib().paif_tail_fwd(_p(x16), _p(w.detach().contiguous()), _p(prelu), _p(fused), B, H, W, _stream()), "tail")
-    return fused
+    z = torch.empty((B, 1, H, W), device=x16.device, dtype=torch.float32) if save else None
+    _lib.check(lib().paif_tail_fwd(_p(x16), _p(w.detach().contiguous()), _p(prelu), _p(fused), _p(z), B, H, W, _stream()), "tail")
+    return (fused, z) if save else fused
 
 
 def add(a, b):
@@ -505,3 +593,55 @@ def nchw_to_nhwc(x):
     y = torch.empty((B, H, W, C), device=x.device, dtype=torch.float32)
     _lib.check(lib().paif_nchw_to_nhwc_fwd(_p(x), _p(y), B, H * W, C, _stream()), "nchw_to_nhwc")
     return y
+
+
+# ---------------------------------------------------------------------------------------------
+# glue backward, PGD update
+# ---------------------------------------------------------------------------------------------
+def glue_bwd(dseg, fused, ycc, minmax, dfused_direct=None):
+    """d/d(seg_in) NCHW [B,3,H,W] -> (d/d(fused) [B,1,H,W], d/d(Cr,Cb) [B,2,H,W])."""
+    B, _, H, W = ycc.shape
+    L = lib()
+    partial = torch.empty(4 * L.paif_glue_bwd_blocks(B, H, W), device=ycc.device, dtype=torch.float32)
+    dfused = torch.empty((B, 1, H, W), device=ycc.device, dtype=torch.float32)
+    dcrcb = torch.empty((B, 2, H, W), device=ycc.device, dtype=torch.float32)
+    _lib.check(L.paif_glue_bwd_input(_p(dseg.contiguous()), _p(fused), _p(ycc), _p(minmax), _p(dfused_direct), _p(partial), _p(dfused),
+                                     _p(dcrcb), B, H, W, _stream()), "glue_bwd")
+    return dfused, dcrcb
+
+
+def rgb2ycrcb_bwd(dY, dcrcb):
+    B, _, H, W = dcrcb.shape
+    dvis = torch.empty((B, 3, H, W), device=dcrcb.device, dtype=torch.float32)
+    _lib.check(lib().paif_rgb2ycrcb_bwd_input(_p(dY.contiguous()), _p(dcrcb), _p(dvis), B, H, W, _stream()), "rgb2ycrcb_bwd")
+    return dvis
+
+
+def pgd_step_(delta, grad_sum, X, alpha, eps):
+    _lib.check(lib().paif_pgd_step(_p(delta), _p(grad_sum), _p(X), alpha, eps, delta.numel(), _stream()), "pgd_step")
+    return delta
+
+
+def axpy_(y, x, a=1.0):
+    _lib.check(lib().paif_axpy(_p(y), _p(x), a, y.numel(), _stream()), "axpy")
+    return y
+
+
+# ---------------------------------------------------------------------------------------------
+# evaluation harness
+# ---------------------------------------------------------------------------------------------
+def upsample_argmax(logits_nhwc, OH, OW):
+    B, IH, IW, C = logits_nhwc.shape
+    pred = torch.empty((B, OH, OW), device=logits_nhwc.device, dtype=torch.int64)
+    _lib.check(lib().paif_upsample_argmax_fwd(_p(logits_nhwc), ctypes.c_void_p(pred.data_ptr()), B, IH, IW, C, OH, OW, _stream()),
+               "upsample_argmax")
+    return pred
+
+
+def confusion_matrix_accum_(conf, label, pred, ncls):
+    """conf: int64 [ncls, ncls] device tensor (rows = label, cols = prediction), accumulated in place."""
+    assert conf.dtype == torch.int64 and conf.is_contiguous() and label.dtype == torch.int64 and pred.dtype == torch.int64
+    label, pred = label.contiguous(), pred.contiguous()
+    _lib.check(lib().paif_confusion_matrix_accum(ctypes.c_void_p(label.data_ptr()), ctypes.c_void_p(pred.data_ptr()),
+                                                 ctypes.c_void_p(conf.data_ptr()), label.numel(), ncls, _stream()), "confusion_matrix")
+    return conf

@@ -1,0 +1,182 @@
+"""GPU parity tests of the PGD inner loop (through the C ABI) against the traces captured from the reference's own
+attack_both (tests/golden/gg_attack_*.npz) and of the input-gradient passes against the reference's gradients.
+
+Parity metric for attacks (SURVEY.md 8(a) A1 -- sign(g) is discrete, so elementwise equality of delta is the wrong
+test): loss trajectory rel. err, sign-mismatch fraction of the accumulated gradient, fraction of delta elements that
+differ, |delta| <= eps.  Gradients pass through A = cov/(var+1e-4): the reference's own fp32-vs-fp64 floor on
+d fused/d ir is 6e-3 at scale 1.7, so gradient tolerances are stated against an fp64 oracle run."""
+import numpy as np
+import pytest
+import torch
+
+from paif_amd import ops, synthetic as S
+from tests import helpers as Hh
+from tests.helpers import t, maxabs
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _exact_convs():
+    """gradient parity is asserted with the exact-fp32 conv kernels; the split-bf16 mode is checked separately"""
+    old = ops.CONFIG["conv_precision"]
+    ops.set_conv_precision("f32")
+    yield
+    ops.set_conv_precision(old)
+
+
+def _model(bb="mit_b0"):
+    from oracle.paif_oracle import FUSION_AT
+    from paif_amd.core.model_fusion_auto import Network_MM_Searched
+
+    m = Network_MM_Searched(32, FUSION_AT, None, None, bb, num_classes=9).eval()
+    S.load_formula_weights(m)
+    return m.to(_dev())
+
+
+@pytest.mark.parametrize("prim", ["Denseblocks_3_1", "DilConv_3_2", "ECAattention_3", "Residualblocks_7_1", "Denseblocks_5_2",
+                                  "Residualblocks_3_2"])
+def test_primitive_input_grad(golden, prim):
+    from paif_amd.core.model_fusion_auto import MixedOp
+
+    g = golden("ga_primitives")
+    op = MixedOp(32, prim).eval()
+    S.load_formula_weights(op, salt=Hh.PRIMITIVES.index(prim) + 1)
+    op.to(_dev())
+    x = t(S.make_smooth_feature(11, 1, 32, 24, 32)).to(_dev()).requires_grad_(True)
+    y = op(x)
+    (y * t(S.make_feature(12, (1, 32, 24, 32))).to(_dev())).sum().backward()
+    ref = g[prim + ".dx"]
+    assert maxabs(x.grad.cpu(), ref) <= 1e-4 * max(1.0, float(np.abs(ref).max()))
+
+
+def test_fusion_input_grads_vs_fp64_oracle(golden):
+    from oracle import paif_oracle as O
+    from paif_amd.core.model_fusion_auto import Network_Fusion_Searched
+
+    g = golden("gc_fusion_2x64x96")
+    net = Network_Fusion_Searched(32, None, O.FUSION_AT).eval()
+    S.load_formula_weights(net)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in net.state_dict().items()}
+    net.to(_dev())
+    ir, vis, _ = S.make_batch(2, 64, 96)
+    ycc = O.rgb2ycrcb(t(vis))
+    irt = t(ir).to(_dev()).requires_grad_(True)
+    yt = ycc[:, 0:1].contiguous().to(_dev()).requires_grad_(True)
+    fused = net(irt, yt)
+    r = t(S.make_feature(31, tuple(fused.shape)))
+    (fused * r.to(_dev())).sum().backward()
+    i64 = t(ir).double().requires_grad_(True)
+    y64 = ycc[:, 0:1].double().clone().requires_grad_(True)
+    (O.fusion_forward(i64, y64, sd64) * r.double()).sum().backward()
+    for mine, ref32, ref64 in ((irt.grad, g["d_ir"], i64.grad), (yt.grad, g["d_y"], y64.grad)):
+        floor = maxabs(t(ref32).double(), ref64)               # the reference's own fp32 error
+        assert maxabs(mine.cpu().double(), ref64) <= 1.5 * floor + 1e-5
+
+
+@pytest.mark.parametrize("bb", ["mit_b0", "mit_b3"])
+def test_wetr_input_grad(golden, bb):
+    g = golden("ge_wetr_" + bb)
+    m = _model(bb)
+    x = t(golden("gd_colour_glue")["seg_in_b2"]).to(_dev()).requires_grad_(True)
+    logits = m.denoise_net(x)
+    (logits * t(S.make_feature(41, tuple(logits.shape))).to(_dev())).sum().backward()
+    assert maxabs(x.grad.cpu(), g["dx"]) <= 1e-4 * max(1.0, float(np.abs(g["dx"]).max()))
+
+
+def _check_attack(g, d_ir, d_vis, trace, loss_rtol, frac):
+    losses = np.array([s["loss"] for s in trace])
+    np.testing.assert_allclose(losses, g["losses"], rtol=loss_rtol)
+    for mine, ref in ((trace[-1]["g_ir"], g["gsum_ir"]), (trace[-1]["g_vis"], g["gsum_vis"])):
+        assert (np.sign(mine.cpu().numpy()) != np.sign(ref)).mean() <= frac
+    for mine, ref in ((d_ir, g["delta_ir"]), (d_vis, g["delta_vis"])):
+        a = mine.detach().cpu().numpy()
+        assert (np.abs(a - ref) > 1e-6).mean() <= frac
+        assert np.abs(a).max() <= 8 / 255. + 1e-7
+
+
+def test_attack_both_pgd_hip_path(golden):
+    """attack_way='PGD': taped forward + fused upsample/CE + hand-written reverse pass + fused PGD update."""
+    from paif_amd.attack.attack import attack_both
+
+    g = golden("gg_attack_PGD")
+    m = _model("mit_b0")
+    ir, vis, lab = S.make_batch(2, 64, 96)
+    trace = []
+    with torch.no_grad():   # robust_test.py:143 calls the attack under no_grad
+        d_ir, d_vis = attack_both(m, t(vis).to(_dev()), t(ir).to(_dev()), t(lab).to(_dev()), epsilon=8 / 255., alpha=2 / 255.,
+                                  attack_iters=3, attack_loss='l_seg', attack_way='PGD',
+                                  delta0_ir=t(g["d0_ir"]), delta0_vis=t(g["d0_vis"]), trace=trace)
+    _check_attack(g, d_ir, d_vis, trace, 1e-4, 2e-3)
+    assert d_ir.grad is not None and d_vis.grad is not None   # the reference's Variables carry the accumulated grad
+
+
+@pytest.mark.parametrize("way", ["segPGD", "cosPGD"])
+def test_attack_both_variants_autograd_path(golden, way):
+    from paif_amd.attack.attack import attack_both
+
+    g = golden("gg_attack_" + way)
+    m = _model("mit_b0")
+    ir, vis, lab = S.make_batch(2, 64, 96)
+    trace = []
+    d_ir, d_vis = attack_both(m, t(vis).to(_dev()), t(ir).to(_dev()), t(lab).to(_dev()), epsilon=8 / 255., alpha=2 / 255.,
+                              attack_iters=3, attack_loss='l_seg', attack_way=way,
+                              delta0_ir=t(g["d0_ir"]), delta0_vis=t(g["d0_vis"]), trace=trace)
+    _check_attack(g, d_ir, d_vis, trace, 1e-4, 2e-3)
+
+
+def test_attack_bad_loss_returns_minus_one(capsys):
+    from paif_amd.attack.attack import attack_both
+
+    r = attack_both(None, torch.zeros(1, 3, 16, 32, device=_dev()), torch.zeros(1, 1, 16, 32, device=_dev()),
+                    torch.zeros(1, 16, 32, dtype=torch.long, device=_dev()), attack_loss='nope')
+    assert r == -1 and 'correct loss' in capsys.readouterr().out
+
+
+def test_seg_loss_and_metrics(golden):
+    from oracle import paif_oracle as O
+    from paif_amd.attack.attack import Seg_loss
+    from paif_amd.util.util import ConfusionMeter, compute_results
+
+    g = golden("gh_losses_metrics")
+    logits = t(S.make_feature(51, (2, 9, 24, 32), -3, 3)).to(_dev())
+    lab = t(S.make_label(3, 24, 32)[None].repeat(2, 0)).to(_dev())
+    with torch.no_grad():
+        l = Seg_loss()(logits, lab)
+    assert abs(float(l) - float(g["seg_loss"])) <= 1e-5
+    prec, rec, iou = compute_results(g["conf"])
+    np.testing.assert_array_equal(np.nan_to_num(iou, nan=-1), np.nan_to_num(g["iou"], nan=-1))
+    # confusion matrix on the GPU vs the oracle's bincount, through upsample x4 + argmax
+    gm = golden("gf_model_b3_4x64x96")
+    ir, vis, lab4 = S.make_batch(4, 64, 96)
+    meter = ConfusionMeter(9, _dev())
+    pred = meter.update(t(gm["logits"]).to(_dev()), t(lab4).to(_dev()))
+    assert (pred.cpu().numpy() == gm["pred"]).mean() >= 0.9999
+    conf = O.confusion_matrix(lab4, pred.cpu().numpy())
+    assert (meter.conf.cpu().numpy() == conf).all()
+
+
+def test_bf16x3_gradients_stay_within_three_floors(golden):
+    """split-bf16 convs: looser but bounded -- within 3x the reference's own fp32-vs-fp64 gradient error"""
+    from oracle import paif_oracle as O
+    from paif_amd.core.model_fusion_auto import Network_Fusion_Searched
+
+    ops.set_conv_precision("bf16x3")
+    g = golden("gc_fusion_2x64x96")
+    net = Network_Fusion_Searched(32, None, O.FUSION_AT).eval()
+    S.load_formula_weights(net)
+    net.to(_dev())
+    ir, vis, _ = S.make_batch(2, 64, 96)
+    ycc = O.rgb2ycrcb(t(vis))
+    irt = t(ir).to(_dev()).requires_grad_(True)
+    yt = ycc[:, 0:1].contiguous().to(_dev()).requires_grad_(True)
+    fused = net(irt, yt)
+    (fused * t(S.make_feature(31, tuple(fused.shape))).to(_dev())).sum().backward()
+    assert maxabs(fused.detach().cpu(), g["fused"]) <= 1e-4
+    assert maxabs(irt.grad.cpu(), g["d_ir"]) <= 3 * 6.4e-3
+    assert maxabs(yt.grad.cpu(), g["d_y"]) <= 3 * 6.4e-3
