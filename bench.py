@@ -37,6 +37,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["fusion", "fusion_seg", "pgd"], default="fusion",
+                    help="fusion = BASELINE configs[1] (the headline line); fusion_seg = configs[2] (bs=16, + mit_b3 SegFormer); "
+                         "pgd = configs[3] (PGD-10 attack + final forward, bs=8)")
     ap.add_argument("--conv-precision", choices=["f32", "bf16x3"], default="bf16x3",
                     help="arithmetic of the dense convs: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs, fp32 accumulate)")
     args = ap.parse_args()
@@ -58,21 +61,41 @@ def main():
 
     from oracle.paif_oracle import FUSION_AT  # genotype constant only (test infrastructure is not on the timed path)
     from paif_amd import ops, synthetic as S
-    from paif_amd.core.model_fusion_auto import Network_Fusion_Searched
+    from paif_amd.core.model_fusion_auto import Network_Fusion_Searched, Network_MM_Searched
 
     ops.set_conv_precision(args.conv_precision)
     DOMINANT = "conv_mfma_%s<3,1,32>" % args.conv_precision
-    net = Network_Fusion_Searched(32, None, FUSION_AT).eval()
+    bpg = 16 if args.workload == "fusion_seg" else B_PER_GPU
+    if args.workload == "fusion":
+        net = Network_Fusion_Searched(32, None, FUSION_AT).eval()
+    else:
+        net = Network_MM_Searched(32, FUSION_AT, None, None, "mit_b3", num_classes=9).eval()
     S.load_formula_weights(net)          # formula weights: no checkpoint exists (reference README.md:34-37)
     net = net.to(dev)
-    ir_np, vis_np, _ = S.make_batch(B_PER_GPU, H, W, start=rank * B_PER_GPU)   # this rank's shard
+    ir_np, vis_np, lab_np = S.make_batch(bpg, H, W, start=rank * bpg)   # this rank's shard
     ir = torch.from_numpy(ir_np).to(dev)
     vis = torch.from_numpy(vis_np).to(dev)
+    lab = torch.from_numpy(lab_np).to(dev)
 
-    def step():
-        with torch.no_grad():
-            ycc = ops.rgb2ycrcb(vis)
-            return net(ir, ycc)
+    if args.workload == "fusion":
+        def step():
+            with torch.no_grad():
+                ycc = ops.rgb2ycrcb(vis)
+                return net(ir, ycc)
+    elif args.workload == "fusion_seg":
+        def step():
+            with torch.no_grad():
+                return net(ir, vis)[1]
+    else:
+        from paif_amd.attack.attack import attack_both
+        d0i = torch.from_numpy(S.make_delta0(rank, ir_np.shape, 8 / 255.)).to(dev)
+        d0v = torch.from_numpy(S.make_delta0(100 + rank, vis_np.shape, 8 / 255.)).to(dev)
+
+        def step():
+            with torch.no_grad():   # robust_test.py:143-166: attack, then forward on the attacked pair
+                d_ir, d_vis = attack_both(net, vis, ir, lab, attack_loss="l_seg", attack_iters=10, epsilon=8 / 255., alpha=2 / 255.,
+                                          attack_way="PGD", delta0_ir=d0i, delta0_vis=d0v)
+                return net(ops.add(ir, d_ir.detach()), ops.add(vis, d_vis.detach()))[1]
 
     def barrier():
         torch.cuda.synchronize()
@@ -98,7 +121,7 @@ def main():
         dt = float(tt.item())
 
     if rank == 0:
-        pairs = B_PER_GPU * world * args.steps
+        pairs = bpg * world * args.steps
         n, ms, flops, nbytes = timer.summary()[DOMINANT]
         tflops = flops / (ms * 1e-3) / 1e12
         gbs = nbytes / (ms * 1e-3) / 1e9
@@ -114,17 +137,20 @@ def main():
         roof.update({"traffic": None, "launches": n, "avg_launch_ms": ms / n, "algorithmic_gflop_per_launch": flops / n / 1e9,
                      "algorithmic_mb_per_launch": nbytes / n / 1e6})
         res = {
-            "metric": "fused image-pairs/sec at 480x640 bs=8 per GPU (fusion-net forward)",
+            "metric": "fused image-pairs/sec at 480x640 bs=%d per GPU (%s)" % (bpg, {"fusion": "fusion-net forward", "fusion_seg": "fusion + SegFormer forward", "pgd": "PGD-10 adversarial eval"}[args.workload]),
             "value": pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.conv_precision == "f32" else "f32 storage; conv products as split-bf16 (3x bf16 MFMA, f32 accumulate)",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: fusion-net forward (RGB2YCrCb + Network_Fusion_Searched, C=32, shipped genotype), "
-                                   "480x640, bs=8/GPU, fp32 storage, conv precision %s" % args.conv_precision, "batch_per_gpu": B_PER_GPU,
+            "config": {"workload": {"fusion": "configs[1]: fusion-net forward (RGB2YCrCb + Network_Fusion_Searched, C=32, shipped genotype)",
+                                    "fusion_seg": "configs[2]: fusion + mit_b3 SegFormer end-to-end inference",
+                                    "pgd": "configs[3]: PGD-10 attack_both (fwd + input-grad bwd x10) + final forward, mit_b3"}[args.workload]
+                                   + ", 480x640, bs=%d/GPU, fp32 storage, conv precision %s" % (bpg, args.conv_precision),
+                       "batch_per_gpu": bpg,
                        "parallelism": "replicas x%d (no data-path collective)" % world},
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "fusion":
             res["cpu_baseline"] = cpu_baseline(ir_np, vis_np)
         print(json.dumps(res), flush=True)
     if dist is not None:

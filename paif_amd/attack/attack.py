@@ -118,7 +118,7 @@ def _attack(model, X_vis, X_ir, label, epsilon, alpha, attack_iters, restarts, a
                     ops.axpy_(g_vis, gv.contiguous())
                     ops.pgd_step_(d_vis, g_vis, X_vis, alpha, epsilon)
             if trace is not None:
-                trace.append(dict(loss=float(loss), g_ir=g_ir.clone(), g_vis=g_vis.clone()))
+                trace.append(dict(loss=float(loss.detach()), g_ir=g_ir.clone(), g_vis=g_vis.clone()))
     # the reference returns Variables that carry the accumulated .grad
     d_ir.requires_grad_(True)
     d_vis.requires_grad_(True)

@@ -1,0 +1,2 @@
+"""`from attack.attack import attack_both, ...` (reference test_original.py:23, robust_test.py:23)."""
+from paif_amd.attack.attack import Seg_loss, attack_both, attack_ir, attack_vis, clamp  # noqa: F401

@@ -1,0 +1,52 @@
+"""Evaluation harnesses -- counterparts of the reference's val_segformer_robust2 (test_original.py:98-258, clean eval)
+and val_segformer_robust (robust_test.py:95-239, PGD eval), without the PNG / txt I/O: per batch the model forward
+(and, for the robust harness, attack_both first), bilinear x4 upsample + argmax, 9-class confusion matrix on the GPU,
+compute_results at the end.  `batches` yields (vis [B,3,H,W], ir [B,1,H,W], label int64 [B,H,W]) device tensors
+(the reference's loader contract, TaskFusion_dataset2.py:74-104, with batch_size hard-coded to 1 at test_original.py:111)."""
+import numpy as np
+import torch
+
+from .attack.attack import attack_both
+from .util.util import ConfusionMeter
+
+
+def _summary(meter):
+    prec, rec, iou = meter.results()
+    return dict(conf=meter.conf.cpu().numpy(), precision=prec, recall=rec, iou=iou,
+                # the two means the reference prints (test_original.py:236-245): all classes / "remove unlabeled" 1..n-1
+                miou=float(np.mean(np.nan_to_num(iou))), miou_labeled=float(np.mean(np.nan_to_num(iou[1:]))),
+                macc=float(np.mean(np.nan_to_num(rec))))
+
+
+def val_segformer_robust2(model, batches, n_class=9):
+    """Clean evaluation (the attack call is commented out in the reference, test_original.py:154-158)."""
+    model.eval()
+    meter = None
+    fused_all = []
+    with torch.no_grad():
+        for vis, ir, label in batches:
+            meter = meter or ConfusionMeter(n_class, vis.device)
+            fused, seg = model.forward(ir, vis)                       # test_original.py:176
+            meter.update(seg, label)                                  # :180, :206-211
+            fused_all.append(fused)
+    out = _summary(meter)
+    out["fused"] = fused_all
+    return out
+
+
+def val_segformer_robust(model, batches, n_class=9, epsilon=8 / 255., alpha=2 / 255., attack_iters=5, attack_loss='l_seg',
+                         attack_way='PGD', delta0=None):
+    """PGD evaluation (robust_test.py:143-212): attack_both under no_grad, then forward on the attacked inputs.
+    delta0: optional callable (batch_index, X_ir, X_vis) -> (delta0_ir, delta0_vis) for a deterministic start."""
+    model.eval()
+    meter = None
+    with torch.no_grad():
+        for bi, (vis, ir, label) in enumerate(batches):
+            meter = meter or ConfusionMeter(n_class, vis.device)
+            d0 = delta0(bi, ir, vis) if delta0 is not None else (None, None)
+            d_ir, d_vis = attack_both(model, vis, ir, label, attack_loss=attack_loss, attack_iters=attack_iters, epsilon=epsilon,
+                                      alpha=alpha, attack_way=attack_way, delta0_ir=d0[0], delta0_vis=d0[1])   # :145-146
+            from . import ops
+            fused, seg = model.forward(ops.add(ir, d_ir.detach()), ops.add(vis, d_vis.detach()))                 # :147-166
+            meter.update(seg, label)
+    return _summary(meter)

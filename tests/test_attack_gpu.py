@@ -180,3 +180,41 @@ def test_bf16x3_gradients_stay_within_three_floors(golden):
     assert maxabs(fused.detach().cpu(), g["fused"]) <= 1e-4
     assert maxabs(irt.grad.cpu(), g["d_ir"]) <= 3 * 6.4e-3
     assert maxabs(yt.grad.cpu(), g["d_y"]) <= 3 * 6.4e-3
+
+
+def test_harness_clean_eval_config1(golden):
+    """H1 (test_original.py:98-258 without file I/O): 4 synthetic pairs, mit_b3 -> confusion matrix, IoU, mIoU."""
+    from paif_amd.harness import val_segformer_robust2
+
+    g = golden("gf_model_b3_4x64x96")
+    m = _model("mit_b3")
+    ir, vis, lab = S.make_batch(4, 64, 96)
+    # the reference loader uses batch_size 1, but the golden was captured on the batch of 4 (min-max is batch-global)
+    out = val_segformer_robust2(m, [(t(vis).to(_dev()), t(ir).to(_dev()), t(lab).to(_dev()))])
+    assert (out["conf"] == g["conf"]).all()
+    np.testing.assert_array_equal(np.nan_to_num(out["iou"], nan=-1), np.nan_to_num(g["iou"], nan=-1))
+    assert maxabs(out["fused"][0].cpu(), g["fused"]) <= 1e-4
+
+
+def test_harness_pgd_eval_vs_oracle():
+    """H2 (robust_test.py:95-239): PGD-3 on 2 pairs (mit_b0), attacked mIoU vs the CPU oracle's run of the same loop."""
+    from oracle import paif_oracle as O
+    from paif_amd.harness import val_segformer_robust
+
+    m = _model("mit_b0")
+    sd = Hh.model_sd("mit_b0")
+    ir, vis, lab = S.make_batch(2, 64, 96)
+    eps = 8 / 255.
+    d0_ir = t(S.make_delta0(0, ir.shape, eps))
+    d0_vis = t(S.make_delta0(1, vis.shape, eps))
+    out = val_segformer_robust(m, [(t(vis).to(_dev()), t(ir).to(_dev()), t(lab).to(_dev()))], attack_iters=3,
+                               delta0=lambda bi, a, b: (d0_ir, d0_vis))
+    fwd = lambda a, b: O.model_forward(a, b, sd, "mit_b0")
+    o_ir, o_vis = O.attack_both(fwd, t(vis), t(ir), t(lab), d0_ir, d0_vis, eps, 2 / 255., 3, "PGD")
+    with torch.no_grad():
+        _, seg = fwd(t(ir) + o_ir, t(vis) + o_vis)
+        up = torch.nn.functional.interpolate(seg, size=lab.shape[1:], mode="bilinear", align_corners=False)
+    conf = O.confusion_matrix(lab, up.argmax(1).numpy())
+    iou = O.compute_results(conf)[2]
+    assert abs(out["miou"] - float(np.mean(np.nan_to_num(iou)))) <= 1e-3          # mIoU within 0.1 pt
+    assert np.abs(out["conf"] - conf).sum() <= 0.002 * conf.sum()                 # <= 0.2 % of the pixels move

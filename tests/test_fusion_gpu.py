@@ -156,11 +156,13 @@ def test_fusion_full_size_480x640(golden):
     assert maxabs(fused.cpu(), g["fused"]) <= 2.0 * floor + 2e-5
 
 
-def test_requires_grad_fails_loudly():
+def test_train_mode_batchnorm_fails_loudly():
+    """BatchNorm batch statistics belong to the training step (not built): no silent eval-mode substitution."""
     net = _fusion_net()
-    x = torch.zeros(1, 1, 16, 32, device=_dev(), requires_grad=True)
+    net.train()
     with pytest.raises(NotImplementedError):
-        net(x, x)
+        with torch.no_grad():
+            net(torch.zeros(1, 1, 16, 32, device=_dev()), torch.zeros(1, 1, 16, 32, device=_dev()))
 
 
 def test_unknown_and_malformed_primitives():
