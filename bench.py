@@ -115,10 +115,8 @@ def main():
     dt = time.perf_counter() - t0
     ops.TIMER = None
     assert torch.isfinite(out).all()
-    if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    from paif_amd.dist_utils import max_over_ranks
+    dt = max_over_ranks(dt, dist, dev)
 
     if rank == 0:
         pairs = bpg * world * args.steps
