@@ -132,7 +132,14 @@ def main():
             # (fp32 storage) the HBM roof binds (833e12 / 8e12 = 104 FLOP/B)
             roof = {"kernel": DOMINANT, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": gbs / HBM_PEAK_GBS, "algorithmic_tflops": tflops}
-        roof.update({"traffic": None, "launches": n, "avg_launch_ms": ms / n, "algorithmic_gflop_per_launch": flops / n / 1e9,
+        traffic = None
+        try:   # PMC counters cannot be read live: use the committed rocprofv3 --pmc summary of this same command
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(DOMINANT)
+            if pm and args.workload == "fusion":
+                traffic = pm["traffic_bytes"]
+        except (OSError, ValueError):
+            pass
+        roof.update({"traffic": traffic, "launches": n, "avg_launch_ms": ms / n, "algorithmic_gflop_per_launch": flops / n / 1e9,
                      "algorithmic_mb_per_launch": nbytes / n / 1e6})
         res = {
             "metric": "fused image-pairs/sec at 480x640 bs=%d per GPU (%s)" % (bpg, {"fusion": "fusion-net forward", "fusion_seg": "fusion + SegFormer forward", "pgd": "PGD-10 adversarial eval"}[args.workload]),

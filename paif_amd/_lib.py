@@ -8,7 +8,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_size_t, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libpaif_hip.so")
+LIB_PATH = os.environ.get("PAIF_LIB") or os.path.join(HERE, "lib", "libpaif_hip.so")  # PAIF_LIB: A/B builds of the same ABI
 
 F = c_void_p  # device pointer
 
