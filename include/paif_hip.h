@@ -179,9 +179,12 @@ int paif_add_fwd(const float* a, const float* b, float* out, size_t n, paif_stre
  * (core/segformer_head.py:50-57; scale/shift = folded BatchNorm or bias) and every strided conv after
  * paif_im2col_fwd (OverlapPatchEmbed.proj core/mix_transformer.py:168, Attention.sr :74).
  * lda/ldc/ldres: row strides in floats; K % 32 == 0; scale/shift/res may be NULL;
- * act: 0 none, 1 GELU (erf), 2 ReLU. */
+ * act: 0 none, 1 GELU (erf), 2 ReLU.
+ * precision: PAIF_CONV_F32 (exact fp32 MFMA) or PAIF_CONV_BF16X3 (operands split into bf16 hi + lo at staging,
+ * hi*hi + hi*lo + lo*hi on the bf16 MFMA, fp32 accumulate: ~1e-5 relative, 5.3x less matrix-pipe time). */
 int paif_gemm_fwd(const float* A, int lda, const float* W, const float* scale, const float* shift, int act,
-                  const float* res, int ldres, float* C, int ldc, int M, int N, int K, paif_stream_t stream);
+                  const float* res, int ldres, float* C, int ldc, int M, int N, int K, int precision,
+                  paif_stream_t stream);
 
 /* nn.LayerNorm over the last dim (core/mix_transformer.py:75,122,127,172,232-253). x,y [M,C]; C % 4 == 0. */
 int paif_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, int M, int C, float eps,
@@ -228,7 +231,7 @@ int paif_nchw_to_nhwc_pad_fwd(const float* x, float* y, int B, int HW, int C, in
  * may be NULL).  Backward of ReLU(BN(.)) in front of a dgrad GEMM (core/segformer_head.py:50-55). */
 int paif_gemm_masked_fwd(const float* A, int lda, const float* a_mask, const float* a_scale, const float* W,
                          const float* scale, const float* shift, int act, const float* res, int ldres, float* C,
-                         int ldc, int M, int N, int K, paif_stream_t stream);
+                         int ldc, int M, int N, int K, int precision, paif_stream_t stream);
 /* w [N,K] -> wt [K,Npad] (zero padded): weight operand of the dgrad GEMM dA = dC . W. */
 int paif_transpose_pad_fwd(const float* w, float* wt, int N, int K, int Npad, paif_stream_t stream);
 

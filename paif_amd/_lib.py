@@ -52,7 +52,7 @@ SIGNATURES = {
     "paif_eca_finish_fwd": (c_int, [F, F, F, F, c_int, F, F, F, F, c_int, c_int, c_int, F]),
     "paif_tail_fwd": (c_int, [F, F, F, F, F, c_int, c_int, c_int, F]),
     "paif_add_fwd": (c_int, [F, F, F, c_size_t, F]),
-    "paif_gemm_fwd": (c_int, [F, c_int, F, F, F, c_int, F, c_int, F, c_int, c_int, c_int, c_int, F]),
+    "paif_gemm_fwd": (c_int, [F, c_int, F, F, F, c_int, F, c_int, F, c_int, c_int, c_int, c_int, c_int, F]),
     "paif_layernorm_fwd": (c_int, [F, F, F, F, c_int, c_int, c_float, F]),
     "paif_im2col_fwd": (c_int, [F, F, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, F]),
     "paif_pack_conv_gemm_weight": (c_int, [F, F, c_int, c_int, c_int, c_int, F]),
@@ -62,7 +62,7 @@ SIGNATURES = {
     "paif_nhwc_to_nchw_fwd": (c_int, [F, F, c_int, c_int, c_int, F]),
     "paif_nchw_to_nhwc_fwd": (c_int, [F, F, c_int, c_int, c_int, F]),
     "paif_nchw_to_nhwc_pad_fwd": (c_int, [F, F, c_int, c_int, c_int, c_int, F]),
-    "paif_gemm_masked_fwd": (c_int, [F, c_int, F, F, F, F, F, c_int, F, c_int, F, c_int, c_int, c_int, c_int, F]),
+    "paif_gemm_masked_fwd": (c_int, [F, c_int, F, F, F, F, F, c_int, F, c_int, F, c_int, c_int, c_int, c_int, c_int, F]),
     "paif_transpose_pad_fwd": (c_int, [F, F, c_int, c_int, c_int, F]),
     "paif_layernorm_bwd_input": (c_int, [F, F, F, F, F, c_int, c_int, c_float, F]),
     "paif_dwconv3_bias_gelu_bwd_input": (c_int, [F, F, F, F, F, F, c_int, c_int, c_int, c_int, F]),

@@ -118,20 +118,129 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32(GemmArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Split-bf16 ("bf16x3") GEMM: same tiling, operands split into bf16 hi + bf16 lo at staging time and multiplied as
+// hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (fp32 accumulate, ~1e-5 relative) -- 5.3x less matrix-pipe time
+// than the exact fp32 MFMA.  LDS row record (144 B): 32 x bf16 hi | 32 x bf16 lo | 16 B pad (conflict-free b128).
+// ---------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int RB = 144;  // bytes per staged row of a 32-wide K tile
+
+__device__ __forceinline__ void split_store(char* dst, float4 t4) {
+  const __bf16 hx = (__bf16)t4.x, hy = (__bf16)t4.y, hz = (__bf16)t4.z, hw = (__bf16)t4.w;
+  const __bf16 lx = (__bf16)(t4.x - (float)hx), ly = (__bf16)(t4.y - (float)hy), lz = (__bf16)(t4.z - (float)hz),
+               lw = (__bf16)(t4.w - (float)hw);
+  uint2 hi, lo;
+  hi.x = (unsigned)__builtin_bit_cast(unsigned short, hx) | ((unsigned)__builtin_bit_cast(unsigned short, hy) << 16);
+  hi.y = (unsigned)__builtin_bit_cast(unsigned short, hz) | ((unsigned)__builtin_bit_cast(unsigned short, hw) << 16);
+  lo.x = (unsigned)__builtin_bit_cast(unsigned short, lx) | ((unsigned)__builtin_bit_cast(unsigned short, ly) << 16);
+  lo.y = (unsigned)__builtin_bit_cast(unsigned short, lz) | ((unsigned)__builtin_bit_cast(unsigned short, lw) << 16);
+  *reinterpret_cast<uint2*>(dst) = hi;
+  *reinterpret_cast<uint2*>(dst + 64) = lo;
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_mfma_bf16x3(GemmArgs a) {
+  __shared__ __align__(16) char sA[BM * RB];
+  __shared__ __align__(16) char sW[BN * RB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, p = lane & 31;
+  const int tn = blockIdx.x % a.tilesN, tm = blockIdx.x / a.tilesN;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int srow = tid >> 3, sq = tid & 7;
+  const int abase = (wave * 32 + p) * RB + 16 * hh;
+  const int wbase = p * RB + 16 * hh;
+
+  for (int k0 = 0; k0 < a.K; k0 += BK) {
+    float4 va[4], vw[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = min(m0 + srow + 32 * i, a.M - 1);   // unconditional (clamped) loads; rows >= M are never stored
+      va[i] = *reinterpret_cast<const float4*>(a.A + (size_t)m * a.lda + k0 + sq * 4);
+      if (a.a_mask) {
+        const float4 mk = *reinterpret_cast<const float4*>(a.a_mask + (size_t)m * a.lda + k0 + sq * 4);
+        va[i].x = mk.x > 0.f ? va[i].x : 0.f; va[i].y = mk.y > 0.f ? va[i].y : 0.f;
+        va[i].z = mk.z > 0.f ? va[i].z : 0.f; va[i].w = mk.w > 0.f ? va[i].w : 0.f;
+      }
+      if (a.a_scale) {
+        const float4 sc4 = *reinterpret_cast<const float4*>(a.a_scale + k0 + sq * 4);
+        va[i].x *= sc4.x; va[i].y *= sc4.y; va[i].z *= sc4.z; va[i].w *= sc4.w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int n = min(n0 + srow + 32 * i, a.N - 1);   // columns >= N are never stored
+      vw[i] = *reinterpret_cast<const float4*>(a.W + (size_t)n * a.K + k0 + sq * 4);
+    }
+    if (k0 > 0) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split_store(sA + (srow + 32 * i) * RB + sq * 8, va[i]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) split_store(sW + (srow + 32 * i) * RB + sq * 8, vw[i]);
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 ah = *reinterpret_cast<const bf16x8*>(sA + abase + 32 * ks);
+      const bf16x8 al = *reinterpret_cast<const bf16x8*>(sA + abase + 64 + 32 * ks);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bf16x8 wh = *reinterpret_cast<const bf16x8*>(sW + wbase + t * 32 * RB + 32 * ks);
+        const bf16x8 wl = *reinterpret_cast<const bf16x8*>(sW + wbase + t * 32 * RB + 64 + 32 * ks);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc[t], 0, 0, 0);
+      }
+    }
+  }
+
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int n = n0 + 32 * t + p;
+    if (n >= a.N) continue;
+    const float sc = a.scale ? a.scale[n] : 1.f;
+    const float sh = a.shift ? a.shift[n] : 0.f;
+    float rv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      rv[r] = (a.res && m < a.M) ? a.res[(size_t)m * a.ldres + n] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      if (m < a.M) {
+        float v = acc[t][r] * sc + sh;
+        if (a.act == 1) v = gelu_erf(v);
+        else if (a.act == 2) v = fmaxf(v, 0.f);
+        if (a.res) v += rv[r];
+        a.C[(size_t)m * a.ldc + n] = v;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int paif_gemm_masked_fwd(const float* A, int lda, const float* a_mask, const float* a_scale, const float* W,
                                     const float* scale, const float* shift, int act, const float* res, int ldres, float* C,
-                                    int ldc, int M, int N, int K, paif_stream_t stream);
+                                    int ldc, int M, int N, int K, int precision, paif_stream_t stream);
 
 extern "C" int paif_gemm_fwd(const float* A, int lda, const float* W, const float* scale, const float* shift, int act,
-                             const float* res, int ldres, float* C, int ldc, int M, int N, int K, paif_stream_t stream) {
-  return paif_gemm_masked_fwd(A, lda, nullptr, nullptr, W, scale, shift, act, res, ldres, C, ldc, M, N, K, stream);
+                             const float* res, int ldres, float* C, int ldc, int M, int N, int K, int precision,
+                             paif_stream_t stream) {
+  return paif_gemm_masked_fwd(A, lda, nullptr, nullptr, W, scale, shift, act, res, ldres, C, ldc, M, N, K, precision, stream);
 }
 
 extern "C" int paif_gemm_masked_fwd(const float* A, int lda, const float* a_mask, const float* a_scale, const float* W,
                                     const float* scale, const float* shift, int act, const float* res, int ldres, float* C,
-                                    int ldc, int M, int N, int K, paif_stream_t stream) {
+                                    int ldc, int M, int N, int K, int precision, paif_stream_t stream) {
+  PAIF_REQUIRE(precision == 0 || precision == 1, PAIF_EINVAL, "gemm: precision=%d", precision);
   PAIF_REQUIRE(A && W && C, PAIF_EINVAL, "gemm: null pointer");
   PAIF_REQUIRE(M > 0 && N > 0 && K > 0, PAIF_EINVAL, "gemm: empty shape %dx%dx%d", M, N, K);
   PAIF_REQUIRE(K % 32 == 0, PAIF_ENOSUP, "gemm: K=%d must be a multiple of 32 (pad the operands)", K);
@@ -143,7 +252,8 @@ extern "C" int paif_gemm_masked_fwd(const float* A, int lda, const float* a_mask
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldres = res ? ldres : 0; a.act = act;
   a.tilesN = (N + BN - 1) / BN;
   a.nblk = a.tilesN * ((M + BM - 1) / BM);
-  hipLaunchKernelGGL(gemm_mfma_f32, dim3(a.nblk), dim3(256), 0, paif::as_stream(stream), a);
+  if (precision == 1) hipLaunchKernelGGL(gemm_mfma_bf16x3, dim3(a.nblk), dim3(256), 0, paif::as_stream(stream), a);
+  else hipLaunchKernelGGL(gemm_mfma_f32, dim3(a.nblk), dim3(256), 0, paif::as_stream(stream), a);
   PAIF_LAUNCH_CHECK("gemm");
   return 0;
 }

@@ -19,8 +19,15 @@ ACT_GELU = 1  # paif_gemm_fwd's act code 1 is GELU (the conv's code 1 is PReLU)
 #   "f32"    -- v_mfma_f32_32x32x2_f32, bit-exact fp32 products (parity ~1e-6 vs the fp32 reference)
 #   "bf16x3" -- split-bf16: hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate
 #               (~1e-5 relative; 5.3x less matrix-pipe time -> the convs become HBM-bound)
-CONFIG = {"conv_precision": "bf16x3"}
+CONFIG = {"conv_precision": "bf16x3", "gemm_precision": "f32"}
 _PREC_CODE = {"f32": 0, "bf16x3": 1}
+
+
+def set_gemm_precision(mode):
+    """Arithmetic of the SegFormer GEMMs: "f32" (exact fp32 MFMA) or "bf16x3" (split-bf16)."""
+    if mode not in _PREC_CODE:
+        raise ValueError("gemm precision must be one of %s" % sorted(_PREC_CODE))
+    CONFIG["gemm_precision"] = mode
 
 
 def set_conv_precision(mode):
@@ -423,10 +430,10 @@ def gemm(a, w, scale=None, shift=None, act=ACT_NONE, res=None, out=None, out_col
         assert res.shape[-1] == N and res.numel() == M * N
     if a_mask is not None:
         assert a_cols is None and a_mask.shape == a.shape
-    tag = "gemm_mfma_f32"
+    tag = "gemm_mfma_%s" % CONFIG["gemm_precision"]
     e0 = TIMER.start(tag) if TIMER is not None else None
     _lib.check(lib().paif_gemm_masked_fwd(aptr, lda, _p(a_mask), _p(a_scale), _p(w), _p(scale), _p(shift), act, _p(res), N, cptr,
-                                          ldc, M, N, K, _stream()), "gemm")
+                                          ldc, M, N, K, _PREC_CODE[CONFIG["gemm_precision"]], _stream()), "gemm")
     if e0 is not None:
         TIMER.stop(tag, e0, 2 * M * N * K, 4 * (M * K + N * K + M * N * (2 if res is not None else 1)))
     return out

@@ -153,3 +153,15 @@ if __name__ == "__main__":
     run("unit_bwd", unit_bwd)
     run("wetr_bwd mit_b0", lambda: wetr_bwd("mit_b0"))
     run("wetr_bwd mit_b3", lambda: wetr_bwd("mit_b3"))
+
+    for prec in ("f32", "bf16x3"):
+        ops.set_gemm_precision(prec)
+        print("=== gemm precision", prec, flush=True)
+        run("unit", unit)
+        holder = {}
+        def b3():
+            r, m = wetr("mit_b3"); holder["m"] = m; return r
+        run("wetr mit_b3", b3)
+        run("wetr_bwd mit_b3", lambda: wetr_bwd("mit_b3"))
+        if "m" in holder:
+            run("full 480x640", lambda: full(holder["m"]))
