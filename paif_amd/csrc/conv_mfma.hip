@@ -29,7 +29,10 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int TH = 8;    // tile rows  (one segment per row)
+#ifndef PAIF_TH
+#define PAIF_TH 8
+#endif
+constexpr int TH = PAIF_TH;    // tile rows  (one segment per row)
 constexpr int TW = 32;   // tile cols  (= MFMA M)
 constexpr int NTHREADS = 256;
 constexpr int SEGS_PER_WAVE = TH / 4;
@@ -144,6 +147,85 @@ __device__ __forceinline__ float epilogue(const ConvArgs& a, const f32x16 (&acc)
   return psum;
 }
 
+
+// Wide epilogue through LDS (guide T21: a row-per-lane dword epilogue is store-ISSUE bound): each wave parks its
+// accumulator tiles in a private LDS region as [pixel][channel] and re-reads them as float4 per (pixel, channel quad),
+// so residual loads and output stores are 16 B per lane / 1 KiB per wave-instruction (8 instead of 32 per tensor).
+// Ablation: the dword epilogue was 25 % of the 3x3 kernel (profiles/r01_ablation_conv3x3_bf16x3.txt).
+// Must be called after a __syncthreads() that retires every read of the staged tile (the region is reused).
+template <bool FULL, bool HOOKS>
+__device__ __forceinline__ float4 epilogue_lds(const ConvArgs& a, const f32x16 (&acc)[SEGS_PER_WAVE], float* lds, int b, int y0,
+                                               int x0, int wave, int lane) {
+  float* ep = lds + wave * (SEGS_PER_WAVE * 32 * 32);
+  const int h = lane >> 5, n = lane & 31;
+#pragma unroll
+  for (int sg = 0; sg < SEGS_PER_WAVE; ++sg)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ep[(sg * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 32 + n] = acc[sg][r];
+  // same wave wrote and reads: LDS operations of one wave complete in order (the compiler's lgkmcnt covers the RAW)
+  const int q = lane & 7;
+  const bool qvalid = FULL || (4 * q < a.cout);
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (qvalid) {
+    if (a.scale) sc = *reinterpret_cast<const float4*>(a.scale + 4 * q);
+    if (a.shift) sh = *reinterpret_cast<const float4*>(a.shift + 4 * q);
+  }
+  float slope = 0.f;
+  if (a.act == 1 || (HOOKS && a.epi_dact == 1)) slope = *a.prelu;
+  const int nres = a.res[0] ? (a.res[1] ? (a.res[2] ? 3 : 2) : 1) : 0;
+  float4 psum = make_float4(0.f, 0.f, 0.f, 0.f);
+  constexpr int NITER = SEGS_PER_WAVE * 32 * 8 / 64;
+  float4 r0[NITER], r1[NITER], r2[NITER], ea[NITER];
+  // element (it): pixel it*8 + lane/8 of the wave's SEGS*32 pixels, channel quad q
+  auto locate = [&](int it, size_t& off) -> bool {
+    const int pix = it * 8 + (lane >> 3);
+    const int sg = pix >> 5, px = pix & 31;
+    const int y = y0 + wave * SEGS_PER_WAVE + sg, x = x0 + px;
+    off = ((size_t)(b * a.H + y) * a.W + x) * a.cout + 4 * q;
+    return FULL || (qvalid && y < a.H && x < a.W);
+  };
+#pragma unroll
+  for (int it = 0; it < NITER; ++it) {
+    size_t off;
+    const bool ok = locate(it, off);
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    r0[it] = (nres > 0 && ok) ? *reinterpret_cast<const float4*>(a.res[0] + off) : z4;
+    r1[it] = (nres > 1 && ok) ? *reinterpret_cast<const float4*>(a.res[1] + off) : z4;
+    r2[it] = (nres > 2 && ok) ? *reinterpret_cast<const float4*>(a.res[2] + off) : z4;
+    ea[it] = (HOOKS && a.epi_dact && ok) ? *reinterpret_cast<const float4*>(a.epi_aux + off) : z4;
+  }
+#pragma unroll
+  for (int it = 0; it < NITER; ++it) {
+    size_t off;
+    const bool ok = locate(it, off);
+    const int pix = it * 8 + (lane >> 3);
+    float4 v = *reinterpret_cast<const float4*>(ep + pix * 32 + 4 * q);
+    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+    if (HOOKS && a.aux_out && ok) *reinterpret_cast<float4*>(a.aux_out + off) = v;
+    if (a.act == 1) {
+      v.x = paif::prelu_f(v.x, slope); v.y = paif::prelu_f(v.y, slope); v.z = paif::prelu_f(v.z, slope); v.w = paif::prelu_f(v.w, slope);
+    } else if (a.act == 2) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    v.x *= a.alpha; v.y *= a.alpha; v.z *= a.alpha; v.w *= a.alpha;
+    if (HOOKS && a.epi_dact == 1) {
+      v.x *= ea[it].x >= 0.f ? 1.f : slope; v.y *= ea[it].y >= 0.f ? 1.f : slope;
+      v.z *= ea[it].z >= 0.f ? 1.f : slope; v.w *= ea[it].w >= 0.f ? 1.f : slope;
+    } else if (HOOKS && a.epi_dact == 2) {
+      v.x *= ea[it].x > 0.f ? 1.f : 0.f; v.y *= ea[it].y > 0.f ? 1.f : 0.f;
+      v.z *= ea[it].z > 0.f ? 1.f : 0.f; v.w *= ea[it].w > 0.f ? 1.f : 0.f;
+    }
+    if (nres > 0) { v.x += r0[it].x; v.y += r0[it].y; v.z += r0[it].z; v.w += r0[it].w; }
+    if (nres > 1) { v.x += r1[it].x; v.y += r1[it].y; v.z += r1[it].z; v.w += r1[it].w; }
+    if (nres > 2) { v.x += r2[it].x; v.y += r2[it].y; v.z += r2[it].z; v.w += r2[it].w; }
+    if (ok) {
+      *reinterpret_cast<float4*>(a.out + off) = v;
+      psum.x += v.x; psum.y += v.y; psum.z += v.z; psum.w += v.w;
+    }
+  }
+  return psum;   // per-lane partial channel sums of quad q (for the ECA pool)
+}
+
 template <int KH, int DIL, int CIN, bool HOOKS>
 __global__ __launch_bounds__(NTHREADS, HOOKS ? 2 : 3) void conv_mfma_f32(ConvArgs a) {
   constexpr int P = DIL * (KH - 1) / 2;
@@ -255,14 +337,19 @@ __global__ __launch_bounds__(NTHREADS, HOOKS ? 2 : 3) void conv_mfma_f32(ConvArg
 
   // ---- epilogue --------------------------------------------------------------------------------
   const bool full = (y0 + TH <= a.H) && (x0 + TW <= a.W) && (a.cout == 32);  // block-uniform
-  float psum;
-  if (full) psum = epilogue<true, HOOKS>(a, acc, b, y0, x0, wave, h, p);
-  else psum = epilogue<false, HOOKS>(a, acc, b, y0, x0, wave, h, p);
+  __syncthreads();  // every wave has finished reading the staged tile: its LDS is reused by the epilogue
+  float4 ps;
+  if (full) ps = epilogue_lds<true, HOOKS>(a, acc, lds, b, y0, x0, wave, lane);
+  else ps = epilogue_lds<false, HOOKS>(a, acc, lds, b, y0, x0, wave, lane);
   if (a.pool_partial) {
-    // lanes (h=0,n) and (h=1,n) -> one value per channel per wave, then across the 4 waves via LDS
-    psum += __shfl_xor(psum, 32);
-    __syncthreads();  // tile no longer needed
-    if (lane < 32) lds[wave * 32 + lane] = psum;
+    // lanes with equal (lane & 7) hold the same channel quad for different pixels: reduce over the 8 pixel lanes,
+    // then over the 4 waves through LDS (fixed order -> deterministic)
+#pragma unroll
+    for (int m = 8; m < 64; m <<= 1) {
+      ps.x += __shfl_xor(ps.x, m); ps.y += __shfl_xor(ps.y, m); ps.z += __shfl_xor(ps.z, m); ps.w += __shfl_xor(ps.w, m);
+    }
+    __syncthreads();  // the per-wave epilogue regions are no longer needed
+    if (lane < 8) *reinterpret_cast<float4*>(lds + wave * 32 + lane * 4) = ps;
     __syncthreads();
     if (tid < 32) a.pool_partial[(size_t)tile_id * 32 + tid] = lds[tid] + lds[32 + tid] + lds[64 + tid] + lds[96 + tid];
   }
@@ -287,7 +374,10 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 }
 
 template <int KH, int DIL, bool HOOKS>
-__global__ __launch_bounds__(NTHREADS, HOOKS ? 2 : 3) void conv_mfma_bf16x3(ConvArgs a) {
+#ifndef PAIF_LB
+#define PAIF_LB 3
+#endif
+__global__ __launch_bounds__(NTHREADS, HOOKS ? 2 : PAIF_LB) void conv_mfma_bf16x3(ConvArgs a) {
   constexpr int CIN = 32;
   constexpr int P = DIL * (KH - 1) / 2;
   constexpr int TWH = TW + 2 * P;
@@ -362,14 +452,23 @@ __global__ __launch_bounds__(NTHREADS, HOOKS ? 2 : 3) void conv_mfma_bf16x3(Conv
       for (int u = 0; u < UB; ++u) {
         if (dst[u] >= 0) {
           const float4 t4 = stage_xform<HOOKS>(a, v[u], xa[u], in_slope, (dst[u] % PSB) >> 3);
+#ifdef PAIF_ABL_NO_CVT
+          uint2 hi, lo;
+          hi.x = __float_as_uint(t4.x); hi.y = __float_as_uint(t4.y); lo.x = __float_as_uint(t4.z); lo.y = __float_as_uint(t4.w);
+#else
           const __bf16 hx = (__bf16)t4.x, hy = (__bf16)t4.y, hz = (__bf16)t4.z, hw = (__bf16)t4.w;
           uint2 hi, lo;
           hi.x = (unsigned)__builtin_bit_cast(unsigned short, hx) | ((unsigned)__builtin_bit_cast(unsigned short, hy) << 16);
           hi.y = (unsigned)__builtin_bit_cast(unsigned short, hz) | ((unsigned)__builtin_bit_cast(unsigned short, hw) << 16);
           lo.x = pack_bf16(t4.x - (float)hx, t4.y - (float)hy);
           lo.y = pack_bf16(t4.z - (float)hz, t4.w - (float)hw);
+#endif
+#ifdef PAIF_ABL_NO_LDSW
+          asm volatile("" ::"v"(hi.x), "v"(hi.y), "v"(lo.x), "v"(lo.y));
+#else
           *reinterpret_cast<uint2*>(ldsb + dst[u]) = hi;
           *reinterpret_cast<uint2*>(ldsb + dst[u] + 64) = lo;
+#endif
         }
       }
     }
@@ -414,14 +513,20 @@ __global__ __launch_bounds__(NTHREADS, HOOKS ? 2 : 3) void conv_mfma_bf16x3(Conv
     }
   }
 
-  const bool full = (y0 + TH <= a.H) && (x0 + TW <= a.W) && (a.cout == 32);
-  float psum;
-  if (full) psum = epilogue<true, HOOKS>(a, acc, b, y0, x0, wave, hh, p);
-  else psum = epilogue<false, HOOKS>(a, acc, b, y0, x0, wave, hh, p);
+  const bool full = (y0 + TH <= a.H) && (x0 + TW <= a.W) && (a.cout == 32);  // block-uniform
+  __syncthreads();  // every wave has finished reading the staged tile: its LDS is reused by the epilogue
+  float4 ps;
+  if (full) ps = epilogue_lds<true, HOOKS>(a, acc, lds, b, y0, x0, wave, lane);
+  else ps = epilogue_lds<false, HOOKS>(a, acc, lds, b, y0, x0, wave, lane);
   if (a.pool_partial) {
-    psum += __shfl_xor(psum, 32);
-    __syncthreads();
-    if (lane < 32) lds[wave * 32 + lane] = psum;
+    // lanes with equal (lane & 7) hold the same channel quad for different pixels: reduce over the 8 pixel lanes,
+    // then over the 4 waves through LDS (fixed order -> deterministic)
+#pragma unroll
+    for (int m = 8; m < 64; m <<= 1) {
+      ps.x += __shfl_xor(ps.x, m); ps.y += __shfl_xor(ps.y, m); ps.z += __shfl_xor(ps.z, m); ps.w += __shfl_xor(ps.w, m);
+    }
+    __syncthreads();  // the per-wave epilogue regions are no longer needed
+    if (lane < 8) *reinterpret_cast<float4*>(lds + wave * 32 + lane * 4) = ps;
     __syncthreads();
     if (tid < 32) a.pool_partial[(size_t)tile_id * 32 + tid] = lds[tid] + lds[32 + tid] + lds[64 + tid] + lds[96 + tid];
   }
@@ -430,7 +535,9 @@ __global__ __launch_bounds__(NTHREADS, HOOKS ? 2 : 3) void conv_mfma_bf16x3(Conv
 template <int KH, int DIL, bool HOOKS>
 int launch_bf16x3_h(const ConvArgs& a, hipStream_t st) {
   constexpr int P = DIL * (KH - 1) / 2;
-  constexpr size_t lds_bytes = (size_t)(TH + 2 * P) * (TW + 2 * P) * 144;
+  constexpr size_t tile_bytes = (size_t)(TH + 2 * P) * (TW + 2 * P) * 144;
+  constexpr size_t epi_bytes = (size_t)TH * 32 * 32 * 4;
+  constexpr size_t lds_bytes = tile_bytes > epi_bytes ? tile_bytes : epi_bytes;
   static_assert(lds_bytes <= 160 * 1024, "tile does not fit LDS");
   if (lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_bf16x3<KH, DIL, HOOKS>),
@@ -640,6 +747,7 @@ int launch_bf16x3_pipe(const ConvArgs& a, hipStream_t st) {
 }
 
 
+#if PAIF_TH == 8
 // ---------------------------------------------------------------------------------------------------
 // 3x3 split-bf16 forward kernel, version 2: 8 waves, 16 x 32-pixel tiles, weights AND tile in LDS, next
 // item (tile x source) prefetched through registers during the MFMA loop.  Ablation of the plain kernel
@@ -648,16 +756,16 @@ int launch_bf16x3_pipe(const ConvArgs& a, hipStream_t st) {
 // prefetch -- so here the MFMA loop touches LDS only.
 // ---------------------------------------------------------------------------------------------------
 template <int DIL>
-__global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_v2(ConvArgs a, int tpb, int ntiles, int tilesY2) {
+__global__ __launch_bounds__(256, 1) void conv3x3_bf16x3_v2(ConvArgs a, int tpb, int ntiles, int tilesY2) {
   constexpr int KH = 3, CIN = 32, P = DIL, TH2 = 16;
-  constexpr int TWH = TW + 2 * P, THH = TH2 + 2 * P, PSB = 144, QPP = 8, NKS = 2, NTAP = 9, NT = 512;
+  constexpr int TWH = TW + 2 * P, THH = TH2 + 2 * P, PSB = 144, QPP = 8, NKS = 2, NTAP = 9, NT = 256, SG = 4;
   constexpr int TOTAL = THH * TWH * QPP;
   constexpr int NIT = (TOTAL + NT - 1) / NT;
   constexpr int TILE_BYTES = THH * TWH * PSB;
   constexpr int WQ = NTAP * NKS * 2 * 64;       // uint4 per source
   constexpr int NW = (WQ + NT - 1) / NT;
   extern __shared__ __align__(16) float lds[];
-  __shared__ float pool_s[256];
+  __shared__ float pool_s[256];   // [8 row-pairs][32 channels]
   char* ldsb = reinterpret_cast<char*>(lds);
   char* wlds = ldsb + TILE_BYTES;
 
@@ -668,9 +776,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_v2(ConvArgs a, int tpb,
   const int nitems = (t1 - t0) * a.nsrc;
   float in_slope = 0.f;
   if (a.in_act == 1) in_slope = *a.in_prelu;
-  int abase[2];
+  int abase[SG];
 #pragma unroll
-  for (int s = 0; s < 2; ++s) abase[s] = ((wave * 2 + s) * TWH + p) * PSB + 16 * hh;
+  for (int s = 0; s < SG; ++s) abase[s] = ((wave * SG + s) * TWH + p) * PSB + 16 * hh;
 
   float4 v[NIT];
   uint4 wv[NW];
@@ -741,12 +849,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_v2(ConvArgs a, int tpb,
   write_lds(0, true);
   __syncthreads();
 
-  f32x16 acc[2];
+  f32x16 acc[SG];
   for (int item = 0; item < nitems; ++item) {
     const int tl = item / a.nsrc, s = item - tl * a.nsrc;
     if (s == 0) {
 #pragma unroll
-      for (int sg = 0; sg < 2; ++sg)
+      for (int sg = 0; sg < SG; ++sg)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[sg][r] = 0.f;
     }
@@ -763,7 +871,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_v2(ConvArgs a, int tpb,
         const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wlds + ((tap * NKS + ks) * 2 + 0) * 1024 + lane * 16);
         const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wlds + ((tap * NKS + ks) * 2 + 1) * 1024 + lane * 16);
 #pragma unroll
-        for (int sg = 0; sg < 2; ++sg) {
+        for (int sg = 0; sg < SG; ++sg) {
           const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ldsb + abase[sg] + toff + 32 * ks);
           const bf16x8 al = *reinterpret_cast<const bf16x8*>(ldsb + abase[sg] + toff + 64 + 32 * ks);
           acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[sg], 0, 0, 0);
@@ -780,13 +888,22 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_v2(ConvArgs a, int tpb,
       int b, y0, x0;
       tile_coords(tile, b, y0, x0);
       const bool full = (y0 + TH2 <= a.H) && (x0 + TW <= a.W) && (a.cout == 32);
-      float psum;
-      // epilogue<> addresses rows as y0 + wave*SEGS_PER_WAVE + sg with SEGS_PER_WAVE = 2: the same mapping as here
-      if (full) psum = epilogue<true, false>(a, acc, b, y0, x0, wave, hh, p);
-      else psum = epilogue<false, false>(a, acc, b, y0, x0, wave, hh, p);
+      // epilogue<> addresses rows as y0 + w*2 + sg (2 segments per call): this wave's 4 segments are two such
+      // "virtual waves" 2*wave and 2*wave+1
+      const f32x16 lo2[2] = {acc[0], acc[1]};
+      const f32x16 hi2[2] = {acc[2], acc[3]};
+      float psum0, psum1;
+      if (full) {
+        psum0 = epilogue<true, false>(a, lo2, b, y0, x0, 2 * wave, hh, p);
+        psum1 = epilogue<true, false>(a, hi2, b, y0, x0, 2 * wave + 1, hh, p);
+      } else {
+        psum0 = epilogue<false, false>(a, lo2, b, y0, x0, 2 * wave, hh, p);
+        psum1 = epilogue<false, false>(a, hi2, b, y0, x0, 2 * wave + 1, hh, p);
+      }
       if (a.pool_partial) {
-        psum += __shfl_xor(psum, 32);
-        if (lane < 32) pool_s[wave * 32 + lane] = psum;
+        psum0 += __shfl_xor(psum0, 32);
+        psum1 += __shfl_xor(psum1, 32);
+        if (lane < 32) { pool_s[(2 * wave) * 32 + lane] = psum0; pool_s[(2 * wave + 1) * 32 + lane] = psum1; }
         __syncthreads();
         // the partial buffer is indexed by 8-row tiles (paif_conv2d_blocks): one slot per half of this 16-row tile
         if (tid < 64) {
@@ -826,10 +943,12 @@ int launch_conv3x3_v2(const ConvArgs& a, hipStream_t st) {
     if (best < 0 || cost < best || (cost == best && t > tpb)) { best = cost; tpb = t; }
   }
   const int grid = (ntiles + tpb - 1) / tpb;
-  hipLaunchKernelGGL((conv3x3_bf16x3_v2<DIL>), dim3(grid), dim3(512), lds_bytes, st, a, tpb, ntiles, tilesY2);
+  hipLaunchKernelGGL((conv3x3_bf16x3_v2<DIL>), dim3(grid), dim3(256), lds_bytes, st, a, tpb, ntiles, tilesY2);
   PAIF_LAUNCH_CHECK("conv2d(3x3 v2)");
   return 0;
 }
+
+#endif  // PAIF_TH == 8
 
 static inline bool needs_hooks(const ConvArgs& a) { return a.in_act >= 3 || a.aux_out || a.epi_dact; }
 
@@ -840,9 +959,11 @@ int launch_bf16x3(const ConvArgs& a, hipStream_t st) {
   // the 1x1 is a pure stream (HBM-bound at 4.8 TB/s already)
   // Experimental software-pipelined forms (correct, parity-tested, but NOT yet faster than the plain kernel at
   // 3 workgroups/CU -- DESIGN.md section 6): opt-in via environment for A/B runs.
+#if PAIF_TH == 8
   if constexpr (KH == 3) {
     if (a.nblk >= 64 && getenv("PAIF_CONV_V2")) return launch_conv3x3_v2<DIL>(a, st);
   }
+#endif
   if (KH >= 3 && a.nblk >= 16 && getenv("PAIF_CONV_PIPE")) return launch_bf16x3_pipe<KH, DIL>(a, st);
   return launch_bf16x3_h<KH, DIL, false>(a, st);
 }
@@ -887,7 +1008,9 @@ __global__ void pack_decomp1x1_bf16x3_kernel(const float* __restrict__ w, unsign
 template <int KH, int DIL, int CIN, bool HOOKS>
 int launch_h(const ConvArgs& a, hipStream_t st) {
   constexpr int P = DIL * (KH - 1) / 2;
-  constexpr size_t lds_bytes = (size_t)(TH + 2 * P) * (TW + 2 * P) * (CIN + 4) * 4;
+  constexpr size_t tile_bytes = (size_t)(TH + 2 * P) * (TW + 2 * P) * (CIN + 4) * 4;
+  constexpr size_t epi_bytes = (size_t)TH * 32 * 32 * 4;   // the LDS-transposed epilogue reuses the tile's LDS
+  constexpr size_t lds_bytes = tile_bytes > epi_bytes ? tile_bytes : epi_bytes;
   static_assert(lds_bytes <= 160 * 1024, "tile does not fit LDS");
   if (lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_f32<KH, DIL, CIN, HOOKS>),
