@@ -229,6 +229,29 @@ def main():
              gsum_sign_ir=np.sign(npy(d_ir.grad)).astype(np.int8), gsum_sign_vis=np.sign(npy(d_vis.grad)).astype(np.int8),
              gsum_ir=npy(d_ir.grad), gsum_vis=npy(d_vis.grad), losses=np.array(losses))
 
+    # ---- G-g2: the single-modality attacks nobody calls (attack/attack.py:117-411), 2 iterations ------------
+    with torch.no_grad():
+        X_fusion = m0(t(ir), t(vis))[0]
+    out = {}
+    cases = [
+        ("pgd_attack_ir.l_seg", lambda: R["attack"].pgd_attack_ir(m0, t(vis), t(ir), X_fusion, t(lab), eps, alpha, 2, 1, "l_seg"), ir.shape),
+        ("pgd_attack_ir.l_2", lambda: R["attack"].pgd_attack_ir(m0, t(vis), t(ir), X_fusion, t(lab), eps, alpha, 2, 1, "l_2"), ir.shape),
+        ("pgd_attack_vision.l_seg", lambda: R["attack"].pgd_attack_vision(m0, t(vis), t(ir), X_fusion, t(lab), eps, alpha, 2, 1, "l_seg"), vis.shape),
+        # fgsm_ir (:247-304) cannot run in the reference: with_mask=False hits UnboundLocalError on `black_X` (:295),
+        # with_mask=True calls get_ir_mask whose map_generate3 is undefined (:232-244) -> no golden, not built
+        ("seg_pgd.vis", lambda: R["attack"].seg_pgd(m0, t(vis), t(ir), X_fusion, t(lab), eps, alpha, 2, 1, "l_seg", "vis"), vis.shape),
+        ("cos_pgd.ir", lambda: R["attack"].cos_pgd(m0, t(vis), t(ir), X_fusion, t(lab), eps, alpha, 2, 1, "l_seg", "ir"), ir.shape),
+    ]
+    for name, fn, shp in cases:
+        torch.manual_seed(4321)
+        d0 = torch.zeros(shp).uniform_(-eps, eps)
+        torch.manual_seed(4321)
+        with ref_import.quiet():
+            d = fn()
+        out[name + ".d0"] = npy(d0)
+        out[name + ".delta"] = npy(d)
+    save("gg2_single_modality_attacks", **out)
+
     # ---- G-h: losses, metrics, schedule --------------------------------------------------------
     logits = S.make_feature(51, (2, 9, 24, 32), -3, 3)
     lab_s = S.make_label(3, 24, 32)[None].repeat(2, 0)

@@ -147,3 +147,100 @@ def attack_ir(model, X_vis, X_ir, label, epsilon=8 / 255., alpha=2 / 255., attac
     r = _attack(model, X_vis, X_ir, label, epsilon, alpha, attack_iters, restarts, attack_loss, attack_way, True, False,
                 delta0_ir, None)
     return r if r == -1 else r[0]
+
+
+# ---------------------------------------------------------------------------------------------
+# Single-modality attacks that neither entry script calls (attack/attack.py:117-411).
+# They take a FRESH gradient every iteration (torch.autograd.grad, no accumulation).  The model forward/backward is
+# the HIP autograd node; the loss glue on top (trans_format, masked / cosine losses) is torch on the device.
+# fgsm_ir (:247-304) is not provided: it cannot run in the reference either (UnboundLocalError on `black_X` at :295
+# without the mask, undefined `map_generate3` in get_ir_mask (:232-244) with it).
+# ---------------------------------------------------------------------------------------------
+def trans_format(image_fusion, images_vis):
+    """attack/attack.py:75-100: recompose RGB from the fused Y + the visible Cr/Cb, clamp, global min-max (torch ops:
+    differentiable w.r.t. image_fusion; only the image-space losses l_2 / l_1 of the unused attacks need it)."""
+    with torch.no_grad():
+        ycc = ops.rgb2ycrcb(images_vis.contiguous())
+    mat = torch.tensor([[1.0, 1.0, 1.0], [1.403, -0.714, 0.0], [0.0, -0.344, 1.773]], device=image_fusion.device)
+    bias = torch.tensor([0.0 / 255, -0.5, -0.5], device=image_fusion.device)
+    x = torch.cat((image_fusion, ycc[:, 1:2], ycc[:, 2:]), dim=1)
+    B, _, H, W = x.shape
+    rgb = (x.permute(0, 2, 3, 1).reshape(-1, 3) + bias).mm(mat).reshape(B, H, W, 3).permute(0, 3, 1, 2)
+    rgb = torch.where(rgb > 1, torch.ones_like(rgb), rgb)
+    rgb = torch.where(rgb < 0, torch.zeros_like(rgb), rgb)
+    return (rgb - torch.min(rgb)) / (torch.max(rgb) - torch.min(rgb))
+
+
+def _fresh_grad_attack(model, X_vis, X_ir, X_fusion, label, epsilon, alpha, attack_iters, restarts, mode, loss_fn, delta0):
+    X = (X_vis if mode == 'vis' else X_ir).contiguous().float()
+    delta = None
+    for _ in range(restarts):
+        delta = _init_delta(X, epsilon, delta0)
+        for i in range(attack_iters):
+            xa = ops.add(X, delta).requires_grad_(True)
+            with torch.enable_grad():
+                fused, seg_map = model(X_ir, xa) if mode == 'vis' else model(xa, X_vis)
+                loss = loss_fn(fused, seg_map, i)
+            g = torch.autograd.grad(loss, [xa])[0]
+            with torch.no_grad():
+                ops.pgd_step_(delta, g.contiguous(), X, alpha, epsilon)
+    delta.requires_grad_(True)
+    return delta
+
+
+def _image_or_seg_loss(attack_loss, X_vis, X_fusion, label, sign=1.0):
+    if attack_loss == 'l_seg':
+        crit = Seg_loss()
+        return lambda fused, seg, i: crit(F.interpolate(seg, size=label.shape[1:], mode='bilinear', align_corners=False), label)
+    if attack_loss == 'l_2':
+        crit = nn.MSELoss()
+    elif attack_loss == 'l_1':
+        crit = nn.L1Loss()
+    else:
+        raise NotImplementedError("attack_loss %r: only l_seg / l_2 / l_1 are built (l_ssim, lpips are not)" % attack_loss)
+    return lambda fused, seg, i: sign * crit(trans_format(fused, X_vis), X_fusion)
+
+
+def pgd_attack_ir(model, X_vis, X_ir, X_fusion, label, epsilon=8 / 255., alpha=2 / 255., attack_iters=50, restarts=1,
+                  attack_loss='l_2', delta0=None):
+    """attack/attack.py:117-172."""
+    return _fresh_grad_attack(model, X_vis, X_ir, X_fusion, label, epsilon, alpha, attack_iters, restarts, 'ir',
+                              _image_or_seg_loss(attack_loss, X_vis, X_fusion, label), delta0)
+
+
+def pgd_attack_vision(model, X_vis, X_ir, X_fusion, label, epsilon=8 / 255., alpha=2 / 255., attack_iters=50,
+                      restarts=1, attack_loss='l_seg', delta0=None):
+    """attack/attack.py:175-229 (the image-space losses enter with a minus sign there, :218)."""
+    return _fresh_grad_attack(model, X_vis, X_ir, X_fusion, label, epsilon, alpha, attack_iters, restarts, 'vis',
+                              _image_or_seg_loss(attack_loss, X_vis, X_fusion, label, sign=-1.0), delta0)
+
+
+def seg_pgd(model, X_vis, X_ir, X_fusion, label, epsilon=8 / 255., alpha=2 / 255., attack_iters=50, restarts=1,
+            attack_loss='l_seg', attack_mode='vis', delta0=None):
+    """attack/attack.py:307-365."""
+    crit = Seg_loss()
+
+    def loss_fn(fused, seg, i):
+        outputs = F.interpolate(seg, size=label.shape[1:], mode='bilinear', align_corners=False)
+        return _loss_variant(outputs, label, crit, 'segPGD', i, attack_iters)
+
+    return _fresh_grad_attack(model, X_vis, X_ir, X_fusion, label, epsilon, alpha, attack_iters, restarts,
+                              'vis' if attack_mode == 'vis' else 'ir', loss_fn, delta0)
+
+
+def cos_pgd(model, X_vis, X_ir, X_fusion, label, epsilon=8 / 255., alpha=2 / 255., attack_iters=50, restarts=1,
+            attack_loss='l_seg', attack_mode='vis', delta0=None):
+    """attack/attack.py:368-411."""
+    crit = Seg_loss()
+
+    def loss_fn(fused, seg, i):
+        outputs = F.interpolate(seg, size=label.shape[1:], mode='bilinear', align_corners=False)
+        return _loss_variant(outputs, label, crit, 'cosPGD', i, attack_iters)
+
+    return _fresh_grad_attack(model, X_vis, X_ir, X_fusion, label, epsilon, alpha, attack_iters, restarts,
+                              'vis' if attack_mode == 'vis' else 'ir', loss_fn, delta0)
+
+
+def fgsm_ir(*args, **kwargs):
+    raise NotImplementedError("fgsm_ir cannot run in the reference either (attack/attack.py:295 UnboundLocalError `black_X`; "
+                              "with_mask=True needs the undefined map_generate3, :232-244)")

@@ -218,3 +218,38 @@ def test_harness_pgd_eval_vs_oracle():
     iou = O.compute_results(conf)[2]
     assert abs(out["miou"] - float(np.mean(np.nan_to_num(iou)))) <= 1e-3          # mIoU within 0.1 pt
     assert np.abs(out["conf"] - conf).sum() <= 0.002 * conf.sum()                 # <= 0.2 % of the pixels move
+
+
+@pytest.mark.parametrize("name", ["pgd_attack_ir.l_seg", "pgd_attack_ir.l_2", "pgd_attack_vision.l_seg", "seg_pgd.vis", "cos_pgd.ir"])
+def test_single_modality_attacks(golden, name):
+    """A3 rows (attack/attack.py:117-411, never called by the entry scripts): fresh-gradient PGD variants, 2 iterations,
+    against the reference's own outputs.  delta moves in +-alpha steps: elements may differ only where sign(g) flips."""
+    from paif_amd.attack import attack as A
+
+    g = golden("gg2_single_modality_attacks")
+    m = _model("mit_b0")
+    ir, vis, lab = S.make_batch(2, 64, 96)
+    irt, vist, labt = t(ir).to(_dev()), t(vis).to(_dev()), t(lab).to(_dev())
+    with torch.no_grad():
+        X_fusion = m(irt, vist)[0]
+    d0 = t(g[name + ".d0"])
+    eps, alpha = 8 / 255., 2 / 255.
+    fn, mode = name.split(".")
+    if fn == "pgd_attack_ir":
+        d = A.pgd_attack_ir(m, vist, irt, X_fusion, labt, eps, alpha, 2, 1, mode, delta0=d0)
+    elif fn == "pgd_attack_vision":
+        d = A.pgd_attack_vision(m, vist, irt, X_fusion, labt, eps, alpha, 2, 1, mode, delta0=d0)
+    elif fn == "seg_pgd":
+        d = A.seg_pgd(m, vist, irt, X_fusion, labt, eps, alpha, 2, 1, "l_seg", mode, delta0=d0)
+    else:
+        d = A.cos_pgd(m, vist, irt, X_fusion, labt, eps, alpha, 2, 1, "l_seg", mode, delta0=d0)
+    a, ref = d.detach().cpu().numpy(), g[name + ".delta"]
+    assert a.shape == ref.shape and np.abs(a).max() <= eps + 1e-7
+    assert (np.abs(a - ref) > 1e-6).mean() <= 5e-3
+
+
+def test_fgsm_ir_is_unrunnable_like_the_reference():
+    from paif_amd.attack.attack import fgsm_ir
+
+    with pytest.raises(NotImplementedError):
+        fgsm_ir(None, None, None, None)
