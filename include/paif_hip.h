@@ -321,6 +321,14 @@ int paif_upsample_argmax_fwd(const float* logits, long long* pred, int B, int IH
 int paif_confusion_matrix_accum(const long long* label, const long long* pred, unsigned long long* conf, size_t n, int ncls,
                                 paif_stream_t stream);
 
+/* ---- SPAattention (operations_m.py:148-204; in the search space, not in the shipped genotype) ---- */
+/* comp = (max_c o, mean_c o); s = sigmoid(conv kxk 2->1 (comp)); out = PReLU(o*s + r).  w [1,2,k,k]; comp [B,H,W,2] scratch;
+ * s_out [B,H,W], u_out (pre-activation) optional, saved for the backward pass. */
+int paif_spa1_fwd(const float* o, const float* r, const float* w, int k, const float* prelu, float* comp, float* s_out,
+                  float* u_out, float* out, int B, int H, int W, paif_stream_t stream);
+int paif_spa1_bwd_input(const float* dout, const float* u, const float* o, const float* s, const float* w, int k,
+                        const float* prelu, float* dpre, float* d_o, float* d_r, int B, int H, int W, paif_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,6 +83,8 @@ SIGNATURES = {
     "paif_guided_filter_bwd_input": (c_int, [F, F, F, F, c_float, c_float, F, F, F, F, F, F, c_int, c_int, c_int, F]),
     "paif_upsample_argmax_fwd": (c_int, [F, F, c_int, c_int, c_int, c_int, c_int, c_int, F]),
     "paif_confusion_matrix_accum": (c_int, [F, F, F, c_size_t, c_int, F]),
+    "paif_spa1_fwd": (c_int, [F, F, F, c_int, F, F, F, F, F, c_int, c_int, c_int, F]),
+    "paif_spa1_bwd_input": (c_int, [F, F, F, F, F, c_int, F, F, F, F, c_int, c_int, c_int, F]),
     "paif_glue_bwd_blocks": (c_int, [c_int, c_int, c_int]),
     "paif_glue_bwd_input": (c_int, [F, F, F, F, F, F, F, F, c_int, c_int, c_int, F]),
     "paif_rgb2ycrcb_bwd_input": (c_int, [F, F, F, c_int, c_int, c_int, F]),

@@ -660,3 +660,165 @@ int paif_guided_filter_bwd_input(const float* guide, const float* y, const float
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// SPAattention (operations_m.py:148-204): comp = (max_c o, mean_c o); s = sigmoid(conv kxk 2->1 (comp));
+// out = PReLU(o*s + r).  Forward in two passes (pool, then conv+apply); backward mirrors spa_blend's.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void channel_pool1_kernel(const float* __restrict__ o, float* __restrict__ comp, size_t npix) {
+  const int q = threadIdx.x & 7;
+  for (size_t pix = (size_t)blockIdx.x * 32 + (threadIdx.x >> 3); pix < npix; pix += (size_t)gridDim.x * 32) {
+    const float4 a = *reinterpret_cast<const float4*>(o + pix * 32 + q * 4);
+    float mx = fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), sm = (a.x + a.y) + (a.z + a.w);
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) {
+      mx = fmaxf(mx, __shfl_xor(mx, m));
+      sm += __shfl_xor(sm, m);
+    }
+    if (q == 0) *reinterpret_cast<float2*>(comp + pix * 2) = make_float2(mx, sm * (1.0f / 32.0f));
+  }
+}
+
+__global__ __launch_bounds__(256) void spa1_apply_kernel(const float* __restrict__ comp, const float* __restrict__ w, int k,
+                                                         const float* __restrict__ o, const float* __restrict__ r,
+                                                         const float* __restrict__ prelu, float* __restrict__ s_out,
+                                                         float* __restrict__ u_out, float* __restrict__ out, int B, int H, int W) {
+  __shared__ float ws[2 * 49];
+  const int kk = k * k, pad = k / 2;
+  if ((int)threadIdx.x < 2 * kk) ws[threadIdx.x] = w[threadIdx.x];
+  __syncthreads();
+  const int q = threadIdx.x & 7;
+  const float slope = *prelu;
+  const size_t npix = (size_t)B * H * W;
+  for (size_t pix = (size_t)blockIdx.x * 32 + (threadIdx.x >> 3); pix < npix; pix += (size_t)gridDim.x * 32) {
+    const int x0 = (int)(pix % W);
+    const size_t rowid = pix / W;
+    const int y0 = (int)(rowid % H);
+    const float* cbase = comp + (rowid - y0) * W * 2;
+    float acc = 0.f;
+    for (int tap = q; tap < kk; tap += 8) {
+      const int dy = tap / k, dx = tap - dy * k;
+      const int yy = y0 + dy - pad, xx = x0 + dx - pad;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+        const float2 c = *reinterpret_cast<const float2*>(cbase + ((size_t)yy * W + xx) * 2);
+        acc = fmaf(c.x, ws[tap], acc);
+        acc = fmaf(c.y, ws[kk + tap], acc);
+      }
+    }
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) acc += __shfl_xor(acc, m);
+    const float sc = 1.0f / (1.0f + expf(-acc));
+    const float4 ov = *reinterpret_cast<const float4*>(o + pix * 32 + q * 4);
+    const float4 rv = *reinterpret_cast<const float4*>(r + pix * 32 + q * 4);
+    float4 u;
+    u.x = __fadd_rn(__fmul_rn(ov.x, sc), rv.x); u.y = __fadd_rn(__fmul_rn(ov.y, sc), rv.y);
+    u.z = __fadd_rn(__fmul_rn(ov.z, sc), rv.z); u.w = __fadd_rn(__fmul_rn(ov.w, sc), rv.w);
+    if (u_out) *reinterpret_cast<float4*>(u_out + pix * 32 + q * 4) = u;
+    if (s_out && q == 0) s_out[pix] = sc;
+    *reinterpret_cast<float4*>(out + pix * 32 + q * 4) =
+        make_float4(paif::prelu_f(u.x, slope), paif::prelu_f(u.y, slope), paif::prelu_f(u.z, slope), paif::prelu_f(u.w, slope));
+  }
+}
+
+// pass 1 of the backward: dpre = (sum_c du*o) * s(1-s), du = dout*P'(u)
+__global__ __launch_bounds__(256) void spa1_bwd_dpre_kernel(const float* __restrict__ dout, const float* __restrict__ u,
+                                                            const float* __restrict__ o, const float* __restrict__ s,
+                                                            const float* __restrict__ prelu, float* __restrict__ dpre, size_t npix) {
+  const int q = threadIdx.x & 7;
+  const float slope = *prelu;
+  for (size_t pix = (size_t)blockIdx.x * 32 + (threadIdx.x >> 3); pix < npix; pix += (size_t)gridDim.x * 32) {
+    const float4 d = *reinterpret_cast<const float4*>(dout + pix * 32 + q * 4);
+    const float4 uu = *reinterpret_cast<const float4*>(u + pix * 32 + q * 4);
+    const float4 oo = *reinterpret_cast<const float4*>(o + pix * 32 + q * 4);
+    float t = (d.x * (uu.x >= 0.f ? 1.f : slope) * oo.x + d.y * (uu.y >= 0.f ? 1.f : slope) * oo.y) +
+              (d.z * (uu.z >= 0.f ? 1.f : slope) * oo.z + d.w * (uu.w >= 0.f ? 1.f : slope) * oo.w);
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) t += __shfl_xor(t, m);
+    if (q == 0) {
+      const float sc = s[pix];
+      dpre[pix] = t * sc * (1.f - sc);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void spa1_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ u,
+                                                             const float* __restrict__ o, const float* __restrict__ s,
+                                                             const float* __restrict__ dpre, const float* __restrict__ w, int k,
+                                                             const float* __restrict__ prelu, float* __restrict__ d_o,
+                                                             float* __restrict__ d_r, int B, int H, int W) {
+  __shared__ float ws[2 * 49];
+  const int kk = k * k, pad = k / 2;
+  if ((int)threadIdx.x < 2 * kk) ws[threadIdx.x] = w[threadIdx.x];
+  __syncthreads();
+  const int q = threadIdx.x & 7;
+  const float slope = *prelu;
+  const size_t npix = (size_t)B * H * W;
+  for (size_t pix = (size_t)blockIdx.x * 32 + (threadIdx.x >> 3); pix < npix; pix += (size_t)gridDim.x * 32) {
+    const int x0 = (int)(pix % W);
+    const size_t rowid = pix / W;
+    const int y0 = (int)(rowid % H);
+    const size_t img = (rowid - y0) * W;
+    float dc0 = 0.f, dc1 = 0.f;
+    for (int tap = q; tap < kk; tap += 8) {
+      const int ky = tap / k, kx = tap - ky * k;
+      const int yy = y0 - (ky - pad), xx = x0 - (kx - pad);
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+        const float dp = dpre[img + (size_t)yy * W + xx];
+        dc0 = fmaf(dp, ws[tap], dc0);
+        dc1 = fmaf(dp, ws[kk + tap], dc1);
+      }
+    }
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) { dc0 += __shfl_xor(dc0, m); dc1 += __shfl_xor(dc1, m); }
+    const float4 oo = *reinterpret_cast<const float4*>(o + pix * 32 + q * 4);
+    float mx = oo.x; int im = 4 * q;
+    if (oo.y > mx) { mx = oo.y; im = 4 * q + 1; } if (oo.z > mx) { mx = oo.z; im = 4 * q + 2; } if (oo.w > mx) { mx = oo.w; im = 4 * q + 3; }
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) {
+      const float om = __shfl_xor(mx, m); const int oi = __shfl_xor(im, m);
+      if (om > mx || (om == mx && oi < im)) { mx = om; im = oi; }
+    }
+    const float4 d = *reinterpret_cast<const float4*>(dout + pix * 32 + q * 4);
+    const float4 uu = *reinterpret_cast<const float4*>(u + pix * 32 + q * 4);
+    float4 du;
+    du.x = d.x * (uu.x >= 0.f ? 1.f : slope); du.y = d.y * (uu.y >= 0.f ? 1.f : slope);
+    du.z = d.z * (uu.z >= 0.f ? 1.f : slope); du.w = d.w * (uu.w >= 0.f ? 1.f : slope);
+    *reinterpret_cast<float4*>(d_r + pix * 32 + q * 4) = du;
+    const float sc = s[pix], mean_g = dc1 * (1.0f / 32.0f);
+    float4 go = make_float4(du.x * sc + mean_g, du.y * sc + mean_g, du.z * sc + mean_g, du.w * sc + mean_g);
+    if ((im >> 2) == q) { const int j = im & 3; if (j == 0) go.x += dc0; else if (j == 1) go.y += dc0; else if (j == 2) go.z += dc0; else go.w += dc0; }
+    *reinterpret_cast<float4*>(d_o + pix * 32 + q * 4) = go;
+  }
+}
+
+}  // namespace
+
+extern "C" int paif_spa1_fwd(const float* o, const float* r, const float* w, int k, const float* prelu, float* comp, float* s_out,
+                             float* u_out, float* out, int B, int H, int W, paif_stream_t stream) {
+  PAIF_REQUIRE(o && r && w && prelu && comp && out && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "spa1: bad arguments");
+  PAIF_REQUIRE(k == 3 || k == 5 || k == 7, PAIF_ENOSUP, "spa1: k=%d", k);
+  hipStream_t st = paif::as_stream(stream);
+  const size_t npix = (size_t)B * H * W;
+  hipLaunchKernelGGL(channel_pool1_kernel, dim3(grid_for(npix, 32)), dim3(256), 0, st, o, comp, npix);
+  PAIF_LAUNCH_CHECK("spa1(pool)");
+  hipLaunchKernelGGL(spa1_apply_kernel, dim3(grid_for(npix, 32)), dim3(256), 0, st, comp, w, k, o, r, prelu, s_out, u_out, out, B, H, W);
+  PAIF_LAUNCH_CHECK("spa1(apply)");
+  return 0;
+}
+
+extern "C" int paif_spa1_bwd_input(const float* dout, const float* u, const float* o, const float* s, const float* w, int k,
+                                   const float* prelu, float* dpre, float* d_o, float* d_r, int B, int H, int W,
+                                   paif_stream_t stream) {
+  PAIF_REQUIRE(dout && u && o && s && w && prelu && dpre && d_o && d_r && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "spa1_bwd: bad arguments");
+  PAIF_REQUIRE(k == 3 || k == 5 || k == 7, PAIF_ENOSUP, "spa1_bwd: k=%d", k);
+  hipStream_t st = paif::as_stream(stream);
+  const size_t npix = (size_t)B * H * W;
+  hipLaunchKernelGGL(spa1_bwd_dpre_kernel, dim3(grid_for(npix, 32)), dim3(256), 0, st, dout, u, o, s, prelu, dpre, npix);
+  PAIF_LAUNCH_CHECK("spa1_bwd(dpre)");
+  hipLaunchKernelGGL(spa1_bwd_apply_kernel, dim3(grid_for(npix, 32)), dim3(256), 0, st, dout, u, o, s, dpre, w, k, prelu, d_o, d_r, B, H,
+                     W);
+  PAIF_LAUNCH_CHECK("spa1_bwd(apply)");
+  return 0;
+}

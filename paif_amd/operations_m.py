@@ -321,14 +321,25 @@ class SepConv(_HipOp):
             BatchNormParams(C_out, affine=affine),
         )
 
+    def backward_nhwc(self, g, t):
+        op = self.op
+        s1, _ = _bn_scale_shift(op[3], self._packs, 'bn1')
+        s2, _ = _bn_scale_shift(op[7], self._packs, 'bn2')
+        d_t5 = ops.conv2d([g], self._dgrad_w("c6", op[6].weight), 1, 1, in_act=ops.IN_SCALE, in_scale=s2)
+        d_z3 = ops.dwconv_bwd(d_t5, op[5].weight, self.k, 1, aux=t["z3"])          # through dw5 and the ReLU after BN3
+        d_t1 = ops.conv2d([d_z3], self._dgrad_w("c2", op[2].weight), 1, 1, in_act=ops.IN_SCALE, in_scale=s1)
+        return ops.dwconv_bwd(d_t1, op[1].weight, self.k, 1, aux=t["x"])            # through dw1 and the leading ReLU
+
     def forward_nhwc(self, x, res=(), tape=None):
-        if tape is not None:
-            raise NotImplementedError("SepConv backward kernels are not built (not in the shipped genotype)")
         op = self.op
         t = ops.dwconv(x, op[1].weight, self.k, 1, in_relu=True)
         w1 = self._packs.get("w1", [op[2].weight], lambda: ops.pack_conv_weight(op[2].weight, 1, 32, 1))
         s1, b1 = _bn_scale_shift(op[3], self._packs, 'bn1')
-        t = ops.conv2d([t], w1, 1, 1, scale=s1, shift=b1, act=ops.ACT_RELU)
+        if tape is not None:
+            t, z3 = ops.conv2d([t], w1, 1, 1, scale=s1, shift=b1, act=ops.ACT_RELU, want_aux=True)
+            tape.append(dict(x=x, z3=z3))
+        else:
+            t = ops.conv2d([t], w1, 1, 1, scale=s1, shift=b1, act=ops.ACT_RELU)
         t = ops.dwconv(t, op[5].weight, self.k, 1, in_relu=False)
         w2 = self._packs.get("w2", [op[6].weight], lambda: ops.pack_conv_weight(op[6].weight, 1, 32, 1))
         s2, b2 = _bn_scale_shift(op[7], self._packs, 'bn2')
@@ -384,8 +395,7 @@ class ECABasicBlock(_HipOp):
 
 
 class Spatial_BasicBlock(_HipOp):
-    """operations_m.py:179-204 (SPAattention): in the search space, not in the shipped genotype.
-    Constructible (state_dict parity); its fused kernels are a SURVEY.md 8(f) rank-1 follow-up."""
+    """operations_m.py:179-204 (SPAattention): in the search space, not in the shipped genotype."""
 
     def __init__(self, inplanes, planes, kernel=3, dilation=1, stride=1, reduction=64, with_norm=False):
         super().__init__()
@@ -396,7 +406,23 @@ class Spatial_BasicBlock(_HipOp):
         self.relu = PReLUParams()
 
     def forward_nhwc(self, x, res=(), tape=None):
-        raise NotImplementedError("SPAattention HIP kernels are not built yet (SURVEY.md 8(f) rank 1)")
+        a = self.relu.weight
+        w1 = self._packs.get("w1", [self.conv1.weight], lambda: ops.pack_conv_weight(self.conv1.weight, 1, 32, 3))
+        r = ops.conv2d([x], w1, 3, 1)
+        o = ops.conv2d([r], self.conv2.wpk(1, 32), self.k, 1, in_act=ops.ACT_PRELU, in_prelu=a)
+        wsp = self.se.spatial.conv.weight
+        if tape is None:
+            out = ops.spa1(o, r, wsp, self.k, a)
+        else:
+            out, u, s = ops.spa1(o, r, wsp, self.k, a, save=True)
+            tape.append(dict(r=r, o=o, u=u, s=s))
+        return self._add_res(out, res)
+
+    def backward_nhwc(self, g, t):
+        a = self.relu.weight
+        d_o, d_r = ops.spa1_bwd(g, t["u"], t["o"], t["s"], self.se.spatial.conv.weight, self.k, a)
+        d_r = ops.conv2d([d_o], self._dgrad_w("c2", self.conv2.conv.weight), self.k, 1, epi_dact=1, epi_aux=t["r"], prelu=a, res=(d_r,))
+        return ops.conv2d([d_r], self._dgrad_w("c1", self.conv1.weight), 3, 1)
 
 
 class ChannelPool(nn.Module):

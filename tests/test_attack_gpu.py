@@ -39,8 +39,7 @@ def _model(bb="mit_b0"):
     return m.to(_dev())
 
 
-@pytest.mark.parametrize("prim", ["Denseblocks_3_1", "DilConv_3_2", "ECAattention_3", "Residualblocks_7_1", "Denseblocks_5_2",
-                                  "Residualblocks_3_2"])
+@pytest.mark.parametrize("prim", Hh.PRIMITIVES)
 def test_primitive_input_grad(golden, prim):
     from paif_amd.core.model_fusion_auto import MixedOp
 
