@@ -75,6 +75,9 @@ int paif_guided_filter_ab_fwd(const float* guide, const float* y, float* ab, flo
                               int B, int H, int W, paif_stream_t stream);
 int paif_guided_filter_lf_fwd(const float* guide, const float* ab, float* lf, int B, int H, int W,
                               paif_stream_t stream);
+/* Both stages fused (inference: the coefficient maps never reach HBM); same result as ab_fwd + lf_fwd. */
+int paif_guided_filter_fused_fwd(const float* guide, const float* y, float* lf, float eps0, float eps1,
+                                 int B, int H, int W, paif_stream_t stream);
 
 /* Dense k x k convolution, stride 1, "same" zero padding (pad = dil*(k-1)/2), Cout <= 32, inputs =
  * virtual concat of up to 3 NHWC sources of `cin` channels each, fp32 MFMA (v_mfma_f32_32x32x2_f32)

@@ -20,6 +20,7 @@
 #include <stdlib.h>
 
 #include "paif_common.h"
+#include <type_traits>
 
 #ifndef PAIF_UB
 #define PAIF_UB 6   // staged float4 loads in flight per lane (forward kernels)
@@ -153,36 +154,79 @@ __device__ __forceinline__ float epilogue(const ConvArgs& a, const f32x16 (&acc)
 // so residual loads and output stores are 16 B per lane / 1 KiB per wave-instruction (8 instead of 32 per tensor).
 // Ablation: the dword epilogue was 25 % of the 3x3 kernel (profiles/r01_ablation_conv3x3_bf16x3.txt).
 // Must be called after a __syncthreads() that retires every read of the staged tile (the region is reused).
-template <bool FULL, bool HOOKS>
-__device__ __forceinline__ float4 epilogue_lds(const ConvArgs& a, const f32x16 (&acc)[SEGS_PER_WAVE], float* lds, int b, int y0,
-                                               int x0, int wave, int lane) {
-  float* ep = lds + wave * (SEGS_PER_WAVE * 32 * 32);
+// Per-launch epilogue constants of one lane (channel quad q = lane & 7).  Loaded through pointer SELECTS, not
+// branches: a load under a branch makes hipcc wait for it at the join, which put three serial L2 round trips
+// (scale, shift, slope) on every tile's critical path.
+struct EpiParams {
+  float4 sc, sh;
+  float slope;
+};
+__device__ const float k_ones[32] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f,
+                                     1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+__device__ const float k_zeros[32] = {};
+
+template <bool HOOKS>
+__device__ __forceinline__ EpiParams load_epi_params(const ConvArgs& a, int lane) {
+  const int q = lane & 7;
+  EpiParams e;
+  const bool want_slope = a.act == 1 || (HOOKS && a.epi_dact == 1);
+  const float* pp = want_slope ? a.prelu : k_zeros;
+  if (a.cout == 32) {   // launch-uniform
+    const float* sp = a.scale ? a.scale : k_ones;
+    const float* hp = a.shift ? a.shift : k_zeros;
+    e.sc = *reinterpret_cast<const float4*>(sp + 4 * q);
+    e.sh = *reinterpret_cast<const float4*>(hp + 4 * q);
+  } else {
+    float scv[4], shv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = 4 * q + j;
+      scv[j] = (a.scale && c < a.cout) ? a.scale[c] : 1.f;
+      shv[j] = (a.shift && c < a.cout) ? a.shift[c] : 0.f;
+    }
+    e.sc = make_float4(scv[0], scv[1], scv[2], scv[3]);
+    e.sh = make_float4(shv[0], shv[1], shv[2], shv[3]);
+  }
+  e.slope = *pp;
+  return e;
+}
+
+template <bool FULL, bool HOOKS, int NRES, int SEGS>
+__device__ __forceinline__ float4 epilogue_lds_n(const ConvArgs& a, const EpiParams& ep_par, const f32x16 (&acc)[SEGS],
+                                                 float* lds, int b, int y0, int x0, int wave, int lane) {
+  float* ep = lds + wave * (SEGS * 32 * 32);
   const int h = lane >> 5, n = lane & 31;
 #pragma unroll
-  for (int sg = 0; sg < SEGS_PER_WAVE; ++sg)
+  for (int sg = 0; sg < SEGS; ++sg)
 #pragma unroll
     for (int r = 0; r < 16; ++r) ep[(sg * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 32 + n] = acc[sg][r];
   // same wave wrote and reads: LDS operations of one wave complete in order (the compiler's lgkmcnt covers the RAW)
   const int q = lane & 7;
   const bool qvalid = FULL || (4 * q < a.cout);
-  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (qvalid) {
-    if (a.scale) sc = *reinterpret_cast<const float4*>(a.scale + 4 * q);
-    if (a.shift) sh = *reinterpret_cast<const float4*>(a.shift + 4 * q);
-  }
-  float slope = 0.f;
-  if (a.act == 1 || (HOOKS && a.epi_dact == 1)) slope = *a.prelu;
-  const int nres = a.res[0] ? (a.res[1] ? (a.res[2] ? 3 : 2) : 1) : 0;
+  const float4 sc = ep_par.sc, sh = ep_par.sh;
+  const float slope = ep_par.slope;
+  constexpr int nres = NRES;   // compile-time: the residual loads are straight-line, not one branch per load
   float4 psum = make_float4(0.f, 0.f, 0.f, 0.f);
-  constexpr int NITER = SEGS_PER_WAVE * 32 * 8 / 64;
+  constexpr int NITER = SEGS * 32 * 8 / 64;
   float4 r0[NITER], r1[NITER], r2[NITER], ea[NITER];
-  // element (it): pixel it*8 + lane/8 of the wave's SEGS*32 pixels, channel quad q
+  // element (it): pixel it*8 + lane/8 of the wave's SEGS*32 pixels, channel quad q.
+  // FULL tiles: (uniform row base) + (compile-time step) + (32-bit lane offset), so the address arithmetic is a
+  // handful of scalar ops per row instead of 64-bit vector multiplies per element (VALU issue shares the SIMD
+  // with the MFMA stream).
+  const unsigned lane_off = (unsigned)(lane >> 3) * 32u + 4u * (unsigned)q;
   auto locate = [&](int it, size_t& off) -> bool {
-    const int pix = it * 8 + (lane >> 3);
-    const int sg = pix >> 5, px = pix & 31;
-    const int y = y0 + wave * SEGS_PER_WAVE + sg, x = x0 + px;
-    off = ((size_t)(b * a.H + y) * a.W + x) * a.cout + 4 * q;
-    return FULL || (qvalid && y < a.H && x < a.W);
+    if constexpr (FULL) {
+      const int sg = it >> 2;
+      const size_t rowbase = ((size_t)(b * a.H + y0 + wave * SEGS + sg) * a.W + x0) * 32;
+      off = rowbase + (size_t)((it & 3) * 256) + lane_off;
+      return true;
+    } else {
+      const int pix = it * 8 + (lane >> 3);
+      const int sg = pix >> 5, px = pix & 31;
+      const int y = y0 + wave * SEGS + sg, x = x0 + px;
+      off = ((size_t)(b * a.H + y) * a.W + x) * a.cout + 4 * q;
+      return qvalid && y < a.H && x < a.W;
+    }
   };
 #pragma unroll
   for (int it = 0; it < NITER; ++it) {
@@ -219,11 +263,25 @@ __device__ __forceinline__ float4 epilogue_lds(const ConvArgs& a, const f32x16 (
     if (nres > 1) { v.x += r1[it].x; v.y += r1[it].y; v.z += r1[it].z; v.w += r1[it].w; }
     if (nres > 2) { v.x += r2[it].x; v.y += r2[it].y; v.z += r2[it].z; v.w += r2[it].w; }
     if (ok) {
+#ifndef PAIF_ABL_NO_STORE
       *reinterpret_cast<float4*>(a.out + off) = v;
+#else
+      asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+#endif
       psum.x += v.x; psum.y += v.y; psum.z += v.z; psum.w += v.w;
     }
   }
   return psum;   // per-lane partial channel sums of quad q (for the ECA pool)
+}
+
+template <bool FULL, bool HOOKS, int SEGS = SEGS_PER_WAVE>
+__device__ __forceinline__ float4 epilogue_lds(const ConvArgs& a, const EpiParams& ep_par, const f32x16 (&acc)[SEGS], float* lds,
+                                               int b, int y0, int x0, int wave, int lane) {
+  // residuals are packed from index 0; the count is launch-uniform
+  if (!a.res[0]) return epilogue_lds_n<FULL, HOOKS, 0, SEGS>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
+  if (!a.res[1]) return epilogue_lds_n<FULL, HOOKS, 1, SEGS>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
+  if (!a.res[2]) return epilogue_lds_n<FULL, HOOKS, 2, SEGS>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
+  return epilogue_lds_n<FULL, HOOKS, 3, SEGS>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
 }
 
 template <int KH, int DIL, int CIN, bool HOOKS>
@@ -337,10 +395,11 @@ __global__ __launch_bounds__(NTHREADS, HOOKS ? 2 : 3) void conv_mfma_f32(ConvArg
 
   // ---- epilogue --------------------------------------------------------------------------------
   const bool full = (y0 + TH <= a.H) && (x0 + TW <= a.W) && (a.cout == 32);  // block-uniform
+  const EpiParams ep_par = load_epi_params<HOOKS>(a, lane);   // in flight across the barrier
   __syncthreads();  // every wave has finished reading the staged tile: its LDS is reused by the epilogue
   float4 ps;
-  if (full) ps = epilogue_lds<true, HOOKS>(a, acc, lds, b, y0, x0, wave, lane);
-  else ps = epilogue_lds<false, HOOKS>(a, acc, lds, b, y0, x0, wave, lane);
+  if (full) ps = epilogue_lds<true, HOOKS>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
+  else ps = epilogue_lds<false, HOOKS>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
   if (a.pool_partial) {
     // lanes with equal (lane & 7) hold the same channel quad for different pixels: reduce over the 8 pixel lanes,
     // then over the 4 waves through LDS (fixed order -> deterministic)
@@ -514,10 +573,11 @@ __global__ __launch_bounds__(NTHREADS, HOOKS ? 2 : PAIF_LB) void conv_mfma_bf16x
   }
 
   const bool full = (y0 + TH <= a.H) && (x0 + TW <= a.W) && (a.cout == 32);  // block-uniform
+  const EpiParams ep_par = load_epi_params<HOOKS>(a, lane);   // in flight across the barrier
   __syncthreads();  // every wave has finished reading the staged tile: its LDS is reused by the epilogue
   float4 ps;
-  if (full) ps = epilogue_lds<true, HOOKS>(a, acc, lds, b, y0, x0, wave, lane);
-  else ps = epilogue_lds<false, HOOKS>(a, acc, lds, b, y0, x0, wave, lane);
+  if (full) ps = epilogue_lds<true, HOOKS>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
+  else ps = epilogue_lds<false, HOOKS>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
   if (a.pool_partial) {
     // lanes with equal (lane & 7) hold the same channel quad for different pixels: reduce over the 8 pixel lanes,
     // then over the 4 waves through LDS (fixed order -> deterministic)
@@ -950,6 +1010,360 @@ int launch_conv3x3_v2(const ConvArgs& a, hipStream_t st) {
 
 #endif  // PAIF_TH == 8
 
+// ---------------------------------------------------------------------------------------------------
+// Wave-specialised persistent form of the split-bf16 kernel (forward, no hooks, no in-activation, cout == 32).
+// The plain kernel runs load -> LDS -> MFMA -> store as serial phases of one workgroup and relies on 3
+// workgroups per CU drifting apart to overlap them.  Here the overlap is structural: one workgroup per CU,
+// 12 waves in three roles, one wave of each role per SIMD:
+//   LOADERS  (waves 8-11): stream (tile, source) stages HBM -> registers -> split-bf16 -> LDS tile[stage & 1];
+//            the loads of stage g+1 are issued before stage g is converted (two register sets, counted vmcnt);
+//   MFMA     (waves 0-3):  run the MFMA loop on tile[(g-1) & 1]; their only memory traffic is the B-operand
+//            ring from L2 (loads only); after a tile's last source they park the accumulators in LDS;
+//   STORERS  (waves 4-7):  pick the parked tile up, apply scale/shift/activation/alpha, add the residual maps
+//            and store -- the only waves that mix loads and stores.
+// Why three roles (cycle-stamped timeline + ablations of the two-role form):
+//   * hipcc's wait-count pass treats vmcnt as out-of-order once a wave has loads AND stores pending and then
+//     waits vmcnt(0): a wave that loads B and stores outputs stalls on its own stores, a wave that loads tiles
+//     and stores outputs loses its prefetch.  Keeping every role single-kind keeps the waits counted.
+//   * VMEM issue back-pressure (store queue behind the HBM read stream) stalled the MFMA wave for 2.6 us per
+//     tile when it issued the stores itself.
+//   * MFMA and VALU of the waves of one SIMD share its issue port: the loader is written for instruction count
+//     (per-lane tile coordinates computed once per launch; med3 + mad + shift per load with 32-bit offsets from a
+//     scalar base; the hi/lo split is 10 packed instructions per float4) and the MFMA waves run no address math.
+// A step has two LDS-only barriers (no vmcnt drain): phase A = load/convert | MFMA | store, phase B = park.
+// Tiles are dealt so that the 32 workgroups of one XCD walk a contiguous tile range (halo rows hit that XCD's L2).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// fp32 x4 -> (hi bf16 x4, lo bf16 x4): v_cvt_pk_bf16_f32 / shift / and / v_pk_add_f32 (10 instructions)
+__device__ __forceinline__ void split_bf16x4(float4 t, uint2& hi, uint2& lo) {
+  const f32x2 a = {t.x, t.y}, b = {t.z, t.w};
+  const unsigned ua = __builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16x2));
+  const unsigned ub = __builtin_bit_cast(unsigned, __builtin_convertvector(b, bf16x2));
+  const f32x2 ra = {t.x - __uint_as_float(ua << 16), t.y - __uint_as_float(ua & 0xffff0000u)};
+  const f32x2 rb = {t.z - __uint_as_float(ub << 16), t.w - __uint_as_float(ub & 0xffff0000u)};
+  hi = make_uint2(ua, ub);
+  lo = make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(ra, bf16x2)),
+                  __builtin_bit_cast(unsigned, __builtin_convertvector(rb, bf16x2)));
+}
+
+#ifdef PAIF_WS_TRACE
+__device__ unsigned long long g_ws_trace[8 * 64];
+#define WS_MARK(stage, k)                                                                       \
+  do {                                                                                          \
+    if (blockIdx.x == 0 && (stage) >= 0 && (stage) < 64 && (threadIdx.x & 63) == 0)             \
+      g_ws_trace[(stage) * 8 + (k)] = __builtin_readcyclecounter();                             \
+  } while (0)
+#else
+#define WS_MARK(stage, k) do { } while (0)
+#endif
+
+constexpr int WS_THREADS = 12 * 64;
+
+template <int KH, int DIL>
+__global__ __launch_bounds__(WS_THREADS, 1) void conv_bf16x3_ws(ConvArgs a, int ntiles) {
+  static_assert(TH == 8, "the MFMA-wave mapping assumes 8-row tiles");
+  constexpr int CIN = 32;
+  constexpr int P = DIL * (KH - 1) / 2;
+  constexpr int TWH = TW + 2 * P;
+  constexpr int THH = TH + 2 * P;
+  constexpr int PSB = 144;
+  constexpr int QPP = CIN / 4;
+  constexpr int NKS = CIN / 16;
+  constexpr int NTAP = KH * KH;
+  constexpr int NB = NTAP * NKS * 2;   // uint4 of B per lane per source
+  constexpr int TILE_BYTES = THH * TWH * PSB;
+  extern __shared__ __align__(16) float lds[];
+  char* ldsb = reinterpret_cast<char*>(lds);
+  float* outbuf = reinterpret_cast<float*>(ldsb + 2 * TILE_BYTES);   // [8 rows][32 px][32 ch] fp32
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: scalar role branch
+
+  // tile schedule: XCD x owns tiles [x*per, (x+1)*per); its workgroups interleave over that range
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+  const int per = (ntiles + 7) >> 3;
+  const int tbeg = xcd * per + slot, tend = min(ntiles, (xcd + 1) * per);
+  const int cnt = tbeg < tend ? (tend - tbeg + nslot - 1) / nslot : 0;
+  const int nsrc = a.nsrc;
+  const int S = cnt * nsrc;            // stages; steps g = 0 .. S+1, two barriers each
+  auto tile_of = [&](int i, int& b, int& y0, int& x0) {
+    int t = tbeg + i * nslot;
+    x0 = (t % a.tilesX) * TW;
+    t /= a.tilesX;
+    y0 = (t % a.tilesY) * TH;
+    b = t / a.tilesY;
+  };
+
+  if (wave >= 8) {
+    // ------------------------------- loaders -------------------------------
+    const int pt = tid - 8 * 64;
+    const unsigned q16 = (unsigned)(pt & 7) * 16u;
+    constexpr int TOTAL = THH * TWH * QPP;
+    constexpr int NIT = (TOTAL + 255) / 256;
+    // per-lane tile coordinates of its NIT elements: fixed for the whole launch
+    int tyy[NIT], txx[NIT];
+    unsigned ldo[NIT];
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+      const int pix = min(pt + u * 256, TOTAL - 1) >> 3;
+      tyy[u] = pix / TWH;
+      txx[u] = pix - tyy[u] * TWH;
+      ldo[u] = (unsigned)pix * PSB + (unsigned)(pt & 7) * 8u;
+    }
+    const bool live_last = pt + (NIT - 1) * 256 < TOTAL;
+    // Every load is unconditional on a clamped stage / address (a load under a branch makes hipcc wait at the
+    // join); the in-image mask travels with the register set and zero padding is applied at the LDS write.
+    auto issue = [&](int st, float4 (&v)[NIT], unsigned& mask) {
+      st = min(st, S - 1);
+      const int i = st / nsrc, s = st - i * nsrc;
+      int b, y0, x0;
+      tile_of(i, b, y0, x0);
+      const char* base = reinterpret_cast<const char*>(a.src[s]) + (size_t)b * a.H * a.W * (CIN * 4);
+      const int y0p = y0 - P, x0p = x0 - P;
+      unsigned m = 0;
+#pragma unroll
+      for (int u = 0; u < NIT; ++u) {
+        const int gy = y0p + tyy[u], gx = x0p + txx[u];
+        const int gyc = min(max(gy, 0), a.H - 1), gxc = min(max(gx, 0), a.W - 1);
+        const unsigned off = ((unsigned)(gyc * a.W + gxc) << 7) + q16;   // < 4 GiB per image: checked at launch
+        v[u] = *reinterpret_cast<const float4*>(base + off);
+        m |= (gy == gyc && gx == gxc) ? (1u << u) : 0u;
+      }
+      mask = m;
+    };
+    auto commit = [&](int st, const float4 (&v)[NIT], unsigned mask) {
+      char* buf = ldsb + (st & 1) * TILE_BYTES;
+#pragma unroll
+      for (int u = 0; u < NIT; ++u) {
+        uint2 hi, lo;
+        split_bf16x4(v[u], hi, lo);
+        if (!((mask >> u) & 1u)) hi = lo = make_uint2(0u, 0u);
+        if (u < NIT - 1 || live_last) {
+          *reinterpret_cast<uint2*>(buf + ldo[u]) = hi;
+          *reinterpret_cast<uint2*>(buf + ldo[u] + 64) = lo;
+        }
+      }
+    };
+    if (S > 0) {
+      // straight-line pair body + peeled odd tail: with a conditional second half the wait-count pass must assume
+      // set B is still pending at the loop header and drains vmcnt(0) there, which kills the prefetch
+      float4 va[NIT], vb[NIT];
+      unsigned ma, mb;
+      issue(0, va, ma);
+      const int npair = S >> 1;
+      for (int k = 0; k < npair; ++k) {
+        const int st = 2 * k;
+        if (wave == 8) WS_MARK(st, 0);
+        issue(st + 1, vb, mb);
+        commit(st, va, ma);
+        if (wave == 8) WS_MARK(st, 1);
+        lds_barrier();
+        lds_barrier();
+        if (wave == 8) WS_MARK(st + 1, 0);
+        issue(st + 2, va, ma);
+        commit(st + 1, vb, mb);
+        if (wave == 8) WS_MARK(st + 1, 1);
+        lds_barrier();
+        lds_barrier();
+      }
+      if (S & 1) {
+        commit(S - 1, va, ma);
+        lds_barrier();
+        lds_barrier();
+      }
+    }
+    lds_barrier();   // steps S and S+1
+    lds_barrier();
+    lds_barrier();
+    lds_barrier();
+  } else if (wave < 4) {
+    // ------------------------------- MFMA waves -------------------------------
+    const int hh = lane >> 5, p = lane & 31;
+    int abase[2];
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) abase[sg] = ((wave * 2 + sg) * TWH + p) * PSB + 16 * hh;
+    // park address of acc[sg][r]: pixel (row = wave*2+sg, px = (r&3) + 8*(r>>2) + 4*hh), channel p
+    const int pbase = (wave * 2 * 32 + 4 * hh) * 32 + p;
+    f32x16 acc[2];
+    // B-operand ring: 3 taps in registers (4 x 16 B per lane per tap), refilled from L2 three taps ahead and running
+    // straight into the next stage's taps (NTAP % 3 == 0 keeps the slots static).  The L2 hits queue behind the
+    // loaders' HBM stream in the CU's memory pipeline (~3.4k cycles per B load under load, cycle-stamped), which is
+    // what still paces this loop; a 6-tap ring (two statically indexed stage phases) spills at 168 registers.
+    constexpr int BR = NTAP % 3 == 0 ? 3 : 1;
+    static_assert(NTAP % BR == 0, "ring slots must stay static across stages");
+    uint4 bw[BR][NKS * 2];
+    const uint4* wbase = reinterpret_cast<const uint4*>(a.wpk) + lane;
+#pragma unroll
+    for (int t = 0; t < BR; ++t)
+#pragma unroll
+      for (int j = 0; j < NKS * 2; ++j) bw[t][j] = wbase[(t * NKS * 2 + j) * 64];
+    int s = 0;
+    for (int g = 0; g <= S + 1; ++g) {
+      const bool work = g >= 1 && g <= S;
+      const bool last = s == nsrc - 1;
+      if (work) {
+        if (wave == 0) WS_MARK(g - 1, 4);
+        const char* buf = ldsb + ((g - 1) & 1) * TILE_BYTES;
+        const int ns = last ? 0 : s + 1;
+        const uint4* wcur = wbase + (size_t)s * NB * 64;
+        const uint4* wnxt = wbase + (size_t)ns * NB * 64;   // always a valid source: the refill needs no branch
+        if (s == 0) {
+#pragma unroll
+          for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[sg][r] = 0.f;
+        }
+#pragma unroll
+        for (int tap = 0; tap < NTAP; ++tap) {
+          const int dy = tap / KH, dx = tap - dy * KH;
+          const int toff = (dy * DIL * TWH + dx * DIL) * PSB;
+#pragma unroll
+          for (int ks = 0; ks < NKS; ++ks) {
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, bw[tap % BR][ks * 2]);
+            const bf16x8 bl = __builtin_bit_cast(bf16x8, bw[tap % BR][ks * 2 + 1]);
+#pragma unroll
+            for (int sg = 0; sg < 2; ++sg) {
+              const bf16x8 ah = *reinterpret_cast<const bf16x8*>(buf + abase[sg] + toff + 32 * ks);
+              const bf16x8 al = *reinterpret_cast<const bf16x8*>(buf + abase[sg] + toff + 64 + 32 * ks);
+              acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[sg], 0, 0, 0);
+              acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[sg], 0, 0, 0);
+              acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[sg], 0, 0, 0);
+            }
+          }
+          {
+            const int nt = tap + BR;
+            const uint4* wsrc = nt < NTAP ? wcur + (size_t)nt * NKS * 2 * 64 : wnxt + (size_t)(nt - NTAP) * NKS * 2 * 64;
+#pragma unroll
+            for (int j = 0; j < NKS * 2; ++j) bw[tap % BR][j] = wsrc[j * 64];
+          }
+        }
+        if (wave == 0) WS_MARK(g - 1, 5);
+      }
+      lds_barrier();
+      if (work) {
+        if (last) {
+#pragma unroll
+          for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) outbuf[pbase + (sg * 32 + (r & 3) + 8 * (r >> 2)) * 32] = acc[sg][r];
+        }
+        s = last ? 0 : s + 1;
+        if (wave == 0) WS_MARK(g - 1, 6);
+      }
+      lds_barrier();
+    }
+  } else {
+    // ------------------------------- storers -------------------------------
+    const int t = tid - 4 * 64;
+    const int q = t & 7, px = t >> 3;
+    const float4 sc = *reinterpret_cast<const float4*>((a.scale ? a.scale : k_ones) + 4 * q);
+    const float4 sh = *reinterpret_cast<const float4*>((a.shift ? a.shift : k_zeros) + 4 * q);
+    const float slope = *(a.act == 1 ? a.prelu : k_zeros);
+    const int nres = a.res[0] ? (a.res[1] ? (a.res[2] ? 3 : 2) : 1) : 0;
+    const unsigned lane_off = (unsigned)px * 32u + 4u * (unsigned)q;
+    // The residual maps of tile e+1 are requested right after tile e has been stored, so they are in flight for a
+    // whole tile period (a storer mixes loads and stores, its waits are vmcnt(0) anyway -- but everything it waits
+    // for is a step old).  Loads are unconditional on clamped coordinates; the store is predicated.
+    auto run = [&](auto nres_c) {
+      constexpr int NR = decltype(nres_c)::value;
+      float4 r[NR > 0 ? NR : 1][8];
+      auto request = [&](int i) {
+        int b, y0, x0;
+        tile_of(min(i, cnt - 1), b, y0, x0);
+        const size_t base = ((size_t)(b * a.H + y0) * a.W + x0) * 32;
+        const unsigned lo = x0 + px < a.W ? lane_off : 0u;
+#pragma unroll
+        for (int k = 0; k < NR; ++k)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int yy = min(y0 + j, a.H - 1) - y0;
+            r[k][j] = *reinterpret_cast<const float4*>(a.res[k] + base + (size_t)yy * a.W * 32 + lo);
+          }
+      };
+      if (cnt > 0) request(0);
+      // a tile parked in phase B of step g-1 (stage g-2 was the last source of its tile) is stored in phase A of step g
+      int s2 = 0, i2 = 0;   // source index / tile index of stage g-2
+      for (int g = 0; g <= S + 1; ++g) {
+        if (g >= 2) {
+          if (s2 == nsrc - 1) {
+            if (wave == 4) WS_MARK(g - 2, 2);
+            int b, y0, x0;
+            tile_of(i2, b, y0, x0);
+            float4 o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = *reinterpret_cast<const float4*>(outbuf + (j * 32 + px) * 32 + 4 * q);
+            const size_t base = ((size_t)(b * a.H + y0) * a.W + x0) * 32;
+            const bool colok = x0 + px < a.W;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              float4 v = o[j];
+              v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+              if (a.act == 1) {
+                v.x = paif::prelu_f(v.x, slope); v.y = paif::prelu_f(v.y, slope);
+                v.z = paif::prelu_f(v.z, slope); v.w = paif::prelu_f(v.w, slope);
+              } else if (a.act == 2) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+              }
+              v.x *= a.alpha; v.y *= a.alpha; v.z *= a.alpha; v.w *= a.alpha;
+#pragma unroll
+              for (int k = 0; k < NR; ++k) { v.x += r[k][j].x; v.y += r[k][j].y; v.z += r[k][j].z; v.w += r[k][j].w; }
+              if (colok && y0 + j < a.H)
+                *reinterpret_cast<float4*>(a.out + base + (size_t)j * a.W * 32 + lane_off) = v;
+            }
+            if (NR > 0) request(i2 + 1);
+            if (wave == 4) WS_MARK(g - 2, 3);
+          }
+          if (++s2 == nsrc) { s2 = 0; ++i2; }
+        }
+        lds_barrier();
+        lds_barrier();
+      }
+    };
+    if (nres == 0) run(std::integral_constant<int, 0>{});
+    else if (nres == 1) run(std::integral_constant<int, 1>{});
+    else if (nres == 2) run(std::integral_constant<int, 2>{});
+    else run(std::integral_constant<int, 3>{});
+  }
+}
+
+template <int KH, int DIL>
+int launch_bf16x3_ws(const ConvArgs& a, hipStream_t st) {
+  constexpr int P = DIL * (KH - 1) / 2;
+  constexpr size_t lds_bytes = 2 * (size_t)(TH + 2 * P) * (TW + 2 * P) * 144 + 8 * 32 * 32 * 4;
+  static_assert(lds_bytes <= 160 * 1024, "two tile buffers + the parked tile do not fit LDS");
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_ws<KH, DIL>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e != hipSuccess) {
+    paif::set_error("conv2d(bf16x3 ws): cannot raise dynamic LDS to %zu: %s", lds_bytes, hipGetErrorString(e));
+    return (int)e;
+  }
+  hipLaunchKernelGGL((conv_bf16x3_ws<KH, DIL>), dim3(256), dim3(WS_THREADS), lds_bytes, st, a, a.nblk);
+  PAIF_LAUNCH_CHECK("conv2d(bf16x3 ws)");
+  return 0;
+}
+
+// the loaders address a source image with 32-bit byte offsets; in-activations and the ECA pool stay on the plain kernel
+static inline bool ws_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("PAIF_CONV_WS");   // PAIF_CONV_WS=0 selects the plain kernel everywhere (A/B runs)
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+static inline bool ws_eligible(const ConvArgs& a) {
+  return ws_enabled() && a.nblk >= 1024 && !a.pool_partial && a.cout == 32 && a.in_act == 0 &&
+         (size_t)a.H * a.W * 128 < ((size_t)1 << 32);
+}
+
 static inline bool needs_hooks(const ConvArgs& a) { return a.in_act >= 3 || a.aux_out || a.epi_dact; }
 
 template <int KH, int DIL>
@@ -965,6 +1379,15 @@ int launch_bf16x3(const ConvArgs& a, hipStream_t st) {
   }
 #endif
   if (KH >= 3 && a.nblk >= 16 && getenv("PAIF_CONV_PIPE")) return launch_bf16x3_pipe<KH, DIL>(a, st);
+#if PAIF_TH == 8
+  if constexpr (KH <= 3) {
+    // persistent wave-specialised form: needs several tiles per CU to amortise its pipeline fill
+    // measured per configuration against the plain kernel (tools/conv_bench.py, B=8 480x640): faster everywhere
+    // except 3x3 / 3 sources / >= 2 residual maps, where the storers' residual traffic paces the tile (-4 %)
+    const bool many_res = a.res[0] && a.res[1];
+    if (ws_eligible(a) && !(KH == 3 && DIL == 1 && a.nsrc == 3 && many_res)) return launch_bf16x3_ws<KH, DIL>(a, st);
+  }
+#endif
   return launch_bf16x3_h<KH, DIL, false>(a, st);
 }
 
@@ -1076,6 +1499,12 @@ __global__ void bn_fold_kernel(const float* g, const float* bta, const float* me
 }  // namespace
 
 extern "C" {
+#ifdef PAIF_WS_TRACE
+// debug builds only (tools/ws_trace.py): cycle stamps of workgroup 0's first producer and first consumer wave
+int paif_debug_ws_trace(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ws_trace), sizeof(unsigned long long) * 8 * 64);
+}
+#endif
 
 int paif_conv2d_blocks(int B, int H, int W) { return B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW); }
 

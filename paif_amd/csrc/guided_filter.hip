@@ -203,3 +203,168 @@ int paif_guided_filter_lf_fwd(const float* guide, const float* ab, float* lf, in
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// Fused guided filter (inference path): stage 1 and stage 2 in ONE kernel, the coefficient maps A, b never
+// touch HBM (the two-kernel form writes 4 and re-reads 4 x 1.33 thirty-two-channel maps per stream).
+// Two-level row streaming: ring 1 = last 9 rows of (y, g) in registers -> vertical sums -> LDS -> horizontal sums
+// -> (A_e, b_e) of row i; ring 2 = last 9 rows of (A_e, b_e) in registers -> vertical sums -> LDS -> horizontal sums
+// -> LF_e of row i-4.  One eps per blockIdx.y (the register budget holds one (A, b) ring).
+// Workgroup = 64 loaded columns x 8 channel quads (512 threads); 56 columns carry valid stage-1 values,
+// 48 columns valid outputs.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int FC = 64;             // loaded columns
+constexpr int FO = FC - 4 * R;     // 48 output columns
+#ifndef PAIF_GF_FROWS
+#define PAIF_GF_FROWS 120
+#endif
+constexpr int FROWS = PAIF_GF_FROWS;   // output rows per workgroup
+constexpr int PF = 3;                  // rows of (y, g) loads kept in flight ahead of the row being processed
+
+// LDS-only barrier: the rows' output stores and the prefetched loads stay in flight across it (a __syncthreads()
+// fence would drain vmcnt; nothing in this kernel communicates through global memory).
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+__global__ __launch_bounds__(512) void gf_fused_kernel(const float* __restrict__ guide, const float* __restrict__ y,
+                                                       float* __restrict__ lf, float eps0, float eps1, int B, int H, int W,
+                                                       int nstrip, int nseg) {
+  __shared__ float4 s_a[2][FC][8];
+  __shared__ float4 s_b[2][FC][8];
+  __shared__ float2 s_g[2][FC];
+  const int q = threadIdx.x & 7, xi = threadIdx.x >> 3;
+  int t = blockIdx.x;
+  const int strip = t % nstrip; t /= nstrip;
+  const int seg = t % nseg;
+  const int b = t / nseg;
+  const int e = blockIdx.y;
+  const float eps = e == 0 ? eps0 : eps1;
+  const int col = strip * FO - 2 * R + xi;
+  const bool colin = col >= 0 && col < W;
+  const int ybeg = seg * FROWS, yend = min(H, ybeg + FROWS);
+  const size_t img = (size_t)b * H * W;
+  float* out = lf + (size_t)e * ((size_t)B * H * W * 32);
+
+  float4 ry[K], rA[K], rB[K];
+  float rg[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) { rA[k] = make_float4(0.f, 0.f, 0.f, 0.f); rB[k] = rA[k]; }
+  const int r0 = ybeg - 2 * R, r1 = yend + 2 * R;   // streamed input rows [r0, r1)
+  // Loads are unconditional on a clamped address (a load under a divergent branch makes hipcc wait for it at the
+  // join); out-of-image values are zeroed when they enter the ring.
+  const int colc = min(max(col, 0), W - 1);
+  float4 pv[PF];
+  float pg[PF];
+#pragma unroll
+  for (int p = 0; p < PF; ++p) {
+    const size_t px = img + (size_t)min(max(r0 + p, 0), H - 1) * W + colc;
+    pv[p] = *reinterpret_cast<const float4*>(y + px * 32 + q * 4);
+    pg[p] = guide[px];
+  }
+  for (int rr = r0; rr < r1; rr += K) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int row = rr + k;
+      if (row >= r1) break;   // block-uniform
+      const bool in = colin && row >= 0 && row < H;
+      ry[k] = in ? pv[k % PF] : make_float4(0.f, 0.f, 0.f, 0.f);
+      rg[k] = in ? pg[k % PF] : 0.f;
+      {
+        const size_t px = img + (size_t)min(max(row + PF, 0), H - 1) * W + colc;
+        pv[k % PF] = *reinterpret_cast<const float4*>(y + px * 32 + q * 4);
+        pg[k % PF] = guide[px];
+      }
+      const int irow = row - R;               // stage-1 row whose 9-row window is complete
+      if (irow < ybeg - R) continue;          // block-uniform
+      // ---- stage 1: vertical sums -> LDS -> horizontal sums -> (A, b) of (irow, col) ----
+      {
+        float4 vy = make_float4(0.f, 0.f, 0.f, 0.f), vgy = vy;
+        float vg = 0.f, vgg = 0.f;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          vy = f4add(vy, ry[j]);
+          vgy = f4fma(rg[j], ry[j], vgy);
+          vg += rg[j];
+          vgg = fmaf(rg[j], rg[j], vgg);
+        }
+        s_a[0][xi][q] = vy;
+        s_b[0][xi][q] = vgy;
+        if (q == 0) s_g[0][xi] = make_float2(vg, vgg);
+      }
+      lds_barrier();
+      float4 A = make_float4(0.f, 0.f, 0.f, 0.f), Bc = A;
+      if (xi >= R && xi < FC - R && colin && irow >= 0 && irow < H) {   // outside the image the coefficients are zero padding
+        float4 by = make_float4(0.f, 0.f, 0.f, 0.f), bgy = by;
+        float bg = 0.f, bgg = 0.f;
+#pragma unroll
+        for (int j = -R; j <= R; ++j) {
+          by = f4add(by, s_a[0][xi + j][q]);
+          bgy = f4add(bgy, s_b[0][xi + j][q]);
+          const float2 gg = s_g[0][xi + j];
+          bg += gg.x;
+          bgg += gg.y;
+        }
+        const int cy = min(irow + R, H - 1) - max(irow - R, 0) + 1;
+        const int cx = min(col + R, W - 1) - max(col - R, 0) + 1;
+        const float rn = 1.0f / (float)(cy * cx);   // one exact division; x * (1/n) is within 1 ulp of x / n
+        const float mg = bg * rn;
+        const float rden = 1.0f / (bgg * rn - mg * mg + eps);
+        const float4 my = make_float4(by.x * rn, by.y * rn, by.z * rn, by.w * rn);
+        A = make_float4((bgy.x * rn - mg * my.x) * rden, (bgy.y * rn - mg * my.y) * rden, (bgy.z * rn - mg * my.z) * rden,
+                        (bgy.w * rn - mg * my.w) * rden);
+        Bc = make_float4(my.x - A.x * mg, my.y - A.y * mg, my.z - A.z * mg, my.w - A.w * mg);
+      }
+      rA[k] = A;   // ring 2 shares the slot index with ring 1 (both advance one row per iteration)
+      rB[k] = Bc;
+      const int orow = irow - R;              // output row whose 9-row (A, b) window is complete
+      // the first ring-2 window is complete once stage-1 rows ybeg-R .. ybeg+R are in
+      if (orow < ybeg) { lds_barrier(); continue; }   // block-uniform; the barrier keeps s_*[0] safe for the next row
+      // ---- stage 2: vertical sums of (A, b) -> LDS -> horizontal sums -> LF ----
+      {
+        float4 ua = make_float4(0.f, 0.f, 0.f, 0.f), ub = ua;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          ua = f4add(ua, rA[j]);
+          ub = f4add(ub, rB[j]);
+        }
+        s_a[1][xi][q] = ua;
+        s_b[1][xi][q] = ub;
+      }
+      lds_barrier();
+      if (xi >= 2 * R && xi < FC - 2 * R && col < W) {
+        float4 ba = make_float4(0.f, 0.f, 0.f, 0.f), bb = ba;
+#pragma unroll
+        for (int j = -R; j <= R; ++j) {
+          ba = f4add(ba, s_a[1][xi + j][q]);
+          bb = f4add(bb, s_b[1][xi + j][q]);
+        }
+        const int cy = min(orow + R, H - 1) - max(orow - R, 0) + 1;
+        const int cx = min(col + R, W - 1) - max(col - R, 0) + 1;
+        const float rn = 1.0f / (float)(cy * cx);
+        const size_t px = img + (size_t)orow * W + col;
+        const float g0 = rg[(k + 1) % K];   // guide(orow, col): the oldest ring-1 row (row - 2R)
+        *reinterpret_cast<float4*>(out + px * 32 + q * 4) =
+            make_float4(fmaf(ba.x * rn, g0, bb.x * rn), fmaf(ba.y * rn, g0, bb.y * rn), fmaf(ba.z * rn, g0, bb.z * rn),
+                        fmaf(ba.w * rn, g0, bb.w * rn));
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int paif_guided_filter_fused_fwd(const float* guide, const float* y, float* lf, float eps0, float eps1, int B, int H,
+                                            int W, paif_stream_t stream) {
+  PAIF_REQUIRE(guide && y && lf && B > 0, PAIF_EINVAL, "guided_filter_fused: bad arguments");
+  PAIF_REQUIRE(H > 2 * R + 1 && W > 2 * R + 1, PAIF_EINVAL, "guided_filter: H,W must exceed 2r+1 = %d (got %dx%d)", K, H, W);
+  const int nstrip = (W + FO - 1) / FO, nseg = (H + FROWS - 1) / FROWS;
+  hipLaunchKernelGGL(gf_fused_kernel, dim3(B * nstrip * nseg, 2), dim3(512), 0, paif::as_stream(stream), guide, y, lf, eps0, eps1, B,
+                     H, W, nstrip, nseg);
+  PAIF_LAUNCH_CHECK("guided_filter_fused");
+  return 0;
+}

@@ -178,9 +178,12 @@ def guided_filter_pair(guide, y, eps=(0.001, 0.0001), want_ab=False):
     B, H, W, C = y.shape
     assert C == 32
     assert H > 9 and W > 9, "guided filter needs H, W > 2r+1 = 9"
-    ab = torch.empty((4, B, H, W, 32), device=y.device, dtype=torch.float32)
     lf = torch.empty((2, B, H, W, 32), device=y.device, dtype=torch.float32)
     L = lib()
+    if not want_ab and CONFIG.get("gf_fused", True):
+        _lib.check(L.paif_guided_filter_fused_fwd(_p(guide), _p(y), _p(lf), eps[0], eps[1], B, H, W, _stream()), "guided_filter_fused")
+        return lf
+    ab = torch.empty((4, B, H, W, 32), device=y.device, dtype=torch.float32)
     _lib.check(L.paif_guided_filter_ab_fwd(_p(guide), _p(y), _p(ab), eps[0], eps[1], B, H, W, _stream()), "guided_filter_ab")
     _lib.check(L.paif_guided_filter_lf_fwd(_p(guide), _p(ab), _p(lf), B, H, W, _stream()), "guided_filter_lf")
     return (lf, ab) if want_ab else lf

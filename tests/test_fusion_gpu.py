@@ -75,6 +75,23 @@ def test_guided_filter(golden):
         ops.guided_filter_pair(torch.zeros(1, 9, 20, device=_dev()), torch.zeros(1, 9, 20, 32, device=_dev()))
 
 
+@pytest.mark.parametrize("shape", [(1, 24, 32), (2, 50, 70), (1, 130, 97), (1, 10, 10), (1, 251, 49)])
+def test_guided_filter_fused_matches_two_kernel_form(shape):
+    """The inference path fuses both stages (coefficient maps stay on chip); the gradient path keeps them.
+    Both must agree on ragged sizes (strip / segment / image borders in every combination)."""
+    from paif_amd import ops
+
+    B, H, W = shape
+    y = ops.to_nhwc(t(S.make_smooth_feature(5, B, 32, H, W)).to(_dev()))
+    guide = ops.channel_residue(y)
+    fused = ops.guided_filter_pair(guide, y)
+    two, _ab = ops.guided_filter_pair(guide, y, want_ab=True)
+    assert torch.isfinite(fused).all()
+    # 1/n and 1/(var+eps) are formed once and multiplied in the fused kernel (divisions in the two-kernel form):
+    # a few ulp through A = cov / (var + eps)
+    assert maxabs(fused.cpu(), two.cpu()) <= 1e-5 * max(1.0, float(two.abs().max()))
+
+
 def _fusion_net(prefix=""):
     """prefix='enhance_net.' gives the weights the fusion net has INSIDE the composite model's goldens
     (the formula is keyed on the full state_dict key)."""
