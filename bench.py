@@ -11,7 +11,8 @@ the C ABI.  One process per GPU; replicas only (no data-path collective: the pat
         bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0 (contract in the task statement): value = whole-job pairs/s, plus
-  roofline     -- dominant kernel (3x3 fp32-MFMA conv), HIP-event timed on its launch stream inside the timed region
+  roofline     -- dominant kernel (the 3x3 dense conv: conv_bf16x3_ws<3,1>, or conv_mfma_f32<3,1,32> with --conv-precision f32),
+                  HIP-event timed on its launch stream inside the timed region
   cpu_baseline -- the CPU oracle (torch fp32 port of the reference) on the host cores, bounded sample, rank 0, N=1 only
 """
 import argparse
@@ -64,7 +65,9 @@ def main():
     from paif_amd.core.model_fusion_auto import Network_Fusion_Searched, Network_MM_Searched
 
     ops.set_conv_precision(args.conv_precision)
-    DOMINANT = "conv_mfma_%s<3,1,32>" % args.conv_precision
+    # the 3x3 dense convs: at bf16x3 they run on the persistent wave-specialised kernel (10 of the 12 launches per
+    # step; the ECA-pool conv and the 3-source/3-residual conv stay on conv_mfma_bf16x3), at f32 on conv_mfma_f32
+    DOMINANT = "conv_bf16x3_ws<3,1>" if args.conv_precision == "bf16x3" else "conv_mfma_f32<3,1,32>"
     bpg = 16 if args.workload == "fusion_seg" else B_PER_GPU
     if args.workload == "fusion":
         net = Network_Fusion_Searched(32, None, FUSION_AT).eval()

@@ -124,6 +124,9 @@ typedef struct {
 
 int paif_conv2d_blocks(int B, int H, int W);
 int paif_conv2d_fwd(const paif_conv_desc* d, int B, int H, int W, paif_stream_t stream);
+/* 1 if paif_conv2d_fwd would run this descriptor on the persistent wave-specialised kernel (conv_bf16x3_ws),
+ * 0 for the tile-per-workgroup kernel (conv_mfma_*): lets a profiler-side caller name the kernel it times. */
+int paif_conv2d_is_persistent(const paif_conv_desc* d, int B, int H, int W);
 /* w: torch layout [cout, nsrc*cin, kh, kh]; wpk: paif_conv_wpk_floats(...) floats.
  * Layout wpk[src][tap][cin/8][64 lanes][4]: lane (h = lane>>5, n = lane&31) holds
  * w[n][src*cin + 8*o + 4*h + i][tap], i = 0..3 -- the B operand of four consecutive MFMAs. */

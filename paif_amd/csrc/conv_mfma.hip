@@ -91,64 +91,6 @@ __device__ __forceinline__ float4 stage_xform(const ConvArgs& a, float4 v, float
 }
 
 // Fused epilogue of one wave: y = act(acc*scale+shift)*alpha (+res0 +res1 +res2), NHWC store.
-// FULL = interior tile with cout == 32: no per-element predicates, so the compiler can issue all
-// residual loads of a segment, then all stores, without intervening waits.
-template <bool FULL, bool HOOKS>
-__device__ __forceinline__ float epilogue(const ConvArgs& a, const f32x16 (&acc)[SEGS_PER_WAVE], int b, int y0, int x0,
-                                          int wave, int h, int n) {
-  const bool nvalid = FULL || n < a.cout;
-  float sc = 1.f, sh = 0.f, slope = 0.f;
-  if (nvalid) {
-    if (a.scale) sc = a.scale[n];
-    if (a.shift) sh = a.shift[n];
-  }
-  if (a.act == 1 || (HOOKS && a.epi_dact == 1)) slope = *a.prelu;
-  const int nres = a.res[0] ? (a.res[1] ? (a.res[2] ? 3 : 2) : 1) : 0;  // residuals are packed from index 0
-  float psum = 0.f;
-#pragma unroll
-  for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) {
-    const int y = y0 + wave * SEGS_PER_WAVE + sg;
-    const bool rowok = FULL || (nvalid && y < a.H);
-    const size_t rowbase = ((size_t)(b * a.H + y) * a.W + x0 + 4 * h) * a.cout + n;
-    float r0[16], r1[16], r2[16], ea[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int dx = (r & 3) + 8 * (r >> 2);
-      const bool ok = FULL || (rowok && x0 + dx + 4 * h < a.W);
-      const size_t o = rowbase + (size_t)dx * a.cout;
-      r0[r] = (nres > 0 && ok) ? a.res[0][o] : 0.f;
-      r1[r] = (nres > 1 && ok) ? a.res[1][o] : 0.f;
-      r2[r] = (nres > 2 && ok) ? a.res[2][o] : 0.f;
-      ea[r] = (HOOKS && a.epi_dact && ok) ? a.epi_aux[o] : 0.f;
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int dx = (r & 3) + 8 * (r >> 2);
-      const bool ok = FULL || (rowok && x0 + dx + 4 * h < a.W);
-      float v = acc[sg][r] * sc + sh;
-      if (HOOKS && a.aux_out && ok) a.aux_out[rowbase + (size_t)dx * a.cout] = v;
-      if (a.act == 1) v = paif::prelu_f(v, slope);
-      else if (a.act == 2) v = fmaxf(v, 0.f);
-      v *= a.alpha;
-      if (HOOKS && a.epi_dact == 1) v *= ea[r] >= 0.f ? 1.f : slope;      // d PReLU (slope = *prelu)
-      else if (HOOKS && a.epi_dact == 2) v *= ea[r] > 0.f ? 1.f : 0.f;    // d ReLU
-      if (nres > 0) v += r0[r];
-      if (nres > 1) v += r1[r];
-      if (nres > 2) v += r2[r];
-      if (ok) {
-#ifndef PAIF_ABL_NO_STORE
-        a.out[rowbase + (size_t)dx * a.cout] = v;
-#else
-        asm volatile("" ::"v"(v));
-#endif
-        psum += v;
-      }
-    }
-  }
-  return psum;
-}
-
-
 // Wide epilogue through LDS (guide T21: a row-per-lane dword epilogue is store-ISSUE bound): each wave parks its
 // accumulator tiles in a private LDS region as [pixel][channel] and re-reads them as float4 per (pixel, channel quad),
 // so residual loads and output stores are 16 B per lane / 1 KiB per wave-instruction (8 instead of 32 per tensor).
@@ -614,403 +556,6 @@ int launch_bf16x3_h(const ConvArgs& a, hipStream_t st) {
 
 
 // ---------------------------------------------------------------------------------------------------
-// Software-pipelined split-bf16 kernel (forward path, no dgrad hooks).  The plain kernel above spends ~63 % of
-// its wave cycles in s_waitcnt (rocprofv3 SQ_WAIT_ANY, profiles/r01_pmc_*): staging and MFMA phases of one
-// workgroup do not overlap.  Here a workgroup walks TPB consecutive tiles x nsrc sources as a flat list of
-// items and issues the global loads of item i+1 into REGISTERS before the MFMA loop of item i, writing them to
-// LDS (with the bf16 hi/lo split) after it -- one LDS buffer, HBM latency hidden behind the matrix pipe.
-// ---------------------------------------------------------------------------------------------------
-template <int KH, int DIL>
-__global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_bf16x3_pipe(ConvArgs a, int tpb, int ntiles) {
-  constexpr int CIN = 32;
-  constexpr int P = DIL * (KH - 1) / 2;
-  constexpr int TWH = TW + 2 * P;
-  constexpr int THH = TH + 2 * P;
-  constexpr int PSB = 144;
-  constexpr int QPP = CIN / 4;
-  constexpr int NKS = CIN / 16;
-  constexpr int NTAP = KH * KH;
-  constexpr int TOTAL = THH * TWH * QPP;
-  constexpr int NIT = (TOTAL + NTHREADS - 1) / NTHREADS;
-  extern __shared__ __align__(16) float lds[];
-  __shared__ float pool_s[128];
-  char* ldsb = reinterpret_cast<char*>(lds);
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int hh = lane >> 5;
-  const int p = lane & 31;
-
-  // this workgroup's tiles: [t0, t1) in the XCD-remapped order (neighbouring tiles -> same L2)
-  const int blk = paif::xcd_remap(blockIdx.x, gridDim.x);
-  const int t0 = blk * tpb, t1 = min(ntiles, t0 + tpb);
-  if (t0 >= t1) return;
-  const int nitems = (t1 - t0) * a.nsrc;
-
-  float in_slope = 0.f;
-  if (a.in_act == 1) in_slope = *a.in_prelu;
-
-  int abase[SEGS_PER_WAVE];
-#pragma unroll
-  for (int s = 0; s < SEGS_PER_WAVE; ++s) abase[s] = ((wave * SEGS_PER_WAVE + s) * TWH + p) * PSB + 16 * hh;
-
-  float4 v[NIT];
-  auto tile_coords = [&](int tile, int& b, int& y0, int& x0) {
-    const int tx = tile % a.tilesX;
-    const int r = tile / a.tilesX;
-    y0 = (r % a.tilesY) * TH;
-    b = r / a.tilesY;
-    x0 = tx * TW;
-  };
-  auto issue_loads = [&](int item) {
-    const int tile = t0 + item / a.nsrc, s = item - (item / a.nsrc) * a.nsrc;
-    int b, y0, x0;
-    tile_coords(tile, b, y0, x0);
-    const float* src = a.src[s];
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {   // unconditional clamped loads (see conv3x3_bf16x3_v2)
-      const int idx = min(tid + i * NTHREADS, TOTAL - 1);
-      const int pix = idx / QPP, q = idx - pix * QPP;
-      const int tyy = pix / TWH, txx = pix - tyy * TWH;
-      const int gy = min(max(y0 - P + tyy, 0), a.H - 1), gx = min(max(x0 - P + txx, 0), a.W - 1);
-      v[i] = *reinterpret_cast<const float4*>(src + ((size_t)(b * a.H + gy) * a.W + gx) * CIN + q * 4);
-    }
-  };
-  auto write_lds = [&](int item) {
-    int wb, wy0, wx0;
-    tile_coords(t0 + item / a.nsrc, wb, wy0, wx0);
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const int idx = tid + i * NTHREADS;
-      if (idx < TOTAL) {
-        const int pix = idx / QPP, q = idx - pix * QPP;
-        const int tyy = pix / TWH, txx = pix - tyy * TWH;
-        const int gy = wy0 - P + tyy, gx = wx0 - P + txx;
-        float4 t4 = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.in_act == 1) {
-          t4.x = paif::prelu_f(t4.x, in_slope); t4.y = paif::prelu_f(t4.y, in_slope);
-          t4.z = paif::prelu_f(t4.z, in_slope); t4.w = paif::prelu_f(t4.w, in_slope);
-        } else if (a.in_act == 2) {
-          t4.x = fmaxf(t4.x, 0.f); t4.y = fmaxf(t4.y, 0.f); t4.z = fmaxf(t4.z, 0.f); t4.w = fmaxf(t4.w, 0.f);
-        }
-        const __bf16 hx = (__bf16)t4.x, hy = (__bf16)t4.y, hz = (__bf16)t4.z, hw = (__bf16)t4.w;
-        uint2 hi, lo;
-        hi.x = (unsigned)__builtin_bit_cast(unsigned short, hx) | ((unsigned)__builtin_bit_cast(unsigned short, hy) << 16);
-        hi.y = (unsigned)__builtin_bit_cast(unsigned short, hz) | ((unsigned)__builtin_bit_cast(unsigned short, hw) << 16);
-        lo.x = pack_bf16(t4.x - (float)hx, t4.y - (float)hy);
-        lo.y = pack_bf16(t4.z - (float)hz, t4.w - (float)hw);
-        const int dst = pix * PSB + q * 8;
-        *reinterpret_cast<uint2*>(ldsb + dst) = hi;
-        *reinterpret_cast<uint2*>(ldsb + dst + 64) = lo;
-      }
-    }
-  };
-
-  issue_loads(0);
-  write_lds(0);
-  __syncthreads();
-
-  f32x16 acc[SEGS_PER_WAVE];
-  for (int item = 0; item < nitems; ++item) {
-    const int tl = item / a.nsrc, s = item - tl * a.nsrc;
-    if (s == 0) {
-#pragma unroll
-      for (int sg = 0; sg < SEGS_PER_WAVE; ++sg)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[sg][r] = 0.f;
-    }
-    if (item + 1 < nitems) issue_loads(item + 1);   // in flight during the MFMA loop below
-
-    const uint4* wsrc = reinterpret_cast<const uint4*>(a.wpk) + (size_t)s * NTAP * NKS * 2 * 64 + lane;
-    uint4 bcur[NKS * 2], bnxt[NKS * 2];
-#pragma unroll
-    for (int i = 0; i < NKS * 2; ++i) bcur[i] = wsrc[i * 64];
-#pragma unroll 1
-    for (int tap = 0; tap < NTAP; ++tap) {
-      if (tap + 1 < NTAP) {
-#pragma unroll
-        for (int i = 0; i < NKS * 2; ++i) bnxt[i] = wsrc[((tap + 1) * NKS * 2 + i) * 64];
-      }
-      const int dy = tap / KH, dx = tap - dy * KH;
-      const int toff = (dy * DIL * TWH + dx * DIL) * PSB;
-#pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        const bf16x8 bh = __builtin_bit_cast(bf16x8, bcur[2 * ks]);
-        const bf16x8 bl = __builtin_bit_cast(bf16x8, bcur[2 * ks + 1]);
-#pragma unroll
-        for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) {
-          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ldsb + abase[sg] + toff + 32 * ks);
-          const bf16x8 al = *reinterpret_cast<const bf16x8*>(ldsb + abase[sg] + toff + 64 + 32 * ks);
-          acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[sg], 0, 0, 0);
-          acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[sg], 0, 0, 0);
-          acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[sg], 0, 0, 0);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < NKS * 2; ++i) bcur[i] = bnxt[i];
-    }
-
-    __syncthreads();   // every wave is done reading the tile in LDS
-    if (item + 1 < nitems) write_lds(item + 1);   // consumes the prefetch registers BEFORE the epilogue needs its own
-    if (s == a.nsrc - 1) {
-      const int tile = t0 + tl;
-      int b, y0, x0;
-      tile_coords(tile, b, y0, x0);
-      const bool full = (y0 + TH <= a.H) && (x0 + TW <= a.W) && (a.cout == 32);
-      float psum;
-      if (full) psum = epilogue<true, false>(a, acc, b, y0, x0, wave, hh, p);
-      else psum = epilogue<false, false>(a, acc, b, y0, x0, wave, hh, p);
-      if (a.pool_partial) {   // block-uniform
-        psum += __shfl_xor(psum, 32);
-        if (lane < 32) pool_s[wave * 32 + lane] = psum;
-        __syncthreads();
-        if (tid < 32) a.pool_partial[(size_t)tile * 32 + tid] = pool_s[tid] + pool_s[32 + tid] + pool_s[64 + tid] + pool_s[96 + tid];
-      }
-    }
-    __syncthreads();   // next tile fully staged (and pool_s free again)
-  }
-}
-
-// tiles per workgroup: fewest "rounds x tiles" over the 2-workgroups-per-CU residency (tail quantisation)
-static inline int choose_tpb(int ntiles, int cus) {
-  const int slots = cus * 2;
-  int best = 1;
-  long best_cost = -1;
-  for (int tpb = 2; tpb <= 8; ++tpb) {
-    const int blocks = (ntiles + tpb - 1) / tpb;
-    const long rounds = (blocks + slots - 1) / slots;
-    const long cost = rounds * tpb;
-    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = tpb; }
-  }
-  return best;
-}
-
-template <int KH, int DIL>
-int launch_bf16x3_pipe(const ConvArgs& a, hipStream_t st) {
-  constexpr int P = DIL * (KH - 1) / 2;
-  constexpr size_t lds_bytes = (size_t)(TH + 2 * P) * (TW + 2 * P) * 144;
-  static_assert(lds_bytes <= 160 * 1024, "tile does not fit LDS");
-  if (lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_bf16x3_pipe<KH, DIL>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) {
-      paif::set_error("conv2d(bf16x3 pipe): cannot raise dynamic LDS to %zu: %s", lds_bytes, hipGetErrorString(e));
-      return (int)e;
-    }
-  }
-  const int tpb = choose_tpb(a.nblk, 256);
-  const int grid = (a.nblk + tpb - 1) / tpb;
-  hipLaunchKernelGGL((conv_mfma_bf16x3_pipe<KH, DIL>), dim3(grid), dim3(NTHREADS), lds_bytes, st, a, tpb, a.nblk);
-  PAIF_LAUNCH_CHECK("conv2d(bf16x3 pipe)");
-  return 0;
-}
-
-
-#if PAIF_TH == 8
-// ---------------------------------------------------------------------------------------------------
-// 3x3 split-bf16 forward kernel, version 2: 8 waves, 16 x 32-pixel tiles, weights AND tile in LDS, next
-// item (tile x source) prefetched through registers during the MFMA loop.  Ablation of the plain kernel
-// (profiles/r01_ablation.txt) showed the global tile loads, not the matrix pipe, bound it (0.40 ms -> 0.22 ms with
-// the loads removed), and in-order vmcnt makes any VMEM operand fetch inside the MFMA loop wait for the
-// prefetch -- so here the MFMA loop touches LDS only.
-// ---------------------------------------------------------------------------------------------------
-template <int DIL>
-__global__ __launch_bounds__(256, 1) void conv3x3_bf16x3_v2(ConvArgs a, int tpb, int ntiles, int tilesY2) {
-  constexpr int KH = 3, CIN = 32, P = DIL, TH2 = 16;
-  constexpr int TWH = TW + 2 * P, THH = TH2 + 2 * P, PSB = 144, QPP = 8, NKS = 2, NTAP = 9, NT = 256, SG = 4;
-  constexpr int TOTAL = THH * TWH * QPP;
-  constexpr int NIT = (TOTAL + NT - 1) / NT;
-  constexpr int TILE_BYTES = THH * TWH * PSB;
-  constexpr int WQ = NTAP * NKS * 2 * 64;       // uint4 per source
-  constexpr int NW = (WQ + NT - 1) / NT;
-  extern __shared__ __align__(16) float lds[];
-  __shared__ float pool_s[256];   // [8 row-pairs][32 channels]
-  char* ldsb = reinterpret_cast<char*>(lds);
-  char* wlds = ldsb + TILE_BYTES;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, p = lane & 31;
-  const int blk = paif::xcd_remap(blockIdx.x, gridDim.x);
-  const int t0 = blk * tpb, t1 = min(ntiles, t0 + tpb);
-  if (t0 >= t1) return;
-  const int nitems = (t1 - t0) * a.nsrc;
-  float in_slope = 0.f;
-  if (a.in_act == 1) in_slope = *a.in_prelu;
-  int abase[SG];
-#pragma unroll
-  for (int s = 0; s < SG; ++s) abase[s] = ((wave * SG + s) * TWH + p) * PSB + 16 * hh;
-
-  float4 v[NIT];
-  uint4 wv[NW];
-  auto tile_coords = [&](int tile, int& b, int& y0, int& x0) {
-    const int tx = tile % a.tilesX;
-    const int r = tile / a.tilesX;
-    y0 = (r % tilesY2) * TH2;
-    b = r / tilesY2;
-    x0 = tx * TW;
-  };
-  auto issue_loads = [&](int item, bool with_w) {
-    const int tl = item / a.nsrc, s = item - tl * a.nsrc;
-    int b, y0, x0;
-    tile_coords(t0 + tl, b, y0, x0);
-    const float* src = a.src[s];
-    // UNCONDITIONAL loads from clamped coordinates: a load under an exec-masked branch makes hipcc wait for it at
-    // the join (one dependent HBM round trip per float4); zero padding is applied in write_lds instead.
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const int idx = min(tid + i * NT, TOTAL - 1);
-      const int pix = idx / QPP, q = idx - pix * QPP;
-      const int tyy = pix / TWH, txx = pix - tyy * TWH;
-      const int gy = min(max(y0 - P + tyy, 0), a.H - 1), gx = min(max(x0 - P + txx, 0), a.W - 1);
-      v[i] = *reinterpret_cast<const float4*>(src + ((size_t)(b * a.H + gy) * a.W + gx) * CIN + q * 4);
-    }
-    // weights of the item's source: always re-fetched (37 KB from L2) -- a load under `if (with_w)` would be
-    // waited for at the join, serialising five L2 round trips behind the whole tile prefetch
-    const uint4* wsrc = reinterpret_cast<const uint4*>(a.wpk) + (size_t)s * WQ;
-#pragma unroll
-    for (int i = 0; i < NW; ++i) wv[i] = wsrc[min(tid + i * NT, WQ - 1)];
-  };
-  auto write_lds = [&](int item, bool with_w) {
-    int wb, wy0, wx0;
-    tile_coords(t0 + item / a.nsrc, wb, wy0, wx0);
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const int idx = tid + i * NT;
-      if (idx < TOTAL) {
-        const int pix = idx / QPP, q = idx - pix * QPP;
-        const int tyy = pix / TWH, txx = pix - tyy * TWH;
-        const int gy = wy0 - P + tyy, gx = wx0 - P + txx;
-        float4 t4 = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.in_act == 1) {
-          t4.x = paif::prelu_f(t4.x, in_slope); t4.y = paif::prelu_f(t4.y, in_slope);
-          t4.z = paif::prelu_f(t4.z, in_slope); t4.w = paif::prelu_f(t4.w, in_slope);
-        } else if (a.in_act == 2) {
-          t4.x = fmaxf(t4.x, 0.f); t4.y = fmaxf(t4.y, 0.f); t4.z = fmaxf(t4.z, 0.f); t4.w = fmaxf(t4.w, 0.f);
-        }
-        const __bf16 hx = (__bf16)t4.x, hy = (__bf16)t4.y, hz = (__bf16)t4.z, hw = (__bf16)t4.w;
-        uint2 hi, lo;
-        hi.x = (unsigned)__builtin_bit_cast(unsigned short, hx) | ((unsigned)__builtin_bit_cast(unsigned short, hy) << 16);
-        hi.y = (unsigned)__builtin_bit_cast(unsigned short, hz) | ((unsigned)__builtin_bit_cast(unsigned short, hw) << 16);
-        lo.x = pack_bf16(t4.x - (float)hx, t4.y - (float)hy);
-        lo.y = pack_bf16(t4.z - (float)hz, t4.w - (float)hw);
-        const int dst = pix * PSB + q * 8;
-        *reinterpret_cast<uint2*>(ldsb + dst) = hi;
-        *reinterpret_cast<uint2*>(ldsb + dst + 64) = lo;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-      const int idx = tid + i * NT;
-      if (idx < WQ) *reinterpret_cast<uint4*>(wlds + (size_t)idx * 16) = wv[i];
-    }
-  };
-
-  issue_loads(0, true);
-  write_lds(0, true);
-  __syncthreads();
-
-  f32x16 acc[SG];
-  for (int item = 0; item < nitems; ++item) {
-    const int tl = item / a.nsrc, s = item - tl * a.nsrc;
-    if (s == 0) {
-#pragma unroll
-      for (int sg = 0; sg < SG; ++sg)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[sg][r] = 0.f;
-    }
-    const bool has_next = item + 1 < nitems;
-    const bool next_w = has_next && a.nsrc > 1;   // the next item uses another source's weights
-    if (has_next) issue_loads(item + 1, next_w);
-
-#pragma unroll 1
-    for (int tap = 0; tap < NTAP; ++tap) {
-      const int dy = tap / KH, dx = tap - dy * KH;
-      const int toff = (dy * DIL * TWH + dx * DIL) * PSB;
-#pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wlds + ((tap * NKS + ks) * 2 + 0) * 1024 + lane * 16);
-        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wlds + ((tap * NKS + ks) * 2 + 1) * 1024 + lane * 16);
-#pragma unroll
-        for (int sg = 0; sg < SG; ++sg) {
-          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ldsb + abase[sg] + toff + 32 * ks);
-          const bf16x8 al = *reinterpret_cast<const bf16x8*>(ldsb + abase[sg] + toff + 64 + 32 * ks);
-          acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[sg], 0, 0, 0);
-          acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[sg], 0, 0, 0);
-          acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[sg], 0, 0, 0);
-        }
-      }
-    }
-
-    __syncthreads();   // all waves done with the tile and the weights in LDS
-    if (has_next) write_lds(item + 1, next_w);
-    if (s == a.nsrc - 1) {
-      const int tile = t0 + tl;
-      int b, y0, x0;
-      tile_coords(tile, b, y0, x0);
-      const bool full = (y0 + TH2 <= a.H) && (x0 + TW <= a.W) && (a.cout == 32);
-      // epilogue<> addresses rows as y0 + w*2 + sg (2 segments per call): this wave's 4 segments are two such
-      // "virtual waves" 2*wave and 2*wave+1
-      const f32x16 lo2[2] = {acc[0], acc[1]};
-      const f32x16 hi2[2] = {acc[2], acc[3]};
-      float psum0, psum1;
-      if (full) {
-        psum0 = epilogue<true, false>(a, lo2, b, y0, x0, 2 * wave, hh, p);
-        psum1 = epilogue<true, false>(a, hi2, b, y0, x0, 2 * wave + 1, hh, p);
-      } else {
-        psum0 = epilogue<false, false>(a, lo2, b, y0, x0, 2 * wave, hh, p);
-        psum1 = epilogue<false, false>(a, hi2, b, y0, x0, 2 * wave + 1, hh, p);
-      }
-      if (a.pool_partial) {
-        psum0 += __shfl_xor(psum0, 32);
-        psum1 += __shfl_xor(psum1, 32);
-        if (lane < 32) { pool_s[(2 * wave) * 32 + lane] = psum0; pool_s[(2 * wave + 1) * 32 + lane] = psum1; }
-        __syncthreads();
-        // the partial buffer is indexed by 8-row tiles (paif_conv2d_blocks): one slot per half of this 16-row tile
-        if (tid < 64) {
-          const int half = tid >> 5, c = tid & 31;
-          const int ty8 = (y0 >> 3) + half;
-          if (ty8 < a.tilesY) {
-            const float t = (pool_s[(half * 4 + 0) * 32 + c] + pool_s[(half * 4 + 1) * 32 + c]) +
-                            (pool_s[(half * 4 + 2) * 32 + c] + pool_s[(half * 4 + 3) * 32 + c]);
-            a.pool_partial[((size_t)(b * a.tilesY + ty8) * a.tilesX + x0 / TW) * 32 + c] = t;
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-}
-
-template <int DIL>
-int launch_conv3x3_v2(const ConvArgs& a, hipStream_t st) {
-  constexpr int P = DIL;
-  constexpr size_t lds_bytes = (size_t)(16 + 2 * P) * (TW + 2 * P) * 144 + 9 * 2 * 2 * 1024;
-  static_assert(lds_bytes <= 160 * 1024, "tile + weights do not fit LDS");
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x3_v2<DIL>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  if (e != hipSuccess) {
-    paif::set_error("conv2d(3x3 v2): cannot raise dynamic LDS to %zu: %s", lds_bytes, hipGetErrorString(e));
-    return (int)e;
-  }
-  const int tilesY2 = (a.H + 15) / 16;
-  const int ntiles = a.B * tilesY2 * a.tilesX;
-  // one workgroup per CU: pick tiles-per-workgroup with the fewest rounds x tiles (tail quantisation)
-  int tpb = 1;
-  long best = -1;
-  for (int t = 1; t <= 8; ++t) {
-    const int blocks = (ntiles + t - 1) / t;
-    const long cost = (long)((blocks + 255) / 256) * t;
-    if (best < 0 || cost < best || (cost == best && t > tpb)) { best = cost; tpb = t; }
-  }
-  const int grid = (ntiles + tpb - 1) / tpb;
-  hipLaunchKernelGGL((conv3x3_bf16x3_v2<DIL>), dim3(grid), dim3(256), lds_bytes, st, a, tpb, ntiles, tilesY2);
-  PAIF_LAUNCH_CHECK("conv2d(3x3 v2)");
-  return 0;
-}
-
-#endif  // PAIF_TH == 8
-
-// ---------------------------------------------------------------------------------------------------
 // Wave-specialised persistent form of the split-bf16 kernel (forward, no hooks, no in-activation, cout == 32).
 // The plain kernel runs load -> LDS -> MFMA -> store as serial phases of one workgroup and relies on 3
 // workgroups per CU drifting apart to overlap them.  Here the overlap is structural: one workgroup per CU,
@@ -1366,26 +911,25 @@ static inline bool ws_eligible(const ConvArgs& a) {
 
 static inline bool needs_hooks(const ConvArgs& a) { return a.in_act >= 3 || a.aux_out || a.epi_dact; }
 
+// Persistent wave-specialised form (needs several tiles per CU to amortise its pipeline fill).  Measured per
+// configuration against the plain kernel (tools/conv_bench.py, B=8 480x640): faster everywhere except
+// 3x3 / 3 sources / >= 2 residual maps, where the storers' residual traffic paces the tile (-4 %).
+static inline bool takes_ws(const ConvArgs& a, int kh, int dil) {
+#if PAIF_TH == 8
+  if (needs_hooks(a) || kh > 3 || !ws_eligible(a)) return false;
+  const bool many_res = a.res[0] && a.res[1];
+  return !(kh == 3 && dil == 1 && a.nsrc == 3 && many_res);
+#else
+  return false;
+#endif
+}
+
 template <int KH, int DIL>
 int launch_bf16x3(const ConvArgs& a, hipStream_t st) {
   if (needs_hooks(a)) return launch_bf16x3_h<KH, DIL, true>(a, st);
-  // kernels with a halo (k >= 3) are latency-bound without in-block overlap: use the pipelined form;
-  // the 1x1 is a pure stream (HBM-bound at 4.8 TB/s already)
-  // Experimental software-pipelined forms (correct, parity-tested, but NOT yet faster than the plain kernel at
-  // 3 workgroups/CU -- DESIGN.md section 6): opt-in via environment for A/B runs.
-#if PAIF_TH == 8
-  if constexpr (KH == 3) {
-    if (a.nblk >= 64 && getenv("PAIF_CONV_V2")) return launch_conv3x3_v2<DIL>(a, st);
-  }
-#endif
-  if (KH >= 3 && a.nblk >= 16 && getenv("PAIF_CONV_PIPE")) return launch_bf16x3_pipe<KH, DIL>(a, st);
 #if PAIF_TH == 8
   if constexpr (KH <= 3) {
-    // persistent wave-specialised form: needs several tiles per CU to amortise its pipeline fill
-    // measured per configuration against the plain kernel (tools/conv_bench.py, B=8 480x640): faster everywhere
-    // except 3x3 / 3 sources / >= 2 residual maps, where the storers' residual traffic paces the tile (-4 %)
-    const bool many_res = a.res[0] && a.res[1];
-    if (ws_eligible(a) && !(KH == 3 && DIL == 1 && a.nsrc == 3 && many_res)) return launch_bf16x3_ws<KH, DIL>(a, st);
+    if (takes_ws(a, KH, DIL)) return launch_bf16x3_ws<KH, DIL>(a, st);
   }
 #endif
   return launch_bf16x3_h<KH, DIL, false>(a, st);
@@ -1509,6 +1053,17 @@ int paif_debug_ws_trace(unsigned long long* host_out) {
 int paif_conv2d_blocks(int B, int H, int W) { return B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW); }
 
 size_t paif_conv_wpk_floats(int nsrc, int cin, int kh) { return (size_t)nsrc * kh * kh * (cin / 8) * 256; }
+
+int paif_conv2d_is_persistent(const paif_conv_desc* d, int B, int H, int W) {
+  if (!d || d->precision != PAIF_CONV_BF16X3 || d->cin != 32 || B <= 0 || H <= 0 || W <= 0) return 0;
+  ConvArgs a{};
+  for (int s = 0; s < 3; ++s) a.res[s] = d->res[s];
+  a.pool_partial = d->pool_partial; a.nsrc = d->nsrc; a.in_act = d->in_act; a.cout = d->cout;
+  a.aux_out = d->aux_out; a.epi_dact = d->epi_dact;
+  a.H = H; a.W = W;
+  a.nblk = B * ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
+  return takes_ws(a, d->kh, d->dil) ? 1 : 0;
+}
 
 int paif_conv2d_fwd(const paif_conv_desc* d, int B, int H, int W, paif_stream_t stream) {
   PAIF_REQUIRE(d && d->out && d->wpk, PAIF_EINVAL, "conv2d: null descriptor/out/wpk");

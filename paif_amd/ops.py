@@ -266,8 +266,13 @@ def conv2d(srcs, wpk, kh, dil=1, cin=32, cout=32, in_act=ACT_NONE, in_prelu=None
     aux = torch.empty_like(out) if want_aux else None
     d.aux_out, d.in_aux, d.in_scale, d.in_alpha = _p(aux), _p(in_aux), _p(in_scale), in_alpha
     d.epi_aux, d.epi_dact = _p(epi_aux), epi_dact
-    tag = "conv_mfma_%s<%d,%d,%d>" % (wpk.precision, kh, dil, cin)
-    e0 = TIMER.start(tag) if TIMER is not None else None
+    e0 = None
+    if TIMER is not None:   # name the kernel this launch takes, as rocprofv3 will list it
+        if L.paif_conv2d_is_persistent(ctypes.byref(d), B, H, W):
+            tag = "conv_bf16x3_ws<%d,%d>" % (kh, dil)
+        else:
+            tag = "conv_mfma_%s<%d,%d,%d>" % (wpk.precision, kh, dil, cin)
+        e0 = TIMER.start(tag)
     _lib.check(L.paif_conv2d_fwd(ctypes.byref(d), B, H, W, _stream()), "conv2d")
     if e0 is not None:
         px = B * H * W

@@ -92,6 +92,47 @@ def test_guided_filter_fused_matches_two_kernel_form(shape):
     assert maxabs(fused.cpu(), two.cpu()) <= 1e-5 * max(1.0, float(two.abs().max()))
 
 
+@pytest.mark.parametrize("kh,dil,nsrc,nres,act", [(3, 1, 1, 0, 0), (3, 1, 2, 1, 1), (3, 1, 3, 3, 0), (3, 2, 1, 0, 2),
+                                                 (1, 1, 3, 0, 0), (1, 1, 1, 2, 1), (3, 2, 2, 1, 0)])
+def test_dense_conv_persistent_kernel_ragged_edges(kh, dil, nsrc, nres, act):
+    """Shapes with >= 1024 tiles take the wave-specialised persistent kernel (conv_mfma.hip).  A ragged image
+    (partial tiles on both edges, halo clamps on all four borders, an odd number of stages per workgroup and
+    workgroups with no tile at all) is checked against the CPU oracle's conv and against the exact-fp32 MFMA
+    kernel, which never takes that path."""
+    from paif_amd import ops
+
+    B, H, W = 2, 333, 517      # 42 x 17 x 2 = 1428 tiles
+    g = torch.Generator().manual_seed(kh * 100 + dil * 10 + nsrc)
+    xs = [torch.randn(B, 32, H, W, generator=g) for _ in range(nsrc)]
+    rs = [torch.randn(B, 32, H, W, generator=g) for _ in range(nres)]
+    w = torch.randn(32, 32 * nsrc, kh, kh, generator=g) * 0.05
+    scale = torch.rand(32, generator=g) + 0.5
+    shift = torch.randn(32, generator=g) * 0.1
+    slope = torch.tensor([0.2])
+    ref = torch.nn.functional.conv2d(torch.cat(xs, 1), w, padding=dil * (kh - 1) // 2, dilation=dil)
+    ref = ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    if act == 1:
+        ref = torch.where(ref >= 0, ref, ref * slope)
+    elif act == 2:
+        ref = ref.clamp_min(0)
+    ref = ref * 0.5
+    for r in rs:
+        ref = ref + r
+    dev = _dev()
+    xn = [ops.to_nhwc(x.to(dev)) for x in xs]
+    rn = [ops.to_nhwc(r.to(dev)) for r in rs]
+    outs = {}
+    for prec in ("bf16x3", "f32"):
+        wpk = ops.pack_conv_weight(w.to(dev), nsrc, 32, kh, precision=prec)
+        y = ops.conv2d(xn, wpk, kh, dil=dil, scale=scale.to(dev), shift=shift.to(dev), act=act,
+                       prelu=slope.to(dev) if act == 1 else None, alpha=0.5, res=tuple(rn))
+        outs[prec] = y.permute(0, 3, 1, 2).cpu()
+    sc = float(ref.abs().max())
+    assert maxabs(outs["f32"], ref) <= 2e-5 * sc
+    assert maxabs(outs["bf16x3"], ref) <= 1e-4 * sc
+    assert maxabs(outs["bf16x3"], outs["f32"]) <= 1e-4 * sc
+
+
 def _fusion_net(prefix=""):
     """prefix='enhance_net.' gives the weights the fusion net has INSIDE the composite model's goldens
     (the formula is keyed on the full state_dict key)."""
