@@ -108,7 +108,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    timer = ops.KernelTimer(lambda tag: tag == DOMINANT)
+    timer = ops.KernelTimer(lambda tag: tag in (DOMINANT, "conv_mfma_%s<3,1,32>" % args.conv_precision))
     barrier()
     ops.TIMER = timer
     t0 = time.perf_counter()
@@ -123,7 +123,10 @@ def main():
 
     if rank == 0:
         pairs = bpg * world * args.steps
-        n, ms, flops, nbytes = timer.summary()[DOMINANT]
+        summ = timer.summary()
+        if DOMINANT not in summ:   # PAIF_CONV_WS=0 (A/B runs): the same convs on the tile-per-workgroup kernel
+            DOMINANT = "conv_mfma_%s<3,1,32>" % args.conv_precision
+        n, ms, flops, nbytes = summ[DOMINANT]
         tflops = flops / (ms * 1e-3) / 1e12
         gbs = nbytes / (ms * 1e-3) / 1e9
         if args.conv_precision == "f32":

@@ -885,11 +885,15 @@ int launch_bf16x3_ws(const ConvArgs& a, hipStream_t st) {
   constexpr int P = DIL * (KH - 1) / 2;
   constexpr size_t lds_bytes = 2 * (size_t)(TH + 2 * P) * (TW + 2 * P) * 144 + 8 * 32 * 32 * 4;
   static_assert(lds_bytes <= 160 * 1024, "two tile buffers + the parked tile do not fit LDS");
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_ws<KH, DIL>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  if (e != hipSuccess) {
-    paif::set_error("conv2d(bf16x3 ws): cannot raise dynamic LDS to %zu: %s", lds_bytes, hipGetErrorString(e));
-    return (int)e;
+  static bool raised = false;   // once per instantiation (one device per process)
+  if (!raised) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_ws<KH, DIL>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) {
+      paif::set_error("conv2d(bf16x3 ws): cannot raise dynamic LDS to %zu: %s", lds_bytes, hipGetErrorString(e));
+      return (int)e;
+    }
+    raised = true;
   }
   hipLaunchKernelGGL((conv_bf16x3_ws<KH, DIL>), dim3(256), dim3(WS_THREADS), lds_bytes, st, a, a.nblk);
   PAIF_LAUNCH_CHECK("conv2d(bf16x3 ws)");
