@@ -106,15 +106,23 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
     float s = 0.f;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
+      // one tap row (3 x 2 float4) in flight: unconditional loads on clamped coordinates, padding by select
       const int yy = y0 - (ky - 1);
-      if (yy < 0 || yy >= H) continue;
+      const int yc = min(max(yy, 0), H - 1);
+      float4 dv[3], fv[3];
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int xc = min(max(x0 - (kx - 1), 0), W - 1);
+        const size_t o = (img + (size_t)yc * W + xc) * 32 + q * 4;
+        dv[kx] = *reinterpret_cast<const float4*>(dfeat + o);
+        fv[kx] = *reinterpret_cast<const float4*>(feat + o);
+      }
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
         const int xx = x0 - (kx - 1);
-        if (xx < 0 || xx >= W) continue;
-        const size_t o = (img + (size_t)yy * W + xx) * 32 + q * 4;
-        const float4 d = *reinterpret_cast<const float4*>(dfeat + o);
-        const float4 f = *reinterpret_cast<const float4*>(feat + o);
+        float4 d = dv[kx];
+        const float4 f = fv[kx];
+        if (yy < 0 || yy >= H || xx < 0 || xx >= W) d = make_float4(0.f, 0.f, 0.f, 0.f);
         const int k = ky * 3 + kx;
         s = fmaf(d.x * (f.x >= 0.f ? 1.f : slope), wr[0][k], s);
         s = fmaf(d.y * (f.y >= 0.f ? 1.f : slope), wr[1][k], s);
@@ -149,18 +157,34 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict
     const int yy0 = (int)(rowid % H);
     const float* base = dt + (rowid - yy0) * W * 32 + q * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // unconditional loads on clamped coordinates, padding by select (see dwconv_kernel): the whole 3x3 stencil, or one
+    // tap row for k >= 5, is in flight at a time
+    constexpr int ROWS_IN_FLIGHT = K == 3 ? 3 : 1;
 #pragma unroll
-    for (int dy = 0; dy < K; ++dy) {
-      const int yy = yy0 + dy * DIL - P;
-      if (yy < 0 || yy >= H) continue;
+    for (int dy0 = 0; dy0 < K; dy0 += ROWS_IN_FLIGHT) {
+      float4 tv[ROWS_IN_FLIGHT][K];
 #pragma unroll
-      for (int dx = 0; dx < K; ++dx) {
-        const int xx = xx0 + dx * DIL - P;
-        if (xx < 0 || xx >= W) continue;
-        const float4 v = *reinterpret_cast<const float4*>(base + ((size_t)yy * W + xx) * 32);
-        const int k = dy * K + dx;
-        acc.x = fmaf(v.x, wr[0][k], acc.x); acc.y = fmaf(v.y, wr[1][k], acc.y);
-        acc.z = fmaf(v.z, wr[2][k], acc.z); acc.w = fmaf(v.w, wr[3][k], acc.w);
+      for (int r = 0; r < ROWS_IN_FLIGHT; ++r) {
+        const int yy = min(max(yy0 + (dy0 + r) * DIL - P, 0), H - 1);
+#pragma unroll
+        for (int dx = 0; dx < K; ++dx) {
+          const int xx = min(max(xx0 + dx * DIL - P, 0), W - 1);
+          tv[r][dx] = *reinterpret_cast<const float4*>(base + ((size_t)yy * W + xx) * 32);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < ROWS_IN_FLIGHT; ++r) {
+        const int dy = dy0 + r;
+        const int yy = yy0 + dy * DIL - P;
+#pragma unroll
+        for (int dx = 0; dx < K; ++dx) {
+          const int xx = xx0 + dx * DIL - P;
+          float4 v = tv[r][dx];
+          if (yy < 0 || yy >= H || xx < 0 || xx >= W) v = make_float4(0.f, 0.f, 0.f, 0.f);
+          const int k = dy * K + dx;
+          acc.x = fmaf(v.x, wr[0][k], acc.x); acc.y = fmaf(v.y, wr[1][k], acc.y);
+          acc.z = fmaf(v.z, wr[2][k], acc.z); acc.w = fmaf(v.w, wr[3][k], acc.w);
+        }
       }
     }
     if (aux) {

@@ -118,19 +118,37 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
     const int yy0 = (int)(rowid % H);
     const float* base = x + (rowid - yy0) * W * 32 + q * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // Loads are unconditional on clamped coordinates and padding is a select afterwards: a load under a branch is
+    // waited for at the join, which serialised the k*k taps' latencies (1.85 TB/s); one tap row (k loads) is in
+    // flight at a time for k >= 5, the whole 3x3 stencil for k == 3.
+    constexpr int ROWS_IN_FLIGHT = K == 3 ? 3 : 1;
 #pragma unroll
-    for (int dy = 0; dy < K; ++dy) {
-      const int yy = yy0 + dy * DIL - P;
-      if (yy < 0 || yy >= H) continue;
+    for (int dy0 = 0; dy0 < K; dy0 += ROWS_IN_FLIGHT) {
+      float4 v[ROWS_IN_FLIGHT][K];
 #pragma unroll
-      for (int dx = 0; dx < K; ++dx) {
-        const int xx = xx0 + dx * DIL - P;
-        if (xx < 0 || xx >= W) continue;
-        float4 v = *reinterpret_cast<const float4*>(base + ((size_t)yy * W + xx) * 32);
-        if (in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        const int k = dy * K + dx;
-        acc.x = fmaf(v.x, wr[0][k], acc.x); acc.y = fmaf(v.y, wr[1][k], acc.y);
-        acc.z = fmaf(v.z, wr[2][k], acc.z); acc.w = fmaf(v.w, wr[3][k], acc.w);
+      for (int r = 0; r < ROWS_IN_FLIGHT; ++r) {
+        const int yy = min(max(yy0 + (dy0 + r) * DIL - P, 0), H - 1);
+#pragma unroll
+        for (int dx = 0; dx < K; ++dx) {
+          const int xx = min(max(xx0 + dx * DIL - P, 0), W - 1);
+          v[r][dx] = *reinterpret_cast<const float4*>(base + ((size_t)yy * W + xx) * 32);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < ROWS_IN_FLIGHT; ++r) {
+        const int dy = dy0 + r;
+        const int yy = yy0 + dy * DIL - P;
+#pragma unroll
+        for (int dx = 0; dx < K; ++dx) {
+          const int xx = xx0 + dx * DIL - P;
+          const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+          float4 t = v[r][dx];
+          if (in_relu) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
+          if (!ok) t = make_float4(0.f, 0.f, 0.f, 0.f);
+          const int k = dy * K + dx;
+          acc.x = fmaf(t.x, wr[0][k], acc.x); acc.y = fmaf(t.y, wr[1][k], acc.y);
+          acc.z = fmaf(t.z, wr[2][k], acc.z); acc.w = fmaf(t.w, wr[3][k], acc.w);
+        }
       }
     }
     *reinterpret_cast<float4*>(out + pix * 32 + q * 4) = acc;
@@ -288,19 +306,25 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ x, 
     const int y0 = (int)(rowid % H);
     const float* base = x + (rowid - y0) * W * 16 + q * 4;
     float s = 0.f;
+    // all 9 taps in flight: unconditional loads on clamped coordinates, padding by select (see dwconv_kernel)
+    float4 v[9];
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-      const int yy = y0 + dy - 1;
-      if (yy < 0 || yy >= H) continue;
+    for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
-        const int xx = x0 + dx - 1;
-        if (xx < 0 || xx >= W) continue;
-        const float4 v = *reinterpret_cast<const float4*>(base + ((size_t)yy * W + xx) * 16);
-        const int k = dy * 3 + dx;
-        s = fmaf(v.x, wr[0][k], s); s = fmaf(v.y, wr[1][k], s); s = fmaf(v.z, wr[2][k], s); s = fmaf(v.w, wr[3][k], s);
+        const int yy = min(max(y0 + dy - 1, 0), H - 1), xx = min(max(x0 + dx - 1, 0), W - 1);
+        v[dy * 3 + dx] = *reinterpret_cast<const float4*>(base + ((size_t)yy * W + xx) * 16);
       }
-    }
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int yy = y0 + dy - 1, xx = x0 + dx - 1;
+        const int k = dy * 3 + dx;
+        float4 t = v[k];
+        if (yy < 0 || yy >= H || xx < 0 || xx >= W) t = make_float4(0.f, 0.f, 0.f, 0.f);
+        s = fmaf(t.x, wr[0][k], s); s = fmaf(t.y, wr[1][k], s); s = fmaf(t.z, wr[2][k], s); s = fmaf(t.w, wr[3][k], s);
+      }
     s += __shfl_xor(s, 1);
     s += __shfl_xor(s, 2);
     if (q == 0) {

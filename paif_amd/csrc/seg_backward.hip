@@ -125,19 +125,28 @@ __global__ __launch_bounds__(256) void dwconv3_bwd_kernel(const float* __restric
     const int y0 = (int)(rowid % H);
     const float* base = x + (rowid - y0) * W * C + q * 4;
     float4 acc = b4;
+    {
+      // all 9 taps in flight: unconditional loads on clamped coordinates, padding by select (a load under a branch
+      // is waited for at the join, which serialises the taps' latencies)
+      float4 tv[9];
 #pragma unroll
-    for (int dy_ = 0; dy_ < 3; ++dy_) {
-      const int yy = y0 + dy_ - 1;
-      if (yy < 0 || yy >= H) continue;
+      for (int dy_ = 0; dy_ < 3; ++dy_)
 #pragma unroll
-      for (int dx_ = 0; dx_ < 3; ++dx_) {
-        const int xx = x0 + dx_ - 1;
-        if (xx < 0 || xx >= W) continue;
-        const float4 v = *reinterpret_cast<const float4*>(base + ((size_t)yy * W + xx) * C);
-        const int k = dy_ * 3 + dx_;
-        acc.x = fmaf(v.x, wr[0][k], acc.x); acc.y = fmaf(v.y, wr[1][k], acc.y);
-        acc.z = fmaf(v.z, wr[2][k], acc.z); acc.w = fmaf(v.w, wr[3][k], acc.w);
-      }
+        for (int dx_ = 0; dx_ < 3; ++dx_) {
+          const int yy = min(max(y0 + dy_ - 1, 0), H - 1), xx = min(max(x0 + dx_ - 1, 0), W - 1);
+          tv[dy_ * 3 + dx_] = *reinterpret_cast<const float4*>(base + ((size_t)yy * W + xx) * C);
+        }
+#pragma unroll
+      for (int dy_ = 0; dy_ < 3; ++dy_)
+#pragma unroll
+        for (int dx_ = 0; dx_ < 3; ++dx_) {
+          const int yy = y0 + dy_ - 1, xx = x0 + dx_ - 1;
+          const int k = dy_ * 3 + dx_;
+          float4 v = tv[k];
+          if (yy < 0 || yy >= H || xx < 0 || xx >= W) v = make_float4(0.f, 0.f, 0.f, 0.f);
+          acc.x = fmaf(v.x, wr[0][k], acc.x); acc.y = fmaf(v.y, wr[1][k], acc.y);
+          acc.z = fmaf(v.z, wr[2][k], acc.z); acc.w = fmaf(v.w, wr[3][k], acc.w);
+        }
     }
     float4 o = acc;
     if (MODE == 1) {

@@ -158,19 +158,28 @@ __global__ __launch_bounds__(256) void dwconv3_bias_gelu_kernel(const float* __r
     const int y0 = (int)(rowid % H);
     const float* base = x + (rowid - y0) * W * C + q * 4;
     float4 acc = b4;
+    {
+      // all 9 taps in flight: unconditional loads on clamped coordinates, padding by select (a load under a branch
+      // is waited for at the join, which serialises the taps' latencies)
+      float4 tv[9];
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-      const int yy = y0 + dy - 1;
-      if (yy < 0 || yy >= H) continue;
+      for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int xx = x0 + dx - 1;
-        if (xx < 0 || xx >= W) continue;
-        const float4 v = *reinterpret_cast<const float4*>(base + ((size_t)yy * W + xx) * C);
-        const int k = dy * 3 + dx;
-        acc.x = fmaf(v.x, wr[0][k], acc.x); acc.y = fmaf(v.y, wr[1][k], acc.y);
-        acc.z = fmaf(v.z, wr[2][k], acc.z); acc.w = fmaf(v.w, wr[3][k], acc.w);
-      }
+        for (int dx = 0; dx < 3; ++dx) {
+          const int yy = min(max(y0 + dy - 1, 0), H - 1), xx = min(max(x0 + dx - 1, 0), W - 1);
+          tv[dy * 3 + dx] = *reinterpret_cast<const float4*>(base + ((size_t)yy * W + xx) * C);
+        }
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int yy = y0 + dy - 1, xx = x0 + dx - 1;
+          const int k = dy * 3 + dx;
+          float4 v = tv[k];
+          if (yy < 0 || yy >= H || xx < 0 || xx >= W) v = make_float4(0.f, 0.f, 0.f, 0.f);
+          acc.x = fmaf(v.x, wr[0][k], acc.x); acc.y = fmaf(v.y, wr[1][k], acc.y);
+          acc.z = fmaf(v.z, wr[2][k], acc.z); acc.w = fmaf(v.w, wr[3][k], acc.w);
+        }
     }
     *reinterpret_cast<float4*>(y + pix * C + q * 4) = make_float4(gelu_erf(acc.x), gelu_erf(acc.y), gelu_erf(acc.z), gelu_erf(acc.w));
   }
