@@ -11,7 +11,7 @@ the C ABI.  One process per GPU; replicas only (no data-path collective: the pat
         bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0 (contract in the task statement): value = whole-job pairs/s, plus
-  roofline     -- dominant kernel (the 3x3 dense conv: conv_bf16x3_ws<3,1>, or conv_mfma_f32<3,1,32> with --conv-precision f32),
+  roofline     -- dominant kernel (the 3x3 dense conv: conv_mfma_bf16x3<3,1>, or conv_mfma_f32<3,1,32> with --conv-precision f32),
                   HIP-event timed on its launch stream inside the timed region
   cpu_baseline -- the CPU oracle (torch fp32 port of the reference) on the host cores, bounded sample, rank 0, N=1 only
 """
@@ -65,9 +65,7 @@ def main():
     from paif_amd.core.model_fusion_auto import Network_Fusion_Searched, Network_MM_Searched
 
     ops.set_conv_precision(args.conv_precision)
-    # the 3x3 dense convs: at bf16x3 they run on the persistent wave-specialised kernel (10 of the 12 launches per
-    # step; the ECA-pool conv and the 3-source/3-residual conv stay on conv_mfma_bf16x3), at f32 on conv_mfma_f32
-    DOMINANT = "conv_bf16x3_ws<3,1>" if args.conv_precision == "bf16x3" else "conv_mfma_f32<3,1,32>"
+    DOMINANT = "conv_mfma_%s<3,1,32>" % args.conv_precision   # the 12 dense 3x3 convs of a step
     bpg = 16 if args.workload == "fusion_seg" else B_PER_GPU
     if args.workload == "fusion":
         net = Network_Fusion_Searched(32, None, FUSION_AT).eval()
@@ -108,7 +106,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    timer = ops.KernelTimer(lambda tag: tag in (DOMINANT, "conv_mfma_%s<3,1,32>" % args.conv_precision))
+    timer = ops.KernelTimer(lambda tag: tag == DOMINANT)
     barrier()
     ops.TIMER = timer
     t0 = time.perf_counter()
@@ -123,10 +121,7 @@ def main():
 
     if rank == 0:
         pairs = bpg * world * args.steps
-        summ = timer.summary()
-        if DOMINANT not in summ:   # PAIF_CONV_WS=0 (A/B runs): the same convs on the tile-per-workgroup kernel
-            DOMINANT = "conv_mfma_%s<3,1,32>" % args.conv_precision
-        n, ms, flops, nbytes = summ[DOMINANT]
+        n, ms, flops, nbytes = timer.summary()[DOMINANT]
         tflops = flops / (ms * 1e-3) / 1e12
         gbs = nbytes / (ms * 1e-3) / 1e9
         if args.conv_precision == "f32":

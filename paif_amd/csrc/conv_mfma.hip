@@ -23,7 +23,7 @@
 #include <type_traits>
 
 #ifndef PAIF_UB
-#define PAIF_UB 6   // staged float4 loads in flight per lane (forward kernels)
+#define PAIF_UB 11  // staged float4 loads in flight per lane (forward kernels): the whole 3x3 halo tile in one batch
 #endif
 
 namespace {
@@ -278,24 +278,31 @@ __global__ __launch_bounds__(NTHREADS, HOOKS ? 2 : 3) void conv_mfma_f32(ConvArg
     for (int i0 = 0; i0 < NIT; i0 += UB) {
       float4 v[UB], xa[UB];
       int dst[UB];
+      bool inb[UB];
+      size_t go[UB];
+      // Loads are UNCONDITIONAL on clamped indices and padding is applied afterwards: a global load under an
+      // exec-masked branch is followed by s_waitcnt vmcnt(0) at the join, which serialised the UB loads (the asm had
+      // load / wait / load / wait).  Out-of-tile slots re-read the tile's last element and are never written.
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
-        const int idx = tid + (i0 + u) * NTHREADS;
-        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int idx = min(tid + (i0 + u) * NTHREADS, TOTAL - 1);
+        const int pix = idx / QPP, q = idx - pix * QPP;
+        const int tyy = pix / TWH, txx = pix - tyy * TWH;
+        const int gy = y0 - P + tyy, gx = x0 - P + txx;
+        dst[u] = (i0 + u < NIT && tid + (i0 + u) * NTHREADS < TOTAL) ? pix * PS + q * 4 : -1;
+        inb[u] = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        const int gyc = min(max(gy, 0), a.H - 1), gxc = min(max(gx, 0), a.W - 1);
+        go[u] = ((size_t)(b * a.H + gyc) * a.W + gxc) * CIN + q * 4;
+        v[u] = *reinterpret_cast<const float4*>(src + go[u]);
         xa[u] = v[u];
-        dst[u] = -1;
-        if (i0 + u < NIT && idx < TOTAL) {
-          const int pix = idx / QPP, q = idx - pix * QPP;
-          const int tyy = pix / TWH, txx = pix - tyy * TWH;
-          const int gy = y0 - P + tyy, gx = x0 - P + txx;
-          dst[u] = pix * PS + q * 4;
-          if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-            const size_t go = ((size_t)(b * a.H + gy) * a.W + gx) * CIN + q * 4;
-            v[u] = *reinterpret_cast<const float4*>(src + go);
-            if (HOOKS && (a.in_act == 3 || a.in_act == 4)) xa[u] = *reinterpret_cast<const float4*>(a.in_aux + go);
-          }
-        }
       }
+      if (HOOKS && (a.in_act == 3 || a.in_act == 4)) {   // launch-uniform
+#pragma unroll
+        for (int u = 0; u < UB; ++u) xa[u] = *reinterpret_cast<const float4*>(a.in_aux + go[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u)
+        if (!inb[u]) v[u] = xa[u] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
         if (dst[u] >= 0) {
@@ -427,28 +434,34 @@ __global__ __launch_bounds__(NTHREADS, HOOKS ? 2 : PAIF_LB) void conv_mfma_bf16x
     for (int i0 = 0; i0 < NIT; i0 += UB) {
       float4 v[UB], xa[UB];
       int dst[UB];
+      bool inb[UB];
+      size_t go[UB];
+      // Loads are UNCONDITIONAL on clamped indices and padding is applied afterwards: a global load under an
+      // exec-masked branch is followed by s_waitcnt vmcnt(0) at the join, which serialised the UB loads (the asm had
+      // load / wait / load / wait).  Out-of-tile slots re-read the tile's last element and are never written.
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
-        const int idx = tid + (i0 + u) * NTHREADS;
-        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        xa[u] = v[u];
-        dst[u] = -1;
-        if (i0 + u < NIT && idx < TOTAL) {
-          const int pix = idx / QPP, q = idx - pix * QPP;
-          const int tyy = pix / TWH, txx = pix - tyy * TWH;
-          const int gy = y0 - P + tyy, gx = x0 - P + txx;
-          dst[u] = pix * PSB + q * 8;
+        const int idx = min(tid + (i0 + u) * NTHREADS, TOTAL - 1);
+        const int pix = idx / QPP, q = idx - pix * QPP;
+        const int tyy = pix / TWH, txx = pix - tyy * TWH;
+        const int gy = y0 - P + tyy, gx = x0 - P + txx;
+        dst[u] = (i0 + u < NIT && tid + (i0 + u) * NTHREADS < TOTAL) ? pix * PSB + q * 8 : -1;
+        inb[u] = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        const int gyc = min(max(gy, 0), a.H - 1), gxc = min(max(gx, 0), a.W - 1);
+        go[u] = ((size_t)(b * a.H + gyc) * a.W + gxc) * CIN + q * 4;
 #ifdef PAIF_ABL_NO_STAGE
-          if (false) {
-#else
-          if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+        go[u] = 0;
 #endif
-            const size_t go = ((size_t)(b * a.H + gy) * a.W + gx) * CIN + q * 4;
-            v[u] = *reinterpret_cast<const float4*>(src + go);
-            if (HOOKS && (a.in_act == 3 || a.in_act == 4)) xa[u] = *reinterpret_cast<const float4*>(a.in_aux + go);
-          }
-        }
+        v[u] = *reinterpret_cast<const float4*>(src + go[u]);
+        xa[u] = v[u];
       }
+      if (HOOKS && (a.in_act == 3 || a.in_act == 4)) {   // launch-uniform
+#pragma unroll
+        for (int u = 0; u < UB; ++u) xa[u] = *reinterpret_cast<const float4*>(a.in_aux + go[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u)
+        if (!inb[u]) v[u] = xa[u] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
         if (dst[u] >= 0) {
@@ -916,13 +929,16 @@ static inline bool ws_eligible(const ConvArgs& a) {
 static inline bool needs_hooks(const ConvArgs& a) { return a.in_act >= 3 || a.aux_out || a.epi_dact; }
 
 // Persistent wave-specialised form (needs several tiles per CU to amortise its pipeline fill).  Measured per
-// configuration against the plain kernel (tools/conv_bench.py, B=8 480x640): faster everywhere except
-// 3x3 / 3 sources / >= 2 residual maps, where the storers' residual traffic paces the tile (-4 %).
+// configuration against the tile-per-workgroup kernel (tools/conv_bench.py, B=8 480x640, same box,
+// profiles/r01_conv_ws_study.txt).  Since the plain kernel stages with unconditional loads (all 11 in flight) it is
+// the faster one for every 3x3 dilation-1 configuration (e.g. 1 source 191 vs 200 us, 3 sources 479 vs 567 us); the
+// persistent form keeps the pure streams: 1x1 without residual maps (119 vs 125, 171 vs 177, 232 vs 237 us -- the
+// device's copy rate) and the dilation-2 3x3 with one source (222 vs 236 us).
 static inline bool takes_ws(const ConvArgs& a, int kh, int dil) {
 #if PAIF_TH == 8
   if (needs_hooks(a) || kh > 3 || !ws_eligible(a)) return false;
-  const bool many_res = a.res[0] && a.res[1];
-  return !(kh == 3 && dil == 1 && a.nsrc == 3 && many_res);
+  if (kh == 1) return !a.res[0];
+  return dil == 2 && a.nsrc == 1;
 #else
   return false;
 #endif
