@@ -36,8 +36,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < QPL; ++i) {
+      // unconditional loads on a clamped quad index, zeroed afterwards (a load under a branch is waited for at the
+      // join); dy is requested here too so that both streams are in flight during the statistics
       const int q = gl + i * G;
-      v[i] = (q < nq) ? *reinterpret_cast<const float4*>(x + (size_t)row * C + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int qc = min(q, nq - 1);
+      v[i] = *reinterpret_cast<const float4*>(x + (size_t)row * C + qc * 4);
+      g[i] = *reinterpret_cast<const float4*>(dy + (size_t)row * C + qc * 4);
+      if (q >= nq) v[i] = g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
 #pragma unroll
@@ -59,10 +64,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < QPL; ++i) {
       const int q = gl + i * G;
-      g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 g4 = *reinterpret_cast<const float4*>(gamma + min(q, nq - 1) * 4);
       if (q < nq) {
-        const float4 d4 = *reinterpret_cast<const float4*>(dy + (size_t)row * C + q * 4);
-        const float4 g4 = *reinterpret_cast<const float4*>(gamma + q * 4);
+        const float4 d4 = g[i];
         g[i] = make_float4(d4.x * g4.x, d4.y * g4.y, d4.z * g4.z, d4.w * g4.w);
         v[i].x *= rstd; v[i].y *= rstd; v[i].z *= rstd; v[i].w *= rstd;  // xhat
         sg += (g[i].x + g[i].y) + (g[i].z + g[i].w);
@@ -78,16 +82,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < QPL; ++i) {
       const int q = gl + i * G;
+      float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (add) a4 = *reinterpret_cast<const float4*>(add + (size_t)row * C + min(q, nq - 1) * 4);   // launch-uniform branch
       if (q < nq) {
         float4 o;
-        o.x = rstd * (g[i].x - mg - v[i].x * mgx);
-        o.y = rstd * (g[i].y - mg - v[i].y * mgx);
-        o.z = rstd * (g[i].z - mg - v[i].z * mgx);
-        o.w = rstd * (g[i].w - mg - v[i].w * mgx);
-        if (add) {
-          const float4 a4 = *reinterpret_cast<const float4*>(add + (size_t)row * C + q * 4);
-          o.x += a4.x; o.y += a4.y; o.z += a4.z; o.w += a4.w;
-        }
+        o.x = rstd * (g[i].x - mg - v[i].x * mgx) + a4.x;
+        o.y = rstd * (g[i].y - mg - v[i].y * mgx) + a4.y;
+        o.z = rstd * (g[i].z - mg - v[i].z * mgx) + a4.z;
+        o.w = rstd * (g[i].w - mg - v[i].w * mgx) + a4.w;
         *reinterpret_cast<float4*>(dx + (size_t)row * C + q * 4) = o;
       }
     }

@@ -30,8 +30,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < QPL; ++i) {
+      // unconditional load on a clamped quad index, zeroed afterwards (a load under a branch is waited for at the join)
       const int q = gl + i * G;
-      v[i] = (q < nq) ? *reinterpret_cast<const float4*>(x + (size_t)row * C + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      v[i] = *reinterpret_cast<const float4*>(x + (size_t)row * C + min(q, nq - 1) * 4);
+      if (q >= nq) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
 #pragma unroll
@@ -52,9 +54,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < QPL; ++i) {
       const int q = gl + i * G;
+      const float4 g4 = *reinterpret_cast<const float4*>(gamma + min(q, nq - 1) * 4);
+      const float4 b4 = *reinterpret_cast<const float4*>(beta + min(q, nq - 1) * 4);
       if (q < nq) {
-        const float4 g4 = *reinterpret_cast<const float4*>(gamma + q * 4);
-        const float4 b4 = *reinterpret_cast<const float4*>(beta + q * 4);
         float4 o;
         o.x = (v[i].x - mean) * rstd * g4.x + b4.x;
         o.y = (v[i].y - mean) * rstd * g4.y + b4.y;
