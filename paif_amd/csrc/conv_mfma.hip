@@ -489,26 +489,25 @@ __global__ __launch_bounds__(NTHREADS, HOOKS ? 2 : PAIF_LB) void conv_mfma_bf16x
     __syncthreads();
 
     const uint4* wsrc = reinterpret_cast<const uint4*>(a.wpk) + (size_t)s * NTAP * NKS * 2 * 64 + lane;
-    uint4 bcur[NKS * 2], bnxt[NKS * 2];
+    // B operand: a statically indexed 3-slot register ring, two taps ahead.  A rolled loop with `bcur = bnxt` copies
+    // a pending load and therefore waits for the prefetch at the end of every tap (it only ever overlapped one tap's 12
+    // MFMAs with the L2 latency).  The tap loop runs in groups of 3 (slot = position in the group; every k*k is 3n or
+    // 3n+1, the tail tap lands on slot 0); k = 3 unrolls fully, k >= 5 keeps the groups in a rolled outer loop
+    // (full unrolling of 49 taps costs minutes of compile time per instantiation).
+    static_assert(NTAP % 3 == 0 || NTAP % 3 == 1, "tap count must be 3n or 3n+1");
+    constexpr int BRING = NTAP >= 3 ? 3 : 1;
+    uint4 bw[BRING][NKS * 2];
+    auto fetch = [&](int tap, int slot) {
 #pragma unroll
-    for (int i = 0; i < NKS * 2; ++i) bcur[i] = wsrc[i * 64];
-#pragma unroll 1
-    for (int tap = 0; tap < NTAP; ++tap) {
-#ifndef PAIF_ABL_NO_B
-      if (tap + 1 < NTAP) {
-#pragma unroll
-        for (int i = 0; i < NKS * 2; ++i) bnxt[i] = wsrc[((tap + 1) * NKS * 2 + i) * 64];
-      }
-#else
-#pragma unroll
-      for (int i = 0; i < NKS * 2; ++i) bnxt[i] = bcur[i];
-#endif
+      for (int i = 0; i < NKS * 2; ++i) bw[slot][i] = wsrc[(tap * NKS * 2 + i) * 64];
+    };
+    auto mma_tap = [&](int tap, int slot) {
       const int dy = tap / KH, dx = tap - dy * KH;
       const int toff = (dy * DIL * TWH + dx * DIL) * PSB;
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
-        const bf16x8 bh = __builtin_bit_cast(bf16x8, bcur[2 * ks]);
-        const bf16x8 bl = __builtin_bit_cast(bf16x8, bcur[2 * ks + 1]);
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, bw[slot][2 * ks]);
+        const bf16x8 bl = __builtin_bit_cast(bf16x8, bw[slot][2 * ks + 1]);
 #pragma unroll
         for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) {
           const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ldsb + abase[sg] + toff + 32 * ks);
@@ -522,8 +521,30 @@ __global__ __launch_bounds__(NTHREADS, HOOKS ? 2 : PAIF_LB) void conv_mfma_bf16x
 #endif
         }
       }
+    };
+    if constexpr (NTAP == 1) {
+      fetch(0, 0);
+      mma_tap(0, 0);
+    } else {
+      fetch(0, 0);
+      fetch(1, 1);
+      constexpr int NGRP = NTAP / 3;
+      if constexpr (NTAP <= 9) {
 #pragma unroll
-      for (int i = 0; i < NKS * 2; ++i) bcur[i] = bnxt[i];
+        for (int g = 0; g < NGRP; ++g) {
+          fetch(min(3 * g + 2, NTAP - 1), 2); mma_tap(3 * g, 0);
+          fetch(min(3 * g + 3, NTAP - 1), 0); mma_tap(3 * g + 1, 1);
+          fetch(min(3 * g + 4, NTAP - 1), 1); mma_tap(3 * g + 2, 2);
+        }
+      } else {
+#pragma unroll 1
+        for (int g = 0; g < NGRP; ++g) {
+          fetch(min(3 * g + 2, NTAP - 1), 2); mma_tap(3 * g, 0);
+          fetch(min(3 * g + 3, NTAP - 1), 0); mma_tap(3 * g + 1, 1);
+          fetch(min(3 * g + 4, NTAP - 1), 1); mma_tap(3 * g + 2, 2);
+        }
+      }
+      if constexpr (NTAP % 3 == 1) mma_tap(NTAP - 1, 0);
     }
   }
 
