@@ -127,6 +127,33 @@ def main():
     (fused * t(rr)).sum().backward()
     save("gc_fusion_2x64x96", fused=npy(fused), d_ir=npy(irt.grad), d_y=npy(yt.grad))
 
+    # ---- G-j: feature-visualisation path (Network_Fusion_Searched_showfeatures.forward2, :669-679) ----
+    with ref_import.quiet():
+        show = mfa.Network_Fusion_Searched_showfeatures(32, None, O.FUSION_AT)
+    show.eval()
+    S.load_formula_weights(show)
+    ir, vis, _ = S.make_batch(1, 40, 56)
+    ycc = mfa.RGB2YCrCb(t(vis))
+    with torch.no_grad():
+        outs = show.forward2(t(ir), ycc[:, 0:1])
+    names = ("fused", "ir_feature", "vis_feature", "lf_ir", "hf_ir", "res_ir", "lf_vis", "hf_vis", "res_vis")
+    save("gj_showfeatures_40x56", **{n: npy(o) for n, o in zip(names, outs)})
+
+    # ---- G-k: fused-image writer post-processing (test_original.py:181-197), by EXECUTING the reference's own lines ----
+    import textwrap
+    src = open(os.path.join(ref_import.REF_ROOT, "test_original.py")).read().split("\n")
+    beg = next(i for i, l in enumerate(src) if l.strip() == "images_vis_ycrcb = RGB2YCrCb(images_vis)")
+    end = next(i for i in range(beg, len(src)) if src[i].strip() == "for k in range(len(name)):")
+    block = textwrap.dedent("\n".join(src[beg:end]))
+    ir, vis, _ = S.make_batch(2, 48, 64)
+    with torch.no_grad():
+        ycc = mfa.RGB2YCrCb(t(vis))
+        fused_in = fus(t(ir), ycc[:, 0:1])
+    ns = dict(RGB2YCrCb=mfa.RGB2YCrCb, YCrCb2RGB=mfa.YCrCb2RGB, torch=torch, np=np, images_vis=t(vis), image_fusion=fused_in)
+    exec(block, ns)
+    assert ns["fused_image"].dtype == np.uint8 and ns["fused_image"].shape == (2, 48, 64, 3)
+    save("gk_fused_writer_2x48x64", fused=npy(fused_in), fused_image=ns["fused_image"])
+
     # ---- G-d: colour transforms + clamp / batch-global min-max / normalise ------------------
     m0 = build_model(R, "mit_b0")
     ir, vis, _ = S.make_batch(2, 64, 96)

@@ -280,6 +280,34 @@ def fusion_forward(ir, vis_y, sd, p="", geno=FUSION_AT, inter=None):
     return out
 
 
+def fused_image_uint8(fused, vis):
+    """Fused-image writer post-processing, test_original.py:181-197: RGB recomposition with the visible chroma, clamp to
+    [0,1], np.uint8(255*x) (truncation), batch-global min-max of the uint8 array in float64, np.uint8(255*x) again.
+    fused [B,1,H,W], vis [B,3,H,W] -> uint8 [B,H,W,3]."""
+    import numpy as np
+    ycc = rgb2ycrcb(vis)
+    rgb = ycrcb2rgb(torch.cat((fused, ycc[:, 1:2], ycc[:, 2:]), 1))
+    rgb = torch.where(rgb > 1, torch.ones_like(rgb), rgb)
+    rgb = torch.where(rgb < 0, torch.zeros_like(rgb), rgb)
+    q = np.uint8(255.0 * rgb.detach().numpy()).transpose((0, 2, 3, 1))
+    q = (q - np.min(q)) / (np.max(q) - np.min(q))
+    return np.uint8(255.0 * q)
+
+
+def fusion_forward2(ir, vis_y, sd, p="", geno=FUSION_AT):
+    """Network_Fusion_Searched_showfeatures.forward2 (core/model_fusion_auto.py:669-679) with Cell_Decom_decom
+    (:536-581): the fused image plus the decomposition intermediates (LF / HF of both eps concatenated, residue)."""
+    inter = {}
+    out = fusion_forward(ir, vis_y, sd, p, geno, inter)
+    fir, fvis = inter["fir"], inter["fvis"]
+    res_ir = fir.max(1, keepdim=True)[0] - fir.min(1, keepdim=True)[0]
+    res_vis = fvis.max(1, keepdim=True)[0] - fvis.min(1, keepdim=True)[0]
+    lf_ir, lf_vis = inter["lf_ir"], inter["lf_vis"]
+    hf_ir = torch.cat([fir, fir], 1) - lf_ir
+    hf_vis = torch.cat([fvis, fvis], 1) - lf_vis
+    return out, inter["ir_feature"], inter["vis_feature"], lf_ir, hf_ir, res_ir, lf_vis, hf_vis, res_vis
+
+
 # --------------------------------------------------------------------------------------
 # MiT encoder + SegFormer head -- core/mix_transformer.py, core/segformer_head.py
 # --------------------------------------------------------------------------------------

@@ -128,7 +128,8 @@ class Cell_Decom(nn.Module):
         """API parity with the reference: returns (LF [B,2C,H,W], HF [B,2C,H,W])."""
         raise NotImplementedError("HF = x - LF is folded into the 1x1 conv; use decomposition_nhwc for the LF maps")
 
-    def forward_nhwc(self, fir, fvis, g_ir=None, g_vis=None, tape=None):
+    def forward_nhwc(self, fir, fvis, g_ir=None, g_vis=None, tape=None, feats=None):
+        """feats (dict): receives the decomposition intermediates (LF maps, residues) for the visualisation path."""
         if g_ir is None:
             g_ir = ops.channel_residue(fir)
         if g_vis is None:
@@ -141,6 +142,8 @@ class Cell_Decom(nn.Module):
             lf_vis, ab_vis = self.decomposition_nhwc(fvis, g_vis, want_ab=True)
         w_lf = self._packs.get("lf", [self.conv1x1_lf.weight], lambda: ops.pack_decomp1x1_weight(self.conv1x1_lf.weight))
         w_hf = self._packs.get("hf", [self.conv1x1_hf.weight], lambda: ops.pack_decomp1x1_weight(self.conv1x1_hf.weight))
+        if feats is not None:
+            feats.update(lf_ir=lf_ir, lf_vis=lf_vis, g_ir=g_ir, g_vis=g_vis)
         lf = ops.conv2d([fir, lf_ir[0], lf_ir[1]], w_lf, 1, 1, shift=self.conv1x1_lf.bias)
         hf = ops.conv2d([fvis, lf_vis[0], lf_vis[1]], w_hf, 1, 1, shift=self.conv1x1_hf.bias)
         t1 = None if tape is None else []
@@ -180,6 +183,40 @@ class ChannelPool(nn.Module):
     def forward(self, ir, vis):
         ops.require_no_grad(ir, vis)
         return ops.to_nchw_view(ops.channel_pool2(ops.to_nhwc(ir), ops.to_nhwc(vis)))
+
+
+class Cell_Decom_decom(Cell_Decom):
+    """core/model_fusion_auto.py:536-581 -- the decomposition cell of the feature-visualisation network: same
+    parameters and arithmetic as Cell_Decom, but it also RETURNS the decomposition (LF and HF of both eps concatenated
+    on the channel axis, and the residue guide).  HF = x - LF is materialised here because showing it is the point."""
+
+    @staticmethod
+    def _cat_lf_hf(x, lf):
+        lf_cat = torch.cat([lf[0], lf[1]], dim=-1)          # [B,H,W,2C]: eps 1e-3 then 1e-4 (the reference's list order)
+        hf_cat = torch.cat([x, x], dim=-1) - lf_cat
+        return ops.to_nchw_view(lf_cat), ops.to_nchw_view(hf_cat)
+
+    def decomposition(self, x, C=None):
+        """(LF [B,2C,H,W], HF [B,2C,H,W], res [B,1,H,W]) -- :567-581."""
+        ops.require_no_grad(x)
+        xn = ops.to_nhwc(x)
+        g = ops.channel_residue(xn)
+        lf, hf = self._cat_lf_hf(xn, self.decomposition_nhwc(xn, g))
+        return lf, hf, ops.to_nchw_view(g.unsqueeze(-1))
+
+    def forward_feats_nhwc(self, fir, fvis, g_ir=None, g_vis=None):
+        feats = {}
+        ir_feature, vis_feature = self.forward_nhwc(fir, fvis, g_ir, g_vis, None, feats)
+        lf_ir, hf_ir = self._cat_lf_hf(fir, feats["lf_ir"])
+        lf_vis, hf_vis = self._cat_lf_hf(fvis, feats["lf_vis"])
+        res_ir = ops.to_nchw_view(feats["g_ir"].unsqueeze(-1))
+        res_vis = ops.to_nchw_view(feats["g_vis"].unsqueeze(-1))
+        return ir_feature, vis_feature, lf_ir, hf_ir, res_ir, lf_vis, hf_vis, res_vis
+
+    def forward(self, inp_ir, inp_vis):
+        ops.require_no_grad(inp_ir, inp_vis)
+        r = self.forward_feats_nhwc(ops.to_nhwc(inp_ir), ops.to_nhwc(inp_vis))
+        return (ops.to_nchw_view(r[0]), ops.to_nchw_view(r[1])) + r[2:]
 
 
 class spatial_attn_layer_M(nn.Module):
@@ -225,9 +262,11 @@ class Network_Fusion_Searched(nn.Module):
         )
         self.tanh = nn.Tanh()
         self.spa = spatial_attn_layer_M()
-        self.decompation = Cell_Decom(C, [self._genotype.normal_1, self._genotype.normal_2], self._genotype.normal_1_concat)
+        self.decompation = self._decom_cls(C, [self._genotype.normal_1, self._genotype.normal_2], self._genotype.normal_1_concat)
         self.chain = Cell_Chain(C, self._genotype.normal_3, self._genotype.normal_1_concat)
         self._packs = _PackCache()
+
+    _decom_cls = Cell_Decom
 
     def forward(self, ir, vis, inter=None):
         if torch.is_grad_enabled() and (ir.requires_grad or vis.requires_grad):
@@ -242,7 +281,10 @@ class Network_Fusion_Searched(nn.Module):
         fir, g_ir = ops.stem(ir, self.stem_1[0].weight, self.stem_1[1].weight)
         fvis, g_vis = ops.stem(vis, self.stem_2[0].weight, self.stem_2[1].weight)
         t_dec = None if tape is None else {}
-        ir_feature, vis_feature = self.decompation.forward_nhwc(fir, fvis, g_ir, g_vis, t_dec)
+        feats = {} if (inter is not None and inter.get("want_decomposition")) else None
+        ir_feature, vis_feature = self.decompation.forward_nhwc(fir, fvis, g_ir, g_vis, t_dec, feats)
+        if feats is not None:
+            inter.update(feats)
         t_chain = None if tape is None else []
         if tape is None:
             agg = self.spa.blend_nhwc(ir_feature, vis_feature)
@@ -279,6 +321,28 @@ class Network_Fusion_Searched(nn.Module):
     def _loss(self, ir, vis, mask):
         logits = self(ir, vis)
         return self._criterion(ir, vis, logits, mask)
+
+
+class Network_Fusion_Searched_showfeatures(Network_Fusion_Searched):
+    """core/model_fusion_auto.py:643-695 -- the feature-visualisation variant (caller: `val_fusion_train`,
+    test_original.py:548-662).  Same parameters (state_dict keys identical), same fused output; `forward2` also returns
+    the decomposition intermediates."""
+
+    _decom_cls = Cell_Decom_decom
+
+    def forward2(self, ir, vis):
+        """-> (fused, ir_feature, vis_feature, lf_ir, hf_ir, res_ir, lf_vis, hf_vis, res_vis)   (:669-679)"""
+        ops.require_no_grad(ir, vis)
+        with torch.no_grad():
+            inter = {"want_decomposition": True}
+            out = self.forward_impl(ir, vis, inter=inter)
+            fir, fvis = inter["fir"], inter["fvis"]
+            lf_ir, hf_ir = Cell_Decom_decom._cat_lf_hf(fir, inter["lf_ir"])
+            lf_vis, hf_vis = Cell_Decom_decom._cat_lf_hf(fvis, inter["lf_vis"])
+            res_ir = ops.to_nchw_view(inter["g_ir"].unsqueeze(-1))
+            res_vis = ops.to_nchw_view(inter["g_vis"].unsqueeze(-1))
+            return (out, ops.to_nchw_view(inter["ir_feature"]), ops.to_nchw_view(inter["vis_feature"]), lf_ir, hf_ir, res_ir,
+                    lf_vis, hf_vis, res_vis)
 
 
 class _FusionFn(torch.autograd.Function):

@@ -18,6 +18,28 @@ def _summary(meter):
                 macc=float(np.mean(np.nan_to_num(rec))))
 
 
+def fused_to_uint8(fused, vis):
+    """The reference's fused-image post-processing (test_original.py:181-197), on the GPU: RGB recomposition with the
+    visible image's chroma + clamp (HIP glue kernel), np.uint8(255*x) (truncation), batch-global min-max of the uint8
+    array evaluated in float64, np.uint8(255*x) again.  fused [B,1,H,W], vis [B,3,H,W] -> uint8 [B,H,W,3] (device)."""
+    from . import ops
+    rgb = ops.recompose_clamp(fused, ops.rgb2ycrcb(vis))[0]                       # [B,3,H,W] in [0,1]
+    q = (rgb * 255.0).to(torch.uint8).permute(0, 2, 3, 1)                         # float32 product, truncated
+    mn, mx = q.min(), q.max()
+    x = (q - mn).to(torch.float64) / (mx - mn).to(torch.float64)                  # uint8 - uint8 never wraps (>= min)
+    return (255.0 * x).to(torch.uint8).contiguous()
+
+
+def write_fused_pngs(images_uint8, names, fused_path):
+    """test_original.py:199-203: one RGB PNG per sample (host I/O, PIL)."""
+    import os
+    from PIL import Image
+    arr = images_uint8.cpu().numpy() if torch.is_tensor(images_uint8) else images_uint8
+    os.makedirs(fused_path, exist_ok=True)
+    for k, name in enumerate(names):
+        Image.fromarray(arr[k]).save(os.path.join(fused_path, name))
+
+
 def val_segformer_robust2(model, batches, n_class=9):
     """Clean evaluation (the attack call is commented out in the reference, test_original.py:154-158)."""
     model.eval()

@@ -130,6 +130,18 @@ def rgb2ycrcb(rgb):
     return out
 
 
+def recompose_clamp(fused, ycc):
+    """fused [B,1,H,W] + chroma of ycc [B,3,H,W] -> (RGB clamped to [0,1] [B,3,H,W], per-block (min, max) partials)."""
+    fused = fused.contiguous()
+    ycc = ycc.contiguous()
+    B, _, H, W = ycc.shape
+    L = lib()
+    partial = torch.empty(2 * L.paif_minmax_blocks(B, H, W), device=ycc.device, dtype=torch.float32)
+    rgb = torch.empty_like(ycc)
+    _lib.check(L.paif_recompose_clamp_fwd(_p(fused), _p(ycc), _p(rgb), _p(partial), B, H, W, _stream()), "recompose_clamp")
+    return rgb, partial
+
+
 def seg_input_from_fused(fused, ycc, return_minmax=False):
     """fused [B,1,H,W], ycc [B,3,H,W] -> normalised SegFormer input [B,3,H,W] (batch-global min-max)."""
     fused = fused.contiguous()

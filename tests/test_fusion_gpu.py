@@ -168,6 +168,54 @@ def test_fusion_net_intermediates(golden):
     assert maxabs(fused.cpu(), g["fused"]) <= 1e-4
 
 
+def test_showfeatures_forward2(golden):
+    """Feature-visualisation path: same parameters as the fusion net (identical state_dict keys),
+    forward2 returns the fused image and the decomposition intermediates of the reference."""
+    from oracle.paif_oracle import FUSION_AT
+    from paif_amd.core import model_fusion_auto as M
+    from paif_amd import ops
+
+    g = golden("gj_showfeatures_40x56")
+    net = M.Network_Fusion_Searched_showfeatures(32, None, FUSION_AT).eval()
+    net.load_state_dict({k: t(S.formula_tensor(k, tuple(v.shape))).to(v.dtype) for k, v in net.state_dict().items()}, strict=True)
+    assert list(net.state_dict().keys()) == list(_fusion_net().state_dict().keys())
+    net = net.to(_dev())
+    ir, vis, _ = S.make_batch(1, 40, 56)
+    ycc = ops.rgb2ycrcb(t(vis).to(_dev()))
+    outs = net.forward2(t(ir).to(_dev()), ycc[:, 0:1])
+    names = ("fused", "ir_feature", "vis_feature", "lf_ir", "hf_ir", "res_ir", "lf_vis", "hf_vis", "res_vis")
+    assert len(outs) == len(names)
+    for n, o in zip(names, outs):
+        assert tuple(o.shape) == tuple(g[n].shape), n
+        # the guided-filter outputs carry the reference's own cumsum noise (DESIGN.md section 2): 2e-4 abs as in test_guided_filter
+        assert maxabs(o.cpu(), g[n]) <= max(2e-4, 1e-4 * _scale(g[n])), n
+    # plain forward of the same module = the fused image
+    assert maxabs(net(t(ir).to(_dev()), ycc[:, 0:1]).cpu(), g["fused"]) <= 1e-4
+    # Cell_Decom_decom.decomposition materialises (LF, HF, res) like the reference's
+    lf, hf, res = net.decompation.decomposition(outs[1].contiguous())
+    assert lf.shape[1] == 64 and hf.shape[1] == 64 and res.shape[1] == 1
+    assert maxabs((lf + hf).cpu(), torch.cat([outs[1], outs[1]], 1).cpu()) <= 1e-5
+
+
+def test_fused_image_writer_postprocessing(golden, tmp_path):
+    """Harness post-processing (test_original.py:181-203): uint8 fused images on the GPU, exact
+    against the golden made by executing the reference's own lines; PNG round trip."""
+    from paif_amd import harness
+    from PIL import Image
+
+    g = golden("gk_fused_writer_2x48x64")
+    _, vis, _ = S.make_batch(2, 48, 64)
+    img = harness.fused_to_uint8(t(g["fused"]).to(_dev()), t(vis).to(_dev()))
+    assert img.dtype == torch.uint8 and tuple(img.shape) == g["fused_image"].shape
+    diff = (img.cpu().numpy().astype(np.int32) - g["fused_image"].astype(np.int32))
+    # the first quantisation truncates 255*x: an fp32 last-bit difference in the colour transform can move a value
+    # across an integer; the reference's own k-ordered fma chain is reproduced, so the result is exact
+    assert np.abs(diff).max() == 0, (np.abs(diff).max(), int((diff != 0).sum()))
+    harness.write_fused_pngs(img, ["a.png", "b.png"], str(tmp_path))
+    back = np.asarray(Image.open(str(tmp_path / "b.png")))
+    assert np.array_equal(back, g["fused_image"][1])
+
+
 def test_fusion_net_b2(golden):
     from paif_amd import ops
 

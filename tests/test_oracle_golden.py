@@ -99,6 +99,31 @@ def test_fusion_net_intermediates(golden):
         assert maxabs(inter[k], g[k]) <= 2e-5 * max(1.0, float(np.abs(g[k]).max())), k
 
 
+SHOW_NAMES = ("fused", "ir_feature", "vis_feature", "lf_ir", "hf_ir", "res_ir", "lf_vis", "hf_vis", "res_vis")
+
+
+def test_showfeatures_forward2(golden):
+    """Feature-visualisation path: Network_Fusion_Searched_showfeatures.forward2."""
+    g = golden("gj_showfeatures_40x56")
+    ir, vis, _ = S.make_batch(1, 40, 56)
+    ycc = O.rgb2ycrcb(t(vis))
+    with torch.no_grad():
+        outs = O.fusion_forward2(t(ir), ycc[:, 0:1], Hh.fusion_sd())
+    for n, o in zip(SHOW_NAMES, outs):
+        assert tuple(o.shape) == tuple(g[n].shape), n
+        assert maxabs(o, g[n]) <= 2e-5 * max(1.0, float(np.abs(g[n]).max())), n
+
+
+def test_fused_image_writer_postprocessing(golden):
+    """test_original.py:181-197 (uint8 fused-image pipeline); the golden was produced by executing the reference's own
+    lines (oracle/make_golden.py G-k).  Integer output: exact."""
+    g = golden("gk_fused_writer_2x48x64")
+    _, vis, _ = S.make_batch(2, 48, 64)
+    out = O.fused_image_uint8(t(g["fused"]), t(vis))
+    assert out.dtype == np.uint8 and out.shape == g["fused_image"].shape
+    assert np.array_equal(out, g["fused_image"])
+
+
 def test_fusion_net_b2_and_input_grads(golden):
     g = golden("gc_fusion_2x64x96")
     ir, vis, _ = S.make_batch(2, 64, 96)
