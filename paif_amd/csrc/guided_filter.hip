@@ -217,10 +217,6 @@ namespace {
 
 constexpr int FC = 64;             // loaded columns
 constexpr int FO = FC - 4 * R;     // 48 output columns
-#ifndef PAIF_GF_FROWS
-#define PAIF_GF_FROWS 120
-#endif
-constexpr int FROWS = PAIF_GF_FROWS;   // output rows per workgroup
 constexpr int PF = 3;                  // rows of (y, g) loads kept in flight ahead of the row being processed
 
 // LDS-only barrier: the rows' output stores and the prefetched loads stay in flight across it (a __syncthreads()
@@ -233,7 +229,7 @@ __device__ __forceinline__ void lds_barrier() {
 
 __global__ __launch_bounds__(512) void gf_fused_kernel(const float* __restrict__ guide, const float* __restrict__ y,
                                                        float* __restrict__ lf, float eps0, float eps1, int B, int H, int W,
-                                                       int nstrip, int nseg) {
+                                                       int nstrip, int nseg, int frows) {
   __shared__ float4 s_a[2][FC][8];
   __shared__ float4 s_b[2][FC][8];
   __shared__ float2 s_g[2][FC];
@@ -246,7 +242,7 @@ __global__ __launch_bounds__(512) void gf_fused_kernel(const float* __restrict__
   const float eps = e == 0 ? eps0 : eps1;
   const int col = strip * FO - 2 * R + xi;
   const bool colin = col >= 0 && col < W;
-  const int ybeg = seg * FROWS, yend = min(H, ybeg + FROWS);
+  const int ybeg = seg * frows, yend = min(H, ybeg + frows);   // frows = output rows per workgroup (chosen at launch)
   const size_t img = (size_t)b * H * W;
   float* out = lf + (size_t)e * ((size_t)B * H * W * 32);
 
@@ -362,9 +358,21 @@ extern "C" int paif_guided_filter_fused_fwd(const float* guide, const float* y, 
                                             int W, paif_stream_t stream) {
   PAIF_REQUIRE(guide && y && lf && B > 0, PAIF_EINVAL, "guided_filter_fused: bad arguments");
   PAIF_REQUIRE(H > 2 * R + 1 && W > 2 * R + 1, PAIF_EINVAL, "guided_filter: H,W must exceed 2r+1 = %d (got %dx%d)", K, H, W);
-  const int nstrip = (W + FO - 1) / FO, nseg = (H + FROWS - 1) / FROWS;
+  const int nstrip = (W + FO - 1) / FO;
+  // Rows per workgroup: one workgroup is resident per CU (246 VGPRs x 512 threads), so the launch runs in rounds of
+  // 256 workgroups and a workgroup costs (rows + 4R halo) row-iterations: pick the split with the fewest
+  // rounds x (rows + 16)  (B=8, 480x640: 2 segments of 240 rows -> 2 rounds x 256 instead of 4 x 136).
+  int nseg = 1;
+  long best = -1;
+  for (int n = 1; n <= 16 && n <= H; ++n) {
+    const int rows = (H + n - 1) / n;
+    const long blocks = (long)B * nstrip * n * 2;
+    const long cost = ((blocks + 255) / 256) * (rows + 4 * R);
+    if (best < 0 || cost < best) { best = cost; nseg = n; }
+  }
+  const int frows = (H + nseg - 1) / nseg;
   hipLaunchKernelGGL(gf_fused_kernel, dim3(B * nstrip * nseg, 2), dim3(512), 0, paif::as_stream(stream), guide, y, lf, eps0, eps1, B,
-                     H, W, nstrip, nseg);
+                     H, W, nstrip, nseg, frows);
   PAIF_LAUNCH_CHECK("guided_filter_fused");
   return 0;
 }
