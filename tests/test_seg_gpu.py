@@ -113,3 +113,27 @@ def test_train_mode_fails_loudly():
                 m(torch.zeros(1, 1, 64, 96, device=_dev()), torch.zeros(1, 3, 64, 96, device=_dev()))
     finally:
         m.eval()
+
+
+def test_graph_capture_replay_is_bit_identical():
+    """paif_amd.graph.GraphedForward: every HIP kernel is launched on torch's current stream, so one eval forward can be
+    captured in a hipGraph and replayed on new inputs (same shapes) with bit-identical results."""
+    from oracle.paif_oracle import FUSION_AT
+    from paif_amd.core.model_fusion_auto import Network_MM_Searched
+    from paif_amd.graph import GraphedForward
+
+    dev = torch.device("cuda:0")
+    net = Network_MM_Searched(32, FUSION_AT, None, None, "mit_b0", num_classes=9).eval()
+    S.load_formula_weights(net)
+    net = net.to(dev)
+    ir, vis, _ = S.make_batch(1, 64, 96)
+    ir, vis = t(ir).to(dev), t(vis).to(dev)
+    g = GraphedForward(net, ir, vis)
+    ir2, vis2, _ = S.make_batch(1, 64, 96, start=3)
+    ir2, vis2 = t(ir2).to(dev), t(vis2).to(dev)
+    with torch.no_grad():
+        f_e, s_e = net(ir2, vis2)
+    f_g, s_g = g(ir2, vis2)
+    assert torch.equal(f_e, f_g) and torch.equal(s_e, s_g)
+    with pytest.raises(ValueError):
+        g(ir2[:, :, :32], vis2)
