@@ -191,6 +191,13 @@ int paif_add_fwd(const float* a, const float* b, float* out, size_t n, paif_stre
 int paif_gemm_fwd(const float* A, int lda, const float* W, const float* scale, const float* shift, int act,
                   const float* res, int ldres, float* C, int ldc, int M, int N, int K, int precision,
                   paif_stream_t stream);
+/* Split-K form of paif_gemm_fwd (exact fp32) for small output grids with a long k loop: paif_gemm_splitk_plan returns
+ * the number of k splits (1 = do not split); the caller provides workspace[splits * M * N] floats.  Partial sums are
+ * added in split order by a second pass (deterministic), which also applies scale / shift / act / res. */
+int paif_gemm_splitk_plan(int M, int N, int K);
+int paif_gemm_splitk_fwd(const float* A, int lda, const float* W, const float* scale, const float* shift, int act,
+                         const float* res, int ldres, float* C, int ldc, int M, int N, int K, int splits,
+                         float* workspace, paif_stream_t stream);
 
 /* nn.LayerNorm over the last dim (core/mix_transformer.py:75,122,127,172,232-253). x,y [M,C]; C % 4 == 0. */
 int paif_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, int M, int C, float eps,

@@ -25,6 +25,8 @@ struct GemmArgs {
   const float* a_mask; const float* a_scale;
   int M, N, K, lda, ldc, ldres, act;
   int tilesN, nblk;
+  int kper;            // k extent of one split (= K without split-K); blockIdx.y selects the split
+  float* partial;      // split-K: raw accumulators go to partial[split][M][N] (no epilogue); else NULL
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -48,7 +50,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32(GemmArgs a) {
   const int abase = (wave * 32 + p) * LDS_STRIDE + 4 * h;
   const int wbase = p * LDS_STRIDE + 4 * h;
 
-  for (int k0 = 0; k0 < a.K; k0 += BK) {
+  const int kbeg = blockIdx.y * a.kper, kend = kbeg + a.kper;
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
     float4 va[4], vw[2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32(GemmArgs a) {
       const int n = n0 + srow + 32 * i;
       vw[i] = (n < a.N) ? *reinterpret_cast<const float4*>(a.W + (size_t)n * a.K + k0 + sq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (k0 > 0) __syncthreads();  // previous tile fully consumed
+    if (k0 > kbeg) __syncthreads();  // previous tile fully consumed
 #pragma unroll
     for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(sA + (srow + 32 * i) * LDS_STRIDE + sq * 4) = va[i];
 #pragma unroll
@@ -91,6 +94,19 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32(GemmArgs a) {
     }
   }
 
+  if (a.partial) {   // split-K: raw partial sums; scale / activation / residual are applied by the reduction pass
+    float* slab = a.partial + (size_t)blockIdx.y * a.M * a.N;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int n = n0 + 32 * t + p;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < a.M && n < a.N) slab[(size_t)m * a.N + n] = acc[t][r];
+      }
+    }
+    return;
+  }
   // ---- epilogue ----
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
@@ -225,6 +241,24 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16x3(GemmArgs a) {
   }
 }
 
+// split-K second pass: C[m][n] = act(scale[n] * sum_s partial[s][m][n] + shift[n]) (+ res), splits summed in index order
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ partial, int splits,
+                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                 int act, const float* __restrict__ res, int ldres,
+                                                                 float* __restrict__ C, int ldc, int M, int N) {
+  const size_t total = (size_t)M * N;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int m = (int)(i / N), n = (int)(i - (size_t)m * N);
+    float v = 0.f;
+    for (int s = 0; s < splits; ++s) v += partial[(size_t)s * total + i];
+    v = v * (scale ? scale[n] : 1.f) + (shift ? shift[n] : 0.f);
+    if (act == 1) v = gelu_erf(v);
+    else if (act == 2) v = fmaxf(v, 0.f);
+    if (res) v += res[(size_t)m * ldres + n];
+    C[(size_t)m * ldc + n] = v;
+  }
+}
+
 }  // namespace
 
 extern "C" int paif_gemm_masked_fwd(const float* A, int lda, const float* a_mask, const float* a_scale, const float* W,
@@ -252,8 +286,53 @@ extern "C" int paif_gemm_masked_fwd(const float* A, int lda, const float* a_mask
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldres = res ? ldres : 0; a.act = act;
   a.tilesN = (N + BN - 1) / BN;
   a.nblk = a.tilesN * ((M + BM - 1) / BM);
+  a.kper = K;
+  a.partial = nullptr;
   if (precision == 1) hipLaunchKernelGGL(gemm_mfma_bf16x3, dim3(a.nblk), dim3(256), 0, paif::as_stream(stream), a);
   else hipLaunchKernelGGL(gemm_mfma_f32, dim3(a.nblk), dim3(256), 0, paif::as_stream(stream), a);
   PAIF_LAUNCH_CHECK("gemm");
+  return 0;
+}
+
+// Split-K plan for the exact-fp32 GEMM: a 128 x 64 tile grid that leaves most of the 256 CUs idle while each
+// workgroup walks a long k loop (MiT stages 3-4 and the SR convs at small batch) is split over k so that about one
+// workgroup per CU is in flight; every split keeps at least 2 k-tiles.  Returns 1 when splitting does not pay.
+extern "C" int paif_gemm_splitk_plan(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K < 256 || (K % 32) != 0) return 1;
+  const int nblk = ((N + BN - 1) / BN) * ((M + BM - 1) / BM);
+  if (nblk >= 128) return 1;
+  int splits = (256 + nblk - 1) / nblk;
+  const int ktiles = K / BK;
+  if (splits > ktiles / 2) splits = ktiles / 2;
+  if (splits > 16) splits = 16;
+  while (splits > 1 && ktiles % splits) --splits;   // equal k extents per split
+  return splits < 2 ? 1 : splits;
+}
+
+extern "C" int paif_gemm_splitk_fwd(const float* A, int lda, const float* W, const float* scale, const float* shift, int act,
+                                    const float* res, int ldres, float* C, int ldc, int M, int N, int K, int splits,
+                                    float* workspace, paif_stream_t stream) {
+  PAIF_REQUIRE(A && W && C && workspace, PAIF_EINVAL, "gemm_splitk: null pointer");
+  PAIF_REQUIRE(M > 0 && N > 0 && K > 0 && K % 32 == 0, PAIF_EINVAL, "gemm_splitk: shape %dx%dx%d", M, N, K);
+  PAIF_REQUIRE(splits >= 2 && (K / BK) % splits == 0, PAIF_EINVAL, "gemm_splitk: splits=%d does not divide %d k-tiles", splits,
+               K / BK);
+  PAIF_REQUIRE(lda >= K && ldc >= N && (lda % 4) == 0, PAIF_EINVAL, "gemm_splitk: bad leading dimensions lda=%d ldc=%d", lda, ldc);
+  PAIF_REQUIRE(act >= 0 && act <= 2, PAIF_EINVAL, "gemm_splitk: act=%d", act);
+  GemmArgs a;
+  a.a_mask = nullptr; a.a_scale = nullptr;
+  a.A = A; a.W = W; a.scale = nullptr; a.shift = nullptr; a.res = nullptr; a.C = C;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldres = 0; a.act = 0;
+  a.tilesN = (N + BN - 1) / BN;
+  a.nblk = a.tilesN * ((M + BM - 1) / BM);
+  a.kper = K / splits;
+  a.partial = workspace;
+  hipStream_t st = paif::as_stream(stream);
+  hipLaunchKernelGGL(gemm_mfma_f32, dim3(a.nblk, splits), dim3(256), 0, st, a);
+  PAIF_LAUNCH_CHECK("gemm_splitk");
+  const size_t total = (size_t)M * N;
+  const int rblocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(rblocks), dim3(256), 0, st, workspace, splits, scale, shift, act, res,
+                     res ? ldres : 0, C, ldc, M, N);
+  PAIF_LAUNCH_CHECK("gemm_splitk_reduce");
   return 0;
 }

@@ -452,7 +452,16 @@ def gemm(a, w, scale=None, shift=None, act=ACT_NONE, res=None, out=None, out_col
         assert a_cols is None and a_mask.shape == a.shape
     tag = "gemm_mfma_%s" % CONFIG["gemm_precision"]
     e0 = TIMER.start(tag) if TIMER is not None else None
-    _lib.check(lib().paif_gemm_masked_fwd(aptr, lda, _p(a_mask), _p(a_scale), _p(w), _p(scale), _p(shift), act, _p(res), N, cptr,
+    L = lib()
+    splits = 1
+    if CONFIG["gemm_precision"] == "f32" and a_mask is None and a_scale is None:
+        splits = L.paif_gemm_splitk_plan(M, N, K)   # small grid + long k loop (small batch): spread k over the idle CUs
+    if splits > 1:
+        ws = torch.empty(splits * M * N, device=a.device, dtype=torch.float32)
+        _lib.check(L.paif_gemm_splitk_fwd(aptr, lda, _p(w), _p(scale), _p(shift), act, _p(res), N, cptr, ldc, M, N, K, splits,
+                                          _p(ws), _stream()), "gemm_splitk")
+    else:
+        _lib.check(L.paif_gemm_masked_fwd(aptr, lda, _p(a_mask), _p(a_scale), _p(w), _p(scale), _p(shift), act, _p(res), N, cptr,
                                           ldc, M, N, K, _PREC_CODE[CONFIG["gemm_precision"]], _stream()), "gemm")
     if e0 is not None:
         TIMER.stop(tag, e0, 2 * M * N * K, 4 * (M * K + N * K + M * N * (2 if res is not None else 1)))
