@@ -22,6 +22,9 @@
 #include "paif_common.h"
 #include <type_traits>
 
+#ifndef PAIF_UB_HOOKS
+#define PAIF_UB_HOOKS 3   // same, gradient-hook kernels (each staged element also carries the saved pre-activation)
+#endif
 #ifndef PAIF_UB
 #define PAIF_UB 11  // staged float4 loads in flight per lane (forward kernels): the whole 3x3 halo tile in one batch
 #endif
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(NTHREADS, HOOKS ? 2 : 3) void conv_mfma_f32(ConvArg
     // per lane (one-at-a-time staging is latency-bound: ~1 us per dependent HBM load)
     constexpr int TOTAL = THH * TWH * QPP;
     constexpr int NIT = (TOTAL + NTHREADS - 1) / NTHREADS;
-    constexpr int UB = HOOKS ? 3 : PAIF_UB;
+    constexpr int UB = HOOKS ? PAIF_UB_HOOKS : PAIF_UB;
 #pragma unroll
     for (int i0 = 0; i0 < NIT; i0 += UB) {
       float4 v[UB], xa[UB];
@@ -429,7 +432,7 @@ __global__ __launch_bounds__(NTHREADS, HOOKS ? 2 : PAIF_LB) void conv_mfma_bf16x
     const float* src = a.src[s];
     constexpr int TOTAL = THH * TWH * QPP;
     constexpr int NIT = (TOTAL + NTHREADS - 1) / NTHREADS;
-    constexpr int UB = HOOKS ? 3 : PAIF_UB;
+    constexpr int UB = HOOKS ? PAIF_UB_HOOKS : PAIF_UB;
 #pragma unroll
     for (int i0 = 0; i0 < NIT; i0 += UB) {
       float4 v[UB], xa[UB];
