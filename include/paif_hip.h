@@ -342,6 +342,13 @@ int paif_spa1_fwd(const float* o, const float* r, const float* w, int k, const f
 int paif_spa1_bwd_input(const float* dout, const float* u, const float* o, const float* s, const float* w, int k,
                         const float* prelu, float* dpre, float* d_o, float* d_r, int B, int H, int W, paif_stream_t stream);
 
+/* ---- training-API losses (forward values; core/loss.py:490-502, pytorch_ssim/__init__.py:8-43) --------------------------
+ * x, y: [B,1,H,W] planes.  window1d: the 11 fp32 Gaussian weights (sigma 1.5, normalised) as the reference builds them.
+ * partial[2*blocks]: per-workgroup (sum of the SSIM map, sum of |y - x|); the caller adds them and divides by B*H*W. */
+int paif_ssim_l1_blocks(int B, int H, int W);
+int paif_ssim_l1_fwd(const float* x, const float* y, const float* window1d, float* partial, int B, int H, int W,
+                     paif_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

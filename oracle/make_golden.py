@@ -154,6 +154,24 @@ def main():
     assert ns["fused_image"].dtype == np.uint8 and ns["fused_image"].shape == (2, 48, 64, 3)
     save("gk_fused_writer_2x48x64", fused=npy(fused_in), fused_image=ns["fused_image"])
 
+    # ---- G-l: training-API loss values (_loss, _loss_coupled, _fusion_loss_lower, _fusion_loss; :1093-1122) ----
+    with ref_import.quiet():
+        crit = R["loss"].Fusionloss_grad2()
+        ml = mfa.Network_MM_Searched(32, O.FUSION_AT, crit, torch.nn.CrossEntropyLoss(ignore_index=255), "mit_b0", num_classes=9)
+    ml.eval()
+    S.load_formula_weights(ml)
+    ir, vis, lab = S.make_batch(2, 64, 96)
+    ir2, vis2, _ = S.make_batch(2, 64, 96, start=2)
+    mask = np.maximum(ir, vis[:, :1]).astype(np.float32)      # any [B,1,H,W] target image
+    with torch.no_grad():
+        out = dict(
+            loss=float(ml._loss(t(ir), t(vis), t(mask), t(lab))),
+            loss_coupled=float(ml._loss_coupled((t(ir), t(ir2)), (t(vis), t(vis2)), t(mask), t(lab))),
+            fusion_loss_lower=float(ml._fusion_loss_lower(t(ir), t(vis), t(mask))),
+            fusion_loss=float(ml._fusion_loss(t(ir), t(vis), t(mask))),
+        )
+    save("gl_training_losses_2x64x96", **{k: np.array(v, dtype=np.float64) for k, v in out.items()})
+
     # ---- G-d: colour transforms + clamp / batch-global min-max / normalise ------------------
     m0 = build_model(R, "mit_b0")
     ir, vis, _ = S.make_batch(2, 64, 96)

@@ -528,6 +528,17 @@ def fusionloss_grad2(image_ir, image_vis, generate_img, mask):
     return F.l1_loss(mask, generate_img) + 1.1 * (1 - ssim(generate_img, mask))
 
 
+def model_losses(ir, vis, ir2, vis2, mask, labels, sd, backbone="mit_b0"):
+    """Network_MM_Searched._loss / _loss_coupled / _fusion_loss_lower / _fusion_loss (core/model_fusion_auto.py:1093-1122)
+    with Fusionloss_grad2 and CrossEntropyLoss(ignore_index=255)."""
+    fused, seg = model_forward(ir, vis, sd, backbone)
+    up = F.interpolate(seg, size=labels.shape[1:], mode="bilinear", align_corners=False)
+    den = F.cross_entropy(up, labels.long(), ignore_index=255)
+    enh = fusionloss_grad2(ir, rgb2ycrcb(vis), fused, mask)
+    enh_c = fusionloss_grad2(ir2, rgb2ycrcb(vis2), fused, mask)     # the criterion ignores its image arguments
+    return dict(loss=enh * 0.1 + den * 4, loss_coupled=enh_c * 0.1 + den * 4, fusion_loss_lower=enh, fusion_loss=enh)
+
+
 def poly_warmup_lr_mult(step, warmup_iter, max_iter, warmup_ratio, power):
     """PolyWarmupAdamW.step's LR multiplier, utils/optimizer.py:17-28 (None = lr left unchanged)."""
     if step < warmup_iter:

@@ -513,10 +513,50 @@ class _CompositeBase(nn.Module):
     def forward_object(self, ir, vis):
         raise NotImplementedError("forward_object (second min-max on the fused plane, :743-772) is only used by _detection_loss; not built")
 
-    def _loss(self, *a, **k):
-        raise NotImplementedError("training losses need the backward kernels (config 5; not built yet)")
+    # ---- training-API losses (:1093-1128): forward VALUES.  The parameter-gradient kernels of the training step
+    # (BASELINE config 5) are not built, so these return tensors without a grad_fn and refuse inputs that require grad.
+    def _seg_term(self, seg_map, labels):
+        """self.seg_loss(F.interpolate(seg_map, size=labels.shape[1:], bilinear), labels.long())"""
+        labels = labels.type(torch.long).contiguous()
+        sl = self.seg_loss
+        if isinstance(sl, nn.CrossEntropyLoss) and sl.reduction == "mean" and sl.weight is None and sl.label_smoothing == 0.0:
+            # fused bilinear upsample + cross entropy (HIP), same arithmetic as attack.Seg_loss
+            return ops.upsample_ce_fwd(ops.to_nhwc(seg_map), labels, ignore_index=sl.ignore_index)[0]
+        # any other user criterion: the reference's own two calls (the 9-class upsample is not on the hot path)
+        import torch.nn.functional as F
+        return sl(F.interpolate(seg_map, size=labels.shape[1:], mode='bilinear', align_corners=False), labels)
 
-    _loss_coupled = _fusion_loss_lower = _fusion_loss = _fusion_loss_wogan = _detection_loss = _loss
+    def _loss(self, ir, vis, mask, labels):
+        ops.require_no_grad(ir, vis, mask)
+        with torch.no_grad():
+            fused_img, seg_map = self(ir, vis)
+            enhance_loss = self._criterion(ir, ops.rgb2ycrcb(vis), fused_img, mask)
+            return enhance_loss * 0.1 + self._seg_term(seg_map, labels) * 4
+
+    def _loss_coupled(self, ir_, vis_, mask, labels):
+        ops.require_no_grad(ir_[0], vis_[0], ir_[1], vis_[1], mask)
+        with torch.no_grad():
+            fused_img, seg_map = self(ir_[0], vis_[0])
+            denoise_loss = self._seg_term(seg_map, labels)
+            enhance_loss = self._criterion(ir_[1], ops.rgb2ycrcb(vis_[1]), fused_img, mask)
+            return enhance_loss * 0.1 + denoise_loss * 4
+
+    def _fusion_loss_lower(self, ir, vis, mask):
+        ops.require_no_grad(ir, vis, mask)
+        with torch.no_grad():
+            fused_img, _ = self(ir, vis)
+            return self._criterion(ir, ops.rgb2ycrcb(vis), fused_img, mask)
+
+    def _fusion_loss(self, ir, vis, mask):
+        ops.require_no_grad(ir, vis, mask)
+        with torch.no_grad():
+            fused_img = self.forward_fusion(ir, vis)
+            return self._criterion(ir, ops.rgb2ycrcb(vis), fused_img, mask)
+
+    _fusion_loss_wogan = _fusion_loss
+
+    def _detection_loss(self, *a, **k):
+        raise NotImplementedError("_detection_loss needs forward_object (second min-max on the fused plane, :743-772); not built")
 
     def enhance_net_parameters(self):
         return self.enhance_net.parameters()

@@ -1,0 +1,84 @@
+// Fusion loss of the training API: Fusionloss_grad2 = L1(mask, fused) + 1.1 * (1 - SSIM_11x11(fused, mask))
+// (core/loss.py:490-502; pytorch_ssim/__init__.py:8-43,70-78: Gaussian window sigma 1.5, zero padding 5, mean of the map).
+// Forward values only -- the parameter-gradient kernels of the training step are not built.
+//
+// One workgroup = a 16 x 16 pixel tile of one image; the 26 x 26 halo tiles of both images sit in LDS (zero padded);
+// a thread forms the five windowed sums (x, y, x^2, y^2, xy) of its pixel with the separable weights g[i]*g[j] given by
+// the host (computed there in fp32 exactly as the reference builds its window) and the SSIM / |y - x| terms; the
+// workgroup's two sums go to partial[2 * block] in a fixed lane order (no float atomics; the host adds the partials).
+#include "paif_common.h"
+
+namespace {
+
+constexpr int T = 16, WS = 11, PADW = WS / 2, HT = T + 2 * PADW;   // 26
+
+__global__ __launch_bounds__(256) void ssim_l1_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                      const float* __restrict__ g, float* __restrict__ partial, int H, int W,
+                                                      int tilesX, int tilesY) {
+  __shared__ float sx[HT][HT + 1], sy[HT][HT + 1];
+  __shared__ float sg[WS];
+  __shared__ float red[2][4];
+  const int tid = threadIdx.x;
+  int t = blockIdx.x;
+  const int tx = t % tilesX; t /= tilesX;
+  const int ty = t % tilesY;
+  const int b = t / tilesY;
+  const int x0 = tx * T - PADW, y0 = ty * T - PADW;
+  const size_t img = (size_t)b * H * W;
+  if (tid < WS) sg[tid] = g[tid];
+  for (int i = tid; i < HT * HT; i += 256) {
+    const int r = i / HT, c = i - r * HT;
+    const int gy = min(max(y0 + r, 0), H - 1), gx = min(max(x0 + c, 0), W - 1);   // unconditional load, zero by select
+    const bool in = y0 + r >= 0 && y0 + r < H && x0 + c >= 0 && x0 + c < W;
+    const float vx = x[img + (size_t)gy * W + gx], vy = y[img + (size_t)gy * W + gx];
+    sx[r][c] = in ? vx : 0.f;
+    sy[r][c] = in ? vy : 0.f;
+  }
+  __syncthreads();
+  const int ly = tid >> 4, lx = tid & 15;
+  const int py = ty * T + ly, px = tx * T + lx;
+  float s_ssim = 0.f, s_l1 = 0.f;
+  if (py < H && px < W) {
+    float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+    for (int i = 0; i < WS; ++i) {
+      const float gi = sg[i];
+#pragma unroll
+      for (int j = 0; j < WS; ++j) {
+        const float w = gi * sg[j];   // the reference's 2-D window is the fp32 outer product of the 1-D one
+        const float a = sx[ly + i][lx + j], c = sy[ly + i][lx + j];
+        m1 = fmaf(w, a, m1); m2 = fmaf(w, c, m2);
+        e11 = fmaf(w, a * a, e11); e22 = fmaf(w, c * c, e22); e12 = fmaf(w, a * c, e12);
+      }
+    }
+    const float m11 = m1 * m1, m22 = m2 * m2, m12 = m1 * m2;
+    const float s1 = e11 - m11, s2 = e22 - m22, s12 = e12 - m12;
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    s_ssim = ((2.f * m12 + C1) * (2.f * s12 + C2)) / ((m11 + m22 + C1) * (s1 + s2 + C2));
+    s_l1 = fabsf(sy[ly + PADW][lx + PADW] - sx[ly + PADW][lx + PADW]);
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    s_ssim += __shfl_xor(s_ssim, m);
+    s_l1 += __shfl_xor(s_l1, m);
+  }
+  if ((tid & 63) == 0) { red[0][tid >> 6] = s_ssim; red[1][tid >> 6] = s_l1; }
+  __syncthreads();
+  if (tid == 0) {
+    partial[2 * (size_t)blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    partial[2 * (size_t)blockIdx.x + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+
+}  // namespace
+
+extern "C" int paif_ssim_l1_blocks(int B, int H, int W) { return B * ((H + T - 1) / T) * ((W + T - 1) / T); }
+
+extern "C" int paif_ssim_l1_fwd(const float* x, const float* y, const float* window1d, float* partial, int B, int H, int W,
+                                paif_stream_t stream) {
+  PAIF_REQUIRE(x && y && window1d && partial && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "ssim_l1: bad arguments");
+  const int tilesX = (W + T - 1) / T, tilesY = (H + T - 1) / T;
+  hipLaunchKernelGGL(ssim_l1_kernel, dim3(B * tilesX * tilesY), dim3(256), 0, paif::as_stream(stream), x, y, window1d, partial, H, W,
+                     tilesX, tilesY);
+  PAIF_LAUNCH_CHECK("ssim_l1");
+  return 0;
+}

@@ -556,6 +556,27 @@ def upsample_ce_bwd(logits, label, gscale, cp=32, ignore_index=255):
     return resize_bilinear_adjoint(dfull, 0, cp, IH, IW)
 
 
+_SSIM_WINDOW = {}
+
+
+def ssim_l1(x, y):
+    """x, y: [B,1,H,W] -> (mean SSIM_11x11(x, y), mean |y - x|) as 0-d device tensors (forward values only).
+    pytorch_ssim/__init__.py:8-43: Gaussian window sigma 1.5 (built in fp32 like the reference), zero padding, mean."""
+    import math
+    assert x.shape == y.shape and x.shape[1] == 1
+    x, y = x.contiguous(), y.contiguous()
+    B, _, H, W = x.shape
+    g = _SSIM_WINDOW.get(x.device)
+    if g is None:
+        g1 = torch.Tensor([math.exp(-(i - 11 // 2) ** 2 / float(2 * 1.5 ** 2)) for i in range(11)])
+        g = _SSIM_WINDOW[x.device] = (g1 / g1.sum()).to(x.device)
+    L = lib()
+    partial = torch.empty((L.paif_ssim_l1_blocks(B, H, W), 2), device=x.device, dtype=torch.float32)
+    _lib.check(L.paif_ssim_l1_fwd(_p(x), _p(y), _p(g), _p(partial), B, H, W, _stream()), "ssim_l1")
+    s = partial.sum(0) / float(B * H * W)
+    return s[0], s[1]
+
+
 def layernorm(x, weight, bias, eps):
     C = x.shape[-1]
     y = torch.empty_like(x)

@@ -252,3 +252,37 @@ def test_fgsm_ir_is_unrunnable_like_the_reference():
 
     with pytest.raises(NotImplementedError):
         fgsm_ir(None, None, None, None)
+
+
+def test_training_api_loss_values(golden):
+    """T1, forward part: _loss / _loss_coupled / _fusion_loss_lower / _fusion_loss (core/model_fusion_auto.py:1093-1122)
+    with Fusionloss_grad2 (HIP SSIM + L1 kernel) and CrossEntropyLoss(ignore_index=255) (fused HIP upsample + CE) against
+    the reference's values; inputs that require grad are refused (the parameter-gradient kernels are not built)."""
+    from oracle.paif_oracle import FUSION_AT
+    from paif_amd.core.model_fusion_auto import Network_MM_Searched
+    from paif_amd.core.loss import Fusionloss_grad2, ssim
+
+    g = golden("gl_training_losses_2x64x96")
+    dev = torch.device("cuda:0")
+    net = Network_MM_Searched(32, FUSION_AT, Fusionloss_grad2(), torch.nn.CrossEntropyLoss(ignore_index=255), "mit_b0", num_classes=9).eval()
+    S.load_formula_weights(net)
+    net = net.to(dev)
+    ir, vis, lab = S.make_batch(2, 64, 96)
+    ir2, vis2, _ = S.make_batch(2, 64, 96, start=2)
+    mask = np.maximum(ir, vis[:, :1]).astype(np.float32)
+    d = lambda a: t(a).to(dev)
+    got = dict(
+        loss=net._loss(d(ir), d(vis), d(mask), d(lab)),
+        loss_coupled=net._loss_coupled((d(ir), d(ir2)), (d(vis), d(vis2)), d(mask), d(lab)),
+        fusion_loss_lower=net._fusion_loss_lower(d(ir), d(vis), d(mask)),
+        fusion_loss=net._fusion_loss(d(ir), d(vis), d(mask)),
+    )
+    for k, v in got.items():
+        assert abs(float(v) - float(g[k])) <= 5e-5 * max(1.0, abs(float(g[k]))), (k, float(v), float(g[k]))
+    # SSIM alone against the standalone golden (gh_losses_metrics: ssim of two formula images)
+    gh = golden("gh_losses_metrics")
+    a, b = S.make_smooth_feature(52, 2, 1, 32, 40), S.make_smooth_feature(53, 2, 1, 32, 40)
+    assert abs(float(ssim(d(a), d(b))) - float(gh["ssim"])) <= 2e-5
+    assert abs(float(Fusionloss_grad2()(d(a), d(a), d(a), d(b))) - float(gh["fusionloss_grad2"])) <= 2e-5
+    with pytest.raises(NotImplementedError):
+        net._loss(d(ir).requires_grad_(True), d(vis), d(mask), d(lab))

@@ -124,6 +124,18 @@ def test_fused_image_writer_postprocessing(golden):
     assert np.array_equal(out, g["fused_image"])
 
 
+def test_training_api_loss_values(golden):
+    """_loss / _loss_coupled / _fusion_loss_lower / _fusion_loss (core/model_fusion_auto.py:1093-1122), forward values."""
+    g = golden("gl_training_losses_2x64x96")
+    ir, vis, lab = S.make_batch(2, 64, 96)
+    ir2, vis2, _ = S.make_batch(2, 64, 96, start=2)
+    mask = np.maximum(ir, vis[:, :1]).astype(np.float32)
+    with torch.no_grad():
+        out = O.model_losses(t(ir), t(vis), t(ir2), t(vis2), t(mask), t(lab), Hh.model_sd("mit_b0"), "mit_b0")
+    for k in ("loss", "loss_coupled", "fusion_loss_lower", "fusion_loss"):
+        assert abs(float(out[k]) - float(g[k])) <= 2e-5 * max(1.0, abs(float(g[k]))), (k, float(out[k]), float(g[k]))
+
+
 def test_fusion_net_b2_and_input_grads(golden):
     g = golden("gc_fusion_2x64x96")
     ir, vis, _ = S.make_batch(2, 64, 96)
