@@ -286,3 +286,37 @@ def test_training_api_loss_values(golden):
     assert abs(float(Fusionloss_grad2()(d(a), d(a), d(a), d(b))) - float(gh["fusionloss_grad2"])) <= 2e-5
     with pytest.raises(NotImplementedError):
         net._loss(d(ir).requires_grad_(True), d(vis), d(mask), d(lab))
+
+
+def test_dataset_prefetcher_feeds_the_harness(tmp_path):
+    """paif_amd.TaskFusion_dataset2.device_batches (PNG decode -> pinned host batch -> side-stream upload) as the
+    `batches` of the clean-evaluation harness: same confusion matrix as feeding the same images as ready-made tensors."""
+    from PIL import Image
+    from oracle.paif_oracle import FUSION_AT
+    from paif_amd import harness
+    from paif_amd.core.model_fusion_auto import Network_MM_Searched
+    from paif_amd.TaskFusion_dataset2 import Fusion_dataset, device_batches
+
+    dev = torch.device("cuda:0")
+    root = str(tmp_path)
+    for d in ("vi", "ir", "label"):
+        (tmp_path / d).mkdir()
+    items = []
+    for i in range(3):
+        ir, vis = S.make_pair(i, 64, 96)
+        lab = S.make_label(i, 64, 96)
+        v8, i8 = np.uint8(np.round(vis.transpose(1, 2, 0) * 255)), np.uint8(np.round(ir[0] * 255))
+        Image.fromarray(v8).save("%s/vi/%03d.png" % (root, i))
+        Image.fromarray(i8).save("%s/ir/%03d.png" % (root, i))
+        Image.fromarray(np.uint8(lab)).save("%s/label/%03d.png" % (root, i))
+        items.append((t(v8.transpose(2, 0, 1).astype(np.float32) / 255.0)[None], t(i8.astype(np.float32) / 255.0)[None, None],
+                      t(lab.astype(np.int64))[None]))
+    net = Network_MM_Searched(32, FUSION_AT, None, None, "mit_b0", num_classes=9).eval()
+    S.load_formula_weights(net)
+    net = net.to(dev)
+    ds = Fusion_dataset('val', ir_path=root + "/ir", vi_path=root + "/vi", label_path=root + "/label")
+    got = harness.val_segformer_robust2(net, device_batches(ds, dev, batch_size=1))
+    ref = harness.val_segformer_robust2(net, [(v.to(dev), i.to(dev), l.to(dev)) for v, i, l in items])
+    assert np.array_equal(got["conf"], ref["conf"]) and got["conf"].sum() == 3 * 64 * 96 - int((np.stack([x[2].numpy() for x in items]) == 255).sum())
+    names = [b[3] for b in device_batches(ds, dev, batch_size=2, with_names=True)]
+    assert names == [["000.png", "001.png"], ["002.png"]]
