@@ -146,7 +146,7 @@ def main():
             "metric": "fused image-pairs/sec at 480x640 bs=%d per GPU (%s)" % (bpg, {"fusion": "fusion-net forward", "fusion_seg": "fusion + SegFormer forward", "pgd": "PGD-10 adversarial eval"}[args.workload]),
             "value": pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.conv_precision == "f32" else "f32 storage; conv products as split-bf16 (3x bf16 MFMA, f32 accumulate)",
+            "dtype": "f32" if args.conv_precision == "f32" else "f32 (storage and accumulation f32; conv products as split-bf16: 3x bf16 MFMA)",
             "data": "synthetic",
             "config": {"workload": {"fusion": "configs[1]: fusion-net forward (RGB2YCrCb + Network_Fusion_Searched, C=32, shipped genotype)",
                                     "fusion_seg": "configs[2]: fusion + mit_b3 SegFormer end-to-end inference",
