@@ -348,6 +348,10 @@ int paif_spa1_bwd_input(const float* dout, const float* u, const float* o, const
 int paif_ssim_l1_blocks(int B, int H, int W);
 int paif_ssim_l1_fwd(const float* x, const float* y, const float* window1d, float* partial, int B, int H, int W,
                      paif_stream_t stream);
+/* d/dx of  k[0] * sum|y - x| + k[1] * sum(1 - SSIM_map)  (k: 2 device floats = upstream gradient times the loss weights
+ * over B*H*W);  abc_scratch[3*B*H*W] floats (per-pixel partials of the SSIM map).  dx [B,1,H,W]. */
+int paif_ssim_l1_bwd_input(const float* x, const float* y, const float* window1d, const float* k, float* abc_scratch,
+                           float* dx, int B, int H, int W, paif_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -170,7 +170,13 @@ def main():
             fusion_loss_lower=float(ml._fusion_loss_lower(t(ir), t(vis), t(mask))),
             fusion_loss=float(ml._fusion_loss(t(ir), t(vis), t(mask))),
         )
-    save("gl_training_losses_2x64x96", **{k: np.array(v, dtype=np.float64) for k, v in out.items()})
+    # input gradients of _loss (loss gradient -> fused and seg_map -> both networks -> ir, vis)
+    irg, visg = t(ir).requires_grad_(True), t(vis).requires_grad_(True)
+    ml._loss(irg, visg, t(mask), t(lab)).backward()
+    irl, visl = t(ir).requires_grad_(True), t(vis).requires_grad_(True)
+    ml._fusion_loss_lower(irl, visl, t(mask)).backward()
+    save("gl_training_losses_2x64x96", **{k: np.array(v, dtype=np.float64) for k, v in out.items()},
+         loss_d_ir=npy(irg.grad), loss_d_vis=npy(visg.grad), lower_d_ir=npy(irl.grad), lower_d_vis=npy(visl.grad))
 
     # ---- G-d: colour transforms + clamp / batch-global min-max / normalise ------------------
     m0 = build_model(R, "mit_b0")

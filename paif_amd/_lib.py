@@ -58,6 +58,7 @@ SIGNATURES = {
     "paif_gemm_splitk_plan": (c_int, [c_int, c_int, c_int]),
     "paif_ssim_l1_blocks": (c_int, [c_int, c_int, c_int]),
     "paif_ssim_l1_fwd": (c_int, [F, F, F, F, c_int, c_int, c_int, F]),
+    "paif_ssim_l1_bwd_input": (c_int, [F, F, F, F, F, F, c_int, c_int, c_int, F]),
     "paif_gemm_splitk_fwd": (c_int, [F, c_int, F, F, F, c_int, F, c_int, F, c_int, c_int, c_int, c_int, c_int, F, F]),
     "paif_layernorm_fwd": (c_int, [F, F, F, F, c_int, c_int, c_float, F]),
     "paif_im2col_fwd": (c_int, [F, F, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, F]),

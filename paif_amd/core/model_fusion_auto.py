@@ -513,45 +513,43 @@ class _CompositeBase(nn.Module):
     def forward_object(self, ir, vis):
         raise NotImplementedError("forward_object (second min-max on the fused plane, :743-772) is only used by _detection_loss; not built")
 
-    # ---- training-API losses (:1093-1128): forward VALUES.  The parameter-gradient kernels of the training step
-    # (BASELINE config 5) are not built, so these return tensors without a grad_fn and refuse inputs that require grad.
+    # ---- training-API losses (:1093-1128).  Values, and gradients w.r.t. the INPUT images (the models' autograd nodes +
+    # the loss gradient kernels).  Parameter gradients -- the training step itself, BASELINE config 5 -- are not built.
     def _seg_term(self, seg_map, labels):
         """self.seg_loss(F.interpolate(seg_map, size=labels.shape[1:], bilinear), labels.long())"""
         labels = labels.type(torch.long).contiguous()
         sl = self.seg_loss
-        if isinstance(sl, nn.CrossEntropyLoss) and sl.reduction == "mean" and sl.weight is None and sl.label_smoothing == 0.0:
+        plain_ce = isinstance(sl, nn.CrossEntropyLoss) and sl.reduction == "mean" and sl.weight is None and sl.label_smoothing == 0.0
+        if plain_ce and not (torch.is_grad_enabled() and seg_map.requires_grad):
             # fused bilinear upsample + cross entropy (HIP), same arithmetic as attack.Seg_loss
             return ops.upsample_ce_fwd(ops.to_nhwc(seg_map), labels, ignore_index=sl.ignore_index)[0]
-        # any other user criterion: the reference's own two calls (the 9-class upsample is not on the hot path)
+        # with a gradient (or any other user criterion): the reference's own two calls; torch differentiates this small
+        # tail, the model underneath is the HIP autograd node
         import torch.nn.functional as F
         return sl(F.interpolate(seg_map, size=labels.shape[1:], mode='bilinear', align_corners=False), labels)
 
+    @staticmethod
+    def _ycc(vis):
+        return ops.rgb2ycrcb(vis.detach())   # the criterion ignores its image arguments (core/loss.py:494-502)
+
     def _loss(self, ir, vis, mask, labels):
-        ops.require_no_grad(ir, vis, mask)
-        with torch.no_grad():
-            fused_img, seg_map = self(ir, vis)
-            enhance_loss = self._criterion(ir, ops.rgb2ycrcb(vis), fused_img, mask)
-            return enhance_loss * 0.1 + self._seg_term(seg_map, labels) * 4
+        fused_img, seg_map = self(ir, vis)
+        enhance_loss = self._criterion(ir, self._ycc(vis), fused_img, mask)
+        return enhance_loss * 0.1 + self._seg_term(seg_map, labels) * 4
 
     def _loss_coupled(self, ir_, vis_, mask, labels):
-        ops.require_no_grad(ir_[0], vis_[0], ir_[1], vis_[1], mask)
-        with torch.no_grad():
-            fused_img, seg_map = self(ir_[0], vis_[0])
-            denoise_loss = self._seg_term(seg_map, labels)
-            enhance_loss = self._criterion(ir_[1], ops.rgb2ycrcb(vis_[1]), fused_img, mask)
-            return enhance_loss * 0.1 + denoise_loss * 4
+        fused_img, seg_map = self(ir_[0], vis_[0])
+        denoise_loss = self._seg_term(seg_map, labels)
+        enhance_loss = self._criterion(ir_[1], self._ycc(vis_[1]), fused_img, mask)
+        return enhance_loss * 0.1 + denoise_loss * 4
 
     def _fusion_loss_lower(self, ir, vis, mask):
-        ops.require_no_grad(ir, vis, mask)
-        with torch.no_grad():
-            fused_img, _ = self(ir, vis)
-            return self._criterion(ir, ops.rgb2ycrcb(vis), fused_img, mask)
+        fused_img, _ = self(ir, vis)
+        return self._criterion(ir, self._ycc(vis), fused_img, mask)
 
     def _fusion_loss(self, ir, vis, mask):
-        ops.require_no_grad(ir, vis, mask)
-        with torch.no_grad():
-            fused_img = self.forward_fusion(ir, vis)
-            return self._criterion(ir, ops.rgb2ycrcb(vis), fused_img, mask)
+        fused_img = self.forward_fusion(ir, vis)
+        return self._criterion(ir, self._ycc(vis), fused_img, mask)
 
     _fusion_loss_wogan = _fusion_loss
 

@@ -1,6 +1,7 @@
 // Fusion loss of the training API: Fusionloss_grad2 = L1(mask, fused) + 1.1 * (1 - SSIM_11x11(fused, mask))
 // (core/loss.py:490-502; pytorch_ssim/__init__.py:8-43,70-78: Gaussian window sigma 1.5, zero padding 5, mean of the map).
-// Forward values only -- the parameter-gradient kernels of the training step are not built.
+// Forward value and the gradient w.r.t. the generated image; the parameter-gradient kernels of the training step are
+// not built.
 //
 // One workgroup = a 16 x 16 pixel tile of one image; the 26 x 26 halo tiles of both images sit in LDS (zero padded);
 // a thread forms the five windowed sums (x, y, x^2, y^2, xy) of its pixel with the separable weights g[i]*g[j] given by
@@ -69,7 +70,117 @@ __global__ __launch_bounds__(256) void ssim_l1_kernel(const float* __restrict__ 
   }
 }
 
+// ---- gradient w.r.t. x of  L = k_l1 * sum|y - x| + k_ss * sum(1 - S)   (k_* carry the upstream gradient and 1/N) ----
+// pass 1: per pixel p the partials of S_p w.r.t. its windowed means  (mu1 = E[x], e11 = E[x^2], e12 = E[xy]):
+//   A1 = 2 mu1 mu2 + C1, A2 = 2 s12 + C2, B1 = mu1^2 + mu2^2 + C1, B2 = s1 + s2 + C2,  S = A1 A2 / (B1 B2)
+//   dS/dmu1 = 2 mu2 (A2 - A1) / (B1 B2) - 2 mu1 S (1/B1 - 1/B2),   dS/de11 = -S / B2,   dS/de12 = 2 A1 / (B1 B2)
+__global__ __launch_bounds__(256) void ssim_bwd1_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                        const float* __restrict__ g, float* __restrict__ abc, int B, int H, int W,
+                                                        int tilesX, int tilesY) {
+  __shared__ float sx[HT][HT + 1], sy[HT][HT + 1];
+  __shared__ float sg[WS];
+  const int tid = threadIdx.x;
+  int t = blockIdx.x;
+  const int tx = t % tilesX; t /= tilesX;
+  const int ty = t % tilesY;
+  const int b = t / tilesY;
+  const int x0 = tx * T - PADW, y0 = ty * T - PADW;
+  const size_t img = (size_t)b * H * W, plane = (size_t)B * H * W;
+  if (tid < WS) sg[tid] = g[tid];
+  for (int i = tid; i < HT * HT; i += 256) {
+    const int r = i / HT, c = i - r * HT;
+    const int gy = min(max(y0 + r, 0), H - 1), gx = min(max(x0 + c, 0), W - 1);
+    const bool in = y0 + r >= 0 && y0 + r < H && x0 + c >= 0 && x0 + c < W;
+    const float vx = x[img + (size_t)gy * W + gx], vy = y[img + (size_t)gy * W + gx];
+    sx[r][c] = in ? vx : 0.f;
+    sy[r][c] = in ? vy : 0.f;
+  }
+  __syncthreads();
+  const int ly = tid >> 4, lx = tid & 15;
+  const int py = ty * T + ly, px = tx * T + lx;
+  if (py >= H || px >= W) return;
+  float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+  for (int i = 0; i < WS; ++i) {
+    const float gi = sg[i];
+#pragma unroll
+    for (int j = 0; j < WS; ++j) {
+      const float w = gi * sg[j];
+      const float a = sx[ly + i][lx + j], c = sy[ly + i][lx + j];
+      m1 = fmaf(w, a, m1); m2 = fmaf(w, c, m2);
+      e11 = fmaf(w, a * a, e11); e22 = fmaf(w, c * c, e22); e12 = fmaf(w, a * c, e12);
+    }
+  }
+  const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+  const float A1 = 2.f * m1 * m2 + C1, A2 = 2.f * (e12 - m1 * m2) + C2;
+  const float B1 = m1 * m1 + m2 * m2 + C1, B2 = (e11 - m1 * m1) + (e22 - m2 * m2) + C2;
+  const float inv = 1.f / (B1 * B2), S = A1 * A2 * inv;
+  const size_t o = img + (size_t)py * W + px;
+  abc[o] = 2.f * m2 * (A2 - A1) * inv - 2.f * m1 * S * (1.f / B1 - 1.f / B2);
+  abc[plane + o] = -S / B2;
+  abc[2 * plane + o] = 2.f * A1 * inv;
+}
+
+// pass 2: dx[q] = -k_ss * ( sum_p w[p-q] a_p + 2 x_q sum_p w[p-q] b_p + y_q sum_p w[p-q] c_p ) - k_l1 * sign(y_q - x_q)
+__global__ __launch_bounds__(256) void ssim_bwd2_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                        const float* __restrict__ g, const float* __restrict__ abc,
+                                                        const float* __restrict__ k, float* __restrict__ dx, int B, int H, int W,
+                                                        int tilesX, int tilesY) {
+  __shared__ float sa[HT][HT + 1], sb[HT][HT + 1], sc[HT][HT + 1];
+  __shared__ float sg[WS];
+  const int tid = threadIdx.x;
+  int t = blockIdx.x;
+  const int tx = t % tilesX; t /= tilesX;
+  const int ty = t % tilesY;
+  const int b = t / tilesY;
+  const int x0 = tx * T - PADW, y0 = ty * T - PADW;
+  const size_t img = (size_t)b * H * W, plane = (size_t)B * H * W;
+  if (tid < WS) sg[tid] = g[tid];
+  for (int i = tid; i < HT * HT; i += 256) {
+    const int r = i / HT, c = i - r * HT;
+    const int gy = min(max(y0 + r, 0), H - 1), gx = min(max(x0 + c, 0), W - 1);
+    const bool in = y0 + r >= 0 && y0 + r < H && x0 + c >= 0 && x0 + c < W;
+    const size_t o = img + (size_t)gy * W + gx;
+    const float va = abc[o], vb = abc[plane + o], vc = abc[2 * plane + o];
+    sa[r][c] = in ? va : 0.f;
+    sb[r][c] = in ? vb : 0.f;
+    sc[r][c] = in ? vc : 0.f;
+  }
+  __syncthreads();
+  const int ly = tid >> 4, lx = tid & 15;
+  const int py = ty * T + ly, px = tx * T + lx;
+  if (py >= H || px >= W) return;
+  float wa = 0.f, wb = 0.f, wc = 0.f;
+  for (int i = 0; i < WS; ++i) {
+    const float gi = sg[i];
+#pragma unroll
+    for (int j = 0; j < WS; ++j) {
+      const float w = gi * sg[j];   // symmetric window: correlation = convolution
+      wa = fmaf(w, sa[ly + i][lx + j], wa);
+      wb = fmaf(w, sb[ly + i][lx + j], wb);
+      wc = fmaf(w, sc[ly + i][lx + j], wc);
+    }
+  }
+  const size_t o = img + (size_t)py * W + px;
+  const float xv = x[o], yv = y[o];
+  const float d = yv - xv;
+  const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+  dx[o] = -k[1] * (wa + 2.f * xv * wb + yv * wc) - k[0] * sgn;
+}
+
 }  // namespace
+
+extern "C" int paif_ssim_l1_bwd_input(const float* x, const float* y, const float* window1d, const float* k, float* abc_scratch,
+                                      float* dx, int B, int H, int W, paif_stream_t stream) {
+  PAIF_REQUIRE(x && y && window1d && k && abc_scratch && dx && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "ssim_l1_bwd: bad arguments");
+  const int tilesX = (W + T - 1) / T, tilesY = (H + T - 1) / T;
+  hipStream_t st = paif::as_stream(stream);
+  hipLaunchKernelGGL(ssim_bwd1_kernel, dim3(B * tilesX * tilesY), dim3(256), 0, st, x, y, window1d, abc_scratch, B, H, W, tilesX, tilesY);
+  PAIF_LAUNCH_CHECK("ssim_bwd1");
+  hipLaunchKernelGGL(ssim_bwd2_kernel, dim3(B * tilesX * tilesY), dim3(256), 0, st, x, y, window1d, abc_scratch, k, dx, B, H, W, tilesX,
+                     tilesY);
+  PAIF_LAUNCH_CHECK("ssim_bwd2");
+  return 0;
+}
 
 extern "C" int paif_ssim_l1_blocks(int B, int H, int W) { return B * ((H + T - 1) / T) * ((W + T - 1) / T); }
 

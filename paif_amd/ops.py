@@ -559,17 +559,34 @@ def upsample_ce_bwd(logits, label, gscale, cp=32, ignore_index=255):
 _SSIM_WINDOW = {}
 
 
+def _ssim_window(device):
+    import math
+    g = _SSIM_WINDOW.get(device)
+    if g is None:
+        g1 = torch.Tensor([math.exp(-(i - 11 // 2) ** 2 / float(2 * 1.5 ** 2)) for i in range(11)])
+        g = _SSIM_WINDOW[device] = (g1 / g1.sum()).to(device)
+    return g
+
+
+def ssim_l1_bwd(x, y, k_l1, k_ss):
+    """d/dx of k_l1 * sum|y - x| + k_ss * sum(1 - SSIM map): x, y [B,1,H,W]; k_* 0-d device tensors -> dx [B,1,H,W]."""
+    x, y = x.contiguous(), y.contiguous()
+    B, _, H, W = x.shape
+    k = torch.stack([k_l1.reshape(()), k_ss.reshape(())]).to(torch.float32).contiguous()
+    abc = torch.empty((3, B, H, W), device=x.device, dtype=torch.float32)
+    dx = torch.empty_like(x)
+    _lib.check(lib().paif_ssim_l1_bwd_input(_p(x), _p(y), _p(_ssim_window(x.device)), _p(k), _p(abc), _p(dx), B, H, W, _stream()),
+               "ssim_l1_bwd")
+    return dx
+
+
 def ssim_l1(x, y):
     """x, y: [B,1,H,W] -> (mean SSIM_11x11(x, y), mean |y - x|) as 0-d device tensors (forward values only).
     pytorch_ssim/__init__.py:8-43: Gaussian window sigma 1.5 (built in fp32 like the reference), zero padding, mean."""
-    import math
     assert x.shape == y.shape and x.shape[1] == 1
     x, y = x.contiguous(), y.contiguous()
     B, _, H, W = x.shape
-    g = _SSIM_WINDOW.get(x.device)
-    if g is None:
-        g1 = torch.Tensor([math.exp(-(i - 11 // 2) ** 2 / float(2 * 1.5 ** 2)) for i in range(11)])
-        g = _SSIM_WINDOW[x.device] = (g1 / g1.sum()).to(x.device)
+    g = _ssim_window(x.device)
     L = lib()
     partial = torch.empty((L.paif_ssim_l1_blocks(B, H, W), 2), device=x.device, dtype=torch.float32)
     _lib.check(L.paif_ssim_l1_fwd(_p(x), _p(y), _p(g), _p(partial), B, H, W, _stream()), "ssim_l1")

@@ -136,6 +136,22 @@ def test_training_api_loss_values(golden):
         assert abs(float(out[k]) - float(g[k])) <= 2e-5 * max(1.0, abs(float(g[k]))), (k, float(out[k]), float(g[k]))
 
 
+def test_training_api_loss_input_gradients(golden):
+    """d _loss / d (ir, vis) and d _fusion_loss_lower / d (ir, vis): the oracle's autograd against the reference's.
+    Tolerance: the fused path runs through A = cov / (var + eps) (fp32 noise floor 6e-3 relative on such gradients,
+    DESIGN.md section 2)."""
+    g = golden("gl_training_losses_2x64x96")
+    ir, vis, lab = S.make_batch(2, 64, 96)
+    mask = np.maximum(ir, vis[:, :1]).astype(np.float32)
+    for key, pre in (("loss", "loss"), ("fusion_loss_lower", "lower")):
+        irt, vist = t(ir).requires_grad_(True), t(vis).requires_grad_(True)
+        out = O.model_losses(irt, vist, irt, vist, t(mask), t(lab), Hh.model_sd("mit_b0"), "mit_b0")
+        out[key].backward()
+        for name, got in (("d_ir", irt.grad), ("d_vis", vist.grad)):
+            ref = g["%s_%s" % (pre, name)]
+            assert maxabs(got, ref) <= 1e-2 * float(np.abs(ref).max()), (key, name, maxabs(got, ref), float(np.abs(ref).max()))
+
+
 def test_fusion_net_b2_and_input_grads(golden):
     g = golden("gc_fusion_2x64x96")
     ir, vis, _ = S.make_batch(2, 64, 96)
