@@ -342,6 +342,16 @@ int paif_spa1_fwd(const float* o, const float* r, const float* w, int k, const f
 int paif_spa1_bwd_input(const float* dout, const float* u, const float* o, const float* s, const float* w, int k,
                         const float* prelu, float* dpre, float* d_o, float* d_r, int B, int H, int W, paif_stream_t stream);
 
+/* ---- training step, first kernel: dense-conv weight gradient (exact fp32 MFMA) --------------------------------------------
+ * dW[cout=32][nsrc*32][kh][kh] (PyTorch layout) of the forward conv of paif_conv2d_fwd over the virtual concat of `src`:
+ *   dAcc = dout * alpha * act'(z) * scale[cout]   (act 0 none | 1 PReLU(slope) | 2 ReLU; z = the saved pre-activation)
+ *   dW[co][s*32+ci][ky][kx] = sum_px dAcc[px][co] * src_s[px + tap][ci]   (zero padding, dilation 1 or 2)
+ * workspace: paif_conv2d_wgrad_workspace_floats(nsrc, kh, B, H) floats (per-workgroup slabs, summed in block order). */
+size_t paif_conv2d_wgrad_workspace_floats(int nsrc, int kh, int B, int H);
+int paif_conv2d_wgrad(const float* const* src, int nsrc, const float* dout, const float* z, const float* scale,
+                      const float* prelu, int act, float alpha, int kh, int dil, float* workspace, float* dw, int B, int H,
+                      int W, paif_stream_t stream);
+
 /* ---- training-API losses (forward values; core/loss.py:490-502, pytorch_ssim/__init__.py:8-43) --------------------------
  * x, y: [B,1,H,W] planes.  window1d: the 11 fp32 Gaussian weights (sigma 1.5, normalised) as the reference builds them.
  * partial[2*blocks]: per-workgroup (sum of the SSIM map, sum of |y - x|); the caller adds them and divides by B*H*W. */

@@ -56,6 +56,8 @@ SIGNATURES = {
     "paif_add_fwd": (c_int, [F, F, F, c_size_t, F]),
     "paif_gemm_fwd": (c_int, [F, c_int, F, F, F, c_int, F, c_int, F, c_int, c_int, c_int, c_int, c_int, F]),
     "paif_gemm_splitk_plan": (c_int, [c_int, c_int, c_int]),
+    "paif_conv2d_wgrad_workspace_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "paif_conv2d_wgrad": (c_int, [POINTER(c_void_p), c_int, F, F, F, F, c_int, c_float, c_int, c_int, F, F, c_int, c_int, c_int, F]),
     "paif_ssim_l1_blocks": (c_int, [c_int, c_int, c_int]),
     "paif_ssim_l1_fwd": (c_int, [F, F, F, F, c_int, c_int, c_int, F]),
     "paif_ssim_l1_bwd_input": (c_int, [F, F, F, F, F, F, c_int, c_int, c_int, F]),

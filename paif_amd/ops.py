@@ -556,6 +556,22 @@ def upsample_ce_bwd(logits, label, gscale, cp=32, ignore_index=255):
     return resize_bilinear_adjoint(dfull, 0, cp, IH, IW)
 
 
+def conv2d_wgrad(srcs, dout, kh, dil=1, z=None, scale=None, act=ACT_NONE, prelu=None, alpha=1.0):
+    """Weight gradient of the dense conv over the virtual concat of `srcs` (NHWC [B,H,W,32] each):
+    returns dW [32, 32*len(srcs), kh, kh].  dout NHWC [B,H,W,32]; z = saved pre-activation when act != none."""
+    B, H, W, C = srcs[0].shape
+    assert C == 32 and tuple(dout.shape) == (B, H, W, 32) and 1 <= len(srcs) <= 3
+    L = lib()
+    ptrs = (ctypes.c_void_p * len(srcs))(*[s.data_ptr() for s in srcs])
+    for s_ in srcs:
+        _p(s_)
+    ws = torch.empty(L.paif_conv2d_wgrad_workspace_floats(len(srcs), kh, B, H), device=dout.device, dtype=torch.float32)
+    dw = torch.empty((32, 32 * len(srcs), kh, kh), device=dout.device, dtype=torch.float32)
+    _lib.check(L.paif_conv2d_wgrad(ptrs, len(srcs), _p(dout), _p(z), _p(scale), _p(prelu), act, alpha, kh, dil, _p(ws), _p(dw), B, H, W,
+                                   _stream()), "conv2d_wgrad")
+    return dw
+
+
 _SSIM_WINDOW = {}
 
 

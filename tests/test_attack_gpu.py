@@ -334,3 +334,25 @@ def test_dataset_prefetcher_feeds_the_harness(tmp_path):
     assert np.array_equal(got["conf"], ref["conf"]) and got["conf"].sum() == 3 * 64 * 96 - int((np.stack([x[2].numpy() for x in items]) == 255).sum())
     names = [b[3] for b in device_batches(ds, dev, batch_size=2, with_names=True)]
     assert names == [["000.png", "001.png"], ["002.png"]]
+
+
+@pytest.mark.parametrize("kh,dil,nsrc,act", [(3, 1, 1, 0), (3, 1, 3, 1), (3, 2, 2, 2), (1, 1, 3, 0), (5, 1, 1, 1), (7, 1, 1, 0), (5, 2, 1, 2)])
+def test_dense_conv_weight_gradient(kh, dil, nsrc, act):
+    """First kernel of the training step (plan item 2): dW of y = act(conv(cat(srcs), W) * scale + shift) * alpha
+    against torch's autograd on the CPU (odd width, rows not a multiple of the 8-row workgroup)."""
+    B, H, W = 2, 21, 27
+    g = torch.Generator().manual_seed(kh * 100 + dil * 10 + nsrc + act)
+    xs = [torch.randn(B, 32, H, W, generator=g) for _ in range(nsrc)]
+    w = (torch.randn(32, 32 * nsrc, kh, kh, generator=g) * 0.05).requires_grad_(True)
+    scale, shift = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.1
+    slope = torch.tensor([0.2])
+    dy = torch.randn(B, 32, H, W, generator=g)
+    z = torch.nn.functional.conv2d(torch.cat(xs, 1), w, padding=dil * (kh - 1) // 2, dilation=dil) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    y = (torch.where(z >= 0, z, z * slope) if act == 1 else (z.clamp_min(0) if act == 2 else z)) * 0.5
+    (y * dy).sum().backward()
+    dev = _dev()
+    dw = ops.conv2d_wgrad([ops.to_nhwc(x.to(dev)) for x in xs], ops.to_nhwc(dy.to(dev)), kh, dil,
+                          z=ops.to_nhwc(z.detach().to(dev)) if act else None, scale=scale.to(dev), act=act,
+                          prelu=slope.to(dev) if act == 1 else None, alpha=0.5)
+    ref = w.grad
+    assert maxabs(dw.cpu(), ref) <= 2e-5 * float(ref.abs().max()), (maxabs(dw.cpu(), ref), float(ref.abs().max()))
