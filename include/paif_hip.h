@@ -352,6 +352,13 @@ int paif_conv2d_wgrad(const float* const* src, int nsrc, const float* dout, cons
                       const float* prelu, int act, float alpha, int kh, int dil, float* workspace, float* dw, int B, int H,
                       int W, paif_stream_t stream);
 
+/* Linear-layer weight / bias gradient (exact fp32 MFMA): dw[N][K] = dy^T x, db[N] = column sums of dy (db may be NULL).
+ * dy [M, >=N] row stride lddy, x [M, >=K] row stride ldx.  splits = paif_gemm_wgrad_splits(M,N,K) token slices;
+ * workspace: splits * (N*K + N) floats; slices are summed in order by a second pass (deterministic). */
+int paif_gemm_wgrad_splits(int M, int N, int K);
+int paif_gemm_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, float* db, int M, int N, int K, int splits,
+                    float* workspace, paif_stream_t stream);
+
 /* ---- training-API losses (forward values; core/loss.py:490-502, pytorch_ssim/__init__.py:8-43) --------------------------
  * x, y: [B,1,H,W] planes.  window1d: the 11 fp32 Gaussian weights (sigma 1.5, normalised) as the reference builds them.
  * partial[2*blocks]: per-workgroup (sum of the SSIM map, sum of |y - x|); the caller adds them and divides by B*H*W. */

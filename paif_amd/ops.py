@@ -572,6 +572,20 @@ def conv2d_wgrad(srcs, dout, kh, dil=1, z=None, scale=None, act=ACT_NONE, prelu=
     return dw
 
 
+def gemm_wgrad(dy, x, want_bias=True):
+    """Linear-layer gradients: dy [..., N], x [..., K] (same leading shape) -> (dW [N, K], db [N] or None)."""
+    N, K = dy.shape[-1], x.shape[-1]
+    M = dy.numel() // N
+    assert x.numel() // K == M
+    L = lib()
+    splits = L.paif_gemm_wgrad_splits(M, N, K)
+    ws = torch.empty(splits * (N * K + N), device=dy.device, dtype=torch.float32)
+    dw = torch.empty((N, K), device=dy.device, dtype=torch.float32)
+    db = torch.empty(N, device=dy.device, dtype=torch.float32) if want_bias else None
+    _lib.check(L.paif_gemm_wgrad(_p(dy), N, _p(x), K, _p(dw), _p(db), M, N, K, splits, _p(ws), _stream()), "gemm_wgrad")
+    return dw, db
+
+
 _SSIM_WINDOW = {}
 
 

@@ -137,3 +137,19 @@ def test_graph_capture_replay_is_bit_identical():
     assert torch.equal(f_e, f_g) and torch.equal(s_e, s_g)
     with pytest.raises(ValueError):
         g(ir2[:, :, :32], vis2)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 512, 2048), (1201, 320, 64), (4803, 64, 256), (77, 9, 256), (19200, 64, 64)])
+def test_linear_weight_and_bias_gradient(M, N, K):
+    """Training step, plan item 3: dW = dY^T X and db = column sums of dY (odd token counts, N / K that are not multiples
+    of the 32 x 128 tile) against fp64 torch on the CPU."""
+    from paif_amd import ops
+
+    g = torch.Generator().manual_seed(M + N + K)
+    dy, x = torch.randn(M, N, generator=g), torch.randn(M, K, generator=g)
+    dw, db = ops.gemm_wgrad(dy.to("cuda:0"), x.to("cuda:0"))
+    ref_w = (dy.double().t() @ x.double()).float()
+    ref_b = dy.double().sum(0).float()
+    assert tuple(dw.shape) == (N, K) and tuple(db.shape) == (N,)
+    assert maxabs(dw.cpu(), ref_w) <= 3e-6 * float(ref_w.abs().max()) * max(1.0, (M / 1000.0) ** 0.5)
+    assert maxabs(db.cpu(), ref_b) <= 3e-6 * float(ref_b.abs().max() + 1.0) * max(1.0, (M / 1000.0) ** 0.5)
