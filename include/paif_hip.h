@@ -359,6 +359,12 @@ int paif_gemm_wgrad_splits(int M, int N, int K);
 int paif_gemm_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, float* db, int M, int N, int K, int splits,
                     float* workspace, paif_stream_t stream);
 
+/* LayerNorm affine gradients: dgamma[c] = sum_rows dy * xhat, dbeta[c] = sum_rows dy (x, dy [M, C] dense).
+ * workspace: paif_layernorm_wgrad_blocks(M) * 2 * C floats (per-workgroup partials, summed in block order). */
+int paif_layernorm_wgrad_blocks(int M);
+int paif_layernorm_wgrad(const float* x, const float* dy, float* dgamma, float* dbeta, float* workspace, int M, int C,
+                         float eps, paif_stream_t stream);
+
 /* ---- training-API losses (forward values; core/loss.py:490-502, pytorch_ssim/__init__.py:8-43) --------------------------
  * x, y: [B,1,H,W] planes.  window1d: the 11 fp32 Gaussian weights (sigma 1.5, normalised) as the reference builds them.
  * partial[2*blocks]: per-workgroup (sum of the SSIM map, sum of |y - x|); the caller adds them and divides by B*H*W. */

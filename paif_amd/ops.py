@@ -586,6 +586,19 @@ def gemm_wgrad(dy, x, want_bias=True):
     return dw, db
 
 
+def layernorm_wgrad(x, dy, eps):
+    """LayerNorm affine gradients: x, dy [..., C] -> (dgamma [C], dbeta [C])."""
+    C = x.shape[-1]
+    M = x.numel() // C
+    assert dy.shape == x.shape
+    L = lib()
+    ws = torch.empty(L.paif_layernorm_wgrad_blocks(M) * 2 * C, device=x.device, dtype=torch.float32)
+    dg = torch.empty(C, device=x.device, dtype=torch.float32)
+    db = torch.empty(C, device=x.device, dtype=torch.float32)
+    _lib.check(L.paif_layernorm_wgrad(_p(x), _p(dy), _p(dg), _p(db), _p(ws), M, C, eps, _stream()), "layernorm_wgrad")
+    return dg, db
+
+
 _SSIM_WINDOW = {}
 
 

@@ -153,3 +153,18 @@ def test_linear_weight_and_bias_gradient(M, N, K):
     assert tuple(dw.shape) == (N, K) and tuple(db.shape) == (N,)
     assert maxabs(dw.cpu(), ref_w) <= 3e-6 * float(ref_w.abs().max()) * max(1.0, (M / 1000.0) ** 0.5)
     assert maxabs(db.cpu(), ref_b) <= 3e-6 * float(ref_b.abs().max() + 1.0) * max(1.0, (M / 1000.0) ** 0.5)
+
+
+@pytest.mark.parametrize("M,C", [(300, 512), (1201, 320), (4803, 64), (19200, 128), (5, 32)])
+def test_layernorm_affine_gradient(M, C):
+    """Training step, plan item 3: d gamma / d beta of nn.LayerNorm(C, eps) against torch's autograd (CPU)."""
+    from paif_amd import ops
+
+    g = torch.Generator().manual_seed(M + C)
+    x = torch.randn(M, C, generator=g) * 1.5 + 0.3
+    dy = torch.randn(M, C, generator=g)
+    ln = torch.nn.LayerNorm(C, eps=1e-6)
+    (ln(x) * dy).sum().backward()
+    dg, db = ops.layernorm_wgrad(x.to("cuda:0"), dy.to("cuda:0"), 1e-6)
+    for got, ref in ((dg, ln.weight.grad), (db, ln.bias.grad)):
+        assert maxabs(got.cpu(), ref) <= 2e-5 * max(1.0, float(ref.abs().max())), (maxabs(got.cpu(), ref), float(ref.abs().max()))
