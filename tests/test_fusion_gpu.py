@@ -133,6 +133,41 @@ def test_dense_conv_persistent_kernel_ragged_edges(kh, dil, nsrc, nres, act):
     assert maxabs(outs["bf16x3"], outs["f32"]) <= 1e-4 * sc
 
 
+def test_dense_conv_seeded_shape_sweep():
+    """40 seeded random configurations (shape, kernel size, dilation, sources, residuals, activation, affine on/off) of the
+    dense conv, split-bf16 kernels (persistent and tile-per-workgroup, chosen by the library) against the exact-fp32 MFMA
+    kernel: every dispatch path with ragged edges, odd sizes and tiny images."""
+    import random
+    from paif_amd import ops
+
+    rnd = random.Random(20261003)
+    dev = _dev()
+    for it in range(40):
+        kh, dil = rnd.choice([(1, 1), (3, 1), (3, 1), (3, 2), (5, 1), (7, 1)])
+        nsrc, nres, act = rnd.randint(1, 3), rnd.randint(0, 3), rnd.randint(0, 2)
+        if it % 4 == 0:   # large enough for the persistent kernel (>= 1024 tiles of 8 x 32)
+            B, H, W = rnd.choice([(1, 8 * rnd.randint(40, 50) + rnd.randint(0, 7), 32 * rnd.randint(28, 34) + rnd.randint(0, 31)),
+                                  (3, 131 + rnd.randint(0, 20), 353 + rnd.randint(0, 40))])
+        else:
+            B, H, W = rnd.randint(1, 3), rnd.randint(1, 70), rnd.randint(1, 90)
+        g = torch.Generator().manual_seed(1000 + it)
+        xs = [ops.to_nhwc(torch.randn(B, 32, H, W, generator=g).to(dev)) for _ in range(nsrc)]
+        rs = [ops.to_nhwc(torch.randn(B, 32, H, W, generator=g).to(dev)) for _ in range(nres)]
+        w = (torch.randn(32, 32 * nsrc, kh, kh, generator=g) * 0.05).to(dev)
+        affine = rnd.random() < 0.7
+        scale = (torch.rand(32, generator=g) + 0.5).to(dev) if affine else None
+        shift = (torch.randn(32, generator=g) * 0.1).to(dev) if affine else None
+        slope = torch.tensor([0.25], device=dev)
+        outs = []
+        for prec in ("f32", "bf16x3"):
+            wpk = ops.pack_conv_weight(w, nsrc, 32, kh, precision=prec)
+            outs.append(ops.conv2d(xs, wpk, kh, dil=dil, scale=scale, shift=shift, act=act, prelu=slope if act == 1 else None,
+                                   alpha=0.75, res=tuple(rs)))
+        sc = float(outs[0].abs().max())
+        assert torch.isfinite(outs[1]).all()
+        assert maxabs(outs[1].cpu(), outs[0].cpu()) <= 1e-4 * max(sc, 1.0), (it, kh, dil, nsrc, nres, act, B, H, W)
+
+
 def _fusion_net(prefix=""):
     """prefix='enhance_net.' gives the weights the fusion net has INSIDE the composite model's goldens
     (the formula is keyed on the full state_dict key)."""
