@@ -60,7 +60,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)  # RCCL; used for the barrier + max-over-ranks only
 
-    from oracle.paif_oracle import FUSION_AT  # genotype constant only (test infrastructure is not on the timed path)
+    from paif_amd.genotypes import FUSION_AT
     from paif_amd import ops, synthetic as S
     from paif_amd.core.model_fusion_auto import Network_Fusion_Searched, Network_MM_Searched
 
@@ -183,10 +183,11 @@ def cpu_baseline(ir_np, vis_np):
     from oracle import paif_oracle as O
     from paif_amd import synthetic as S
     from paif_amd.core.model_fusion_auto import Network_Fusion_Searched
+    from paif_amd.genotypes import FUSION_AT
 
     cores = host_cores()
     torch.set_num_threads(cores)
-    net = Network_Fusion_Searched(32, None, O.FUSION_AT)
+    net = Network_Fusion_Searched(32, None, FUSION_AT)
     S.load_formula_weights(net)
     sd = {k: v.clone() for k, v in net.state_dict().items()}
     ir, vis = torch.from_numpy(ir_np[:1]), torch.from_numpy(vis_np[:1])

@@ -39,6 +39,10 @@ int paif_device_cus(void);
 /* RGB2YCrCb, core/model_fusion_auto.py:69-92.  rgb, ycc: NCHW [B,3,H,W]. */
 int paif_rgb2ycrcb_fwd(const float* rgb, float* ycc, int B, int H, int W, paif_stream_t stream);
 
+/* YCrCb2RGB stand-alone, core/model_fusion_auto.py:94-111: (x + [0,-.5,-.5]) @ [[1,1,1],[1.403,-.714,0],[0,-.344,1.773]],
+ * no clamp.  ycc, rgb: NCHW [B,3,H,W]. */
+int paif_ycrcb2rgb_fwd(const float* ycc, float* rgb, int B, int H, int W, paif_stream_t stream);
+
 /* cat(fused, Cr, Cb) -> YCrCb2RGB -> clamp[0,1]  (core/model_fusion_auto.py:715-720) with per-block
  * min/max partials for the batch-global min-max that follows (:721-723).
  *   fused NCHW [B,1,H,W]; ycc NCHW [B,3,H,W] (Cr,Cb read); rgb_out NCHW [B,3,H,W];
@@ -46,6 +50,11 @@ int paif_rgb2ycrcb_fwd(const float* rgb, float* ycc, int B, int H, int W, paif_s
 int paif_minmax_blocks(int B, int H, int W);
 int paif_recompose_clamp_fwd(const float* fused, const float* ycc, float* rgb_out, float* minmax_partial,
                              int B, int H, int W, paif_stream_t stream);
+/* Fused-image writer post-processing, test_original.py:186-197, on the output of paif_recompose_clamp_fwd (rgb + partials):
+ * q = uint8(255*rgb) (truncation), batch-global min/max of q, uint8(255 * (q - mn)/(mx - mn)) with the ratio in float64.
+ * out: NHWC uint8 [B,H,W,3] (device). */
+int paif_fused_uint8_fwd(const float* rgb, const float* minmax_partial, int npartial, unsigned char* out, int B, int H, int W,
+                         paif_stream_t stream);
 /* (x - min)/(max - min) * 255, then per channel (x - mean[c]) / std[c]   (:721-727), in place allowed.
  * Reduces the partials itself (every block re-reduces them in a fixed order: deterministic).
  * minmax_out (optional, 2 floats): the global min and max. */
@@ -348,33 +357,117 @@ int paif_spa1_bwd_input(const float* dout, const float* u, const float* o, const
  *   dW[co][s*32+ci][ky][kx] = sum_px dAcc[px][co] * src_s[px + tap][ci]   (zero padding, dilation 1 or 2)
  * workspace: paif_conv2d_wgrad_workspace_floats(nsrc, kh, B, H) floats (per-workgroup slabs, summed in block order). */
 size_t paif_conv2d_wgrad_workspace_floats(int nsrc, int kh, int B, int H);
+/* dout always has 32 channels; only the first `cout` rows of dW are produced (stem_out.0 is 32 -> 16: its dout is zero padded).
+ * accumulate != 0: dW += (gradients accumulate like loss.backward()); 0: dW = . */
 int paif_conv2d_wgrad(const float* const* src, int nsrc, const float* dout, const float* z, const float* scale,
-                      const float* prelu, int act, float alpha, int kh, int dil, float* workspace, float* dw, int B, int H,
-                      int W, paif_stream_t stream);
+                      const float* prelu, int act, float alpha, int kh, int dil, float* workspace, float* dw, int cout,
+                      int accumulate, int B, int H, int W, paif_stream_t stream);
 
 /* Linear-layer weight / bias gradient (exact fp32 MFMA): dw[N][K] = dy^T x, db[N] = column sums of dy (db may be NULL).
  * dy [M, >=N] row stride lddy, x [M, >=K] row stride ldx.  splits = paif_gemm_wgrad_splits(M,N,K) token slices;
  * workspace: splits * (N*K + N) floats; slices are summed in order by a second pass (deterministic). */
 int paif_gemm_wgrad_splits(int M, int N, int K);
 int paif_gemm_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, float* db, int M, int N, int K, int splits,
-                    float* workspace, paif_stream_t stream);
+                    float* workspace, int accumulate, paif_stream_t stream);
 
 /* LayerNorm affine gradients: dgamma[c] = sum_rows dy * xhat, dbeta[c] = sum_rows dy (x, dy [M, C] dense).
  * workspace: paif_layernorm_wgrad_blocks(M) * 2 * C floats (per-workgroup partials, summed in block order). */
 int paif_layernorm_wgrad_blocks(int M);
 int paif_layernorm_wgrad(const float* x, const float* dy, float* dgamma, float* dbeta, float* workspace, int M, int C,
-                         float eps, paif_stream_t stream);
+                         float eps, int accumulate, paif_stream_t stream);
 
 /* ---- training-API losses (forward values; core/loss.py:490-502, pytorch_ssim/__init__.py:8-43) --------------------------
  * x, y: [B,1,H,W] planes.  window1d: the 11 fp32 Gaussian weights (sigma 1.5, normalised) as the reference builds them.
- * partial[2*blocks]: per-workgroup (sum of the SSIM map, sum of |y - x|); the caller adds them and divides by B*H*W. */
+ * partial[2*blocks]: per-workgroup scratch; means[2] = (mean of the SSIM map, mean of |y - x|), reduced on the device in
+ * block order (double). */
 int paif_ssim_l1_blocks(int B, int H, int W);
-int paif_ssim_l1_fwd(const float* x, const float* y, const float* window1d, float* partial, int B, int H, int W,
+int paif_ssim_l1_fwd(const float* x, const float* y, const float* window1d, float* partial, float* means, int B, int H, int W,
                      paif_stream_t stream);
 /* d/dx of  k[0] * sum|y - x| + k[1] * sum(1 - SSIM_map)  (k: 2 device floats = upstream gradient times the loss weights
  * over B*H*W);  abc_scratch[3*B*H*W] floats (per-pixel partials of the SSIM map).  dx [B,1,H,W]. */
 int paif_ssim_l1_bwd_input(const float* x, const float* y, const float* window1d, const float* k, float* abc_scratch,
                            float* dx, int B, int H, int W, paif_stream_t stream);
+
+/* ---- input pipeline, device side (TaskFusion_dataset2.py:57-70,85-98; csrc/io_kernels.hip) ----------------------------------
+ * src uint8 [B][HW][C] (decoded image bytes, HWC) -> dst float32 [B][C][HW] = src / 255 (fp32 division, as numpy does). */
+int paif_u8_to_planes_fwd(const unsigned char* src, float* dst, int B, int HW, int C, paif_stream_t stream);
+/* label bytes -> int64 */
+int paif_u8_to_i64_fwd(const unsigned char* src, long long* dst, size_t n, paif_stream_t stream);
+
+/* =============================================================================================
+ * Training step (BASELINE configs[4]; csrc/train_kernels.hip).  Every gradient entry point ACCUMULATES
+ * into its destination (like loss.backward() into .grad); reductions are two-pass in a fixed order (deterministic).
+ * "rows" = NHWC pixels or tokens, M of them, C channels (C % 4 == 0; C/4 a power of two < 32 or a multiple of 32).
+ * ============================================================================================= */
+
+/* NHWC [B,HW,ldx] channels [0,C) -> NCHW [B,C,HW] (gradient of the 9-class logits leaving the fused CE kernel). */
+int paif_nhwc_slice_to_nchw_fwd(const float* x, float* y, int B, int HW, int C, int ldx, paif_stream_t stream);
+/* y[M,Cd] = x[M,Cs] zero padded on the channel axis (the 16-channel gradient of stem_out.0 entering the dense-conv wgrad). */
+int paif_pad_channels_fwd(const float* x, float* y, size_t M, int Cs, int Cd, paif_stream_t stream);
+/* Cell_Decom.decomposition's return value (core/model_fusion_auto.py:522-535): x [M,32], lf [2][M,32] (both eps) ->
+ * lfcat = cat(LF0, LF1) [M,64], hfcat = cat(x-LF0, x-LF1) [M,64]. */
+int paif_decomp_cat_fwd(const float* x, const float* lf, float* lfcat, float* hfcat, size_t M, paif_stream_t stream);
+/* floats of per-workgroup partials a row reduction with `nacc` float4-accumulator planes needs (0 = unsupported C). */
+size_t paif_row_reduce_workspace_floats(int M, int C, int nacc);
+
+/* Train-mode nn.BatchNorm2d statistics (operations_m.py:458-459,503; mmcv ConvModule core/segformer_head.py:50-55) over x [M,C]:
+ * mean, invstd = 1/sqrt(biased var + eps), scale = gamma*invstd, shift = beta - mean*scale (gamma/beta NULL -> 1/0);
+ * running_mean/var (optional) updated in place with `momentum` (unbiased variance), as torch does.
+ * workspace: 2 * paif_row_reduce_workspace_floats(M, C, 2) floats (double partials). */
+int paif_bn_stats_fwd(const float* x, int M, int C, const float* gamma, const float* beta, float eps, float momentum,
+                      float* running_mean, float* running_var, float* mean, float* invstd, float* scale, float* shift,
+                      float* workspace, paif_stream_t stream);
+/* out = act(x*scale[c] + shift[c]) + res0 + res1 (act 0 none | 1 PReLU | 2 ReLU; z_out: the pre-activation, optional). */
+int paif_affine_act_res_fwd(const float* x, const float* scale, const float* shift, int act, const float* prelu, const float* res0,
+                            const float* res1, float* out, float* z_out, size_t M, int C, paif_stream_t stream);
+/* Backward of y = act(BN_train(x)):  z = x*scale+shift, dz = g*act'(z), xhat = (x-mean)*invstd,
+ *   dbeta += sum dz, dgamma += sum dz*xhat, dslope += sum g*z over z<0 (PReLU), dx = scale*(dz - mean(dz) - xhat*mean(dz*xhat)).
+ * sums: 2*C floats scratch; workspace: paif_row_reduce_workspace_floats(M, C, 3). dgamma/dbeta/dslope may be NULL. */
+int paif_bn_act_bwd(const float* g, const float* x, const float* scale, const float* shift, const float* mean, const float* invstd,
+                    int act, const float* prelu, float* dx, float* dgamma, float* dbeta, float* dslope, float* sums, float* workspace,
+                    int M, int C, paif_stream_t stream);
+/* PReLU on an element stream: dx = t*P'(r) + add (dx, add optional), dslope[0] += factor * sum t*r over r<0
+ * (nn.PReLU weight gradient, operations_m.py:441,460,392; workspace: 2048 floats). */
+int paif_prelu_bwd(const float* t, const float* r, const float* add, const float* prelu, float factor, float* dx, float* dslope,
+                   float* workspace, size_t n, paif_stream_t stream);
+/* tail (stem_out.2 + tanh, core/model_fusion_auto.py:618-619,634): dz = dfused*(1-fused^2)*P'(z); dslope += sum dfused*(1-fused^2)*z, z<0. */
+int paif_tail_dz(const float* dfused, const float* fused, const float* z, const float* prelu, float* dz, float* dslope, float* workspace,
+                 size_t n, paif_stream_t stream);
+/* out[c] += sum_rows x[row*ld + c], c < C (conv bias gradient, Cell_Decom.conv1x1_*.bias :501-502). workspace: row_reduce(M,C,1). */
+int paif_colsum(const float* x, int ld, float* out, float* workspace, int M, int C, paif_stream_t stream);
+/* Depthwise conv weight/bias gradient: dw[C][k][k] += sum dy[px][c]*in(x)[px+tap][c], db[c] += sum dy (db optional);
+ * in = ReLU when in_relu (DilConv, operations_m.py:496-498); MiT Mlp.dwconv (core/mix_transformer.py:376-387).
+ * k in {3,5}, dil in {1,2}; workspace: row_reduce(B*H*W, C, k*k+1). */
+int paif_dwconv_wgrad(const float* x, const float* dy, float* dw, float* db, float* workspace, int k, int dil, int in_relu, int B, int H,
+                      int W, int C, paif_stream_t stream);
+/* stem_1/stem_2 (Conv2d(1,32,3)+PReLU, core/model_fusion_auto.py:607-614): dw[32][9] +=, dslope +=; the pre-activation is
+ * recomputed from the image.  img as in paif_stem_fwd.  workspace: row_reduce(B*H*W, 32, 10). */
+int paif_stem_wgrad(const float* img, size_t img_bstride, const float* dfeat, const float* w, const float* prelu, float* dw, float* dslope,
+                    float* workspace, int B, int H, int W, paif_stream_t stream);
+/* Weight gradient of a Cm -> 1 "same" conv from its 1-channel output gradient s [B,H,W] and input m [B,H,W,Cm]:
+ * dw[Cm][k][k] += sum s[px]*m[px+tap][c] (stem_out.1: Cm 16, k 3, :617; spatial_attn_layer_M: Cm 4, k 5, :1361).
+ * workspace: row_reduce(B*H*W, Cm, k*k). */
+int paif_corr1_wgrad(const float* s, const float* m, float* dw, float* workspace, int Cm, int k, int B, int H, int W, paif_stream_t stream);
+/* eca_layer's Conv1d weight gradient (operations_m.py:353-367): dw[k] += sum_b sum_c dpre[b][c]*mean[b][c+j-pad].
+ * pool_partial: the forward conv's per-tile channel sums; dgate_partial [B][blocks][32]: paif_eca_bwd_input's partials. */
+int paif_eca_wgrad(const float* pool_partial, const float* dgate_partial, int dgate_blocks_per_img, const float* gate, int k, float* dw,
+                   int B, int H, int W, paif_stream_t stream);
+/* Cell_Decom 1x1: G [32][96] = gradient of the folded weight over [x, LF1, LF2] -> dw [32][128] += [G1, G2, Gx-G1, Gx-G2]. */
+int paif_unfold_decomp1x1_wgrad(const float* G, float* dw, paif_stream_t stream);
+/* conv-as-GEMM weight gradient back to the PyTorch layout: dw[Cout][Cin][k][k] += dwp[Cout][tap*Cin + c] (row stride Kpad). */
+int paif_unpack_conv_gemm_wgrad(const float* dwp, float* dw, int Cout, int Cin, int k, int Kpad, paif_stream_t stream);
+/* Keep masks of DropPath (timm; core/mix_transformer.py:126) / Dropout2d (core/segformer_head.py:47,79):
+ * out[i] = u_i >= p ? 1/(1-p) : 0 with the counter-based uniform u_i = (splitmix64(seed*0x100000001B3 + offset + i) >> 11) * 2^-53. */
+int paif_keep_mask(float* out, int n, unsigned long long seed, unsigned long long offset, float p, paif_stream_t stream);
+/* out[b][r][c] = x[b][r][c] * s[b] (per_channel: s[b][c]) + res (res optional). */
+int paif_rowscale_add_fwd(const float* x, const float* s, const float* res, float* out, int B, size_t rows_per_b, int C, int per_channel,
+                          paif_stream_t stream);
+/* Multi-tensor AdamW over a flat arena (utils/optimizer.py:3-33 = torch.optim.AdamW, eps 1e-8, no amsgrad).  chunk_group[i]
+ * (device bytes): parameter group of arena chunk i (1024 floats), >= 8 = skip.  group_decay[g] = 1 - lr_g*wd_g and
+ * group_step_size[g] = lr_g / (1 - beta1^t) are HOST arrays (the schedule changes them every step); bc2_sqrt = sqrt(1 - beta2^t). */
+int paif_adamw_step(float* p, const float* g, float* m, float* v, const unsigned char* chunk_group, size_t nchunks, int ngroups,
+                    const float* group_decay, const float* group_step_size, float one_minus_beta1, float beta2, float one_minus_beta2,
+                    float bc2_sqrt, float eps, paif_stream_t stream);
 
 #ifdef __cplusplus
 }

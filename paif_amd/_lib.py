@@ -5,7 +5,7 @@ shared object is missing or a symbol is absent, importing an op raises immediate
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_size_t, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_size_t, c_ulonglong, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PAIF_LIB") or os.path.join(HERE, "lib", "libpaif_hip.so")  # PAIF_LIB: A/B builds of the same ABI
@@ -31,8 +31,10 @@ SIGNATURES = {
     "paif_last_error": (c_char_p, []),
     "paif_device_cus": (c_int, []),
     "paif_rgb2ycrcb_fwd": (c_int, [F, F, c_int, c_int, c_int, F]),
+    "paif_ycrcb2rgb_fwd": (c_int, [F, F, c_int, c_int, c_int, F]),
     "paif_minmax_blocks": (c_int, [c_int, c_int, c_int]),
     "paif_recompose_clamp_fwd": (c_int, [F, F, F, F, c_int, c_int, c_int, F]),
+    "paif_fused_uint8_fwd": (c_int, [F, F, c_int, F, c_int, c_int, c_int, F]),
     "paif_minmax_normalize_fwd": (c_int, [F, F, c_int, F, F, c_int, c_int, c_int, F]),
     "paif_stem_fwd": (c_int, [F, c_size_t, F, F, F, F, c_int, c_int, c_int, F]),
     "paif_channel_residue_fwd": (c_int, [F, F, c_int, c_int, c_int, F]),
@@ -57,13 +59,13 @@ SIGNATURES = {
     "paif_gemm_fwd": (c_int, [F, c_int, F, F, F, c_int, F, c_int, F, c_int, c_int, c_int, c_int, c_int, F]),
     "paif_gemm_splitk_plan": (c_int, [c_int, c_int, c_int]),
     "paif_conv2d_wgrad_workspace_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
-    "paif_conv2d_wgrad": (c_int, [POINTER(c_void_p), c_int, F, F, F, F, c_int, c_float, c_int, c_int, F, F, c_int, c_int, c_int, F]),
+    "paif_conv2d_wgrad": (c_int, [POINTER(c_void_p), c_int, F, F, F, F, c_int, c_float, c_int, c_int, F, F, c_int, c_int, c_int, c_int, c_int, F]),
     "paif_gemm_wgrad_splits": (c_int, [c_int, c_int, c_int]),
-    "paif_gemm_wgrad": (c_int, [F, c_int, F, c_int, F, F, c_int, c_int, c_int, c_int, F, F]),
+    "paif_gemm_wgrad": (c_int, [F, c_int, F, c_int, F, F, c_int, c_int, c_int, c_int, F, c_int, F]),
     "paif_layernorm_wgrad_blocks": (c_int, [c_int]),
-    "paif_layernorm_wgrad": (c_int, [F, F, F, F, F, c_int, c_int, c_float, F]),
+    "paif_layernorm_wgrad": (c_int, [F, F, F, F, F, c_int, c_int, c_float, c_int, F]),
     "paif_ssim_l1_blocks": (c_int, [c_int, c_int, c_int]),
-    "paif_ssim_l1_fwd": (c_int, [F, F, F, F, c_int, c_int, c_int, F]),
+    "paif_ssim_l1_fwd": (c_int, [F, F, F, F, F, c_int, c_int, c_int, F]),
     "paif_ssim_l1_bwd_input": (c_int, [F, F, F, F, F, F, c_int, c_int, c_int, F]),
     "paif_gemm_splitk_fwd": (c_int, [F, c_int, F, F, F, c_int, F, c_int, F, c_int, c_int, c_int, c_int, c_int, F, F]),
     "paif_layernorm_fwd": (c_int, [F, F, F, F, c_int, c_int, c_float, F]),
@@ -104,6 +106,29 @@ SIGNATURES = {
     "paif_pgd_step": (c_int, [F, F, F, c_float, c_float, c_size_t, F]),
     "paif_axpy": (c_int, [F, F, c_float, c_size_t, F]),
     "paif_upsample_ce_bwd": (c_int, [F, F, F, F, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, F]),
+    "paif_u8_to_planes_fwd": (c_int, [F, F, c_int, c_int, c_int, F]),
+    "paif_u8_to_i64_fwd": (c_int, [F, F, c_size_t, F]),
+    # ---- training step (csrc/train_kernels.hip) ----
+    "paif_nhwc_slice_to_nchw_fwd": (c_int, [F, F, c_int, c_int, c_int, c_int, F]),
+    "paif_pad_channels_fwd": (c_int, [F, F, c_size_t, c_int, c_int, F]),
+    "paif_decomp_cat_fwd": (c_int, [F, F, F, F, c_size_t, F]),
+    "paif_row_reduce_workspace_floats": (c_size_t, [c_int, c_int, c_int]),
+    "paif_bn_stats_fwd": (c_int, [F, c_int, c_int, F, F, c_float, c_float, F, F, F, F, F, F, F, F]),
+    "paif_affine_act_res_fwd": (c_int, [F, F, F, c_int, F, F, F, F, F, c_size_t, c_int, F]),
+    "paif_bn_act_bwd": (c_int, [F, F, F, F, F, F, c_int, F, F, F, F, F, F, F, c_int, c_int, F]),
+    "paif_prelu_bwd": (c_int, [F, F, F, F, c_float, F, F, F, c_size_t, F]),
+    "paif_tail_dz": (c_int, [F, F, F, F, F, F, F, c_size_t, F]),
+    "paif_colsum": (c_int, [F, c_int, F, F, c_int, c_int, F]),
+    "paif_dwconv_wgrad": (c_int, [F, F, F, F, F, c_int, c_int, c_int, c_int, c_int, c_int, c_int, F]),
+    "paif_stem_wgrad": (c_int, [F, c_size_t, F, F, F, F, F, F, c_int, c_int, c_int, F]),
+    "paif_corr1_wgrad": (c_int, [F, F, F, F, c_int, c_int, c_int, c_int, c_int, F]),
+    "paif_eca_wgrad": (c_int, [F, F, c_int, F, c_int, F, c_int, c_int, c_int, F]),
+    "paif_unfold_decomp1x1_wgrad": (c_int, [F, F, F]),
+    "paif_unpack_conv_gemm_wgrad": (c_int, [F, F, c_int, c_int, c_int, c_int, F]),
+    "paif_keep_mask": (c_int, [F, c_int, c_ulonglong, c_ulonglong, c_float, F]),
+    "paif_rowscale_add_fwd": (c_int, [F, F, F, F, c_int, c_size_t, c_int, c_int, F]),
+    "paif_adamw_step": (c_int, [F, F, F, F, F, c_size_t, c_int, POINTER(c_float), POINTER(c_float), c_float, c_float, c_float, c_float,
+                                c_float, F]),
 }
 
 _lib = None

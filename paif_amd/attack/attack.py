@@ -30,17 +30,15 @@ def clamp(X, lower_limit, upper_limit):
 
 class Seg_loss(nn.Module):
     """attack/attack.py:103-114: CrossEntropyLoss(ignore_index=255) on already-upsampled outputs [B,C,H,W].
-    Runs the fused HIP kernel (identity-size bilinear sampling is exact) when no gradient is required."""
+    Runs the fused HIP kernels (paif_upsample_ce_fwd / _bwd; identity-size bilinear sampling is exact), with or
+    without a gradient (ops.UpsampleCE is the autograd node)."""
 
     def __init__(self):
         super().__init__()
-        self._loss = torch.nn.CrossEntropyLoss(ignore_index=255)
+        self._loss = torch.nn.CrossEntropyLoss(ignore_index=255)   # kept for attribute parity; never evaluated
 
     def forward(self, outputs, labels):
-        if torch.is_grad_enabled() and outputs.requires_grad:
-            return self._loss(outputs, labels.type(torch.long))   # next-tier variants: torch autograd above the HIP model
-        lc = ops.upsample_ce_fwd(ops.to_nhwc(outputs), labels.type(torch.long).contiguous())
-        return lc[0]
+        return ops.upsample_ce(outputs, labels.type(torch.long).contiguous(), ignore_index=255)
 
 
 def _loss_variant(outputs, label, criterion, attack_way, i, attack_iters):
@@ -127,23 +125,24 @@ def _attack(model, X_vis, X_ir, label, epsilon, alpha, attack_iters, restarts, a
 
 
 def attack_both(model, X_vis, X_ir, label, epsilon=8 / 255., alpha=2 / 255., attack_iters=50,
-                restarts=1, attack_loss='l_seg', attack_mode='vis', attack_way='PGD', delta0_ir=None, delta0_vis=None, trace=None):
+                restarts=1, attack_loss='l_seg', attack_mode='vis', attack_way='PGD', *, delta0_ir=None, delta0_vis=None, trace=None):
     """attack/attack.py:417-514.  Extra keyword-only extensions: delta0_* (deterministic start), trace (per-iteration log)."""
     return _attack(model, X_vis, X_ir, label, epsilon, alpha, attack_iters, restarts, attack_loss, attack_way, True, True,
                    delta0_ir, delta0_vis, trace)
 
 
-def attack_vis(model, X_vis, X_ir, label, epsilon=8 / 255., alpha=2 / 255., attack_iters=50,
-               restarts=1, attack_loss='l_seg', attack_mode='vis', attack_way='PGD', delta0_vis=None):
-    """attack/attack.py:517-604: perturb the visible image only; returns delta_vis."""
+def attack_vis(model, X_vis, X_ir, X_fusion, label, epsilon=8 / 255., alpha=2 / 255., attack_iters=50,
+               restarts=1, attack_loss='l_seg', attack_mode='vis', attack_way='PGD', *, delta0_vis=None):
+    """attack/attack.py:517-604: perturb the visible image only; returns delta_vis.  X_fusion is accepted and unused,
+    as in the reference (its body never reads it); call sites: robust_test.py:169-176."""
     r = _attack(model, X_vis, X_ir, label, epsilon, alpha, attack_iters, restarts, attack_loss, attack_way, False, True,
                 None, delta0_vis)
     return r if r == -1 else r[1]
 
 
-def attack_ir(model, X_vis, X_ir, label, epsilon=8 / 255., alpha=2 / 255., attack_iters=50,
-              restarts=1, attack_loss='l_seg', attack_mode='vis', attack_way='PGD', delta0_ir=None):
-    """attack/attack.py:607-690: perturb the infrared image only; returns delta_ir."""
+def attack_ir(model, X_vis, X_ir, X_fusion, label, epsilon=8 / 255., alpha=2 / 255., attack_iters=50,
+              restarts=1, attack_loss='l_seg', attack_mode='vis', attack_way='PGD', *, delta0_ir=None):
+    """attack/attack.py:607-690: perturb the infrared image only; returns delta_ir.  X_fusion: accepted, unused."""
     r = _attack(model, X_vis, X_ir, label, epsilon, alpha, attack_iters, restarts, attack_loss, attack_way, True, False,
                 delta0_ir, None)
     return r if r == -1 else r[0]
@@ -196,8 +195,21 @@ def _image_or_seg_loss(attack_loss, X_vis, X_fusion, label, sign=1.0):
         crit = nn.MSELoss()
     elif attack_loss == 'l_1':
         crit = nn.L1Loss()
+    elif attack_loss == 'l_ssim':
+        # pytorch_ssim.SSIM()(robust_output, X_fusion) (attack/attack.py:136-137): every channel uses the same 11x11 window
+        # and the result is the mean over everything, so [B,3,H,W] is evaluated as 3B single-channel images (HIP SSIM
+        # forward / gradient kernels).  X_fusion must have the recomposed image's 3 channels, as in pytorch_ssim.
+        from ..core.loss import ssim as _ssim
+
+        def crit(a, b):
+            if a.shape != b.shape:
+                raise RuntimeError("l_ssim: X_fusion %s must match the recomposed image %s (pytorch_ssim convolves both with "
+                                   "the same per-channel window)" % (tuple(b.shape), tuple(a.shape)))
+            H, W = a.shape[-2:]
+            return _ssim(a.reshape(-1, 1, H, W), b.reshape(-1, 1, H, W))
     else:
-        raise NotImplementedError("attack_loss %r: only l_seg / l_2 / l_1 are built (l_ssim, lpips are not)" % attack_loss)
+        raise NotImplementedError("attack_loss %r: l_seg / l_2 / l_1 / l_ssim are built (lpips needs the un-vendored LPIPS "
+                                  "network weights, SURVEY.md section 2)" % attack_loss)
     return lambda fused, seg, i: sign * crit(trans_format(fused, X_vis), X_fusion)
 
 

@@ -23,10 +23,10 @@ def RGB2YCrCb(input_im):
 
 
 def YCrCb2RGB(input_im):
-    """core/model_fusion_auto.py:94-111 -- on the path only inside the fusion->seg glue, where it is
-    fused with the clamp and the min/max pass (ops.seg_input_from_fused)."""
-    raise NotImplementedError("YCrCb2RGB is fused into the glue kernel (paif_recompose_clamp_fwd); "
-                              "a stand-alone kernel is not built")
+    """core/model_fusion_auto.py:94-111.  [B,3,H,W] (Y, Cr, Cb) -> [B,3,H,W] RGB, not clamped.  (Inside the
+    fusion->seg glue the same arithmetic runs fused with the clamp and the min/max pass: ops.seg_input_from_fused.)"""
+    ops.require_no_grad(input_im)
+    return ops.ycrcb2rgb(input_im)
 
 
 class MixedOp(nn.Module):
@@ -124,9 +124,18 @@ class Cell_Decom(nn.Module):
             guide = ops.channel_residue(x)
         return ops.guided_filter_pair(guide, x, tuple(self.eps_list), want_ab=want_ab)
 
+    @staticmethod
+    def _cat_lf_hf(x, lf):
+        """-> (LF, HF) as [B,2C,H,W] views: eps 1e-3 then 1e-4 on the channel axis (the reference's list order, :533-534)."""
+        lf_cat, hf_cat = ops.decomp_cat(x, lf)
+        return ops.to_nchw_view(lf_cat), ops.to_nchw_view(hf_cat)
+
     def decomposition(self, x, C=None):
-        """API parity with the reference: returns (LF [B,2C,H,W], HF [B,2C,H,W])."""
-        raise NotImplementedError("HF = x - LF is folded into the 1x1 conv; use decomposition_nhwc for the LF maps")
+        """core/model_fusion_auto.py:522-535: (LF [B,2C,H,W], HF [B,2C,H,W]).  (forward() never materialises HF: it is folded
+        into the 1x1 conv; this public form does, because returning it is the point.)"""
+        ops.require_no_grad(x)
+        xn = ops.to_nhwc(x)
+        return self._cat_lf_hf(xn, self.decomposition_nhwc(xn))
 
     def forward_nhwc(self, fir, fvis, g_ir=None, g_vis=None, tape=None, feats=None):
         """feats (dict): receives the decomposition intermediates (LF maps, residues) for the visualisation path."""
@@ -189,12 +198,6 @@ class Cell_Decom_decom(Cell_Decom):
     """core/model_fusion_auto.py:536-581 -- the decomposition cell of the feature-visualisation network: same
     parameters and arithmetic as Cell_Decom, but it also RETURNS the decomposition (LF and HF of both eps concatenated
     on the channel axis, and the residue guide).  HF = x - LF is materialised here because showing it is the point."""
-
-    @staticmethod
-    def _cat_lf_hf(x, lf):
-        lf_cat = torch.cat([lf[0], lf[1]], dim=-1)          # [B,H,W,2C]: eps 1e-3 then 1e-4 (the reference's list order)
-        hf_cat = torch.cat([x, x], dim=-1) - lf_cat
-        return ops.to_nchw_view(lf_cat), ops.to_nchw_view(hf_cat)
 
     def decomposition(self, x, C=None):
         """(LF [B,2C,H,W], HF [B,2C,H,W], res [B,1,H,W]) -- :567-581."""
@@ -516,15 +519,13 @@ class _CompositeBase(nn.Module):
     # ---- training-API losses (:1093-1128).  Values, and gradients w.r.t. the INPUT images (the models' autograd nodes +
     # the loss gradient kernels).  Parameter gradients -- the training step itself, BASELINE config 5 -- are not built.
     def _seg_term(self, seg_map, labels):
-        """self.seg_loss(F.interpolate(seg_map, size=labels.shape[1:], bilinear), labels.long())"""
+        """self.seg_loss(F.interpolate(seg_map, size=labels.shape[1:], bilinear), labels.long())   (:1096-1098)"""
         labels = labels.type(torch.long).contiguous()
         sl = self.seg_loss
-        plain_ce = isinstance(sl, nn.CrossEntropyLoss) and sl.reduction == "mean" and sl.weight is None and sl.label_smoothing == 0.0
-        if plain_ce and not (torch.is_grad_enabled() and seg_map.requires_grad):
-            # fused bilinear upsample + cross entropy (HIP), same arithmetic as attack.Seg_loss
-            return ops.upsample_ce_fwd(ops.to_nhwc(seg_map), labels, ignore_index=sl.ignore_index)[0]
-        # with a gradient (or any other user criterion): the reference's own two calls; torch differentiates this small
-        # tail, the model underneath is the HIP autograd node
+        if isinstance(sl, nn.CrossEntropyLoss) and sl.reduction == "mean" and sl.weight is None and sl.label_smoothing == 0.0:
+            # fused bilinear upsample + cross entropy, forward and gradient (HIP; ops.UpsampleCE is the autograd node)
+            return ops.upsample_ce(seg_map, labels, ignore_index=sl.ignore_index)
+        # any other user criterion: the reference's own two calls on torch ops above the HIP model
         import torch.nn.functional as F
         return sl(F.interpolate(seg_map, size=labels.shape[1:], mode='bilinear', align_corners=False), labels)
 

@@ -100,8 +100,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 
 // dw[co][s*32+ci][ky][kx] = sum over blocks of slab[blk][s*KH+ky][kx][co][ci]
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int nblk, int nz,
-                                                                int kh, int nsrc) {
-  const int total = 32 * nsrc * 32 * kh * kh;
+                                                                int kh, int nsrc, int cout, int accumulate) {
+  const int total = cout * nsrc * 32 * kh * kh;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
     int tmp = i;
     const int kx = tmp % kh; tmp /= kh;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
     const size_t off = ((size_t)(s * kh + ky) * kh + kx) * 1024 + (size_t)co * 32 + ci;
     float v = 0.f;
     for (int blk = 0; blk < nblk; ++blk) v += slabs[((size_t)blk * nz) * kh * 1024 + off];
-    dw[i] = v;
+    dw[i] = accumulate ? dw[i] + v : v;
   }
 }
 
@@ -123,13 +123,14 @@ extern "C" size_t paif_conv2d_wgrad_workspace_floats(int nsrc, int kh, int B, in
 }
 
 extern "C" int paif_conv2d_wgrad(const float* const* src, int nsrc, const float* dout, const float* z, const float* scale,
-                                 const float* prelu, int act, float alpha, int kh, int dil, float* workspace, float* dw, int B, int H,
-                                 int W, paif_stream_t stream) {
+                                 const float* prelu, int act, float alpha, int kh, int dil, float* workspace, float* dw, int cout,
+                                 int accumulate, int B, int H, int W, paif_stream_t stream) {
   PAIF_REQUIRE(src && dout && workspace && dw, PAIF_EINVAL, "conv2d_wgrad: null pointer");
   PAIF_REQUIRE(nsrc >= 1 && nsrc <= 3, PAIF_EINVAL, "conv2d_wgrad: nsrc=%d", nsrc);
   PAIF_REQUIRE(B > 0 && H > 0 && W > 0, PAIF_EINVAL, "conv2d_wgrad: empty shape");
   PAIF_REQUIRE(act >= 0 && act <= 2 && (!act || z) && (act != 1 || prelu), PAIF_EINVAL, "conv2d_wgrad: act=%d needs z (and the slope)", act);
   PAIF_REQUIRE(dil == 1 || dil == 2, PAIF_ENOSUP, "conv2d_wgrad: dil=%d", dil);
+  PAIF_REQUIRE(cout >= 1 && cout <= 32, PAIF_EINVAL, "conv2d_wgrad: cout=%d (dout always has 32 channels; rows >= cout are dropped)", cout);
   WgradArgs a;
   for (int s = 0; s < 3; ++s) a.src[s] = s < nsrc ? src[s] : nullptr;
   for (int s = 0; s < nsrc; ++s) PAIF_REQUIRE(a.src[s], PAIF_EINVAL, "conv2d_wgrad: src[%d] null", s);
@@ -147,8 +148,9 @@ extern "C" int paif_conv2d_wgrad(const float* const* src, int nsrc, const float*
       return PAIF_ENOSUP;
   }
   PAIF_LAUNCH_CHECK("conv2d_wgrad");
-  const int total = 32 * nsrc * 32 * kh * kh;
-  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, workspace, dw, B * a.nrb, nsrc * kh, kh, nsrc);
+  const int total = cout * nsrc * 32 * kh * kh;
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, workspace, dw, B * a.nrb, nsrc * kh, kh, nsrc,
+                     cout, accumulate);
   PAIF_LAUNCH_CHECK("conv2d_wgrad_reduce");
   return 0;
 }

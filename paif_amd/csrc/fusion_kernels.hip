@@ -46,6 +46,23 @@ __global__ void rgb2ycrcb_kernel(const float* __restrict__ rgb, float* __restric
   }
 }
 
+// YCrCb2RGB stand-alone (core/model_fusion_auto.py:94-111): (im_flat + bias).mm(mat), no clamp
+__global__ void ycrcb2rgb_kernel(const float* __restrict__ ycc, float* __restrict__ rgb, int B, size_t HW) {
+  const size_t total = (size_t)B * HW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = i / HW, px = i - b * HW;
+    const float* s = ycc + b * 3 * HW + px;
+    const float y0 = __fadd_rn(s[0], 0.0f);
+    const float cr = __fadd_rn(s[HW], -0.5f);
+    const float cb = __fadd_rn(s[2 * HW], -0.5f);
+    // mat rows: [1,1,1], [1.403,-0.714,0], [0,-0.344,1.773]; k-ordered fma chain (same as recompose_clamp_kernel)
+    float* d = rgb + b * 3 * HW + px;
+    d[0] = fmaf(cb, 0.0f, fmaf(cr, 1.403f, y0 * 1.0f));
+    d[HW] = fmaf(cb, -0.344f, fmaf(cr, -0.714f, y0 * 1.0f));
+    d[2 * HW] = fmaf(cb, 1.773f, fmaf(cr, 0.0f, y0 * 1.0f));
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // stem: 3x3 conv 1->32 (no bias) + PReLU, fused with the guide max_c - min_c
 // thread = (pixel, channel quad); 8 lanes of a pixel read the same 9 taps (broadcast from L1)
@@ -415,9 +432,51 @@ __global__ __launch_bounds__(256) void minmax_normalize_kernel(const float* __re
   }
 }
 
+// Fused-image writer post-processing (test_original.py:181-197) after the recomposition + clamp: q = uint8(255*rgb)
+// (truncation, fp32 product), batch-global min/max of q (= trunc of the float min/max: monotone), (q - mn)/(mx - mn) in
+// float64, uint8(255*x) again.  rgb NCHW [B,3,H,W] -> out NHWC uint8 [B,H,W,3].
+__global__ __launch_bounds__(256) void fused_uint8_kernel(const float* __restrict__ rgb, const float* __restrict__ partial, int npartial,
+                                                          unsigned char* __restrict__ out, int B, size_t HW) {
+  float mn = INFINITY, mx = -INFINITY;
+  for (int i = threadIdx.x; i < npartial; i += 256) {
+    mn = fminf(mn, partial[i]);
+    mx = fmaxf(mx, partial[npartial + i]);
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, m));
+    mx = fmaxf(mx, __shfl_xor(mx, m));
+  }
+  __shared__ float smn[4], smx[4];
+  if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  mn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+  mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+  const int qmn = (int)(unsigned char)__fmul_rn(255.0f, mn), qmx = (int)(unsigned char)__fmul_rn(255.0f, mx);
+  const double range = (double)(qmx - qmn);
+  const size_t total = (size_t)B * HW * 3;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % 3);
+    const size_t t = i / 3;
+    const size_t px = t % HW, b = t / HW;
+    const int q = (int)(unsigned char)__fmul_rn(255.0f, rgb[(b * 3 + c) * HW + px]);
+    out[i] = (unsigned char)(255.0 * ((double)(q - qmn) / range));
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int paif_fused_uint8_fwd(const float* rgb, const float* minmax_partial, int npartial, unsigned char* out, int B, int H, int W,
+                         paif_stream_t stream) {
+  PAIF_REQUIRE(rgb && minmax_partial && out && npartial > 0 && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "fused_uint8: bad arguments");
+  const size_t HW = (size_t)H * W;
+  hipLaunchKernelGGL(fused_uint8_kernel, dim3(grid_for((size_t)B * 3 * HW, 256)), dim3(256), 0, paif::as_stream(stream), rgb,
+                     minmax_partial, npartial, out, B, HW);
+  PAIF_LAUNCH_CHECK("fused_uint8");
+  return 0;
+}
 
 int paif_version(void) { return PAIF_ABI_VERSION; }
 const char* paif_last_error(void) { return paif::g_err; }
@@ -437,6 +496,14 @@ int paif_rgb2ycrcb_fwd(const float* rgb, float* ycc, int B, int H, int W, paif_s
   const size_t HW = (size_t)H * W;
   hipLaunchKernelGGL(rgb2ycrcb_kernel, dim3(grid_for(B * HW, 256)), dim3(256), 0, paif::as_stream(stream), rgb, ycc, B, HW);
   PAIF_LAUNCH_CHECK("rgb2ycrcb");
+  return 0;
+}
+
+int paif_ycrcb2rgb_fwd(const float* ycc, float* rgb, int B, int H, int W, paif_stream_t stream) {
+  PAIF_REQUIRE(ycc && rgb && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "ycrcb2rgb: bad arguments");
+  const size_t HW = (size_t)H * W;
+  hipLaunchKernelGGL(ycrcb2rgb_kernel, dim3(grid_for(B * HW, 256)), dim3(256), 0, paif::as_stream(stream), ycc, rgb, B, HW);
+  PAIF_LAUNCH_CHECK("ycrcb2rgb");
   return 0;
 }
 

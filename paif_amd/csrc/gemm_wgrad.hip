@@ -49,17 +49,17 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const float* __restrict
 
 __global__ __launch_bounds__(256) void gemm_wgrad_reduce_kernel(const float* __restrict__ part_w, const float* __restrict__ part_b,
                                                                 float* __restrict__ dw, float* __restrict__ db, int splits, int N,
-                                                                int K) {
+                                                                int K, int accumulate) {
   const size_t total = (size_t)N * K;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total + (db ? N : 0); i += (size_t)gridDim.x * 256) {
     float v = 0.f;
     if (i < total) {
       for (int s = 0; s < splits; ++s) v += part_w[(size_t)s * total + i];
-      dw[i] = v;
+      dw[i] = accumulate ? dw[i] + v : v;
     } else {
       const size_t n = i - total;
       for (int s = 0; s < splits; ++s) v += part_b[(size_t)s * N + n];
-      db[n] = v;
+      db[n] = accumulate ? db[n] + v : v;
     }
   }
 }
@@ -78,7 +78,7 @@ extern "C" int paif_gemm_wgrad_splits(int M, int N, int K) {
 }
 
 extern "C" int paif_gemm_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, float* db, int M, int N, int K, int splits,
-                               float* workspace, paif_stream_t stream) {
+                               float* workspace, int accumulate, paif_stream_t stream) {
   PAIF_REQUIRE(dy && x && dw && workspace, PAIF_EINVAL, "gemm_wgrad: null pointer");
   PAIF_REQUIRE(M > 0 && N > 0 && K > 0 && lddy >= N && ldx >= K, PAIF_EINVAL, "gemm_wgrad: shape %dx%dx%d ld %d/%d", M, N, K, lddy, ldx);
   PAIF_REQUIRE(splits >= 1 && splits <= 64, PAIF_EINVAL, "gemm_wgrad: splits=%d", splits);
@@ -92,7 +92,7 @@ extern "C" int paif_gemm_wgrad(const float* dy, int lddy, const float* x, int ld
   PAIF_LAUNCH_CHECK("gemm_wgrad");
   const size_t total = (size_t)N * K + (db ? N : 0);
   const int rb = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(gemm_wgrad_reduce_kernel, dim3(rb), dim3(256), 0, st, part_w, part_b, dw, db, splits, N, K);
+  hipLaunchKernelGGL(gemm_wgrad_reduce_kernel, dim3(rb), dim3(256), 0, st, part_w, part_b, dw, db, splits, N, K, accumulate);
   PAIF_LAUNCH_CHECK("gemm_wgrad_reduce");
   return 0;
 }

@@ -182,14 +182,33 @@ extern "C" int paif_ssim_l1_bwd_input(const float* x, const float* y, const floa
   return 0;
 }
 
+namespace {
+// out[0] = sum(partial[2i]) * inv_n (mean SSIM), out[1] = sum(partial[2i+1]) * inv_n (mean |y - x|); block order, double
+__global__ void ssim_l1_finish_kernel(const float* __restrict__ partial, int nblk, float inv_n, float* __restrict__ out) {
+  __shared__ double sl[2][64];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += 64) { a += partial[2 * (size_t)i]; b += partial[2 * (size_t)i + 1]; }
+  sl[0][threadIdx.x] = a; sl[1][threadIdx.x] = b;
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    double t = 0.0;
+    for (int i = 0; i < 64; ++i) t += sl[threadIdx.x][i];
+    out[threadIdx.x] = (float)(t * (double)inv_n);
+  }
+}
+}  // namespace
+
 extern "C" int paif_ssim_l1_blocks(int B, int H, int W) { return B * ((H + T - 1) / T) * ((W + T - 1) / T); }
 
-extern "C" int paif_ssim_l1_fwd(const float* x, const float* y, const float* window1d, float* partial, int B, int H, int W,
+extern "C" int paif_ssim_l1_fwd(const float* x, const float* y, const float* window1d, float* partial, float* means, int B, int H, int W,
                                 paif_stream_t stream) {
-  PAIF_REQUIRE(x && y && window1d && partial && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "ssim_l1: bad arguments");
+  PAIF_REQUIRE(x && y && window1d && partial && means && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "ssim_l1: bad arguments");
   const int tilesX = (W + T - 1) / T, tilesY = (H + T - 1) / T;
-  hipLaunchKernelGGL(ssim_l1_kernel, dim3(B * tilesX * tilesY), dim3(256), 0, paif::as_stream(stream), x, y, window1d, partial, H, W,
-                     tilesX, tilesY);
+  hipStream_t st = paif::as_stream(stream);
+  hipLaunchKernelGGL(ssim_l1_kernel, dim3(B * tilesX * tilesY), dim3(256), 0, st, x, y, window1d, partial, H, W, tilesX, tilesY);
   PAIF_LAUNCH_CHECK("ssim_l1");
+  hipLaunchKernelGGL(ssim_l1_finish_kernel, dim3(1), dim3(64), 0, st, partial, B * tilesX * tilesY,
+                     (float)(1.0 / ((double)B * H * W)), means);
+  PAIF_LAUNCH_CHECK("ssim_l1_finish");
   return 0;
 }

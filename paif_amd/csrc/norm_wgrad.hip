@@ -43,12 +43,13 @@ __global__ __launch_bounds__(256) void layernorm_wgrad_kernel(const float* __res
 }
 
 __global__ __launch_bounds__(256) void layernorm_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
-                                                                     float* __restrict__ dbeta, int nblk, int C) {
+                                                                     float* __restrict__ dbeta, int nblk, int C, int accumulate) {
   for (int i = blockIdx.x * 256 + threadIdx.x; i < 2 * C; i += gridDim.x * 256) {
     const int which = i / C, c = i - which * C;
     float v = 0.f;
     for (int b = 0; b < nblk; ++b) v += partial[((size_t)b * 2 + which) * C + c];
-    (which ? dbeta : dgamma)[c] = v;
+    float* dst = which ? dbeta : dgamma;
+    dst[c] = accumulate ? dst[c] + v : v;
   }
 }
 
@@ -57,13 +58,13 @@ __global__ __launch_bounds__(256) void layernorm_wgrad_reduce_kernel(const float
 extern "C" int paif_layernorm_wgrad_blocks(int M) { return (M + RB - 1) / RB; }
 
 extern "C" int paif_layernorm_wgrad(const float* x, const float* dy, float* dgamma, float* dbeta, float* workspace, int M, int C,
-                                    float eps, paif_stream_t stream) {
+                                    float eps, int accumulate, paif_stream_t stream) {
   PAIF_REQUIRE(x && dy && dgamma && dbeta && workspace && M > 0 && C > 0, PAIF_EINVAL, "layernorm_wgrad: bad arguments");
   const int nblk = (M + RB - 1) / RB;
   hipStream_t st = paif::as_stream(stream);
   hipLaunchKernelGGL(layernorm_wgrad_kernel, dim3(nblk), dim3(256), 0, st, x, dy, workspace, M, C, eps);
   PAIF_LAUNCH_CHECK("layernorm_wgrad");
-  hipLaunchKernelGGL(layernorm_wgrad_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, workspace, dgamma, dbeta, nblk, C);
+  hipLaunchKernelGGL(layernorm_wgrad_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, workspace, dgamma, dbeta, nblk, C, accumulate);
   PAIF_LAUNCH_CHECK("layernorm_wgrad_reduce");
   return 0;
 }

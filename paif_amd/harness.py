@@ -19,15 +19,11 @@ def _summary(meter):
 
 
 def fused_to_uint8(fused, vis):
-    """The reference's fused-image post-processing (test_original.py:181-197), on the GPU: RGB recomposition with the
-    visible image's chroma + clamp (HIP glue kernel), np.uint8(255*x) (truncation), batch-global min-max of the uint8
-    array evaluated in float64, np.uint8(255*x) again.  fused [B,1,H,W], vis [B,3,H,W] -> uint8 [B,H,W,3] (device)."""
+    """The reference's fused-image post-processing (test_original.py:181-197), on the GPU (HIP kernels): RGB recomposition
+    with the visible image's chroma + clamp, np.uint8(255*x) (truncation), batch-global min-max of the uint8 array
+    evaluated in float64, np.uint8(255*x) again.  fused [B,1,H,W], vis [B,3,H,W] -> uint8 [B,H,W,3] (device)."""
     from . import ops
-    rgb = ops.recompose_clamp(fused, ops.rgb2ycrcb(vis))[0]                       # [B,3,H,W] in [0,1]
-    q = (rgb * 255.0).to(torch.uint8).permute(0, 2, 3, 1)                         # float32 product, truncated
-    mn, mx = q.min(), q.max()
-    x = (q - mn).to(torch.float64) / (mx - mn).to(torch.float64)                  # uint8 - uint8 never wraps (>= min)
-    return (255.0 * x).to(torch.uint8).contiguous()
+    return ops.fused_to_uint8(fused, ops.rgb2ycrcb(vis))
 
 
 def write_fused_pngs(images_uint8, names, fused_path):

@@ -47,14 +47,23 @@ class LayerNormParams(_NeverCalled, nn.LayerNorm):
     pass
 
 
+def invalidate_weight_caches():
+    """Drop every packed-weight / folded-BN cache entry at its next use.  The caches are keyed on (data_ptr, tensor version):
+    in-place torch ops and load_state_dict bump the version, but writes through `param.data` and raw-pointer kernels (the
+    AdamW kernel of paif_amd.utils.optimizer, which calls this after every step) do not -- call this after any such write."""
+    ops.CONFIG["weights_generation"] = ops.CONFIG.get("weights_generation", 0) + 1
+
+
 class _PackCache:
-    """Packed-weight cache keyed on (data_ptr, version, device) of the source parameter(s)."""
+    """Packed-weight cache keyed on (data_ptr, version, device) of the source parameter(s) + the global weights generation
+    (invalidate_weight_caches)."""
 
     def __init__(self):
         self._store = {}
 
     def get(self, name, params, builder):
-        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in params) + (ops.CONFIG["conv_precision"],)
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in params) + (ops.CONFIG["conv_precision"],
+                                                                                   ops.CONFIG.get("weights_generation", 0))
         hit = self._store.get(name)
         if hit is None or hit[0] != key:
             hit = (key, builder())
@@ -77,7 +86,7 @@ _slope_checked = {}
 def check_positive_slope(param, what):
     """Backward kernels that read the sign of a PReLU OUTPUT (instead of a saved pre-activation) need a
     non-negative slope.  One host sync per parameter version."""
-    key = (param.data_ptr(), param._version)
+    key = (param.data_ptr(), param._version, ops.CONFIG.get("weights_generation", 0))
     if _slope_checked.get(id(param)) != key:
         if float(param.detach().min()) < 0.0:
             raise NotImplementedError("%s: negative PReLU slope is not supported by the backward kernels" % what)

@@ -101,11 +101,13 @@ def _p(t):
 
 
 def require_no_grad(*tensors):
-    """Round-1 scope: forward kernels only.  Fail loudly rather than silently dropping gradients."""
+    """Entry points that are forward-only (no autograd node of their own): fail loudly rather than silently
+    dropping gradients.  The differentiable entry points are the models' / operators' forward() (autograd nodes
+    with hand-written reverse passes) and the loss functions."""
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
         raise NotImplementedError(
-            "paif_amd: backward (input-gradient) HIP kernels are not built yet; run under torch.no_grad(). "
-            "There is deliberately no autograd/eager fallback.")
+            "paif_amd: this entry point is forward-only (it has no autograd node); call it under torch.no_grad(), or go "
+            "through the model / operator forward().  There is deliberately no autograd/eager fallback.")
 
 
 def to_nhwc(x):
@@ -130,6 +132,15 @@ def rgb2ycrcb(rgb):
     return out
 
 
+def ycrcb2rgb(ycc):
+    ycc = ycc.contiguous()
+    B, C, H, W = ycc.shape
+    assert C == 3
+    out = torch.empty_like(ycc)
+    _lib.check(lib().paif_ycrcb2rgb_fwd(_p(ycc), _p(out), B, H, W, _stream()), "ycrcb2rgb")
+    return out
+
+
 def recompose_clamp(fused, ycc):
     """fused [B,1,H,W] + chroma of ycc [B,3,H,W] -> (RGB clamped to [0,1] [B,3,H,W], per-block (min, max) partials)."""
     fused = fused.contiguous()
@@ -140,6 +151,17 @@ def recompose_clamp(fused, ycc):
     rgb = torch.empty_like(ycc)
     _lib.check(L.paif_recompose_clamp_fwd(_p(fused), _p(ycc), _p(rgb), _p(partial), B, H, W, _stream()), "recompose_clamp")
     return rgb, partial
+
+
+def fused_to_uint8(fused, ycc):
+    """fused [B,1,H,W], ycc [B,3,H,W] -> uint8 NHWC [B,H,W,3]: the reference's fused-image post-processing
+    (test_original.py:181-197: recomposition, clamp, uint8, batch-global min-max in float64, uint8)."""
+    rgb, partial = recompose_clamp(fused, ycc)
+    B, _, H, W = rgb.shape
+    out = torch.empty((B, H, W, 3), device=rgb.device, dtype=torch.uint8)
+    _lib.check(lib().paif_fused_uint8_fwd(_p(rgb), _p(partial), partial.numel() // 2, ctypes.c_void_p(out.data_ptr()), B, H, W, _stream()),
+               "fused_uint8")
+    return out
 
 
 def seg_input_from_fused(fused, ycc, return_minmax=False):
@@ -156,6 +178,24 @@ def seg_input_from_fused(fused, ycc, return_minmax=False):
     _lib.check(L.paif_minmax_normalize_fwd(_p(rgb), _p(partial), nblk, _p(rgb), _p(mm), B, H, W, _stream()),
                "minmax_normalize")
     return (rgb, mm) if return_minmax else rgb
+
+
+def u8_to_planes(src):
+    """uint8 [B,H,W,C] (or [B,H,W]) device bytes -> float32 [B,C,H,W] = src / 255."""
+    if src.dim() == 3:
+        src = src.unsqueeze(-1)
+    assert src.dtype == torch.uint8 and src.is_cuda and src.is_contiguous()
+    B, H, W, C = src.shape
+    out = torch.empty((B, C, H, W), device=src.device, dtype=torch.float32)
+    _lib.check(lib().paif_u8_to_planes_fwd(ctypes.c_void_p(src.data_ptr()), _p(out), B, H * W, C, _stream()), "u8_to_planes")
+    return out
+
+
+def u8_to_i64(src):
+    assert src.dtype == torch.uint8 and src.is_cuda and src.is_contiguous()
+    out = torch.empty(src.shape, device=src.device, dtype=torch.int64)
+    _lib.check(lib().paif_u8_to_i64_fwd(ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(out.data_ptr()), src.numel(), _stream()), "u8_to_i64")
+    return out
 
 
 # ---------------------------------------------------------------------------------------------
@@ -556,9 +596,22 @@ def upsample_ce_bwd(logits, label, gscale, cp=32, ignore_index=255):
     return resize_bilinear_adjoint(dfull, 0, cp, IH, IW)
 
 
-def conv2d_wgrad(srcs, dout, kh, dil=1, z=None, scale=None, act=ACT_NONE, prelu=None, alpha=1.0):
+def grad_of(p):
+    """The tensor parameter gradients ACCUMULATE into: p.grad (a view into the flat gradient arena when an optimizer of
+    paif_amd.utils.optimizer owns the parameter; allocated as zeros otherwise).  None when p does not require grad."""
+    if p is None or not p.requires_grad:
+        return None
+    if p.grad is None:
+        p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+    if not p.grad.is_contiguous():
+        raise RuntimeError("parameter gradients must be dense")
+    return p.grad
+
+
+def conv2d_wgrad(srcs, dout, kh, dil=1, z=None, scale=None, act=ACT_NONE, prelu=None, alpha=1.0, out=None, cout=32):
     """Weight gradient of the dense conv over the virtual concat of `srcs` (NHWC [B,H,W,32] each):
-    returns dW [32, 32*len(srcs), kh, kh].  dout NHWC [B,H,W,32]; z = saved pre-activation when act != none."""
+    dW [cout, 32*len(srcs), kh, kh]; ACCUMULATED into `out` when given, else returned fresh.
+    dout NHWC [B,H,W,32] (zero padded when cout < 32); z = saved pre-activation when act != none."""
     B, H, W, C = srcs[0].shape
     assert C == 32 and tuple(dout.shape) == (B, H, W, 32) and 1 <= len(srcs) <= 3
     L = lib()
@@ -566,37 +619,257 @@ def conv2d_wgrad(srcs, dout, kh, dil=1, z=None, scale=None, act=ACT_NONE, prelu=
     for s_ in srcs:
         _p(s_)
     ws = torch.empty(L.paif_conv2d_wgrad_workspace_floats(len(srcs), kh, B, H), device=dout.device, dtype=torch.float32)
-    dw = torch.empty((32, 32 * len(srcs), kh, kh), device=dout.device, dtype=torch.float32)
-    _lib.check(L.paif_conv2d_wgrad(ptrs, len(srcs), _p(dout), _p(z), _p(scale), _p(prelu), act, alpha, kh, dil, _p(ws), _p(dw), B, H, W,
-                                   _stream()), "conv2d_wgrad")
+    acc = out is not None
+    dw = out if acc else torch.empty((cout, 32 * len(srcs), kh, kh), device=dout.device, dtype=torch.float32)
+    assert dw.numel() == cout * 32 * len(srcs) * kh * kh
+    _lib.check(L.paif_conv2d_wgrad(ptrs, len(srcs), _p(dout), _p(z), _p(scale), _p(prelu), act, alpha, kh, dil, _p(ws), _p(dw), cout,
+                                   int(acc), B, H, W, _stream()), "conv2d_wgrad")
     return dw
 
 
-def gemm_wgrad(dy, x, want_bias=True):
-    """Linear-layer gradients: dy [..., N], x [..., K] (same leading shape) -> (dW [N, K], db [N] or None)."""
-    N, K = dy.shape[-1], x.shape[-1]
-    M = dy.numel() // N
-    assert x.numel() // K == M
+def gemm_wgrad(dy, x, want_bias=True, out_w=None, out_b=None, n=None, k=None):
+    """Linear-layer gradients: dy [..., ldy], x [..., ldx] (same leading shape) -> (dW [N, K], db [N] or None).
+    n / k: use only the first n columns of dy / k columns of x.  out_w / out_b: ACCUMULATE into these instead."""
+    lddy, ldx = dy.shape[-1], x.shape[-1]
+    N, K = n or lddy, k or ldx
+    M = dy.numel() // lddy
+    assert x.numel() // ldx == M
     L = lib()
     splits = L.paif_gemm_wgrad_splits(M, N, K)
     ws = torch.empty(splits * (N * K + N), device=dy.device, dtype=torch.float32)
-    dw = torch.empty((N, K), device=dy.device, dtype=torch.float32)
-    db = torch.empty(N, device=dy.device, dtype=torch.float32) if want_bias else None
-    _lib.check(L.paif_gemm_wgrad(_p(dy), N, _p(x), K, _p(dw), _p(db), M, N, K, splits, _p(ws), _stream()), "gemm_wgrad")
+    acc = out_w is not None
+    dw = out_w if acc else torch.empty((N, K), device=dy.device, dtype=torch.float32)
+    assert dw.numel() == N * K
+    if acc:
+        db = out_b
+        assert db is None or db.numel() == N
+    else:
+        db = torch.empty(N, device=dy.device, dtype=torch.float32) if want_bias else None
+    _lib.check(L.paif_gemm_wgrad(_p(dy), lddy, _p(x), ldx, _p(dw), _p(db), M, N, K, splits, _p(ws), int(acc), _stream()), "gemm_wgrad")
     return dw, db
 
 
-def layernorm_wgrad(x, dy, eps):
-    """LayerNorm affine gradients: x, dy [..., C] -> (dgamma [C], dbeta [C])."""
+def layernorm_wgrad(x, dy, eps, out_g=None, out_b=None):
+    """LayerNorm affine gradients: x, dy [..., C] -> (dgamma [C], dbeta [C]); accumulated into out_g / out_b when given."""
     C = x.shape[-1]
     M = x.numel() // C
     assert dy.shape == x.shape
     L = lib()
     ws = torch.empty(L.paif_layernorm_wgrad_blocks(M) * 2 * C, device=x.device, dtype=torch.float32)
-    dg = torch.empty(C, device=x.device, dtype=torch.float32)
-    db = torch.empty(C, device=x.device, dtype=torch.float32)
-    _lib.check(L.paif_layernorm_wgrad(_p(x), _p(dy), _p(dg), _p(db), _p(ws), M, C, eps, _stream()), "layernorm_wgrad")
+    acc = out_g is not None
+    assert acc == (out_b is not None)
+    dg = out_g if acc else torch.empty(C, device=x.device, dtype=torch.float32)
+    db = out_b if acc else torch.empty(C, device=x.device, dtype=torch.float32)
+    _lib.check(L.paif_layernorm_wgrad(_p(x), _p(dy), _p(dg), _p(db), _p(ws), M, C, eps, int(acc), _stream()), "layernorm_wgrad")
     return dg, db
+
+
+# ---------------------------------------------------------------------------------------------
+# training step (csrc/train_kernels.hip): every *_wgrad ACCUMULATES into its `out` tensors
+# ---------------------------------------------------------------------------------------------
+def _rr_ws(M, C, nacc, device, mult=1):
+    n = lib().paif_row_reduce_workspace_floats(M, C, nacc)
+    if n == 0:
+        raise NotImplementedError("row reduction over %d channels is not built (C/4 must be a power of two < 32 or a multiple of 32)" % C)
+    return torch.empty(mult * n, device=device, dtype=torch.float32)
+
+
+def nhwc_slice_to_nchw(x, C):
+    """x NHWC [B,H,W,ld] -> NCHW [B,C,H,W] of channels [0,C)."""
+    B, H, W, ld = x.shape
+    y = torch.empty((B, C, H, W), device=x.device, dtype=torch.float32)
+    _lib.check(lib().paif_nhwc_slice_to_nchw_fwd(_p(x), _p(y), B, H * W, C, ld, _stream()), "nhwc_slice_to_nchw")
+    return y
+
+
+def decomp_cat(x, lf):
+    """x [B,H,W,32], lf [2,B,H,W,32] -> (cat(LF0, LF1), cat(x-LF0, x-LF1)) as NHWC [B,H,W,64] each."""
+    B, H, W, _ = x.shape
+    lfc = torch.empty((B, H, W, 64), device=x.device, dtype=torch.float32)
+    hfc = torch.empty_like(lfc)
+    _lib.check(lib().paif_decomp_cat_fwd(_p(x), _p(lf), _p(lfc), _p(hfc), B * H * W, _stream()), "decomp_cat")
+    return lfc, hfc
+
+
+def pad_channels(x, cd):
+    cs = x.shape[-1]
+    y = torch.empty(x.shape[:-1] + (cd,), device=x.device, dtype=torch.float32)
+    _lib.check(lib().paif_pad_channels_fwd(_p(x), _p(y), x.numel() // cs, cs, cd, _stream()), "pad_channels")
+    return y
+
+
+def bn_stats(x, gamma, beta, eps, momentum, running_mean, running_var):
+    """Train-mode BatchNorm statistics of x [..., C] -> (mean, invstd, scale, shift); running stats updated in place."""
+    C = x.shape[-1]
+    M = x.numel() // C
+    st = torch.empty((4, C), device=x.device, dtype=torch.float32)
+    ws = _rr_ws(M, C, 2, x.device, mult=2)
+    _lib.check(lib().paif_bn_stats_fwd(_p(x), M, C, _p(gamma), _p(beta), eps, momentum, _p(running_mean), _p(running_var), _p(st[0]),
+                                       _p(st[1]), _p(st[2]), _p(st[3]), _p(ws), _stream()), "bn_stats")
+    return st[0], st[1], st[2], st[3]
+
+
+def affine_act_res(x, scale, shift, act=ACT_NONE, prelu=None, res=(), want_z=False):
+    """act(x*scale[c] + shift[c]) + res[0] + res[1] (+ further residuals as plain adds); optionally also the pre-activation."""
+    C = x.shape[-1]
+    res = [r for r in res if r is not None]
+    out = torch.empty_like(x)
+    z = torch.empty_like(x) if want_z else None
+    _lib.check(lib().paif_affine_act_res_fwd(_p(x), _p(scale), _p(shift), act, _p(prelu), _p(res[0]) if res else None,
+                                             _p(res[1]) if len(res) > 1 else None, _p(out), _p(z), x.numel() // C, C, _stream()),
+               "affine_act_res")
+    for r in res[2:]:
+        out = add(out, r)
+    return (out, z) if want_z else out
+
+
+def bn_act_bwd(g, x, stats, act=ACT_NONE, prelu=None, d_gamma=None, d_beta=None, d_slope=None):
+    """Backward of act(BN_train(x)) (stats = (mean, invstd, scale, shift) of bn_stats): returns dx; accumulates the
+    affine / slope gradients into d_gamma, d_beta, d_slope (any may be None)."""
+    C = x.shape[-1]
+    M = x.numel() // C
+    mean, invstd, scale, shift = stats
+    dx = torch.empty_like(x)
+    sums = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+    ws = _rr_ws(M, C, 3, x.device)
+    _lib.check(lib().paif_bn_act_bwd(_p(g), _p(x), _p(scale), _p(shift), _p(mean), _p(invstd), act, _p(prelu), _p(dx), _p(d_gamma),
+                                     _p(d_beta), _p(d_slope), _p(sums), _p(ws), M, C, _stream()), "bn_act_bwd")
+    return dx
+
+
+def prelu_bwd(t, r, prelu, d_slope, add=None, want_dx=False, factor=1.0):
+    """d_slope[0] += factor * sum t*r over r<0; with want_dx also returns t*P'(r) (+ add)."""
+    assert t.shape == r.shape and t.numel() % 4 == 0
+    dx = torch.empty_like(t) if want_dx else None
+    ws = torch.empty(2048, device=t.device, dtype=torch.float32)
+    if d_slope is None:   # slope frozen: only the input gradient is wanted
+        d_slope = torch.zeros(1, device=t.device, dtype=torch.float32)
+    _lib.check(lib().paif_prelu_bwd(_p(t), _p(r), _p(add), _p(prelu), factor, _p(dx), _p(d_slope), _p(ws), t.numel(), _stream()), "prelu_bwd")
+    return dx
+
+
+def tail_dz(dfused, fused, z, prelu, d_slope):
+    dz = torch.empty_like(fused)
+    ws = torch.empty(2048, device=fused.device, dtype=torch.float32)
+    if d_slope is None:
+        d_slope = torch.zeros(1, device=fused.device, dtype=torch.float32)
+    _lib.check(lib().paif_tail_dz(_p(dfused.contiguous()), _p(fused), _p(z), _p(prelu), _p(dz), _p(d_slope), _p(ws), fused.numel(), _stream()),
+               "tail_dz")
+    return dz
+
+
+def colsum(x, out, ncols=None):
+    """out[c] += column sums of x [..., ld] (first ncols columns)."""
+    ld = x.shape[-1]
+    C = ncols or ld
+    M = x.numel() // ld
+    ws = _rr_ws(M, C, 1, x.device)
+    _lib.check(lib().paif_colsum(_p(x), ld, _p(out), _p(ws), M, C, _stream()), "colsum")
+    return out
+
+
+def dwconv_wgrad(x, dy, k, dil, in_relu, out_w, out_b=None):
+    """Depthwise-conv gradients accumulated into out_w [C,1,k,k] (and out_b [C])."""
+    B, H, W, C = x.shape
+    assert dy.shape == x.shape and out_w.numel() == C * k * k
+    ws = _rr_ws(B * H * W, C, k * k + 1, x.device)
+    _lib.check(lib().paif_dwconv_wgrad(_p(x), _p(dy), _p(out_w), _p(out_b), _p(ws), k, dil, int(in_relu), B, H, W, C, _stream()), "dwconv_wgrad")
+
+
+def stem_wgrad(img, dfeat, w, prelu, out_w, out_slope):
+    """stem conv (1->32, 3x3) + PReLU gradients accumulated into out_w [32,1,3,3], out_slope [1]."""
+    B, _, H, W = img.shape
+    if img.stride(3) != 1 or img.stride(2) != W:
+        img = img.contiguous()
+    bstride = img.stride(0) if B > 1 else H * W
+    ws = _rr_ws(B * H * W, 32, 10, dfeat.device)
+    dev = dfeat.device
+    ow = out_w if out_w is not None else torch.zeros(32 * 9, device=dev)
+    osl = out_slope if out_slope is not None else torch.zeros(1, device=dev)
+    _lib.check(lib().paif_stem_wgrad(ctypes.c_void_p(img.data_ptr()), bstride, _p(dfeat), _p(w.detach()), _p(prelu), _p(ow), _p(osl), _p(ws),
+                                     B, H, W, _stream()), "stem_wgrad")
+
+
+def corr1_wgrad(s, m, k, out_w):
+    """out_w [1,Cm,k,k] += sum_px s[px] * m[px+tap][c]   (s [B,H,W] or [B,1,H,W], m NHWC [B,H,W,Cm])."""
+    B, H, W, Cm = m.shape
+    assert s.numel() == B * H * W and out_w.numel() == Cm * k * k
+    ws = _rr_ws(B * H * W, Cm, k * k, m.device)
+    _lib.check(lib().paif_corr1_wgrad(_p(s), _p(m), _p(out_w), _p(ws), Cm, k, B, H, W, _stream()), "corr1_wgrad")
+
+
+def eca_wgrad(pool_partial, dgate_partial, gate, k, out_w, B, H, W):
+    _lib.check(lib().paif_eca_wgrad(_p(pool_partial), _p(dgate_partial), dgate_partial.shape[1], _p(gate), k, _p(out_w), B, H, W, _stream()),
+               "eca_wgrad")
+
+
+def unfold_decomp1x1_wgrad(G, out_w):
+    assert G.numel() == 32 * 96 and out_w.numel() == 32 * 128
+    _lib.check(lib().paif_unfold_decomp1x1_wgrad(_p(G), _p(out_w), _stream()), "unfold_decomp1x1_wgrad")
+
+
+def unpack_conv_gemm_wgrad(dwp, out_w):
+    Cout, Cin, k, _ = out_w.shape
+    _lib.check(lib().paif_unpack_conv_gemm_wgrad(_p(dwp), _p(out_w), Cout, Cin, k, dwp.shape[1], _stream()), "unpack_conv_gemm_wgrad")
+
+
+class DropRNG:
+    """Counter-based random stream of the stochastic layers (DropPath, Dropout2d): mask i of a call is the uniform
+    u(seed, offset + i) of paif_keep_mask (= paif_amd.synthetic.hash_uniform), offset advancing by the mask size per call
+    -- reproducible from (seed, rank, step) alone."""
+
+    def __init__(self, seed=0):
+        self.reseed(seed)
+
+    def reseed(self, seed, rank=0, step=0):
+        self.seed = (int(seed) * 1000003 + int(rank) * 7919 + int(step) * 104729) & 0xFFFFFFFF
+        self.offset = 0
+
+    def keep_mask(self, n, p, device):
+        out = torch.empty(n, device=device, dtype=torch.float32)
+        _lib.check(lib().paif_keep_mask(_p(out), n, self.seed, self.offset, float(p), _stream()), "keep_mask")
+        self.offset += n
+        return out
+
+
+DROP_RNG = DropRNG(0)
+
+
+def rowscale_add(x, s, res=None, per_channel=False):
+    """x [B, ..., C] * s[b] (or s[b, c]) + res."""
+    B, C = x.shape[0], x.shape[-1]
+    out = torch.empty_like(x)
+    _lib.check(lib().paif_rowscale_add_fwd(_p(x), _p(s), _p(res), _p(out), B, x.numel() // (B * C), C, int(per_channel), _stream()),
+               "rowscale_add")
+    return out
+
+
+class UpsampleCE(torch.autograd.Function):
+    """CrossEntropyLoss(ignore_index)(F.interpolate(seg_map, label.shape[1:], bilinear, align_corners=False), label) as the
+    fused HIP kernels paif_upsample_ce_fwd / _bwd (attack/attack.py:103-114,446-448; core/model_fusion_auto.py:1096-1098)."""
+
+    @staticmethod
+    def forward(ctx, seg_map, label, ignore_index):
+        logits = to_nhwc(seg_map.detach())
+        lc = upsample_ce_fwd(logits, label, ignore_index)
+        ctx.save_for_backward(logits, label, lc)
+        ctx.ignore_index = ignore_index
+        return lc[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, label, lc = ctx.saved_tensors
+        gscale = (g.reshape(1).to(torch.float32) / lc[1:2]).contiguous()      # dloss / #valid (1-element tensor)
+        d32 = upsample_ce_bwd(logits, label, gscale, ignore_index=ctx.ignore_index)
+        return nhwc_slice_to_nchw(d32, logits.shape[-1]), None, None
+
+
+def upsample_ce(seg_map, label, ignore_index=255):
+    """seg_map [B,C,h,w] (any strides), label int64 [B,H,W] -> mean NLL over the valid pixels (differentiable w.r.t. seg_map)."""
+    label = label.contiguous()
+    if torch.is_grad_enabled() and seg_map.requires_grad:
+        return UpsampleCE.apply(seg_map, label, ignore_index)
+    return upsample_ce_fwd(to_nhwc(seg_map.detach()), label, ignore_index)[0]
 
 
 _SSIM_WINDOW = {}
@@ -632,8 +905,8 @@ def ssim_l1(x, y):
     g = _ssim_window(x.device)
     L = lib()
     partial = torch.empty((L.paif_ssim_l1_blocks(B, H, W), 2), device=x.device, dtype=torch.float32)
-    _lib.check(L.paif_ssim_l1_fwd(_p(x), _p(y), _p(g), _p(partial), B, H, W, _stream()), "ssim_l1")
-    s = partial.sum(0) / float(B * H * W)
+    s = torch.empty(2, device=x.device, dtype=torch.float32)
+    _lib.check(L.paif_ssim_l1_fwd(_p(x), _p(y), _p(g), _p(partial), _p(s), B, H, W, _stream()), "ssim_l1")
     return s[0], s[1]
 
 

@@ -1,0 +1,125 @@
+"""GPU parity of the hand-written reverse pass AT THE SIZE THE PGD CONFIGURATION RUNS (BASELINE configs[3]: 480x640, mit_b3):
+the small-shape gradient tests never reach Nk = 300 keys / N = 19,200 queries in the SR attention (64x96 has Nk = 6), the
+guided-filter backward's 60-row segment seams, or the split-K / persistent dispatch of the dgrad GEMMs and convs.
+Checker: the pinned CPU oracle's autograd (oracle/paif_oracle.py), run on the host beside the GPU (fp64 where the
+reference's own fp32 noise floor would otherwise be the limit)."""
+import numpy as np
+import pytest
+import torch
+
+from paif_amd import ops, synthetic as S
+from tests.helpers import t, maxabs
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _exact_convs():
+    old = ops.CONFIG["conv_precision"]
+    ops.set_conv_precision("f32")
+    yield
+    ops.set_conv_precision(old)
+
+
+@pytest.mark.parametrize("B,N,Nk,C,heads", [
+    (1, 19200, 300, 64, 1),     # mit_b3 stage 1 at 480x640: the longest query axis, one head
+    (2, 4800, 300, 128, 2),     # stage 2
+    (1, 1200, 300, 320, 5),     # stage 3 (head_dim 64, 5 heads)
+    (1, 300, 300, 512, 8),      # stage 4: sr = 1, keys = queries
+])
+def test_sr_attention_forward_backward_at_480x640_token_counts(B, N, Nk, C, heads):
+    """core/mix_transformer.py:93-115 (softmax(q k^T * hd^-0.5) v) and its autograd, vs torch in float64."""
+    g = torch.Generator().manual_seed(N + C)
+    q = torch.randn(B, N, C, generator=g)
+    kv = torch.randn(B, Nk, 2 * C, generator=g)
+    dout = torch.randn(B, N, C, generator=g)
+    dev = _dev()
+    qd, kvd = q.to(dev), kv.to(dev)
+    out, lse = ops.sr_attention(qd, kvd, heads, want_lse=True)
+    dq, dkv = ops.sr_attention_bwd(qd, kvd, out, dout.to(dev), lse, heads)
+    hd = C // heads
+    q64 = q.double().requires_grad_(True)
+    kv64 = kv.double().requires_grad_(True)
+    qh = q64.reshape(B, N, heads, hd).permute(0, 2, 1, 3)
+    kvh = kv64.reshape(B, Nk, 2, heads, hd).permute(2, 0, 3, 1, 4)
+    attn = ((qh @ kvh[0].transpose(-2, -1)) * hd ** -0.5).softmax(dim=-1)
+    ref = (attn @ kvh[1]).transpose(1, 2).reshape(B, N, C)
+    (ref * dout.double()).sum().backward()
+    assert maxabs(out.cpu().double(), ref.detach()) <= 2e-6 * float(ref.abs().max())
+    for mine, r in ((dq, q64.grad), (dkv, kv64.grad)):
+        assert maxabs(mine.cpu().double(), r) <= 2e-5 * float(r.abs().max()), (B, N, Nk, C, heads)
+
+
+def test_guided_filter_backward_at_480x640_across_segment_seams():
+    """Cell_Decom.decomposition (core/model_fusion_auto.py:517-535) backward on one 480x640 32-channel map: the HIP kernels
+    stream 60-row segments; the gradient (incl. the guide's arg-max / arg-min routing) must match the oracle's autograd in
+    float64 at least as well as the oracle's own float32 run does."""
+    from oracle import paif_oracle as O
+
+    H, W = 480, 640
+    x = t(S.make_smooth_feature(71, 1, 32, H, W))
+    r = [t(S.make_feature(72 + e, (1, 32, H, W))) for e in range(2)]
+    dev = _dev()
+    xn = ops.to_nhwc(x.to(dev))
+    guide = ops.channel_residue(xn)
+    lf, ab = ops.guided_filter_pair(guide, xn, want_ab=True)
+    dlf = torch.stack([ops.to_nhwc(ri.to(dev)) for ri in r]).contiguous()
+    dx = ops.guided_filter_bwd(guide, xn, ab, dlf).permute(0, 3, 1, 2).cpu()
+
+    def oracle(dtype):
+        xx = x.to(dtype).requires_grad_(True)
+        res = O.get_residue(xx)
+        loss = sum((O.guided_filter(res, xx, 4, eps) * ri.to(dtype)).sum() for eps, ri in zip((0.001, 0.0001), r))
+        loss.backward()
+        return xx.grad
+
+    g64, g32 = oracle(torch.float64), oracle(torch.float32)
+    floor = maxabs(g32.double(), g64)                      # the reference arithmetic's own float32 error
+    scale = float(g64.abs().max())
+    err = maxabs(dx.double(), g64)
+    assert err <= max(1.5 * floor, 1e-4 * scale), (err, floor, scale)
+    # seam rows of the 60-row segments specifically
+    rows = [59, 60, 119, 120, 239, 240, 419, 420]
+    assert maxabs(dx[:, :, rows].double(), g64[:, :, rows]) <= max(1.5 * floor, 1e-4 * scale)
+
+
+def test_one_pgd_iteration_at_480x640_mit_b3_vs_oracle():
+    """One full attack_both iteration (attack/attack.py:443-512) at 1x480x640 through mit_b3, exact-fp32 convs: taped
+    forward, fused upsample+CE, hand-written reverse pass through both networks, vs the oracle's autograd on the host.
+    Stated tolerance: loss rel. 1e-4; sign-mismatch fraction of the gradient <= 2e-3; |delta| <= eps."""
+    from oracle import paif_oracle as O
+    from paif_amd.attack.attack import attack_both
+    from paif_amd.core.model_fusion_auto import Network_MM_Searched
+    from paif_amd.genotypes import FUSION_AT
+
+    m = Network_MM_Searched(32, FUSION_AT, None, None, "mit_b3", num_classes=9).eval()
+    S.load_formula_weights(m)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m.to(_dev())
+    ir, vis, lab = S.make_batch(1, 480, 640)
+    eps, alpha = 8 / 255., 2 / 255.
+    d0i = t(S.make_delta0(5, ir.shape, eps))
+    d0v = t(S.make_delta0(105, vis.shape, eps))
+    trace = []
+    with torch.no_grad():
+        d_ir, d_vis = attack_both(m, t(vis).to(_dev()), t(ir).to(_dev()), t(lab).to(_dev()), epsilon=eps, alpha=alpha, attack_iters=1,
+                                  attack_loss='l_seg', attack_way='PGD', delta0_ir=d0i, delta0_vis=d0v, trace=trace)
+    otrace = []
+    od_ir, od_vis = O.attack_both(lambda a, b: O.model_forward(a, b, sd, "mit_b3"), t(vis), t(ir), t(lab), d0i, d0v, epsilon=eps,
+                                  alpha=alpha, attack_iters=1, attack_way="PGD", trace=otrace)
+    assert abs(trace[0]["loss"] - otrace[0]["loss"]) <= 1e-4 * abs(otrace[0]["loss"])
+    for mine, ref in ((trace[0]["g_ir"], otrace[0]["g_ir"]), (trace[0]["g_vis"], otrace[0]["g_vis"])):
+        a, b = mine.cpu().numpy(), ref.numpy()
+        assert (np.sign(a) != np.sign(b)).mean() <= 2e-3
+        # magnitude parity where the gradient is not tiny
+        big = np.abs(b) > 1e-3 * np.abs(b).max()
+        assert np.abs(a[big] - b[big]).max() <= 2e-2 * np.abs(b).max()
+    for mine, ref in ((d_ir, od_ir), (d_vis, od_vis)):
+        a = mine.detach().cpu().numpy()
+        assert (np.abs(a - ref.numpy()) > 1e-6).mean() <= 2e-3
+        assert np.abs(a).max() <= eps + 1e-7

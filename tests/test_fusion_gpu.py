@@ -133,10 +133,47 @@ def test_dense_conv_persistent_kernel_ragged_edges(kh, dil, nsrc, nres, act):
     assert maxabs(outs["bf16x3"], outs["f32"]) <= 1e-4 * sc
 
 
+@pytest.mark.parametrize("kh,dil,nsrc,nres,act", [
+    (1, 1, 1, 0, 0), (1, 1, 2, 0, 1), (1, 1, 3, 0, 2),                       # 1x1 without residual maps
+    (3, 2, 1, 0, 0), (3, 2, 1, 1, 1), (3, 2, 1, 2, 2), (3, 2, 1, 3, 1),      # dilation 2 / one source, residual storer path NR = 0..3
+])
+def test_dense_conv_persistent_kernel_is_dispatched_and_correct(kh, dil, nsrc, nres, act):
+    """Every configuration the library routes to the persistent wave-specialised kernel (conv_bf16x3_ws), at >= 1024 tiles
+    with ragged edges: the dispatch is ASSERTED (kernel tag of the launch) and the result is checked against
+    torch.nn.functional.conv2d on the CPU -- an independent reference, not the repo's own fp32 kernel."""
+    from paif_amd import ops
+
+    B, H, W = 2, 331, 523      # 42 x 17 x 2 = 1428 tiles of 8 x 32, ragged in both directions
+    g = torch.Generator().manual_seed(7000 + kh * 100 + dil * 10 + nsrc + 5 * nres)
+    xs = [torch.randn(B, 32, H, W, generator=g) for _ in range(nsrc)]
+    rs = [torch.randn(B, 32, H, W, generator=g) for _ in range(nres)]
+    w = torch.randn(32, 32 * nsrc, kh, kh, generator=g) * 0.05
+    scale, shift = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.1
+    slope = torch.tensor([0.2])
+    ref = torch.nn.functional.conv2d(torch.cat(xs, 1), w, padding=dil * (kh - 1) // 2, dilation=dil)
+    ref = ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    ref = torch.where(ref >= 0, ref, ref * slope) if act == 1 else (ref.clamp_min(0) if act == 2 else ref)
+    ref = ref * 0.5 + sum(rs) if rs else ref * 0.5
+    dev = _dev()
+    timer = ops.KernelTimer(lambda tag: True)
+    ops.TIMER = timer
+    try:
+        wpk = ops.pack_conv_weight(w.to(dev), nsrc, 32, kh, precision="bf16x3")
+        y = ops.conv2d([ops.to_nhwc(x.to(dev)) for x in xs], wpk, kh, dil=dil, scale=scale.to(dev), shift=shift.to(dev), act=act,
+                       prelu=slope.to(dev) if act == 1 else None, alpha=0.5, res=tuple(ops.to_nhwc(r.to(dev)) for r in rs))
+    finally:
+        ops.TIMER = None
+    torch.cuda.synchronize()
+    assert list(timer.summary()) == ["conv_bf16x3_ws<%d,%d>" % (kh, dil)], list(timer.summary())
+    assert maxabs(y.permute(0, 3, 1, 2).cpu(), ref) <= 1e-4 * float(ref.abs().max())
+
+
 def test_dense_conv_seeded_shape_sweep():
     """40 seeded random configurations (shape, kernel size, dilation, sources, residuals, activation, affine on/off) of the
-    dense conv, split-bf16 kernels (persistent and tile-per-workgroup, chosen by the library) against the exact-fp32 MFMA
-    kernel: every dispatch path with ragged edges, odd sizes and tiny images."""
+    dense conv: the split-bf16 kernel the library picks against the exact-fp32 MFMA kernel, and -- on the small shapes --
+    against torch.nn.functional.conv2d on the CPU.  Ragged edges, odd sizes, tiny images.  (The persistent kernel's own
+    configurations are forced and asserted in test_dense_conv_persistent_kernel_is_dispatched_and_correct; of this sweep's
+    seeds only the tile-per-workgroup kernels are guaranteed.)"""
     import random
     from paif_amd import ops
 
@@ -166,6 +203,16 @@ def test_dense_conv_seeded_shape_sweep():
         sc = float(outs[0].abs().max())
         assert torch.isfinite(outs[1]).all()
         assert maxabs(outs[1].cpu(), outs[0].cpu()) <= 1e-4 * max(sc, 1.0), (it, kh, dil, nsrc, nres, act, B, H, W)
+        if B * H * W <= 20000:   # independent reference on the CPU
+            ref = torch.nn.functional.conv2d(torch.cat([x.permute(0, 3, 1, 2).cpu() for x in xs], 1), w.cpu(),
+                                             padding=dil * (kh - 1) // 2, dilation=dil)
+            if affine:
+                ref = ref * scale.cpu().view(1, -1, 1, 1) + shift.cpu().view(1, -1, 1, 1)
+            ref = torch.where(ref >= 0, ref, ref * 0.25) if act == 1 else (ref.clamp_min(0) if act == 2 else ref)
+            ref = ref * 0.75
+            for r in rs:
+                ref = ref + r.permute(0, 3, 1, 2).cpu()
+            assert maxabs(outs[0].permute(0, 3, 1, 2).cpu(), ref) <= 3e-5 * max(sc, 1.0), (it, kh, dil, nsrc, nres, act, B, H, W)
 
 
 def _fusion_net(prefix=""):
