@@ -397,7 +397,7 @@ int paif_u8_to_i64_fwd(const unsigned char* src, long long* dst, size_t n, paif_
 /* =============================================================================================
  * Training step (BASELINE configs[4]; csrc/train_kernels.hip).  Every gradient entry point ACCUMULATES
  * into its destination (like loss.backward() into .grad); reductions are two-pass in a fixed order (deterministic).
- * "rows" = NHWC pixels or tokens, M of them, C channels (C % 4 == 0; C/4 a power of two < 32 or a multiple of 32).
+ * "rows" = NHWC pixels or tokens, M of them, C channels (C % 4 == 0).
  * ============================================================================================= */
 
 /* NHWC [B,HW,ldx] channels [0,C) -> NCHW [B,C,HW] (gradient of the 9-class logits leaving the fused CE kernel). */
@@ -422,10 +422,14 @@ int paif_affine_act_res_fwd(const float* x, const float* scale, const float* shi
                             const float* res1, float* out, float* z_out, size_t M, int C, paif_stream_t stream);
 /* Backward of y = act(BN_train(x)):  z = x*scale+shift, dz = g*act'(z), xhat = (x-mean)*invstd,
  *   dbeta += sum dz, dgamma += sum dz*xhat, dslope += sum g*z over z<0 (PReLU), dx = scale*(dz - mean(dz) - xhat*mean(dz*xhat)).
+ * training == 0 (eval-mode BN, running statistics from paif_bn_eval_stats): dx = scale*dz, no batch-mean terms.
  * sums: 2*C floats scratch; workspace: paif_row_reduce_workspace_floats(M, C, 3). dgamma/dbeta/dslope may be NULL. */
 int paif_bn_act_bwd(const float* g, const float* x, const float* scale, const float* shift, const float* mean, const float* invstd,
                     int act, const float* prelu, float* dx, float* dgamma, float* dbeta, float* dslope, float* sums, float* workspace,
-                    int M, int C, paif_stream_t stream);
+                    int training, int M, int C, paif_stream_t stream);
+/* eval-mode nn.BatchNorm2d as the same statistics: mean = running_mean, invstd = 1/sqrt(running_var + eps), scale, shift. */
+int paif_bn_eval_stats(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, int C,
+                       float* mean, float* invstd, float* scale, float* shift, paif_stream_t stream);
 /* PReLU on an element stream: dx = t*P'(r) + add (dx, add optional), dslope[0] += factor * sum t*r over r<0
  * (nn.PReLU weight gradient, operations_m.py:441,460,392; workspace: 2048 floats). */
 int paif_prelu_bwd(const float* t, const float* r, const float* add, const float* prelu, float factor, float* dx, float* dslope,

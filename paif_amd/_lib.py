@@ -115,7 +115,8 @@ SIGNATURES = {
     "paif_row_reduce_workspace_floats": (c_size_t, [c_int, c_int, c_int]),
     "paif_bn_stats_fwd": (c_int, [F, c_int, c_int, F, F, c_float, c_float, F, F, F, F, F, F, F, F]),
     "paif_affine_act_res_fwd": (c_int, [F, F, F, c_int, F, F, F, F, F, c_size_t, c_int, F]),
-    "paif_bn_act_bwd": (c_int, [F, F, F, F, F, F, c_int, F, F, F, F, F, F, F, c_int, c_int, F]),
+    "paif_bn_act_bwd": (c_int, [F, F, F, F, F, F, c_int, F, F, F, F, F, F, F, c_int, c_int, c_int, F]),
+    "paif_bn_eval_stats": (c_int, [F, F, F, F, c_float, c_int, F, F, F, F, F]),
     "paif_prelu_bwd": (c_int, [F, F, F, F, c_float, F, F, F, c_size_t, F]),
     "paif_tail_dz": (c_int, [F, F, F, F, F, F, F, c_size_t, F]),
     "paif_colsum": (c_int, [F, c_int, F, F, c_int, c_int, F]),

@@ -103,7 +103,7 @@ def _attack(model, X_vis, X_ir, label, epsilon, alpha, attack_iters, restarts, a
             else:
                 xi = ops.add(X_ir, d_ir).requires_grad_(True)
                 xv = ops.add(X_vis, d_vis).requires_grad_(True)
-                with torch.enable_grad():
+                with torch.enable_grad(), ops.no_param_grads():
                     _, seg_map = model(xi, xv)
                     outputs = F.interpolate(seg_map, size=label.shape[1:], mode='bilinear', align_corners=False)
                     loss = _loss_variant(outputs, label, criterion, attack_way, i, attack_iters)
@@ -177,7 +177,7 @@ def _fresh_grad_attack(model, X_vis, X_ir, X_fusion, label, epsilon, alpha, atta
         delta = _init_delta(X, epsilon, delta0)
         for i in range(attack_iters):
             xa = ops.add(X, delta).requires_grad_(True)
-            with torch.enable_grad():
+            with torch.enable_grad(), ops.no_param_grads():
                 fused, seg_map = model(X_ir, xa) if mode == 'vis' else model(xa, X_vis)
                 loss = loss_fn(fused, seg_map, i)
             g = torch.autograd.grad(loss, [xa])[0]

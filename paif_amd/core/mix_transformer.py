@@ -3,8 +3,8 @@ core/mix_transformer.py (NVIDIA SegFormer code).  Same classes, constructor argu
 state_dict keys; forward bodies launch the gfx950 kernels (fp32 MFMA GEMM, fused SR attention, LayerNorm,
 depthwise-conv+GELU).  Tokens [B,N,C] are NHWC images, so the encoder never transposes.
 
-Inference only for now: DropPath is identity in eval (core/mix_transformer.py:126; timm semantics) and
-train-mode forward raises until the training kernels exist.
+Forward, input-gradient and parameter-gradient passes; DropPath (timm semantics, core/mix_transformer.py:126) is the
+identity in eval and a per-sample keep/scale in train mode (counter-based stream, ops.DROP_RNG).
 """
 import math
 from functools import partial
@@ -38,16 +38,23 @@ def _init_weights(m):
 
 
 class DropPath(nn.Module):
-    """Stochastic depth (timm.models.layers.DropPath): identity when p == 0 or in eval."""
+    """Stochastic depth (timm.models.layers.DropPath, core/mix_transformer.py:126,152-153): identity when p == 0 or in eval;
+    in train mode each sample's branch is kept with probability 1-p and scaled by 1/(1-p).  The per-sample factors come
+    from the counter-based stream ops.DROP_RNG (reproducible from seed / rank / step); `Block` applies them."""
 
     def __init__(self, drop_prob=0.0):
         super().__init__()
         self.drop_prob = drop_prob
 
-    def forward(self, x):
+    def sample_scale(self, B, device):
+        """-> per-sample factors [B] (0 or 1/(1-p)), or None when the layer is the identity."""
         if self.drop_prob == 0.0 or not self.training:
-            return x
-        raise NotImplementedError("train-mode DropPath belongs to the training step (not built yet)")
+            return None
+        return ops.DROP_RNG.keep_mask(B, self.drop_prob, device)
+
+    def forward(self, x):
+        s = self.sample_scale(x.shape[0], x.device)
+        return x if s is None else ops.rowscale_add(x.contiguous(), s)
 
 
 class DWConv(nn.Module):
@@ -76,24 +83,71 @@ class Mlp(nn.Module):
         self.apply(_init_weights)
 
     def forward_tokens(self, x, H, W, res, tape=None):
-        """x [B,N,C] -> fc2(gelu(dwconv(fc1 x))) + res."""
+        """x [B,N,C] -> fc2(gelu(dwconv(fc1 x))) + res   (res None: the bare branch)."""
         B, N, _ = x.shape
         hid1 = ops.gemm(x, self.fc1.weight, shift=self.fc1.bias)
         hid = ops.dwconv3_bias_gelu(hid1.view(B, H, W, -1), self.dwconv.dwconv.weight, self.dwconv.dwconv.bias).view(B, N, -1)
         if tape is not None:
             tape.update(hid1=hid1, H=H, W=W)
+            if ops.taping_wgrad():
+                tape.update(x=x, hid=hid)
         return ops.gemm(hid, self.fc2.weight, shift=self.fc2.bias, res=res)
 
-    def backward_tokens(self, dy, tape):
-        """dy = d/d(fc2 output) -> d/d(x) (input gradient only)."""
+    def backward_tokens(self, dy, tape, wgrad=False):
+        """dy = d/d(fc2 output) -> d/d(x); wgrad: fc1 / dwconv / fc2 parameter gradients too."""
         B, N, _ = dy.shape
         H, W = tape["H"], tape["W"]
         fc2t = self._packs.get("fc2T", [self.fc2.weight], lambda: ops.transpose_pad(self.fc2.weight))
         fc1t = self._packs.get("fc1T", [self.fc1.weight], lambda: ops.transpose_pad(self.fc1.weight))
         d_h2 = ops.gemm(dy, fc2t)
-        d_h1 = ops.dwconv3_bias_gelu_bwd(tape["hid1"].view(B, H, W, -1), self.dwconv.dwconv.weight, self.dwconv.dwconv.bias,
-                                         d_h2.view(B, H, W, -1)).view(B, N, -1)
+        dw = self.dwconv.dwconv
+        hid1 = tape["hid1"].view(B, H, W, -1)
+        if not wgrad:
+            d_h1 = ops.dwconv3_bias_gelu_bwd(hid1, dw.weight, dw.bias, d_h2.view(B, H, W, -1)).view(B, N, -1)
+            return ops.gemm(d_h1, fc1t)
+        _linear_wgrad(self.fc2, dy, tape["hid"])
+        d_h1, d_pre = ops.dwconv3_bias_gelu_bwd(hid1, dw.weight, dw.bias, d_h2.view(B, H, W, -1), want_dpre=True)
+        gw, gb = ops.grad_of(dw.weight), ops.grad_of(dw.bias)
+        if gw is not None or gb is not None:
+            C = hid1.shape[-1]
+            ops.dwconv_wgrad(hid1, d_pre, 3, 1, False, gw if gw is not None else torch.zeros(C * 9, device=dy.device), gb)
+        d_h1 = d_h1.view(B, N, -1)
+        _linear_wgrad(self.fc1, d_h1, tape["x"])
         return ops.gemm(d_h1, fc1t)
+
+
+def _linear_wgrad(lin, dy, x):
+    """nn.Linear parameter gradients accumulated into .grad (dW = dy^T x, db = column sums of dy)."""
+    gw, gb = ops.grad_of(lin.weight), ops.grad_of(lin.bias) if lin.bias is not None else None
+    if gw is None and gb is None:
+        return
+    if gw is None:
+        ops.colsum(dy, gb)
+        return
+    ops.gemm_wgrad(dy, x, out_w=gw, out_b=gb)
+
+
+def _ln_wgrad(norm, x, dy):
+    """nn.LayerNorm affine gradients accumulated into .grad."""
+    gg, gb = ops.grad_of(norm.weight), ops.grad_of(norm.bias)
+    if gg is None and gb is None:
+        return
+    C = x.shape[-1]
+    z = lambda: torch.zeros(C, device=x.device, dtype=torch.float32)
+    ops.layernorm_wgrad(x, dy, norm.eps, gg if gg is not None else z(), gb if gb is not None else z())
+
+
+def _conv_as_gemm_wgrad(conv, d_out, col):
+    """Gradients of a conv evaluated as im2col + GEMM (patch embeddings, SR convs): d_out [.., Cout], col [.., Kpad]."""
+    gw, gb = ops.grad_of(conv.weight), ops.grad_of(conv.bias) if conv.bias is not None else None
+    if gw is None and gb is None:
+        return
+    Cout, kpad = d_out.shape[-1], col.shape[-1]
+    dwp, _ = ops.gemm_wgrad(d_out.reshape(-1, Cout), col.reshape(-1, kpad), want_bias=False)
+    if gb is not None:
+        ops.colsum(d_out, gb)
+    if gw is not None:
+        ops.unpack_conv_gemm_wgrad(dwp, gw)
 
 
 class Attention(nn.Module):
@@ -121,7 +175,7 @@ class Attention(nn.Module):
         self.apply(_init_weights)
 
     def forward_tokens(self, x, H, W, res, tape=None):
-        """x = norm1(tokens) [B,N,C]; returns proj(attn) + res."""
+        """x = norm1(tokens) [B,N,C]; returns proj(attn) + res   (res None: the bare branch)."""
         B, N, C = x.shape
         q = ops.gemm(x, self.q.weight, shift=self.q.bias)
         x_sr = None
@@ -139,10 +193,12 @@ class Attention(nn.Module):
         else:
             o, lse = ops.sr_attention(q, kv, self.num_heads, want_lse=True)
             tape.update(q=q, kv=kv, o=o, lse=lse, x_sr=x_sr, H=H, W=W)
+            if ops.taping_wgrad():
+                tape.update(x=x, x_kv=x_)
         return ops.gemm(o, self.proj.weight, shift=self.proj.bias, res=res)
 
-    def backward_tokens(self, dy, tape):
-        """dy = d/d(proj output) -> d/d(x) where x = norm1(tokens) (input gradient only)."""
+    def backward_tokens(self, dy, tape, wgrad=False):
+        """dy = d/d(proj output) -> d/d(x) where x = norm1(tokens); wgrad: q / kv / sr / norm / proj parameter gradients too."""
         B, N, C = dy.shape
         H, W = tape["H"], tape["W"]
         pt = self._packs.get("projT", [self.proj.weight], lambda: ops.transpose_pad(self.proj.weight))
@@ -151,11 +207,19 @@ class Attention(nn.Module):
         d_o = ops.gemm(dy, pt)
         dq, dkv = ops.sr_attention_bwd(tape["q"], tape["kv"], tape["o"], d_o, tape["lse"], self.num_heads)
         d_xkv = ops.gemm(dkv, kvt)
+        if wgrad:
+            _linear_wgrad(self.proj, dy, tape["o"])
+            _linear_wgrad(self.kv, dkv, tape["x_kv"])
+            _linear_wgrad(self.q, dq, tape["x"])
         if self.sr_ratio > 1:
             sr = self.sr_ratio
             wsr = self._packs.get("sr", [self.sr.weight], lambda: ops.pack_conv_gemm_weight(self.sr.weight))
             wsrt = self._packs.get("srT", [self.sr.weight], lambda: ops.transpose_pad(wsr))
+            if wgrad:
+                _ln_wgrad(self.norm, tape["x_sr"], d_xkv)
             d_sr = ops.layernorm_bwd(tape["x_sr"], self.norm.weight, d_xkv, self.norm.eps)
+            if wgrad:   # the SR conv's im2col columns are rebuilt from the saved input (cheaper than keeping them)
+                _conv_as_gemm_wgrad(self.sr, d_sr, ops.im2col(tape["x"].view(B, H, W, C), sr, sr, 0, wsr.shape[1]))
             d_col = ops.gemm(d_sr, wsrt)
             d_xkv = ops.col2im(d_col, B, H, W, C, sr, sr, 0).view(B, N, C)
         return ops.gemm(dq, qt, res=d_xkv)
@@ -176,22 +240,41 @@ class Block(nn.Module):
         self.apply(_init_weights)
 
     def forward_tokens(self, x, H, W, tape=None):
-        if self.training and isinstance(self.drop_path, DropPath) and self.drop_path.drop_prob > 0:
-            raise NotImplementedError("train-mode DropPath belongs to the training step (not built yet); call .eval()")
+        """x + drop_path(attn(norm1(x))), then + drop_path(mlp(norm2(.)))   (core/mix_transformer.py:151-155)."""
         t_attn = t_mlp = None
         if tape is not None:
             t_attn, t_mlp = {}, {}
-        x1 = self.attn.forward_tokens(ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps), H, W, res=x, tape=t_attn)
-        x2 = self.mlp.forward_tokens(ops.layernorm(x1, self.norm2.weight, self.norm2.bias, self.norm2.eps), H, W, res=x1, tape=t_mlp)
+        dp = self.drop_path if isinstance(self.drop_path, DropPath) else None
+        B = x.shape[0]
+        ln1 = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        s1 = dp.sample_scale(B, x.device) if dp is not None else None
+        if s1 is None:
+            x1 = self.attn.forward_tokens(ln1, H, W, res=x, tape=t_attn)
+        else:   # stochastic depth: the residual add moves out of the GEMM epilogue
+            x1 = ops.rowscale_add(self.attn.forward_tokens(ln1, H, W, res=None, tape=t_attn), s1, x)
+        ln2 = ops.layernorm(x1, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        s2 = dp.sample_scale(B, x.device) if dp is not None else None
+        if s2 is None:
+            x2 = self.mlp.forward_tokens(ln2, H, W, res=x1, tape=t_mlp)
+        else:
+            x2 = ops.rowscale_add(self.mlp.forward_tokens(ln2, H, W, res=None, tape=t_mlp), s2, x1)
         if tape is not None:
-            tape.append(dict(x=x, x1=x1, attn=t_attn, mlp=t_mlp))
+            tape.append(dict(x=x, x1=x1, attn=t_attn, mlp=t_mlp, s1=s1, s2=s2))
         return x2
 
-    def backward_tokens(self, d_x2, t):
-        d_ln2 = self.mlp.backward_tokens(d_x2, t["mlp"])
+    def backward_tokens(self, d_x2, t, wgrad=False):
+        d_b2 = d_x2 if t["s2"] is None else ops.rowscale_add(d_x2, t["s2"])
+        d_ln2 = self.mlp.backward_tokens(d_b2, t["mlp"], wgrad)
+        if wgrad:
+            _ln_wgrad(self.norm2, t["x1"], d_ln2)
         d_x1 = ops.layernorm_bwd(t["x1"], self.norm2.weight, d_ln2, self.norm2.eps, add=d_x2)
-        d_ln1 = self.attn.backward_tokens(d_x1, t["attn"])
-        return ops.layernorm_bwd(t["x"], self.norm1.weight, d_ln1, self.norm1.eps, add=d_x1)
+        d_b1 = d_x1 if t["s1"] is None else ops.rowscale_add(d_x1, t["s1"])
+        d_ln1 = self.attn.backward_tokens(d_b1, t["attn"], wgrad)
+        if wgrad:
+            _ln_wgrad(self.norm1, t["x"], d_ln1)
+        d_x = ops.layernorm_bwd(t["x"], self.norm1.weight, d_ln1, self.norm1.eps, add=d_x1)
+        ops.grads_ready(self)
+        return d_x
 
 
 def _make_norm(norm_layer, dim):
@@ -228,17 +311,22 @@ class OverlapPatchEmbed(nn.Module):
         B, OH, OW, _ = col.shape
         t = ops.gemm(col.view(B, OH * OW, -1), w, shift=self.proj.bias)
         if tape is not None:
-            tape.append(dict(pre=t, in_shape=tuple(x.shape)))
+            tape.append(dict(pre=t, in_shape=tuple(x.shape), x_in=x if ops.taping_wgrad() else None))
         return ops.layernorm(t, self.norm.weight, self.norm.bias, self.norm.eps), OH, OW
 
-    def backward_nhwc(self, d_tok, t):
-        """d/d(tokens after the norm) -> d/d(input map) NHWC."""
+    def backward_nhwc(self, d_tok, t, wgrad=False):
+        """d/d(tokens after the norm) -> d/d(input map) NHWC; wgrad: proj / norm parameter gradients too."""
         k = self.patch_size[0]
         B, H, W, Cin = t["in_shape"]
         w = self._packs.get("w", [self.proj.weight], lambda: ops.pack_conv_gemm_weight(self.proj.weight))
         wt = self._packs.get("wT", [self.proj.weight], lambda: ops.transpose_pad(w))
+        if wgrad:
+            _ln_wgrad(self.norm, t["pre"], d_tok)
         d_pre = ops.layernorm_bwd(t["pre"], self.norm.weight, d_tok, self.norm.eps)
+        if wgrad:
+            _conv_as_gemm_wgrad(self.proj, d_pre, ops.im2col(t["x_in"], k, self.stride, k // 2, w.shape[1]))
         d_col = ops.gemm(d_pre, wt)
+        ops.grads_ready(self)
         return ops.col2im(d_col, B, H, W, Cin, k, self.stride, k // 2)
 
 
@@ -299,19 +387,23 @@ class MixVisionTransformer(nn.Module):
             outs.append(x)
         return outs
 
-    def backward_features_nhwc(self, d_feats, tape):
-        """d/d(4 stage outputs, NHWC) -> d/d(input) NHWC [B,H,W,3]."""
+    def backward_features_nhwc(self, d_feats, tape, wgrad=False):
+        """d/d(4 stage outputs, NHWC) -> d/d(input) NHWC [B,H,W,3]; wgrad: every encoder parameter gradient too."""
         d_next = None
         for s in (3, 2, 1, 0):
             st = tape[s]
             d_out = d_feats[s] if d_next is None else ops.add(d_feats[s].contiguous(), d_next)
             B = d_out.shape[0]
             n = getattr(self, "norm%d" % (s + 1))
-            d_t = ops.layernorm_bwd(st["pre_norm"], n.weight, d_out.reshape(B, st["H"] * st["W"], -1), n.eps)
+            d_out = d_out.reshape(B, st["H"] * st["W"], -1)
+            if wgrad:
+                _ln_wgrad(n, st["pre_norm"], d_out)
+                ops.grads_ready(n)
+            d_t = ops.layernorm_bwd(st["pre_norm"], n.weight, d_out, n.eps)
             blocks = getattr(self, "block%d" % (s + 1))
             for i in range(len(blocks) - 1, -1, -1):
-                d_t = blocks[i].backward_tokens(d_t, st["blocks"][i])
-            d_next = getattr(self, "patch_embed%d" % (s + 1)).backward_nhwc(d_t, st["pe"][0])
+                d_t = blocks[i].backward_tokens(d_t, st["blocks"][i], wgrad)
+            d_next = getattr(self, "patch_embed%d" % (s + 1)).backward_nhwc(d_t, st["pe"][0], wgrad)
         return d_next
 
     def forward_features(self, x):

@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..operations_m import OPS, BasicConv, Conv2dParams, PReLUParams, _HipOp, _PackCache
+from ..operations_m import OPS, BasicConv, Conv2dParams, PReLUParams, _HipOp, _PackCache, grad_anchor
 
 
 # ---------------------------------------------------------------------------------------------
@@ -53,8 +53,8 @@ class MixedOp(nn.Module):
     def forward_nhwc(self, x, res=(), tape=None):
         return self._op.forward_nhwc(x, res, tape)
 
-    def backward_nhwc(self, g, t):
-        return self._op.backward_nhwc(g, t)
+    def backward_nhwc(self, g, t, wgrad=False):
+        return self._op.backward_nhwc(g, t, wgrad)
 
 
 class Cell_Chain(_HipOp):
@@ -85,11 +85,11 @@ class Cell_Chain(_HipOp):
             s1 = self._ops[i].forward_nhwc(s1, ((inp,) + tuple(res)) if last else (), tape)
         return s1
 
-    def backward_nhwc(self, g, tape):
+    def backward_nhwc(self, g, tape, wgrad=False):
         """g = d/d(chain output) -> d/d(inp).  `tape`: this chain's entries in forward order (one per op)."""
         d = g
         for i in range(self._steps - 1, -1, -1):
-            d = self._ops[i].backward_nhwc(d, tape[i])
+            d = self._ops[i].backward_nhwc(d, tape[i], wgrad)
         return ops.add(d, g)   # the chain's own residual: out = inp + ops(inp)
 
 
@@ -161,11 +161,20 @@ class Cell_Decom(nn.Module):
         vis_feature = self.chain2.forward_nhwc(hf, (fvis,), t2)   # hf_re + inp_vis
         if tape is not None:
             tape.update(fir=fir, fvis=fvis, g_ir=g_ir, g_vis=g_vis, ab_ir=ab_ir, ab_vis=ab_vis, chain=t1, chain2=t2)
+            if ops.taping_wgrad():
+                tape.update(lf_ir=lf_ir, lf_vis=lf_vis)
         return ir_feature, vis_feature
 
-    def _stream_backward(self, d_feat, chain, chain_tape, conv, name, feat, guide, ab):
-        """One stream: d/d(ir_feature) -> d/d(stem feature)."""
-        d_l = chain.backward_nhwc(d_feat, chain_tape)                        # through chain(lf) (+ its residual)
+    def _stream_backward(self, d_feat, chain, chain_tape, conv, name, feat, guide, ab, lf=None):
+        """One stream: d/d(ir_feature) -> d/d(stem feature).  lf (the stream's two LF maps): also the 1x1's parameter gradients."""
+        wgrad = lf is not None
+        d_l = chain.backward_nhwc(d_feat, chain_tape, wgrad)                 # through chain(lf) (+ its residual)
+        if wgrad:
+            gb, gw = ops.grad_of(conv.bias), ops.grad_of(conv.weight)
+            if gb is not None:
+                ops.colsum(d_l, gb)
+            if gw is not None:   # gradient of the folded 96-channel weight over [x, LF1, LF2], unfolded to cat[LF1, LF2, x-LF1, x-LF2]
+                ops.unfold_decomp1x1_wgrad(ops.conv2d_wgrad([feat, lf[0], lf[1]], d_l, 1), gw)
         wf = self._packs.get("fold_" + name, [conv.weight], lambda: ops.fold_decomp1x1_weight(conv.weight))
         dg = lambda s: self._packs.get("dg_%s%d" % (name, s), [conv.weight], lambda: ops.pack_conv_dgrad_weight(wf, 32 * s, 32))
         d_x = ops.conv2d([d_l], dg(0), 1, 1, res=(d_feat,))                  # x term of the folded 1x1 + the outer "+ inp"
@@ -174,9 +183,11 @@ class Cell_Decom(nn.Module):
         ops.conv2d([d_l], dg(2), 1, 1, out=dlf[1])
         return ops.guided_filter_bwd(guide, feat, ab, dlf, tuple(self.eps_list), add=d_x)
 
-    def backward_nhwc(self, d_ir_feature, d_vis_feature, t):
-        d_fir = self._stream_backward(d_ir_feature, self.chain, t["chain"], self.conv1x1_lf, "lf", t["fir"], t["g_ir"], t["ab_ir"])
-        d_fvis = self._stream_backward(d_vis_feature, self.chain2, t["chain2"], self.conv1x1_hf, "hf", t["fvis"], t["g_vis"], t["ab_vis"])
+    def backward_nhwc(self, d_ir_feature, d_vis_feature, t, wgrad=False):
+        d_fir = self._stream_backward(d_ir_feature, self.chain, t["chain"], self.conv1x1_lf, "lf", t["fir"], t["g_ir"], t["ab_ir"],
+                                      t["lf_ir"] if wgrad else None)
+        d_fvis = self._stream_backward(d_vis_feature, self.chain2, t["chain2"], self.conv1x1_hf, "hf", t["fvis"], t["g_vis"], t["ab_vis"],
+                                       t["lf_vis"] if wgrad else None)
         return d_fir, d_fvis
 
     def forward(self, inp_ir, inp_vis):
@@ -232,12 +243,21 @@ class spatial_attn_layer_M(nn.Module):
         self.compress = ChannelPool()
         self.spatial = BasicConv(4, 1, kernel_size, relu=False)
 
-    def blend_nhwc(self, ir, vis, want_scale=False):
+    def blend_nhwc(self, ir, vis, want_scale=False, want_comp=False):
         comp = ops.channel_pool2(ir, vis)
-        return ops.spa_blend(comp, self.spatial.conv.weight, ir, vis, want_scale)
+        r = ops.spa_blend(comp, self.spatial.conv.weight, ir, vis, want_scale)
+        return (r + (comp,)) if want_comp else r
 
-    def blend_backward_nhwc(self, d_agg, ir, vis, scale):
-        return ops.spa_blend_bwd(d_agg, self.spatial.conv.weight, ir, vis, scale)
+    def blend_backward_nhwc(self, d_agg, ir, vis, scale, comp=None):
+        """comp (the pooled 4-channel map of the forward): also accumulate the 5x5 conv's weight gradient."""
+        w = self.spatial.conv.weight
+        if comp is None:
+            return ops.spa_blend_bwd(d_agg, w, ir, vis, scale)
+        d_ir, d_vis, dpre = ops.spa_blend_bwd(d_agg, w, ir, vis, scale, want_dpre=True)
+        gw = ops.grad_of(w)
+        if gw is not None:
+            ops.corr1_wgrad(dpre, comp, 5, gw)
+        return d_ir, d_vis
 
     def forward(self, ir, vis):
         ops.require_no_grad(ir, vis)
@@ -272,8 +292,9 @@ class Network_Fusion_Searched(nn.Module):
     _decom_cls = Cell_Decom
 
     def forward(self, ir, vis, inter=None):
-        if torch.is_grad_enabled() and (ir.requires_grad or vis.requires_grad):
-            return _FusionFn.apply(ir, vis, self)
+        wg = ops.want_param_grads(self)
+        if torch.is_grad_enabled() and (ir.requires_grad or vis.requires_grad or wg):
+            return _FusionFn.apply(ir, vis, self, wg, grad_anchor(ir.device))
         with torch.no_grad():
             return self.forward_impl(ir, vis, inter=inter)
 
@@ -289,8 +310,11 @@ class Network_Fusion_Searched(nn.Module):
         if feats is not None:
             inter.update(feats)
         t_chain = None if tape is None else []
+        comp = None
         if tape is None:
             agg = self.spa.blend_nhwc(ir_feature, vis_feature)
+        elif ops.taping_wgrad():
+            agg, scale, comp = self.spa.blend_nhwc(ir_feature, vis_feature, want_scale=True, want_comp=True)
         else:
             agg, scale = self.spa.blend_nhwc(ir_feature, vis_feature, want_scale=True)
         feature2 = self.chain.forward_nhwc(agg, (), t_chain)
@@ -301,24 +325,43 @@ class Network_Fusion_Searched(nn.Module):
         else:
             out, z = ops.tail(t16, self.stem_out[1].weight, self.stem_out[2].weight, save=True)
             tape.update(dec=t_dec, chain=t_chain, ir_feature=ir_feature, vis_feature=vis_feature, scale=scale, fused=out, z=z)
+            if ops.taping_wgrad():
+                tape.update(comp=comp, feature2=feature2, t16=t16, img_ir=ir, img_vis=vis)
         if inter is not None:
             inter.update(fir=fir, fvis=fvis, ir_feature=ir_feature, vis_feature=vis_feature, agg=agg, feature2=feature2)
         return out
 
-    def backward_impl(self, d_fused, tape):
-        """d/d(fused) [B,1,H,W] -> (d/d(ir), d/d(vis channel 0)) as [B,1,H,W] each."""
+    def backward_impl(self, d_fused, tape, wgrad=False):
+        """d/d(fused) [B,1,H,W] -> (d/d(ir), d/d(vis channel 0)) as [B,1,H,W] each; wgrad: parameter gradients too."""
         from ..operations_m import check_positive_slope
         for prm, what in ((self.stem_1[1].weight, "stem_1"), (self.stem_2[1].weight, "stem_2")):
             check_positive_slope(prm, what)
-        d_t16 = ops.tail_bwd(d_fused, tape["fused"], tape["z"], self.stem_out[1].weight, self.stem_out[2].weight)
-        w0t = self._packs.get("so0T", [self.stem_out[0].weight], lambda: ops.pack_conv_dgrad_weight(self.stem_out[0].weight, 0, 32))
+        so = self.stem_out
+        if wgrad:
+            dz = ops.tail_dz(d_fused, tape["fused"], tape["z"], so[2].weight, ops.grad_of(so[2].weight))
+            gw = ops.grad_of(so[1].weight)
+            if gw is not None:
+                ops.corr1_wgrad(dz, tape["t16"], 3, gw)
+        d_t16 = ops.tail_bwd(d_fused, tape["fused"], tape["z"], so[1].weight, so[2].weight)
+        if wgrad:
+            gw = ops.grad_of(so[0].weight)
+            if gw is not None:   # 32 -> 16 conv: the 16-channel gradient zero padded, first 16 rows of dW
+                ops.conv2d_wgrad([tape["feature2"]], ops.pad_channels(d_t16, 32), 3, 1, out=gw, cout=16)
+        w0t = self._packs.get("so0T", [so[0].weight], lambda: ops.pack_conv_dgrad_weight(so[0].weight, 0, 32))
         d_feat2 = ops.conv2d([d_t16], w0t, 3, 1, cin=16, cout=32)
-        d_agg = self.chain.backward_nhwc(d_feat2, tape["chain"])
-        d_irf, d_visf = self.spa.blend_backward_nhwc(d_agg, tape["ir_feature"], tape["vis_feature"], tape["scale"])
-        d_fir, d_fvis = self.decompation.backward_nhwc(d_irf, d_visf, tape["dec"])
+        d_agg = self.chain.backward_nhwc(d_feat2, tape["chain"], wgrad)
+        d_irf, d_visf = self.spa.blend_backward_nhwc(d_agg, tape["ir_feature"], tape["vis_feature"], tape["scale"],
+                                                     tape["comp"] if wgrad else None)
+        d_fir, d_fvis = self.decompation.backward_nhwc(d_irf, d_visf, tape["dec"], wgrad)
         t = tape["dec"]
+        if wgrad:
+            for stem, img, d_f in ((self.stem_1, tape["img_ir"], d_fir), (self.stem_2, tape["img_vis"], d_fvis)):
+                gw, gs = ops.grad_of(stem[0].weight), ops.grad_of(stem[1].weight)
+                if gw is not None or gs is not None:
+                    ops.stem_wgrad(img, d_f, stem[0].weight, stem[1].weight, gw, gs)
         d_ir = ops.stem_bwd(d_fir, t["fir"], self.stem_1[0].weight, self.stem_1[1].weight)
         d_y = ops.stem_bwd(d_fvis, t["fvis"], self.stem_2[0].weight, self.stem_2[1].weight)
+        ops.grads_ready(self)
         return d_ir, d_y
 
     def _loss(self, ir, vis, mask):
@@ -349,19 +392,21 @@ class Network_Fusion_Searched_showfeatures(Network_Fusion_Searched):
 
 
 class _FusionFn(torch.autograd.Function):
-    """Input-gradient autograd node of the fusion network (hand-written reverse pass; no parameter grads)."""
+    """Autograd node of the fusion network: hand-written reverse pass; with `wgrad` the parameter gradients are accumulated
+    into param.grad by the wgrad kernels (the reference's loss.backward() does the same through torch autograd)."""
 
     @staticmethod
-    def forward(ctx, ir, vis, module):
+    def forward(ctx, ir, vis, module, wgrad, anchor):
         tape = {}
-        out = module.forward_impl(ir.detach(), vis.detach(), tape=tape)
-        ctx.tape, ctx.module = tape, module
+        with ops.tape_mode("wgrad" if wgrad else "dgrad"):
+            out = module.forward_impl(ir.detach(), vis.detach(), tape=tape)
+        ctx.tape, ctx.module, ctx.wgrad = tape, module, wgrad
         ctx.shapes = (tuple(ir.shape), tuple(vis.shape))
         return out
 
     @staticmethod
     def backward(ctx, d_fused):
-        d_ir1, d_y1 = ctx.module.backward_impl(d_fused.contiguous(), ctx.tape)
+        d_ir1, d_y1 = ctx.module.backward_impl(d_fused.contiguous(), ctx.tape, ctx.wgrad)
         ctx.tape = None
         outs = []
         for g1, shp in ((d_ir1, ctx.shapes[0]), (d_y1, ctx.shapes[1])):
@@ -371,7 +416,7 @@ class _FusionFn(torch.autograd.Function):
                 full = torch.zeros(shp, device=g1.device, dtype=g1.dtype)
                 full[:, 0:1] = g1
                 outs.append(full)
-        return outs[0], outs[1], None
+        return outs[0], outs[1], None, None, None
 
 
 # ---------------------------------------------------------------------------------------------
@@ -428,35 +473,38 @@ class WeTr(nn.Module):
             tape.update(enc=enc_tape, head=head_tape)
         return out
 
-    def backward_nhwc(self, d_logits32, tape):
-        """d/d(logits) as NHWC [B,H/4,W/4,32] (zero padded) -> d/d(input) NHWC [B,H,W,3]."""
-        d_feats = self.decoder.backward_nhwc(d_logits32, tape["head"])
-        return self.encoder.backward_features_nhwc(d_feats, tape["enc"])
+    def backward_nhwc(self, d_logits32, tape, wgrad=False):
+        """d/d(logits) as NHWC [B,H/4,W/4,32] (zero padded) -> d/d(input) NHWC [B,H,W,3]; wgrad: parameter gradients too
+        (every parameter except `classifier.weight`, whose output the forward discards -- it never receives a gradient in
+        the reference either)."""
+        d_feats = self.decoder.backward_nhwc(d_logits32, tape["head"], wgrad)
+        return self.encoder.backward_features_nhwc(d_feats, tape["enc"], wgrad)
 
     def forward(self, x):
-        if torch.is_grad_enabled() and x.requires_grad:
-            return _WeTrFn.apply(x, self)
+        wg = ops.want_param_grads(self)
+        if torch.is_grad_enabled() and (x.requires_grad or wg):
+            return _WeTrFn.apply(x, self, wg, grad_anchor(x.device))
         with torch.no_grad():
             return ops.nhwc_to_nchw(self.forward_nhwc(ops.nchw_to_nhwc(x)))
 
 
 class _WeTrFn(torch.autograd.Function):
-    """Input-gradient autograd node of WeTr: hand-written reverse pass, no parameter gradients (the PGD loop
-    only consumes d loss / d input)."""
+    """Autograd node of WeTr: hand-written reverse pass; with `wgrad` the parameter gradients are accumulated into param.grad."""
 
     @staticmethod
-    def forward(ctx, x, module):
+    def forward(ctx, x, module, wgrad, anchor):
         tape = {}
-        out = ops.nhwc_to_nchw(module.forward_nhwc(ops.nchw_to_nhwc(x.detach()), tape))
-        ctx.tape, ctx.module = tape, module
+        with ops.tape_mode("wgrad" if wgrad else "dgrad"):
+            out = ops.nhwc_to_nchw(module.forward_nhwc(ops.nchw_to_nhwc(x.detach()), tape))
+        ctx.tape, ctx.module, ctx.wgrad = tape, module, wgrad
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         d32 = ops.nchw_to_nhwc_pad(d_out, 32)
-        d_x = ctx.module.backward_nhwc(d32, ctx.tape)
+        d_x = ctx.module.backward_nhwc(d32, ctx.tape, ctx.wgrad)
         ctx.tape = None
-        return ops.nhwc_to_nchw(d_x), None
+        return ops.nhwc_to_nchw(d_x), None, None, None
 
 
 class _CompositeBase(nn.Module):
@@ -472,15 +520,29 @@ class _CompositeBase(nn.Module):
         self.seg_channel = 64
         self._criterion = f_loss
         self.seg_loss = segloss
+        # optional: True = the glue's min/max is taken over ALL ranks' batches (one 2-float all-reduce),
+        # reproducing one process that runs the whole batch; default False = per rank, what DDP around the reference does
+        self.global_minmax = False
+
+    def _minmax_sync(self):
+        if not self.global_minmax:
+            return None
+        if torch.is_grad_enabled():
+            raise NotImplementedError("global_minmax=True is an inference mode (the gradient of a min/max element living on "
+                                      "another rank is not exchanged)")
+        import torch.distributed as dist
+        from ..dist_utils import global_minmax
+        return lambda mn, mx: global_minmax(mn, mx, dist)
 
     def forward(self, ir, vis):
         """-> (fused [B,1,H,W] in tanh range, seg_map [B,num_classes,H/4,W/4]); :712-729 / :1043-1060."""
-        if torch.is_grad_enabled() and (ir.requires_grad or vis.requires_grad):
-            return _CompositeFn.apply(ir, vis, self)
+        wg = ops.want_param_grads(self)
+        if torch.is_grad_enabled() and (ir.requires_grad or vis.requires_grad or wg):
+            return _CompositeFn.apply(ir, vis, self, wg, grad_anchor(ir.device))
         with torch.no_grad():
             ycc = ops.rgb2ycrcb(vis)
             fused = self.enhance_net.forward_impl(ir[:, 0:1, :, :], ycc)
-            seg_in = ops.seg_input_from_fused(fused, ycc)   # clamp, BATCH-GLOBAL min-max, x255, mean/std
+            seg_in = ops.seg_input_from_fused(fused, ycc, minmax_sync=self._minmax_sync())   # clamp, BATCH-GLOBAL min-max, x255, mean/std
             seg_map = self.denoise_net(seg_in)
         return fused, seg_map
 
@@ -495,11 +557,12 @@ class _CompositeBase(nn.Module):
         tape.update(ycc=ycc, fused=fused, minmax=mm)
         return fused, logits, tape
 
-    def backward_taped(self, d_logits32, tape, d_fused=None):
-        """d/d(logits) NHWC [B,H/4,W/4,32] (zero padded) [+ d/d(fused)] -> (d/d(ir) [B,Cir,H,W], d/d(vis) [B,3,H,W])."""
-        d_seg_in = ops.nhwc_to_nchw(self.denoise_net.backward_nhwc(d_logits32, tape["seg"]))
+    def backward_taped(self, d_logits32, tape, d_fused=None, wgrad=False):
+        """d/d(logits) NHWC [B,H/4,W/4,32] (zero padded) [+ d/d(fused)] -> (d/d(ir) [B,Cir,H,W], d/d(vis) [B,3,H,W]);
+        wgrad: parameter gradients of both networks too (the tape must come from forward_taped under tape_mode("wgrad"))."""
+        d_seg_in = ops.nhwc_to_nchw(self.denoise_net.backward_nhwc(d_logits32, tape["seg"], wgrad))
         d_f, dcrcb = ops.glue_bwd(d_seg_in, tape["fused"], tape["ycc"], tape["minmax"], d_fused)
-        d_ir1, d_y = self.enhance_net.backward_impl(d_f, tape["fus"])
+        d_ir1, d_y = self.enhance_net.backward_impl(d_f, tape["fus"], wgrad)
         d_vis = ops.rgb2ycrcb_bwd(d_y, dcrcb)
         shp = tape["ir_shape"]
         if shp[1] != 1:   # forward used channel 0 only
@@ -516,8 +579,8 @@ class _CompositeBase(nn.Module):
     def forward_object(self, ir, vis):
         raise NotImplementedError("forward_object (second min-max on the fused plane, :743-772) is only used by _detection_loss; not built")
 
-    # ---- training-API losses (:1093-1128).  Values, and gradients w.r.t. the INPUT images (the models' autograd nodes +
-    # the loss gradient kernels).  Parameter gradients -- the training step itself, BASELINE config 5 -- are not built.
+    # ---- training-API losses (:1093-1128): values, input gradients and parameter gradients (the models' autograd nodes +
+    # the loss gradient kernels); `loss.backward()` fills param.grad like in the reference.
     def _seg_term(self, seg_map, labels):
         """self.seg_loss(F.interpolate(seg_map, size=labels.shape[1:], bilinear), labels.long())   (:1096-1098)"""
         labels = labels.type(torch.long).contiguous()
@@ -565,21 +628,58 @@ class _CompositeBase(nn.Module):
 
 
 class _CompositeFn(torch.autograd.Function):
-    """Input-gradient autograd node of the composite model: lets the reference's own attack code
-    (`loss.backward()` on F.interpolate(seg_map) + CrossEntropyLoss, attack/attack.py:445-501) drive the HIP reverse pass."""
+    """Autograd node of the composite model: lets the reference's own training / attack code (`loss.backward()`) drive the
+    HIP reverse pass.  With `wgrad` (autograd recording outside an attack, parameters requiring grad) the parameter
+    gradients of both networks are accumulated straight into param.grad by the wgrad kernels."""
 
     @staticmethod
-    def forward(ctx, ir, vis, module):
-        fused, logits, tape = module.forward_taped(ir.detach(), vis.detach())
-        ctx.tape, ctx.module = tape, module
+    def forward(ctx, ir, vis, module, wgrad, anchor):
+        with ops.tape_mode("wgrad" if wgrad else "dgrad"):
+            fused, logits, tape = module.forward_taped(ir.detach(), vis.detach())
+        ctx.tape, ctx.module, ctx.wgrad = tape, module, wgrad
         return fused, ops.nhwc_to_nchw(logits)
 
     @staticmethod
     def backward(ctx, d_fused, d_seg):
         d32 = ops.nchw_to_nhwc_pad(d_seg, 32)
-        d_ir, d_vis = ctx.module.backward_taped(d32, ctx.tape, d_fused.contiguous())
+        d_ir, d_vis = ctx.module.backward_taped(d32, ctx.tape, d_fused.contiguous(), ctx.wgrad)
         ctx.tape = None
-        return d_ir, d_vis, None
+        return d_ir, d_vis, None, None, None
+
+
+def grad_milestones(model):
+    """The sub-modules of a composite model (or a bare WeTr / fusion net) in the order the reverse pass FINISHES their
+    parameter gradients -- each calls ops.grads_ready(module) at that point: SegFormer head, then per encoder stage
+    (last to first) the stage norm, its blocks (last to first) and its patch embedding, then the fusion network."""
+    out = []
+    seg = getattr(model, "denoise_net", None) or (model if isinstance(model, WeTr) else None)
+    if seg is not None:
+        out.append(seg.decoder)
+        for s in (4, 3, 2, 1):
+            out.append(getattr(seg.encoder, "norm%d" % s))
+            out.extend(reversed(list(getattr(seg.encoder, "block%d" % s))))
+            out.append(getattr(seg.encoder, "patch_embed%d" % s))
+    fus = getattr(model, "enhance_net", None) or (model if isinstance(model, Network_Fusion_Searched) else None)
+    if fus is not None:
+        out.append(fus)
+    return out
+
+
+def assign_grad_order(model):
+    """Tag every parameter with `_paif_order` = its position in the backward-completion order (the optimizer lays the
+    arenas out in that order, so contiguous gradient buckets become ready one after the other), and the parameters that
+    never receive a gradient -- WeTr.classifier.weight (its output is discarded, :66) and Cell_Decom.relu.weight (unused,
+    :505) -- with `_paif_never_grad` (kept at the arena's tail, outside every all-reduce bucket)."""
+    order = 0
+    for m in grad_milestones(model):
+        for p in reversed(list(m.parameters())):
+            if not hasattr(p, "_paif_order"):
+                p._paif_order = order
+                order += 1
+    for name, p in model.named_parameters():
+        if name.endswith("classifier.weight") or name.endswith("decompation.relu.weight"):
+            p._paif_never_grad = True
+    return model
 
 
 class Network_MM_CompModel(_CompositeBase):
@@ -590,6 +690,7 @@ class Network_MM_CompModel(_CompositeBase):
         self._setup(f_loss, segloss)
         self.enhance_net = model
         self.denoise_net = WeTr(backbone, num_classes, embedding_dim, pretrained)
+        assign_grad_order(self)
 
 
 class Network_MM_Searched(_CompositeBase):
@@ -600,6 +701,7 @@ class Network_MM_Searched(_CompositeBase):
         self._setup(f_loss, segloss)
         self.enhance_net = Network_Fusion_Searched(C, f_loss, genotype)
         self.denoise_net = WeTr(backbone, num_classes, embedding_dim, pretrained)
+        assign_grad_order(self)
 
 
 class Network_MM_SearchedFusion(nn.Module):

@@ -5,7 +5,8 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..operations_m import BatchNormParams, Conv2dParams, LinearParams, _PackCache, _bn_scale_shift
+from .mix_transformer import _linear_wgrad
+from ..operations_m import BatchNormParams, Conv2dParams, LinearParams, _PackCache, _bn_scale_shift, _bn_split
 
 
 class MLP(nn.Module):
@@ -51,9 +52,8 @@ class SegFormerHead(nn.Module):
         self._packs = _PackCache()
 
     def forward_nhwc(self, feats, tape=None):
-        """feats: 4 NHWC maps -> logits NHWC [B,H/4,W/4,num_classes]."""
-        if self.training:
-            raise NotImplementedError("train-mode head (Dropout2d, BatchNorm batch statistics) is not built yet; call .eval()")
+        """feats: 4 NHWC maps -> logits NHWC [B,H/4,W/4,num_classes].  Train mode: batch statistics in linear_fuse's BatchNorm
+        (mmcv ConvModule: conv -> BN -> ReLU) and Dropout2d(0.1) on its output (core/segformer_head.py:47,79-80)."""
         c1, c2, c3, c4 = feats
         B, H1, W1, _ = c1.shape
         E = self.embedding_dim
@@ -63,33 +63,73 @@ class SegFormerHead(nn.Module):
             y = ops.gemm(c, lin.proj.weight, shift=lin.proj.bias)
             ops.resize_bilinear_into(y, cat, i * E)
         ops.gemm(c1, self.linear_c1.proj.weight, shift=self.linear_c1.proj.bias, out=cat, col_offset=3 * E)
-        scale, shift = _bn_scale_shift(self.linear_fuse.bn, self._packs)
+        bn = self.linear_fuse.bn
         fw = self.linear_fuse.conv.weight.view(E, 4 * E)
-        x = ops.gemm(cat, fw, scale=scale, shift=shift, act=ops.ACT_RELU)
+        wg = tape is not None and ops.taping_wgrad()
+        pre = stats = drop = None
+        if bn.training or wg:     # split form: raw GEMM -> BatchNorm statistics (batch or running) -> affine + ReLU
+            pre = ops.gemm(cat, fw)
+            x, stats = _bn_split(bn, pre, ops.ACT_RELU, None, ())
+        else:
+            scale, shift = _bn_scale_shift(bn, self._packs)
+            x = ops.gemm(cat, fw, scale=scale, shift=shift, act=ops.ACT_RELU)
+        xd = x
+        if self.training and self.dropout.p > 0:
+            drop = ops.DROP_RNG.keep_mask(B * E, self.dropout.p, x.device).view(B, E)     # Dropout2d: whole channels per sample
+            xd = ops.rowscale_add(x, drop, None, per_channel=True)
         if tape is not None:
-            tape.update(x=x, shapes=[tuple(c.shape) for c in feats])
+            tape.update(x=x, shapes=[tuple(c.shape) for c in feats], pre=pre, stats=stats, drop=drop, bn_training=bn.training)
+            if wg:
+                tape.update(feats=list(feats), cat=cat, xd=xd)
         pw = self.linear_pred.weight.view(self.num_classes, E)
-        return ops.gemm(x, pw, shift=self.linear_pred.bias)
+        return ops.gemm(xd, pw, shift=self.linear_pred.bias)
 
-    def backward_nhwc(self, d_logits, tape):
-        """d_logits NHWC [B,H/4,W/4,32] (channels >= num_classes zero) -> [d_c1, d_c2, d_c3, d_c4] NHWC."""
+    def backward_nhwc(self, d_logits, tape, wgrad=False):
+        """d_logits NHWC [B,H/4,W/4,32] (channels >= num_classes zero) -> [d_c1, d_c2, d_c3, d_c4] NHWC; wgrad: the head's
+        parameter gradients too."""
         E = self.embedding_dim
         pw = self.linear_pred.weight.view(self.num_classes, E)
         fw = self.linear_fuse.conv.weight.view(E, 4 * E)
         pwt = self._packs.get("predT", [self.linear_pred.weight], lambda: ops.transpose_pad(pw))     # [E, 32]
         fwt = self._packs.get("fuseT", [self.linear_fuse.conv.weight], lambda: ops.transpose_pad(fw))  # [4E, E]
-        scale, _ = _bn_scale_shift(self.linear_fuse.bn, self._packs)
         assert d_logits.shape[-1] == pwt.shape[1]
+        if wgrad:
+            gw, gb = ops.grad_of(self.linear_pred.weight), ops.grad_of(self.linear_pred.bias)
+            if gw is not None:
+                ops.gemm_wgrad(d_logits, tape["xd"], out_w=gw, out_b=gb, n=self.num_classes)
+            elif gb is not None:
+                ops.colsum(d_logits, gb, ncols=4 * ((self.num_classes + 3) // 4))
         d_x = ops.gemm(d_logits, pwt)                                           # [B,H1,W1,E]
-        d_cat = ops.gemm(d_x, fwt, a_mask=tape["x"], a_scale=scale)             # through ReLU and the folded BN
+        if tape["drop"] is not None:
+            d_x = ops.rowscale_add(d_x, tape["drop"], None, per_channel=True)
+        if tape["pre"] is not None:   # split form: BatchNorm (+ReLU) backward as its own kernels
+            bn = self.linear_fuse.bn
+            d_pre = ops.bn_act_bwd(d_x, tape["pre"], tape["stats"], ops.ACT_RELU, None, ops.grad_of(bn.weight) if wgrad else None,
+                                   ops.grad_of(bn.bias) if wgrad else None, None, training=tape["bn_training"])
+            if wgrad:
+                gw = ops.grad_of(self.linear_fuse.conv.weight)
+                if gw is not None:
+                    ops.gemm_wgrad(d_pre, tape["cat"], want_bias=False, out_w=gw)
+            d_cat = ops.gemm(d_pre, fwt)
+        else:
+            scale, _ = _bn_scale_shift(self.linear_fuse.bn, self._packs)
+            d_cat = ops.gemm(d_x, fwt, a_mask=tape["x"], a_scale=scale)         # through ReLU and the folded BN
         grads = [None] * 4
         for i, (idx, lin) in enumerate(((3, self.linear_c4), (2, self.linear_c3), (1, self.linear_c2))):
             _, h, w, _ = tape["shapes"][idx]
             d_y = ops.resize_bilinear_adjoint(d_cat, i * E, E, h, w)
+            if wgrad:
+                _linear_wgrad(lin.proj, d_y, tape["feats"][idx])
             lt = self._packs.get("linT%d" % idx, [lin.proj.weight], lambda lin=lin: ops.transpose_pad(lin.proj.weight))
             grads[idx] = ops.gemm(d_y, lt)
+        if wgrad:
+            lin = self.linear_c1.proj
+            gw, gb = ops.grad_of(lin.weight), ops.grad_of(lin.bias)
+            if gw is not None:   # d_y of linear_c1 = columns [3E, 4E) of d_cat
+                ops.gemm_wgrad(d_cat, tape["feats"][0], out_w=gw, out_b=gb, n=E, dy_col0=3 * E)
         l1t = self._packs.get("linT0", [self.linear_c1.proj.weight], lambda: ops.transpose_pad(self.linear_c1.proj.weight))
         grads[0] = ops.gemm(d_cat, l1t, a_cols=(3 * E, E))
+        ops.grads_ready(self)
         return grads
 
     def forward(self, x):

@@ -8,7 +8,7 @@
 // `loss.backward()`; the caller zeroes the gradient arena once per step).  No float atomics.
 //
 // Layout: NHWC rows [M, C] (M = B*H*W), one float4 (4 channels) per lane.  Workgroup geometry for per-channel
-// reductions: QB = min(C/4, 32) channel quads x PB = 256/QB rows in parallel; blockIdx.y walks quad groups (C > 128).
+// reductions: QB (a power of two <= 32 dividing C/4) channel quads x PB = 256/QB rows in parallel; blockIdx.y walks quad groups.
 #include "paif_common.h"
 
 namespace {
@@ -26,17 +26,14 @@ struct RowGeom {
   int QB, PB, cgroups, rows_per_block, nblk;
 };
 
-// C % 4 == 0; C/4 in {1,2,4,8,16} or a multiple of 32
+// C % 4 == 0.  QB = the largest power of two <= 32 dividing the quad count (so that lane % QB is the quad lane)
 inline bool row_geom(int M, int C, RowGeom& g) {
-  if (C <= 0 || (C & 3)) return false;
+  if (C <= 0 || (C & 3) || M <= 0) return false;
   const int Q = C / 4;
-  if (Q < 32) {
-    if (Q & (Q - 1)) return false;
-    g.QB = Q; g.cgroups = 1;
-  } else {
-    if (Q % 32) return false;
-    g.QB = 32; g.cgroups = Q / 32;
-  }
+  int qb = 32;
+  while (Q % qb) qb >>= 1;
+  g.QB = qb;
+  g.cgroups = Q / qb;
   g.PB = 256 / g.QB;
   long rpb = ((long)M + 1023) / 1024;            // <= 1024 row blocks
   if (rpb < 256) rpb = 256;
@@ -192,6 +189,20 @@ __global__ void bn_stats_finish_kernel(const double* __restrict__ ws, int nblk, 
       const float unbiased = M > 1 ? (float)(var * ((double)M / (double)(M - 1))) : varf;
       running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
     }
+  }
+}
+
+// eval-mode BatchNorm as the same 4 statistics (running mean / var): lets one backward kernel serve both modes
+__global__ void bn_eval_stats_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rm,
+                                     const float* __restrict__ rv, float eps, int C, float* __restrict__ mean_out,
+                                     float* __restrict__ invstd_out, float* __restrict__ scale_out, float* __restrict__ shift_out) {
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+    const float invstd = 1.0f / sqrtf(rv[c] + eps);
+    const float sc = (gamma ? gamma[c] : 1.f) * invstd;
+    mean_out[c] = rm[c];
+    invstd_out[c] = invstd;
+    scale_out[c] = sc;
+    shift_out[c] = (beta ? beta[c] : 0.f) - rm[c] * sc;
   }
 }
 
@@ -743,6 +754,15 @@ int paif_bn_stats_fwd(const float* x, int M, int C, const float* gamma, const fl
   return 0;
 }
 
+int paif_bn_eval_stats(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, int C,
+                       float* mean, float* invstd, float* scale, float* shift, paif_stream_t stream) {
+  PAIF_REQUIRE(running_mean && running_var && mean && invstd && scale && shift && C > 0, PAIF_EINVAL, "bn_eval_stats: bad arguments");
+  hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, paif::as_stream(stream), gamma, beta, running_mean,
+                     running_var, eps, C, mean, invstd, scale, shift);
+  PAIF_LAUNCH_CHECK("bn_eval_stats");
+  return 0;
+}
+
 int paif_affine_act_res_fwd(const float* x, const float* scale, const float* shift, int act, const float* prelu, const float* res0,
                             const float* res1, float* out, float* z_out, size_t M, int C, paif_stream_t stream) {
   PAIF_REQUIRE(x && out && M > 0 && C > 0 && (C & 3) == 0, PAIF_EINVAL, "affine_act_res: bad arguments");
@@ -756,7 +776,7 @@ int paif_affine_act_res_fwd(const float* x, const float* scale, const float* shi
 
 int paif_bn_act_bwd(const float* g, const float* x, const float* scale, const float* shift, const float* mean, const float* invstd,
                     int act, const float* prelu, float* dx, float* dgamma, float* dbeta, float* dslope, float* sums, float* workspace,
-                    int M, int C, paif_stream_t stream) {
+                    int training, int M, int C, paif_stream_t stream) {
   PAIF_REQUIRE(g && x && scale && shift && mean && invstd && dx && sums && workspace && M > 0, PAIF_EINVAL, "bn_act_bwd: bad arguments");
   PAIF_REQUIRE(act >= 0 && act <= 2 && (act != 1 || prelu), PAIF_EINVAL, "bn_act_bwd: act=%d", act);
   RowGeom gm;
@@ -770,7 +790,7 @@ int paif_bn_act_bwd(const float* g, const float* x, const float* scale, const fl
   PAIF_LAUNCH_CHECK("bn_act_bwd(finish)");
   const size_t n4 = (size_t)M * (C / 4);
   hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(grid_for(n4, 256)), dim3(256), 0, st, g, x, scale, shift, mean, invstd, act, prelu, sums,
-                     1.0f / (float)M, dx, n4, C / 4);
+                     training ? 1.0f / (float)M : 0.f, dx, n4, C / 4);
   PAIF_LAUNCH_CHECK("bn_act_bwd(apply)");
   return 0;
 }

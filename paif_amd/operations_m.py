@@ -101,16 +101,18 @@ class _HipOp(nn.Module):
         self._packs = _PackCache()
 
     def forward(self, x):
-        if torch.is_grad_enabled() and x.requires_grad:
-            return _OpFn.apply(x, self)
+        wg = ops.want_param_grads(self)
+        if torch.is_grad_enabled() and (x.requires_grad or wg):
+            return _OpFn.apply(x, self, wg, grad_anchor(x.device))
         with torch.no_grad():
             return ops.to_nchw_view(self.forward_nhwc(ops.to_nhwc(x)))
 
     def forward_nhwc(self, x, res=(), tape=None):
         raise NotImplementedError
 
-    def backward_nhwc(self, g, tape):
-        """g = d/d(output) -> d/d(x), INCLUDING the op's own residual path when it has one."""
+    def backward_nhwc(self, g, tape, wgrad=False):
+        """g = d/d(output) -> d/d(x), INCLUDING the op's own residual path when it has one.  wgrad: also accumulate the
+        parameter gradients into ops.grad_of(param) (the tape must have been recorded under ops.tape_mode("wgrad"))."""
         raise NotImplementedError("%s: backward kernels not built" % type(self).__name__)
 
     def _dgrad_w(self, name, w, coff=0, cs=32):
@@ -123,23 +125,37 @@ class _HipOp(nn.Module):
         return y
 
 
+_ANCHORS = {}
+
+
+def grad_anchor(device):
+    """A 0-d tensor that requires grad: handed to the autograd nodes so that their backward runs (and deposits the
+    parameter gradients into param.grad) even when no INPUT requires grad -- the training step's case."""
+    a = _ANCHORS.get(str(device))
+    if a is None:
+        a = _ANCHORS[str(device)] = torch.zeros((), device=device, requires_grad=True)
+    return a
+
+
 class _OpFn(torch.autograd.Function):
-    """Input-gradient autograd node of one NAS-cell operator (hand-written reverse pass, no parameter grads)."""
+    """Autograd node of one NAS-cell operator: hand-written reverse pass; parameter gradients (when `wgrad`) are
+    accumulated straight into param.grad by the wgrad kernels, like loss.backward() does in the reference."""
 
     @staticmethod
-    def forward(ctx, x, module):
+    def forward(ctx, x, module, wgrad, anchor):
         tape = []
-        y = module.forward_nhwc(ops.to_nhwc(x.detach()), (), tape)
+        with ops.tape_mode("wgrad" if wgrad else "dgrad"):
+            y = module.forward_nhwc(ops.to_nhwc(x.detach()), (), tape)
         # single ops record one entry; containers (Cell_Chain) consume the whole list
         ctx.entry = tape if getattr(module, "_tape_is_list", False) else tape[0]
-        ctx.module = module
+        ctx.module, ctx.wgrad = module, wgrad
         return ops.to_nchw_view(y)
 
     @staticmethod
     def backward(ctx, g):
-        d = ctx.module.backward_nhwc(ops.to_nhwc(g), ctx.entry)
+        d = ctx.module.backward_nhwc(ops.to_nhwc(g), ctx.entry, ctx.wgrad)
         ctx.entry = None
-        return ops.to_nchw_view(d), None
+        return ops.to_nchw_view(d), None, None, None
 
 
 class BasicConv(_HipOp):
@@ -203,29 +219,48 @@ class ResidualDenseBlock(_HipOp):
     def forward_nhwc(self, x, res=(), tape=None):
         a = self.lrelu.weight
         k, d = self.k, self.d
-        x1 = ops.conv2d([x], self.conv1.wpk(1, 32), k, d, act=ops.ACT_PRELU, prelu=a)
-        x2 = ops.conv2d([x, x1], self.conv2.wpk(2, 32), k, d, act=ops.ACT_PRELU, prelu=a)
+        kw = dict(act=ops.ACT_PRELU, prelu=a)
+        if tape is not None and ops.taping_wgrad():     # parameter gradients need every pre-activation and the block input
+            x1, z1 = ops.conv2d([x], self.conv1.wpk(1, 32), k, d, want_aux=True, **kw)
+            x2, z2 = ops.conv2d([x, x1], self.conv2.wpk(2, 32), k, d, want_aux=True, **kw)
+            out, z3 = ops.conv2d([x, x1, x2], self.conv3.wpk(3, 32), k, d, alpha=0.333333, res=(x,) + tuple(res), want_aux=True, **kw)
+            tape.append(dict(x=x, x1=x1, x2=x2, z1=z1, z2=z2, z3=z3))
+            return out
+        x1 = ops.conv2d([x], self.conv1.wpk(1, 32), k, d, **kw)
+        x2 = ops.conv2d([x, x1], self.conv2.wpk(2, 32), k, d, **kw)
         if tape is None:
-            return ops.conv2d([x, x1, x2], self.conv3.wpk(3, 32), k, d, act=ops.ACT_PRELU, prelu=a, alpha=0.333333,
-                              res=(x,) + tuple(res))
-        out, z3 = ops.conv2d([x, x1, x2], self.conv3.wpk(3, 32), k, d, act=ops.ACT_PRELU, prelu=a, alpha=0.333333,
-                             res=(x,) + tuple(res), want_aux=True)
+            return ops.conv2d([x, x1, x2], self.conv3.wpk(3, 32), k, d, alpha=0.333333, res=(x,) + tuple(res), **kw)
+        out, z3 = ops.conv2d([x, x1, x2], self.conv3.wpk(3, 32), k, d, alpha=0.333333, res=(x,) + tuple(res), want_aux=True, **kw)
         tape.append(dict(x1=x1, x2=x2, z3=z3))
         return out
 
-    def backward_nhwc(self, g, t):
+    def backward_nhwc(self, g, t, wgrad=False):
         a = self.lrelu.weight
-        check_positive_slope(a, "ResidualDenseBlock")   # x1, x2 are PReLU outputs: their sign is the pre-activation's
         k, d = self.k, self.d
         w1, w2, w3 = self.conv1.conv.weight, self.conv2.conv.weight, self.conv3.conv.weight
+        # sign source of PReLU': the saved pre-activation when there is one, else the output (needs a non-negative slope)
+        s1, s2 = t.get("z1"), t.get("z2")
+        if s1 is None:
+            check_positive_slope(a, "ResidualDenseBlock")
+            s1, s2 = t["x1"], t["x2"]
         hook3 = dict(in_act=ops.IN_DPRELU, in_aux=t["z3"], in_alpha=0.333333, in_prelu=a)
         d_x = ops.conv2d([g], self._dgrad_w("c3s0", w3, 0), k, d, res=(g,), **hook3)
         d_x1 = ops.conv2d([g], self._dgrad_w("c3s1", w3, 32), k, d, **hook3)
         d_x2 = ops.conv2d([g], self._dgrad_w("c3s2", w3, 64), k, d, **hook3)
-        hook2 = dict(in_act=ops.IN_DPRELU, in_aux=t["x2"], in_prelu=a)
+        hook2 = dict(in_act=ops.IN_DPRELU, in_aux=s2, in_prelu=a)
         d_x = ops.conv2d([d_x2], self._dgrad_w("c2s0", w2, 0), k, d, res=(d_x,), **hook2)
         d_x1 = ops.conv2d([d_x2], self._dgrad_w("c2s1", w2, 32), k, d, res=(d_x1,), **hook2)
-        return ops.conv2d([d_x1], self._dgrad_w("c1", w1, 0), k, d, res=(d_x,), in_act=ops.IN_DPRELU, in_aux=t["x1"], in_prelu=a)
+        if wgrad:
+            x, x1, x2 = t["x"], t["x1"], t["x2"]
+            ds = ops.grad_of(a)
+            for w, srcs, dout, z, alpha in ((w3, [x, x1, x2], g, t["z3"], 0.333333), (w2, [x, x1], d_x2, t["z2"], 1.0),
+                                            (w1, [x], d_x1, t["z1"], 1.0)):
+                gw = ops.grad_of(w)
+                if gw is not None:
+                    ops.conv2d_wgrad(srcs, dout, k, d, z=z, act=ops.ACT_PRELU, prelu=a, alpha=alpha, out=gw)
+                if ds is not None:
+                    ops.prelu_bwd(dout, z, a, ds, factor=alpha)
+        return ops.conv2d([d_x1], self._dgrad_w("c1", w1, 0), k, d, res=(d_x,), in_act=ops.IN_DPRELU, in_aux=s1, in_prelu=a)
 
 
 class ResidualModule(_HipOp):
@@ -248,6 +283,13 @@ class ResidualModule(_HipOp):
         w2 = self._packs.get("w2", [op[1].weight], lambda: ops.pack_conv_weight(op[1].weight, 1, 32, 3))
         t2 = ops.conv2d([t1], w2, 3, 2)
         w3 = self._packs.get("w3", [op[2].weight], lambda: ops.pack_conv_weight(op[2].weight, 1, 32, 1))
+        if op[3].training or (tape is not None and ops.taping_wgrad()):
+            # split form: raw 1x1 -> BatchNorm statistics (batch or running) -> affine + PReLU + residuals
+            c = ops.conv2d([t2], w3, 1, 1)
+            out, stats = _bn_split(op[3], c, ops.ACT_PRELU, op[4].weight, (x,) + tuple(res))
+            if tape is not None:
+                tape.append(dict(x=x, t1=t1, t2=t2, c=c, stats=stats, bn_training=op[3].training))
+            return out
         scale, shift = _bn_scale_shift(op[3], self._packs)
         kw = dict(scale=scale, shift=shift, act=ops.ACT_PRELU, prelu=op[4].weight, res=(x,) + tuple(res))
         if tape is None:
@@ -256,8 +298,22 @@ class ResidualModule(_HipOp):
         tape.append(dict(z=z))
         return out
 
-    def backward_nhwc(self, g, t):
+    def backward_nhwc(self, g, t, wgrad=False):
         op = self.op
+        if "c" in t:   # split form (train-mode BatchNorm and / or parameter gradients)
+            bn = op[3]
+            d_c = ops.bn_act_bwd(g, t["c"], t["stats"], ops.ACT_PRELU, op[4].weight,
+                                 ops.grad_of(bn.weight) if wgrad else None, ops.grad_of(bn.bias) if wgrad else None,
+                                 ops.grad_of(op[4].weight) if wgrad else None, training=t["bn_training"])
+            d_t2 = ops.conv2d([d_c], self._dgrad_w("c1x1", op[2].weight), 1, 1)
+            d_t1 = ops.conv2d([d_t2], self._dgrad_w("c3d2", op[1].weight), 3, 2)
+            if wgrad:
+                for w, src, dout, kk, dd in ((op[2].weight, t["t2"], d_c, 1, 1), (op[1].weight, t["t1"], d_t2, 3, 2),
+                                             (op[0].conv.weight, t["x"], d_t1, self.k, self.d)):
+                    gw = ops.grad_of(w)
+                    if gw is not None:
+                        ops.conv2d_wgrad([src], dout, kk, dd, out=gw)
+            return ops.conv2d([d_t1], self._dgrad_w("ck", op[0].conv.weight), self.k, self.d, res=(g,))
         scale, _ = _bn_scale_shift(op[3], self._packs)
         d_t2 = ops.conv2d([g], self._dgrad_w("c1x1", op[2].weight), 1, 1, in_act=ops.IN_DPRELU, in_aux=t["z"], in_scale=scale,
                           in_prelu=op[4].weight)
@@ -282,16 +338,51 @@ class DilConv(_HipOp):
         op = self.op
         t = ops.dwconv(x, op[1].conv.weight, self.k, self.d, in_relu=True)
         w = self._packs.get("w", [op[2].weight], lambda: ops.pack_conv_weight(op[2].weight, 1, 32, 1))
+        if op[3].training or (tape is not None and ops.taping_wgrad()):
+            c = ops.conv2d([t], w, 1, 1)
+            out, stats = _bn_split(op[3], c, ops.ACT_NONE, None, (x,) + tuple(res))
+            if tape is not None:
+                tape.append(dict(x=x, t=t, c=c, stats=stats, bn_training=op[3].training))
+            return out
         scale, shift = _bn_scale_shift(op[3], self._packs)
         if tape is not None:
             tape.append(dict(x=x))
         return ops.conv2d([t], w, 1, 1, scale=scale, shift=shift, res=(x,) + tuple(res))
 
-    def backward_nhwc(self, g, t):
+    def backward_nhwc(self, g, t, wgrad=False):
         op = self.op
+        if "c" in t:
+            bn = op[3]
+            d_c = ops.bn_act_bwd(g, t["c"], t["stats"], ops.ACT_NONE, None,
+                                 ops.grad_of(bn.weight) if wgrad and bn.affine else None,
+                                 ops.grad_of(bn.bias) if wgrad and bn.affine else None, None, training=t["bn_training"])
+            d_t = ops.conv2d([d_c], self._dgrad_w("c1x1", op[2].weight), 1, 1)
+            if wgrad:
+                gw = ops.grad_of(op[2].weight)
+                if gw is not None:
+                    ops.conv2d_wgrad([t["t"]], d_c, 1, 1, out=gw)
+                gd = ops.grad_of(op[1].conv.weight)
+                if gd is not None:
+                    ops.dwconv_wgrad(t["x"], d_t, self.k, self.d, True, gd)
+            return ops.dwconv_bwd(d_t, op[1].conv.weight, self.k, self.d, aux=t["x"], add=g)
         scale, _ = _bn_scale_shift(op[3], self._packs)
         d_t = ops.conv2d([g], self._dgrad_w("c1x1", op[2].weight), 1, 1, in_act=ops.IN_SCALE, in_scale=scale)
         return ops.dwconv_bwd(d_t, op[1].conv.weight, self.k, self.d, aux=t["x"], add=g)
+
+
+def _bn_split(bn, c, act, slope, res):
+    """act(BatchNorm(c)) + residuals in split form: statistics kernel (train mode: batch statistics + running-statistics
+    update, as nn.BatchNorm2d does; eval mode: the running statistics) then one affine/activation/residual pass.
+    Returns (out, (mean, invstd, scale, shift))."""
+    g, b = (bn.weight, bn.bias) if bn.affine else (None, None)
+    if bn.training:
+        if bn.momentum is None or not bn.track_running_stats:
+            raise NotImplementedError("BatchNorm with momentum=None / track_running_stats=False is not used by the reference")
+        stats = ops.bn_stats(c, g, b, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
+        bn.num_batches_tracked.add_(1)
+    else:
+        stats = ops.bn_eval_stats(g, b, bn.running_mean, bn.running_var, bn.eps)
+    return ops.affine_act_res(c, stats[2], stats[3], act, slope, res), stats
 
 
 def _bn_scale_shift(bn, cache=None, name="bn"):
@@ -330,7 +421,9 @@ class SepConv(_HipOp):
             BatchNormParams(C_out, affine=affine),
         )
 
-    def backward_nhwc(self, g, t):
+    def backward_nhwc(self, g, t, wgrad=False):
+        if wgrad:
+            raise NotImplementedError("SepConv: parameter gradients are built for the shipped genotype's operators only")
         op = self.op
         s1, _ = _bn_scale_shift(op[3], self._packs, 'bn1')
         s2, _ = _bn_scale_shift(op[7], self._packs, 'bn2')
@@ -392,14 +485,32 @@ class ECABasicBlock(_HipOp):
             out = ops.eca_finish(o, r, partial, self.se.conv.weight, self.k, a)
         else:
             out, u, gate = ops.eca_finish(o, r, partial, self.se.conv.weight, self.k, a, save=True)
-            tape.append(dict(r=r, o=o, u=u, gate=gate))
+            tape.append(dict(r=r, o=o, u=u, gate=gate, x=x, pool=partial) if ops.taping_wgrad() else dict(r=r, o=o, u=u, gate=gate))
         return self._add_res(out, res)
 
-    def backward_nhwc(self, g, t):
+    def backward_nhwc(self, g, t, wgrad=False):
         a = self.relu.weight
-        d_o, d_r = ops.eca_bwd(g, t["u"], t["o"], t["gate"], self.se.conv.weight, self.k, a)
-        # o = conv2(PReLU(r)):  d_r += conv2^T(d_o) * PReLU'(r)
-        d_r = ops.conv2d([d_o], self._dgrad_w("c2", self.conv2.conv.weight), self.k, 1, epi_dact=1, epi_aux=t["r"], prelu=a, res=(d_r,))
+        if not wgrad:
+            d_o, d_r = ops.eca_bwd(g, t["u"], t["o"], t["gate"], self.se.conv.weight, self.k, a)
+            # o = conv2(PReLU(r)):  d_r += conv2^T(d_o) * PReLU'(r)
+            d_r = ops.conv2d([d_o], self._dgrad_w("c2", self.conv2.conv.weight), self.k, 1, epi_dact=1, epi_aux=t["r"], prelu=a, res=(d_r,))
+            return ops.conv2d([d_r], self._dgrad_w("c1", self.conv1.weight), 3, 1)
+        B, H, W, _ = g.shape
+        ds = ops.grad_of(a)
+        if ds is not None:
+            ops.prelu_bwd(g, t["u"], a, ds)                                   # out = PReLU(u)
+        d_o, d_r, dgate = ops.eca_bwd(g, t["u"], t["o"], t["gate"], self.se.conv.weight, self.k, a, want_partial=True)
+        g1d = ops.grad_of(self.se.conv.weight)
+        if g1d is not None:
+            ops.eca_wgrad(t["pool"], dgate, t["gate"], self.k, g1d, B, H, W)
+        gw2 = ops.grad_of(self.conv2.conv.weight)
+        if gw2 is not None:                                                   # conv2's input is PReLU(r): materialised for the wgrad
+            ops.conv2d_wgrad([ops.affine_act_res(t["r"], None, None, ops.ACT_PRELU, a)], d_o, self.k, 1, out=gw2)
+        tt = ops.conv2d([d_o], self._dgrad_w("c2", self.conv2.conv.weight), self.k, 1)     # d/d PReLU(r)
+        d_r = ops.prelu_bwd(tt, t["r"], a, ds, add=d_r, want_dx=True)
+        gw1 = ops.grad_of(self.conv1.weight)
+        if gw1 is not None:
+            ops.conv2d_wgrad([t["x"]], d_r, 3, 1, out=gw1)
         return ops.conv2d([d_r], self._dgrad_w("c1", self.conv1.weight), 3, 1)
 
 
@@ -427,7 +538,9 @@ class Spatial_BasicBlock(_HipOp):
             tape.append(dict(r=r, o=o, u=u, s=s))
         return self._add_res(out, res)
 
-    def backward_nhwc(self, g, t):
+    def backward_nhwc(self, g, t, wgrad=False):
+        if wgrad:
+            raise NotImplementedError("SPAattention: parameter gradients are built for the shipped genotype's operators only")
         a = self.relu.weight
         d_o, d_r = ops.spa1_bwd(g, t["u"], t["o"], t["s"], self.se.spatial.conv.weight, self.k, a)
         d_r = ops.conv2d([d_o], self._dgrad_w("c2", self.conv2.conv.weight), self.k, 1, epi_dact=1, epi_aux=t["r"], prelu=a, res=(d_r,))

@@ -36,6 +36,55 @@ def set_conv_precision(mode):
     CONFIG["conv_precision"] = mode
 
 
+# ---- what a taped forward records: "dgrad" = enough for the input-gradient pass (PGD attacks); "wgrad" = also what the
+# parameter-gradient kernels need (layer inputs, pre-activations, BatchNorm statistics).  Set by the autograd nodes.
+_TAPE_MODE = ["dgrad"]
+
+
+class tape_mode:
+    def __init__(self, mode):
+        assert mode in ("dgrad", "wgrad")
+        self.mode = mode
+
+    def __enter__(self):
+        self.old = _TAPE_MODE[0]
+        _TAPE_MODE[0] = self.mode
+
+    def __exit__(self, *a):
+        _TAPE_MODE[0] = self.old
+
+
+def taping_wgrad():
+    return _TAPE_MODE[0] == "wgrad"
+
+
+# attacks differentiate w.r.t. the INPUT only: inside this context the autograd nodes skip the parameter gradients
+_NO_PARAM_GRADS = [0]
+
+
+class no_param_grads:
+    def __enter__(self):
+        _NO_PARAM_GRADS[0] += 1
+
+    def __exit__(self, *a):
+        _NO_PARAM_GRADS[0] -= 1
+
+
+def want_param_grads(module):
+    """Parameter gradients are produced when autograd is recording, the caller is not an attack, and some parameter of
+    the module requires grad."""
+    return torch.is_grad_enabled() and _NO_PARAM_GRADS[0] == 0 and any(p.requires_grad for p in module.parameters())
+
+
+# called by the reverse passes when a sub-module's parameter gradients are final (bucketed all-reduce hooks in here)
+GRAD_READY = [None]
+
+
+def grads_ready(module):
+    if GRAD_READY[0] is not None:
+        GRAD_READY[0](module)
+
+
 class PackedWeight:
     """Packed MFMA B-operand stream + the precision it was packed for."""
 
@@ -164,8 +213,10 @@ def fused_to_uint8(fused, ycc):
     return out
 
 
-def seg_input_from_fused(fused, ycc, return_minmax=False):
-    """fused [B,1,H,W], ycc [B,3,H,W] -> normalised SegFormer input [B,3,H,W] (batch-global min-max)."""
+def seg_input_from_fused(fused, ycc, return_minmax=False, minmax_sync=None):
+    """fused [B,1,H,W], ycc [B,3,H,W] -> normalised SegFormer input [B,3,H,W] (batch-global min-max).
+    minmax_sync (optional): callable (mn, mx) -> (mn, mx) on 0-d device tensors, e.g. dist_utils.global_minmax for the
+    all-ranks min/max of the `global_minmax=True` mode."""
     fused = fused.contiguous()
     ycc = ycc.contiguous()
     B, _, H, W = ycc.shape
@@ -174,6 +225,9 @@ def seg_input_from_fused(fused, ycc, return_minmax=False):
     partial = torch.empty(2 * nblk, device=ycc.device, dtype=torch.float32)
     rgb = torch.empty_like(ycc)
     _lib.check(L.paif_recompose_clamp_fwd(_p(fused), _p(ycc), _p(rgb), _p(partial), B, H, W, _stream()), "recompose_clamp")
+    if minmax_sync is not None:
+        mn, mx = minmax_sync(partial[:nblk].min(), partial[nblk:].max())    # two scalars cross the ranks
+        partial, nblk = torch.stack([mn.reshape(()), mx.reshape(())]).contiguous(), 1
     mm = torch.empty(2, device=ycc.device, dtype=torch.float32)
     _lib.check(L.paif_minmax_normalize_fwd(_p(rgb), _p(partial), nblk, _p(rgb), _p(mm), B, H, W, _stream()),
                "minmax_normalize")
@@ -388,7 +442,7 @@ def eca_finish(o, r, partial, w1d, k, prelu, save=False):
     return (out, u, gate) if save else out
 
 
-def eca_bwd(dout, u, o, gate, w1d, k, prelu):
+def eca_bwd(dout, u, o, gate, w1d, k, prelu, want_partial=False):
     B, H, W, _ = o.shape
     L = lib()
     partial = torch.empty((B, L.paif_eca_bwd_blocks(H, W), 32), device=o.device, dtype=torch.float32)
@@ -396,16 +450,16 @@ def eca_bwd(dout, u, o, gate, w1d, k, prelu):
     d_o, d_r = torch.empty_like(o), torch.empty_like(o)
     _lib.check(L.paif_eca_bwd_input(_p(dout), _p(u), _p(o), _p(gate), _p(w1d.detach().contiguous()), k, _p(prelu), _p(partial), _p(coef),
                                     _p(d_o), _p(d_r), B, H, W, _stream()), "eca_bwd")
-    return d_o, d_r
+    return (d_o, d_r, partial) if want_partial else (d_o, d_r)
 
 
-def spa_blend_bwd(dagg, w, ir, vis, s, add_ir=None, add_vis=None):
+def spa_blend_bwd(dagg, w, ir, vis, s, add_ir=None, add_vis=None, want_dpre=False):
     B, H, W, _ = ir.shape
     dpre = torch.empty((B, H, W), device=ir.device, dtype=torch.float32)
     d_ir, d_vis = torch.empty_like(ir), torch.empty_like(vis)
     _lib.check(lib().paif_spa_blend_bwd_input(_p(dagg), _p(w.detach().contiguous()), _p(ir), _p(vis), _p(s), _p(add_ir), _p(add_vis),
                                               _p(dpre), _p(d_ir), _p(d_vis), B, H, W, _stream()), "spa_blend_bwd")
-    return d_ir, d_vis
+    return (d_ir, d_vis, dpre) if want_dpre else (d_ir, d_vis)
 
 
 def dwconv_bwd(dt, w, k, dil, aux=None, add=None):
@@ -525,13 +579,15 @@ def layernorm_bwd(x, weight, dy, eps, add=None):
     return dx
 
 
-def dwconv3_bias_gelu_bwd(x, w, bias, dy):
+def dwconv3_bias_gelu_bwd(x, w, bias, dy, want_dpre=False):
+    """-> dx (and, with want_dpre, the gradient at the depthwise conv's OUTPUT, dy * gelu'(conv(x)+b): the operand of its
+    weight / bias gradient)."""
     B, H, W, C = x.shape
     tmp = torch.empty_like(x)
     dx = torch.empty_like(x)
     _lib.check(lib().paif_dwconv3_bias_gelu_bwd_input(_p(x), _p(w.detach().contiguous()), _p(bias), _p(dy), _p(tmp), _p(dx), B, H, W, C,
                                                       _stream()), "dwconv3_bias_gelu_bwd")
-    return dx
+    return (dx, tmp) if want_dpre else dx
 
 
 def col2im(dcol, B, H, W, Cin, k, stride, pad):
@@ -602,7 +658,8 @@ def grad_of(p):
     if p is None or not p.requires_grad:
         return None
     if p.grad is None:
-        p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        view = getattr(p, "_paif_grad_view", None)     # the parameter's slot in the optimizer's gradient arena (zeroed by zero_grad)
+        p.grad = view if view is not None else torch.zeros_like(p, memory_format=torch.contiguous_format)
     if not p.grad.is_contiguous():
         raise RuntimeError("parameter gradients must be dense")
     return p.grad
@@ -627,11 +684,12 @@ def conv2d_wgrad(srcs, dout, kh, dil=1, z=None, scale=None, act=ACT_NONE, prelu=
     return dw
 
 
-def gemm_wgrad(dy, x, want_bias=True, out_w=None, out_b=None, n=None, k=None):
+def gemm_wgrad(dy, x, want_bias=True, out_w=None, out_b=None, n=None, k=None, dy_col0=0):
     """Linear-layer gradients: dy [..., ldy], x [..., ldx] (same leading shape) -> (dW [N, K], db [N] or None).
-    n / k: use only the first n columns of dy / k columns of x.  out_w / out_b: ACCUMULATE into these instead."""
+    n / k: use only n columns of dy (starting at dy_col0) / the first k columns of x.  out_w / out_b: ACCUMULATE into these."""
     lddy, ldx = dy.shape[-1], x.shape[-1]
-    N, K = n or lddy, k or ldx
+    N, K = n or (lddy - dy_col0), k or ldx
+    assert dy_col0 % 4 == 0 and dy_col0 + N <= lddy
     M = dy.numel() // lddy
     assert x.numel() // ldx == M
     L = lib()
@@ -645,7 +703,9 @@ def gemm_wgrad(dy, x, want_bias=True, out_w=None, out_b=None, n=None, k=None):
         assert db is None or db.numel() == N
     else:
         db = torch.empty(N, device=dy.device, dtype=torch.float32) if want_bias else None
-    _lib.check(L.paif_gemm_wgrad(_p(dy), lddy, _p(x), ldx, _p(dw), _p(db), M, N, K, splits, _p(ws), int(acc), _stream()), "gemm_wgrad")
+    _p(dy)
+    dyp = ctypes.c_void_p(dy.data_ptr() + 4 * dy_col0)
+    _lib.check(L.paif_gemm_wgrad(dyp, lddy, _p(x), ldx, _p(dw), _p(db), M, N, K, splits, _p(ws), int(acc), _stream()), "gemm_wgrad")
     return dw, db
 
 
@@ -670,7 +730,7 @@ def layernorm_wgrad(x, dy, eps, out_g=None, out_b=None):
 def _rr_ws(M, C, nacc, device, mult=1):
     n = lib().paif_row_reduce_workspace_floats(M, C, nacc)
     if n == 0:
-        raise NotImplementedError("row reduction over %d channels is not built (C/4 must be a power of two < 32 or a multiple of 32)" % C)
+        raise NotImplementedError("row reduction over %d channels is not built (C must be a multiple of 4)" % C)
     return torch.empty(mult * n, device=device, dtype=torch.float32)
 
 
@@ -723,9 +783,18 @@ def affine_act_res(x, scale, shift, act=ACT_NONE, prelu=None, res=(), want_z=Fal
     return (out, z) if want_z else out
 
 
-def bn_act_bwd(g, x, stats, act=ACT_NONE, prelu=None, d_gamma=None, d_beta=None, d_slope=None):
-    """Backward of act(BN_train(x)) (stats = (mean, invstd, scale, shift) of bn_stats): returns dx; accumulates the
-    affine / slope gradients into d_gamma, d_beta, d_slope (any may be None)."""
+def bn_eval_stats(gamma, beta, running_mean, running_var, eps):
+    """Eval-mode BatchNorm as (mean, invstd, scale, shift) -- same tuple as bn_stats, from the running statistics."""
+    C = running_mean.numel()
+    st = torch.empty((4, C), device=running_mean.device, dtype=torch.float32)
+    _lib.check(lib().paif_bn_eval_stats(_p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, C, _p(st[0]), _p(st[1]), _p(st[2]),
+                                        _p(st[3]), _stream()), "bn_eval_stats")
+    return st[0], st[1], st[2], st[3]
+
+
+def bn_act_bwd(g, x, stats, act=ACT_NONE, prelu=None, d_gamma=None, d_beta=None, d_slope=None, training=True):
+    """Backward of act(BN(x)) (stats = (mean, invstd, scale, shift) of bn_stats / bn_eval_stats): returns dx; accumulates the
+    affine / slope gradients into d_gamma, d_beta, d_slope (any may be None).  training=False: running statistics."""
     C = x.shape[-1]
     M = x.numel() // C
     mean, invstd, scale, shift = stats
@@ -733,7 +802,7 @@ def bn_act_bwd(g, x, stats, act=ACT_NONE, prelu=None, d_gamma=None, d_beta=None,
     sums = torch.empty(2 * C, device=x.device, dtype=torch.float32)
     ws = _rr_ws(M, C, 3, x.device)
     _lib.check(lib().paif_bn_act_bwd(_p(g), _p(x), _p(scale), _p(shift), _p(mean), _p(invstd), act, _p(prelu), _p(dx), _p(d_gamma),
-                                     _p(d_beta), _p(d_slope), _p(sums), _p(ws), M, C, _stream()), "bn_act_bwd")
+                                     _p(d_beta), _p(d_slope), _p(sums), _p(ws), int(training), M, C, _stream()), "bn_act_bwd")
     return dx
 
 

@@ -167,3 +167,11 @@ def make_smooth_feature(seed, B, C, H, W):
             f = _smooth_field(seed + 131 * b + 7 * c, H, W).astype(np.float32) / np.float32(255.0)
             out[b, c] = f * np.float32(0.5 + 0.03 * c) - np.float32(0.1 * (c % 5))
     return out
+
+
+def sample_indices(n, k=512):
+    """Up to k evenly spaced flat indices into a tensor of n elements (golden fixtures keep a sample of the big
+    gradient / parameter tensors, not all 4 M values)."""
+    if n <= k:
+        return np.arange(n, dtype=np.int64)
+    return np.unique(np.linspace(0, n - 1, k).astype(np.int64))

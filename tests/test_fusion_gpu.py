@@ -344,13 +344,28 @@ def test_fusion_full_size_480x640(golden):
     assert maxabs(fused.cpu(), g["fused"]) <= 2.0 * floor + 2e-5
 
 
-def test_train_mode_batchnorm_fails_loudly():
-    """BatchNorm batch statistics belong to the training step (not built): no silent eval-mode substitution."""
+def test_train_mode_forward_uses_batch_statistics():
+    """Train-mode forward (BatchNorm batch statistics in DilConv / ResidualModule, running statistics updated) vs the oracle."""
+    from oracle import paif_oracle as O
+
     net = _fusion_net()
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     net.train()
-    with pytest.raises(NotImplementedError):
+    ir, vis, _ = S.make_batch(2, 40, 56)
+    ycc = O.rgb2ycrcb(t(vis))
+    with torch.no_grad():
+        fused = net(t(ir).to(_dev()), ycc[:, 0:1].contiguous().to(_dev()))
+    O.TRAIN = O.TrainCtx(0)
+    try:
         with torch.no_grad():
-            net(torch.zeros(1, 1, 16, 32, device=_dev()), torch.zeros(1, 1, 16, 32, device=_dev()))
+            ref = O.fusion_forward(t(ir), ycc[:, 0:1], sd)
+    finally:
+        O.TRAIN = None
+    assert maxabs(fused.cpu(), ref) <= 1e-4
+    for k, v in net.state_dict().items():
+        if "running_" in k:
+            assert maxabs(v.cpu(), sd[k]) <= 1e-5, k
+    net.eval()
 
 
 def test_unknown_and_malformed_primitives():

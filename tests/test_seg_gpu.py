@@ -104,15 +104,28 @@ def test_full_model_480x640(golden):
     assert (up.argmax(1).numpy() == g["pred"]).mean() >= 0.999
 
 
-def test_train_mode_fails_loudly():
+def test_train_mode_forward_matches_oracle():
+    """Train-mode forward of the composite model (batch-statistic BatchNorm x4, DropPath and Dropout2d masks from the
+    counter-based stream) vs the oracle's train-mode restatement with the same stream."""
+    from oracle import paif_oracle as O
+    from paif_amd import ops
+
     m = _model("mit_b0")
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     m.train()
+    ir, vis, _ = S.make_batch(2, 64, 96)
+    ops.DROP_RNG.reseed(77, rank=1, step=5)
     try:
-        with pytest.raises(NotImplementedError):
-            with torch.no_grad():
-                m(torch.zeros(1, 1, 64, 96, device=_dev()), torch.zeros(1, 3, 64, 96, device=_dev()))
+        with torch.no_grad():
+            fused, seg = m(t(ir).to(_dev()), t(vis).to(_dev()))
+        O.TRAIN = O.TrainCtx(77, rank=1, step=5)
+        with torch.no_grad():
+            fo, so = O.model_forward(t(ir), t(vis), sd, "mit_b0")
     finally:
+        O.TRAIN = None
         m.eval()
+    assert maxabs(fused.cpu(), fo) <= 1e-4
+    assert maxabs(seg.cpu(), so) <= 1e-3 * float(so.max() - so.min())
 
 
 def test_graph_capture_replay_is_bit_identical():

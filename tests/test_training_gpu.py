@@ -1,0 +1,282 @@
+"""GPU parity of the TRAINING STEP (BASELINE configs[4]) through the C ABI:
+parameter gradients of `_loss_coupled(...).backward()` for every trainable tensor, train-mode BatchNorm / DropPath /
+Dropout2d, and the multi-tensor AdamW kernel with the PolyWarmupAdamW schedule.
+
+Checkers: (1) the oracle's autograd (oracle/paif_oracle.py, pinned to the reference's own gradients by
+tests/test_oracle_training.py) run on the host beside the GPU -- in float64 as the truth and in float32 to measure the
+reference arithmetic's own noise floor (gradients through the guided filter's A = cov/(var+1e-4) carry ~6e-3 of relative
+fp32 noise); (2) the golden samples of the reference's run (tests/golden/gm_*.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from paif_amd import ops, synthetic as S
+from tests import helpers as Hh
+from tests.helpers import t
+from tests.test_oracle_training import (BETAS, DROP_SEED, GROUP_LR_WD, LR, NEVER, SCHED, START_STEP, WD, group_of, movement_mismatch,
+                                        training_inputs)
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _exact_convs():
+    old = ops.CONFIG["conv_precision"]
+    ops.set_conv_precision("f32")
+    yield
+    ops.set_conv_precision(old)
+
+
+def _model(bb="mit_b0", train=False):
+    from paif_amd.core.loss import Fusionloss_grad2
+    from paif_amd.core.model_fusion_auto import Network_MM_Searched
+    from paif_amd.genotypes import FUSION_AT
+
+    m = Network_MM_Searched(32, FUSION_AT, Fusionloss_grad2(), torch.nn.CrossEntropyLoss(ignore_index=255), bb, num_classes=9)
+    S.load_formula_weights(m)
+    m.train(train)
+    return m.to(_dev())
+
+
+def _oracle_grads(bb, inputs, dtype, train_step=None):
+    """-> (loss, {name: grad or None}, sd) from the oracle's autograd on the host."""
+    from oracle import paif_oracle as O
+
+    ir, vis, lab, ir_adv, vis_adv, mask = inputs
+    sd = Hh.model_sd(bb)
+    names = [k for k, v in sd.items() if v.is_floating_point() and "running_" not in k]
+    for k in sd:
+        if sd[k].is_floating_point():
+            sd[k] = sd[k].to(dtype).clone().requires_grad_(k in names)
+    O.TRAIN = None if train_step is None else O.TrainCtx(DROP_SEED, rank=0, step=train_step)
+    try:
+        loss = O.loss_coupled(t(ir_adv).to(dtype), t(vis_adv).to(dtype), t(mask).to(dtype), t(lab), sd, bb)
+        loss.backward()
+    finally:
+        O.TRAIN = None
+    return float(loss), {k: sd[k].grad for k in names}, sd
+
+
+def _compare_grads(model, g64, g32, what, floor_mult=2.0, rel=2e-4):
+    worst = []
+    for k, p in model.named_parameters():
+        if g64[k] is None:
+            assert p.grad is None, "%s: %s must not receive a gradient (the reference leaves it None)" % (what, k)
+            continue
+        assert p.grad is not None, "%s: %s has no gradient" % (what, k)
+        ref = g64[k].double()
+        scale = max(float(ref.abs().max()), float(torch.sqrt((ref ** 2).mean())), 1e-12)
+        floor = float((g32[k].double() - ref).abs().max()) if g32 is not None else 0.0
+        err = float((p.grad.detach().cpu().double() - ref).abs().max())
+        tol = max(floor_mult * floor, rel * scale) + 1e-7
+        worst.append((err / tol, k, err, floor, scale))
+        assert err <= tol, (what, k, err, floor, scale)
+    return max(worst)
+
+
+def test_param_grads_eval_mode_all_tensors(golden):
+    """`_loss_coupled([ir_adv, ir], [vis_adv, vis], mask, labels).backward()` in eval mode: param.grad of all 205 trainable
+    tensors of Network_MM_Searched(mit_b0) at 2x64x96 vs the oracle in float64 (floor = the oracle's own float32 run) and
+    vs the reference's golden samples; classifier.weight / decompation.relu.weight stay None."""
+    from tests.test_oracle_training import check_sampled
+
+    inputs = training_inputs()
+    ir, vis, lab, ir_adv, vis_adv, mask = inputs
+    m = _model()
+    d = lambda a: t(a).to(_dev())
+    loss = m._loss_coupled((d(ir_adv), d(ir)), (d(vis_adv), d(vis)), d(mask), d(lab))
+    loss.backward()
+    l64, g64, _ = _oracle_grads("mit_b0", inputs, torch.float64)
+    l32, g32, _ = _oracle_grads("mit_b0", inputs, torch.float32)
+    assert abs(float(loss) - l64) <= 2e-5 * abs(l64)
+    _compare_grads(m, g64, g32, "eval-mode")
+    g = golden("gm_param_grads_eval_mit_b0_2x64x96")
+    # against the reference's own fp32 samples: within (its noise + ours)
+    for k, p in m.named_parameters():
+        if k + "#none" in g:
+            assert p.grad is None
+            continue
+        ref = g[k + "#s"]
+        a = p.grad.detach().cpu().reshape(-1).numpy()[S.sample_indices(p.numel())]
+        floor = float((g32[k].double() - g64[k]).abs().max())
+        assert np.abs(a - ref).max() <= 3.0 * floor + 2e-4 * max(np.abs(ref).max(), 1e-12) + 1e-7, k
+    # gradients ACCUMULATE over backward passes, like torch's
+    before = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    m._loss_coupled((d(ir_adv), d(ir)), (d(vis_adv), d(vis)), d(mask), d(lab)).backward()
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            assert float((p.grad - 2 * before[k]).abs().max()) <= 1e-5 * max(1e-12, float(before[k].abs().max())) + 1e-9, k
+
+
+def test_param_grads_mit_b3_depths():
+    """The deep encoder (mit_b3: depths 3/4/18/3, dims 64..512): all 633 trainable tensors' gradients vs the oracle (fp32)."""
+    inputs = tuple(a[:1] for a in training_inputs())
+    ir, vis, lab, ir_adv, vis_adv, mask = inputs
+    m = _model("mit_b3")
+    d = lambda a: t(a).to(_dev())
+    loss = m._loss_coupled((d(ir_adv), d(ir)), (d(vis_adv), d(vis)), d(mask), d(lab))
+    loss.backward()
+    l32, g32, _ = _oracle_grads("mit_b3", inputs, torch.float32)
+    assert abs(float(loss) - l32) <= 5e-5 * abs(l32)
+    n = 0
+    for k, p in m.named_parameters():
+        if g32[k] is None:
+            assert p.grad is None
+            continue
+        n += 1
+        ref = g32[k]
+        scale = max(float(ref.abs().max()), 1e-12)
+        tol = (3e-2 if k.startswith("enhance_net.") else 3e-3) * scale + 1e-7     # fp32 vs fp32; fusion grads pass the guided filter
+        assert float((p.grad.cpu() - ref).abs().max()) <= tol, k
+    assert n == 633 - 0 or n >= 630, n
+
+
+@pytest.mark.parametrize("prim", ["Denseblocks_3_1", "DilConv_3_2", "ECAattention_3", "Residualblocks_7_1"])
+@pytest.mark.parametrize("train", [False, True])
+def test_primitive_param_grads(prim, train):
+    """Each operator of the shipped genotype stand-alone (MixedOp(x).backward()): parameter gradients and, in train mode,
+    BatchNorm batch statistics, vs torch autograd on the oracle's restatement (float64)."""
+    from oracle import paif_oracle as O
+    from paif_amd.core.model_fusion_auto import MixedOp
+
+    op = MixedOp(32, prim)
+    S.load_formula_weights(op, salt=3)
+    sd = {k: v.clone() for k, v in op.state_dict().items()}
+    op.train(train).to(_dev())
+    x = t(S.make_smooth_feature(11, 2, 32, 25, 31))
+    r = t(S.make_feature(12, (2, 32, 25, 31)))
+    xd = x.to(_dev()).requires_grad_(True)
+    (op(xd) * r.to(_dev())).sum().backward()
+    names = [k for k, v in sd.items() if v.is_floating_point() and "running_" not in k]
+    sd64 = {k: (v.double().requires_grad_(k in names) if v.is_floating_point() else v) for k, v in sd.items()}
+    x64 = x.double().requires_grad_(True)
+    O.TRAIN = O.TrainCtx(0) if train else None
+    try:
+        (O.mixed_op(x64, sd64, "", prim) * r.double()).sum().backward()
+    finally:
+        O.TRAIN = None
+    assert float((xd.grad.cpu().double() - x64.grad).abs().max()) <= 1e-4 * float(x64.grad.abs().max())
+    for k, p in op.named_parameters():
+        ref = sd64[k].grad
+        assert p.grad is not None, k
+        assert float((p.grad.cpu().double() - ref).abs().max()) <= 1e-4 * max(float(ref.abs().max()), 1e-9) + 1e-7, (k, prim)
+    if train:
+        for k, v in op.state_dict().items():
+            if "running_" in k:
+                assert float((v.cpu().double() - sd64[k]).abs().max()) <= 1e-5, k
+
+
+def test_adamw_kernel_vs_torch_adamw():
+    """paif_adamw_step through PolyWarmupAdamW vs torch.optim.AdamW on the CPU: 3 steps, 3 parameter groups with their own lr /
+    weight decay, one parameter without a gradient (skipped: no weight decay either), the poly schedule in effect."""
+    from paif_amd.utils.optimizer import PolyWarmupAdamW
+
+    g = torch.Generator().manual_seed(3)
+    shapes = [(33, 7, 3, 3), (1,), (257,), (64, 64), (5, 1000), (9,)]
+    cpu = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+    gpu = [torch.nn.Parameter(p.detach().clone().to(_dev())) for p in cpu]
+    groups = lambda ps: [dict(params=ps[0:2], lr=1e-3, weight_decay=0.01), dict(params=ps[2:4], lr=1e-2, weight_decay=0.0),
+                         dict(params=ps[4:6], lr=3e-3, weight_decay=0.1)]
+    ref = torch.optim.AdamW(groups(cpu), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    mine = PolyWarmupAdamW(groups(gpu), lr=1e-3, weight_decay=0.01, betas=(0.9, 0.999), warmup_iter=2, max_iter=10, warmup_ratio=0.1, power=1.0)
+    base = [grp["lr"] for grp in ref.param_groups]
+    from oracle.paif_oracle import poly_warmup_lr_mult
+    for step in range(3):
+        ref.zero_grad()
+        mine.zero_grad()
+        for i, (pc, pg) in enumerate(zip(cpu, gpu)):
+            if i == 3:
+                continue                         # never gets a gradient
+            gr = torch.randn(pc.shape, generator=g) * (10.0 ** (i - 3))
+            pc.grad = gr.clone()
+            if i % 2 == 0:
+                ops.grad_of(pg).copy_(gr.to(_dev()))           # the wgrad kernels' route: into the arena slot
+            else:
+                pg.grad = gr.to(_dev())                        # a foreign tensor (plain autograd's route): adopted at step()
+        mult = poly_warmup_lr_mult(step, 2, 10, 0.1, 1.0)
+        for grp, b in zip(ref.param_groups, base):
+            grp["lr"] = b * mult
+        ref.step()
+        mine.step()
+        for i, (pc, pg) in enumerate(zip(cpu, gpu)):
+            assert float((pg.detach().cpu() - pc.detach()).abs().max()) <= 2e-6 * max(1.0, float(pc.abs().max())), (step, i)
+    assert torch.equal(gpu[3].detach().cpu(), cpu[3].detach())
+
+
+def test_training_step_two_optimizer_steps(golden):
+    """The adversarial-training step proper, twice: train mode (BatchNorm batch statistics x4, DropPath, Dropout2d from the
+    counter-based stream), `_loss_coupled(...).backward()`, PolyWarmupAdamW.step() -- losses, step-0 gradients, BatchNorm
+    running statistics and the parameter movement after two steps vs the oracle and the reference's golden run."""
+    from paif_amd.utils.optimizer import PolyWarmupAdamW
+
+    g = golden("gm_train_step_mit_b0_2x64x96")
+    inputs = training_inputs()
+    ir, vis, lab, ir_adv, vis_adv, mask = inputs
+    m = _model(train=True)
+    sd0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    pg = m.denoise_net.get_param_groups()
+    opt = PolyWarmupAdamW(params=[dict(params=pg[0], lr=LR, weight_decay=WD), dict(params=pg[1], lr=LR, weight_decay=0.0),
+                                  dict(params=pg[2], lr=LR * 10, weight_decay=WD),
+                                  dict(params=list(m.enhance_net.parameters()), lr=LR, weight_decay=WD)],
+                          lr=LR, weight_decay=WD, betas=BETAS, **SCHED)
+    opt.global_step = START_STEP
+    d = lambda a: t(a).to(_dev())
+    for step in range(2):
+        ops.DROP_RNG.reseed(DROP_SEED, rank=0, step=step)
+        opt.zero_grad()
+        loss = m._loss_coupled((d(ir_adv), d(ir)), (d(vis_adv), d(vis)), d(mask), d(lab))
+        loss.backward()
+        assert abs(float(loss) - float(g["losses"][step])) <= 1e-4 * abs(float(g["losses"][step])), (step, float(loss))
+        if step == 0:
+            l64, g64, _ = _oracle_grads("mit_b0", inputs, torch.float64, train_step=0)
+            l32, g32, sd32 = _oracle_grads("mit_b0", inputs, torch.float32, train_step=0)
+            assert abs(float(loss) - l64) <= 2e-5 * abs(l64)
+            _compare_grads(m, g64, g32, "train-mode", floor_mult=3.0, rel=5e-4)
+            for k, v in m.state_dict().items():
+                if "running_" in k:
+                    assert float((v.cpu() - t(g["bn0/" + k + "#b"])).abs().max()) <= 2e-6, k
+                if k.endswith("num_batches_tracked"):
+                    assert int(v) == 1
+        opt.step()
+        assert [grp["lr"] for grp in opt.param_groups] == pytest.approx(list(g["lrs"][step]), rel=1e-12)
+    bad = tot = 0
+    for k, p in m.named_parameters():
+        if k in NEVER:
+            assert torch.equal(p.detach().cpu(), sd0[k])          # no gradient: untouched (no weight decay either)
+            continue
+        b, n = movement_mismatch(g, k, (p.detach().cpu() - sd0[k]).reshape(-1).numpy(), sd0[k].reshape(-1).numpy(), GROUP_LR_WD[group_of(k)][0])
+        bad, tot = bad + b, tot + n
+    assert tot > 40000 and bad <= 0.01 * tot, (bad, tot)
+    for k, v in m.state_dict().items():
+        if "running_" in k:
+            assert float((v.cpu() - t(g["bn2/" + k + "#b"])).abs().max()) <= 1e-3, k
+    # the packed-weight caches followed the kernel's in-place update: an eval forward now uses the NEW weights
+    m.eval()
+    with torch.no_grad():
+        fused_new = m(d(ir), d(vis))[0]
+    m2 = _model()
+    m2.load_state_dict({k: v.detach().clone() for k, v in m.state_dict().items()})
+    with torch.no_grad():
+        fused_chk = m2(d(ir), d(vis))[0]
+    assert torch.equal(fused_new, fused_chk)
+
+
+def test_split_bf16_training_step_stays_within_the_fp32_noise():
+    """Default conv arithmetic (split-bf16 forward / dgrad, exact-fp32 wgrad): loss and gradients stay within a few times the
+    reference arithmetic's own fp32 floor."""
+    ops.set_conv_precision("bf16x3")
+    inputs = training_inputs()
+    ir, vis, lab, ir_adv, vis_adv, mask = inputs
+    m = _model()
+    d = lambda a: t(a).to(_dev())
+    loss = m._loss_coupled((d(ir_adv), d(ir)), (d(vis_adv), d(vis)), d(mask), d(lab))
+    loss.backward()
+    l64, g64, _ = _oracle_grads("mit_b0", inputs, torch.float64)
+    l32, g32, _ = _oracle_grads("mit_b0", inputs, torch.float32)
+    assert abs(float(loss) - l64) <= 1e-4 * abs(l64)
+    _compare_grads(m, g64, g32, "split-bf16", floor_mult=4.0, rel=2e-3)
