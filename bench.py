@@ -38,9 +38,14 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["fusion", "fusion_seg", "pgd"], default="fusion",
+    ap.add_argument("--workload", choices=["fusion", "fusion_seg", "pgd", "train"], default="fusion",
                     help="fusion = BASELINE configs[1] (the headline line); fusion_seg = configs[2] (bs=16, + mit_b3 SegFormer); "
-                         "pgd = configs[3] (PGD-10 attack + final forward, bs=8)")
+                         "pgd = configs[3] (PGD-10 attack + final forward, bs=8); train = configs[4] (adversarial-training step: "
+                         "PGD-k attack, _loss_coupled forward + full backward, gradient all-reduce over RCCL when N > 1, AdamW; bs=8/GPU)")
+    ap.add_argument("--attack-iters", type=int, default=5, help="PGD iterations inside the training step (robust_test.py:42 default)")
+    ap.add_argument("--backbone", default="mit_b3")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="BASELINE.md 3b protocol for both batch sizes (3 warm-up + 5 timed at "
+                    "B=1 and B=8: several minutes of CPU time); default = that protocol at B=1, one timed forward at B=8")
     ap.add_argument("--conv-precision", choices=["f32", "bf16x3"], default="bf16x3",
                     help="arithmetic of the dense convs: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs, fp32 accumulate)")
     args = ap.parse_args()
@@ -51,14 +56,16 @@ def main():
     if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, world, args.gpus))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X; there is no CPU path")
-    torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
+        # the process group comes up BEFORE this process makes any other GPU call.  RCCL over xGMI: configs 1-3 use it for the
+        # barrier + max-over-ranks only (replicas); configs[4] for the bucketed gradient all-reduce
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)  # RCCL; used for the barrier + max-over-ranks only
+        dist.init_process_group("nccl", device_id=dev)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU path")
+    torch.cuda.set_device(local_rank)
 
     from paif_amd.genotypes import FUSION_AT
     from paif_amd import ops, synthetic as S
@@ -69,8 +76,11 @@ def main():
     bpg = 16 if args.workload == "fusion_seg" else B_PER_GPU
     if args.workload == "fusion":
         net = Network_Fusion_Searched(32, None, FUSION_AT).eval()
+    elif args.workload == "train":
+        from paif_amd.core.loss import Fusionloss_grad2
+        net = Network_MM_Searched(32, FUSION_AT, Fusionloss_grad2(), torch.nn.CrossEntropyLoss(ignore_index=255), args.backbone, num_classes=9)
     else:
-        net = Network_MM_Searched(32, FUSION_AT, None, None, "mit_b3", num_classes=9).eval()
+        net = Network_MM_Searched(32, FUSION_AT, None, None, args.backbone, num_classes=9).eval()
     S.load_formula_weights(net)          # formula weights: no checkpoint exists (reference README.md:34-37)
     net = net.to(dev)
     ir_np, vis_np, lab_np = S.make_batch(bpg, H, W, start=rank * bpg)   # this rank's shard
@@ -87,6 +97,45 @@ def main():
         def step():
             with torch.no_grad():
                 return net(ir, vis)[1]
+    elif args.workload == "train":
+        # The adversarial-training step the reference's API implies (the reference ships no training loop):
+        #   delta = attack_both(model, ...)  [eval mode, input gradients only]
+        #   loss = model._loss_coupled([ir+d_ir, ir], [vis+d_vis, vis], mask, labels); loss.backward()   [train mode]
+        #   gradient all-reduce (N > 1, bucketed, overlapped with the reverse pass); PolyWarmupAdamW.step()
+        from paif_amd.attack.attack import attack_both
+        from paif_amd.dist_utils import GradAllReduce
+        from paif_amd.utils.optimizer import PolyWarmupAdamW
+        import numpy as np
+        pg = net.denoise_net.get_param_groups()                       # configs/voc.yaml:12-31 + the SegFormer recipe
+        opt = PolyWarmupAdamW(params=[dict(params=pg[0], lr=8e-5, weight_decay=0.01), dict(params=pg[1], lr=8e-5, weight_decay=0.0),
+                                      dict(params=pg[2], lr=8e-4, weight_decay=0.01),
+                                      dict(params=list(net.enhance_net.parameters()), lr=8e-5, weight_decay=0.01)],
+                              lr=8e-5, weight_decay=0.01, betas=(0.9, 0.999), warmup_iter=3000, max_iter=160000, warmup_ratio=1e-5, power=1.0)
+        reducer = GradAllReduce(opt.arena(), model=net).install() if world > 1 else None
+        mask = torch.from_numpy(np.maximum(ir_np, vis_np[:, :1]).astype("float32")).to(dev)    # fusion target: any [B,1,H,W] image
+        d0i = torch.from_numpy(S.make_delta0(rank, ir_np.shape, 8 / 255.)).to(dev)
+        d0v = torch.from_numpy(S.make_delta0(100 + rank, vis_np.shape, 8 / 255.)).to(dev)
+        state = {"step": 0, "exposed_ms": 0.0}
+
+        def step():
+            net.eval()
+            with torch.no_grad():
+                d_ir, d_vis = attack_both(net, vis, ir, lab, attack_loss="l_seg", attack_iters=args.attack_iters, epsilon=8 / 255.,
+                                          alpha=2 / 255., attack_way="PGD", delta0_ir=d0i, delta0_vis=d0v)
+            net.train()
+            ops.DROP_RNG.reseed(20261003, rank=rank, step=state["step"])
+            opt.zero_grad()
+            loss = net._loss_coupled((ops.add(ir, d_ir.detach()), ir), (ops.add(vis, d_vis.detach()), vis), mask, lab)
+            loss.backward()
+            if reducer is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                reducer.finish()
+                e1.record()
+                state.setdefault("events", []).append((e0, e1))
+            opt.step()
+            state["step"] += 1
+            return loss.detach()
     else:
         from paif_amd.attack.attack import attack_both
         d0i = torch.from_numpy(S.make_delta0(rank, ir_np.shape, 8 / 255.)).to(dev)
@@ -133,31 +182,51 @@ def main():
             # (fp32 storage) the HBM roof binds (833e12 / 8e12 = 104 FLOP/B)
             roof = {"kernel": DOMINANT, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": gbs / HBM_PEAK_GBS, "algorithmic_tflops": tflops}
-        traffic = None
-        try:   # PMC counters cannot be read live: use the committed rocprofv3 --pmc summary of this same command
+        # PMC counters cannot be read live: `traffic` comes from the committed rocprofv3 --pmc summary of this same command,
+        # and ONLY while that summary still describes the kernel being benchmarked (hash of its source) -- otherwise null + why
+        traffic, traffic_note = None, None
+        try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(DOMINANT)
-            if pm and args.workload == "fusion":
+            if not pm:
+                traffic_note = "no PMC record for %s" % DOMINANT
+            elif args.workload != "fusion":
+                traffic_note = "PMC record is for the configs[1] workload"
+            elif pm.get("kernel_source_sha16") != kernel_source_sha16():
+                traffic_note = "stale: profiles/pmc_traffic.json was measured on kernel source %s, the library is built from %s" % (
+                    pm.get("kernel_source_sha16"), kernel_source_sha16())
+            else:
                 traffic = pm["traffic_bytes"]
-        except (OSError, ValueError):
-            pass
+        except (OSError, ValueError) as e:
+            traffic_note = "pmc_traffic.json unreadable: %s" % e
         roof.update({"traffic": traffic, "launches": n, "avg_launch_ms": ms / n, "algorithmic_gflop_per_launch": flops / n / 1e9,
                      "algorithmic_mb_per_launch": nbytes / n / 1e6})
+        if traffic_note:
+            roof["traffic_note"] = traffic_note
         res = {
-            "metric": "fused image-pairs/sec at 480x640 bs=%d per GPU (%s)" % (bpg, {"fusion": "fusion-net forward", "fusion_seg": "fusion + SegFormer forward", "pgd": "PGD-10 adversarial eval"}[args.workload]),
+            "metric": "fused image-pairs/sec at 480x640 bs=%d per GPU (%s)" % (bpg, {"fusion": "fusion-net forward", "fusion_seg": "fusion + SegFormer forward", "pgd": "PGD-10 adversarial eval", "train": "adversarial-training step"}[args.workload]),
             "value": pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.conv_precision == "f32" else "f32 (storage and accumulation f32; conv products as split-bf16: 3x bf16 MFMA)",
             "data": "synthetic",
             "config": {"workload": {"fusion": "configs[1]: fusion-net forward (RGB2YCrCb + Network_Fusion_Searched, C=32, shipped genotype)",
                                     "fusion_seg": "configs[2]: fusion + mit_b3 SegFormer end-to-end inference",
-                                    "pgd": "configs[3]: PGD-10 attack_both (fwd + input-grad bwd x10) + final forward, mit_b3"}[args.workload]
+                                    "pgd": "configs[3]: PGD-10 attack_both (fwd + input-grad bwd x10) + final forward, mit_b3",
+                                    "train": "configs[4]: adversarial-training step = PGD-%d attack_both (eval mode) + _loss_coupled forward/backward with "
+                                             "all parameter gradients (train mode) + %s + PolyWarmupAdamW (one AdamW kernel over the flat arena), %s"
+                                             % (args.attack_iters, "bucketed RCCL gradient all-reduce overlapped with the backward" if world > 1
+                                                else "no all-reduce at N=1", args.backbone)}[args.workload]
                                    + ", 480x640, bs=%d/GPU, fp32 storage, conv precision %s" % (bpg, args.conv_precision),
                        "batch_per_gpu": bpg,
-                       "parallelism": "replicas x%d (no data-path collective)" % world},
+                       "parallelism": ("dp%d: batch sharded, weights replicated, 179.5 MB fp32 gradient all-reduce (25 MB buckets) per step" % world
+                                       if args.workload == "train" else "replicas x%d (no data-path collective)" % world)},
             "roofline": roof,
         }
+        if args.workload == "train":
+            res["steps_per_s"] = args.steps / dt
+            if state.get("events"):
+                res["allreduce_exposed_ms_per_step"] = sum(a.elapsed_time(b) for a, b in state["events"][-args.steps:]) / args.steps
         if world == 1 and not args.no_cpu_baseline and args.workload == "fusion":
-            res["cpu_baseline"] = cpu_baseline(ir_np, vis_np)
+            res["cpu_baseline"] = cpu_baseline(ir_np, vis_np, args.cpu_baseline_full)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
@@ -177,9 +246,30 @@ def host_cores():
     return n
 
 
-def cpu_baseline(ir_np, vis_np):
-    """The CPU oracle (fp32 torch port of the reference's path) on the host cores: same workload, bounded
-    sample = 1 pair per forward, 1 warm-up + 3 timed forwards (~10-20 s)."""
+def kernel_source_sha16():
+    """Identity of the dominant kernel's source (the dense-conv file + the shared header): ties a PMC record to a build."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("paif_amd/csrc/conv_mfma.hip", "paif_amd/csrc/paif_common.h"):
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(ir_np, vis_np, full=False):
+    """The CPU oracle (fp32 torch port of the reference's path, pinned to the reference by tests/test_oracle_golden.py) on the
+    host cores this job may use.  BASELINE.md 3b protocol: 3 warm-up + 5 timed forwards at B=1; B=8 gets the same protocol
+    with --cpu-baseline-full, otherwise ONE timed forward (it costs ~8x a B=1 forward and the default run must stay within
+    minutes).  value = best-B pairs/s."""
     from oracle import paif_oracle as O
     from paif_amd import synthetic as S
     from paif_amd.core.model_fusion_auto import Network_Fusion_Searched
@@ -190,21 +280,31 @@ def cpu_baseline(ir_np, vis_np):
     net = Network_Fusion_Searched(32, None, FUSION_AT)
     S.load_formula_weights(net)
     sd = {k: v.clone() for k, v in net.state_dict().items()}
-    ir, vis = torch.from_numpy(ir_np[:1]), torch.from_numpy(vis_np[:1])
 
-    def fwd():
-        with torch.no_grad():
-            ycc = O.rgb2ycrcb(vis)
-            return O.fusion_forward(ir, ycc[:, 0:1], sd)
+    def rate(B, warm, reps):
+        ir, vis = torch.from_numpy(ir_np[:B]), torch.from_numpy(vis_np[:B])
 
-    fwd()
-    t0 = time.perf_counter()
-    reps = 3
-    for _ in range(reps):
-        fwd()
-    dt = (time.perf_counter() - t0) / reps
-    return {"value": 1.0 / dt, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "oracle fusion forward, B=1 480x640 fp32, 1 warm-up + %d timed forwards, torch %s CPU" % (reps, torch.__version__)}
+        def fwd():
+            with torch.no_grad():
+                ycc = O.rgb2ycrcb(vis)
+                return O.fusion_forward(ir, ycc[:, 0:1], sd)
+
+        for _ in range(warm):
+            fwd()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fwd()
+        return B * reps / (time.perf_counter() - t0)
+
+    r1 = rate(1, 3, 5)
+    r8 = rate(8, 3, 5) if full else rate(8, 0, 1)
+    logical = os.cpu_count() or 0
+    return {"value": max(r1, r8), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "by_batch": {"1": r1, "8": r8},
+            "cpu_model": cpu_model(), "logical_cpus": logical, "cpu_quota": cores,
+            "sample": "oracle fusion forward 480x640 fp32, torch %s CPU, %d threads (= the job's CPU quota on a host with %d logical CPUs); "
+                      "B=1: 3 warm-up + 5 timed; B=8: %s; value = best batch size" % (
+                          torch.__version__, torch.get_num_threads(), logical, "3 warm-up + 5 timed" if full else "1 timed forward, no warm-up")}
 
 
 if __name__ == "__main__":

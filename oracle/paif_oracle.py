@@ -552,7 +552,7 @@ def ssim(img1, img2, window_size=11):
     ch = img1.shape[1]
     g = torch.tensor([math.exp(-(x - window_size // 2) ** 2 / float(2 * 1.5 ** 2)) for x in range(window_size)])
     g = (g / g.sum()).unsqueeze(1)
-    win = g.mm(g.t()).float()[None, None].expand(ch, 1, window_size, window_size).contiguous()
+    win = g.mm(g.t()).float()[None, None].expand(ch, 1, window_size, window_size).contiguous().to(img1.dtype)   # built in fp32 like the reference
     pad = window_size // 2
     mu1, mu2 = F.conv2d(img1, win, padding=pad, groups=ch), F.conv2d(img2, win, padding=pad, groups=ch)
     mu1_sq, mu2_sq, mu12 = mu1.pow(2), mu2.pow(2), mu1 * mu2

@@ -422,9 +422,25 @@ class SepConv(_HipOp):
         )
 
     def backward_nhwc(self, g, t, wgrad=False):
-        if wgrad:
-            raise NotImplementedError("SepConv: parameter gradients are built for the shipped genotype's operators only")
         op = self.op
+        if "c2" in t:   # split form (train-mode BatchNorm and / or parameter gradients)
+            go = lambda p_: ops.grad_of(p_) if wgrad else None
+            aff = lambda bn: (go(bn.weight), go(bn.bias)) if bn.affine else (None, None)
+            d_c2 = ops.bn_act_bwd(g, t["c2"], t["stats2"], ops.ACT_NONE, None, *aff(op[7]), None, training=t["bn_training"])
+            d_t2 = ops.conv2d([d_c2], self._dgrad_w("c6", op[6].weight), 1, 1)
+            d_a = ops.dwconv_bwd(d_t2, op[5].weight, self.k, 1)                         # a = ReLU(BN1(c1)): the gate is in bn_act_bwd
+            d_c1 = ops.bn_act_bwd(d_a, t["c1"], t["stats1"], ops.ACT_RELU, None, *aff(op[3]), None, training=t["bn_training"])
+            d_t = ops.conv2d([d_c1], self._dgrad_w("c2", op[2].weight), 1, 1)
+            if wgrad:
+                for w, src, dout in ((op[6].weight, t["t2"], d_c2), (op[2].weight, t["t"], d_c1)):
+                    gw = ops.grad_of(w)
+                    if gw is not None:
+                        ops.conv2d_wgrad([src], dout, 1, 1, out=gw)
+                for w, src, dout, relu in ((op[5].weight, t["a"], d_t2, False), (op[1].weight, t["x"], d_t, True)):
+                    gw = ops.grad_of(w)
+                    if gw is not None:
+                        ops.dwconv_wgrad(src, dout, self.k, 1, relu, gw)
+            return ops.dwconv_bwd(d_t, op[1].weight, self.k, 1, aux=t["x"])
         s1, _ = _bn_scale_shift(op[3], self._packs, 'bn1')
         s2, _ = _bn_scale_shift(op[7], self._packs, 'bn2')
         d_t5 = ops.conv2d([g], self._dgrad_w("c6", op[6].weight), 1, 1, in_act=ops.IN_SCALE, in_scale=s2)
@@ -436,6 +452,16 @@ class SepConv(_HipOp):
         op = self.op
         t = ops.dwconv(x, op[1].weight, self.k, 1, in_relu=True)
         w1 = self._packs.get("w1", [op[2].weight], lambda: ops.pack_conv_weight(op[2].weight, 1, 32, 1))
+        w2 = self._packs.get("w2", [op[6].weight], lambda: ops.pack_conv_weight(op[6].weight, 1, 32, 1))
+        if op[3].training or (tape is not None and ops.taping_wgrad()):
+            c1 = ops.conv2d([t], w1, 1, 1)
+            a, stats1 = _bn_split(op[3], c1, ops.ACT_RELU, None, ())
+            t2 = ops.dwconv(a, op[5].weight, self.k, 1, in_relu=False)
+            c2 = ops.conv2d([t2], w2, 1, 1)
+            out, stats2 = _bn_split(op[7], c2, ops.ACT_NONE, None, tuple(res))
+            if tape is not None:
+                tape.append(dict(x=x, t=t, c1=c1, a=a, t2=t2, c2=c2, stats1=stats1, stats2=stats2, bn_training=op[3].training))
+            return out
         s1, b1 = _bn_scale_shift(op[3], self._packs, 'bn1')
         if tape is not None:
             t, z3 = ops.conv2d([t], w1, 1, 1, scale=s1, shift=b1, act=ops.ACT_RELU, want_aux=True)
@@ -443,7 +469,6 @@ class SepConv(_HipOp):
         else:
             t = ops.conv2d([t], w1, 1, 1, scale=s1, shift=b1, act=ops.ACT_RELU)
         t = ops.dwconv(t, op[5].weight, self.k, 1, in_relu=False)
-        w2 = self._packs.get("w2", [op[6].weight], lambda: ops.pack_conv_weight(op[6].weight, 1, 32, 1))
         s2, b2 = _bn_scale_shift(op[7], self._packs, 'bn2')
         return ops.conv2d([t], w2, 1, 1, scale=s2, shift=b2, res=res)
 
@@ -533,17 +558,38 @@ class Spatial_BasicBlock(_HipOp):
         wsp = self.se.spatial.conv.weight
         if tape is None:
             out = ops.spa1(o, r, wsp, self.k, a)
+        elif ops.taping_wgrad():
+            out, u, s, comp = ops.spa1(o, r, wsp, self.k, a, save=True, want_comp=True)
+            tape.append(dict(r=r, o=o, u=u, s=s, x=x, comp=comp))
         else:
             out, u, s = ops.spa1(o, r, wsp, self.k, a, save=True)
             tape.append(dict(r=r, o=o, u=u, s=s))
         return self._add_res(out, res)
 
     def backward_nhwc(self, g, t, wgrad=False):
-        if wgrad:
-            raise NotImplementedError("SPAattention: parameter gradients are built for the shipped genotype's operators only")
         a = self.relu.weight
-        d_o, d_r = ops.spa1_bwd(g, t["u"], t["o"], t["s"], self.se.spatial.conv.weight, self.k, a)
-        d_r = ops.conv2d([d_o], self._dgrad_w("c2", self.conv2.conv.weight), self.k, 1, epi_dact=1, epi_aux=t["r"], prelu=a, res=(d_r,))
+        wsp = self.se.spatial.conv.weight
+        if not wgrad:
+            d_o, d_r = ops.spa1_bwd(g, t["u"], t["o"], t["s"], wsp, self.k, a)
+            d_r = ops.conv2d([d_o], self._dgrad_w("c2", self.conv2.conv.weight), self.k, 1, epi_dact=1, epi_aux=t["r"], prelu=a, res=(d_r,))
+            return ops.conv2d([d_r], self._dgrad_w("c1", self.conv1.weight), 3, 1)
+        ds = ops.grad_of(a)
+        if ds is not None:
+            ops.prelu_bwd(g, t["u"], a, ds)                                   # out = PReLU(u)
+        d_o, d_r, dpre = ops.spa1_bwd(g, t["u"], t["o"], t["s"], wsp, self.k, a, want_dpre=True)
+        gsp = ops.grad_of(wsp)
+        if gsp is not None:   # 2 -> 1 conv: the pooled map zero padded to 4 channels, first 2*k*k values of the 4-channel gradient
+            tmp = torch.zeros(4 * self.k * self.k, device=g.device, dtype=torch.float32)
+            ops.corr1_wgrad(dpre, ops.pad_channels(t["comp"], 4), self.k, tmp)
+            ops.axpy_(gsp.view(-1), tmp[:2 * self.k * self.k])
+        gw2 = ops.grad_of(self.conv2.conv.weight)
+        if gw2 is not None:
+            ops.conv2d_wgrad([ops.affine_act_res(t["r"], None, None, ops.ACT_PRELU, a)], d_o, self.k, 1, out=gw2)
+        tt = ops.conv2d([d_o], self._dgrad_w("c2", self.conv2.conv.weight), self.k, 1)
+        d_r = ops.prelu_bwd(tt, t["r"], a, ds, add=d_r, want_dx=True)
+        gw1 = ops.grad_of(self.conv1.weight)
+        if gw1 is not None:
+            ops.conv2d_wgrad([t["x"]], d_r, 3, 1, out=gw1)
         return ops.conv2d([d_r], self._dgrad_w("c1", self.conv1.weight), 3, 1)
 
 

@@ -1109,7 +1109,7 @@ def confusion_matrix_accum_(conf, label, pred, ncls):
 # ---------------------------------------------------------------------------------------------
 # SPAattention
 # ---------------------------------------------------------------------------------------------
-def spa1(o, r, w, k, prelu, save=False):
+def spa1(o, r, w, k, prelu, save=False, want_comp=False):
     B, H, W, _ = o.shape
     comp = torch.empty((B, H, W, 2), device=o.device, dtype=torch.float32)
     out = torch.empty_like(o)
@@ -1117,13 +1117,15 @@ def spa1(o, r, w, k, prelu, save=False):
     u = torch.empty_like(o) if save else None
     _lib.check(lib().paif_spa1_fwd(_p(o), _p(r), _p(w.detach().contiguous()), k, _p(prelu), _p(comp), _p(s), _p(u), _p(out), B, H, W, _stream()),
                "spa1")
+    if want_comp:
+        return out, u, s, comp
     return (out, u, s) if save else out
 
 
-def spa1_bwd(dout, u, o, s, w, k, prelu):
+def spa1_bwd(dout, u, o, s, w, k, prelu, want_dpre=False):
     B, H, W, _ = o.shape
     dpre = torch.empty((B, H, W), device=o.device, dtype=torch.float32)
     d_o, d_r = torch.empty_like(o), torch.empty_like(o)
     _lib.check(lib().paif_spa1_bwd_input(_p(dout), _p(u), _p(o), _p(s), _p(w.detach().contiguous()), k, _p(prelu), _p(dpre), _p(d_o), _p(d_r),
                                          B, H, W, _stream()), "spa1_bwd")
-    return d_o, d_r
+    return (d_o, d_r, dpre) if want_dpre else (d_o, d_r)

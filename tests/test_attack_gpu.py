@@ -356,3 +356,33 @@ def test_dense_conv_weight_gradient(kh, dil, nsrc, act):
                           prelu=slope.to(dev) if act == 1 else None, alpha=0.5)
     ref = w.grad
     assert maxabs(dw.cpu(), ref) <= 2e-5 * float(ref.abs().max()), (maxabs(dw.cpu(), ref), float(ref.abs().max()))
+
+
+def test_round2_attack_branches(golden):
+    """Round-2 attack rows against the reference's own outputs (tests/golden/gg3_attacks_round2.npz):
+    * attack_vis / attack_ir called exactly the way robust_test.py:169-176 calls them (keywords, X_fusion=, 'newPGD');
+    * pgd_attack_ir with attack_loss='l_ssim' (attack/attack.py:136-137): pytorch_ssim.SSIM on the recomposed RGB image,
+      evaluated by the HIP SSIM forward / gradient kernels."""
+    from paif_amd.attack import attack as A
+
+    g = golden("gg3_attacks_round2")
+    m = _model("mit_b0")
+    ir, vis, lab = S.make_batch(2, 64, 96)
+    irt, vist, labt = t(ir).to(_dev()), t(vis).to(_dev()), t(lab).to(_dev())
+    eps, alpha = 8 / 255., 2 / 255.
+    with torch.no_grad():
+        fused = m(irt, vist)[0]
+        d_vi = A.attack_vis(m, X_vis=vist, X_ir=irt, X_fusion=fused, label=labt, attack_loss="l_seg", attack_iters=2, epsilon=eps,
+                            alpha=alpha, attack_mode="vis", attack_way="newPGD", delta0_vis=t(g["attack_vis.newPGD.d0"]))
+        d_ir = A.attack_ir(m, X_vis=vist, X_ir=irt, X_fusion=fused, label=labt, attack_loss="l_seg", attack_iters=2, epsilon=eps,
+                           alpha=alpha, attack_mode="ir", attack_way="newPGD", delta0_ir=t(g["attack_ir.newPGD.d0"]))
+    # positional call with the reference's argument order binds X_fusion to the 4th slot, not the label
+    with torch.no_grad():
+        d_pos = A.attack_ir(m, vist, irt, fused, labt, eps, alpha, 2, 1, "l_seg", "ir", "newPGD", delta0_ir=t(g["attack_ir.newPGD.d0"]))
+    assert torch.equal(d_pos.detach(), d_ir.detach())
+    X_rgb = t(g["X_rgb"]).to(_dev())
+    d_ss = A.pgd_attack_ir(m, vist, irt, X_rgb, labt, eps, alpha, 2, 1, "l_ssim", delta0=t(g["pgd_attack_ir.l_ssim.d0"]))
+    for name, d in (("attack_vis.newPGD", d_vi), ("attack_ir.newPGD", d_ir), ("pgd_attack_ir.l_ssim", d_ss)):
+        a, ref = d.detach().cpu().numpy(), g[name + ".delta"]
+        assert a.shape == ref.shape and np.abs(a).max() <= eps + 1e-7
+        assert (np.abs(a - ref) > 1e-6).mean() <= 5e-3, name

@@ -115,6 +115,8 @@ def test_train_mode_forward_matches_oracle():
     m.train()
     ir, vis, _ = S.make_batch(2, 64, 96)
     ops.DROP_RNG.reseed(77, rank=1, step=5)
+    old = ops.CONFIG["conv_precision"]
+    ops.set_conv_precision("f32")
     try:
         with torch.no_grad():
             fused, seg = m(t(ir).to(_dev()), t(vis).to(_dev()))
@@ -124,6 +126,7 @@ def test_train_mode_forward_matches_oracle():
     finally:
         O.TRAIN = None
         m.eval()
+        ops.set_conv_precision(old)
     assert maxabs(fused.cpu(), fo) <= 1e-4
     assert maxabs(seg.cpu(), so) <= 1e-3 * float(so.max() - so.min())
 
