@@ -84,8 +84,10 @@ int paif_guided_filter_ab_fwd(const float* guide, const float* y, float* ab, flo
                               int B, int H, int W, paif_stream_t stream);
 int paif_guided_filter_lf_fwd(const float* guide, const float* ab, float* lf, int B, int H, int W,
                               paif_stream_t stream);
-/* Both stages fused (inference: the coefficient maps never reach HBM); same result as ab_fwd + lf_fwd. */
-int paif_guided_filter_fused_fwd(const float* guide, const float* y, float* lf, float eps0, float eps1,
+/* Both stages fused (inference: the coefficient maps never reach HBM); same result as ab_fwd + lf_fwd.
+ * workspace: paif_guided_filter_fused_workspace_floats(B,H,W) floats (per-pixel guide statistics for both eps). */
+size_t paif_guided_filter_fused_workspace_floats(int B, int H, int W);
+int paif_guided_filter_fused_fwd(const float* guide, const float* y, float* lf, float eps0, float eps1, float* workspace,
                                  int B, int H, int W, paif_stream_t stream);
 
 /* Dense k x k convolution, stride 1, "same" zero padding (pad = dil*(k-1)/2), Cout <= 32, inputs =

@@ -227,40 +227,88 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
+// Per-pixel guide statistics of the fused kernel, precomputed once per stream (1-channel work: 3 % of the traffic):
+//   gs[e][px] = (mean_g, 1 / (var_g + eps_e))  with the border-clipped 9x9 window -- direct sums, fp32.
+// In the fused kernel these were recomputed by all 8 channel-quad lanes of every column in every workgroup (17 % of
+// its VALU instructions, a fifth of its LDS operations and one of its three divisions per row).
+__global__ __launch_bounds__(256) void gf_guide_stats_kernel(const float* __restrict__ guide, float2* __restrict__ gs, float eps0,
+                                                             float eps1, int B, int H, int W) {
+  const size_t npix = (size_t)B * H * W;
+  for (size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x; pix < npix; pix += (size_t)gridDim.x * 256) {
+    const int x0 = (int)(pix % W);
+    const size_t rowid = pix / W;
+    const int y0 = (int)(rowid % H);
+    const float* base = guide + (rowid - y0) * W;
+    float s = 0.f, ss = 0.f;
+    for (int yy = max(y0 - R, 0); yy <= min(y0 + R, H - 1); ++yy)
+      for (int xx = max(x0 - R, 0); xx <= min(x0 + R, W - 1); ++xx) {
+        const float g = base[(size_t)yy * W + xx];
+        s += g;
+        ss = fmaf(g, g, ss);
+      }
+    const int cy = min(y0 + R, H - 1) - max(y0 - R, 0) + 1;
+    const int cx = min(x0 + R, W - 1) - max(x0 - R, 0) + 1;
+    const float rn = 1.0f / (float)(cy * cx);
+    const float mg = s * rn;
+    const float var = ss * rn - mg * mg;
+    gs[pix] = make_float2(mg, 1.0f / (var + eps0));
+    gs[npix + pix] = make_float2(mg, 1.0f / (var + eps1));
+  }
+}
+
 __global__ __launch_bounds__(512) void gf_fused_kernel(const float* __restrict__ guide, const float* __restrict__ y,
-                                                       float* __restrict__ lf, float eps0, float eps1, int B, int H, int W,
+                                                       const float2* __restrict__ gs, float* __restrict__ lf, int B, int H, int W,
                                                        int nstrip, int nseg, int frows) {
   __shared__ float4 s_a[2][FC][8];
   __shared__ float4 s_b[2][FC][8];
-  __shared__ float2 s_g[2][FC];
   const int q = threadIdx.x & 7, xi = threadIdx.x >> 3;
   int t = blockIdx.x;
   const int strip = t % nstrip; t /= nstrip;
   const int seg = t % nseg;
   const int b = t / nseg;
   const int e = blockIdx.y;
-  const float eps = e == 0 ? eps0 : eps1;
   const int col = strip * FO - 2 * R + xi;
   const bool colin = col >= 0 && col < W;
   const int ybeg = seg * frows, yend = min(H, ybeg + frows);   // frows = output rows per workgroup (chosen at launch)
   const size_t img = (size_t)b * H * W;
   float* out = lf + (size_t)e * ((size_t)B * H * W * 32);
+  const float2* gse = gs + (size_t)e * ((size_t)B * H * W);
 
-  float4 ry[K], rA[K], rB[K];
-  float rg[K];
+  // 1/n of the border-clipped window, n = cy * cx: cx is fixed per thread and cy takes the values 5..9 -- the five
+  // reciprocals are formed once (exact divisions, same values as before) instead of one division per row and stage
+  const int cx = min(col + R, W - 1) - max(col - R, 0) + 1;
+  float rnt[R + 1];
 #pragma unroll
-  for (int k = 0; k < K; ++k) { rA[k] = make_float4(0.f, 0.f, 0.f, 0.f); rB[k] = rA[k]; }
+  for (int i = 0; i <= R; ++i) rnt[i] = 1.0f / (float)((K - i) * max(cx, 1));
+  auto rn_of = [&](int row) -> float {
+    const int miss = K - (min(row + R, H - 1) - max(row - R, 0) + 1);    // rows clipped away: 0..4
+    float r = rnt[0];
+#pragma unroll
+    for (int i = 1; i <= R; ++i) r = miss == i ? rnt[i] : r;
+    return r;
+  };
+
+  // ring 1: the last 9 rows of y and of the guide.  ring 2 holds the (A, b) rows as 3-row partial sums:
+  //   tA[j] = A(i) + A(i+1) + A(i+2);   a 9-row window = three of them 3 rows apart (4 adds per row instead of 8, still a
+  //   plain sum of the nine terms -- no running add/subtract, no drift)
+  float4 ry[K], tA[K], tB[K];
+  float rg[K];
+  float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1, b1 = a1, b2 = a1;   // the two previous (A, b) rows
+#pragma unroll
+  for (int k = 0; k < K; ++k) { tA[k] = make_float4(0.f, 0.f, 0.f, 0.f); tB[k] = tA[k]; }
   const int r0 = ybeg - 2 * R, r1 = yend + 2 * R;   // streamed input rows [r0, r1)
   // Loads are unconditional on a clamped address (a load under a divergent branch makes hipcc wait for it at the
   // join); out-of-image values are zeroed when they enter the ring.
   const int colc = min(max(col, 0), W - 1);
   float4 pv[PF];
   float pg[PF];
+  float2 ps[PF];
 #pragma unroll
   for (int p = 0; p < PF; ++p) {
     const size_t px = img + (size_t)min(max(r0 + p, 0), H - 1) * W + colc;
     pv[p] = *reinterpret_cast<const float4*>(y + px * 32 + q * 4);
     pg[p] = guide[px];
+    ps[p] = gse[img + (size_t)min(max(r0 + p - R, 0), H - 1) * W + colc];
   }
   for (int rr = r0; rr < r1; rr += K) {
 #pragma unroll
@@ -270,64 +318,54 @@ __global__ __launch_bounds__(512) void gf_fused_kernel(const float* __restrict__
       const bool in = colin && row >= 0 && row < H;
       ry[k] = in ? pv[k % PF] : make_float4(0.f, 0.f, 0.f, 0.f);
       rg[k] = in ? pg[k % PF] : 0.f;
+      const float2 st = ps[k % PF];             // (mean_g, 1/(var_g + eps)) of (row - R, col)
       {
         const size_t px = img + (size_t)min(max(row + PF, 0), H - 1) * W + colc;
         pv[k % PF] = *reinterpret_cast<const float4*>(y + px * 32 + q * 4);
         pg[k % PF] = guide[px];
+        ps[k % PF] = gse[img + (size_t)min(max(row + PF - R, 0), H - 1) * W + colc];
       }
       const int irow = row - R;               // stage-1 row whose 9-row window is complete
       if (irow < ybeg - R) continue;          // block-uniform
       // ---- stage 1: vertical sums -> LDS -> horizontal sums -> (A, b) of (irow, col) ----
       {
         float4 vy = make_float4(0.f, 0.f, 0.f, 0.f), vgy = vy;
-        float vg = 0.f, vgg = 0.f;
 #pragma unroll
         for (int j = 0; j < K; ++j) {
           vy = f4add(vy, ry[j]);
           vgy = f4fma(rg[j], ry[j], vgy);
-          vg += rg[j];
-          vgg = fmaf(rg[j], rg[j], vgg);
         }
         s_a[0][xi][q] = vy;
         s_b[0][xi][q] = vgy;
-        if (q == 0) s_g[0][xi] = make_float2(vg, vgg);
       }
       lds_barrier();
       float4 A = make_float4(0.f, 0.f, 0.f, 0.f), Bc = A;
       if (xi >= R && xi < FC - R && colin && irow >= 0 && irow < H) {   // outside the image the coefficients are zero padding
         float4 by = make_float4(0.f, 0.f, 0.f, 0.f), bgy = by;
-        float bg = 0.f, bgg = 0.f;
 #pragma unroll
         for (int j = -R; j <= R; ++j) {
           by = f4add(by, s_a[0][xi + j][q]);
           bgy = f4add(bgy, s_b[0][xi + j][q]);
-          const float2 gg = s_g[0][xi + j];
-          bg += gg.x;
-          bgg += gg.y;
         }
-        const int cy = min(irow + R, H - 1) - max(irow - R, 0) + 1;
-        const int cx = min(col + R, W - 1) - max(col - R, 0) + 1;
-        const float rn = 1.0f / (float)(cy * cx);   // one exact division; x * (1/n) is within 1 ulp of x / n
-        const float mg = bg * rn;
-        const float rden = 1.0f / (bgg * rn - mg * mg + eps);
+        const float rn = rn_of(irow);
+        const float mg = st.x, rden = st.y;
         const float4 my = make_float4(by.x * rn, by.y * rn, by.z * rn, by.w * rn);
         A = make_float4((bgy.x * rn - mg * my.x) * rden, (bgy.y * rn - mg * my.y) * rden, (bgy.z * rn - mg * my.z) * rden,
                         (bgy.w * rn - mg * my.w) * rden);
         Bc = make_float4(my.x - A.x * mg, my.y - A.y * mg, my.z - A.z * mg, my.w - A.w * mg);
       }
-      rA[k] = A;   // ring 2 shares the slot index with ring 1 (both advance one row per iteration)
-      rB[k] = Bc;
+      // 3-row partial sums of ring 2: slot k <- rows (irow-2, irow-1, irow)
+      tA[k] = f4add(f4add(a2, a1), A);
+      tB[k] = f4add(f4add(b2, b1), Bc);
+      a2 = a1; a1 = A; b2 = b1; b1 = Bc;
       const int orow = irow - R;              // output row whose 9-row (A, b) window is complete
       // the first ring-2 window is complete once stage-1 rows ybeg-R .. ybeg+R are in
       if (orow < ybeg) { lds_barrier(); continue; }   // block-uniform; the barrier keeps s_*[0] safe for the next row
       // ---- stage 2: vertical sums of (A, b) -> LDS -> horizontal sums -> LF ----
       {
-        float4 ua = make_float4(0.f, 0.f, 0.f, 0.f), ub = ua;
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-          ua = f4add(ua, rA[j]);
-          ub = f4add(ub, rB[j]);
-        }
+        // window rows irow-8 .. irow = partial sums ending at irow, irow-3, irow-6 (slots k, k-3, k-6 mod 9)
+        const float4 ua = f4add(f4add(tA[k], tA[(k + 6) % K]), tA[(k + 3) % K]);
+        const float4 ub = f4add(f4add(tB[k], tB[(k + 6) % K]), tB[(k + 3) % K]);
         s_a[1][xi][q] = ua;
         s_b[1][xi][q] = ub;
       }
@@ -339,9 +377,7 @@ __global__ __launch_bounds__(512) void gf_fused_kernel(const float* __restrict__
           ba = f4add(ba, s_a[1][xi + j][q]);
           bb = f4add(bb, s_b[1][xi + j][q]);
         }
-        const int cy = min(orow + R, H - 1) - max(orow - R, 0) + 1;
-        const int cx = min(col + R, W - 1) - max(col - R, 0) + 1;
-        const float rn = 1.0f / (float)(cy * cx);
+        const float rn = rn_of(orow);
         const size_t px = img + (size_t)orow * W + col;
         const float g0 = rg[(k + 1) % K];   // guide(orow, col): the oldest ring-1 row (row - 2R)
         *reinterpret_cast<float4*>(out + px * 32 + q * 4) =
@@ -354,9 +390,11 @@ __global__ __launch_bounds__(512) void gf_fused_kernel(const float* __restrict__
 
 }  // namespace
 
-extern "C" int paif_guided_filter_fused_fwd(const float* guide, const float* y, float* lf, float eps0, float eps1, int B, int H,
-                                            int W, paif_stream_t stream) {
-  PAIF_REQUIRE(guide && y && lf && B > 0, PAIF_EINVAL, "guided_filter_fused: bad arguments");
+extern "C" size_t paif_guided_filter_fused_workspace_floats(int B, int H, int W) { return (size_t)4 * B * H * W; }
+
+extern "C" int paif_guided_filter_fused_fwd(const float* guide, const float* y, float* lf, float eps0, float eps1, float* workspace, int B,
+                                            int H, int W, paif_stream_t stream) {
+  PAIF_REQUIRE(guide && y && lf && workspace && B > 0, PAIF_EINVAL, "guided_filter_fused: bad arguments");
   PAIF_REQUIRE(H > 2 * R + 1 && W > 2 * R + 1, PAIF_EINVAL, "guided_filter: H,W must exceed 2r+1 = %d (got %dx%d)", K, H, W);
   const int nstrip = (W + FO - 1) / FO;
   // Rows per workgroup: one workgroup is resident per CU (246 VGPRs x 512 threads), so the launch runs in rounds of
@@ -371,8 +409,13 @@ extern "C" int paif_guided_filter_fused_fwd(const float* guide, const float* y, 
     if (best < 0 || cost < best) { best = cost; nseg = n; }
   }
   const int frows = (H + nseg - 1) / nseg;
-  hipLaunchKernelGGL(gf_fused_kernel, dim3(B * nstrip * nseg, 2), dim3(512), 0, paif::as_stream(stream), guide, y, lf, eps0, eps1, B,
-                     H, W, nstrip, nseg, frows);
+  hipStream_t st = paif::as_stream(stream);
+  float2* gs = reinterpret_cast<float2*>(workspace);
+  const size_t npix = (size_t)B * H * W;
+  hipLaunchKernelGGL(gf_guide_stats_kernel, dim3((unsigned)((npix + 255) / 256 < 4096 ? (npix + 255) / 256 : 4096)), dim3(256), 0, st, guide,
+                     gs, eps0, eps1, B, H, W);
+  PAIF_LAUNCH_CHECK("guided_filter_fused(stats)");
+  hipLaunchKernelGGL(gf_fused_kernel, dim3(B * nstrip * nseg, 2), dim3(512), 0, st, guide, y, gs, lf, B, H, W, nstrip, nseg, frows);
   PAIF_LAUNCH_CHECK("guided_filter_fused");
   return 0;
 }

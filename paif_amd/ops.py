@@ -287,7 +287,8 @@ def guided_filter_pair(guide, y, eps=(0.001, 0.0001), want_ab=False):
     lf = torch.empty((2, B, H, W, 32), device=y.device, dtype=torch.float32)
     L = lib()
     if not want_ab and CONFIG.get("gf_fused", True):
-        _lib.check(L.paif_guided_filter_fused_fwd(_p(guide), _p(y), _p(lf), eps[0], eps[1], B, H, W, _stream()), "guided_filter_fused")
+        ws = torch.empty(L.paif_guided_filter_fused_workspace_floats(B, H, W), device=y.device, dtype=torch.float32)
+        _lib.check(L.paif_guided_filter_fused_fwd(_p(guide), _p(y), _p(lf), eps[0], eps[1], _p(ws), B, H, W, _stream()), "guided_filter_fused")
         return lf
     ab = torch.empty((4, B, H, W, 32), device=y.device, dtype=torch.float32)
     _lib.check(L.paif_guided_filter_ab_fwd(_p(guide), _p(y), _p(ab), eps[0], eps[1], B, H, W, _stream()), "guided_filter_ab")
