@@ -231,26 +231,46 @@ __device__ __forceinline__ void lds_barrier() {
 //   gs[e][px] = (mean_g, 1 / (var_g + eps_e))  with the border-clipped 9x9 window -- direct sums, fp32.
 // In the fused kernel these were recomputed by all 8 channel-quad lanes of every column in every workgroup (17 % of
 // its VALU instructions, a fifth of its LDS operations and one of its three divisions per row).
+constexpr int GT = 32, GH = GT + 2 * R;   // 32 x 32 output tile, 40 x 40 halo tile
 __global__ __launch_bounds__(256) void gf_guide_stats_kernel(const float* __restrict__ guide, float2* __restrict__ gs, float eps0,
-                                                             float eps1, int B, int H, int W) {
-  const size_t npix = (size_t)B * H * W;
-  for (size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x; pix < npix; pix += (size_t)gridDim.x * 256) {
-    const int x0 = (int)(pix % W);
-    const size_t rowid = pix / W;
-    const int y0 = (int)(rowid % H);
-    const float* base = guide + (rowid - y0) * W;
+                                                             float eps1, int B, int H, int W, int tilesX, int tilesY) {
+  __shared__ float sG[GH][GH + 1];
+  __shared__ float sH[GH][GT + 1], sH2[GH][GT + 1];
+  int t = blockIdx.x;
+  const int tx = t % tilesX; t /= tilesX;
+  const int ty = t % tilesY;
+  const int b = t / tilesY;
+  const int x0 = tx * GT - R, y0 = ty * GT - R;
+  const float* base = guide + (size_t)b * H * W;
+  for (int i = threadIdx.x; i < GH * GH; i += 256) {
+    const int r = i / GH, c = i - r * GH;
+    const int gy = y0 + r, gx = x0 + c;
+    const float v = base[(size_t)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1)];   // unconditional load, zero by select
+    sG[r][c] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? v : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < GH * GT; i += 256) {      // horizontal 9-sums of g and g^2
+    const int r = i / GT, c = i - r * GT;
     float s = 0.f, ss = 0.f;
-    for (int yy = max(y0 - R, 0); yy <= min(y0 + R, H - 1); ++yy)
-      for (int xx = max(x0 - R, 0); xx <= min(x0 + R, W - 1); ++xx) {
-        const float g = base[(size_t)yy * W + xx];
-        s += g;
-        ss = fmaf(g, g, ss);
-      }
-    const int cy = min(y0 + R, H - 1) - max(y0 - R, 0) + 1;
-    const int cx = min(x0 + R, W - 1) - max(x0 - R, 0) + 1;
+#pragma unroll
+    for (int j = 0; j < K; ++j) { const float g = sG[r][c + j]; s += g; ss = fmaf(g, g, ss); }
+    sH[r][c] = s; sH2[r][c] = ss;
+  }
+  __syncthreads();
+  const size_t npix = (size_t)B * H * W;
+  for (int i = threadIdx.x; i < GT * GT; i += 256) {      // vertical 9-sums -> statistics
+    const int r = i / GT, c = i - r * GT;
+    const int yy = ty * GT + r, xx = tx * GT + c;
+    if (yy >= H || xx >= W) continue;
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < K; ++j) { s += sH[r + j][c]; ss += sH2[r + j][c]; }
+    const int cy = min(yy + R, H - 1) - max(yy - R, 0) + 1;
+    const int cx = min(xx + R, W - 1) - max(xx - R, 0) + 1;
     const float rn = 1.0f / (float)(cy * cx);
     const float mg = s * rn;
     const float var = ss * rn - mg * mg;
+    const size_t pix = (size_t)b * H * W + (size_t)yy * W + xx;
     gs[pix] = make_float2(mg, 1.0f / (var + eps0));
     gs[npix + pix] = make_float2(mg, 1.0f / (var + eps1));
   }
@@ -411,9 +431,8 @@ extern "C" int paif_guided_filter_fused_fwd(const float* guide, const float* y, 
   const int frows = (H + nseg - 1) / nseg;
   hipStream_t st = paif::as_stream(stream);
   float2* gs = reinterpret_cast<float2*>(workspace);
-  const size_t npix = (size_t)B * H * W;
-  hipLaunchKernelGGL(gf_guide_stats_kernel, dim3((unsigned)((npix + 255) / 256 < 4096 ? (npix + 255) / 256 : 4096)), dim3(256), 0, st, guide,
-                     gs, eps0, eps1, B, H, W);
+  const int gtx = (W + GT - 1) / GT, gty = (H + GT - 1) / GT;
+  hipLaunchKernelGGL(gf_guide_stats_kernel, dim3(B * gtx * gty), dim3(256), 0, st, guide, gs, eps0, eps1, B, H, W, gtx, gty);
   PAIF_LAUNCH_CHECK("guided_filter_fused(stats)");
   hipLaunchKernelGGL(gf_fused_kernel, dim3(B * nstrip * nseg, 2), dim3(512), 0, st, guide, y, gs, lf, B, H, W, nstrip, nseg, frows);
   PAIF_LAUNCH_CHECK("guided_filter_fused");

@@ -101,6 +101,7 @@ class PolyWarmupAdamW(torch.optim.AdamW):
         self.__init_lr = [group['lr'] for group in self.param_groups]
         self._arena = None
         self._cg_cache = (None, None)
+        self._adam_t = 0            # torch's per-parameter state['step']: counts step() calls, independent of global_step
         if len(self.param_groups) > 8:
             raise NotImplementedError("PolyWarmupAdamW: at most 8 parameter groups (the reference uses 3)")
 
@@ -150,7 +151,8 @@ class PolyWarmupAdamW(torch.optim.AdamW):
         key = cg.tobytes()
         if self._cg_cache[0] != key:
             self._cg_cache = (key, torch.from_numpy(cg).to(A.param.device))
-        t = self.global_step + 1                       # bias corrections: step count = number of step() calls
+        self._adam_t += 1
+        t = self._adam_t                               # bias corrections: step count = number of step() calls
         beta1, beta2 = g0['betas']
         bc1 = 1 - beta1 ** t
         bc2_sqrt = math.sqrt(1 - beta2 ** t)
