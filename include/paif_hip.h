@@ -390,6 +390,15 @@ int paif_ssim_l1_fwd(const float* x, const float* y, const float* window1d, floa
 int paif_ssim_l1_bwd_input(const float* x, const float* y, const float* window1d, const float* k, float* abc_scratch,
                            float* dx, int B, int H, int W, paif_stream_t stream);
 
+/* ---- SegFormerHead with linear_fuse folded in front of the upsampling (core/segformer_head.py:63-80) ------------------------------
+ * conv1x1(cat[up y4, up y3, up y2, y1]) = up(W4 y4) + up(W3 y3) + up(W2 y2) + W1 y1 (both maps are linear): z_i = W_i y_i are
+ * GEMMs at each stage's own resolution; this kernel forms relu((z1 + up z2 + up z3 + up z4) * scale + shift) at 1/4 resolution.
+ * z1..z4 NHWC [B,h_i,w_i,C]; hw = HOST array {h1,w1,h2,w2,h3,w3,h4,w4}; scale/shift = the folded eval-mode BatchNorm. */
+int paif_head_sum_fwd(const float* z1, const float* z2, const float* z3, const float* z4, const int* hw, const float* scale,
+                      const float* shift, float* out, int B, int C, paif_stream_t stream);
+/* its backward through BatchNorm + ReLU: out = dx * (x > 0) * scale[c]   (x = the forward's output). */
+int paif_relu_mask_scale_fwd(const float* dx, const float* x, const float* scale, float* out, size_t M, int C, paif_stream_t stream);
+
 /* ---- input pipeline, device side (TaskFusion_dataset2.py:57-70,85-98; csrc/io_kernels.hip) ----------------------------------
  * src uint8 [B][HW][C] (decoded image bytes, HWC) -> dst float32 [B][C][HW] = src / 255 (fp32 division, as numpy does). */
 int paif_u8_to_planes_fwd(const unsigned char* src, float* dst, int B, int HW, int C, paif_stream_t stream);
@@ -455,9 +464,10 @@ int paif_stem_wgrad(const float* img, size_t img_bstride, const float* dfeat, co
  * workspace: row_reduce(B*H*W, Cm, k*k). */
 int paif_corr1_wgrad(const float* s, const float* m, float* dw, float* workspace, int Cm, int k, int B, int H, int W, paif_stream_t stream);
 /* eca_layer's Conv1d weight gradient (operations_m.py:353-367): dw[k] += sum_b sum_c dpre[b][c]*mean[b][c+j-pad].
- * pool_partial: the forward conv's per-tile channel sums; dgate_partial [B][blocks][32]: paif_eca_bwd_input's partials. */
+ * pool_partial: the forward conv's per-tile channel sums; dgate_partial [B][blocks][32]: paif_eca_bwd_input's partials;
+ * workspace: 9*B floats. */
 int paif_eca_wgrad(const float* pool_partial, const float* dgate_partial, int dgate_blocks_per_img, const float* gate, int k, float* dw,
-                   int B, int H, int W, paif_stream_t stream);
+                   float* workspace, int B, int H, int W, paif_stream_t stream);
 /* Cell_Decom 1x1: G [32][96] = gradient of the folded weight over [x, LF1, LF2] -> dw [32][128] += [G1, G2, Gx-G1, Gx-G2]. */
 int paif_unfold_decomp1x1_wgrad(const float* G, float* dw, paif_stream_t stream);
 /* conv-as-GEMM weight gradient back to the PyTorch layout: dw[Cout][Cin][k][k] += dwp[Cout][tap*Cin + c] (row stride Kpad). */

@@ -107,6 +107,8 @@ SIGNATURES = {
     "paif_pgd_step": (c_int, [F, F, F, c_float, c_float, c_size_t, F]),
     "paif_axpy": (c_int, [F, F, c_float, c_size_t, F]),
     "paif_upsample_ce_bwd": (c_int, [F, F, F, F, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, F]),
+    "paif_head_sum_fwd": (c_int, [F, F, F, F, POINTER(c_int), F, F, F, c_int, c_int, F]),
+    "paif_relu_mask_scale_fwd": (c_int, [F, F, F, F, c_size_t, c_int, F]),
     "paif_u8_to_planes_fwd": (c_int, [F, F, c_int, c_int, c_int, F]),
     "paif_u8_to_i64_fwd": (c_int, [F, F, c_size_t, F]),
     # ---- training step (csrc/train_kernels.hip) ----
@@ -124,7 +126,7 @@ SIGNATURES = {
     "paif_dwconv_wgrad": (c_int, [F, F, F, F, F, c_int, c_int, c_int, c_int, c_int, c_int, c_int, F]),
     "paif_stem_wgrad": (c_int, [F, c_size_t, F, F, F, F, F, F, c_int, c_int, c_int, F]),
     "paif_corr1_wgrad": (c_int, [F, F, F, F, c_int, c_int, c_int, c_int, c_int, F]),
-    "paif_eca_wgrad": (c_int, [F, F, c_int, F, c_int, F, c_int, c_int, c_int, F]),
+    "paif_eca_wgrad": (c_int, [F, F, c_int, F, c_int, F, F, c_int, c_int, c_int, F]),
     "paif_unfold_decomp1x1_wgrad": (c_int, [F, F, F]),
     "paif_unpack_conv_gemm_wgrad": (c_int, [F, F, c_int, c_int, c_int, c_int, F]),
     "paif_keep_mask": (c_int, [F, c_int, c_ulonglong, c_ulonglong, c_float, F]),

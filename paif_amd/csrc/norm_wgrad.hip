@@ -42,12 +42,18 @@ __global__ __launch_bounds__(256) void layernorm_wgrad_kernel(const float* __res
   }
 }
 
+// one wave per (which, c): its 64 lanes stride over the block partials, then a fixed xor-shuffle tree (deterministic)
 __global__ __launch_bounds__(256) void layernorm_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
                                                                      float* __restrict__ dbeta, int nblk, int C, int accumulate) {
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < 2 * C; i += gridDim.x * 256) {
-    const int which = i / C, c = i - which * C;
-    float v = 0.f;
-    for (int b = 0; b < nblk; ++b) v += partial[((size_t)b * 2 + which) * C + c];
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= 2 * C) return;      // wave-uniform
+  const int which = i / C, c = i - which * C;
+  float v = 0.f;
+  for (int b = lane; b < nblk; b += 64) v += partial[((size_t)b * 2 + which) * C + c];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  if (lane == 0) {
     float* dst = which ? dbeta : dgamma;
     dst[c] = accumulate ? dst[c] + v : v;
   }
@@ -64,7 +70,7 @@ extern "C" int paif_layernorm_wgrad(const float* x, const float* dy, float* dgam
   hipStream_t st = paif::as_stream(stream);
   hipLaunchKernelGGL(layernorm_wgrad_kernel, dim3(nblk), dim3(256), 0, st, x, dy, workspace, M, C, eps);
   PAIF_LAUNCH_CHECK("layernorm_wgrad");
-  hipLaunchKernelGGL(layernorm_wgrad_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, workspace, dgamma, dbeta, nblk, C, accumulate);
+  hipLaunchKernelGGL(layernorm_wgrad_reduce_kernel, dim3((2 * C + 3) / 4), dim3(256), 0, st, workspace, dgamma, dbeta, nblk, C, accumulate);
   PAIF_LAUNCH_CHECK("layernorm_wgrad_reduce");
   return 0;
 }

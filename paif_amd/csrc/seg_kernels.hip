@@ -188,6 +188,76 @@ __global__ __launch_bounds__(256) void dwconv3_bias_gelu_kernel(const float* __r
 }
 
 // ---------------------------------------------------------------------------------------------
+// SegFormerHead with linear_fuse folded in front of the upsampling (core/segformer_head.py:63-80): the 1x1 conv over
+// cat[up(y4), up(y3), up(y2), y1] is linear, and bilinear interpolation is linear and per channel, so
+//   conv(cat) = up(W4 y4) + up(W3 y3) + up(W2 y2) + W1 y1         (W_i = the i-th 256-column block of the fuse weight)
+// z_i = W_i y_i are formed at each stage's own resolution (1.2 instead of 10.1 GFLOP per 480x640 pair); this kernel adds
+// the four maps at 1/4 resolution and applies the folded BatchNorm + ReLU:  out = relu((z1 + up z2 + up z3 + up z4) * scale + shift)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 bilerp4(const float* __restrict__ xb, int IH, int IW, int C, float sy, float sx, int oy, int ox) {
+  float fy = sy * ((float)oy + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
+  float fx = sx * ((float)ox + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = y0 + (y0 < IH - 1 ? 1 : 0), x1 = x0 + (x0 < IW - 1 ? 1 : 0);
+  const float ly = fy - (float)y0, lx = fx - (float)x0;
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  const float4 v00 = *reinterpret_cast<const float4*>(xb + ((size_t)y0 * IW + x0) * C);
+  const float4 v01 = *reinterpret_cast<const float4*>(xb + ((size_t)y0 * IW + x1) * C);
+  const float4 v10 = *reinterpret_cast<const float4*>(xb + ((size_t)y1 * IW + x0) * C);
+  const float4 v11 = *reinterpret_cast<const float4*>(xb + ((size_t)y1 * IW + x1) * C);
+  float4 o;
+  o.x = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
+  o.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
+  o.z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
+  o.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
+  return o;
+}
+
+struct HeadSumArgs {
+  const float* z[4];     // z[0] at the output size, z[1..3] coarser
+  int ih[4], iw[4];
+};
+
+__global__ __launch_bounds__(256) void head_sum_kernel(HeadSumArgs a, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       float* __restrict__ out, int B, int OH, int OW, int C) {
+  const int cq = C / 4;
+  const size_t total = (size_t)B * OH * OW * cq;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c4 = (int)(i % cq);
+    const size_t tok = i / cq;
+    const int ox = (int)(tok % OW);
+    const size_t t2 = tok / OW;
+    const int oy = (int)(t2 % OH);
+    const int b = (int)(t2 / OH);
+    float4 acc = *reinterpret_cast<const float4*>(a.z[0] + tok * C + c4 * 4);
+    // summed in the concat order of the reference's K axis: _c4, _c3, _c2, then _c1 (already in acc)
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 3; k >= 1; --k) {
+      const float4 v = bilerp4(a.z[k] + (size_t)b * a.ih[k] * a.iw[k] * C + c4 * 4, a.ih[k], a.iw[k], C, (float)a.ih[k] / (float)OH,
+                               (float)a.iw[k] / (float)OW, oy, ox);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    acc.x += s.x; acc.y += s.y; acc.z += s.z; acc.w += s.w;
+    const float4 sc = *reinterpret_cast<const float4*>(scale + c4 * 4), sh = *reinterpret_cast<const float4*>(shift + c4 * 4);
+    acc.x = fmaxf(fmaf(acc.x, sc.x, sh.x), 0.f); acc.y = fmaxf(fmaf(acc.y, sc.y, sh.y), 0.f);
+    acc.z = fmaxf(fmaf(acc.z, sc.z, sh.z), 0.f); acc.w = fmaxf(fmaf(acc.w, sc.w, sh.w), 0.f);
+    *reinterpret_cast<float4*>(out + tok * C + c4 * 4) = acc;
+  }
+}
+
+// d_pre = d_x * (x > 0) * scale[c]: backward of the folded BatchNorm + ReLU on the head's 1/4-resolution map
+__global__ __launch_bounds__(256) void relu_mask_scale_kernel(const float* __restrict__ dx, const float* __restrict__ x,
+                                                              const float* __restrict__ scale, float* __restrict__ out, size_t n4, int Q) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 d = reinterpret_cast<const float4*>(dx)[i], v = reinterpret_cast<const float4*>(x)[i];
+    const float4 sc = reinterpret_cast<const float4*>(scale)[i % Q];
+    reinterpret_cast<float4*>(out)[i] = make_float4(v.x > 0.f ? d.x * sc.x : 0.f, v.y > 0.f ? d.y * sc.y : 0.f,
+                                                    v.z > 0.f ? d.z * sc.z : 0.f, v.w > 0.f ? d.w * sc.w : 0.f);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // bilinear resize (align_corners=False) of an NHWC map into a channel slice of a wider NHWC tensor:
 // SegFormerHead's F.interpolate + torch.cat (core/segformer_head.py:66-77).  Identity size = plain copy.
 // ---------------------------------------------------------------------------------------------
@@ -320,6 +390,26 @@ int paif_resize_bilinear_into_fwd(const float* x, float* out, int B, int IH, int
   hipLaunchKernelGGL(resize_into_kernel, dim3(grid_for((size_t)B * OH * OW * (C / 4), 256)), dim3(256), 0, paif::as_stream(stream), x,
                      out, B, IH, IW, C, OH, OW, ldo, coff);
   PAIF_LAUNCH_CHECK("resize_bilinear_into");
+  return 0;
+}
+
+int paif_head_sum_fwd(const float* z1, const float* z2, const float* z3, const float* z4, const int* hw, const float* scale,
+                      const float* shift, float* out, int B, int C, paif_stream_t stream) {
+  PAIF_REQUIRE(z1 && z2 && z3 && z4 && hw && scale && shift && out && B > 0 && C > 0 && (C & 3) == 0, PAIF_EINVAL, "head_sum: bad arguments");
+  HeadSumArgs a;
+  const float* zs[4] = {z1, z2, z3, z4};
+  for (int k = 0; k < 4; ++k) { a.z[k] = zs[k]; a.ih[k] = hw[2 * k]; a.iw[k] = hw[2 * k + 1]; }
+  hipLaunchKernelGGL(head_sum_kernel, dim3(grid_for((size_t)B * a.ih[0] * a.iw[0] * (C / 4), 256)), dim3(256), 0, paif::as_stream(stream), a,
+                     scale, shift, out, B, a.ih[0], a.iw[0], C);
+  PAIF_LAUNCH_CHECK("head_sum");
+  return 0;
+}
+
+int paif_relu_mask_scale_fwd(const float* dx, const float* x, const float* scale, float* out, size_t M, int C, paif_stream_t stream) {
+  PAIF_REQUIRE(dx && x && scale && out && M > 0 && C > 0 && (C & 3) == 0, PAIF_EINVAL, "relu_mask_scale: bad arguments");
+  const size_t n4 = M * (C / 4);
+  hipLaunchKernelGGL(relu_mask_scale_kernel, dim3(grid_for(n4, 256)), dim3(256), 0, paif::as_stream(stream), dx, x, scale, out, n4, C / 4);
+  PAIF_LAUNCH_CHECK("relu_mask_scale");
   return 0;
 }
 

@@ -565,33 +565,44 @@ __global__ void corr1_wgrad_finish_kernel(const float* __restrict__ ws, int nblk
 //   dW[j] = sum_b sum_c dpre[b][c] * mean[b][c + j - pad]
 // pool_partial: the forward conv's per-tile channel sums; dgate_partial: eca_bwd's per-block sums of du*o
 // ---------------------------------------------------------------------------------------------
-__global__ void eca_wgrad_kernel(const float* __restrict__ pool_partial, int tiles_per_img, const float* __restrict__ dgate_partial,
-                                 int blocks_per_img, const float* __restrict__ gate, int k, int B, float inv_hw, float* __restrict__ dw) {
+__global__ __launch_bounds__(1024) void eca_wgrad_kernel(const float* __restrict__ pool_partial, int tiles_per_img,
+                                                         const float* __restrict__ dgate_partial, int blocks_per_img,
+                                                         const float* __restrict__ gate, int k, float inv_hw, float* __restrict__ ws) {
+  // one workgroup per image: thread (part = tid >> 5, c = tid & 31) sums every 32nd partial, the 32 parts are added in a
+  // fixed order (deterministic); ws[b][j] = this image's contribution to dW[j]
+  __shared__ float ps[32][32], pd[32][32];
   __shared__ float mean[32], dpre[32];
-  __shared__ double accw[9];
-  const int c = threadIdx.x;   // 32 threads
-  if (c < 9) accw[c] = 0.0;
-  const int pad = (k - 1) / 2;
-  for (int b = 0; b < B; ++b) {
-    double s = 0.0, d = 0.0;
-    for (int t = 0; t < tiles_per_img; ++t) s += (double)pool_partial[((size_t)b * tiles_per_img + t) * 32 + c];
-    for (int t = 0; t < blocks_per_img; ++t) d += (double)dgate_partial[((size_t)b * blocks_per_img + t) * 32 + c];
+  const int b = blockIdx.x, c = threadIdx.x & 31, part = threadIdx.x >> 5;
+  float s = 0.f, d = 0.f;
+  for (int t = part; t < tiles_per_img; t += 32) s += pool_partial[((size_t)b * tiles_per_img + t) * 32 + c];
+  for (int t = part; t < blocks_per_img; t += 32) d += dgate_partial[((size_t)b * blocks_per_img + t) * 32 + c];
+  ps[part][c] = s; pd[part][c] = d;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    double ts = 0.0, td = 0.0;
+    for (int i = 0; i < 32; ++i) { ts += (double)ps[i][c]; td += (double)pd[i][c]; }
     const float gt = gate[b * 32 + c];
-    __syncthreads();
-    mean[c] = (float)s * inv_hw;
-    dpre[c] = (float)d * gt * (1.f - gt);
-    __syncthreads();
-    if (c < k) {
-      double t = 0.0;
-      for (int cc = 0; cc < 32; ++cc) {
-        const int src = cc + c - pad;
-        if (src >= 0 && src < 32) t += (double)dpre[cc] * (double)mean[src];
-      }
-      accw[c] += t;
-    }
+    mean[c] = (float)ts * inv_hw;
+    dpre[c] = (float)td * gt * (1.f - gt);
   }
   __syncthreads();
-  if (c < k) dw[c] += (float)accw[c];
+  if ((int)threadIdx.x < k) {
+    const int j = threadIdx.x, pad = (k - 1) / 2;
+    double t = 0.0;
+    for (int cc = 0; cc < 32; ++cc) {
+      const int src = cc + j - pad;
+      if (src >= 0 && src < 32) t += (double)dpre[cc] * (double)mean[src];
+    }
+    ws[b * 9 + j] = (float)t;
+  }
+}
+
+__global__ void eca_wgrad_finish_kernel(const float* __restrict__ ws, int B, int k, float* __restrict__ dw) {
+  const int j = threadIdx.x;
+  if (j >= k) return;
+  double t = 0.0;
+  for (int b = 0; b < B; ++b) t += (double)ws[b * 9 + j];
+  dw[j] += (float)t;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -887,12 +898,16 @@ int paif_corr1_wgrad(const float* s, const float* m, float* dw, float* workspace
 }
 
 int paif_eca_wgrad(const float* pool_partial, const float* dgate_partial, int dgate_blocks_per_img, const float* gate, int k, float* dw,
-                   int B, int H, int W, paif_stream_t stream) {
-  PAIF_REQUIRE(pool_partial && dgate_partial && gate && dw && B > 0 && dgate_blocks_per_img > 0, PAIF_EINVAL, "eca_wgrad: bad arguments");
+                   float* workspace, int B, int H, int W, paif_stream_t stream) {
+  PAIF_REQUIRE(pool_partial && dgate_partial && gate && dw && workspace && B > 0 && dgate_blocks_per_img > 0, PAIF_EINVAL,
+               "eca_wgrad: bad arguments");
   PAIF_REQUIRE(k >= 1 && k <= 9 && (k & 1), PAIF_ENOSUP, "eca_wgrad: k=%d", k);
-  hipLaunchKernelGGL(eca_wgrad_kernel, dim3(1), dim3(32), 0, paif::as_stream(stream), pool_partial, paif_conv2d_blocks(1, H, W),
-                     dgate_partial, dgate_blocks_per_img, gate, k, B, 1.0f / ((float)H * (float)W), dw);
+  hipStream_t st = paif::as_stream(stream);
+  hipLaunchKernelGGL(eca_wgrad_kernel, dim3(B), dim3(1024), 0, st, pool_partial, paif_conv2d_blocks(1, H, W), dgate_partial,
+                     dgate_blocks_per_img, gate, k, 1.0f / ((float)H * (float)W), workspace);
   PAIF_LAUNCH_CHECK("eca_wgrad");
+  hipLaunchKernelGGL(eca_wgrad_finish_kernel, dim3(1), dim3(32), 0, st, workspace, B, k, dw);
+  PAIF_LAUNCH_CHECK("eca_wgrad(finish)");
   return 0;
 }
 

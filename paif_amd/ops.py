@@ -869,8 +869,9 @@ def corr1_wgrad(s, m, k, out_w):
 
 
 def eca_wgrad(pool_partial, dgate_partial, gate, k, out_w, B, H, W):
-    _lib.check(lib().paif_eca_wgrad(_p(pool_partial), _p(dgate_partial), dgate_partial.shape[1], _p(gate), k, _p(out_w), B, H, W, _stream()),
-               "eca_wgrad")
+    ws = torch.empty(9 * B, device=gate.device, dtype=torch.float32)
+    _lib.check(lib().paif_eca_wgrad(_p(pool_partial), _p(dgate_partial), dgate_partial.shape[1], _p(gate), k, _p(out_w), _p(ws), B, H, W,
+                                    _stream()), "eca_wgrad")
 
 
 def unfold_decomp1x1_wgrad(G, out_w):
@@ -1037,6 +1038,22 @@ def resize_bilinear_into(x, out, coff):
     B, IH, IW, C = x.shape
     _, OH, OW, ldo = out.shape
     _lib.check(lib().paif_resize_bilinear_into_fwd(_p(x), _p(out), B, IH, IW, C, OH, OW, ldo, coff, _stream()), "resize_bilinear_into")
+    return out
+
+
+def head_sum(zs, scale, shift):
+    """relu((z1 + up z2 + up z3 + up z4) * scale + shift): zs = 4 NHWC maps, the first at the output resolution."""
+    B, H1, W1, C = zs[0].shape
+    hw = (ctypes.c_int * 8)(*[d for z in zs for d in z.shape[1:3]])
+    out = torch.empty_like(zs[0])
+    _lib.check(lib().paif_head_sum_fwd(_p(zs[0]), _p(zs[1]), _p(zs[2]), _p(zs[3]), hw, _p(scale), _p(shift), _p(out), B, C, _stream()), "head_sum")
+    return out
+
+
+def relu_mask_scale(dx, x, scale):
+    C = x.shape[-1]
+    out = torch.empty_like(x)
+    _lib.check(lib().paif_relu_mask_scale_fwd(_p(dx), _p(x), _p(scale), _p(out), x.numel() // C, C, _stream()), "relu_mask_scale")
     return out
 
 
