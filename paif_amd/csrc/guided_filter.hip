@@ -10,6 +10,8 @@
 //   and each thread adds its 9 horizontal neighbours.
 // Box sums are exact border-clipped window sums; N = (#valid rows) x (#valid cols).
 // fp32 throughout (SURVEY.md section 7 hard part 1: A = cov/(var+eps) with eps = 1e-4).
+#include <stdlib.h>
+
 #include "paif_common.h"
 
 namespace {
@@ -276,12 +278,19 @@ __global__ __launch_bounds__(256) void gf_guide_stats_kernel(const float* __rest
   }
 }
 
-__global__ __launch_bounds__(512) void gf_fused_kernel(const float* __restrict__ guide, const float* __restrict__ y,
-                                                       const float2* __restrict__ gs, float* __restrict__ lf, int B, int H, int W,
-                                                       int nstrip, int nseg, int frows) {
-  __shared__ float4 s_a[2][FC][8];
-  __shared__ float4 s_b[2][FC][8];
-  const int q = threadIdx.x & 7, xi = threadIdx.x >> 3;
+// NQ = channel quads per workgroup (blockIdx.z walks the 8 / NQ channel groups).  The two LDS phases of a row put every
+// wave of a workgroup into its LDS-read burst, then into its VALU burst, together (barrier-locked): with ONE 512-thread
+// workgroup per CU the LDS array and the VALUs take turns.  Smaller workgroups (NQ = 4: 256 threads x 2 per CU, NQ = 2:
+// 128 x 4) hold the same 8 waves per CU in independent barrier groups that drift apart and overlap the two resources.
+template <int NQ>
+__global__ __launch_bounds__(FC * NQ) void gf_fused_kernel(const float* __restrict__ guide, const float* __restrict__ y,
+                                                           const float2* __restrict__ gs, float* __restrict__ lf, int B, int H, int W,
+                                                           int nstrip, int nseg, int frows) {
+  __shared__ float4 s_a[2][FC][NQ];
+  __shared__ float4 s_b[2][FC][NQ];
+  const int xi = threadIdx.x / NQ;
+  const int q = threadIdx.x - xi * NQ + blockIdx.z * NQ;      // channel quad of this thread (0..7)
+  const int ql = threadIdx.x - xi * NQ;                       // ... and its slot in the LDS rows
   int t = blockIdx.x;
   const int strip = t % nstrip; t /= nstrip;
   const int seg = t % nseg;
@@ -355,8 +364,8 @@ __global__ __launch_bounds__(512) void gf_fused_kernel(const float* __restrict__
           vy = f4add(vy, ry[j]);
           vgy = f4fma(rg[j], ry[j], vgy);
         }
-        s_a[0][xi][q] = vy;
-        s_b[0][xi][q] = vgy;
+        s_a[0][xi][ql] = vy;
+        s_b[0][xi][ql] = vgy;
       }
       lds_barrier();
       float4 A = make_float4(0.f, 0.f, 0.f, 0.f), Bc = A;
@@ -364,8 +373,8 @@ __global__ __launch_bounds__(512) void gf_fused_kernel(const float* __restrict__
         float4 by = make_float4(0.f, 0.f, 0.f, 0.f), bgy = by;
 #pragma unroll
         for (int j = -R; j <= R; ++j) {
-          by = f4add(by, s_a[0][xi + j][q]);
-          bgy = f4add(bgy, s_b[0][xi + j][q]);
+          by = f4add(by, s_a[0][xi + j][ql]);
+          bgy = f4add(bgy, s_b[0][xi + j][ql]);
         }
         const float rn = rn_of(irow);
         const float mg = st.x, rden = st.y;
@@ -386,16 +395,16 @@ __global__ __launch_bounds__(512) void gf_fused_kernel(const float* __restrict__
         // window rows irow-8 .. irow = partial sums ending at irow, irow-3, irow-6 (slots k, k-3, k-6 mod 9)
         const float4 ua = f4add(f4add(tA[k], tA[(k + 6) % K]), tA[(k + 3) % K]);
         const float4 ub = f4add(f4add(tB[k], tB[(k + 6) % K]), tB[(k + 3) % K]);
-        s_a[1][xi][q] = ua;
-        s_b[1][xi][q] = ub;
+        s_a[1][xi][ql] = ua;
+        s_b[1][xi][ql] = ub;
       }
       lds_barrier();
       if (xi >= 2 * R && xi < FC - 2 * R && col < W) {
         float4 ba = make_float4(0.f, 0.f, 0.f, 0.f), bb = ba;
 #pragma unroll
         for (int j = -R; j <= R; ++j) {
-          ba = f4add(ba, s_a[1][xi + j][q]);
-          bb = f4add(bb, s_b[1][xi + j][q]);
+          ba = f4add(ba, s_a[1][xi + j][ql]);
+          bb = f4add(bb, s_b[1][xi + j][ql]);
         }
         const float rn = rn_of(orow);
         const size_t px = img + (size_t)orow * W + col;
@@ -417,15 +426,17 @@ extern "C" int paif_guided_filter_fused_fwd(const float* guide, const float* y, 
   PAIF_REQUIRE(guide && y && lf && workspace && B > 0, PAIF_EINVAL, "guided_filter_fused: bad arguments");
   PAIF_REQUIRE(H > 2 * R + 1 && W > 2 * R + 1, PAIF_EINVAL, "guided_filter: H,W must exceed 2r+1 = %d (got %dx%d)", K, H, W);
   const int nstrip = (W + FO - 1) / FO;
-  // Rows per workgroup: one workgroup is resident per CU (246 VGPRs x 512 threads), so the launch runs in rounds of
-  // 256 workgroups and a workgroup costs (rows + 4R halo) row-iterations: pick the split with the fewest
-  // rounds x (rows + 16)  (B=8, 480x640: 2 segments of 240 rows -> 2 rounds x 256 instead of 4 x 136).
+  // Rows per workgroup: 8 / NQ workgroups are resident per CU (~250 VGPRs per thread, 8 waves), so the launch runs in rounds
+  // of 256 * 8 / NQ workgroups and a workgroup costs (rows + 4R halo) row-iterations: pick the split with the fewest
+  // rounds x (rows + 16).
+  static const int NQ = [] { const char* e = getenv("PAIF_GF_NQ"); const int v = e ? atoi(e) : 4; return (v == 8 || v == 2) ? v : 4; }();
+  const int zgroups = 8 / NQ;
   int nseg = 1;
   long best = -1;
   for (int n = 1; n <= 16 && n <= H; ++n) {
     const int rows = (H + n - 1) / n;
-    const long blocks = (long)B * nstrip * n * 2;
-    const long cost = ((blocks + 255) / 256) * (rows + 4 * R);
+    const long blocks = (long)B * nstrip * n * 2 * zgroups;
+    const long cost = ((blocks + 256 * zgroups - 1) / (256 * zgroups)) * (rows + 4 * R);
     if (best < 0 || cost < best) { best = cost; nseg = n; }
   }
   const int frows = (H + nseg - 1) / nseg;
@@ -434,7 +445,10 @@ extern "C" int paif_guided_filter_fused_fwd(const float* guide, const float* y, 
   const int gtx = (W + GT - 1) / GT, gty = (H + GT - 1) / GT;
   hipLaunchKernelGGL(gf_guide_stats_kernel, dim3(B * gtx * gty), dim3(256), 0, st, guide, gs, eps0, eps1, B, H, W, gtx, gty);
   PAIF_LAUNCH_CHECK("guided_filter_fused(stats)");
-  hipLaunchKernelGGL(gf_fused_kernel, dim3(B * nstrip * nseg, 2), dim3(512), 0, st, guide, y, gs, lf, B, H, W, nstrip, nseg, frows);
+  const dim3 grid(B * nstrip * nseg, 2, zgroups);
+  if (NQ == 8) hipLaunchKernelGGL(gf_fused_kernel<8>, grid, dim3(FC * 8), 0, st, guide, y, gs, lf, B, H, W, nstrip, nseg, frows);
+  else if (NQ == 4) hipLaunchKernelGGL(gf_fused_kernel<4>, grid, dim3(FC * 4), 0, st, guide, y, gs, lf, B, H, W, nstrip, nseg, frows);
+  else hipLaunchKernelGGL(gf_fused_kernel<2>, grid, dim3(FC * 2), 0, st, guide, y, gs, lf, B, H, W, nstrip, nseg, frows);
   PAIF_LAUNCH_CHECK("guided_filter_fused");
   return 0;
 }

@@ -1,10 +1,16 @@
 """Thin host wrappers: torch CUDA tensors -> raw pointers -> libpaif_hip.so (include/paif_hip.h).
 
-torch is used for device memory (caching allocator) and the current HIP stream only; every
-arithmetic op runs in a hand-written gfx950 kernel.  Internal activation layout is NHWC
-([B,H,W,C] contiguous float32).  `to_nhwc` / `to_nchw_view` convert at the module boundary:
-an NHWC tensor viewed as [B,C,H,W] is exactly torch's channels_last format, so the reference's
-NCHW operator API is kept without copies between our own ops.
+torch supplies device memory (caching allocator, zero fills / memsets, copies), the current HIP stream and the autograd
+graph nodes; the arithmetic of the path -- forward, input gradients, parameter gradients, optimizer -- runs in the
+hand-written gfx950 kernels of libpaif_hip.so.  What is left to torch ops, all outside the hot loops:
+  * scalar bookkeeping on 1-2 element device tensors (1/#valid pixels of the CE, stacking two loss weights, the
+    BatchNorm `num_batches_tracked` counter, the optional 2-float global min/max exchange);
+  * the loss glue of the attack variants neither entry script uses by default (segPGD / cosPGD / newPGD masks and cosine
+    similarity, `trans_format` of the never-called single-modality attacks): torch ops on top of the HIP autograd nodes;
+  * a user-supplied seg_loss that is not a plain CrossEntropyLoss.
+Internal activation layout is NHWC ([B,H,W,C] contiguous float32).  `to_nhwc` / `to_nchw_view` convert at the module
+boundary: an NHWC tensor viewed as [B,C,H,W] is exactly torch's channels_last format, so the reference's NCHW operator API
+is kept without copies between our own ops.
 """
 import ctypes
 
