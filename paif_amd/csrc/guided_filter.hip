@@ -278,10 +278,11 @@ __global__ __launch_bounds__(256) void gf_guide_stats_kernel(const float* __rest
   }
 }
 
-// NQ = channel quads per workgroup (blockIdx.z walks the 8 / NQ channel groups).  The two LDS phases of a row put every
-// wave of a workgroup into its LDS-read burst, then into its VALU burst, together (barrier-locked): with ONE 512-thread
-// workgroup per CU the LDS array and the VALUs take turns.  Smaller workgroups (NQ = 4: 256 threads x 2 per CU, NQ = 2:
-// 128 x 4) hold the same 8 waves per CU in independent barrier groups that drift apart and overlap the two resources.
+// NQ = channel quads per workgroup (blockIdx.z walks the 8 / NQ channel groups).  Measured at B=8, 480x640 (one launch, both
+// eps): NQ = 8 (one 512-thread workgroup per CU) 0.844 ms, NQ = 4 (2 x 256 threads per CU) 0.912 ms, NQ = 2 0.947 ms --
+// splitting the barrier group does NOT help: the kernel is paced by VALU issue (tools/microbench/valu_rate.hip: with two
+// waves per SIMD a v_add_f32 costs 3.0 and a v_pk_add_f32 7.5 cycles of the SIMD, i.e. packed fp32 buys nothing), ~2.6k of
+// the ~3.9k cycles per row, then the LDS array (~1.2k).  PAIF_GF_NQ selects the form for A/B runs.
 template <int NQ>
 __global__ __launch_bounds__(FC * NQ) void gf_fused_kernel(const float* __restrict__ guide, const float* __restrict__ y,
                                                            const float2* __restrict__ gs, float* __restrict__ lf, int B, int H, int W,
@@ -289,8 +290,9 @@ __global__ __launch_bounds__(FC * NQ) void gf_fused_kernel(const float* __restri
   __shared__ float4 s_a[2][FC][NQ];
   __shared__ float4 s_b[2][FC][NQ];
   const int xi = threadIdx.x / NQ;
-  const int q = threadIdx.x - xi * NQ + blockIdx.z * NQ;      // channel quad of this thread (0..7)
-  const int ql = threadIdx.x - xi * NQ;                       // ... and its slot in the LDS rows
+  const int ql = threadIdx.x - xi * NQ;                       // channel quad slot in the LDS rows; quad = blockIdx.z * NQ + ql
+  y += (blockIdx.z * NQ + ql) * 4;
+  lf += (blockIdx.z * NQ + ql) * 4;
   int t = blockIdx.x;
   const int strip = t % nstrip; t /= nstrip;
   const int seg = t % nseg;
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(FC * NQ) void gf_fused_kernel(const float* __restri
 #pragma unroll
   for (int p = 0; p < PF; ++p) {
     const size_t px = img + (size_t)min(max(r0 + p, 0), H - 1) * W + colc;
-    pv[p] = *reinterpret_cast<const float4*>(y + px * 32 + q * 4);
+    pv[p] = *reinterpret_cast<const float4*>(y + px * 32);
     pg[p] = guide[px];
     ps[p] = gse[img + (size_t)min(max(r0 + p - R, 0), H - 1) * W + colc];
   }
@@ -350,7 +352,7 @@ __global__ __launch_bounds__(FC * NQ) void gf_fused_kernel(const float* __restri
       const float2 st = ps[k % PF];             // (mean_g, 1/(var_g + eps)) of (row - R, col)
       {
         const size_t px = img + (size_t)min(max(row + PF, 0), H - 1) * W + colc;
-        pv[k % PF] = *reinterpret_cast<const float4*>(y + px * 32 + q * 4);
+        pv[k % PF] = *reinterpret_cast<const float4*>(y + px * 32);
         pg[k % PF] = guide[px];
         ps[k % PF] = gse[img + (size_t)min(max(row + PF - R, 0), H - 1) * W + colc];
       }
@@ -409,7 +411,7 @@ __global__ __launch_bounds__(FC * NQ) void gf_fused_kernel(const float* __restri
         const float rn = rn_of(orow);
         const size_t px = img + (size_t)orow * W + col;
         const float g0 = rg[(k + 1) % K];   // guide(orow, col): the oldest ring-1 row (row - 2R)
-        *reinterpret_cast<float4*>(out + px * 32 + q * 4) =
+        *reinterpret_cast<float4*>(out + px * 32) =
             make_float4(fmaf(ba.x * rn, g0, bb.x * rn), fmaf(ba.y * rn, g0, bb.y * rn), fmaf(ba.z * rn, g0, bb.z * rn),
                         fmaf(ba.w * rn, g0, bb.w * rn));
       }
@@ -429,7 +431,7 @@ extern "C" int paif_guided_filter_fused_fwd(const float* guide, const float* y, 
   // Rows per workgroup: 8 / NQ workgroups are resident per CU (~250 VGPRs per thread, 8 waves), so the launch runs in rounds
   // of 256 * 8 / NQ workgroups and a workgroup costs (rows + 4R halo) row-iterations: pick the split with the fewest
   // rounds x (rows + 16).
-  static const int NQ = [] { const char* e = getenv("PAIF_GF_NQ"); const int v = e ? atoi(e) : 4; return (v == 8 || v == 2) ? v : 4; }();
+  static const int NQ = [] { const char* e = getenv("PAIF_GF_NQ"); const int v = e ? atoi(e) : 8; return (v == 4 || v == 2) ? v : 8; }();
   const int zgroups = 8 / NQ;
   int nseg = 1;
   long best = -1;
