@@ -42,6 +42,9 @@ def main():
                     help="fusion = BASELINE configs[1] (the headline line); fusion_seg = configs[2] (bs=16, + mit_b3 SegFormer); "
                          "pgd = configs[3] (PGD-10 attack + final forward, bs=8); train = configs[4] (adversarial-training step: "
                          "PGD-k attack, _loss_coupled forward + full backward, gradient all-reduce over RCCL when N > 1, AdamW; bs=8/GPU)")
+    ap.add_argument("--gemm-precision", choices=["f32", "bf16x3", "auto"], default="f32",
+                    help="arithmetic of the SegFormer GEMMs (workloads with the segmentation net): exact fp32 MFMA (default), split-bf16, "
+                         "or auto = split-bf16 only where the fp32 GEMM is matrix-pipe bound (K >= 256)")
     ap.add_argument("--attack-iters", type=int, default=5, help="PGD iterations inside the training step (robust_test.py:42 default)")
     ap.add_argument("--backbone", default="mit_b3")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="BASELINE.md 3b protocol for both batch sizes (3 warm-up + 5 timed at "
@@ -72,6 +75,7 @@ def main():
     from paif_amd.core.model_fusion_auto import Network_Fusion_Searched, Network_MM_Searched
 
     ops.set_conv_precision(args.conv_precision)
+    ops.set_gemm_precision(args.gemm_precision)
     DOMINANT = "conv_mfma_%s<3,1,32>" % args.conv_precision   # the 12 dense 3x3 convs of a step
     bpg = 16 if args.workload == "fusion_seg" else B_PER_GPU
     if args.workload == "fusion":
@@ -155,7 +159,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    timer = ops.KernelTimer(lambda tag: tag == DOMINANT)
+    # HIP events around every dense-conv / GEMM / attention launch of the timed region (on the launch stream)
+    timer = ops.KernelTimer(lambda tag: True)
     barrier()
     ops.TIMER = timer
     t0 = time.perf_counter()
@@ -170,25 +175,43 @@ def main():
 
     if rank == 0:
         pairs = bpg * world * args.steps
-        n, ms, flops, nbytes = timer.summary()[DOMINANT]
-        tflops = flops / (ms * 1e-3) / 1e12
-        gbs = nbytes / (ms * 1e-3) / 1e9
-        if args.conv_precision == "f32":
-            # exact-fp32 MFMA: compute-bound (intensity 72-108 FLOP/B against 157.3 TF / 8 TB/s = 19.7 FLOP/B)
-            roof = {"kernel": DOMINANT, "bound": "mfma", "achieved": tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": tflops / MFMA_F32_PEAK_TFLOPS}
+        summ = timer.summary()
+        if args.workload != "fusion":       # the segmentation workloads: the kernel with the largest share of the timed region
+            DOM = max(summ, key=lambda k: summ[k][1])
         else:
-            # split-bf16: 3 bf16 MFMA passes -> effective matrix peak 2500/3 = 833 TF algorithmic; at 72-108 FLOP/B
-            # (fp32 storage) the HBM roof binds (833e12 / 8e12 = 104 FLOP/B)
-            roof = {"kernel": DOMINANT, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": gbs / HBM_PEAK_GBS, "algorithmic_tflops": tflops}
+            DOM = DOMINANT
+
+        def roof_block(tag):
+            n_, ms_, fl_, by_ = summ[tag]
+            tf, gb = fl_ / (ms_ * 1e-3) / 1e12, by_ / (ms_ * 1e-3) / 1e9
+            if tag.startswith("conv_") and "bf16x3" in tag or tag.startswith("conv_bf16x3_ws"):
+                # split-bf16 convs: 3 bf16 MFMA passes -> effective matrix peak 2500/3 = 833 TF algorithmic; at 72-108 FLOP/B
+                # (fp32 storage) the HBM roof binds (833e12 / 8e12 = 104 FLOP/B)
+                blk = {"bound": "hbm", "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS, "algorithmic_tflops": tf}
+            elif tag.startswith("conv_"):
+                blk = {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS}
+            else:
+                # GEMMs / attention, aggregated over all shapes of the step: report against the roof that binds the aggregate
+                peak_tf = MFMA_F32_PEAK_TFLOPS if not tag.endswith("bf16x3") else 2500.0 / 3
+                f_m, f_h = tf / peak_tf, gb / HBM_PEAK_GBS
+                if f_m >= f_h:
+                    blk = {"bound": "mfma", "achieved": tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": f_m, "algorithmic_gbs": gb}
+                else:
+                    blk = {"bound": "hbm", "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": f_h, "algorithmic_tflops": tf}
+            blk.update({"kernel": tag, "launches": n_, "avg_launch_ms": ms_ / n_, "share_of_step": ms_ / (dt * 1e3),
+                        "algorithmic_gflop_per_launch": fl_ / n_ / 1e9, "algorithmic_mb_per_launch": by_ / n_ / 1e6})
+            return blk
+
+        roof = roof_block(DOM)
+        roof["traffic"] = None
+        n = roof["launches"]
         # PMC counters cannot be read live: `traffic` comes from the committed rocprofv3 --pmc summary of this same command,
         # and ONLY while that summary still describes the kernel being benchmarked (hash of its source) -- otherwise null + why
         traffic, traffic_note = None, None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(DOMINANT)
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(DOM)
             if not pm:
-                traffic_note = "no PMC record for %s" % DOMINANT
+                traffic_note = "no PMC record for %s" % DOM
             elif args.workload != "fusion":
                 traffic_note = "PMC record is for the configs[1] workload"
             elif pm.get("kernel_source_sha16") != kernel_source_sha16():
@@ -198,10 +221,10 @@ def main():
                 traffic = pm["traffic_bytes"]
         except (OSError, ValueError) as e:
             traffic_note = "pmc_traffic.json unreadable: %s" % e
-        roof.update({"traffic": traffic, "launches": n, "avg_launch_ms": ms / n, "algorithmic_gflop_per_launch": flops / n / 1e9,
-                     "algorithmic_mb_per_launch": nbytes / n / 1e6})
+        roof["traffic"] = traffic
         if traffic_note:
             roof["traffic_note"] = traffic_note
+        others = [roof_block(k) for k in sorted(summ, key=lambda k: -summ[k][1]) if k != DOM][:4]
         res = {
             "metric": "fused image-pairs/sec at 480x640 bs=%d per GPU (%s)" % (bpg, {"fusion": "fusion-net forward", "fusion_seg": "fusion + SegFormer forward", "pgd": "PGD-10 adversarial eval", "train": "adversarial-training step"}[args.workload]),
             "value": pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -220,6 +243,7 @@ def main():
                        "parallelism": ("dp%d: batch sharded, weights replicated, 179.5 MB fp32 gradient all-reduce (25 MB buckets) per step" % world
                                        if args.workload == "train" else "replicas x%d (no data-path collective)" % world)},
             "roofline": roof,
+            "roofline_other": others,
         }
         if args.workload == "train":
             res["steps_per_s"] = args.steps / dt

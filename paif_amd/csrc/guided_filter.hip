@@ -11,6 +11,7 @@
 // Box sums are exact border-clipped window sums; N = (#valid rows) x (#valid cols).
 // fp32 throughout (SURVEY.md section 7 hard part 1: A = cov/(var+eps) with eps = 1e-4).
 #include <stdlib.h>
+#include <string.h>
 
 #include "paif_common.h"
 
@@ -278,21 +279,46 @@ __global__ __launch_bounds__(256) void gf_guide_stats_kernel(const float* __rest
   }
 }
 
-// NQ = channel quads per workgroup (blockIdx.z walks the 8 / NQ channel groups).  Measured at B=8, 480x640 (one launch, both
-// eps): NQ = 8 (one 512-thread workgroup per CU) 0.844 ms, NQ = 4 (2 x 256 threads per CU) 0.912 ms, NQ = 2 0.947 ms --
-// splitting the barrier group does NOT help: the kernel is paced by VALU issue (tools/microbench/valu_rate.hip: with two
-// waves per SIMD a v_add_f32 costs 3.0 and a v_pk_add_f32 7.5 cycles of the SIMD, i.e. packed fp32 buys nothing), ~2.6k of
-// the ~3.9k cycles per row, then the LDS array (~1.2k).  PAIF_GF_NQ selects the form for A/B runs.
-template <int NQ>
-__global__ __launch_bounds__(FC * NQ) void gf_fused_kernel(const float* __restrict__ guide, const float* __restrict__ y,
+// Generic over the per-thread channel vector V (float4 or float2) and NL = vectors per pixel handled by one workgroup
+// (blockIdx.z walks the 32 / (VW * NL) channel groups).  Measured at B=8, 480x640 (one launch, both eps), V = float4:
+// NL = 8 (one 512-thread workgroup per CU) 0.844 ms, NL = 4 (2 x 256 threads) 0.912 ms, NL = 2 0.947 ms -- splitting the
+// barrier group does not help.  PMC (profiles/r02_pmc_fusion.txt): waves are PARKED (s_waitcnt / barrier) 46 % of their
+// cycles, issue-stalled 21 %, issuing 33 %; with ~250 VGPRs per thread only 8 waves fit a CU.  V = float2 halves the
+// register rings (16 waves per CU) at the price of repeating the per-column scalar work for twice as many threads.
+// PAIF_GF_FORM selects the form for A/B runs: "4x8" (default), "4x4", "4x2", "2x16".
+template <typename V> struct VecOps;
+template <> struct VecOps<float4> {
+  static constexpr int VW = 4;
+  static __device__ __forceinline__ float4 zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+};
+template <> struct VecOps<float2> {
+  static constexpr int VW = 2;
+  static __device__ __forceinline__ float2 zero() { return make_float2(0.f, 0.f); }
+};
+template <typename V> __device__ __forceinline__ V vadd(V a, V b) {
+  V r; float* pr = reinterpret_cast<float*>(&r); const float* pa = reinterpret_cast<const float*>(&a); const float* pb = reinterpret_cast<const float*>(&b);
+#pragma unroll
+  for (int i = 0; i < VecOps<V>::VW; ++i) pr[i] = pa[i] + pb[i];
+  return r;
+}
+template <typename V> __device__ __forceinline__ V vfma(float s, V a, V c) {
+  V r; float* pr = reinterpret_cast<float*>(&r); const float* pa = reinterpret_cast<const float*>(&a); const float* pc = reinterpret_cast<const float*>(&c);
+#pragma unroll
+  for (int i = 0; i < VecOps<V>::VW; ++i) pr[i] = fmaf(s, pa[i], pc[i]);
+  return r;
+}
+
+template <typename V, int NL>
+__global__ __launch_bounds__(FC * NL) void gf_fused_kernel(const float* __restrict__ guide, const float* __restrict__ y,
                                                            const float2* __restrict__ gs, float* __restrict__ lf, int B, int H, int W,
                                                            int nstrip, int nseg, int frows) {
-  __shared__ float4 s_a[2][FC][NQ];
-  __shared__ float4 s_b[2][FC][NQ];
-  const int xi = threadIdx.x / NQ;
-  const int ql = threadIdx.x - xi * NQ;                       // channel quad slot in the LDS rows; quad = blockIdx.z * NQ + ql
-  y += (blockIdx.z * NQ + ql) * 4;
-  lf += (blockIdx.z * NQ + ql) * 4;
+  constexpr int VW = VecOps<V>::VW;
+  __shared__ V s_a[2][FC][NL];
+  __shared__ V s_b[2][FC][NL];
+  const int xi = threadIdx.x / NL;
+  const int ql = threadIdx.x - xi * NL;                       // vector slot in the LDS rows; channel = (blockIdx.z * NL + ql) * VW
+  y += (blockIdx.z * NL + ql) * VW;
+  lf += (blockIdx.z * NL + ql) * VW;
   int t = blockIdx.x;
   const int strip = t % nstrip; t /= nstrip;
   const int seg = t % nseg;
@@ -322,22 +348,22 @@ __global__ __launch_bounds__(FC * NQ) void gf_fused_kernel(const float* __restri
   // ring 1: the last 9 rows of y and of the guide.  ring 2 holds the (A, b) rows as 3-row partial sums:
   //   tA[j] = A(i) + A(i+1) + A(i+2);   a 9-row window = three of them 3 rows apart (4 adds per row instead of 8, still a
   //   plain sum of the nine terms -- no running add/subtract, no drift)
-  float4 ry[K], tA[K], tB[K];
+  V ry[K], tA[K], tB[K];
   float rg[K];
-  float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1, b1 = a1, b2 = a1;   // the two previous (A, b) rows
+  V a1 = VecOps<V>::zero(), a2 = a1, b1 = a1, b2 = a1;   // the two previous (A, b) rows
 #pragma unroll
-  for (int k = 0; k < K; ++k) { tA[k] = make_float4(0.f, 0.f, 0.f, 0.f); tB[k] = tA[k]; }
+  for (int k = 0; k < K; ++k) { tA[k] = VecOps<V>::zero(); tB[k] = tA[k]; }
   const int r0 = ybeg - 2 * R, r1 = yend + 2 * R;   // streamed input rows [r0, r1)
   // Loads are unconditional on a clamped address (a load under a divergent branch makes hipcc wait for it at the
   // join); out-of-image values are zeroed when they enter the ring.
   const int colc = min(max(col, 0), W - 1);
-  float4 pv[PF];
+  V pv[PF];
   float pg[PF];
   float2 ps[PF];
 #pragma unroll
   for (int p = 0; p < PF; ++p) {
     const size_t px = img + (size_t)min(max(r0 + p, 0), H - 1) * W + colc;
-    pv[p] = *reinterpret_cast<const float4*>(y + px * 32);
+    pv[p] = *reinterpret_cast<const V*>(y + px * 32);
     pg[p] = guide[px];
     ps[p] = gse[img + (size_t)min(max(r0 + p - R, 0), H - 1) * W + colc];
   }
@@ -347,12 +373,12 @@ __global__ __launch_bounds__(FC * NQ) void gf_fused_kernel(const float* __restri
       const int row = rr + k;
       if (row >= r1) break;   // block-uniform
       const bool in = colin && row >= 0 && row < H;
-      ry[k] = in ? pv[k % PF] : make_float4(0.f, 0.f, 0.f, 0.f);
+      ry[k] = in ? pv[k % PF] : VecOps<V>::zero();
       rg[k] = in ? pg[k % PF] : 0.f;
       const float2 st = ps[k % PF];             // (mean_g, 1/(var_g + eps)) of (row - R, col)
       {
         const size_t px = img + (size_t)min(max(row + PF, 0), H - 1) * W + colc;
-        pv[k % PF] = *reinterpret_cast<const float4*>(y + px * 32);
+        pv[k % PF] = *reinterpret_cast<const V*>(y + px * 32);
         pg[k % PF] = guide[px];
         ps[k % PF] = gse[img + (size_t)min(max(row + PF - R, 0), H - 1) * W + colc];
       }
@@ -360,34 +386,40 @@ __global__ __launch_bounds__(FC * NQ) void gf_fused_kernel(const float* __restri
       if (irow < ybeg - R) continue;          // block-uniform
       // ---- stage 1: vertical sums -> LDS -> horizontal sums -> (A, b) of (irow, col) ----
       {
-        float4 vy = make_float4(0.f, 0.f, 0.f, 0.f), vgy = vy;
+        V vy = VecOps<V>::zero(), vgy = vy;
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-          vy = f4add(vy, ry[j]);
-          vgy = f4fma(rg[j], ry[j], vgy);
+          vy = vadd(vy, ry[j]);
+          vgy = vfma(rg[j], ry[j], vgy);
         }
         s_a[0][xi][ql] = vy;
         s_b[0][xi][ql] = vgy;
       }
       lds_barrier();
-      float4 A = make_float4(0.f, 0.f, 0.f, 0.f), Bc = A;
+      V A = VecOps<V>::zero(), Bc = A;
       if (xi >= R && xi < FC - R && colin && irow >= 0 && irow < H) {   // outside the image the coefficients are zero padding
-        float4 by = make_float4(0.f, 0.f, 0.f, 0.f), bgy = by;
+        V by = VecOps<V>::zero(), bgy = by;
 #pragma unroll
         for (int j = -R; j <= R; ++j) {
-          by = f4add(by, s_a[0][xi + j][ql]);
-          bgy = f4add(bgy, s_b[0][xi + j][ql]);
+          by = vadd(by, s_a[0][xi + j][ql]);
+          bgy = vadd(bgy, s_b[0][xi + j][ql]);
         }
         const float rn = rn_of(irow);
         const float mg = st.x, rden = st.y;
-        const float4 my = make_float4(by.x * rn, by.y * rn, by.z * rn, by.w * rn);
-        A = make_float4((bgy.x * rn - mg * my.x) * rden, (bgy.y * rn - mg * my.y) * rden, (bgy.z * rn - mg * my.z) * rden,
-                        (bgy.w * rn - mg * my.w) * rden);
-        Bc = make_float4(my.x - A.x * mg, my.y - A.y * mg, my.z - A.z * mg, my.w - A.w * mg);
+        const float* pby = reinterpret_cast<const float*>(&by);
+        const float* pbgy = reinterpret_cast<const float*>(&bgy);
+        float* pA = reinterpret_cast<float*>(&A);
+        float* pB = reinterpret_cast<float*>(&Bc);
+#pragma unroll
+        for (int i = 0; i < VW; ++i) {
+          const float my = pby[i] * rn;
+          pA[i] = (pbgy[i] * rn - mg * my) * rden;
+          pB[i] = my - pA[i] * mg;
+        }
       }
       // 3-row partial sums of ring 2: slot k <- rows (irow-2, irow-1, irow)
-      tA[k] = f4add(f4add(a2, a1), A);
-      tB[k] = f4add(f4add(b2, b1), Bc);
+      tA[k] = vadd(vadd(a2, a1), A);
+      tB[k] = vadd(vadd(b2, b1), Bc);
       a2 = a1; a1 = A; b2 = b1; b1 = Bc;
       const int orow = irow - R;              // output row whose 9-row (A, b) window is complete
       // the first ring-2 window is complete once stage-1 rows ybeg-R .. ybeg+R are in
@@ -395,25 +427,27 @@ __global__ __launch_bounds__(FC * NQ) void gf_fused_kernel(const float* __restri
       // ---- stage 2: vertical sums of (A, b) -> LDS -> horizontal sums -> LF ----
       {
         // window rows irow-8 .. irow = partial sums ending at irow, irow-3, irow-6 (slots k, k-3, k-6 mod 9)
-        const float4 ua = f4add(f4add(tA[k], tA[(k + 6) % K]), tA[(k + 3) % K]);
-        const float4 ub = f4add(f4add(tB[k], tB[(k + 6) % K]), tB[(k + 3) % K]);
-        s_a[1][xi][ql] = ua;
-        s_b[1][xi][ql] = ub;
+        s_a[1][xi][ql] = vadd(vadd(tA[k], tA[(k + 6) % K]), tA[(k + 3) % K]);
+        s_b[1][xi][ql] = vadd(vadd(tB[k], tB[(k + 6) % K]), tB[(k + 3) % K]);
       }
       lds_barrier();
       if (xi >= 2 * R && xi < FC - 2 * R && col < W) {
-        float4 ba = make_float4(0.f, 0.f, 0.f, 0.f), bb = ba;
+        V ba = VecOps<V>::zero(), bb = ba;
 #pragma unroll
         for (int j = -R; j <= R; ++j) {
-          ba = f4add(ba, s_a[1][xi + j][ql]);
-          bb = f4add(bb, s_b[1][xi + j][ql]);
+          ba = vadd(ba, s_a[1][xi + j][ql]);
+          bb = vadd(bb, s_b[1][xi + j][ql]);
         }
         const float rn = rn_of(orow);
         const size_t px = img + (size_t)orow * W + col;
         const float g0 = rg[(k + 1) % K];   // guide(orow, col): the oldest ring-1 row (row - 2R)
-        *reinterpret_cast<float4*>(out + px * 32) =
-            make_float4(fmaf(ba.x * rn, g0, bb.x * rn), fmaf(ba.y * rn, g0, bb.y * rn), fmaf(ba.z * rn, g0, bb.z * rn),
-                        fmaf(ba.w * rn, g0, bb.w * rn));
+        V o;
+        float* po = reinterpret_cast<float*>(&o);
+        const float* pa = reinterpret_cast<const float*>(&ba);
+        const float* pb = reinterpret_cast<const float*>(&bb);
+#pragma unroll
+        for (int i = 0; i < VW; ++i) po[i] = fmaf(pa[i] * rn, g0, pb[i] * rn);
+        *reinterpret_cast<V*>(out + px * 32) = o;
       }
     }
   }
@@ -428,17 +462,22 @@ extern "C" int paif_guided_filter_fused_fwd(const float* guide, const float* y, 
   PAIF_REQUIRE(guide && y && lf && workspace && B > 0, PAIF_EINVAL, "guided_filter_fused: bad arguments");
   PAIF_REQUIRE(H > 2 * R + 1 && W > 2 * R + 1, PAIF_EINVAL, "guided_filter: H,W must exceed 2r+1 = %d (got %dx%d)", K, H, W);
   const int nstrip = (W + FO - 1) / FO;
-  // Rows per workgroup: 8 / NQ workgroups are resident per CU (~250 VGPRs per thread, 8 waves), so the launch runs in rounds
-  // of 256 * 8 / NQ workgroups and a workgroup costs (rows + 4R halo) row-iterations: pick the split with the fewest
-  // rounds x (rows + 16).
-  static const int NQ = [] { const char* e = getenv("PAIF_GF_NQ"); const int v = e ? atoi(e) : 8; return (v == 4 || v == 2) ? v : 8; }();
-  const int zgroups = 8 / NQ;
+  // Rows per workgroup: `resident` workgroups fit a CU (8 waves at ~250 VGPRs for the float4 forms, 16 waves for float2), so
+  // the launch runs in rounds of 256 * resident workgroups and a workgroup costs (rows + 4R halo) row-iterations: pick the
+  // split with the fewest rounds x (rows + 16).
+  static const int form = [] {
+    const char* e = getenv("PAIF_GF_FORM");
+    if (!e) return 0;
+    return !strcmp(e, "4x4") ? 1 : !strcmp(e, "4x2") ? 2 : !strcmp(e, "2x16") ? 3 : 0;
+  }();
+  const int zgroups = form == 0 ? 1 : form == 1 ? 2 : form == 2 ? 4 : 1;
+  const int resident = form == 0 ? 1 : form == 1 ? 2 : form == 2 ? 4 : 1;
   int nseg = 1;
   long best = -1;
   for (int n = 1; n <= 16 && n <= H; ++n) {
     const int rows = (H + n - 1) / n;
     const long blocks = (long)B * nstrip * n * 2 * zgroups;
-    const long cost = ((blocks + 256 * zgroups - 1) / (256 * zgroups)) * (rows + 4 * R);
+    const long cost = ((blocks + 256 * resident - 1) / (256 * resident)) * (rows + 4 * R);
     if (best < 0 || cost < best) { best = cost; nseg = n; }
   }
   const int frows = (H + nseg - 1) / nseg;
@@ -448,9 +487,10 @@ extern "C" int paif_guided_filter_fused_fwd(const float* guide, const float* y, 
   hipLaunchKernelGGL(gf_guide_stats_kernel, dim3(B * gtx * gty), dim3(256), 0, st, guide, gs, eps0, eps1, B, H, W, gtx, gty);
   PAIF_LAUNCH_CHECK("guided_filter_fused(stats)");
   const dim3 grid(B * nstrip * nseg, 2, zgroups);
-  if (NQ == 8) hipLaunchKernelGGL(gf_fused_kernel<8>, grid, dim3(FC * 8), 0, st, guide, y, gs, lf, B, H, W, nstrip, nseg, frows);
-  else if (NQ == 4) hipLaunchKernelGGL(gf_fused_kernel<4>, grid, dim3(FC * 4), 0, st, guide, y, gs, lf, B, H, W, nstrip, nseg, frows);
-  else hipLaunchKernelGGL(gf_fused_kernel<2>, grid, dim3(FC * 2), 0, st, guide, y, gs, lf, B, H, W, nstrip, nseg, frows);
+  if (form == 0) hipLaunchKernelGGL((gf_fused_kernel<float4, 8>), grid, dim3(FC * 8), 0, st, guide, y, gs, lf, B, H, W, nstrip, nseg, frows);
+  else if (form == 1) hipLaunchKernelGGL((gf_fused_kernel<float4, 4>), grid, dim3(FC * 4), 0, st, guide, y, gs, lf, B, H, W, nstrip, nseg, frows);
+  else if (form == 2) hipLaunchKernelGGL((gf_fused_kernel<float4, 2>), grid, dim3(FC * 2), 0, st, guide, y, gs, lf, B, H, W, nstrip, nseg, frows);
+  else hipLaunchKernelGGL((gf_fused_kernel<float2, 16>), grid, dim3(FC * 16), 0, st, guide, y, gs, lf, B, H, W, nstrip, nseg, frows);
   PAIF_LAUNCH_CHECK("guided_filter_fused");
   return 0;
 }
