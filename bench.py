@@ -42,9 +42,9 @@ def main():
                     help="fusion = BASELINE configs[1] (the headline line); fusion_seg = configs[2] (bs=16, + mit_b3 SegFormer); "
                          "pgd = configs[3] (PGD-10 attack + final forward, bs=8); train = configs[4] (adversarial-training step: "
                          "PGD-k attack, _loss_coupled forward + full backward, gradient all-reduce over RCCL when N > 1, AdamW; bs=8/GPU)")
-    ap.add_argument("--gemm-precision", choices=["f32", "bf16x3", "auto"], default="f32",
-                    help="arithmetic of the SegFormer GEMMs (workloads with the segmentation net): exact fp32 MFMA (default), split-bf16, "
-                         "or auto = split-bf16 only where the fp32 GEMM is matrix-pipe bound (K >= 256)")
+    ap.add_argument("--gemm-precision", choices=["f32", "bf16x3", "auto"], default="auto",
+                    help="arithmetic of the SegFormer GEMMs (workloads with the segmentation net): auto (default) = split-bf16 only where "
+                         "the exact-fp32 GEMM is matrix-pipe bound (K >= 256), exact fp32 MFMA elsewhere; f32 = exact everywhere; bf16x3")
     ap.add_argument("--attack-iters", type=int, default=5, help="PGD iterations inside the training step (robust_test.py:42 default)")
     ap.add_argument("--backbone", default="mit_b3")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="BASELINE.md 3b protocol for both batch sizes (3 warm-up + 5 timed at "
@@ -229,7 +229,9 @@ def main():
             "metric": "fused image-pairs/sec at 480x640 bs=%d per GPU (%s)" % (bpg, {"fusion": "fusion-net forward", "fusion_seg": "fusion + SegFormer forward", "pgd": "PGD-10 adversarial eval", "train": "adversarial-training step"}[args.workload]),
             "value": pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.conv_precision == "f32" else "f32 (storage and accumulation f32; conv products as split-bf16: 3x bf16 MFMA)",
+            "dtype": ("f32" if args.conv_precision == "f32" else "f32 (storage and accumulation f32; conv products as split-bf16: 3x bf16 MFMA)")
+                     + ("" if args.workload == "fusion" else "; SegFormer GEMMs: %s" % {"f32": "exact fp32 MFMA", "bf16x3": "split-bf16",
+                                                                                      "auto": "exact fp32 MFMA, split-bf16 where K >= 256"}[args.gemm_precision]),
             "data": "synthetic",
             "config": {"workload": {"fusion": "configs[1]: fusion-net forward (RGB2YCrCb + Network_Fusion_Searched, C=32, shipped genotype)",
                                     "fusion_seg": "configs[2]: fusion + mit_b3 SegFormer end-to-end inference",

@@ -24,10 +24,12 @@ def _dev():
 @pytest.fixture(autouse=True)
 def _exact_convs():
     """gradient parity is asserted with the exact-fp32 conv kernels; the split-bf16 mode is checked separately"""
-    old = ops.CONFIG["conv_precision"]
+    old, oldg = ops.CONFIG["conv_precision"], ops.CONFIG["gemm_precision"]
     ops.set_conv_precision("f32")
+    ops.set_gemm_precision("f32")
     yield
     ops.set_conv_precision(old)
+    ops.set_gemm_precision(oldg)
 
 
 def _model(bb="mit_b0"):

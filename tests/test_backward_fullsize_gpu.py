@@ -20,10 +20,12 @@ def _dev():
 
 @pytest.fixture(autouse=True)
 def _exact_convs():
-    old = ops.CONFIG["conv_precision"]
+    old, oldg = ops.CONFIG["conv_precision"], ops.CONFIG["gemm_precision"]
     ops.set_conv_precision("f32")
+    ops.set_gemm_precision("f32")
     yield
     ops.set_conv_precision(old)
+    ops.set_gemm_precision(oldg)
 
 
 @pytest.mark.parametrize("B,N,Nk,C,heads", [

@@ -26,10 +26,12 @@ def _dev():
 
 @pytest.fixture(autouse=True)
 def _exact_convs():
-    old = ops.CONFIG["conv_precision"]
+    old, oldg = ops.CONFIG["conv_precision"], ops.CONFIG["gemm_precision"]
     ops.set_conv_precision("f32")
+    ops.set_gemm_precision("f32")
     yield
     ops.set_conv_precision(old)
+    ops.set_gemm_precision(oldg)
 
 
 def _model(bb="mit_b0", train=False):
@@ -276,6 +278,7 @@ def test_split_bf16_training_step_stays_within_the_fp32_noise():
     """Default conv arithmetic (split-bf16 forward / dgrad, exact-fp32 wgrad): loss and gradients stay within a few times the
     reference arithmetic's own fp32 floor."""
     ops.set_conv_precision("bf16x3")
+    ops.set_gemm_precision("auto")
     inputs = training_inputs()
     ir, vis, lab, ir_adv, vis_adv, mask = inputs
     m = _model()
