@@ -14,26 +14,63 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Operands go through a wave-private LDS region in their natural [token][channel] layout: the MFMA takes ONE dword per lane per
+// operand (lane (kk, c) = channel c of token 2j + kk), and fetching those dwords straight from global memory made every MFMA wait
+// on a 256-B wave load (the kernel ran at the CU's L1 rate, ~23 TFLOP/s).  Staged with coalesced float4 loads (8 tokens x 128 B
+// per wave instruction), the same dword is a conflict-free ds_read_b32.
+constexpr int GW_CH = 32;     // tokens per staged chunk
+
 __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
                                                          float* __restrict__ part_w, float* __restrict__ part_b, int M, int N, int K,
                                                          int mper) {
+  __shared__ __align__(16) float lds[4][2][GW_CH * 32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kk = lane >> 5, c = lane & 31;
   const int n0 = blockIdx.x * 32, k0 = blockIdx.y * 128 + wave * 32;
   const int mbeg = blockIdx.z * mper, mend = min(M, mbeg + mper);
-  const int n = min(n0 + c, N - 1), kc = min(k0 + c, K - 1);      // clamped columns: their results are never stored
+  float* sD = lds[wave][0];
+  float* sX = lds[wave][1];
+  const int tl = lane >> 3, q = lane & 7;                      // staging role: token lane, channel quad
+  // clamped columns (ragged N / K): their products land in accumulator rows / columns that are never stored
+  const int nq = min(n0 + 4 * q, max(N - 4, 0)), kq = min(k0 + 4 * q, max(K - 4, 0));
+  const bool nvec = (N % 4 == 0 && lddy % 4 == 0 && n0 + 4 * q + 4 <= N), kvec = (K % 4 == 0 && ldx % 4 == 0 && k0 + 4 * q + 4 <= K);
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   float bsum = 0.f;
-  for (int m = mbeg; m < mend; m += 2) {
-    const int mm = min(m + kk, M - 1);
-    const bool ok = m + kk < mend;
-    float a = dy[(size_t)mm * lddy + n];
-    float b = x[(size_t)mm * ldx + kc];
-    a = ok ? a : 0.f;
-    bsum += a;
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  for (int m0 = mbeg; m0 < mend; m0 += GW_CH) {
+#pragma unroll
+    for (int it = 0; it < GW_CH / 8; ++it) {
+      const int m = m0 + it * 8 + tl;
+      const int mm = min(m, M - 1);
+      const bool in = m < mend;
+      float4 d, v;
+      if (nvec) d = *reinterpret_cast<const float4*>(dy + (size_t)mm * lddy + n0 + 4 * q);
+      else {
+        const float* r_ = dy + (size_t)mm * lddy;
+        d = make_float4(r_[min(n0 + 4 * q, N - 1)], r_[min(n0 + 4 * q + 1, N - 1)], r_[min(n0 + 4 * q + 2, N - 1)], r_[min(n0 + 4 * q + 3, N - 1)]);
+      }
+      if (kvec) v = *reinterpret_cast<const float4*>(x + (size_t)mm * ldx + k0 + 4 * q);
+      else {
+        const float* r_ = x + (size_t)mm * ldx;
+        v = make_float4(r_[min(k0 + 4 * q, K - 1)], r_[min(k0 + 4 * q + 1, K - 1)], r_[min(k0 + 4 * q + 2, K - 1)], r_[min(k0 + 4 * q + 3, K - 1)]);
+      }
+      if (!in) d = make_float4(0.f, 0.f, 0.f, 0.f);             // tokens past the slice contribute nothing
+      *reinterpret_cast<float4*>(sD + (it * 8 + tl) * 32 + 4 * q) = d;
+      *reinterpret_cast<float4*>(sX + (it * 8 + tl) * 32 + 4 * q) = v;
+    }
+    (void)nq; (void)kq;
+    __builtin_amdgcn_wave_barrier();          // wave-private region, LDS operations of one wave complete in order:
+    asm volatile("" ::: "memory");            // only the compiler must not reorder across the phases
+#pragma unroll 4
+    for (int j = 0; j < GW_CH / 2; ++j) {
+      const float a = sD[(2 * j + kk) * 32 + c];
+      const float b = sX[(2 * j + kk) * 32 + c];
+      bsum += a;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
   }
   float* pw = part_w + (size_t)blockIdx.z * N * K;
 #pragma unroll

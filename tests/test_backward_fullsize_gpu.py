@@ -126,3 +126,55 @@ def test_one_pgd_iteration_at_480x640_mit_b3_vs_oracle():
         a = mine.detach().cpu().numpy()
         assert (np.abs(a - ref.numpy()) > 1e-6).mean() <= 2e-3
         assert np.abs(a).max() <= eps + 1e-7
+
+
+def test_parameter_gradients_at_480x640_mit_b3_vs_oracle():
+    """The training step's backward AT FULL SIZE (configs[4] shape class: 480x640, mit_b3, train mode): `_loss_coupled` forward
+    (BatchNorm batch statistics over 307,200 pixels, DropPath / Dropout2d masks) and every parameter gradient, vs the oracle's
+    autograd on the host (float32 against float32: tolerance = a few times the arithmetic's own floor, which is largest for the
+    fusion network's parameters -- their gradients pass through the guided filter)."""
+    from oracle import paif_oracle as O
+    from paif_amd.core.loss import Fusionloss_grad2
+    from paif_amd.core.model_fusion_auto import Network_MM_Searched
+    from paif_amd.genotypes import FUSION_AT
+
+    m = Network_MM_Searched(32, FUSION_AT, Fusionloss_grad2(), torch.nn.CrossEntropyLoss(ignore_index=255), "mit_b3", num_classes=9)
+    S.load_formula_weights(m)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m.train().to(_dev())
+    ir, vis, lab = S.make_batch(1, 480, 640)
+    eps = 8 / 255.
+    ir_adv = np.clip(ir + S.make_delta0(7, ir.shape, eps), 0, 1).astype(np.float32)
+    vis_adv = np.clip(vis + S.make_delta0(107, vis.shape, eps), 0, 1).astype(np.float32)
+    mask = np.maximum(ir, vis[:, :1]).astype(np.float32)
+    d = lambda a: t(a).to(_dev())
+    ops.DROP_RNG.reseed(99, rank=0, step=3)
+    loss = m._loss_coupled((d(ir_adv), d(ir)), (d(vis_adv), d(vis)), d(mask), d(lab))
+    loss.backward()
+    names = [k for k, v in sd.items() if v.is_floating_point() and "running_" not in k]
+    for k in names:
+        sd[k].requires_grad_(True)
+    O.TRAIN = O.TrainCtx(99, rank=0, step=3)
+    try:
+        lo = O.loss_coupled(t(ir_adv), t(vis_adv), t(mask), t(lab), sd, "mit_b3")
+        lo.backward()
+    finally:
+        O.TRAIN = None
+    assert abs(float(loss) - float(lo)) <= 1e-4 * abs(float(lo))
+    worst = (0.0, None)
+    n = 0
+    for k, p in m.named_parameters():
+        ref = sd[k].grad
+        if ref is None:
+            assert p.grad is None, k
+            continue
+        n += 1
+        scale = max(float(ref.abs().max()), 1e-12)
+        err = float((p.grad.cpu() - ref).abs().max())
+        tol = (5e-2 if k.startswith("enhance_net.") else 5e-3) * scale + 1e-7
+        worst = max(worst, (err / tol, k))
+        assert err <= tol, (k, err, scale)
+    assert n == 623
+    for k, v in m.state_dict().items():          # running statistics after one train-mode forward
+        if "running_" in k:
+            assert float((v.cpu() - sd[k]).abs().max()) <= 1e-5 * max(1.0, float(sd[k].abs().max())), k
