@@ -45,6 +45,9 @@ def main():
     ap.add_argument("--gemm-precision", choices=["f32", "bf16x3", "auto"], default="auto",
                     help="arithmetic of the SegFormer GEMMs (workloads with the segmentation net): auto (default) = split-bf16 only where "
                          "the exact-fp32 GEMM is matrix-pipe bound (K >= 256), exact fp32 MFMA elsewhere; f32 = exact everywhere; bf16x3")
+    ap.add_argument("--force-allreduce", action="store_true",
+                    help="train workload: run the bucketed gradient all-reduce even at N=1 (a 1-rank RCCL group): exercises the side-stream / "
+                         "event path on one GPU; needs the torch.distributed.run environment")
     ap.add_argument("--attack-iters", type=int, default=5, help="PGD iterations inside the training step (robust_test.py:42 default)")
     ap.add_argument("--backbone", default="mit_b3")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="BASELINE.md 3b protocol for both batch sizes (3 warm-up + 5 timed at "
@@ -61,7 +64,7 @@ def main():
                          % (args.gpus, world, args.gpus))
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_allreduce:
         # the process group comes up BEFORE this process makes any other GPU call.  RCCL over xGMI: configs 1-3 use it for the
         # barrier + max-over-ranks only (replicas); configs[4] for the bucketed gradient all-reduce
         import torch.distributed as dist
@@ -115,7 +118,7 @@ def main():
                                       dict(params=pg[2], lr=8e-4, weight_decay=0.01),
                                       dict(params=list(net.enhance_net.parameters()), lr=8e-5, weight_decay=0.01)],
                               lr=8e-5, weight_decay=0.01, betas=(0.9, 0.999), warmup_iter=3000, max_iter=160000, warmup_ratio=1e-5, power=1.0)
-        reducer = GradAllReduce(opt.arena(), model=net).install() if world > 1 else None
+        reducer = GradAllReduce(opt.arena(), model=net).install() if dist is not None else None
         mask = torch.from_numpy(np.maximum(ir_np, vis_np[:, :1]).astype("float32")).to(dev)    # fusion target: any [B,1,H,W] image
         d0i = torch.from_numpy(S.make_delta0(rank, ir_np.shape, 8 / 255.)).to(dev)
         d0v = torch.from_numpy(S.make_delta0(100 + rank, vis_np.shape, 8 / 255.)).to(dev)

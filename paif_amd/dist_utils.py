@@ -119,7 +119,7 @@ class GradAllReduce:
         s, e = self.buckets[b]
         buf = self.arena.grad[s:e]
         self.launched.append((s, e))
-        if self.world == 1:
+        if self.world == 1 and not (self.dist.is_available() and self.dist.is_initialized()):
             return
         dist = self.dist
         if self.cuda:
