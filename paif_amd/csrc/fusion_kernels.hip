@@ -84,13 +84,20 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
     const size_t rowid = pix / W;
     const int y = (int)(rowid % H);
     const float* base = img + ((rowid - y) / H) * img_bstride;  // image start (batch stride in floats)
+    // all 9 taps in flight: unconditional loads on clamped coordinates, padding by select (a load under a data-dependent
+    // branch is waited for at the join: the nine loads were serialised)
     float v[9];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx)
+        v[dy * 3 + dx] = base[(size_t)min(max(y + dy - 1, 0), H - 1) * W + min(max(x + dx - 1, 0), W - 1)];
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
         const int yy = y + dy - 1, xx = x + dx - 1;
-        v[dy * 3 + dx] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? base[(size_t)yy * W + xx] : 0.f;
+        if (yy < 0 || yy >= H || xx < 0 || xx >= W) v[dy * 3 + dx] = 0.f;
       }
     float o[4];
 #pragma unroll

@@ -195,6 +195,11 @@ def test_harness_clean_eval_config1(golden):
     assert (out["conf"] == g["conf"]).all()
     np.testing.assert_array_equal(np.nan_to_num(out["iou"], nan=-1), np.nan_to_num(g["iou"], nan=-1))
     assert maxabs(out["fused"][0].cpu(), g["fused"]) <= 1e-4
+    # default = hipGraph replay; the eager path gives bit-identical results, over several batches and a shape change
+    batches = [(t(vis[i:i + 1]).to(_dev()), t(ir[i:i + 1]).to(_dev()), t(lab[i:i + 1]).to(_dev())) for i in range(3)]
+    batches.append((t(vis[:2]).to(_dev()), t(ir[:2]).to(_dev()), t(lab[:2]).to(_dev())))
+    a, b = val_segformer_robust2(m, batches, graph=True), val_segformer_robust2(m, batches, graph=False)
+    assert (a["conf"] == b["conf"]).all() and all(torch.equal(x, y) for x, y in zip(a["fused"], b["fused"]))
 
 
 def test_harness_pgd_eval_vs_oracle():
