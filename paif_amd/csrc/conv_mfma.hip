@@ -384,7 +384,9 @@ template <int KH, int DIL, bool HOOKS>
 #ifndef PAIF_LB
 #define PAIF_LB 3
 #endif
-__global__ __launch_bounds__(NTHREADS, HOOKS ? 2 : PAIF_LB) void conv_mfma_bf16x3(ConvArgs a) {
+// two workgroups per CU (256 VGPRs) for the gradient-hook kernels and the wide halos (k >= 5, dilation 2: at three the
+// staging batch spills 84-220 B/lane and the kernels measure 5-25 % slower), three for the 1x1 / 3x3 dilation-1 kernels
+__global__ __launch_bounds__(NTHREADS, (HOOKS || KH >= 5 || DIL == 2) ? 2 : PAIF_LB) void conv_mfma_bf16x3(ConvArgs a) {
   constexpr int CIN = 32;
   constexpr int P = DIL * (KH - 1) / 2;
   constexpr int TWH = TW + 2 * P;
@@ -488,43 +490,78 @@ __global__ __launch_bounds__(NTHREADS, HOOKS ? 2 : PAIF_LB) void conv_mfma_bf16x
 #pragma unroll
       for (int i = 0; i < NKS * 2; ++i) bw[slot][i] = wsrc[(tap * NKS * 2 + i) * 64];
     };
-    auto mma_tap = [&](int tap, int slot) {
+    // A operand of one K=16 step (hi and lo halves of this wave's two row segments), double-buffered in registers: the
+    // reads of step i+1 are issued before the MFMAs of step i and pinned there with sched_barrier.  Left to itself the
+    // scheduler sinks every ds_read (and the B prefetch) to just above its first use to save registers, and each MFMA
+    // group then eats the full LDS / L2 latency (measured: 9.9k -> 5.6k cycles per 3x3 source on the MFMA phase).
+    struct AStep { bf16x8 h[SEGS_PER_WAVE], l[SEGS_PER_WAVE]; };
+    auto readA = [&](AStep& A, int tap, int ks) {
       const int dy = tap / KH, dx = tap - dy * KH;
-      const int toff = (dy * DIL * TWH + dx * DIL) * PSB;
+      const int toff = (dy * DIL * TWH + dx * DIL) * PSB + 32 * ks;
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        const bf16x8 bh = __builtin_bit_cast(bf16x8, bw[slot][2 * ks]);
-        const bf16x8 bl = __builtin_bit_cast(bf16x8, bw[slot][2 * ks + 1]);
-#pragma unroll
-        for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) {
-          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ldsb + abase[sg] + toff + 32 * ks);
-          const bf16x8 al = *reinterpret_cast<const bf16x8*>(ldsb + abase[sg] + toff + 64 + 32 * ks);
-          acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[sg], 0, 0, 0);
-          acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[sg], 0, 0, 0);
-          acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[sg], 0, 0, 0);
-        }
+      for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) {
+        A.h[sg] = *reinterpret_cast<const bf16x8*>(ldsb + abase[sg] + toff);
+        A.l[sg] = *reinterpret_cast<const bf16x8*>(ldsb + abase[sg] + toff + 64);
       }
     };
+    auto mma_step = [&](const AStep& A, int slot, int ks) {
+      const bf16x8 bh = __builtin_bit_cast(bf16x8, bw[slot][2 * ks]);
+      const bf16x8 bl = __builtin_bit_cast(bf16x8, bw[slot][2 * ks + 1]);
+#pragma unroll
+      for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.l[sg], bh, acc[sg], 0, 0, 0);
+#pragma unroll
+      for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h[sg], bl, acc[sg], 0, 0, 0);
+#pragma unroll
+      for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h[sg], bh, acc[sg], 0, 0, 0);
+    };
+    static_assert(NKS == 2, "the A double buffer alternates on the K step");
+    AStep A[2];
+    // tap `tap` from ring slot `slot`; afterwards the slot is refilled with tap + 3 (two taps of MFMAs ahead of its use)
+    auto mma_tap = [&](int tap, int slot) {
+      readA(A[1], tap, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_step(A[0], slot, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // k <= 3: `tap` is a compile-time constant after unrolling and the tails fold away; k >= 5 (rolled groups): clamped,
+      // unconditional (a branch around loads would make every wait count conservative)
+      if constexpr (NTAP <= 9) {
+        if (tap + 1 < NTAP) readA(A[0], tap + 1, 0);
+      } else {
+        readA(A[0], min(tap + 1, NTAP - 1), 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mma_step(A[1], slot, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (NTAP <= 9) {
+        if (tap + 3 < NTAP) fetch(tap + 3, slot);
+      } else {
+        fetch(min(tap + 3, NTAP - 1), slot);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    fetch(0, 0);
+    if constexpr (NTAP > 1) {
+      fetch(1, 1);
+      fetch(2, 2);
+    }
+    readA(A[0], 0, 0);
     if constexpr (NTAP == 1) {
-      fetch(0, 0);
       mma_tap(0, 0);
     } else {
-      fetch(0, 0);
-      fetch(1, 1);
       constexpr int NGRP = NTAP / 3;
       if constexpr (NTAP <= 9) {
 #pragma unroll
         for (int g = 0; g < NGRP; ++g) {
-          fetch(min(3 * g + 2, NTAP - 1), 2); mma_tap(3 * g, 0);
-          fetch(min(3 * g + 3, NTAP - 1), 0); mma_tap(3 * g + 1, 1);
-          fetch(min(3 * g + 4, NTAP - 1), 1); mma_tap(3 * g + 2, 2);
+          mma_tap(3 * g, 0);
+          mma_tap(3 * g + 1, 1);
+          mma_tap(3 * g + 2, 2);
         }
       } else {
 #pragma unroll 1
         for (int g = 0; g < NGRP; ++g) {
-          fetch(min(3 * g + 2, NTAP - 1), 2); mma_tap(3 * g, 0);
-          fetch(min(3 * g + 3, NTAP - 1), 0); mma_tap(3 * g + 1, 1);
-          fetch(min(3 * g + 4, NTAP - 1), 1); mma_tap(3 * g + 2, 2);
+          mma_tap(3 * g, 0);
+          mma_tap(3 * g + 1, 1);
+          mma_tap(3 * g + 2, 2);
         }
       }
       if constexpr (NTAP % 3 == 1) mma_tap(NTAP - 1, 0);
@@ -614,6 +651,214 @@ __device__ __forceinline__ void split_bf16x4(float4 t, uint2& hi, uint2& lo) {
   hi = make_uint2(ua, ub);
   lo = make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(ra, bf16x2)),
                   __builtin_bit_cast(unsigned, __builtin_convertvector(rb, bf16x2)));
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Multi-source form of the tile-per-workgroup split-bf16 kernel (forward, no hooks, no in-activation, cout == 32):
+// the sources of the virtual concat (RDB conv2 / conv3: 2 and 3 sources) are software-pipelined INSIDE one instruction
+// stream.  What made that impossible in the plain kernel is the in-order vmcnt: a B-operand fetch issued inside the MFMA
+// loop waits for every older load, so a register prefetch of the next source's halo tile stalled each B fetch behind it.
+// Here the WHOLE B operand of a source (9 taps x 4 x 16 B per lane = 144 VGPRs) is resident before its MFMA loop starts:
+// Here the B operand runs PAIF_MS_DEPTH taps ahead over the flattened (source, tap) sequence in a register ring:
+//   prologue : B[0..D) loads, A(0) loads -> split-bf16 -> LDS
+//   source s : issue A(s+1) loads (registers) ; for each tap: MFMAs from LDS + ring slot, refill the slot with tap g+D ;
+//              LDS barrier ; A(s+1) -> split-bf16 -> LDS ; LDS barrier
+// The first D taps of a source were fetched before the A(s+1) prefetch was issued, so they never wait behind it; the
+// later taps do, D taps (>= 2000 cycles of MFMA) after it was issued -- by then the tile has arrived.
+// ---------------------------------------------------------------------------------------------------
+#ifndef PAIF_MS_DEPTH
+#define PAIF_MS_DEPTH 6
+#endif
+#ifndef PAIF_MS_STAMP
+#define PAIF_MS_STAMP(i)   // tools/microbench/conv_ms_trace.hip defines it to record per-phase clock stamps
+#endif
+template <int KH, int DIL, int NSRC>
+__global__ __launch_bounds__(NTHREADS, 2) void conv_bf16x3_ms(ConvArgs a) {
+  constexpr int CIN = 32;
+  constexpr int P = DIL * (KH - 1) / 2;
+  constexpr int TWH = TW + 2 * P;
+  constexpr int THH = TH + 2 * P;
+  constexpr int PSB = 144;             // pixel record in bytes
+  constexpr int QPP = CIN / 4;
+  constexpr int NKS = CIN / 16;        // K=16 steps per tap
+  constexpr int NTAP = KH * KH;
+  constexpr int TOTAL = THH * TWH * QPP;
+  constexpr int NIT = (TOTAL + NTHREADS - 1) / NTHREADS;
+  extern __shared__ __align__(16) float lds[];
+  char* ldsb = reinterpret_cast<char*>(lds);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int hh = lane >> 5;
+  const int p = lane & 31;
+
+  const int tile_id = paif::xcd_remap(blockIdx.x, a.nblk);
+  int t = tile_id;
+  const int tx = t % a.tilesX;
+  t /= a.tilesX;
+  const int ty = t % a.tilesY;
+  const int b = t / a.tilesY;
+  const int x0 = tx * TW, y0 = ty * TH;
+
+  f32x16 acc[SEGS_PER_WAVE];
+#pragma unroll
+  for (int s = 0; s < SEGS_PER_WAVE; ++s)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+
+  int abase[SEGS_PER_WAVE];
+#pragma unroll
+  for (int s = 0; s < SEGS_PER_WAVE; ++s) abase[s] = ((wave * SEGS_PER_WAVE + s) * TWH + p) * PSB + 16 * hh;
+
+  // staging slot u of this thread: element idx = tid + u * NTHREADS of the halo tile (pixel-major, 8 channel quads per
+  // pixel).  The same 32-bit byte offsets / LDS addresses / padding bits serve every source (identical NHWC-32 shapes).
+  unsigned goff[NIT];
+  int dst[NIT];
+  unsigned padmask = 0;
+#pragma unroll
+  for (int u = 0; u < NIT; ++u) {
+    const int idx = min(tid + u * NTHREADS, TOTAL - 1);
+    const int pix = idx / QPP, q = idx - pix * QPP;
+    const int tyy = pix / TWH, txx = pix - tyy * TWH;
+    const int gy = y0 - P + tyy, gx = x0 - P + txx;
+    const int gyc = min(max(gy, 0), a.H - 1), gxc = min(max(gx, 0), a.W - 1);
+    goff[u] = (unsigned)(((b * a.H + gyc) * a.W + gxc) * CIN + q * 4) * 4u;
+    dst[u] = pix * PSB + q * 8;
+    if (gy < 0 || gy >= a.H || gx < 0 || gx >= a.W) padmask |= 1u << u;
+  }
+  constexpr bool LAST_PARTIAL = (TOTAL % NTHREADS) != 0;
+  const bool last_valid = tid + (NIT - 1) * NTHREADS < TOTAL;
+  auto issueA = [&](const float* __restrict__ src, float4 (&v)[NIT]) {
+    const char* base = reinterpret_cast<const char*>(src);
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) v[u] = *reinterpret_cast<const float4*>(base + goff[u]);   // unconditional, clamped
+  };
+  auto convertA = [&](float4 (&v)[NIT]) {
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+      float4 t4 = v[u];
+      if (padmask & (1u << u)) t4 = make_float4(0.f, 0.f, 0.f, 0.f);      // zero padding by select
+      uint2 hi, lo;
+      split_bf16x4(t4, hi, lo);
+      if (!LAST_PARTIAL || u + 1 < NIT || last_valid) {
+        *reinterpret_cast<uint2*>(ldsb + dst[u]) = hi;
+        *reinterpret_cast<uint2*>(ldsb + dst[u] + 64) = lo;
+      }
+    }
+  };
+
+  // B ring: D taps (of the flattened source x tap sequence) resident per lane
+  constexpr int D = PAIF_MS_DEPTH;
+  constexpr int NG = NSRC * NTAP;
+  uint4 bw[D][NKS * 2];
+  const uint4* wbase = reinterpret_cast<const uint4*>(a.wpk) + lane;
+  auto fetchB = [&](int g) {
+#pragma unroll
+    for (int i = 0; i < NKS * 2; ++i) bw[g % D][i] = wbase[((size_t)g * NKS * 2 + i) * 64];
+  };
+  // A operand of one K=16 step: hi and lo halves of this wave's two row segments.  The reads of step i+1 are issued
+  // before the MFMAs of step i and pinned there (sched_barrier): left to itself the scheduler sinks every ds_read to
+  // just above its first use and each MFMA group then eats the LDS latency.
+  struct AStep { bf16x8 h[SEGS_PER_WAVE], l[SEGS_PER_WAVE]; };
+  constexpr int NSTEP = NTAP * NKS;
+  auto readA = [&](AStep& A, int step) {
+    const int tap = step / NKS, ks = step - tap * NKS;
+    const int dy = tap / KH, dx = tap - dy * KH;
+    const int toff = (dy * DIL * TWH + dx * DIL) * PSB + 32 * ks;
+#pragma unroll
+    for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) {
+      A.h[sg] = *reinterpret_cast<const bf16x8*>(ldsb + abase[sg] + toff);
+      A.l[sg] = *reinterpret_cast<const bf16x8*>(ldsb + abase[sg] + toff + 64);
+    }
+  };
+  auto mma_step = [&](const AStep& A, int g, int ks) {
+    const bf16x8 bh = __builtin_bit_cast(bf16x8, bw[g % D][2 * ks]);
+    const bf16x8 bl = __builtin_bit_cast(bf16x8, bw[g % D][2 * ks + 1]);
+#pragma unroll
+    for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.l[sg], bh, acc[sg], 0, 0, 0);
+#pragma unroll
+    for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h[sg], bl, acc[sg], 0, 0, 0);
+#pragma unroll
+    for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h[sg], bh, acc[sg], 0, 0, 0);
+  };
+  // one source: 18 steps, A double-buffered in registers, B slot of a tap refilled (D taps ahead) after its last step
+  auto mma_source = [&](int s) {
+    AStep A[2];
+    readA(A[0], 0);
+#pragma unroll
+    for (int step = 0; step < NSTEP; ++step) {
+      const int tap = step / NKS, ks = step - tap * NKS;
+      const int g = s * NTAP + tap;
+      if (step + 1 < NSTEP) readA(A[(step + 1) & 1], step + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_step(A[step & 1], g, ks);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks == NKS - 1 && g + D < NG) {
+        fetchB(g + D);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+
+  // ---- prologue: the first D taps of B, then A(0) ----
+  PAIF_MS_STAMP(0);
+#pragma unroll
+  for (int g = 0; g < D; ++g) fetchB(g);
+  {
+    float4 v0[NIT];
+    issueA(a.src[0], v0);
+    convertA(v0);
+  }
+  PAIF_MS_STAMP(1);
+  lds_barrier();
+  PAIF_MS_STAMP(2);
+#pragma unroll
+  for (int s = 0; s < NSRC; ++s) {
+    float4 vn[NIT];
+    if (s + 1 < NSRC) issueA(a.src[s + 1], vn);          // the next source's halo tile: in flight during this source's MFMA loop
+    __builtin_amdgcn_sched_barrier(0);
+    mma_source(s);
+    PAIF_MS_STAMP(3 + 4 * s);
+    if (s + 1 < NSRC) {
+      lds_barrier();                                     // every wave has finished reading tile s
+      PAIF_MS_STAMP(4 + 4 * s);
+      convertA(vn);
+      PAIF_MS_STAMP(5 + 4 * s);
+      lds_barrier();
+      PAIF_MS_STAMP(6 + 4 * s);
+    }
+  }
+
+  const bool full = (y0 + TH <= a.H) && (x0 + TW <= a.W) && (a.cout == 32);  // block-uniform
+  const EpiParams ep_par = load_epi_params<false>(a, lane);
+  __syncthreads();  // every wave has finished reading the staged tile: its LDS is reused by the epilogue
+  float4 ps;
+  if (full) ps = epilogue_lds<true, false>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
+  else ps = epilogue_lds<false, false>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
+  (void)ps;
+  PAIF_MS_STAMP(15);
+}
+
+template <int KH, int DIL, int NSRC>
+int launch_bf16x3_ms(const ConvArgs& a, hipStream_t st) {
+  constexpr int P = DIL * (KH - 1) / 2;
+  constexpr size_t tile_bytes = (size_t)(TH + 2 * P) * (TW + 2 * P) * 144;
+  constexpr size_t epi_bytes = (size_t)TH * 32 * 32 * 4;
+  constexpr size_t lds_bytes = tile_bytes > epi_bytes ? tile_bytes : epi_bytes;
+  static_assert(lds_bytes <= 64 * 1024, "ms form: expected a tile under 64 KiB");
+  hipLaunchKernelGGL((conv_bf16x3_ms<KH, DIL, NSRC>), dim3(a.nblk), dim3(NTHREADS), lds_bytes, st, a);
+  PAIF_LAUNCH_CHECK("conv2d(bf16x3 ms)");
+  return 0;
+}
+
+static inline bool ms_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("PAIF_CONV_MS");   // PAIF_CONV_MS=0 keeps multi-source convs on the plain kernel (A/B runs)
+    return !(e && e[0] == '0');
+  }();
+  return on;
 }
 
 
@@ -937,6 +1182,13 @@ int launch_bf16x3(const ConvArgs& a, hipStream_t st) {
     if (takes_ws(a, KH, DIL)) return launch_bf16x3_ws<KH, DIL>(a, st);
   }
 #endif
+  if constexpr (KH == 3 && DIL == 1) {
+    if (ms_enabled() && a.cout == 32 && a.in_act == 0 && !a.pool_partial &&
+        (size_t)a.B * a.H * a.W * 128 < ((size_t)1 << 32)) {   // 32-bit byte offsets into a source
+      if (a.nsrc == 2) return launch_bf16x3_ms<3, 1, 2>(a, st);
+      if (a.nsrc == 3) return launch_bf16x3_ms<3, 1, 3>(a, st);
+    }
+  }
   return launch_bf16x3_h<KH, DIL, false>(a, st);
 }
 
