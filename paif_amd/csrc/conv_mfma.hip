@@ -136,7 +136,9 @@ __device__ __forceinline__ EpiParams load_epi_params(const ConvArgs& a, int lane
   return e;
 }
 
-template <bool FULL, bool HOOKS, int NRES, int SEGS>
+// CH: elements per lane whose residual loads are in flight together (NITER = all, the default; the persistent kernel,
+// which holds a prefetched halo tile in registers across its epilogue, uses half)
+template <bool FULL, bool HOOKS, int NRES, int SEGS, int CH = SEGS * 32 * 8 / 64>
 __device__ __forceinline__ float4 epilogue_lds_n(const ConvArgs& a, const EpiParams& ep_par, const f32x16 (&acc)[SEGS],
                                                  float* lds, int b, int y0, int x0, int wave, int lane) {
   float* ep = lds + wave * (SEGS * 32 * 32);
@@ -153,7 +155,8 @@ __device__ __forceinline__ float4 epilogue_lds_n(const ConvArgs& a, const EpiPar
   constexpr int nres = NRES;   // compile-time: the residual loads are straight-line, not one branch per load
   float4 psum = make_float4(0.f, 0.f, 0.f, 0.f);
   constexpr int NITER = SEGS * 32 * 8 / 64;
-  float4 r0[NITER], r1[NITER], r2[NITER], ea[NITER];
+  static_assert(NITER % CH == 0, "chunk must divide the element count");
+  float4 r0[CH], r1[CH], r2[CH], ea[CH];
   // element (it): pixel it*8 + lane/8 of the wave's SEGS*32 pixels, channel quad q.
   // FULL tiles: (uniform row base) + (compile-time step) + (32-bit lane offset), so the address arithmetic is a
   // handful of scalar ops per row instead of 64-bit vector multiplies per element (VALU issue shares the SIMD
@@ -174,17 +177,19 @@ __device__ __forceinline__ float4 epilogue_lds_n(const ConvArgs& a, const EpiPar
     }
   };
 #pragma unroll
-  for (int it = 0; it < NITER; ++it) {
+  for (int it0 = 0; it0 < NITER; it0 += CH) {
+#pragma unroll
+  for (int it = it0; it < it0 + CH; ++it) {
     size_t off;
     const bool ok = locate(it, off);
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    r0[it] = (nres > 0 && ok) ? *reinterpret_cast<const float4*>(a.res[0] + off) : z4;
-    r1[it] = (nres > 1 && ok) ? *reinterpret_cast<const float4*>(a.res[1] + off) : z4;
-    r2[it] = (nres > 2 && ok) ? *reinterpret_cast<const float4*>(a.res[2] + off) : z4;
-    ea[it] = (HOOKS && a.epi_dact && ok) ? *reinterpret_cast<const float4*>(a.epi_aux + off) : z4;
+    r0[it - it0] = (nres > 0 && ok) ? *reinterpret_cast<const float4*>(a.res[0] + off) : z4;
+    r1[it - it0] = (nres > 1 && ok) ? *reinterpret_cast<const float4*>(a.res[1] + off) : z4;
+    r2[it - it0] = (nres > 2 && ok) ? *reinterpret_cast<const float4*>(a.res[2] + off) : z4;
+    ea[it - it0] = (HOOKS && a.epi_dact && ok) ? *reinterpret_cast<const float4*>(a.epi_aux + off) : z4;
   }
 #pragma unroll
-  for (int it = 0; it < NITER; ++it) {
+  for (int it = it0; it < it0 + CH; ++it) {
     size_t off;
     const bool ok = locate(it, off);
     const int pix = it * 8 + (lane >> 3);
@@ -198,31 +203,32 @@ __device__ __forceinline__ float4 epilogue_lds_n(const ConvArgs& a, const EpiPar
     }
     v.x *= a.alpha; v.y *= a.alpha; v.z *= a.alpha; v.w *= a.alpha;
     if (HOOKS && a.epi_dact == 1) {
-      v.x *= ea[it].x >= 0.f ? 1.f : slope; v.y *= ea[it].y >= 0.f ? 1.f : slope;
-      v.z *= ea[it].z >= 0.f ? 1.f : slope; v.w *= ea[it].w >= 0.f ? 1.f : slope;
+      v.x *= ea[it - it0].x >= 0.f ? 1.f : slope; v.y *= ea[it - it0].y >= 0.f ? 1.f : slope;
+      v.z *= ea[it - it0].z >= 0.f ? 1.f : slope; v.w *= ea[it - it0].w >= 0.f ? 1.f : slope;
     } else if (HOOKS && a.epi_dact == 2) {
-      v.x *= ea[it].x > 0.f ? 1.f : 0.f; v.y *= ea[it].y > 0.f ? 1.f : 0.f;
-      v.z *= ea[it].z > 0.f ? 1.f : 0.f; v.w *= ea[it].w > 0.f ? 1.f : 0.f;
+      v.x *= ea[it - it0].x > 0.f ? 1.f : 0.f; v.y *= ea[it - it0].y > 0.f ? 1.f : 0.f;
+      v.z *= ea[it - it0].z > 0.f ? 1.f : 0.f; v.w *= ea[it - it0].w > 0.f ? 1.f : 0.f;
     }
-    if (nres > 0) { v.x += r0[it].x; v.y += r0[it].y; v.z += r0[it].z; v.w += r0[it].w; }
-    if (nres > 1) { v.x += r1[it].x; v.y += r1[it].y; v.z += r1[it].z; v.w += r1[it].w; }
-    if (nres > 2) { v.x += r2[it].x; v.y += r2[it].y; v.z += r2[it].z; v.w += r2[it].w; }
+    if (nres > 0) { v.x += r0[it - it0].x; v.y += r0[it - it0].y; v.z += r0[it - it0].z; v.w += r0[it - it0].w; }
+    if (nres > 1) { v.x += r1[it - it0].x; v.y += r1[it - it0].y; v.z += r1[it - it0].z; v.w += r1[it - it0].w; }
+    if (nres > 2) { v.x += r2[it - it0].x; v.y += r2[it - it0].y; v.z += r2[it - it0].z; v.w += r2[it - it0].w; }
     if (ok) {
       *reinterpret_cast<float4*>(a.out + off) = v;
       psum.x += v.x; psum.y += v.y; psum.z += v.z; psum.w += v.w;
     }
   }
+  }
   return psum;   // per-lane partial channel sums of quad q (for the ECA pool)
 }
 
-template <bool FULL, bool HOOKS, int SEGS = SEGS_PER_WAVE>
+template <bool FULL, bool HOOKS, int SEGS = SEGS_PER_WAVE, int CH = SEGS * 32 * 8 / 64>
 __device__ __forceinline__ float4 epilogue_lds(const ConvArgs& a, const EpiParams& ep_par, const f32x16 (&acc)[SEGS], float* lds,
                                                int b, int y0, int x0, int wave, int lane) {
   // residuals are packed from index 0; the count is launch-uniform
-  if (!a.res[0]) return epilogue_lds_n<FULL, HOOKS, 0, SEGS>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
-  if (!a.res[1]) return epilogue_lds_n<FULL, HOOKS, 1, SEGS>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
-  if (!a.res[2]) return epilogue_lds_n<FULL, HOOKS, 2, SEGS>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
-  return epilogue_lds_n<FULL, HOOKS, 3, SEGS>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
+  if (!a.res[0]) return epilogue_lds_n<FULL, HOOKS, 0, SEGS, CH>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
+  if (!a.res[1]) return epilogue_lds_n<FULL, HOOKS, 1, SEGS, CH>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
+  if (!a.res[2]) return epilogue_lds_n<FULL, HOOKS, 2, SEGS, CH>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
+  return epilogue_lds_n<FULL, HOOKS, 3, SEGS, CH>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
 }
 
 template <int KH, int DIL, int CIN, bool HOOKS>
@@ -639,6 +645,7 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // fp32 x4 -> (hi bf16 x4, lo bf16 x4): v_cvt_pk_bf16_f32 / shift / and / v_pk_add_f32 (10 instructions)
@@ -671,7 +678,10 @@ __device__ __forceinline__ void split_bf16x4(float4 t, uint2& hi, uint2& lo) {
 #define PAIF_MS_DEPTH 6
 #endif
 #ifndef PAIF_MS_STAMP
-#define PAIF_MS_STAMP(i)   // tools/microbench/conv_ms_trace.hip defines it to record per-phase clock stamps
+#define PAIF_MS_STAMP(i)   // tools/microbench/conv_ms_trace.hip defines these to record per-phase clock stamps
+#define PAIF_TRACE_DECL
+#define PAIF_TRACE(i)
+#define PAIF_TRACE_END
 #endif
 template <int KH, int DIL, int NSRC>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_bf16x3_ms(ConvArgs a) {
@@ -753,10 +763,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bf16x3_ms(ConvArgs a) {
   constexpr int D = PAIF_MS_DEPTH;
   constexpr int NG = NSRC * NTAP;
   uint4 bw[D][NKS * 2];
-  const uint4* wbase = reinterpret_cast<const uint4*>(a.wpk) + lane;
+  // uniform (SGPR) base per load + one 32-bit lane offset: with a per-lane 64-bit pointer the loop-invariant address
+  // of every one of the NG*4 loads is hoisted out of the tile loop into VGPR pairs (hundreds of bytes of spills)
+  const unsigned lane16 = (unsigned)lane * 16u;
   auto fetchB = [&](int g) {
 #pragma unroll
-    for (int i = 0; i < NKS * 2; ++i) bw[g % D][i] = wbase[((size_t)g * NKS * 2 + i) * 64];
+    for (int i = 0; i < NKS * 2; ++i)
+      bw[g % D][i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.wpk) + (size_t)(g * NKS * 2 + i) * 1024 + lane16);
   };
   // A operand of one K=16 step: hi and lo halves of this wave's two row segments.  The reads of step i+1 are issued
   // before the MFMAs of step i and pinned there (sched_barrier): left to itself the scheduler sinks every ds_read to
@@ -839,6 +852,286 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bf16x3_ms(ConvArgs a) {
   else ps = epilogue_lds<false, false>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
   (void)ps;
   PAIF_MS_STAMP(15);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Persistent 3x3 kernel with the B operand of a whole source resident in registers.
+//
+// What paces the tile-per-workgroup kernels is not a roof but latency they cannot cover: nothing is in flight during
+// their prologue wait, last source and epilogue, and a B fetch issued inside the MFMA loop returns in order behind
+// whatever halo-tile prefetch the same wave has outstanding (vmcnt is in-order), so a register prefetch of the next
+// halo tile stalls the MFMA loop a few taps later.  Here:
+//   * one 512-thread workgroup per CU walks its tiles; wave w owns output row w of the 8x32 tile (one 32x32 accumulator),
+//     which leaves room for the B operand of one source -- 9 taps x 4 x 16 B per lane = 144 VGPRs -- to stay resident.
+//     With one source it is loaded once per launch; with 2-3 sources tap t's registers are refilled with the next
+//     source's tap t right after its last use, i.e. a whole source (>= 3.4k MFMA cycles) before they are needed, so it
+//     does not matter that the refill returns behind the halo prefetch: the next source needs that tile anyway.
+//   * the (tile, source) sequence is one flattened software pipeline: while the MFMAs of a unit run from one LDS
+//     buffer, the halo tile of the next unit (next source, or source 0 of the next tile) is in flight into registers;
+//     it is split into bf16 hi/lo and written to the OTHER buffer after the MFMAs -- one barrier per unit, and every
+//     workgroup has a 44.5 KB halo tile outstanding all the time.
+//   * all loads are buffer loads (resource in SGPRs + 32-bit lane offset): with per-lane 64-bit pointers the tile loop's
+//     invariant addresses were hoisted into VGPR pairs and spilled.
+// Tiles are dealt so that the workgroups of one XCD walk one contiguous eighth of the tile list side by side (halo
+// rows and columns shared between neighbouring tiles hit that XCD's L2).
+// ---------------------------------------------------------------------------------------------------
+#ifndef PAIF_RES_ROWS
+#define PAIF_RES_ROWS 4
+#endif
+
+template <int KH, int DIL, int NSRC, int RT>
+__global__ __launch_bounds__(RT * 64, RT == 4 ? 2 : 1) void conv_bf16x3_res(ConvArgs a, int ntiles, int tilesY) {
+  constexpr int RES_THREADS = RT * 64;   // one wave per tile row
+  constexpr int TH = RT;                 // shadows the file-wide tile height
+  constexpr int CIN = 32;
+  constexpr int P = DIL * (KH - 1) / 2;
+  constexpr int TWH = TW + 2 * P;
+  constexpr int THH = TH + 2 * P;
+  constexpr int PSB = 144;             // pixel record in bytes
+  constexpr int QPP = CIN / 4;
+  constexpr int NKS = CIN / 16;        // K=16 steps per tap
+  constexpr int NTAP = KH * KH;
+  constexpr int TOTAL = THH * TWH * QPP;
+  constexpr int NIT = (TOTAL + RES_THREADS - 1) / RES_THREADS;
+  constexpr int TILE_BYTES = THH * TWH * PSB;
+  extern __shared__ __align__(16) float lds[];
+  char* ldsb = reinterpret_cast<char*>(lds);
+  float* epi = reinterpret_cast<float*>(ldsb + 2 * TILE_BYTES);   // RT waves x [32 px][32 ch] fp32
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int hh = lane >> 5;
+  const int p = lane & 31;
+
+  // this workgroup's tiles: XCD x (hardware deals workgroups round-robin over the 8 XCDs) owns tiles [x*tpx, (x+1)*tpx)
+  const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, nwg = gridDim.x >> 3;
+  const int tpx = (ntiles + 7) >> 3;
+  const int t_end = min(ntiles, (xcd + 1) * tpx);
+  int tile = xcd * tpx + wg;
+  if (tile >= t_end) return;           // block-uniform
+
+  f32x16 acc[1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+  const int abase = (wave * TWH + p) * PSB + 16 * hh;
+
+  float in_slope = 0.f;                // in-activation as PReLU: ReLU = slope 0
+  if (a.in_act == 1) in_slope = *a.in_prelu;
+  constexpr unsigned RSRC_W3 = 0x00020000u;
+  __amdgpu_buffer_rsrc_t rsrc[NSRC];
+#pragma unroll
+  for (int s = 0; s < NSRC; ++s)
+    rsrc[s] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src[s]), 0, a.B * a.H * a.W * (CIN * 4), RSRC_W3);
+  const __amdgpu_buffer_rsrc_t rsrc_w =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(a.wpk), 0, NSRC * NTAP * NKS * 2 * 1024, RSRC_W3);
+
+  // staging slot u of this thread: element tid + u * RES_THREADS of the halo tile (pixel-major, 8 channel quads per pixel).
+  // Slot geometry is recomputed from an opaque copy of tid where it is used (a handful of VALU instructions per tile):
+  // as tile-loop invariants the 3 x NIT values would be hoisted and held in registers through every MFMA phase.
+  constexpr bool LAST_PARTIAL = (TOTAL % RES_THREADS) != 0;
+  auto slot_pix = [&](int t, int u) { return min(t + u * RES_THREADS, TOTAL - 1) / QPP; };
+
+  unsigned goff[NIT];                  // 32-bit byte offsets into a source, clamped into the image
+  unsigned padmask = 0;                // slots that are zero padding
+  auto locate = [&](int t, int& b, int& y0, int& x0) {
+    const int tx = t % a.tilesX;
+    t /= a.tilesX;
+    const int ty = t % tilesY;
+    b = t / tilesY; y0 = ty * TH; x0 = tx * TW;
+  };
+  auto setup = [&](int b, int y0, int x0) {
+    int t = tid;
+    asm volatile("" : "+v"(t));
+    const unsigned qoff = (unsigned)(t & (QPP - 1)) * 16u;   // RES_THREADS % QPP == 0: the channel quad is the same in every slot
+    padmask = 0;
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+      const int pix = slot_pix(t, u);
+      const int tyy = pix / TWH, txx = pix - tyy * TWH;
+      const int gy = y0 - P + tyy, gx = x0 - P + txx;
+      const int gyc = min(max(gy, 0), a.H - 1), gxc = min(max(gx, 0), a.W - 1);
+      goff[u] = (unsigned)((b * a.H + gyc) * a.W + gxc) * (CIN * 4u) + qoff;
+      if (gy != gyc || gx != gxc) padmask |= 1u << u;
+    }
+    // materialise the mask here: otherwise the compiler defers it into the conversion as compares of gy/gyc/gx/gxc and
+    // keeps those 4 x NIT values alive through the MFMA phase
+    asm volatile("" : "+v"(padmask));
+  };
+  auto issueA = [&](int s, u32x4 (&v)[NIT]) {
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc[s], goff[u], 0, 0);   // unconditional, clamped
+  };
+  auto convert_n = [&](u32x4 (&v)[NIT], char* buf, auto with_act) {
+    int t = tid;
+    asm volatile("" : "+v"(t));
+    const bool last_valid = t + (NIT - 1) * RES_THREADS < TOTAL;
+    const int q8 = (t & (QPP - 1)) * 8;
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+      const int dstu = slot_pix(t, u) * PSB + q8;
+      float4 t4 = make_float4(__uint_as_float(v[u].x), __uint_as_float(v[u].y), __uint_as_float(v[u].z), __uint_as_float(v[u].w));
+      if constexpr (decltype(with_act)::value) {
+        t4.x = paif::prelu_f(t4.x, in_slope); t4.y = paif::prelu_f(t4.y, in_slope);
+        t4.z = paif::prelu_f(t4.z, in_slope); t4.w = paif::prelu_f(t4.w, in_slope);
+      }
+      if (padmask & (1u << u)) t4 = make_float4(0.f, 0.f, 0.f, 0.f);      // zero padding by select
+      uint2 hi, lo;
+      split_bf16x4(t4, hi, lo);
+      if (!LAST_PARTIAL || u + 1 < NIT || last_valid) {
+        *reinterpret_cast<uint2*>(buf + dstu) = hi;
+        *reinterpret_cast<uint2*>(buf + dstu + 64) = lo;
+      }
+    }
+  };
+  auto convertA = [&](u32x4 (&v)[NIT], char* buf) {
+    if (a.in_act) convert_n(v, buf, std::true_type{});    // launch-uniform: one branch per tile, not one per element
+    else convert_n(v, buf, std::false_type{});
+  };
+
+  u32x4 bw[NTAP][NKS * 2];             // the B operand of one source
+  const unsigned lane16 = (unsigned)lane * 16u;
+  auto fetchB = [&](int s, int tap) {
+#pragma unroll
+    for (int i = 0; i < NKS * 2; ++i)
+      bw[tap][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16, ((s * NTAP + tap) * NKS * 2 + i) * 1024, 0);
+  };
+  struct AStep { bf16x8 h, l; };
+  constexpr int NSTEP = NTAP * NKS;
+  auto readA = [&](AStep& A, const char* buf, int step) {
+    const int tap = step / NKS, ks = step - tap * NKS;
+    const int dy = tap / KH, dx = tap - dy * KH;
+    const int toff = (dy * DIL * TWH + dx * DIL) * PSB + 32 * ks;
+    A.h = *reinterpret_cast<const bf16x8*>(buf + abase + toff);
+    A.l = *reinterpret_cast<const bf16x8*>(buf + abase + toff + 64);
+  };
+  // one source from `buf`: the A operand runs two K steps (>= 192 MFMA cycles) ahead in a 3-slot register ring, issue
+  // order pinned (see conv_mfma_bf16x3): one 3-MFMA dependent chain per wave leaves only that much time per step
+  auto mma_source = [&](int s, const char* buf) {
+    AStep A[3];
+    readA(A[0], buf, 0);
+    readA(A[1], buf, 1);
+#pragma unroll
+    for (int step = 0; step < NSTEP; ++step) {
+      const int tap = step / NKS, ks = step - tap * NKS;
+      if (step + 2 < NSTEP) readA(A[(step + 2) % 3], buf, step + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      const bf16x8 bh = __builtin_bit_cast(bf16x8, bw[tap][2 * ks]);
+      const bf16x8 bl = __builtin_bit_cast(bf16x8, bw[tap][2 * ks + 1]);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[step % 3].l, bh, acc[0], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[step % 3].h, bl, acc[0], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[step % 3].h, bh, acc[0], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (NSRC > 1 && ks == NKS - 1) fetchB((s + 1) % NSRC, tap);    // this tap's registers: next source, same tap
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  int b, y0, x0;
+  locate(tile, b, y0, x0);
+  setup(b, y0, x0);
+#pragma unroll
+  for (int tap = 0; tap < NTAP; ++tap) fetchB(0, tap);
+  {
+    u32x4 v0[NIT];
+    issueA(0, v0);
+    convertA(v0, ldsb);
+  }
+  // the epilogue constants of a lane (scale / shift quad, slope) wait in LDS, not in 9 registers
+  float* epp = epi + RT * 1024 + RT * 32;
+  if (tid < 64) {
+    const EpiParams e0 = load_epi_params<false>(a, lane);
+    *reinterpret_cast<float4*>(epp + lane * 4) = e0.sc;
+    *reinterpret_cast<float4*>(epp + 256 + lane * 4) = e0.sh;
+    if (lane == 0) epp[512] = e0.slope;
+  }
+  lds_barrier();
+  PAIF_TRACE_DECL
+  int par = 0;                         // LDS buffer of the current unit
+  for (;;) {
+    const int tile_next = tile + nwg;
+    const bool more = tile_next < t_end;
+#pragma unroll
+    for (int s = 0; s < NSRC; ++s) {
+      u32x4 vn[NIT];
+      int bn = b, yn = y0, xn = x0;
+      if (s == NSRC - 1) {             // the next unit is source 0 of the next tile (the last tile re-fetches itself: unused)
+        locate(more ? tile_next : tile, bn, yn, xn);
+        setup(bn, yn, xn);
+      }
+      issueA((s + 1) % NSRC, vn);
+      __builtin_amdgcn_sched_barrier(0);
+      PAIF_TRACE(0);
+      mma_source(s, ldsb + par * TILE_BYTES);
+      PAIF_TRACE(1);
+      if (s == NSRC - 1) {
+        const bool full = (y0 + TH <= a.H) && (x0 + TW <= a.W);   // block-uniform
+        // opaque copies: handed the plain ids, the epilogue's loop-invariant per-lane address arithmetic is hoisted
+        // in front of the tile loop and lives (spilled) through every MFMA phase
+        int lane_e = lane, wave_e = wave;
+        asm volatile("" : "+v"(lane_e), "+v"(wave_e));
+        EpiParams ep_par;
+        ep_par.sc = *reinterpret_cast<const float4*>(epp + lane_e * 4);
+        ep_par.sh = *reinterpret_cast<const float4*>(epp + 256 + lane_e * 4);
+        ep_par.slope = epp[512];
+        float4 ps;                     // private per-wave LDS region: no barrier between the MFMAs and the epilogue
+        if (full) ps = epilogue_lds<true, false, 1, 2>(a, ep_par, acc, epi, b, y0, x0, wave_e, lane_e);
+        else ps = epilogue_lds<false, false, 1, 2>(a, ep_par, acc, epi, b, y0, x0, wave_e, lane_e);
+        if (a.pool_partial) {          // launch-uniform; fixed-order reduction -> deterministic
+#pragma unroll
+          for (int m = 8; m < 64; m <<= 1) {
+            ps.x += __shfl_xor(ps.x, m); ps.y += __shfl_xor(ps.y, m); ps.z += __shfl_xor(ps.z, m); ps.w += __shfl_xor(ps.w, m);
+          }
+          if (lane < 8) *reinterpret_cast<float4*>(epi + RT * 1024 + wave * 32 + lane * 4) = ps;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+        PAIF_TRACE(2);
+      }
+      if (!(s == NSRC - 1 && !more)) convertA(vn, ldsb + (par ^ 1) * TILE_BYTES);   // block-uniform
+      PAIF_TRACE(3);
+      lds_barrier();
+      PAIF_TRACE(4);
+      if (s == NSRC - 1) {
+        if (a.pool_partial && tid < 32) {
+          float t = 0.f;
+#pragma unroll
+          for (int w = 0; w < RT; ++w) t += epi[RT * 1024 + w * 32 + tid];
+          a.pool_partial[(size_t)tile * 32 + tid] = t;
+        }
+        b = bn; y0 = yn; x0 = xn;
+      }
+      par ^= 1;
+    }
+    if (!more) {
+      PAIF_TRACE_END
+      return;
+    }
+    tile = tile_next;
+  }
+}
+
+template <int KH, int DIL, int NSRC>
+int launch_bf16x3_res(const ConvArgs& a, hipStream_t st) {
+  constexpr int RT = PAIF_RES_ROWS;
+  constexpr int P = DIL * (KH - 1) / 2;
+  constexpr size_t lds_bytes = 2 * (size_t)(RT + 2 * P) * (TW + 2 * P) * 144 + RT * 32 * 32 * 4 + RT * 32 * 4 + 520 * 4;
+  static_assert(lds_bytes * (RT == 4 ? 2 : 1) <= 160 * 1024, "two halo-tile buffers + the epilogue regions do not fit LDS");
+  static bool raised = false;   // once per instantiation (one device per process)
+  if (!raised) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_res<KH, DIL, NSRC, RT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) {
+      paif::set_error("conv2d(bf16x3 resident): cannot raise dynamic LDS to %zu: %s", lds_bytes, hipGetErrorString(e));
+      return (int)e;
+    }
+    raised = true;
+  }
+  const int tilesY = (a.H + RT - 1) / RT;
+  hipLaunchKernelGGL((conv_bf16x3_res<KH, DIL, NSRC, RT>), dim3(RT == 4 ? 512 : 256), dim3(RT * 64), lds_bytes, st, a,
+                     a.B * tilesY * a.tilesX, tilesY);
+  PAIF_LAUNCH_CHECK("conv2d(bf16x3 resident)");
+  return 0;
 }
 
 template <int KH, int DIL, int NSRC>
@@ -1156,6 +1449,16 @@ static inline bool ws_eligible(const ConvArgs& a) {
          (size_t)a.H * a.W * 128 < ((size_t)1 << 32);
 }
 
+// persistent 3x3: needs several tiles per workgroup to amortise the pipeline fill (512 workgroups)
+static inline bool msp_eligible(const ConvArgs& a) {
+  static const int mode = [] {
+    const char* e = getenv("PAIF_CONV_MSP");  // PAIF_CONV_MSP=0: tile-per-workgroup kernels everywhere; =2: every source count (A/B runs)
+    return e ? atoi(e) : 1;
+  }();
+  return mode && (mode == 2 || a.nsrc == 1) && a.nblk >= 2048 && a.cout == 32 && a.in_act <= 2 && (PAIF_RES_ROWS == 8 || !a.pool_partial) &&
+         (size_t)a.B * a.H * a.W * 128 < ((size_t)1 << 32);
+}
+
 static inline bool needs_hooks(const ConvArgs& a) { return a.in_act >= 3 || a.aux_out || a.epi_dact; }
 
 // Persistent wave-specialised form (needs several tiles per CU to amortise its pipeline fill).  Measured per
@@ -1183,6 +1486,11 @@ int launch_bf16x3(const ConvArgs& a, hipStream_t st) {
   }
 #endif
   if constexpr (KH == 3 && DIL == 1) {
+    if (msp_eligible(a)) {
+      if (a.nsrc == 1) return launch_bf16x3_res<3, 1, 1>(a, st);
+      if (a.nsrc == 2) return launch_bf16x3_res<3, 1, 2>(a, st);
+      return launch_bf16x3_res<3, 1, 3>(a, st);
+    }
     if (ms_enabled() && a.cout == 32 && a.in_act == 0 && !a.pool_partial &&
         (size_t)a.B * a.H * a.W * 128 < ((size_t)1 << 32)) {   // 32-bit byte offsets into a source
       if (a.nsrc == 2) return launch_bf16x3_ms<3, 1, 2>(a, st);

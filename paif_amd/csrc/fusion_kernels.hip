@@ -67,10 +67,14 @@ __global__ void ycrcb2rgb_kernel(const float* __restrict__ ycc, float* __restric
 // stem: 3x3 conv 1->32 (no bias) + PReLU, fused with the guide max_c - min_c
 // thread = (pixel, channel quad); 8 lanes of a pixel read the same 9 taps (broadcast from L1)
 // ---------------------------------------------------------------------------------------------
+// One workgroup = one 128-pixel piece of an image row (4 steps of 32 pixels x 8 channel quads): the row / image
+// coordinates are block-uniform scalars, so the per-pixel index arithmetic is a column clamp -- the flat-pixel form
+// spent most of its instructions on 64-bit div/mod (154 us for a 315 MB write-only stream).
+constexpr int STEM_CHUNK = 128;
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                    const float* __restrict__ prelu, float* __restrict__ feat,
                                                    float* __restrict__ guide, int B, int H, int W,
-                                                   size_t img_bstride) {
+                                                   size_t img_bstride, int chunks) {
   const int q = threadIdx.x & 7;
   float wr[4][9];
 #pragma unroll
@@ -78,27 +82,30 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
 #pragma unroll
     for (int k = 0; k < 9; ++k) wr[c][k] = w[(4 * q + c) * 9 + k];
   const float slope = *prelu;
-  const size_t npix = (size_t)B * H * W;
-  for (size_t pix = (size_t)blockIdx.x * 32 + (threadIdx.x >> 3); pix < npix; pix += (size_t)gridDim.x * 32) {
-    const int x = (int)(pix % W);
-    const size_t rowid = pix / W;
-    const int y = (int)(rowid % H);
-    const float* base = img + ((rowid - y) / H) * img_bstride;  // image start (batch stride in floats)
-    // all 9 taps in flight: unconditional loads on clamped coordinates, padding by select (a load under a data-dependent
-    // branch is waited for at the join: the nine loads were serialised)
+  const int chunk = blockIdx.x % chunks;
+  const int row = blockIdx.x / chunks;       // b * H + y
+  const int y = row % H, b = row / H;
+  const float* base = img + (size_t)b * img_bstride;
+  // the three source rows (clamped: loads are unconditional, padding by select)
+  const float* r0 = base + (size_t)max(y - 1, 0) * W;
+  const float* r1 = base + (size_t)y * W;
+  const float* r2 = base + (size_t)min(y + 1, H - 1) * W;
+  const bool top = y == 0, bot = y == H - 1;
+  float* frow = feat + (size_t)row * W * 32;
+  float* grow = guide ? guide + (size_t)row * W : nullptr;
+#pragma unroll
+  for (int it = 0; it < STEM_CHUNK / 32; ++it) {
+    const int x = chunk * STEM_CHUNK + it * 32 + (threadIdx.x >> 3);
+    const int xc = min(x, W - 1), xl = max(xc - 1, 0), xr = min(xc + 1, W - 1);
     float v[9];
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx)
-        v[dy * 3 + dx] = base[(size_t)min(max(y + dy - 1, 0), H - 1) * W + min(max(x + dx - 1, 0), W - 1)];
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int yy = y + dy - 1, xx = x + dx - 1;
-        if (yy < 0 || yy >= H || xx < 0 || xx >= W) v[dy * 3 + dx] = 0.f;
-      }
+    v[0] = r0[xl]; v[1] = r0[xc]; v[2] = r0[xr];
+    v[3] = r1[xl]; v[4] = r1[xc]; v[5] = r1[xr];
+    v[6] = r2[xl]; v[7] = r2[xc]; v[8] = r2[xr];
+    const bool lft = xc == 0, rgt = xc == W - 1;
+    if (top) v[0] = v[1] = v[2] = 0.f;
+    if (bot) v[6] = v[7] = v[8] = 0.f;
+    if (lft) v[0] = v[3] = v[6] = 0.f;
+    if (rgt) v[2] = v[5] = v[8] = 0.f;
     float o[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -107,8 +114,8 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
       for (int k = 0; k < 9; ++k) s = fmaf(v[k], wr[c][k], s);
       o[c] = paif::prelu_f(s, slope);
     }
-    *reinterpret_cast<float4*>(feat + pix * 32 + q * 4) = make_float4(o[0], o[1], o[2], o[3]);
-    if (guide) {
+    if (x < W) *reinterpret_cast<float4*>(frow + (size_t)x * 32 + q * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    if (grow) {
       float mx = fmaxf(fmaxf(o[0], o[1]), fmaxf(o[2], o[3]));
       float mn = fminf(fminf(o[0], o[1]), fminf(o[2], o[3]));
 #pragma unroll
@@ -116,7 +123,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
         mx = fmaxf(mx, __shfl_xor(mx, m));
         mn = fminf(mn, __shfl_xor(mn, m));
       }
-      if (q == 0) guide[pix] = mx - mn;
+      if (q == 0 && x < W) grow[x] = mx - mn;
     }
   }
 }
@@ -518,8 +525,10 @@ int paif_stem_fwd(const float* img, size_t img_bstride, const float* w, const fl
                   int B, int H, int W, paif_stream_t stream) {
   PAIF_REQUIRE(img && w && prelu && feat && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "stem: bad arguments");
   PAIF_REQUIRE(img_bstride >= (size_t)H * W, PAIF_EINVAL, "stem: batch stride %zu < H*W", img_bstride);
-  hipLaunchKernelGGL(stem_kernel, dim3(grid_for((size_t)B * H * W, 32)), dim3(256), 0, paif::as_stream(stream), img, w,
-                     prelu, feat, guide, B, H, W, img_bstride);
+  const int chunks = (W + STEM_CHUNK - 1) / STEM_CHUNK;
+  PAIF_REQUIRE((size_t)B * H * chunks < ((size_t)1 << 31), PAIF_EINVAL, "stem: %dx%dx%d is too large for one launch", B, H, W);
+  hipLaunchKernelGGL(stem_kernel, dim3((unsigned)(B * H * chunks)), dim3(256), 0, paif::as_stream(stream), img, w,
+                     prelu, feat, guide, B, H, W, img_bstride, chunks);
   PAIF_LAUNCH_CHECK("stem");
   return 0;
 }

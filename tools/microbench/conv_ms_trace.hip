@@ -21,6 +21,20 @@ __device__ unsigned g_where[MAXWG];   // XCC / SE / CU id of the workgroup
     }                                                                                            \
   } while (0)
 
+// persistent kernels: per-phase cycle totals over all tiles of a workgroup (scalar registers)
+#define PAIF_TRACE_DECL unsigned long long tr_last = __builtin_readcyclecounter(), tr_acc[5] = {0, 0, 0, 0, 0}; const unsigned long long tr_w0 = wall_clock64();
+#define PAIF_TRACE(i)                                                    \
+  do {                                                                   \
+    const unsigned long long tr_now = __builtin_readcyclecounter();      \
+    tr_acc[(i)] += tr_now - tr_last;                                     \
+    tr_last = tr_now;                                                    \
+  } while (0)
+#define PAIF_TRACE_END                                                                           \
+  if (lane == 0 && blockIdx.x < MAXWG) {                                                         \
+    for (int tr_i = 0; tr_i < 5; ++tr_i) g_stamps[blockIdx.x][wave & 3][tr_i] = tr_acc[tr_i];    \
+    g_stamps[blockIdx.x][wave & 3][5] = wall_clock64() - tr_w0;                                  \
+  }
+
 #include "../../paif_amd/csrc/conv_mfma.hip"
 
 namespace paif {
@@ -61,6 +75,23 @@ int main(int argc, char** argv) {
   hipEventRecord(e1); hipDeviceSynchronize();
   float ms; hipEventElapsedTime(&ms, e0, e1);
   printf("nsrc %d nres %d: %.1f us per launch\n", nsrc, nres, ms * 100.f);
+  if (getenv("PAIF_TRACE_RES")) {
+    std::vector<unsigned long long> st((size_t)MAXWG * 4 * NSTAMP);
+    hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8);
+    const char* nm[5] = {"issue next halo tile", "MFMA phase", "epilogue", "convert -> LDS", "barrier"};
+    for (int wv = 0; wv < 4; wv += 3) {
+      double tot = 0, t[5] = {}, wall = 0;
+      for (int wg = 0; wg < 256; ++wg) {
+        for (int i = 0; i < 5; ++i) t[i] += (double)st[((size_t)wg * 4 + wv) * NSTAMP + i] / 256;
+        wall += (double)st[((size_t)wg * 4 + wv) * NSTAMP + 5] / 256;
+      }
+      for (int i = 0; i < 5; ++i) tot += t[i];
+      printf("wave %d: cycles per workgroup (mean over 256), %% of total\n", wv);
+      for (int i = 0; i < 5; ++i) printf("  %-22s %10.0f  %5.1f %%\n", nm[i], t[i], 100 * t[i] / tot);
+      printf("  total %.0f cycles in %.1f us  => %.0f MHz\n", tot, wall / 100, tot / (wall / 100));
+    }
+    return 0;
+  }
   const int nwg = B * (H / 8) * (W / 32);
   std::vector<unsigned long long> st((size_t)MAXWG * 4 * NSTAMP);
   hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8);
