@@ -213,7 +213,7 @@ __device__ __forceinline__ float4 epilogue_lds_n(const ConvArgs& a, const EpiPar
     if (nres > 1) { v.x += r1[it - it0].x; v.y += r1[it - it0].y; v.z += r1[it - it0].z; v.w += r1[it - it0].w; }
     if (nres > 2) { v.x += r2[it - it0].x; v.y += r2[it - it0].y; v.z += r2[it - it0].z; v.w += r2[it - it0].w; }
     if (ok) {
-      *reinterpret_cast<float4*>(a.out + off) = v;
+      paif::store_nt(a.out + off, v);
       psum.x += v.x; psum.y += v.y; psum.z += v.z; psum.w += v.w;
     }
   }
@@ -1399,7 +1399,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_bf16x3_ws(ConvArgs a, int 
 #pragma unroll
               for (int k = 0; k < NR; ++k) { v.x += r[k][j].x; v.y += r[k][j].y; v.z += r[k][j].z; v.w += r[k][j].w; }
               if (colok && y0 + j < a.H)
-                *reinterpret_cast<float4*>(a.out + base + (size_t)j * a.W * 32 + lane_off) = v;
+                paif::store_nt(a.out + base + (size_t)j * a.W * 32 + lane_off, v);
             }
             if (NR > 0) request(i2 + 1);
           }

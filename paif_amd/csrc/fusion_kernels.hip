@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
       for (int k = 0; k < 9; ++k) s = fmaf(v[k], wr[c][k], s);
       o[c] = paif::prelu_f(s, slope);
     }
-    if (x < W) *reinterpret_cast<float4*>(frow + (size_t)x * 32 + q * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    if (x < W) paif::store_nt(frow + (size_t)x * 32 + q * 4, make_float4(o[0], o[1], o[2], o[3]));
     if (grow) {
       float mx = fmaxf(fmaxf(o[0], o[1]), fmaxf(o[2], o[3]));
       float mn = fminf(fminf(o[0], o[1]), fminf(o[2], o[3]));
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
         }
       }
     }
-    *reinterpret_cast<float4*>(out + pix * 32 + q * 4) = acc;
+    paif::store_nt(out + pix * 32 + q * 4, acc);
   }
 }
 
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void spa_blend_kernel(const float* __restrict_
     o.y = __fadd_rn(__fmul_rn(sc, a.y), __fmul_rn(om, b.y));
     o.z = __fadd_rn(__fmul_rn(sc, a.z), __fmul_rn(om, b.z));
     o.w = __fadd_rn(__fmul_rn(sc, a.w), __fmul_rn(om, b.w));
-    *reinterpret_cast<float4*>(agg + pix * 32 + q * 4) = o;
+    paif::store_nt(agg + pix * 32 + q * 4, o);
     if (scale_out && q == 0) scale_out[pix] = sc;
   }
 }
@@ -311,9 +311,9 @@ __global__ __launch_bounds__(256) void eca_apply_kernel(const float* __restrict_
     float4 u4;
     u4.x = __fadd_rn(__fmul_rn(ov.x, sv.x), rv.x); u4.y = __fadd_rn(__fmul_rn(ov.y, sv.y), rv.y);
     u4.z = __fadd_rn(__fmul_rn(ov.z, sv.z), rv.z); u4.w = __fadd_rn(__fmul_rn(ov.w, sv.w), rv.w);
-    if (u_out) *reinterpret_cast<float4*>(u_out + pix * 32 + q * 4) = u4;
-    *reinterpret_cast<float4*>(out + pix * 32 + q * 4) =
-        make_float4(paif::prelu_f(u4.x, slope), paif::prelu_f(u4.y, slope), paif::prelu_f(u4.z, slope), paif::prelu_f(u4.w, slope));
+    if (u_out) paif::store_nt(u_out + pix * 32 + q * 4, u4);
+    paif::store_nt(out + pix * 32 + q * 4,
+                   make_float4(paif::prelu_f(u4.x, slope), paif::prelu_f(u4.y, slope), paif::prelu_f(u4.z, slope), paif::prelu_f(u4.w, slope)));
   }
 }
 

@@ -447,7 +447,7 @@ __global__ __launch_bounds__(FC * NL) void gf_fused_kernel(const float* __restri
         const float* pb = reinterpret_cast<const float*>(&bb);
 #pragma unroll
         for (int i = 0; i < VW; ++i) po[i] = fmaf(pa[i] * rn, g0, pb[i] * rn);
-        *reinterpret_cast<V*>(out + px * 32) = o;
+        paif::store_nt(out + px * 32, o);
       }
     }
   }

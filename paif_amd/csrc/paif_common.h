@@ -39,6 +39,21 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 }
 
 __device__ __forceinline__ float prelu_f(float v, float a) { return v >= 0.f ? v : a * v; }
+
+// Streaming 16-byte store (global_store_dwordx4 ... nt): the activation maps of the bench shapes (315 MB each) are far
+// larger than L2 + MALL, so keeping freshly written lines cached only evicts the halo rows the neighbouring tiles are
+// about to re-read.  Measured +1 % on the fusion forward with the conv outputs alone.
+__device__ __forceinline__ void store_nt(float* p, float4 v) {
+  typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+  const f32x4_nt vv = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(vv, reinterpret_cast<f32x4_nt*>(p));
+}
+__device__ __forceinline__ void store_nt(float* p, float2 v) {
+  typedef float f32x2_nt __attribute__((ext_vector_type(2)));
+  const f32x2_nt vv = {v.x, v.y};
+  __builtin_nontemporal_store(vv, reinterpret_cast<f32x2_nt*>(p));
+}
+__device__ __forceinline__ void store_nt(float* p, float v) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + __expf(-v)); }
 
 }  // namespace paif
