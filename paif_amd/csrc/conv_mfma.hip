@@ -183,9 +183,9 @@ __device__ __forceinline__ float4 epilogue_lds_n(const ConvArgs& a, const EpiPar
     size_t off;
     const bool ok = locate(it, off);
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    r0[it - it0] = (nres > 0 && ok) ? *reinterpret_cast<const float4*>(a.res[0] + off) : z4;
-    r1[it - it0] = (nres > 1 && ok) ? *reinterpret_cast<const float4*>(a.res[1] + off) : z4;
-    r2[it - it0] = (nres > 2 && ok) ? *reinterpret_cast<const float4*>(a.res[2] + off) : z4;
+    r0[it - it0] = (nres > 0 && ok) ? paif::load_nt(a.res[0] + off) : z4;
+    r1[it - it0] = (nres > 1 && ok) ? paif::load_nt(a.res[1] + off) : z4;
+    r2[it - it0] = (nres > 2 && ok) ? paif::load_nt(a.res[2] + off) : z4;
     ea[it - it0] = (HOOKS && a.epi_dact && ok) ? *reinterpret_cast<const float4*>(a.epi_aux + off) : z4;
   }
 #pragma unroll
@@ -1225,7 +1225,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_bf16x3_ws(ConvArgs a, int 
         const int gy = y0p + tyy[u], gx = x0p + txx[u];
         const int gyc = min(max(gy, 0), a.H - 1), gxc = min(max(gx, 0), a.W - 1);
         const unsigned off = ((unsigned)(gyc * a.W + gxc) << 7) + q16;   // < 4 GiB per image: checked at launch
-        v[u] = *reinterpret_cast<const float4*>(base + off);
+        v[u] = KH == 1 ? paif::load_nt(reinterpret_cast<const float*>(base + off)) : *reinterpret_cast<const float4*>(base + off);
         m |= (gy == gyc && gx == gxc) ? (1u << u) : 0u;
       }
       mask = m;
@@ -1369,7 +1369,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_bf16x3_ws(ConvArgs a, int 
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const int yy = min(y0 + j, a.H - 1) - y0;
-            r[k][j] = *reinterpret_cast<const float4*>(a.res[k] + base + (size_t)yy * a.W * 32 + lo);
+            r[k][j] = paif::load_nt(a.res[k] + base + (size_t)yy * a.W * 32 + lo);
           }
       };
       if (cnt > 0) request(0);

@@ -193,8 +193,8 @@ __global__ __launch_bounds__(256) void channel_pool2_kernel(const float* __restr
                                                             float* __restrict__ comp, size_t npix) {
   const int q = threadIdx.x & 7;
   for (size_t pix = (size_t)blockIdx.x * 32 + (threadIdx.x >> 3); pix < npix; pix += (size_t)gridDim.x * 32) {
-    const float4 a = *reinterpret_cast<const float4*>(ir + pix * 32 + q * 4);
-    const float4 b = *reinterpret_cast<const float4*>(vis + pix * 32 + q * 4);
+    const float4 a = paif::load_nt(ir + pix * 32 + q * 4);
+    const float4 b = paif::load_nt(vis + pix * 32 + q * 4);
     float mxa = fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), sa = (a.x + a.y) + (a.z + a.w);
     float mxb = fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)), sb = (b.x + b.y) + (b.z + b.w);
 #pragma unroll
@@ -250,8 +250,8 @@ __global__ __launch_bounds__(256) void spa_blend_kernel(const float* __restrict_
 #pragma unroll
     for (int m = 1; m < 8; m <<= 1) s += __shfl_xor(s, m);
     const float sc = 1.0f / (1.0f + expf(-s));
-    const float4 a = *reinterpret_cast<const float4*>(ir + pix * 32 + q * 4);
-    const float4 b = *reinterpret_cast<const float4*>(vis + pix * 32 + q * 4);
+    const float4 a = paif::load_nt(ir + pix * 32 + q * 4);
+    const float4 b = paif::load_nt(vis + pix * 32 + q * 4);
     const float om = 1.0f - sc;
     float4 o;
     o.x = __fadd_rn(__fmul_rn(sc, a.x), __fmul_rn(om, b.x));
@@ -306,8 +306,8 @@ __global__ __launch_bounds__(256) void eca_apply_kernel(const float* __restrict_
   for (size_t pix = (size_t)blockIdx.x * 32 + (threadIdx.x >> 3); pix < npix; pix += (size_t)gridDim.x * 32) {
     const size_t b = pix / pix_per_img;
     const float4 sv = *reinterpret_cast<const float4*>(s + b * 32 + q * 4);
-    const float4 ov = *reinterpret_cast<const float4*>(o + pix * 32 + q * 4);
-    const float4 rv = *reinterpret_cast<const float4*>(r + pix * 32 + q * 4);
+    const float4 ov = paif::load_nt(o + pix * 32 + q * 4);
+    const float4 rv = paif::load_nt(r + pix * 32 + q * 4);
     float4 u4;
     u4.x = __fadd_rn(__fmul_rn(ov.x, sv.x), rv.x); u4.y = __fadd_rn(__fmul_rn(ov.y, sv.y), rv.y);
     u4.z = __fadd_rn(__fmul_rn(ov.z, sv.z), rv.z); u4.w = __fadd_rn(__fmul_rn(ov.w, sv.w), rv.w);

@@ -48,6 +48,12 @@ __device__ __forceinline__ void store_nt(float* p, float4 v) {
   const f32x4_nt vv = {v.x, v.y, v.z, v.w};
   __builtin_nontemporal_store(vv, reinterpret_cast<f32x4_nt*>(p));
 }
+// Streaming 16-byte load for maps that are read exactly once per kernel (residuals, pointwise inputs)
+__device__ __forceinline__ float4 load_nt(const float* p) {
+  typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+  const f32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ void store_nt(float* p, float2 v) {
   typedef float f32x2_nt __attribute__((ext_vector_type(2)));
   const f32x2_nt vv = {v.x, v.y};
