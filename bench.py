@@ -11,13 +11,17 @@ the C ABI.  One process per GPU; replicas only (no data-path collective: the pat
         bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0 (contract in the task statement): value = whole-job pairs/s, plus
-  roofline     -- dominant kernel (the 3x3 dense conv: conv_mfma_bf16x3<3,1>, or conv_mfma_f32<3,1,32> with --conv-precision f32),
-                  HIP-event timed on its launch stream inside the timed region
+  roofline     -- dominant kernel = the dense 3x3 dilation-1 forward conv (42 % of the step).  Since round 2 it is three
+                  instantiations picked by source count (conv_bf16x3_res<3, 1, 1, 4>, conv_bf16x3_ms<3, 1, 2|3>, and
+                  conv_mfma_bf16x3<3, 1, false> for the pooled ones): `roofline` aggregates them exactly as round 1's single kernel was
+                  aggregated and `roofline.kernels` lists each one under the name rocprofv3 gives it; HIP-event timed on the launch
+                  stream inside the timed region.  roofline_other: the next kernels by time (guided filter, 7x7, 1x1 ...)
   cpu_baseline -- the CPU oracle (torch fp32 port of the reference) on the host cores, bounded sample, rank 0, N=1 only
 """
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -79,7 +83,7 @@ def main():
 
     ops.set_conv_precision(args.conv_precision)
     ops.set_gemm_precision(args.gemm_precision)
-    DOMINANT = "conv_mfma_%s<3,1,32>" % args.conv_precision   # the 12 dense 3x3 convs of a step
+    DOMINANT = "dense conv 3x3 dil 1, forward (%s)" % args.conv_precision   # family tag of the 12 dense 3x3 convs of a step
     bpg = 16 if args.workload == "fusion_seg" else B_PER_GPU
     if args.workload == "fusion":
         net = Network_Fusion_Searched(32, None, FUSION_AT).eval()
@@ -178,7 +182,21 @@ def main():
 
     if rank == 0:
         pairs = bpg * world * args.steps
-        summ = timer.summary()
+        per_kernel = timer.summary()
+
+        def family(tag):
+            # the dense 3x3 dilation-1 forward convs are one kernel family (instantiations by source count / pool)
+            m = re.match(r"conv_(mfma_bf16x3|bf16x3_ms|bf16x3_res|mfma_f32)<3, 1\b(.*)>$", tag)
+            if m and "true" not in m.group(2) and not (m.group(1) == "mfma_f32" and ", 16," in tag):
+                return DOMINANT
+            return tag
+
+        summ, members = {}, {}
+        for tag, (n_, ms_, fl_, by_) in per_kernel.items():
+            f = family(tag)
+            a_ = summ.get(f, (0, 0.0, 0, 0))
+            summ[f] = (a_[0] + n_, a_[1] + ms_, a_[2] + fl_, a_[3] + by_)
+            members.setdefault(f, []).append(tag)
         if args.workload != "fusion":       # the segmentation workloads: the kernel with the largest share of the timed region
             DOM = max(summ, key=lambda k: summ[k][1])
         else:
@@ -187,11 +205,14 @@ def main():
         def roof_block(tag):
             n_, ms_, fl_, by_ = summ[tag]
             tf, gb = fl_ / (ms_ * 1e-3) / 1e12, by_ / (ms_ * 1e-3) / 1e9
-            if tag.startswith("conv_") and "bf16x3" in tag or tag.startswith("conv_bf16x3_ws"):
+            if (tag.startswith("conv_") or tag.startswith("dense conv")) and "bf16x3" in tag:
                 # split-bf16 convs: 3 bf16 MFMA passes -> effective matrix peak 2500/3 = 833 TF algorithmic; at 72-108 FLOP/B
                 # (fp32 storage) the HBM roof binds (833e12 / 8e12 = 104 FLOP/B)
                 blk = {"bound": "hbm", "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS, "algorithmic_tflops": tf}
-            elif tag.startswith("conv_"):
+            elif tag.startswith("gf_"):
+                blk = {"bound": "hbm", "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS, "algorithmic_tflops": tf,
+                       "note": "VALU-issue bound (two 9x9 box-filter stages per pixel-channel), see DESIGN.md"}
+            elif tag.startswith("conv_") or tag.startswith("dense conv"):
                 blk = {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS}
             else:
                 # GEMMs / attention, aggregated over all shapes of the step: report against the roof that binds the aggregate
@@ -203,6 +224,12 @@ def main():
                     blk = {"bound": "hbm", "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": f_h, "algorithmic_tflops": tf}
             blk.update({"kernel": tag, "launches": n_, "avg_launch_ms": ms_ / n_, "share_of_step": ms_ / (dt * 1e3),
                         "algorithmic_gflop_per_launch": fl_ / n_ / 1e9, "algorithmic_mb_per_launch": by_ / n_ / 1e6})
+            if len(members.get(tag, [])) > 1 or members.get(tag, [tag])[0] != tag:
+                blk["kernels"] = [{"kernel": k, "launches": per_kernel[k][0], "avg_launch_ms": per_kernel[k][1] / per_kernel[k][0],
+                                   "achieved": per_kernel[k][3] / (per_kernel[k][1] * 1e-3) / 1e9, "unit": "GB/s",
+                                   "frac": per_kernel[k][3] / (per_kernel[k][1] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "algorithmic_mb_per_launch": per_kernel[k][3] / per_kernel[k][0] / 1e6}
+                                  for k in sorted(members[tag], key=lambda k: -per_kernel[k][1])]
             return blk
 
         roof = roof_block(DOM)
@@ -212,17 +239,21 @@ def main():
         # and ONLY while that summary still describes the kernel being benchmarked (hash of its source) -- otherwise null + why
         traffic, traffic_note = None, None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(DOM)
-            if not pm:
-                traffic_note = "no PMC record for %s" % DOM
+            rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            mem = members.get(DOM, [DOM])
+            missing = [k for k in mem if k not in rec]
+            if missing:
+                traffic_note = "no PMC record for %s" % ", ".join(missing)
             elif args.workload != "fusion":
                 traffic_note = "PMC record is for the configs[1] workload"
-            elif pm.get("kernel_source_sha16") != kernel_source_sha16():
+            elif any(rec[k].get("kernel_source_sha16") != kernel_source_sha16() for k in mem):
                 traffic_note = "stale: profiles/pmc_traffic.json was measured on kernel source %s, the library is built from %s" % (
-                    pm.get("kernel_source_sha16"), kernel_source_sha16())
-            else:
-                traffic = pm["traffic_bytes"]
-        except (OSError, ValueError) as e:
+                    rec[mem[0]].get("kernel_source_sha16"), kernel_source_sha16())
+            else:   # HBM bytes per launch, averaged over the launches of the family as `achieved` is
+                traffic = int(sum(rec[k]["traffic_bytes"] * per_kernel[k][0] for k in mem) / sum(per_kernel[k][0] for k in mem))
+                for kk in roof.get("kernels", []):
+                    kk["traffic"] = rec[kk["kernel"]]["traffic_bytes"]
+        except (OSError, ValueError, KeyError) as e:
             traffic_note = "pmc_traffic.json unreadable: %s" % e
         roof["traffic"] = traffic
         if traffic_note:

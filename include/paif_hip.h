@@ -138,6 +138,11 @@ int paif_conv2d_fwd(const paif_conv_desc* d, int B, int H, int W, paif_stream_t 
 /* 1 if paif_conv2d_fwd would run this descriptor on the persistent wave-specialised kernel (conv_bf16x3_ws),
  * 0 for the tile-per-workgroup kernel (conv_mfma_*): lets a profiler-side caller name the kernel it times. */
 int paif_conv2d_is_persistent(const paif_conv_desc* d, int B, int H, int W);
+/* The kernel paif_conv2d_fwd runs for this descriptor and shape, named as rocprofv3 lists it (without the anonymous
+ * namespace and argument list), e.g. "conv_bf16x3_ms<3, 1, 2>": tile-per-workgroup (conv_mfma_bf16x3<k, d, hooks>),
+ * multi-source 3x3 (conv_bf16x3_ms), resident-B persistent 3x3 (conv_bf16x3_res), wave-specialised persistent
+ * (conv_bf16x3_ws), exact fp32 (conv_mfma_f32).  For timing tags and dispatch tests; writes a NUL-terminated string. */
+int paif_conv2d_kernel_name(const paif_conv_desc* d, int B, int H, int W, char* buf, int buflen);
 /* w: torch layout [cout, nsrc*cin, kh, kh]; wpk: paif_conv_wpk_floats(...) floats.
  * Layout wpk[src][tap][cin/8][64 lanes][4]: lane (h = lane>>5, n = lane&31) holds
  * w[n][src*cin + 8*o + 4*h + i][tap], i = 0..3 -- the B operand of four consecutive MFMAs. */

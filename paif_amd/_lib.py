@@ -45,6 +45,7 @@ SIGNATURES = {
     "paif_conv2d_blocks": (c_int, [c_int, c_int, c_int]),
     "paif_conv2d_fwd": (c_int, [POINTER(ConvDesc), c_int, c_int, c_int, F]),
     "paif_conv2d_is_persistent": (c_int, [POINTER(ConvDesc), c_int, c_int, c_int]),
+    "paif_conv2d_kernel_name": (c_int, [POINTER(ConvDesc), c_int, c_int, c_int, c_char_p, c_int]),
     "paif_conv_wpk_floats": (c_size_t, [c_int, c_int, c_int]),
     "paif_pack_conv_weight": (c_int, [F, F, c_int, c_int, c_int, c_int, F]),
     "paif_pack_decomp1x1_weight": (c_int, [F, F, F]),

@@ -1449,13 +1449,16 @@ static inline bool ws_eligible(const ConvArgs& a) {
          (size_t)a.H * a.W * 128 < ((size_t)1 << 32);
 }
 
-// persistent 3x3: needs several tiles per workgroup to amortise the pipeline fill (512 workgroups)
-static inline bool msp_eligible(const ConvArgs& a) {
-  static const int mode = [] {
-    const char* e = getenv("PAIF_CONV_MSP");  // PAIF_CONV_MSP=0: tile-per-workgroup kernels everywhere; =2: every source count (A/B runs)
-    return e ? atoi(e) : 1;
+// Resident-B persistent 3x3 (conv_bf16x3_res): one source, enough tiles to amortise the pipeline fill of 512 workgroups.
+// Measured against the tile-per-workgroup kernel at the bench shape: 165 vs 188 us.  With 2-3 sources its B refills queue
+// behind the halo prefetch of the same wave and stall the MFMA phase (400 / 544 us vs 346 / 444 us for conv_bf16x3_ms),
+// so those stay on the multi-source kernel.
+static inline bool res_eligible(const ConvArgs& a) {
+  static const bool on = [] {
+    const char* e = getenv("PAIF_CONV_RES");  // PAIF_CONV_RES=0: tile-per-workgroup kernels everywhere (A/B runs)
+    return !(e && e[0] == '0');
   }();
-  return mode && (mode == 2 || a.nsrc == 1) && a.nblk >= 2048 && a.cout == 32 && a.in_act <= 2 && (PAIF_RES_ROWS == 8 || !a.pool_partial) &&
+  return on && a.nsrc == 1 && a.nblk >= 2048 && a.cout == 32 && a.in_act <= 2 && (PAIF_RES_ROWS == 8 || !a.pool_partial) &&
          (size_t)a.B * a.H * a.W * 128 < ((size_t)1 << 32);
 }
 
@@ -1477,25 +1480,36 @@ static inline bool takes_ws(const ConvArgs& a, int kh, int dil) {
 #endif
 }
 
+// which split-bf16 kernel a launch takes (one place: the dispatcher and paif_conv2d_kernel_name use it)
+enum ConvVariant { CV_PLAIN, CV_HOOKS, CV_WS, CV_RES, CV_MS };
+static inline ConvVariant bf16x3_variant(const ConvArgs& a, int kh, int dil) {
+  if (needs_hooks(a)) return CV_HOOKS;
+  if (takes_ws(a, kh, dil)) return CV_WS;
+  if (kh == 3 && dil == 1) {
+    if (res_eligible(a)) return CV_RES;
+    if (ms_enabled() && a.nsrc >= 2 && a.cout == 32 && a.in_act == 0 && !a.pool_partial &&
+        (size_t)a.B * a.H * a.W * 128 < ((size_t)1 << 32))   // 32-bit byte offsets into a source
+      return CV_MS;
+  }
+  return CV_PLAIN;
+}
+
 template <int KH, int DIL>
 int launch_bf16x3(const ConvArgs& a, hipStream_t st) {
-  if (needs_hooks(a)) return launch_bf16x3_h<KH, DIL, true>(a, st);
+  switch (bf16x3_variant(a, KH, DIL)) {
+    case CV_HOOKS: return launch_bf16x3_h<KH, DIL, true>(a, st);
+    case CV_WS:
 #if PAIF_TH == 8
-  if constexpr (KH <= 3) {
-    if (takes_ws(a, KH, DIL)) return launch_bf16x3_ws<KH, DIL>(a, st);
-  }
+      if constexpr (KH <= 3) return launch_bf16x3_ws<KH, DIL>(a, st);
 #endif
-  if constexpr (KH == 3 && DIL == 1) {
-    if (msp_eligible(a)) {
-      if (a.nsrc == 1) return launch_bf16x3_res<3, 1, 1>(a, st);
-      if (a.nsrc == 2) return launch_bf16x3_res<3, 1, 2>(a, st);
-      return launch_bf16x3_res<3, 1, 3>(a, st);
-    }
-    if (ms_enabled() && a.cout == 32 && a.in_act == 0 && !a.pool_partial &&
-        (size_t)a.B * a.H * a.W * 128 < ((size_t)1 << 32)) {   // 32-bit byte offsets into a source
-      if (a.nsrc == 2) return launch_bf16x3_ms<3, 1, 2>(a, st);
-      if (a.nsrc == 3) return launch_bf16x3_ms<3, 1, 3>(a, st);
-    }
+      break;
+    case CV_RES:
+      if constexpr (KH == 3 && DIL == 1) return launch_bf16x3_res<3, 1, 1>(a, st);
+      break;
+    case CV_MS:
+      if constexpr (KH == 3 && DIL == 1) return a.nsrc == 2 ? launch_bf16x3_ms<3, 1, 2>(a, st) : launch_bf16x3_ms<3, 1, 3>(a, st);
+      break;
+    default: break;
   }
   return launch_bf16x3_h<KH, DIL, false>(a, st);
 }
@@ -1622,6 +1636,32 @@ int paif_conv2d_is_persistent(const paif_conv_desc* d, int B, int H, int W) {
   a.H = H; a.W = W;
   a.nblk = B * ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
   return takes_ws(a, d->kh, d->dil) ? 1 : 0;
+}
+
+int paif_conv2d_kernel_name(const paif_conv_desc* d, int B, int H, int W, char* buf, int buflen) {
+  PAIF_REQUIRE(d && buf && buflen > 0 && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "conv2d_kernel_name: bad arguments");
+  ConvArgs a{};
+  for (int s = 0; s < 3; ++s) a.res[s] = d->res[s];
+  a.pool_partial = d->pool_partial; a.nsrc = d->nsrc; a.in_act = d->in_act; a.cout = d->cout;
+  a.aux_out = d->aux_out; a.epi_dact = d->epi_dact;
+  a.B = B; a.H = H; a.W = W;
+  a.nblk = B * ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
+  if (d->precision != PAIF_CONV_BF16X3) {
+    snprintf(buf, buflen, "conv_mfma_f32<%d, %d, %d, %s>", d->kh, d->dil, d->cin, needs_hooks(a) ? "true" : "false");
+    return 0;
+  }
+  if (d->cin != 32) {   // the folded decomposition conv (cin 16) runs on the exact-fp32 kernel
+    snprintf(buf, buflen, "conv_mfma_f32<%d, %d, %d, %s>", d->kh, d->dil, d->cin, needs_hooks(a) ? "true" : "false");
+    return 0;
+  }
+  switch (bf16x3_variant(a, d->kh, d->dil)) {
+    case CV_WS: snprintf(buf, buflen, "conv_bf16x3_ws<%d, %d>", d->kh, d->dil); break;
+    case CV_RES: snprintf(buf, buflen, "conv_bf16x3_res<%d, %d, %d, %d>", d->kh, d->dil, d->nsrc, PAIF_RES_ROWS); break;
+    case CV_MS: snprintf(buf, buflen, "conv_bf16x3_ms<%d, %d, %d>", d->kh, d->dil, d->nsrc); break;
+    case CV_HOOKS: snprintf(buf, buflen, "conv_mfma_bf16x3<%d, %d, true>", d->kh, d->dil); break;
+    default: snprintf(buf, buflen, "conv_mfma_bf16x3<%d, %d, false>", d->kh, d->dil); break;
+  }
+  return 0;
 }
 
 int paif_conv2d_fwd(const paif_conv_desc* d, int B, int H, int W, paif_stream_t stream) {

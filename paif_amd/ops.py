@@ -299,7 +299,11 @@ def guided_filter_pair(guide, y, eps=(0.001, 0.0001), want_ab=False):
     L = lib()
     if not want_ab and CONFIG.get("gf_fused", True):
         ws = torch.empty(L.paif_guided_filter_fused_workspace_floats(B, H, W), device=y.device, dtype=torch.float32)
+        tag = "gf_fused_kernel (+ gf_guide_stats_kernel)"
+        e0 = TIMER.start(tag) if TIMER is not None else None
         _lib.check(L.paif_guided_filter_fused_fwd(_p(guide), _p(y), _p(lf), eps[0], eps[1], _p(ws), B, H, W, _stream()), "guided_filter_fused")
+        if e0 is not None:   # algorithmic traffic: guide + y read once, the two low-frequency maps written once; ~650 FLOP per pixel-channel
+            TIMER.stop(tag, e0, 650 * B * H * W * 32, 4 * B * H * W * (1 + 32 + 64))
         return lf
     ab = torch.empty((4, B, H, W, 32), device=y.device, dtype=torch.float32)
     _lib.check(L.paif_guided_filter_ab_fwd(_p(guide), _p(y), _p(ab), eps[0], eps[1], B, H, W, _stream()), "guided_filter_ab")
@@ -349,6 +353,13 @@ def bn_fold(weight, bias, mean, var, eps):
 IN_DPRELU, IN_DRELU, IN_SCALE = 3, 4, 5   # dgrad staging modes of paif_conv_desc.in_act
 
 
+def conv2d_kernel_name(desc, B, H, W):
+    """Kernel paif_conv2d_fwd runs for this descriptor / shape, as rocprofv3 lists it (e.g. 'conv_bf16x3_ms<3, 1, 2>')."""
+    buf = ctypes.create_string_buffer(96)
+    _lib.check(lib().paif_conv2d_kernel_name(ctypes.byref(desc), B, H, W, buf, len(buf)), "conv2d_kernel_name")
+    return buf.value.decode()
+
+
 def conv2d(srcs, wpk, kh, dil=1, cin=32, cout=32, in_act=ACT_NONE, in_prelu=None, scale=None, shift=None,
            act=ACT_NONE, prelu=None, alpha=1.0, res=(), pool=False, want_aux=False, in_aux=None, in_scale=None,
            in_alpha=1.0, epi_dact=0, epi_aux=None, out=None):
@@ -386,10 +397,7 @@ def conv2d(srcs, wpk, kh, dil=1, cin=32, cout=32, in_act=ACT_NONE, in_prelu=None
     d.epi_aux, d.epi_dact = _p(epi_aux), epi_dact
     e0 = None
     if TIMER is not None:   # name the kernel this launch takes, as rocprofv3 will list it
-        if L.paif_conv2d_is_persistent(ctypes.byref(d), B, H, W):
-            tag = "conv_bf16x3_ws<%d,%d>" % (kh, dil)
-        else:
-            tag = "conv_mfma_%s<%d,%d,%d>" % (wpk.precision, kh, dil, cin)
+        tag = conv2d_kernel_name(d, B, H, W)
         e0 = TIMER.start(tag)
     _lib.check(L.paif_conv2d_fwd(ctypes.byref(d), B, H, W, _stream()), "conv2d")
     if e0 is not None:

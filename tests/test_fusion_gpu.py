@@ -164,8 +164,54 @@ def test_dense_conv_persistent_kernel_is_dispatched_and_correct(kh, dil, nsrc, n
     finally:
         ops.TIMER = None
     torch.cuda.synchronize()
-    assert list(timer.summary()) == ["conv_bf16x3_ws<%d,%d>" % (kh, dil)], list(timer.summary())
+    assert list(timer.summary()) == ["conv_bf16x3_ws<%d, %d>" % (kh, dil)], list(timer.summary())
     assert maxabs(y.permute(0, 3, 1, 2).cpu(), ref) <= 1e-4 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("nsrc,nres,act,in_act,pool", [
+    (1, 0, 0, 0, False), (1, 1, 1, 0, False), (1, 3, 2, 0, False), (1, 0, 1, 1, False), (1, 2, 0, 2, False),   # resident-B persistent
+    (1, 0, 0, 1, True),                                                                                     # pooled: tile-per-workgroup
+    (2, 0, 0, 0, False), (2, 2, 1, 0, False), (3, 0, 2, 0, False), (3, 3, 1, 0, False),                     # multi-source
+])
+def test_dense_conv_3x3_kernel_variants_are_dispatched_and_correct(nsrc, nres, act, in_act, pool):
+    """The 3x3 dilation-1 forward conv has three split-bf16 kernels (conv_mfma.hip): the resident-B persistent kernel
+    (one source, >= 2048 tiles), the multi-source kernel (2-3 sources) and the tile-per-workgroup kernel (everything else,
+    e.g. with the fused ECA pool).  On a ragged shape (H not a multiple of 4 or 8, W not a multiple of 32, 2178 tiles, a
+    persistent workgroup count that does not divide them) the dispatch is ASSERTED and the result compared with
+    torch.nn.functional.conv2d on the CPU, including input activations, residual maps and the pool partial sums."""
+    from paif_amd import ops
+
+    B, H, W = 1, 523, 1051     # 66 x 33 tiles of 8 x 32
+    g = torch.Generator().manual_seed(9100 + 100 * nsrc + 10 * nres + act + 3 * in_act)
+    xs = [torch.randn(B, 32, H, W, generator=g) for _ in range(nsrc)]
+    rs = [torch.randn(B, 32, H, W, generator=g) for _ in range(nres)]
+    w = torch.randn(32, 32 * nsrc, 3, 3, generator=g) * 0.05
+    scale, shift = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.1
+    slope, in_slope = torch.tensor([0.2]), torch.tensor([0.3])
+    xin = torch.cat(xs, 1)
+    xin = torch.where(xin >= 0, xin, xin * in_slope) if in_act == 1 else (xin.clamp_min(0) if in_act == 2 else xin)
+    ref = torch.nn.functional.conv2d(xin, w, padding=1)
+    ref = ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    ref = torch.where(ref >= 0, ref, ref * slope) if act == 1 else (ref.clamp_min(0) if act == 2 else ref)
+    ref = ref * 0.5 + sum(rs) if rs else ref * 0.5
+    dev = _dev()
+    timer = ops.KernelTimer(lambda tag: True)
+    ops.TIMER = timer
+    try:
+        wpk = ops.pack_conv_weight(w.to(dev), nsrc, 32, 3, precision="bf16x3")
+        out = ops.conv2d([ops.to_nhwc(x.to(dev)) for x in xs], wpk, 3, scale=scale.to(dev), shift=shift.to(dev), act=act,
+                         prelu=slope.to(dev) if act == 1 else None, alpha=0.5, res=tuple(ops.to_nhwc(r.to(dev)) for r in rs),
+                         in_act=in_act, in_prelu=in_slope.to(dev) if in_act == 1 else None, pool=pool)
+    finally:
+        ops.TIMER = None
+    torch.cuda.synchronize()
+    y, partial = out if pool else (out, None)
+    want = ("conv_mfma_bf16x3<3, 1, false>" if pool else "conv_bf16x3_res<3, 1, 1, 4>") if nsrc == 1 else "conv_bf16x3_ms<3, 1, %d>" % nsrc
+    assert list(timer.summary()) == [want], list(timer.summary())
+    sc = float(ref.abs().max())
+    assert maxabs(y.permute(0, 3, 1, 2).cpu(), ref) <= 1e-4 * sc
+    if pool:
+        assert maxabs(partial.sum(0).cpu().double(), ref.double().sum((0, 2, 3))) <= 1e-5 * sc * H * W
 
 
 def test_dense_conv_seeded_shape_sweep():

@@ -1,5 +1,2 @@
-for i in 1 2; do
-python bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>&1 | tail -1 | cut -c80-130
-PAIF_LIB=$PWD/paif_amd/lib/libpaif_hip_nt.so python bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>&1 | tail -1 | cut -c80-130
-done
-python -m pytest tests/test_fusion_gpu.py -m gpu -x -q 2>&1 | tail -2
+python -m pytest tests/test_fusion_gpu.py -m gpu -x -q 2>&1 | tail -3
+python bench.py --steps 20 --warmup 3 > gpurun_out/bench_r2d.json 2> gpurun_out/bench_r2d.err; tail -c 6000 gpurun_out/bench_r2d.json

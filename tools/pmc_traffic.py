@@ -9,6 +9,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,10 +29,11 @@ rec = {"_note": "HBM bytes per launch from rocprofv3 --pmc passes of `bench.py -
                 "tools/pmc_traffic.py), gfx950 correction applied: traffic = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024, averaged over the "
                 "launches of the kernel.  kernel_source_sha16 ties the record to the source it was measured on (bench.py refuses a stale one)."}
 for k, d in tot.items():
-    if "conv_mfma_bf16x3<3, 1, false>" in k:
-        fs = d["FETCH_SIZE"] / max(1, cnt[(k, "FETCH_SIZE")])
-        ws = d["WRITE_SIZE"] / max(1, cnt[(k, "WRITE_SIZE")])
-        rec["conv_mfma_bf16x3<3,1,32>"] = {"fetch_size_kb": fs, "write_size_kb": ws, "traffic_bytes": int(2 * fs * 1024 + ws * 1024),
-                                          "launches_fetch_pass": cnt[(k, "FETCH_SIZE")], "kernel_source_sha16": kernel_source_sha16(),
-                                          "round": 2}
+    m = re.match(r"(?:void )?(?:\(anonymous namespace\)::)?((?:conv_|gf_)\w+(?:<[^>]*>)?)", k)
+    if not m:
+        continue
+    fs = d["FETCH_SIZE"] / max(1, cnt[(k, "FETCH_SIZE")])
+    ws = d["WRITE_SIZE"] / max(1, cnt[(k, "WRITE_SIZE")])
+    rec[m.group(1)] = {"fetch_size_kb": fs, "write_size_kb": ws, "traffic_bytes": int(2 * fs * 1024 + ws * 1024),
+                       "launches_fetch_pass": cnt[(k, "FETCH_SIZE")], "kernel_source_sha16": kernel_source_sha16(), "round": 2}
 print(json.dumps(rec, indent=2))
