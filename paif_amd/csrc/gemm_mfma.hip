@@ -31,7 +31,52 @@ struct GemmArgs {
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-__global__ __launch_bounds__(256, 2) void gemm_mfma_f32(GemmArgs a) {
+// split-K slab store / fused epilogue of one workgroup tile (shared by the two exact-fp32 kernels)
+__device__ __forceinline__ void gemm_f32_finish(const GemmArgs& a, const f32x16 (&acc)[2], int m0, int n0, int wave, int h, int p) {
+  if (a.partial) {   // split-K: raw partial sums; scale / activation / residual are applied by the reduction pass
+    float* slab = a.partial + (size_t)blockIdx.y * a.M * a.N;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int n = n0 + 32 * t + p;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < a.M && n < a.N) slab[(size_t)m * a.N + n] = acc[t][r];
+      }
+    }
+    return;
+  }
+  // ---- epilogue ----
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int n = n0 + 32 * t + p;
+    if (n >= a.N) continue;
+    const float sc = a.scale ? a.scale[n] : 1.f;
+    const float sh = a.shift ? a.shift[n] : 0.f;
+    float rv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      rv[r] = (a.res && m < a.M) ? a.res[(size_t)m * a.ldres + n] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (m < a.M) {
+        float v = acc[t][r] * sc + sh;
+        if (a.act == 1) v = gelu_erf(v);
+        else if (a.act == 2) v = fmaxf(v, 0.f);
+        if (a.res) v += rv[r];
+        a.C[(size_t)m * a.ldc + n] = v;
+      }
+    }
+  }
+}
+
+// Serial form (load -> wait -> LDS -> MFMA per k tile), kept for short k loops (K <= 160: at most 5 tiles): those GEMMs
+// are bound by the A / C streams, what matters is that every resident workgroup has its loads out as early as possible,
+// and the 88-register serial body measured 10-20 % faster there than the pipelined one (which wins 20-45 % at K >= 320).
+__global__ __launch_bounds__(256, 2) void gemm_mfma_f32_serial(GemmArgs a) {
   __shared__ __align__(16) float sA[BM * LDS_STRIDE];
   __shared__ __align__(16) float sW[BN * LDS_STRIDE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p = lane & 31;
@@ -94,44 +139,104 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32(GemmArgs a) {
     }
   }
 
-  if (a.partial) {   // split-K: raw partial sums; scale / activation / residual are applied by the reduction pass
-    float* slab = a.partial + (size_t)blockIdx.y * a.M * a.N;
+  gemm_f32_finish(a, acc, m0, n0, wave, h, p);
+}
+
+// (at most 4 waves per SIMD: aiming at 5 the register allocator spills one prefetched float4 through scratch every k tile)
+template <bool MASKED>   // MASKED: dgrad prologue (ReLU mask and / or per-column scale on the A operand)
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 4))) void gemm_mfma_f32(GemmArgs a) {
+  __shared__ __align__(16) float sA[BM * LDS_STRIDE];
+  __shared__ __align__(16) float sW[BN * LDS_STRIDE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p = lane & 31;
+  // consecutive workgroups share the same rows of A (same m-tile, different n-tile) -> L2 reuse of A
+  const int tn = blockIdx.x % a.tilesN, tm = blockIdx.x / a.tilesN;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  f32x16 acc[2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int n = n0 + 32 * t + p;
+  for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m < a.M && n < a.N) slab[(size_t)m * a.N + n] = acc[t][r];
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // staging map: A tile = 128 rows x 8 float4 -> 4 per thread; W tile = 64 rows x 8 float4 -> 2 per thread
+  const int srow = tid >> 3, sq = tid & 7;
+  const int abase = (wave * 32 + p) * LDS_STRIDE + 4 * h;
+  const int wbase = p * LDS_STRIDE + 4 * h;
+
+  // Software pipeline over the k tiles: the global loads of tile k+1 are issued right after tile k has been written to
+  // LDS and stay in flight during its 32 MFMAs (the serial load -> wait -> LDS -> MFMA form left the matrix pipe idle
+  // for a full memory latency per k tile and relied on the second workgroup of the CU to fill it).  Loads are
+  // unconditional on clamped rows (rows >= M / columns >= N are never stored).
+  unsigned aoff[4], woff[2];           // element offsets (M * lda and N * K are checked < 2^32 at launch)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) aoff[i] = (unsigned)min(m0 + srow + 32 * i, a.M - 1) * (unsigned)a.lda + sq * 4;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) woff[i] = (unsigned)min(n0 + srow + 32 * i, a.N - 1) * (unsigned)a.K + sq * 4;
+  const bool masked = MASKED && a.a_mask != nullptr, scaled = MASKED && a.a_scale != nullptr;   // launch-uniform
+
+  float4 va[4], vw[2], vm[MASKED ? 4 : 1], vs;
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) va[i] = *reinterpret_cast<const float4*>(a.A + (aoff[i] + (unsigned)k0));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) vw[i] = *reinterpret_cast<const float4*>(a.W + (woff[i] + (unsigned)k0));
+    if constexpr (MASKED) {
+      if (masked) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vm[i] = *reinterpret_cast<const float4*>(a.a_mask + (aoff[i] + (unsigned)k0));
       }
+      if (scaled) vs = *reinterpret_cast<const float4*>(a.a_scale + k0 + sq * 4);
     }
-    return;
-  }
-  // ---- epilogue ----
+  };
+
+  const int kbeg = blockIdx.y * a.kper, kend = kbeg + a.kper;
+  gload(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    if (k0 > kbeg) __syncthreads();  // previous tile fully consumed
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int n = n0 + 32 * t + p;
-    if (n >= a.N) continue;
-    const float sc = a.scale ? a.scale[n] : 1.f;
-    const float sh = a.shift ? a.shift[n] : 0.f;
-    float rv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      rv[r] = (a.res && m < a.M) ? a.res[(size_t)m * a.ldres + n] : 0.f;
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (m < a.M) {
-        float v = acc[t][r] * sc + sh;
-        if (a.act == 1) v = gelu_erf(v);
-        else if (a.act == 2) v = fmaxf(v, 0.f);
-        if (a.res) v += rv[r];
-        a.C[(size_t)m * a.ldc + n] = v;
+    for (int i = 0; i < 4; ++i) {
+      float4 t = va[i];
+      if constexpr (MASKED) {   // dgrad prologue: ReLU mask and per-column scale (folded BatchNorm)
+        if (masked) {
+          t.x = vm[i].x > 0.f ? t.x : 0.f; t.y = vm[i].y > 0.f ? t.y : 0.f;
+          t.z = vm[i].z > 0.f ? t.z : 0.f; t.w = vm[i].w > 0.f ? t.w : 0.f;
+        }
+        if (scaled) { t.x *= vs.x; t.y *= vs.y; t.z *= vs.z; t.w *= vs.w; }
       }
+      *reinterpret_cast<float4*>(sA + (srow + 32 * i) * LDS_STRIDE + sq * 4) = t;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(sW + (srow + 32 * i) * LDS_STRIDE + sq * 4) = vw[i];
+    __syncthreads();
+    if (k0 + BK < kend) gload(k0 + BK);   // block-uniform
+    // operands of step o+1 are read before the 8 MFMAs of step o and pinned there (see conv_mfma.hip: left alone the
+    // scheduler sinks every ds_read to just above its first use)
+    float4 av[2], w0[2], w1[2];
+    av[0] = *reinterpret_cast<const float4*>(sA + abase);
+    w0[0] = *reinterpret_cast<const float4*>(sW + wbase);
+    w1[0] = *reinterpret_cast<const float4*>(sW + wbase + 32 * LDS_STRIDE);
+#pragma unroll
+    for (int o = 0; o < BK / 8; ++o) {
+      const int c = o & 1, n = c ^ 1;
+      if (o + 1 < BK / 8) {
+        av[n] = *reinterpret_cast<const float4*>(sA + abase + 8 * (o + 1));
+        w0[n] = *reinterpret_cast<const float4*>(sW + wbase + 8 * (o + 1));
+        w1[n] = *reinterpret_cast<const float4*>(sW + wbase + 32 * LDS_STRIDE + 8 * (o + 1));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].x, w0[c].x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].x, w1[c].x, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].y, w0[c].y, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].y, w1[c].y, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].z, w0[c].z, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].z, w1[c].z, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].w, w0[c].w, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].w, w1[c].w, acc[1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
+
+  gemm_f32_finish(a, acc, m0, n0, wave, h, p);
 }
 
 
@@ -156,6 +261,7 @@ __device__ __forceinline__ void split_store(char* dst, float4 t4) {
   *reinterpret_cast<uint2*>(dst + 64) = lo;
 }
 
+template <bool MASKED>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16x3(GemmArgs a) {
   __shared__ __align__(16) char sA[BM * RB];
   __shared__ __align__(16) char sW[BN * RB];
@@ -173,46 +279,76 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16x3(GemmArgs a) {
   const int abase = (wave * 32 + p) * RB + 16 * hh;
   const int wbase = p * RB + 16 * hh;
 
+  // software pipeline over the k tiles and pinned operand reads: see gemm_mfma_f32
+  unsigned aoff[4], woff[2];           // element offsets; rows >= M / columns >= N are never stored
+#pragma unroll
+  for (int i = 0; i < 4; ++i) aoff[i] = (unsigned)min(m0 + srow + 32 * i, a.M - 1) * (unsigned)a.lda + sq * 4;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) woff[i] = (unsigned)min(n0 + srow + 32 * i, a.N - 1) * (unsigned)a.K + sq * 4;
+  const bool masked = MASKED && a.a_mask != nullptr, scaled = MASKED && a.a_scale != nullptr;   // launch-uniform
+
+  float4 va[4], vw[2], vm[MASKED ? 4 : 1], vs;
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) va[i] = *reinterpret_cast<const float4*>(a.A + (aoff[i] + (unsigned)k0));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) vw[i] = *reinterpret_cast<const float4*>(a.W + (woff[i] + (unsigned)k0));
+    if constexpr (MASKED) {
+      if (masked) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vm[i] = *reinterpret_cast<const float4*>(a.a_mask + (aoff[i] + (unsigned)k0));
+      }
+      if (scaled) vs = *reinterpret_cast<const float4*>(a.a_scale + k0 + sq * 4);
+    }
+  };
+
+  gload(0);
   for (int k0 = 0; k0 < a.K; k0 += BK) {
-    float4 va[4], vw[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = min(m0 + srow + 32 * i, a.M - 1);   // unconditional (clamped) loads; rows >= M are never stored
-      va[i] = *reinterpret_cast<const float4*>(a.A + (size_t)m * a.lda + k0 + sq * 4);
-      if (a.a_mask) {
-        const float4 mk = *reinterpret_cast<const float4*>(a.a_mask + (size_t)m * a.lda + k0 + sq * 4);
-        va[i].x = mk.x > 0.f ? va[i].x : 0.f; va[i].y = mk.y > 0.f ? va[i].y : 0.f;
-        va[i].z = mk.z > 0.f ? va[i].z : 0.f; va[i].w = mk.w > 0.f ? va[i].w : 0.f;
-      }
-      if (a.a_scale) {
-        const float4 sc4 = *reinterpret_cast<const float4*>(a.a_scale + k0 + sq * 4);
-        va[i].x *= sc4.x; va[i].y *= sc4.y; va[i].z *= sc4.z; va[i].w *= sc4.w;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int n = min(n0 + srow + 32 * i, a.N - 1);   // columns >= N are never stored
-      vw[i] = *reinterpret_cast<const float4*>(a.W + (size_t)n * a.K + k0 + sq * 4);
-    }
     if (k0 > 0) __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) split_store(sA + (srow + 32 * i) * RB + sq * 8, va[i]);
+    for (int i = 0; i < 4; ++i) {
+      float4 t = va[i];
+      if constexpr (MASKED) {
+        if (masked) {
+          t.x = vm[i].x > 0.f ? t.x : 0.f; t.y = vm[i].y > 0.f ? t.y : 0.f;
+          t.z = vm[i].z > 0.f ? t.z : 0.f; t.w = vm[i].w > 0.f ? t.w : 0.f;
+        }
+        if (scaled) { t.x *= vs.x; t.y *= vs.y; t.z *= vs.z; t.w *= vs.w; }
+      }
+      split_store(sA + (srow + 32 * i) * RB + sq * 8, t);
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) split_store(sW + (srow + 32 * i) * RB + sq * 8, vw[i]);
     __syncthreads();
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const bf16x8 ah = *reinterpret_cast<const bf16x8*>(sA + abase + 32 * ks);
-      const bf16x8 al = *reinterpret_cast<const bf16x8*>(sA + abase + 64 + 32 * ks);
+    if (k0 + BK < a.K) gload(k0 + BK);   // block-uniform
+    struct Ops { bf16x8 ah, al, wh[2], wl[2]; };
+    auto rd = [&](Ops& o, int ks) {
+      o.ah = *reinterpret_cast<const bf16x8*>(sA + abase + 32 * ks);
+      o.al = *reinterpret_cast<const bf16x8*>(sA + abase + 64 + 32 * ks);
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const bf16x8 wh = *reinterpret_cast<const bf16x8*>(sW + wbase + t * 32 * RB + 32 * ks);
-        const bf16x8 wl = *reinterpret_cast<const bf16x8*>(sW + wbase + t * 32 * RB + 64 + 32 * ks);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc[t], 0, 0, 0);
+        o.wh[t] = *reinterpret_cast<const bf16x8*>(sW + wbase + t * 32 * RB + 32 * ks);
+        o.wl[t] = *reinterpret_cast<const bf16x8*>(sW + wbase + t * 32 * RB + 64 + 32 * ks);
       }
-    }
+    };
+    Ops o0, o1;
+    rd(o0, 0);
+    rd(o1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o0.al, o0.wh[t], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o0.ah, o0.wl[t], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o0.ah, o0.wh[t], acc[t], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o1.al, o1.wh[t], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o1.ah, o1.wl[t], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o1.ah, o1.wh[t], acc[t], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
 
 #pragma unroll
@@ -288,8 +424,19 @@ extern "C" int paif_gemm_masked_fwd(const float* A, int lda, const float* a_mask
   a.nblk = a.tilesN * ((M + BM - 1) / BM);
   a.kper = K;
   a.partial = nullptr;
-  if (precision == 1) hipLaunchKernelGGL(gemm_mfma_bf16x3, dim3(a.nblk), dim3(256), 0, paif::as_stream(stream), a);
-  else hipLaunchKernelGGL(gemm_mfma_f32, dim3(a.nblk), dim3(256), 0, paif::as_stream(stream), a);
+  PAIF_REQUIRE((size_t)M * lda < ((size_t)1 << 32) && (size_t)N * K < ((size_t)1 << 32), PAIF_ENOSUP,
+               "gemm: operands of %dx%d (lda %d) / %dx%d elements exceed the 32-bit element offsets", M, K, lda, N, K);
+  const bool pro = a_mask || a_scale;
+  const dim3 grid(a.nblk), blk(256);
+  hipStream_t st = paif::as_stream(stream);
+  if (precision == 1) {
+    if (pro) hipLaunchKernelGGL(gemm_mfma_bf16x3<true>, grid, blk, 0, st, a);
+    else hipLaunchKernelGGL(gemm_mfma_bf16x3<false>, grid, blk, 0, st, a);
+  } else {
+    if (K <= 160) hipLaunchKernelGGL(gemm_mfma_f32_serial, grid, blk, 0, st, a);
+    else if (pro) hipLaunchKernelGGL(gemm_mfma_f32<true>, grid, blk, 0, st, a);
+    else hipLaunchKernelGGL(gemm_mfma_f32<false>, grid, blk, 0, st, a);
+  }
   PAIF_LAUNCH_CHECK("gemm");
   return 0;
 }
@@ -327,7 +474,9 @@ extern "C" int paif_gemm_splitk_fwd(const float* A, int lda, const float* W, con
   a.kper = K / splits;
   a.partial = workspace;
   hipStream_t st = paif::as_stream(stream);
-  hipLaunchKernelGGL(gemm_mfma_f32, dim3(a.nblk, splits), dim3(256), 0, st, a);
+  PAIF_REQUIRE((size_t)M * lda < ((size_t)1 << 32) && (size_t)N * K < ((size_t)1 << 32), PAIF_ENOSUP,
+               "gemm_splitk: operands exceed the 32-bit element offsets");
+  hipLaunchKernelGGL(gemm_mfma_f32<false>, dim3(a.nblk, splits), dim3(256), 0, st, a);
   PAIF_LAUNCH_CHECK("gemm_splitk");
   const size_t total = (size_t)M * N;
   const int rblocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
