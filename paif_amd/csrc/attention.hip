@@ -3,6 +3,8 @@
 // The spatial-reduction conv leaves only Nk = (H/sr)(W/sr) keys (300 at 480x640 for every stage), so the
 // whole K and V of one (batch, head) live in LDS (Nk*D*8 B <= 160 KiB) and each wave streams 32 queries
 // through fp32 MFMA (v_mfma_f32_32x32x2_f32) with an online softmax -- no score matrix in HBM.
+// One workgroup per CU (the K/V image fills LDS) of 8 waves = 256 queries: two waves per SIMD, so the softmax VALU
+// section of one overlaps the MFMAs of the other, and the K/V staging is paid once per 256 queries.
 //
 // Orientation ("key on the register, query on the lane"):
 //   S^T tile [32 keys x 32 queries] = K_tile . Q^T   (A = K rows from LDS, B = Q fragment in registers)
@@ -25,8 +27,9 @@ struct AttnArgs {
 };
 
 template <int D>
-__global__ __launch_bounds__(256) void sr_attention_kernel(AttnArgs a) {
+__global__ __launch_bounds__(512) void sr_attention_kernel(AttnArgs a) {
   extern __shared__ __align__(16) float lds[];
+  constexpr int NT = 512;          // threads: 8 waves x 32 queries
   constexpr int CH = D / 4;        // 16-byte chunks per row
   constexpr int NO = D / 8;        // k-octets of the QK^T contraction
   constexpr int DT = D / 32;       // 32-wide dim tiles of O
@@ -38,7 +41,7 @@ __global__ __launch_bounds__(256) void sr_attention_kernel(AttnArgs a) {
   const float* kvb = a.kv + (size_t)b * Nk * 2 * C + hd * D;
 
   // ---- stage K (swizzled) and V of this (batch, head) ----
-  for (int idx = tid; idx < Nk * CH; idx += 256) {
+  for (int idx = tid; idx < Nk * CH; idx += NT) {
     const int key = idx / CH, c = idx - key * CH;
     const float4 kk = *reinterpret_cast<const float4*>(kvb + (size_t)key * 2 * C + c * 4);
     const float4 vv = *reinterpret_cast<const float4*>(kvb + (size_t)key * 2 * C + C + c * 4);
@@ -47,7 +50,7 @@ __global__ __launch_bounds__(256) void sr_attention_kernel(AttnArgs a) {
   }
   __syncthreads();
 
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = blockIdx.x * (NT / 2) + wave * 32;
   if (q0 >= a.N) return;  // whole wave out of range (no barriers below)
   const int qi = min(q0 + p, a.N - 1);  // clamp: lanes past N compute a duplicate and do not store
   const float* qrow = a.q + ((size_t)b * a.N + qi) * C + hd * D;
@@ -143,7 +146,7 @@ int launch_attn(const AttnArgs& a, hipStream_t st) {
       return (int)e;
     }
   }
-  hipLaunchKernelGGL((sr_attention_kernel<D>), dim3((a.N + 127) / 128, a.heads, a.B), dim3(256), lds_bytes, st, a);
+  hipLaunchKernelGGL((sr_attention_kernel<D>), dim3((a.N + 255) / 256, a.heads, a.B), dim3(512), lds_bytes, st, a);
   PAIF_LAUNCH_CHECK("sr_attention");
   return 0;
 }
