@@ -29,7 +29,8 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * D + ((chun
 
 // ---------------------------------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a) {
+// 8 waves (256 queries) per workgroup, like the forward kernel: two waves per SIMD, K/V staged once per 256 queries
+__global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnBwdArgs a) {
   extern __shared__ __align__(16) float lds[];
   constexpr int CH = D / 4, NO = D / 8, DT = D / 32;
   float* Ks = lds;
@@ -38,14 +39,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a) {
   const int hd = blockIdx.y, b = blockIdx.z;
   const int C = a.C, Nk = a.Nk;
   const float* kvb = a.kv + (size_t)b * Nk * 2 * C + hd * D;
-  for (int idx = tid; idx < Nk * CH; idx += 256) {
+  for (int idx = tid; idx < Nk * CH; idx += 512) {
     const int key = idx / CH, c = idx - key * CH;
     *reinterpret_cast<float4*>(Ks + swz<D>(key, c)) = *reinterpret_cast<const float4*>(kvb + (size_t)key * 2 * C + c * 4);
     *reinterpret_cast<float4*>(Vs + swz<D>(key, c)) = *reinterpret_cast<const float4*>(kvb + (size_t)key * 2 * C + C + c * 4);
   }
   __syncthreads();
 
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = blockIdx.x * 256 + wave * 32;
   if (q0 >= a.N) return;
   const int qi = min(q0 + p, a.N - 1);
   const size_t rowoff = ((size_t)b * a.N + qi) * C + hd * D;
@@ -274,7 +275,7 @@ int paif_sr_attention_bwd_input(const float* q, const float* kv, const float* o,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
       if (e != hipSuccess) { paif::set_error("sr_attention_bwd: LDS %zu: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
     }
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, dim3((N + 127) / 128, heads, B), dim3(256), lds_bytes, st, a);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, dim3((N + 255) / 256, heads, B), dim3(512), lds_bytes, st, a);
     PAIF_LAUNCH_CHECK("sr_attention_bwd(dq)");
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, dim3(a.nchunk * ngroups, heads, B), dim3(64 * wpb), 0, st, a);
   } else {
@@ -283,7 +284,7 @@ int paif_sr_attention_bwd_input(const float* q, const float* kv, const float* o,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
       if (e != hipSuccess) { paif::set_error("sr_attention_bwd: LDS %zu: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
     }
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, dim3((N + 127) / 128, heads, B), dim3(256), lds_bytes, st, a);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, dim3((N + 255) / 256, heads, B), dim3(512), lds_bytes, st, a);
     PAIF_LAUNCH_CHECK("sr_attention_bwd(dq)");
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, dim3(a.nchunk * ngroups, heads, B), dim3(64 * wpb), 0, st, a);
   }
