@@ -43,6 +43,12 @@ __device__ __forceinline__ float prelu_f(float v, float a) { return v >= 0.f ? v
 // Streaming 16-byte store (global_store_dwordx4 ... nt): the activation maps of the bench shapes (315 MB each) are far
 // larger than L2 + MALL, so keeping freshly written lines cached only evicts the halo rows the neighbouring tiles are
 // about to re-read.  Measured +1 % on the fusion forward with the conv outputs alone.
+#ifdef PAIF_NO_NT   // A/B knob (tools/build_variant.sh nont -DPAIF_NO_NT): plain cache policy everywhere
+__device__ __forceinline__ void store_nt(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 load_nt(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void store_nt(float* p, float2 v) { *reinterpret_cast<float2*>(p) = v; }
+__device__ __forceinline__ void store_nt(float* p, float v) { *p = v; }
+#else
 __device__ __forceinline__ void store_nt(float* p, float4 v) {
   typedef float f32x4_nt __attribute__((ext_vector_type(4)));
   const f32x4_nt vv = {v.x, v.y, v.z, v.w};
@@ -60,6 +66,7 @@ __device__ __forceinline__ void store_nt(float* p, float2 v) {
   __builtin_nontemporal_store(vv, reinterpret_cast<f32x2_nt*>(p));
 }
 __device__ __forceinline__ void store_nt(float* p, float v) { __builtin_nontemporal_store(v, p); }
+#endif
 __device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + __expf(-v)); }
 
 }  // namespace paif
