@@ -56,6 +56,10 @@ def main():
     ap.add_argument("--backbone", default="mit_b3")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="BASELINE.md 3b protocol for both batch sizes (3 warm-up + 5 timed at "
                     "B=1 and B=8: several minutes of CPU time); default = that protocol at B=1, one timed forward at B=8")
+    ap.add_argument("--graph", action="store_true",
+                    help="fusion / fusion_seg: replay one captured hipGraph per step in the timed region (the clean-eval harness's default "
+                         "mode).  `value` is then the graph-replay rate; the roofline blocks come from an eager, HIP-event-instrumented pass of "
+                         "the same K steps run right after the timed region and say so (`roofline_source`)")
     ap.add_argument("--conv-precision", choices=["f32", "bf16x3"], default="bf16x3",
                     help="arithmetic of the dense convs: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs, fp32 accumulate)")
     args = ap.parse_args()
@@ -168,14 +172,38 @@ def main():
         step()
     # HIP events around every dense-conv / GEMM / attention launch of the timed region (on the launch stream)
     timer = ops.KernelTimer(lambda tag: True)
-    barrier()
-    ops.TIMER = timer
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    ops.TIMER = None
+    if args.graph:
+        if args.workload not in ("fusion", "fusion_seg"):
+            raise SystemExit("--graph: only the inference workloads are captured")
+        gstream = torch.cuda.Stream()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(gstream):
+            step()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph, stream=gstream):
+                gout = step()
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            graph.replay()
+        out = gout
+        barrier()
+        dt = time.perf_counter() - t0
+        ops.TIMER = timer              # the instrumented eager pass (not part of `value`)
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        ops.TIMER = None
+    else:
+        barrier()
+        ops.TIMER = timer
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        barrier()
+        dt = time.perf_counter() - t0
+        ops.TIMER = None
     assert torch.isfinite(out).all()
     from paif_amd.dist_utils import max_over_ranks
     dt = max_over_ranks(dt, dist, dev)
@@ -281,6 +309,9 @@ def main():
             "roofline": roof,
             "roofline_other": others,
         }
+        if args.graph:
+            res["mode"] = "hipGraph replay (one captured graph per step)"
+            res["roofline_source"] = "eager HIP-event pass of the same %d steps after the timed region" % args.steps
         if args.workload == "train":
             res["steps_per_s"] = args.steps / dt
             if state.get("events"):

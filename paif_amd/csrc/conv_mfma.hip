@@ -1459,7 +1459,7 @@ static inline bool res_eligible(const ConvArgs& a) {
     return !(e && e[0] == '0');
   }();
   return on && a.nsrc == 1 && a.nblk >= 2048 && a.cout == 32 && a.in_act <= 2 && (PAIF_RES_ROWS == 8 || !a.pool_partial) &&
-         (size_t)a.B * a.H * a.W * 128 < ((size_t)1 << 32);
+         (size_t)a.B * a.H * a.W * 128 < ((size_t)1 << 31);   // buffer resources: 32-bit byte counts and offsets
 }
 
 static inline bool needs_hooks(const ConvArgs& a) { return a.in_act >= 3 || a.aux_out || a.epi_dact; }
