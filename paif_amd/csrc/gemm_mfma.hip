@@ -12,6 +12,8 @@
 // Replaces nn.Linear in core/mix_transformer.py (Mlp :22-25, Attention :66-69, :74 sr conv via im2col),
 // core/segformer_head.py MLP.proj (:19), linear_fuse 1x1 conv + BN + ReLU (:50-55), linear_pred (:57),
 // OverlapPatchEmbed.proj via im2col (core/mix_transformer.py:168-169).
+#include <stdint.h>
+
 #include "paif_common.h"
 
 namespace {
@@ -27,12 +29,18 @@ struct GemmArgs {
   int tilesN, nblk;
   int kper;            // k extent of one split (= K without split-K); blockIdx.y selects the split
   float* partial;      // split-K: raw accumulators go to partial[split][M][N] (no epilogue); else NULL
+  int wide;            // 1: N, ldc, ldres multiples of 4 and C / res 16-byte aligned -> float4 epilogue through LDS
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-// split-K slab store / fused epilogue of one workgroup tile (shared by the two exact-fp32 kernels)
-__device__ __forceinline__ void gemm_f32_finish(const GemmArgs& a, const f32x16 (&acc)[2], int m0, int n0, int wave, int h, int p) {
+// split-K slab store / fused epilogue of one workgroup tile (shared by all three kernels).
+// Wide form: a row-per-lane dword epilogue is store-ISSUE bound (32 store instructions of 256 B per wave; the stage-1 GEMMs
+// wrote their 315 MB outputs at 1.5 TB/s).  Each wave parks one 32x32 accumulator tile at a time in its private slice of
+// `park` (the A-operand LDS of the finished k loop, 36-float rows) and re-reads it as float4 per (row, column quad): scale /
+// shift / residual become float4 loads and a store instruction writes eight full 128-byte row segments.
+// Must be called after a __syncthreads() that retires every read of the staged operands.
+__device__ __forceinline__ void gemm_finish(const GemmArgs& a, const f32x16 (&acc)[2], float* park, int m0, int n0, int wave, int h, int p) {
   if (a.partial) {   // split-K: raw partial sums; scale / activation / residual are applied by the reduction pass
     float* slab = a.partial + (size_t)blockIdx.y * a.M * a.N;
 #pragma unroll
@@ -46,7 +54,42 @@ __device__ __forceinline__ void gemm_f32_finish(const GemmArgs& a, const f32x16 
     }
     return;
   }
-  // ---- epilogue ----
+  if (a.wide) {      // launch-uniform
+    float* ep = park + wave * (32 * 36);
+    const int lane = h * 32 + p;
+    const int c4 = lane & 7, rsub = lane >> 3;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + p] = acc[t][r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same wave wrote and reads: LDS operations complete in order
+      const int n = n0 + 32 * t + 4 * c4;
+      const bool nok = n < a.N;   // N % 4 == 0: a quad is all in or all out
+      const int nc = nok ? n : 0;
+      const float4 sc = a.scale ? *reinterpret_cast<const float4*>(a.scale + nc) : make_float4(1.f, 1.f, 1.f, 1.f);
+      const float4 sh = a.shift ? *reinterpret_cast<const float4*>(a.shift + nc) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 rv[4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int m = min(m0 + wave * 32 + it * 8 + rsub, a.M - 1);   // unconditional on a clamped row
+        rv[it] = a.res ? *reinterpret_cast<const float4*>(a.res + (size_t)m * a.ldres + nc) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + rsub;
+        const int m = m0 + wave * 32 + row;
+        float4 v = *reinterpret_cast<const float4*>(ep + row * 36 + 4 * c4);
+        v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+        if (a.act == 1) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+        else if (a.act == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (a.res) { v.x += rv[it].x; v.y += rv[it].y; v.z += rv[it].z; v.w += rv[it].w; }
+        if (nok && m < a.M) *reinterpret_cast<float4*>(a.C + (size_t)m * a.ldc + n) = v;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the tile's reads are done before the next one is parked
+    }
+    return;
+  }
+  // ---- scalar epilogue (odd N / leading dimensions: e.g. the 9-class prediction layer) ----
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int n = n0 + 32 * t + p;
@@ -139,7 +182,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_serial(GemmArgs a) {
     }
   }
 
-  gemm_f32_finish(a, acc, m0, n0, wave, h, p);
+  __syncthreads();   // every wave has finished reading the last k tile: its A region becomes the epilogue park
+  gemm_finish(a, acc, sA, m0, n0, wave, h, p);
 }
 
 // (at most 4 waves per SIMD: aiming at 5 the register allocator spills one prefetched float4 through scratch every k tile)
@@ -236,7 +280,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 4))) 
     }
   }
 
-  gemm_f32_finish(a, acc, m0, n0, wave, h, p);
+  __syncthreads();   // every wave has finished reading the last k tile: its A region becomes the epilogue park
+  gemm_finish(a, acc, sA, m0, n0, wave, h, p);
 }
 
 
@@ -351,30 +396,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16x3(GemmArgs a) {
     __builtin_amdgcn_sched_barrier(0);
   }
 
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int n = n0 + 32 * t + p;
-    if (n >= a.N) continue;
-    const float sc = a.scale ? a.scale[n] : 1.f;
-    const float sh = a.shift ? a.shift[n] : 0.f;
-    float rv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      rv[r] = (a.res && m < a.M) ? a.res[(size_t)m * a.ldres + n] : 0.f;
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      if (m < a.M) {
-        float v = acc[t][r] * sc + sh;
-        if (a.act == 1) v = gelu_erf(v);
-        else if (a.act == 2) v = fmaxf(v, 0.f);
-        if (a.res) v += rv[r];
-        a.C[(size_t)m * a.ldc + n] = v;
-      }
-    }
-  }
+  __syncthreads();   // every wave has finished reading the last k tile: its A region becomes the epilogue park
+  gemm_finish(a, acc, reinterpret_cast<float*>(sA), m0, n0, wave, hh, p);
 }
 
 // split-K second pass: C[m][n] = act(scale[n] * sum_s partial[s][m][n] + shift[n]) (+ res), splits summed in index order
@@ -424,6 +447,8 @@ extern "C" int paif_gemm_masked_fwd(const float* A, int lda, const float* a_mask
   a.nblk = a.tilesN * ((M + BM - 1) / BM);
   a.kper = K;
   a.partial = nullptr;
+  a.wide = (N % 4 == 0) && (ldc % 4 == 0) && ((uintptr_t)C % 16 == 0) && (!res || (ldres % 4 == 0 && (uintptr_t)res % 16 == 0)) &&
+           (!scale || (uintptr_t)scale % 16 == 0) && (!shift || (uintptr_t)shift % 16 == 0);
   PAIF_REQUIRE((size_t)M * lda < ((size_t)1 << 32) && (size_t)N * K < ((size_t)1 << 32), PAIF_ENOSUP,
                "gemm: operands of %dx%d (lda %d) / %dx%d elements exceed the 32-bit element offsets", M, K, lda, N, K);
   const bool pro = a_mask || a_scale;
@@ -473,6 +498,7 @@ extern "C" int paif_gemm_splitk_fwd(const float* A, int lda, const float* W, con
   a.nblk = a.tilesN * ((M + BM - 1) / BM);
   a.kper = K / splits;
   a.partial = workspace;
+  a.wide = 0;
   hipStream_t st = paif::as_stream(stream);
   PAIF_REQUIRE((size_t)M * lda < ((size_t)1 << 32) && (size_t)N * K < ((size_t)1 << 32), PAIF_ENOSUP,
                "gemm_splitk: operands exceed the 32-bit element offsets");
