@@ -238,6 +238,10 @@ int paif_dwconv3_bias_gelu_fwd(const float* x, const float* w, const float* bias
  * PAIF_ENOSUP when Nk*(C/heads)*8 B > 160 KiB or the head dim is not 32/64. */
 int paif_sr_attention_fwd(const float* q, const float* kv, float* out, float* lse, int B, int N, int Nk, int C, int heads,
                           paif_stream_t stream);
+/* Same contract, split-bf16 products (hi*hi + hi*lo + lo*hi on the bf16 MFMA, fp32 accumulate and softmax; ~1e-5 relative on
+ * the products): 5.3x less matrix-pipe time than the exact-fp32 kernel.  The backward keeps the exact kernels. */
+int paif_sr_attention_bf16x3_fwd(const float* q, const float* kv, float* out, float* lse, int B, int N, int Nk, int C, int heads,
+                          paif_stream_t stream);
 
 /* F.interpolate(mode='bilinear', align_corners=False) of NHWC x [B,IH,IW,C] written into channels
  * [coff, coff+C) of out [B,OH,OW,ldo] -- the head's upsample + torch.cat (core/segformer_head.py:66-77). */

@@ -1047,9 +1047,12 @@ def sr_attention(q, kv, heads, want_lse=False):
     assert kv.shape[2] == 2 * C
     out = torch.empty_like(q)
     lse = torch.empty((B, heads, N), device=q.device, dtype=torch.float32) if want_lse else None
-    tag = "sr_attention"
+    # arithmetic follows the GEMMs: exact fp32 MFMA under set_gemm_precision("f32") (all gradient-parity tests), split-bf16 otherwise
+    split = CONFIG["gemm_precision"] != "f32"
+    tag = "sr_attention_bf16x3" if split else "sr_attention"
     e0 = TIMER.start(tag) if TIMER is not None else None
-    _lib.check(lib().paif_sr_attention_fwd(_p(q), _p(kv), _p(out), _p(lse), B, N, Nk, C, heads, _stream()), "sr_attention")
+    fn = lib().paif_sr_attention_bf16x3_fwd if split else lib().paif_sr_attention_fwd
+    _lib.check(fn(_p(q), _p(kv), _p(out), _p(lse), B, N, Nk, C, heads, _stream()), "sr_attention")
     if e0 is not None:
         TIMER.stop(tag, e0, 4 * B * N * Nk * C, 4 * (2 * B * N * C + 2 * B * Nk * C))
     return (out, lse) if want_lse else out

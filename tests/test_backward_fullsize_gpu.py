@@ -35,15 +35,15 @@ def _exact_convs():
     (1, 300, 300, 512, 8),      # stage 4: sr = 1, keys = queries
 ])
 def test_sr_attention_forward_backward_at_480x640_token_counts(B, N, Nk, C, heads):
-    """core/mix_transformer.py:93-115 (softmax(q k^T * hd^-0.5) v) and its autograd, vs torch in float64."""
+    """core/mix_transformer.py:93-115 (softmax(q k^T * hd^-0.5) v) and its autograd, vs torch in float64: the exact-fp32 kernels
+    (set_gemm_precision("f32")) and the split-bf16 forward the default arithmetic uses (products ~1e-5 relative; its
+    log-sum-exp feeds the exact backward kernels)."""
     g = torch.Generator().manual_seed(N + C)
     q = torch.randn(B, N, C, generator=g)
     kv = torch.randn(B, Nk, 2 * C, generator=g)
     dout = torch.randn(B, N, C, generator=g)
     dev = _dev()
     qd, kvd = q.to(dev), kv.to(dev)
-    out, lse = ops.sr_attention(qd, kvd, heads, want_lse=True)
-    dq, dkv = ops.sr_attention_bwd(qd, kvd, out, dout.to(dev), lse, heads)
     hd = C // heads
     q64 = q.double().requires_grad_(True)
     kv64 = kv.double().requires_grad_(True)
@@ -52,9 +52,24 @@ def test_sr_attention_forward_backward_at_480x640_token_counts(B, N, Nk, C, head
     attn = ((qh @ kvh[0].transpose(-2, -1)) * hd ** -0.5).softmax(dim=-1)
     ref = (attn @ kvh[1]).transpose(1, 2).reshape(B, N, C)
     (ref * dout.double()).sum().backward()
-    assert maxabs(out.cpu().double(), ref.detach()) <= 2e-6 * float(ref.abs().max())
-    for mine, r in ((dq, q64.grad), (dkv, kv64.grad)):
-        assert maxabs(mine.cpu().double(), r) <= 2e-5 * float(r.abs().max()), (B, N, Nk, C, heads)
+    prev = ops.CONFIG["gemm_precision"]
+    try:
+        for mode, tol_out, tol_grad in (("f32", 2e-6, 2e-5), ("auto", 3e-5, 1e-4)):
+            ops.set_gemm_precision(mode)
+            timer = ops.KernelTimer(lambda tag: tag.startswith("sr_attention"))
+            ops.TIMER = timer
+            try:
+                out, lse = ops.sr_attention(qd, kvd, heads, want_lse=True)
+            finally:
+                ops.TIMER = None
+            torch.cuda.synchronize()
+            assert list(timer.summary()) == ["sr_attention" if mode == "f32" else "sr_attention_bf16x3"]
+            dq, dkv = ops.sr_attention_bwd(qd, kvd, out, dout.to(dev), lse, heads)
+            assert maxabs(out.cpu().double(), ref.detach()) <= tol_out * float(ref.abs().max()), (mode, B, N, Nk, C, heads)
+            for mine, r in ((dq, q64.grad), (dkv, kv64.grad)):
+                assert maxabs(mine.cpu().double(), r) <= tol_grad * float(r.abs().max()), (mode, B, N, Nk, C, heads)
+    finally:
+        ops.set_gemm_precision(prev)
 
 
 def test_guided_filter_backward_at_480x640_across_segment_seams():
