@@ -33,6 +33,8 @@ def _exact_convs():
     (2, 4800, 300, 128, 2),     # stage 2
     (1, 1200, 300, 320, 5),     # stage 3 (head_dim 64, 5 heads)
     (1, 300, 300, 512, 8),      # stage 4: sr = 1, keys = queries
+    (2, 777, 77, 64, 2),        # ragged: head_dim 32, N and Nk not multiples of 32, partial last workgroup
+    (1, 1000, 45, 128, 2),      # ragged, head_dim 64, fewer keys than two tiles
 ])
 def test_sr_attention_forward_backward_at_480x640_token_counts(B, N, Nk, C, heads):
     """core/mix_transformer.py:93-115 (softmax(q k^T * hd^-0.5) v) and its autograd, vs torch in float64: the exact-fp32 kernels

@@ -184,3 +184,71 @@ def test_layernorm_affine_gradient(M, C):
     dg, db = ops.layernorm_wgrad(x.to("cuda:0"), dy.to("cuda:0"), 1e-6)
     for got, ref in ((dg, ln.weight.grad), (db, ln.bias.grad)):
         assert maxabs(got.cpu(), ref) <= 2e-5 * max(1.0, float(ref.abs().max())), (maxabs(got.cpu(), ref), float(ref.abs().max()))
+
+
+def test_gemm_seeded_shape_sweep():
+    """40 seeded configurations of paif_gemm_masked_fwd / paif_gemm_splitk_fwd against torch in float64: every kernel of gemm_mfma.hip
+    (serial K <= 160, pipelined, split-K, split-bf16), the float4 epilogue and its scalar fallback (N % 4 != 0, misaligned slice),
+    ragged M / N, bias / scale, GELU / ReLU, residual, output into a column slice of a wider buffer, input from a column slice, and
+    the dgrad prologue (ReLU mask and per-column scale)."""
+    import random
+    from paif_amd import ops
+
+    rnd = random.Random(20261004)
+    dev = _dev()
+    prev = ops.CONFIG["gemm_precision"]
+    seen = set()
+    try:
+        for it in range(40):
+            K = 32 * rnd.choice([1, 2, 3, 5, 8, 10, 16, 40])
+            M = rnd.choice([1, 7, 128, 131, 300, 1000, 2048 + rnd.randint(0, 300), 5000])
+            N = rnd.choice([4, 9, 32, 64, 68, 100, 130, 256, 321])
+            act = rnd.randint(0, 2)
+            use_scale, use_shift, use_res = rnd.random() < 0.5, rnd.random() < 0.7, rnd.random() < 0.5
+            slice_out, slice_in, masked = rnd.random() < 0.3, rnd.random() < 0.2, rnd.random() < 0.25
+            prec = rnd.choice(["f32", "f32", "bf16x3", "auto"])
+            g = torch.Generator().manual_seed(5000 + it)
+            lda = K + (32 if slice_in else 0)
+            a = torch.randn(M, lda, generator=g)
+            w = torch.randn(N, K, generator=g) * 0.1
+            scale = torch.rand(N, generator=g) + 0.5 if use_scale else None
+            shift = torch.randn(N, generator=g) * 0.1 if use_shift else None
+            res = torch.randn(M, N, generator=g) if use_res else None
+            mask = torch.randn(M, K, generator=g) if (masked and not slice_in) else None
+            ascale = torch.rand(K, generator=g) + 0.5 if (masked and not slice_in) else None
+            a_eff = a[:, 16:16 + K] if slice_in else a
+            a64 = a_eff.double()
+            if mask is not None:
+                a64 = a64 * (mask > 0).double() * ascale.double()
+            ref = a64 @ w.double().t()
+            if scale is not None:
+                ref = ref * scale.double()
+            if shift is not None:
+                ref = ref + shift.double()
+            ref = torch.nn.functional.gelu(ref) if act == 1 else (ref.clamp_min(0) if act == 2 else ref)
+            if res is not None:
+                ref = ref + res.double()
+            ops.set_gemm_precision(prec)
+            coff = rnd.choice([0, 4, 6]) if slice_out else 0
+            out = torch.full((M, N + 12), 7.0, device=dev) if slice_out else None
+            timer = ops.KernelTimer(lambda tag: True)
+            ops.TIMER = timer
+            try:
+                y = ops.gemm(a.to(dev), w.to(dev), scale=None if scale is None else scale.to(dev), shift=None if shift is None else shift.to(dev),
+                             act=act, res=None if res is None else res.to(dev), out=out, col_offset=coff,
+                             a_cols=(16, K) if slice_in else None, a_mask=None if mask is None else mask.to(dev),
+                             a_scale=None if ascale is None else ascale.to(dev))
+            finally:
+                ops.TIMER = None
+            torch.cuda.synchronize()
+            seen.update(timer.summary())
+            got = (y[:, coff:coff + N] if slice_out else y).cpu().double()
+            split = "bf16x3" in list(timer.summary())[0]
+            tol = (3e-5 if split else 3e-6) * max(1.0, float(ref.abs().max()))
+            assert maxabs(got, ref) <= tol, (it, M, N, K, act, prec, slice_out, slice_in, masked, list(timer.summary()))
+            if slice_out:   # the columns around the slice are untouched
+                yc = y.cpu()
+                assert bool((yc[:, :coff] == 7.0).all()) and bool((yc[:, coff + N:] == 7.0).all()), (it, M, N, K, coff)
+    finally:
+        ops.set_gemm_precision(prev)
+    assert {"gemm_mfma_f32", "gemm_mfma_bf16x3"} <= seen, seen
