@@ -286,6 +286,11 @@ int paif_sr_attention_bwd_chunks(int B, int N, int heads);
 int paif_sr_attention_bwd_input(const float* q, const float* kv, const float* o, const float* dout, const float* lse,
                                 float* delta, float* dq, float* dkv, float* dkv_partial, int B, int N, int Nk, int C,
                                 int heads, paif_stream_t stream);
+/* Same, with the arithmetic of the matrix products selectable: precision 0 = exact fp32 MFMA (= paif_sr_attention_bwd_input),
+ * 1 = split-bf16 (hi*hi + hi*lo + lo*hi on the bf16 MFMA, fp32 accumulate; softmax statistics, delta and the slab reduction stay fp32). */
+int paif_sr_attention_bwd_input_p(const float* q, const float* kv, const float* o, const float* dout, const float* lse,
+                                float* delta, float* dq, float* dkv, float* dkv_partial, int B, int N, int Nk, int C,
+                                int heads, int precision, paif_stream_t stream);
 
 /* Seg_loss on bilinearly upsampled logits (attack/attack.py:103-114,446-448; F.interpolate align_corners=False
  * + CrossEntropyLoss(ignore_index), mean over valid pixels).  logits NHWC [B,IH,IW,C]; label int64 [B,OH,OW].

@@ -88,6 +88,7 @@ SIGNATURES = {
     "paif_resize_bilinear_adjoint_fwd": (c_int, [F, F, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, F]),
     "paif_sr_attention_bwd_chunks": (c_int, [c_int, c_int, c_int]),
     "paif_sr_attention_bwd_input": (c_int, [F, F, F, F, F, F, F, F, F, c_int, c_int, c_int, c_int, c_int, F]),
+    "paif_sr_attention_bwd_input_p": (c_int, [F, F, F, F, F, F, F, F, F, c_int, c_int, c_int, c_int, c_int, c_int, F]),
     "paif_upsample_ce_blocks": (c_int, [c_int, c_int, c_int]),
     "paif_upsample_ce_fwd": (c_int, [F, F, F, F, c_int, c_int, c_int, c_int, c_int, c_int, c_int, F]),
     "paif_conv_weight_dgrad": (c_int, [F, F, c_int, c_int, c_int, c_int, c_int, F]),

@@ -119,6 +119,181 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnBwdArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Split-bf16 form of the dq kernel (hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate): the exact kernel
+// runs at the fp32 matrix-pipe roof (6*N*Nk*D FLOP at 157 TF).  Same orientation.  The three A operands -- K and V row-major,
+// K transposed for dQ^T += K^T . dS^T -- are staged as bf16 hi | lo for a CHUNK of keys at a time (all three for 300 keys x 64
+// dims do not fit LDS; the backward has no online softmax, so key chunks are independent).  K^T uses the forward kernel's
+// key-slot permutation: the dS^T accumulator registers are the B operand as they stand.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bbf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void bsplit8(const float (&v)[8], bbf16x8& hi, bbf16x8& lo) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 hx = (__bf16)v[i];
+    hi[i] = hx;
+    lo[i] = (__bf16)(v[i] - (float)hx);
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(512) void attn_bwd_dq_bf16x3_kernel(AttnBwdArgs a) {
+  extern __shared__ __align__(16) char ldsc[];
+  constexpr int NT = 512;
+  constexpr int NO = D / 16, DT = D / 32;
+  constexpr int KC = D == 64 ? 160 : 320;   // keys per LDS chunk
+  constexpr int KREC = D * 4;               // row-major record: hi | lo
+  constexpr int TREC = KC * 4 + 16;         // transposed record: KC slots hi | KC slots lo | pad
+  char* Kr = ldsc;
+  char* Vr = ldsc + KC * KREC;
+  char* Kt = ldsc + 2 * KC * KREC;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p = lane & 31;
+  const int hd = blockIdx.y, b = blockIdx.z;
+  const int C = a.C, Nk = a.Nk;
+  const float* kvb = a.kv + (size_t)b * Nk * 2 * C + hd * D;
+
+  const int q0 = blockIdx.x * (NT / 2) + wave * 32;
+  const bool wave_live = q0 < a.N;          // dead waves still stage and hit the barriers
+  const int qi = min(q0 + p, a.N - 1);
+  const size_t rowoff = ((size_t)b * a.N + qi) * C + hd * D;
+  bbf16x8 qh[NO], ql[NO], doh[NO], dol[NO];
+  float dpart = 0.f;
+#pragma unroll
+  for (int o = 0; o < NO; ++o) {
+    float q8[8], d8[8];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float4 qv = *reinterpret_cast<const float4*>(a.q + rowoff + 16 * o + 8 * h + 4 * j);
+      const float4 dv = *reinterpret_cast<const float4*>(a.dout + rowoff + 16 * o + 8 * h + 4 * j);
+      const float4 ov = *reinterpret_cast<const float4*>(a.o + rowoff + 16 * o + 8 * h + 4 * j);
+      q8[4 * j] = qv.x; q8[4 * j + 1] = qv.y; q8[4 * j + 2] = qv.z; q8[4 * j + 3] = qv.w;
+      d8[4 * j] = dv.x; d8[4 * j + 1] = dv.y; d8[4 * j + 2] = dv.z; d8[4 * j + 3] = dv.w;
+      dpart += (dv.x * ov.x + dv.y * ov.y) + (dv.z * ov.z + dv.w * ov.w);
+    }
+    bsplit8(q8, qh[o], ql[o]);
+    bsplit8(d8, doh[o], dol[o]);
+  }
+  const float delta = dpart + __shfl_xor(dpart, 32);
+  const size_t stat = ((size_t)b * a.heads + hd) * a.N + qi;
+  const float lse = a.lse[stat];
+  if (wave_live && h == 0 && q0 + p < a.N) a.delta[stat] = delta;
+
+  f32x16 dqacc[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dqacc[t][r] = 0.f;
+
+  for (int c0 = 0; c0 < Nk; c0 += KC) {
+    const int kc = min(KC, Nk - c0);
+    const int kcp = (kc + 31) & ~31;
+    if (c0 > 0) __syncthreads();           // previous chunk fully consumed
+    // ---- stage the chunk: K and V row-major (split), K transposed (split, key slots permuted, zero beyond the last key) ----
+    for (int idx = tid; idx < kcp * (D / 8); idx += NT) {
+      const int key = idx / (D / 8), c = idx - key * (D / 8);
+      const bool live = key < kc;
+      const float* krow = kvb + (size_t)(c0 + min(key, kc - 1)) * 2 * C + c * 8;
+      const float4 k0 = *reinterpret_cast<const float4*>(krow), k1 = *reinterpret_cast<const float4*>(krow + 4);
+      const float4 v0 = *reinterpret_cast<const float4*>(krow + C), v1 = *reinterpret_cast<const float4*>(krow + C + 4);
+      const float k8[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+      const float v8[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      bbf16x8 kh, kl, vh, vl;
+      bsplit8(k8, kh, kl);
+      bsplit8(v8, vh, vl);
+      if (live) {
+        const int sw = key & (D / 8 - 1);
+        *reinterpret_cast<bbf16x8*>(Kr + key * KREC + ((c ^ sw) << 4)) = kh;
+        *reinterpret_cast<bbf16x8*>(Kr + key * KREC + D * 2 + ((c ^ sw) << 4)) = kl;
+        *reinterpret_cast<bbf16x8*>(Vr + key * KREC + ((c ^ sw) << 4)) = vh;
+        *reinterpret_cast<bbf16x8*>(Vr + key * KREC + D * 2 + ((c ^ sw) << 4)) = vl;
+      }
+      const int kk = key & 31, tt = key >> 5;
+      const int hh = (kk >> 2) & 1, r = (kk & 3) + 4 * (kk >> 3);
+      const int slot = tt * 32 + (r >> 3) * 16 + 8 * hh + (r & 7);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int dim = c * 8 + i;
+        *reinterpret_cast<__bf16*>(Kt + dim * TREC + slot * 2) = live ? kh[i] : (__bf16)0.f;
+        *reinterpret_cast<__bf16*>(Kt + dim * TREC + KC * 2 + slot * 2) = live ? kl[i] : (__bf16)0.f;
+      }
+    }
+    __syncthreads();
+
+    const int ntile = kcp >> 5;
+    for (int t = 0; t < ntile; ++t) {
+      f32x16 st, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+      const int key_a = min(t * 32 + p, kc - 1);
+      const char* krow = Kr + key_a * KREC;
+      const char* vrow = Vr + key_a * KREC;
+      const int sw = key_a & (D / 8 - 1);
+#pragma unroll
+      for (int o = 0; o < NO; ++o) {
+        const int cc = ((2 * o + h) ^ sw) << 4;
+        const bbf16x8 kh = *reinterpret_cast<const bbf16x8*>(krow + cc);
+        const bbf16x8 kl = *reinterpret_cast<const bbf16x8*>(krow + D * 2 + cc);
+        const bbf16x8 vh = *reinterpret_cast<const bbf16x8*>(vrow + cc);
+        const bbf16x8 vl = *reinterpret_cast<const bbf16x8*>(vrow + D * 2 + cc);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[o], st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, doh[o], dp, 0, 0, 0);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[o], st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, dol[o], dp, 0, 0, 0);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[o], st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, doh[o], dp, 0, 0, 0);
+      }
+      // dS^T = P^T o (dP^T - delta) * scale     (register r <-> key c0 + t*32 + (r&3)+8(r>>2)+4h)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float pr = (key < kc) ? expf(st[r] * a.scale - lse) : 0.f;
+        st[r] = pr * (dp[r] - delta) * a.scale;
+      }
+      // dQ^T[dim][query] += K^T[dim][key slot] . dS^T[key slot][query]: two K=16 steps, step s2 = registers 8*s2 .. 8*s2+7
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        float d8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d8[i] = st[8 * s2 + i];
+        bbf16x8 dsh, dsl;
+        bsplit8(d8, dsh, dsl);
+        const int soff = (t * 32 + s2 * 16 + 8 * h) * 2;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const int dim = 32 * dt + p;
+          const bbf16x8 th = *reinterpret_cast<const bbf16x8*>(Kt + dim * TREC + soff);
+          const bbf16x8 tl = *reinterpret_cast<const bbf16x8*>(Kt + dim * TREC + KC * 2 + soff);
+          dqacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tl, dsh, dqacc[dt], 0, 0, 0);
+          dqacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th, dsl, dqacc[dt], 0, 0, 0);
+          dqacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th, dsh, dqacc[dt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (wave_live && q0 + p < a.N) {
+    float* orow = a.dq + ((size_t)b * a.N + q0 + p) * C + hd * D;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(orow + 32 * dt + 8 * g + 4 * h) =
+            make_float4(dqacc[dt][4 * g], dqacc[dt][4 * g + 1], dqacc[dt][4 * g + 2], dqacc[dt][4 * g + 3]);
+  }
+}
+
+template <int D>
+int launch_dq_bf16x3(const AttnBwdArgs& a, hipStream_t st) {
+  constexpr int KC = D == 64 ? 160 : 320;
+  constexpr size_t lds_bytes = (size_t)2 * KC * D * 4 + (size_t)D * (KC * 4 + 16);
+  static_assert(lds_bytes <= 160 * 1024, "dq(bf16x3): key chunk does not fit LDS");
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_bf16x3_kernel<D>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e != hipSuccess) { paif::set_error("sr_attention_bwd(dq bf16x3): LDS %zu: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
+  hipLaunchKernelGGL(attn_bwd_dq_bf16x3_kernel<D>, dim3((a.N + 255) / 256, a.heads, a.B), dim3(512), lds_bytes, st, a);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // grid (nchunk * ngroups, heads, B); one wave per key tile, KG_TILES key tiles (waves) per workgroup
 constexpr int KG_TILES = 5;
 template <int D>
@@ -225,6 +400,160 @@ __global__ __launch_bounds__(64 * KG_TILES) void attn_bwd_dkv_kernel(AttnBwdArgs
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split-bf16 form of the dkv kernel (same orientation: one wave per 32-key tile, K / V fragments in registers as B operands,
+// query tiles staged in LDS).  A query tile is staged four ways, all as bf16 hi | lo: Q and dO row-major (A operands of
+// S = Q . K^T and dP = dO . V^T) and transposed with the query-slot permutation (A operands of dK^T += Q^T . dS and
+// dV^T += dO^T . P), so that the P / dS accumulator registers are the B operands as they stand.
+// ---------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(64 * KG_TILES) void attn_bwd_dkv_bf16x3_kernel(AttnBwdArgs a) {
+  constexpr int NO = D / 16, DT = D / 32;
+  constexpr int KREC = D * 4;              // row-major record: hi | lo
+  constexpr int TREC = 32 * 4 + 16;        // transposed record: 32 slots hi | 32 slots lo | pad
+  __shared__ __align__(16) char Qr[32 * KREC];
+  __shared__ __align__(16) char Dr[32 * KREC];
+  __shared__ __align__(16) char Qt[D * TREC];
+  __shared__ __align__(16) char Dt[D * TREC];
+  __shared__ float stat[64];  // lse[32], delta[32]
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, p = lane & 31;
+  const int nthreads = blockDim.x;
+  const int ngroups = ((a.Nk + 31) / 32 + KG_TILES - 1) / KG_TILES;
+  const int chunk = blockIdx.x / ngroups, kg = blockIdx.x - chunk * ngroups;
+  const int wave = kg * KG_TILES + (tid >> 6);   // key tile of this wave (may be past the last tile: idle but barrier-safe)
+  const int hd = blockIdx.y, b = blockIdx.z;
+  const int C = a.C, Nk = a.Nk, N = a.N;
+
+  // this wave's key tile: K and V fragments as B operands (lane (h, j) = key j, dims 16o + 8h + i), split once
+  const int key_b = min(wave * 32 + p, Nk - 1);
+  const float* krow = a.kv + ((size_t)b * Nk + key_b) * 2 * C + hd * D;
+  bbf16x8 kh[NO], kl[NO], vh[NO], vl[NO];
+#pragma unroll
+  for (int o = 0; o < NO; ++o) {
+    float k8[8], v8[8];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float4 kv4 = *reinterpret_cast<const float4*>(krow + 16 * o + 8 * h + 4 * j);
+      const float4 vv4 = *reinterpret_cast<const float4*>(krow + C + 16 * o + 8 * h + 4 * j);
+      k8[4 * j] = kv4.x; k8[4 * j + 1] = kv4.y; k8[4 * j + 2] = kv4.z; k8[4 * j + 3] = kv4.w;
+      v8[4 * j] = vv4.x; v8[4 * j + 1] = vv4.y; v8[4 * j + 2] = vv4.z; v8[4 * j + 3] = vv4.w;
+    }
+    bsplit8(k8, kh[o], kl[o]);
+    bsplit8(v8, vh[o], vl[o]);
+  }
+  const bool keyvalid = wave * 32 + p < Nk;
+
+  f32x16 dkacc[DT], dvacc[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dkacc[t][r] = 0.f; dvacc[t][r] = 0.f; }
+
+  const int tile0 = chunk * a.chunk_tiles;
+  const int ntq = (N + 31) / 32;
+  for (int qt = tile0; qt < min(ntq, tile0 + a.chunk_tiles); ++qt) {
+    __syncthreads();  // previous tile consumed
+    for (int idx = tid; idx < 2 * 32 * (D / 8); idx += nthreads) {
+      const int which = idx / (32 * (D / 8));            // 0: Q, 1: dO
+      const int rem = idx - which * (32 * (D / 8));
+      const int row = rem / (D / 8), c = rem - row * (D / 8);
+      const int qi = min(qt * 32 + row, N - 1);
+      const float* src = (which ? a.dout : a.q) + ((size_t)b * N + qi) * C + hd * D + c * 8;
+      const float4 x0 = *reinterpret_cast<const float4*>(src), x1 = *reinterpret_cast<const float4*>(src + 4);
+      const float x8[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+      bbf16x8 xh, xl;
+      bsplit8(x8, xh, xl);
+      char* rm = which ? Dr : Qr;
+      char* tr = which ? Dt : Qt;
+      const int sw = row & (D / 8 - 1);
+      *reinterpret_cast<bbf16x8*>(rm + row * KREC + ((c ^ sw) << 4)) = xh;
+      *reinterpret_cast<bbf16x8*>(rm + row * KREC + D * 2 + ((c ^ sw) << 4)) = xl;
+      const int hh = (row >> 2) & 1, r = (row & 3) + 4 * (row >> 3);
+      const int slot = (r >> 3) * 16 + 8 * hh + (r & 7);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int dim = c * 8 + i;
+        *reinterpret_cast<__bf16*>(tr + dim * TREC + slot * 2) = xh[i];
+        *reinterpret_cast<__bf16*>(tr + dim * TREC + 64 + slot * 2) = xl[i];
+      }
+    }
+    if (tid < 64) {
+      const int row = tid & 31;
+      const int qi = qt * 32 + row;
+      const size_t so = ((size_t)b * a.heads + hd) * N + min(qi, N - 1);
+      // invalid query rows get lse = +inf -> P = exp(-inf) = 0 -> no contribution
+      stat[tid] = tid < 32 ? (qi < N ? a.lse[so] : INFINITY) : a.delta[so];
+    }
+    __syncthreads();
+
+    // S = Q_tile . K^T and dP = dO_tile . V^T : rows (registers) = queries, lanes = keys
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+    const int sw = p & (D / 8 - 1);
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+      const int cc = ((2 * o + h) ^ sw) << 4;
+      const bbf16x8 qh = *reinterpret_cast<const bbf16x8*>(Qr + p * KREC + cc);
+      const bbf16x8 ql = *reinterpret_cast<const bbf16x8*>(Qr + p * KREC + D * 2 + cc);
+      const bbf16x8 dh = *reinterpret_cast<const bbf16x8*>(Dr + p * KREC + cc);
+      const bbf16x8 dl = *reinterpret_cast<const bbf16x8*>(Dr + p * KREC + D * 2 + cc);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ql, kh[o], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dl, vh[o], dp, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh, kl[o], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh, vl[o], dp, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh, kh[o], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh, vh[o], dp, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qr = (r & 3) + 8 * (r >> 2) + 4 * h;   // query row of this register
+      const float pr = keyvalid ? expf(s[r] * a.scale - stat[qr]) : 0.f;
+      s[r] = pr;                                        // P
+      dp[r] = pr * (dp[r] - stat[32 + qr]) * a.scale;   // dS
+    }
+    // dV^T[dim][key] += dO^T[dim][query slot] . P[query slot][key];  dK^T[dim][key] += Q^T[dim][query slot] . dS[query slot][key]
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      float p8[8], d8[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { p8[i] = s[8 * s2 + i]; d8[i] = dp[8 * s2 + i]; }
+      bbf16x8 ph, pl, dsh, dsl;
+      bsplit8(p8, ph, pl);
+      bsplit8(d8, dsh, dsl);
+      const int soff = (s2 * 16 + 8 * h) * 2;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int dim = 32 * dt + p;
+        const bbf16x8 oh = *reinterpret_cast<const bbf16x8*>(Dt + dim * TREC + soff);
+        const bbf16x8 ol = *reinterpret_cast<const bbf16x8*>(Dt + dim * TREC + 64 + soff);
+        const bbf16x8 th = *reinterpret_cast<const bbf16x8*>(Qt + dim * TREC + soff);
+        const bbf16x8 tl = *reinterpret_cast<const bbf16x8*>(Qt + dim * TREC + 64 + soff);
+        dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ol, ph, dvacc[dt], 0, 0, 0);
+        dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tl, dsh, dkacc[dt], 0, 0, 0);
+        dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oh, pl, dvacc[dt], 0, 0, 0);
+        dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th, dsl, dkacc[dt], 0, 0, 0);
+        dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oh, ph, dvacc[dt], 0, 0, 0);
+        dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th, dsh, dkacc[dt], 0, 0, 0);
+      }
+    }
+  }
+
+  // partial slab [nchunk][B][Nk][2C]: lane (h, j = key) holds dims 32*dt + 8*g + 4*h + (0..3)
+  if (keyvalid) {
+    float* base = a.dkv_partial + (((size_t)chunk * a.B + b) * Nk + wave * 32 + p) * 2 * C + hd * D;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        *reinterpret_cast<float4*>(base + 32 * dt + 8 * g + 4 * h) =
+            make_float4(dkacc[dt][4 * g], dkacc[dt][4 * g + 1], dkacc[dt][4 * g + 2], dkacc[dt][4 * g + 3]);
+        *reinterpret_cast<float4*>(base + C + 32 * dt + 8 * g + 4 * h) =
+            make_float4(dvacc[dt][4 * g], dvacc[dt][4 * g + 1], dvacc[dt][4 * g + 2], dvacc[dt][4 * g + 3]);
+      }
+  }
+}
+
 __global__ void reduce_slabs_kernel(const float4* __restrict__ partial, float4* __restrict__ out, size_t n4, int nchunk) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     float4 s = partial[i];
@@ -250,9 +579,20 @@ int paif_sr_attention_bwd_chunks(int B, int N, int heads) {
   return (ntq + chunk_tiles - 1) / chunk_tiles;
 }
 
+int paif_sr_attention_bwd_input_p(const float* q, const float* kv, const float* o, const float* dout, const float* lse,
+                                  float* delta, float* dq, float* dkv, float* dkv_partial, int B, int N, int Nk, int C, int heads,
+                                  int precision, paif_stream_t stream);
+
 int paif_sr_attention_bwd_input(const float* q, const float* kv, const float* o, const float* dout, const float* lse,
                                 float* delta, float* dq, float* dkv, float* dkv_partial, int B, int N, int Nk, int C, int heads,
                                 paif_stream_t stream) {
+  return paif_sr_attention_bwd_input_p(q, kv, o, dout, lse, delta, dq, dkv, dkv_partial, B, N, Nk, C, heads, 0, stream);
+}
+
+int paif_sr_attention_bwd_input_p(const float* q, const float* kv, const float* o, const float* dout, const float* lse,
+                                  float* delta, float* dq, float* dkv, float* dkv_partial, int B, int N, int Nk, int C, int heads,
+                                  int precision, paif_stream_t stream) {
+  PAIF_REQUIRE(precision == 0 || precision == 1, PAIF_EINVAL, "sr_attention_bwd: precision=%d", precision);
   PAIF_REQUIRE(q && kv && o && dout && lse && delta && dq && dkv && dkv_partial, PAIF_EINVAL, "sr_attention_bwd: null pointer");
   PAIF_REQUIRE(B > 0 && N > 0 && Nk > 0 && heads > 0 && C % heads == 0, PAIF_EINVAL, "sr_attention_bwd: bad shape");
   const int D = C / heads;
@@ -275,18 +615,22 @@ int paif_sr_attention_bwd_input(const float* q, const float* kv, const float* o,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
       if (e != hipSuccess) { paif::set_error("sr_attention_bwd: LDS %zu: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
     }
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, dim3((N + 255) / 256, heads, B), dim3(512), lds_bytes, st, a);
+    if (precision == 1) { const int rc = launch_dq_bf16x3<64>(a, st); if (rc) return rc; }
+    else hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, dim3((N + 255) / 256, heads, B), dim3(512), lds_bytes, st, a);
     PAIF_LAUNCH_CHECK("sr_attention_bwd(dq)");
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, dim3(a.nchunk * ngroups, heads, B), dim3(64 * wpb), 0, st, a);
+    if (precision == 1) hipLaunchKernelGGL(attn_bwd_dkv_bf16x3_kernel<64>, dim3(a.nchunk * ngroups, heads, B), dim3(64 * wpb), 0, st, a);
+    else hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, dim3(a.nchunk * ngroups, heads, B), dim3(64 * wpb), 0, st, a);
   } else {
     if (lds_bytes > 64 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<32>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
       if (e != hipSuccess) { paif::set_error("sr_attention_bwd: LDS %zu: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
     }
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, dim3((N + 255) / 256, heads, B), dim3(512), lds_bytes, st, a);
+    if (precision == 1) { const int rc = launch_dq_bf16x3<32>(a, st); if (rc) return rc; }
+    else hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, dim3((N + 255) / 256, heads, B), dim3(512), lds_bytes, st, a);
     PAIF_LAUNCH_CHECK("sr_attention_bwd(dq)");
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, dim3(a.nchunk * ngroups, heads, B), dim3(64 * wpb), 0, st, a);
+    if (precision == 1) hipLaunchKernelGGL(attn_bwd_dkv_bf16x3_kernel<32>, dim3(a.nchunk * ngroups, heads, B), dim3(64 * wpb), 0, st, a);
+    else hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, dim3(a.nchunk * ngroups, heads, B), dim3(64 * wpb), 0, st, a);
   }
   PAIF_LAUNCH_CHECK("sr_attention_bwd(dkv)");
   const size_t n4 = (size_t)B * Nk * 2 * C / 4;

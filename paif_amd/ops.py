@@ -638,8 +638,9 @@ def sr_attention_bwd(q, kv, o, dout, lse, heads):
     dq = torch.empty_like(q)
     dkv = torch.empty_like(kv)
     partial = torch.empty((nchunk, B, Nk, 2 * C), device=q.device, dtype=torch.float32)
-    _lib.check(L.paif_sr_attention_bwd_input(_p(q), _p(kv), _p(o), _p(dout.contiguous()), _p(lse), _p(delta), _p(dq), _p(dkv), _p(partial),
-                                             B, N, Nk, C, heads, _stream()), "sr_attention_bwd")
+    split = 0 if CONFIG["gemm_precision"] == "f32" else 1     # arithmetic follows the GEMMs (sr_attention)
+    _lib.check(L.paif_sr_attention_bwd_input_p(_p(q), _p(kv), _p(o), _p(dout.contiguous()), _p(lse), _p(delta), _p(dq), _p(dkv), _p(partial),
+                                               B, N, Nk, C, heads, split, _stream()), "sr_attention_bwd")
     return dq, dkv
 
 
