@@ -150,6 +150,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: it ships its own libamdhip64.  Loaded after this library (which would pull /opt/rocm's copy in), a process
+    # ends up with two HIP runtimes and kernel launches fail with "no ROCm-capable device is detected"
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise PaifLibraryError(
             "libpaif_hip.so not found at %s -- build it with `python -m paif_amd.build` "
