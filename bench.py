@@ -293,7 +293,8 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32" if args.conv_precision == "f32" else "f32 (storage and accumulation f32; conv products as split-bf16: 3x bf16 MFMA)")
                      + ("" if args.workload == "fusion" else "; SegFormer GEMMs: %s" % {"f32": "exact fp32 MFMA", "bf16x3": "split-bf16",
-                                                                                      "auto": "exact fp32 MFMA, split-bf16 where K >= 256"}[args.gemm_precision]),
+                                                                                      "auto": "exact fp32 MFMA, split-bf16 where K >= 256"}[args.gemm_precision]
+                        + "; attention products: %s" % ("exact fp32 MFMA" if args.gemm_precision == "f32" else "split-bf16")),
             "data": "synthetic",
             "config": {"workload": {"fusion": "configs[1]: fusion-net forward (RGB2YCrCb + Network_Fusion_Searched, C=32, shipped genotype)",
                                     "fusion_seg": "configs[2]: fusion + mit_b3 SegFormer end-to-end inference",
