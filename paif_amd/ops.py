@@ -26,9 +26,11 @@ ACT_GELU = 1  # paif_gemm_fwd's act code 1 is GELU (the conv's code 1 is PReLU)
 #   "bf16x3" -- split-bf16: hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate
 #               (~1e-5 relative; 5.3x less matrix-pipe time -> the convs become HBM-bound)
 # Arithmetic of the SegFormer GEMMs: "f32" | "bf16x3" | "auto" (default): split-bf16 only for the shapes whose exact-fp32 GEMM is
-# matrix-pipe bound (K >= 256: MiT stages 3-4, fc2, SR convs), exact fp32 for the HBM-bound ones.  Measured on the 480x640 mit_b3
-# golden: logits max|d| from the reference's fp64 run 1.8e-5 (f32) / 2.3e-5 (auto) / 4.5e-5 (bf16x3) against the reference's
-# own fp32 floor of 3.8e-5; configs[2] +5.7 %, configs[3] +3.6 %.
+# matrix-pipe bound (K >= 256: MiT stages 3-4, fc2, SR convs), exact fp32 for the others; the attention products follow (split-bf16
+# unless "f32").  Measured on the 480x640 mit_b3 golden (tools/gpu_check_gemm_auto.py): logits max|d| from the reference's fp64 run
+# 1.8e-5 (f32) / 2.2e-5 (auto) / 4.2e-5 (bf16x3) against the reference's own fp32 floor of 3.8e-5, argmax agreement 100 % in all three.
+# With the round-2 kernels split-bf16 is the faster GEMM for every shape without split-K (tools/gemm_shapes_b16.py: another ~2 % on
+# configs[2]); "auto" keeps K < 256 exact because that is what keeps the default inside the reference's own fp32 noise floor.
 CONFIG = {"conv_precision": "bf16x3", "gemm_precision": "auto"}
 _PREC_CODE = {"f32": 0, "bf16x3": 1}
 
