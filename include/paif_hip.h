@@ -214,6 +214,10 @@ int paif_gemm_splitk_plan(int M, int N, int K);
 int paif_gemm_splitk_fwd(const float* A, int lda, const float* W, const float* scale, const float* shift, int act,
                          const float* res, int ldres, float* C, int ldc, int M, int N, int K, int splits,
                          float* workspace, paif_stream_t stream);
+/* Same with the arithmetic of the partial products selectable (0 = exact fp32 MFMA, 1 = split-bf16); the reduction pass is fp32. */
+int paif_gemm_splitk_fwd_p(const float* A, int lda, const float* W, const float* scale, const float* shift, int act,
+                         const float* res, int ldres, float* C, int ldc, int M, int N, int K, int splits,
+                         float* workspace, int precision, paif_stream_t stream);
 
 /* nn.LayerNorm over the last dim (core/mix_transformer.py:75,122,127,172,232-253). x,y [M,C]; C % 4 == 0. */
 int paif_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, int M, int C, float eps,

@@ -70,6 +70,7 @@ SIGNATURES = {
     "paif_ssim_l1_fwd": (c_int, [F, F, F, F, F, c_int, c_int, c_int, F]),
     "paif_ssim_l1_bwd_input": (c_int, [F, F, F, F, F, F, c_int, c_int, c_int, F]),
     "paif_gemm_splitk_fwd": (c_int, [F, c_int, F, F, F, c_int, F, c_int, F, c_int, c_int, c_int, c_int, c_int, F, F]),
+    "paif_gemm_splitk_fwd_p": (c_int, [F, c_int, F, F, F, c_int, F, c_int, F, c_int, c_int, c_int, c_int, c_int, F, c_int, F]),
     "paif_layernorm_fwd": (c_int, [F, F, F, F, c_int, c_int, c_float, F]),
     "paif_im2col_fwd": (c_int, [F, F, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, F]),
     "paif_pack_conv_gemm_weight": (c_int, [F, F, c_int, c_int, c_int, c_int, F]),

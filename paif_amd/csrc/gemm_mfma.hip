@@ -347,9 +347,10 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16x3(GemmArgs a) {
     }
   };
 
-  gload(0);
-  for (int k0 = 0; k0 < a.K; k0 += BK) {
-    if (k0 > 0) __syncthreads();
+  const int kbeg = blockIdx.y * a.kper, kend = kbeg + a.kper;   // split-K: blockIdx.y selects the k range
+  gload(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    if (k0 > kbeg) __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float4 t = va[i];
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16x3(GemmArgs a) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) split_store(sW + (srow + 32 * i) * RB + sq * 8, vw[i]);
     __syncthreads();
-    if (k0 + BK < a.K) gload(k0 + BK);   // block-uniform
+    if (k0 + BK < kend) gload(k0 + BK);   // block-uniform
     struct Ops { bf16x8 ah, al, wh[2], wl[2]; };
     auto rd = [&](Ops& o, int ks) {
       o.ah = *reinterpret_cast<const bf16x8*>(sA + abase + 32 * ks);
@@ -481,9 +482,20 @@ extern "C" int paif_gemm_splitk_plan(int M, int N, int K) {
   return splits < 2 ? 1 : splits;
 }
 
+extern "C" int paif_gemm_splitk_fwd_p(const float* A, int lda, const float* W, const float* scale, const float* shift, int act,
+                                      const float* res, int ldres, float* C, int ldc, int M, int N, int K, int splits,
+                                      float* workspace, int precision, paif_stream_t stream);
+
 extern "C" int paif_gemm_splitk_fwd(const float* A, int lda, const float* W, const float* scale, const float* shift, int act,
                                     const float* res, int ldres, float* C, int ldc, int M, int N, int K, int splits,
                                     float* workspace, paif_stream_t stream) {
+  return paif_gemm_splitk_fwd_p(A, lda, W, scale, shift, act, res, ldres, C, ldc, M, N, K, splits, workspace, 0, stream);
+}
+
+extern "C" int paif_gemm_splitk_fwd_p(const float* A, int lda, const float* W, const float* scale, const float* shift, int act,
+                                      const float* res, int ldres, float* C, int ldc, int M, int N, int K, int splits,
+                                      float* workspace, int precision, paif_stream_t stream) {
+  PAIF_REQUIRE(precision == 0 || precision == 1, PAIF_EINVAL, "gemm_splitk: precision=%d", precision);
   PAIF_REQUIRE(A && W && C && workspace, PAIF_EINVAL, "gemm_splitk: null pointer");
   PAIF_REQUIRE(M > 0 && N > 0 && K > 0 && K % 32 == 0, PAIF_EINVAL, "gemm_splitk: shape %dx%dx%d", M, N, K);
   PAIF_REQUIRE(splits >= 2 && (K / BK) % splits == 0, PAIF_EINVAL, "gemm_splitk: splits=%d does not divide %d k-tiles", splits,
@@ -502,7 +514,8 @@ extern "C" int paif_gemm_splitk_fwd(const float* A, int lda, const float* W, con
   hipStream_t st = paif::as_stream(stream);
   PAIF_REQUIRE((size_t)M * lda < ((size_t)1 << 32) && (size_t)N * K < ((size_t)1 << 32), PAIF_ENOSUP,
                "gemm_splitk: operands exceed the 32-bit element offsets");
-  hipLaunchKernelGGL(gemm_mfma_f32<false>, dim3(a.nblk, splits), dim3(256), 0, st, a);
+  if (precision == 1) hipLaunchKernelGGL(gemm_mfma_bf16x3<false>, dim3(a.nblk, splits), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(gemm_mfma_f32<false>, dim3(a.nblk, splits), dim3(256), 0, st, a);
   PAIF_LAUNCH_CHECK("gemm_splitk");
   const size_t total = (size_t)M * N;
   const int rblocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);

@@ -37,7 +37,7 @@ _PREC_CODE = {"f32": 0, "bf16x3": 1}
 
 def set_gemm_precision(mode):
     """Arithmetic of the SegFormer GEMMs: "f32" (exact fp32 MFMA), "bf16x3" (split-bf16: 3 bf16 MFMAs, ~1e-5 relative),
-    or "auto": split-bf16 where the GEMM is matrix-pipe bound at fp32 (K >= 256, no split-K), exact fp32 elsewhere."""
+    or "auto": split-bf16 where the GEMM is matrix-pipe bound at fp32 (K >= 256 and M >= 2048), exact fp32 elsewhere."""
     if mode not in _PREC_CODE and mode != "auto":
         raise ValueError("gemm precision must be one of %s or 'auto'" % sorted(_PREC_CODE))
     CONFIG["gemm_precision"] = mode
@@ -569,16 +569,16 @@ def gemm(a, w, scale=None, shift=None, act=ACT_NONE, res=None, out=None, out_col
     L = lib()
     prec = CONFIG["gemm_precision"]
     splits = 1
-    if prec in ("f32", "auto") and a_mask is None and a_scale is None:
+    if a_mask is None and a_scale is None:
         splits = L.paif_gemm_splitk_plan(M, N, K)   # small grid + long k loop (small batch): spread k over the idle CUs
-    if prec == "auto":
-        prec = "bf16x3" if (splits == 1 and K >= 256 and M >= 2048) else "f32"
+    if prec == "auto":   # with or without split-K (its partial products take the same arithmetic, the reduction is fp32)
+        prec = "bf16x3" if (K >= 256 and M >= 2048) else "f32"
     tag = "gemm_mfma_%s" % prec
     e0 = TIMER.start(tag) if TIMER is not None else None
     if splits > 1:
         ws = torch.empty(splits * M * N, device=a.device, dtype=torch.float32)
-        _lib.check(L.paif_gemm_splitk_fwd(aptr, lda, _p(w), _p(scale), _p(shift), act, _p(res), N, cptr, ldc, M, N, K, splits,
-                                          _p(ws), _stream()), "gemm_splitk")
+        _lib.check(L.paif_gemm_splitk_fwd_p(aptr, lda, _p(w), _p(scale), _p(shift), act, _p(res), N, cptr, ldc, M, N, K, splits,
+                                            _p(ws), _PREC_CODE[prec], _stream()), "gemm_splitk")
     else:
         _lib.check(L.paif_gemm_masked_fwd(aptr, lda, _p(a_mask), _p(a_scale), _p(w), _p(scale), _p(shift), act, _p(res), N, cptr,
                                           ldc, M, N, K, _PREC_CODE[prec], _stream()), "gemm")
