@@ -20,67 +20,111 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // per wave instruction), the same dword is a conflict-free ds_read_b32.
 constexpr int GW_CH = 32;     // tokens per staged chunk
 
+// NT x KT = 32-row n tiles x 32-column k tiles per wave (1 or 2 each: a 64 x 64 wave tile reads every operand dword from LDS for
+// two MFMAs and halves how often the dY / X strips are fetched -- with 32 x 32 tiles the X strip of a 1280 x 320 weight was read
+// 40 times through L2).  The NEXT chunk's global loads are issued before the MFMAs of the current one (software pipeline): in the
+// serial form every 16 MFMAs waited a full memory latency and the kernel ran at a sixth of the fp32 matrix peak.
+template <int NT, int KT>
 __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
                                                          float* __restrict__ part_w, float* __restrict__ part_b, int M, int N, int K,
                                                          int mper) {
-  __shared__ __align__(16) float lds[4][2][GW_CH * 32];
+  extern __shared__ __align__(16) float lds_dyn[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kk = lane >> 5, c = lane & 31;
-  const int n0 = blockIdx.x * 32, k0 = blockIdx.y * 128 + wave * 32;
+  const int n0 = blockIdx.x * (32 * NT), k0 = blockIdx.y * (128 * KT) + wave * (32 * KT);
   const int mbeg = blockIdx.z * mper, mend = min(M, mbeg + mper);
-  float* sD = lds[wave][0];
-  float* sX = lds[wave][1];
+  float* sD = lds_dyn + wave * ((NT + KT) * GW_CH * 32);      // NT tiles of [token][32]
+  float* sX = sD + NT * GW_CH * 32;                            // KT tiles of [token][32]
   const int tl = lane >> 3, q = lane & 7;                      // staging role: token lane, channel quad
-  // clamped columns (ragged N / K): their products land in accumulator rows / columns that are never stored
-  const int nq = min(n0 + 4 * q, max(N - 4, 0)), kq = min(k0 + 4 * q, max(K - 4, 0));
-  const bool nvec = (N % 4 == 0 && lddy % 4 == 0 && n0 + 4 * q + 4 <= N), kvec = (K % 4 == 0 && ldx % 4 == 0 && k0 + 4 * q + 4 <= K);
-  f32x16 acc;
+  bool nvec[NT], kvec[KT];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  float bsum = 0.f;
-  for (int m0 = mbeg; m0 < mend; m0 += GW_CH) {
+  for (int t = 0; t < NT; ++t) nvec[t] = (N % 4 == 0 && lddy % 4 == 0 && n0 + 32 * t + 4 * q + 4 <= N);
+#pragma unroll
+  for (int t = 0; t < KT; ++t) kvec[t] = (K % 4 == 0 && ldx % 4 == 0 && k0 + 32 * t + 4 * q + 4 <= K);
+  f32x16 acc[NT][KT];
+#pragma unroll
+  for (int u = 0; u < NT; ++u)
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[u][t][r] = 0.f;
+  float bsum[NT];
+#pragma unroll
+  for (int u = 0; u < NT; ++u) bsum[u] = 0.f;
+
+  float4 pd[NT][GW_CH / 8], px[KT][GW_CH / 8];
+  auto gload = [&](int m0) {
 #pragma unroll
     for (int it = 0; it < GW_CH / 8; ++it) {
       const int m = m0 + it * 8 + tl;
       const int mm = min(m, M - 1);
-      const bool in = m < mend;
-      float4 d, v;
-      if (nvec) d = *reinterpret_cast<const float4*>(dy + (size_t)mm * lddy + n0 + 4 * q);
-      else {
-        const float* r_ = dy + (size_t)mm * lddy;
-        d = make_float4(r_[min(n0 + 4 * q, N - 1)], r_[min(n0 + 4 * q + 1, N - 1)], r_[min(n0 + 4 * q + 2, N - 1)], r_[min(n0 + 4 * q + 3, N - 1)]);
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {
+        const int nc = n0 + 32 * u + 4 * q;
+        float4 d;
+        if (nvec[u]) d = *reinterpret_cast<const float4*>(dy + (size_t)mm * lddy + nc);
+        else {
+          const float* r_ = dy + (size_t)mm * lddy;
+          d = make_float4(r_[min(nc, N - 1)], r_[min(nc + 1, N - 1)], r_[min(nc + 2, N - 1)], r_[min(nc + 3, N - 1)]);
+        }
+        if (m >= mend) d = make_float4(0.f, 0.f, 0.f, 0.f);    // tokens past the slice contribute nothing
+        pd[u][it] = d;
       }
-      if (kvec) v = *reinterpret_cast<const float4*>(x + (size_t)mm * ldx + k0 + 4 * q);
-      else {
-        const float* r_ = x + (size_t)mm * ldx;
-        v = make_float4(r_[min(k0 + 4 * q, K - 1)], r_[min(k0 + 4 * q + 1, K - 1)], r_[min(k0 + 4 * q + 2, K - 1)], r_[min(k0 + 4 * q + 3, K - 1)]);
+#pragma unroll
+      for (int t = 0; t < KT; ++t) {
+        const int kc = k0 + 32 * t + 4 * q;
+        if (kvec[t]) px[t][it] = *reinterpret_cast<const float4*>(x + (size_t)mm * ldx + kc);
+        else {
+          const float* r_ = x + (size_t)mm * ldx;
+          px[t][it] = make_float4(r_[min(kc, K - 1)], r_[min(kc + 1, K - 1)], r_[min(kc + 2, K - 1)], r_[min(kc + 3, K - 1)]);
+        }
       }
-      if (!in) d = make_float4(0.f, 0.f, 0.f, 0.f);             // tokens past the slice contribute nothing
-      *reinterpret_cast<float4*>(sD + (it * 8 + tl) * 32 + 4 * q) = d;
-      *reinterpret_cast<float4*>(sX + (it * 8 + tl) * 32 + 4 * q) = v;
     }
-    (void)nq; (void)kq;
+  };
+  if (mbeg < mend) gload(mbeg);
+  for (int m0 = mbeg; m0 < mend; m0 += GW_CH) {
+#pragma unroll
+    for (int it = 0; it < GW_CH / 8; ++it) {
+#pragma unroll
+      for (int u = 0; u < NT; ++u) *reinterpret_cast<float4*>(sD + u * (GW_CH * 32) + (it * 8 + tl) * 32 + 4 * q) = pd[u][it];
+#pragma unroll
+      for (int t = 0; t < KT; ++t) *reinterpret_cast<float4*>(sX + t * (GW_CH * 32) + (it * 8 + tl) * 32 + 4 * q) = px[t][it];
+    }
     __builtin_amdgcn_wave_barrier();          // wave-private region, LDS operations of one wave complete in order:
     asm volatile("" ::: "memory");            // only the compiler must not reorder across the phases
+    if (m0 + GW_CH < mend) gload(m0 + GW_CH); // wave-uniform; in flight during the MFMAs below
 #pragma unroll 4
     for (int j = 0; j < GW_CH / 2; ++j) {
-      const float a = sD[(2 * j + kk) * 32 + c];
-      const float b = sX[(2 * j + kk) * 32 + c];
-      bsum += a;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      float a[NT], b[KT];
+#pragma unroll
+      for (int u = 0; u < NT; ++u) { a[u] = sD[u * (GW_CH * 32) + (2 * j + kk) * 32 + c]; bsum[u] += a[u]; }
+#pragma unroll
+      for (int t = 0; t < KT; ++t) b[t] = sX[t * (GW_CH * 32) + (2 * j + kk) * 32 + c];
+#pragma unroll
+      for (int u = 0; u < NT; ++u)
+#pragma unroll
+        for (int t = 0; t < KT; ++t) acc[u][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[t], acc[u][t], 0, 0, 0);
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
   }
   float* pw = part_w + (size_t)blockIdx.z * N * K;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int nn = n0 + (r & 3) + 8 * (r >> 2) + 4 * kk;     // C/D layout: row = n, column = lane & 31 = k
-    if (nn < N && k0 + c < K) pw[(size_t)nn * K + k0 + c] = acc[r];
-  }
+  for (int u = 0; u < NT; ++u)
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int nn = n0 + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * kk;     // C/D layout: row = n, column = lane & 31 = k
+        const int kc = k0 + 32 * t + c;
+        if (nn < N && kc < K) pw[(size_t)nn * K + kc] = acc[u][t][r];
+      }
   if (part_b && blockIdx.y == 0 && wave == 0) {
-    bsum += __shfl_xor(bsum, 32);                            // the two token halves of the pair
-    if (kk == 0 && n0 + c < N) part_b[(size_t)blockIdx.z * N + n0 + c] = bsum;
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      const float bs = bsum[u] + __shfl_xor(bsum[u], 32);                  // the two token halves of the pair
+      if (kk == 0 && n0 + 32 * u + c < N) part_b[(size_t)blockIdx.z * N + n0 + 32 * u + c] = bs;
+    }
   }
 }
 
@@ -106,7 +150,9 @@ __global__ __launch_bounds__(256) void gemm_wgrad_reduce_kernel(const float* __r
 // token slices: enough workgroups to fill the chip, at least 256 tokens per slice, at most 64 slices
 extern "C" int paif_gemm_wgrad_splits(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 1;
-  const long tiles = (long)((N + 31) / 32) * ((K + 127) / 128);
+  const int kw = K >= 256 ? 256 : 128;   // k columns per workgroup (two 32-column tiles per wave from K = 256)
+  const int nw = N >= 64 ? 64 : 32;      // n rows per workgroup (two 32-row tiles per wave from N = 64)
+  const long tiles = (long)((N + nw - 1) / nw) * ((K + kw - 1) / kw);
   long s = (2048 + tiles - 1) / tiles;
   const long maxs = (M + 255) / 256;
   if (s > maxs) s = maxs;
@@ -124,8 +170,16 @@ extern "C" int paif_gemm_wgrad(const float* dy, int lddy, const float* x, int ld
   float* part_w = workspace;
   float* part_b = db ? workspace + (size_t)splits * N * K : nullptr;
   hipStream_t st = paif::as_stream(stream);
-  hipLaunchKernelGGL(gemm_wgrad_kernel, dim3((N + 31) / 32, (K + 127) / 128, splits), dim3(256), 0, st, dy, lddy, x, ldx, part_w, part_b, M,
-                     N, K, mper);
+  const int NT = N >= 64 ? 2 : 1, KT = K >= 256 ? 2 : 1;
+  const dim3 grid((N + 32 * NT - 1) / (32 * NT), (K + 128 * KT - 1) / (128 * KT), splits);
+  const size_t lds_bytes = (size_t)4 * (NT + KT) * GW_CH * 32 * sizeof(float);   // <= 64 KB
+#define PAIF_GW_LAUNCH(NT_, KT_) \
+  hipLaunchKernelGGL((gemm_wgrad_kernel<NT_, KT_>), grid, dim3(256), lds_bytes, st, dy, lddy, x, ldx, part_w, part_b, M, N, K, mper)
+  if (NT == 2 && KT == 2) PAIF_GW_LAUNCH(2, 2);
+  else if (NT == 2) PAIF_GW_LAUNCH(2, 1);
+  else if (KT == 2) PAIF_GW_LAUNCH(1, 2);
+  else PAIF_GW_LAUNCH(1, 1);
+#undef PAIF_GW_LAUNCH
   PAIF_LAUNCH_CHECK("gemm_wgrad");
   const size_t total = (size_t)N * K + (db ? N : 0);
   const int rb = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
