@@ -43,3 +43,47 @@ def test_cpu_tensor_is_refused():
 
     with pytest.raises(RuntimeError):
         ops.rgb2ycrcb(torch.zeros(1, 3, 16, 16))
+
+
+def test_dense_conv_dispatch_rules_on_the_host():
+    """paif_conv2d_kernel_name is host-only logic (no launch): the dispatch table of DESIGN section 4, kernel by kernel."""
+    import ctypes
+
+    L = _lib.load()
+
+    def name(kh=3, dil=1, nsrc=1, nres=0, B=8, H=480, W=640, pool=False, in_act=0, hooks=False, precision=1, cin=32, cout=32):
+        d = _lib.ConvDesc()
+        one = ctypes.c_void_p(16)          # any non-null pointer: nothing is dereferenced
+        for i in range(3):
+            d.src[i] = one if i < nsrc else None
+            d.res[i] = one if i < nres else None
+        d.nsrc, d.cin, d.cout, d.kh, d.dil, d.in_act, d.precision = nsrc, cin, cout, kh, dil, in_act, precision
+        d.wpk, d.out = one, one
+        d.pool_partial = one if pool else None
+        d.aux_out = one if hooks else None
+        buf = ctypes.create_string_buffer(96)
+        assert L.paif_conv2d_kernel_name(ctypes.byref(d), B, H, W, buf, len(buf)) == 0
+        return buf.value.decode()
+
+    # bench shape (9600 tiles of 8 x 32)
+    assert name(nsrc=1) == "conv_bf16x3_res<3, 1, 1, 4>"
+    assert name(nsrc=1, nres=3) == "conv_bf16x3_res<3, 1, 1, 4>"
+    assert name(nsrc=1, in_act=1) == "conv_bf16x3_res<3, 1, 1, 4>"
+    assert name(nsrc=1, pool=True) == "conv_mfma_bf16x3<3, 1, false>"
+    assert name(nsrc=2) == "conv_bf16x3_ms<3, 1, 2>"
+    assert name(nsrc=3, nres=3) == "conv_bf16x3_ms<3, 1, 3>"
+    assert name(nsrc=3, in_act=1) == "conv_mfma_bf16x3<3, 1, false>"        # multi-source form: no input activation
+    assert name(nsrc=1, hooks=True) == "conv_mfma_bf16x3<3, 1, true>"       # dgrad hooks: tile-per-workgroup kernel
+    assert name(kh=1, nsrc=3) == "conv_bf16x3_ws<1, 1>"
+    assert name(kh=1, nsrc=3, nres=1) == "conv_mfma_bf16x3<1, 1, false>"
+    assert name(kh=3, dil=2, nsrc=1) == "conv_bf16x3_ws<3, 2>"
+    assert name(kh=3, dil=2, nsrc=2) == "conv_mfma_bf16x3<3, 2, false>"
+    assert name(kh=7) == "conv_mfma_bf16x3<7, 1, false>"
+    assert name(kh=5, dil=2) == "conv_mfma_bf16x3<5, 2, false>"
+    # small images: fewer than 1024 / 2048 tiles -> no persistent forms
+    assert name(nsrc=1, B=2, H=64, W=96) == "conv_mfma_bf16x3<3, 1, false>"
+    assert name(kh=1, nsrc=3, B=2, H=64, W=96) == "conv_mfma_bf16x3<1, 1, false>"
+    assert name(nsrc=2, B=2, H=64, W=96) == "conv_bf16x3_ms<3, 1, 2>"      # the multi-source form has no size threshold
+    # exact arithmetic
+    assert name(precision=0) == "conv_mfma_f32<3, 1, 32, false>"
+    assert name(precision=0, cin=16, cout=16) == "conv_mfma_f32<3, 1, 16, false>"
