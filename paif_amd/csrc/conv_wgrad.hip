@@ -61,57 +61,89 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  for (int rr = wave; rr < ROWS; rr += 4) {
+  // The wave's chunks -- (output row rr = wave, wave + 4, ..., 64-pixel piece x0) with the source row inside the image -- form one
+  // sequence, software-pipelined: the global loads of chunk i+1 are issued before the 32 * KH MFMAs of chunk i (the serial
+  // load -> LDS -> MFMA form waited a memory latency per chunk).
+  constexpr int NXV = (CW + 12 + 7) / 8;       // float4 slots of the source chunk per lane (P <= 6)
+  float4 pd[CW / 8], pz[CW / 8], pxv[NXV];
+  const int nx = CW + 2 * P;
+  auto valid_row = [&](int rr) -> bool {       // wave-uniform
     const int y = rb * ROWS + rr;
-    if (y >= a.H) break;                       // wave-uniform
-    const int ys = y + ky * a.dil - P;         // source row of this (output row, ky)
-    if (ys < 0 || ys >= a.H) continue;         // zero padding: contributes nothing (wave-uniform)
+    if (rr >= ROWS || y >= a.H) return false;
+    const int ys = y + ky * a.dil - P;
+    return ys >= 0 && ys < a.H;
+  };
+  auto advance = [&](int& rr, int& x0) {       // next chunk of this wave; rr >= ROWS when done
+    x0 += CW;
+    if (x0 < a.W) return;
+    x0 = 0;
+    rr += 4;
+    while (rr < ROWS && rb * ROWS + rr < a.H && !valid_row(rr)) rr += 4;
+    if (rr < ROWS && rb * ROWS + rr >= a.H) rr = ROWS;
+  };
+  auto gload = [&](int rr, int x0) {
+    const int y = rb * ROWS + rr, ys = y + ky * a.dil - P;
     const size_t orow = ((size_t)b * a.H + y) * a.W, srow = ((size_t)b * a.H + ys) * a.W;
-    for (int x0 = 0; x0 < a.W; x0 += CW) {
-      // ---- stage dAcc[x0 .. x0+CW) and X[x0-P .. x0+CW+P) of this row pair, transposed to [channel][pixel] ----
 #pragma unroll
-      for (int it = 0; it < CW / 8; ++it) {
-        const int x = x0 + it * 8 + pl;
-        const size_t o = (orow + min(x, a.W - 1)) * 32 + 4 * q;          // unconditional load on a clamped column, zero by select
-        float4 d = *reinterpret_cast<const float4*>(a.dout + o);
-        if (a.act) {
-          const float4 zv = *reinterpret_cast<const float4*>(a.z + o);
-          if (a.act == 1) {
-            d.x *= zv.x >= 0.f ? 1.f : slope; d.y *= zv.y >= 0.f ? 1.f : slope; d.z *= zv.z >= 0.f ? 1.f : slope; d.w *= zv.w >= 0.f ? 1.f : slope;
-          } else {
-            d.x *= zv.x > 0.f ? 1.f : 0.f; d.y *= zv.y > 0.f ? 1.f : 0.f; d.z *= zv.z > 0.f ? 1.f : 0.f; d.w *= zv.w > 0.f ? 1.f : 0.f;
-          }
-        }
-        const bool in = x < a.W;
-        float* dst = sD + (4 * q) * DSTR + it * 8 + pl;
-        dst[0] = in ? d.x * sc4.x : 0.f; dst[DSTR] = in ? d.y * sc4.y : 0.f;
-        dst[2 * DSTR] = in ? d.z * sc4.z : 0.f; dst[3 * DSTR] = in ? d.w * sc4.w : 0.f;
-      }
-      const int nx = CW + 2 * P;
-      for (int it = 0; it * 8 < nx; ++it) {
-        const int xl = it * 8 + pl;                                       // local column 0 .. nx-1  <->  image column x0 - P + xl
-        const int xs = x0 - P + xl;
-        const float4 v = *reinterpret_cast<const float4*>(X + (srow + min(max(xs, 0), a.W - 1)) * 32 + 4 * q);
-        const bool in = xs >= 0 && xs < a.W && xl < nx;
-        if (xl < nx) {
-          float* dst = sX + (4 * q) * XSTR + xl;
-          dst[0] = in ? v.x : 0.f; dst[XSTR] = in ? v.y : 0.f; dst[2 * XSTR] = in ? v.z : 0.f; dst[3 * XSTR] = in ? v.w : 0.f;
-        }
-      }
-      __builtin_amdgcn_wave_barrier();         // the region is wave-private and LDS operations of one wave complete in order:
-      asm volatile("" ::: "memory");           // only the compiler has to be kept from reordering across the phases
-      // ---- MFMA over the chunk's pixel pairs: A[co][k] = dAcc[pixel 2j+k][co], B[k][ci] = X[pixel 2j+k + tap][ci] ----
-      const float* pd = sD + ch * DSTR + k;
-      const float* px = sX + ch * XSTR + k;
-#pragma unroll 4
-      for (int j = 0; j < CW / 2; ++j) {
-        const float d = pd[2 * j];
-#pragma unroll
-        for (int t = 0; t < KH; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(d, px[2 * j + t * a.dil], acc[t], 0, 0, 0);
-      }
-      __builtin_amdgcn_wave_barrier();
-      asm volatile("" ::: "memory");
+    for (int it = 0; it < CW / 8; ++it) {
+      const size_t o = (orow + min(x0 + it * 8 + pl, a.W - 1)) * 32 + 4 * q;   // unconditional loads on clamped columns
+      pd[it] = *reinterpret_cast<const float4*>(a.dout + o);
+      if (a.act) pz[it] = *reinterpret_cast<const float4*>(a.z + o);
     }
+#pragma unroll
+    for (int it = 0; it < NXV; ++it) {
+      const int xs = x0 - P + it * 8 + pl;
+      pxv[it] = *reinterpret_cast<const float4*>(X + (srow + min(max(xs, 0), a.W - 1)) * 32 + 4 * q);
+    }
+  };
+  int rr = wave, x0 = 0;
+  while (rr < ROWS && rb * ROWS + rr < a.H && !valid_row(rr)) rr += 4;
+  if (rr < ROWS && rb * ROWS + rr >= a.H) rr = ROWS;
+  if (rr < ROWS) gload(rr, x0);
+  while (rr < ROWS) {
+    // ---- stage dAcc[x0 .. x0+CW) and X[x0-P .. x0+CW+P) of this row pair, transposed to [channel][pixel] ----
+#pragma unroll
+    for (int it = 0; it < CW / 8; ++it) {
+      float4 d = pd[it];
+      if (a.act) {
+        const float4 zv = pz[it];
+        if (a.act == 1) {
+          d.x *= zv.x >= 0.f ? 1.f : slope; d.y *= zv.y >= 0.f ? 1.f : slope; d.z *= zv.z >= 0.f ? 1.f : slope; d.w *= zv.w >= 0.f ? 1.f : slope;
+        } else {
+          d.x *= zv.x > 0.f ? 1.f : 0.f; d.y *= zv.y > 0.f ? 1.f : 0.f; d.z *= zv.z > 0.f ? 1.f : 0.f; d.w *= zv.w > 0.f ? 1.f : 0.f;
+        }
+      }
+      const bool in = x0 + it * 8 + pl < a.W;
+      float* dst = sD + (4 * q) * DSTR + it * 8 + pl;
+      dst[0] = in ? d.x * sc4.x : 0.f; dst[DSTR] = in ? d.y * sc4.y : 0.f;
+      dst[2 * DSTR] = in ? d.z * sc4.z : 0.f; dst[3 * DSTR] = in ? d.w * sc4.w : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < NXV; ++it) {
+      const int xl = it * 8 + pl;                                       // local column 0 .. nx-1  <->  image column x0 - P + xl
+      const int xs = x0 - P + xl;
+      const float4 v = pxv[it];
+      const bool in = xs >= 0 && xs < a.W && xl < nx;
+      if (xl < nx) {
+        float* dst = sX + (4 * q) * XSTR + xl;
+        dst[0] = in ? v.x : 0.f; dst[XSTR] = in ? v.y : 0.f; dst[2 * XSTR] = in ? v.z : 0.f; dst[3 * XSTR] = in ? v.w : 0.f;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();         // the region is wave-private and LDS operations of one wave complete in order:
+    asm volatile("" ::: "memory");           // only the compiler has to be kept from reordering across the phases
+    advance(rr, x0);
+    if (rr < ROWS) gload(rr, x0);            // wave-uniform; in flight during the MFMAs below
+    // ---- MFMA over the chunk's pixel pairs: A[co][k] = dAcc[pixel 2j+k][co], B[k][ci] = X[pixel 2j+k + tap][ci] ----
+    const float* pdl = sD + ch * DSTR + k;
+    const float* pxl = sX + ch * XSTR + k;
+#pragma unroll 4
+    for (int j = 0; j < CW / 2; ++j) {
+      const float d = pdl[2 * j];
+#pragma unroll
+      for (int t = 0; t < KH; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(d, pxl[2 * j + t * a.dil], acc[t], 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
   }
   // ---- reduce the 4 waves (fixed order) through the staging LDS and write the slab ----
   __syncthreads();
