@@ -243,7 +243,8 @@ int paif_dwconv3_bias_gelu_fwd(const float* x, const float* w, const float* bias
 int paif_sr_attention_fwd(const float* q, const float* kv, float* out, float* lse, int B, int N, int Nk, int C, int heads,
                           paif_stream_t stream);
 /* Same contract, split-bf16 products (hi*hi + hi*lo + lo*hi on the bf16 MFMA, fp32 accumulate and softmax; ~1e-5 relative on
- * the products): 5.3x less matrix-pipe time than the exact-fp32 kernel.  The backward keeps the exact kernels. */
+ * the products): 5.3x less matrix-pipe time than the exact-fp32 kernel.  Holds up to 316 keys at head dim 64 in LDS; with more (the exact
+ * kernel takes 320) it runs the exact kernel. */
 int paif_sr_attention_bf16x3_fwd(const float* q, const float* kv, float* out, float* lse, int B, int N, int Nk, int C, int heads,
                           paif_stream_t stream);
 

@@ -343,6 +343,9 @@ int launch_attn(const AttnArgs& a, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int paif_sr_attention_fwd(const float* q, const float* kv, float* out, float* lse, int B, int N, int Nk, int C,
+                                     int heads, paif_stream_t stream);
+
 extern "C" int paif_sr_attention_bf16x3_fwd(const float* q, const float* kv, float* out, float* lse, int B, int N, int Nk, int C,
                                             int heads, paif_stream_t stream) {
   PAIF_REQUIRE(q && kv && out && B > 0 && N > 0 && Nk > 0 && heads > 0, PAIF_EINVAL, "sr_attention(bf16x3): bad arguments");
@@ -352,6 +355,10 @@ extern "C" int paif_sr_attention_bf16x3_fwd(const float* q, const float* kv, flo
   a.q = q; a.kv = kv; a.out = out; a.lse = lse; a.B = B; a.N = N; a.Nk = Nk; a.C = C; a.heads = heads;
   a.scale = 1.0f / sqrtf((float)D);
   hipStream_t st = paif::as_stream(stream);
+  // K row-major + V transposed need Nk*D*4 + D*(ceil32(Nk)*4 + 16) bytes of LDS: 316 keys at D = 64.  Beyond that (up to the 320
+  // keys the exact kernel holds) this entry point runs the exact-fp32 kernel -- same contract, tighter arithmetic.
+  const size_t need = (size_t)Nk * D * 4 + (size_t)D * (((Nk + 31) & ~31) * 4 + 16);
+  if (need > 160 * 1024) return paif_sr_attention_fwd(q, kv, out, lse, B, N, Nk, C, heads, stream);
   if (D == 64) return launch_attn_bf16x3<64>(a, st);
   if (D == 32) return launch_attn_bf16x3<32>(a, st);
   paif::set_error("sr_attention(bf16x3): head dim %d not built (32 and 64 are)", D);

@@ -35,6 +35,7 @@ def _exact_convs():
     (1, 300, 300, 512, 8),      # stage 4: sr = 1, keys = queries
     (2, 777, 77, 64, 2),        # ragged: head_dim 32, N and Nk not multiples of 32, partial last workgroup
     (1, 1000, 45, 128, 2),      # ragged, head_dim 64, fewer keys than two tiles
+    (1, 640, 320, 64, 1),       # 320 keys x 64 dims: the split-bf16 forward does not fit LDS and runs the exact kernel
 ])
 def test_sr_attention_forward_backward_at_480x640_token_counts(B, N, Nk, C, heads):
     """core/mix_transformer.py:93-115 (softmax(q k^T * hd^-0.5) v) and its autograd, vs torch in float64: the exact-fp32 kernels
@@ -65,7 +66,7 @@ def test_sr_attention_forward_backward_at_480x640_token_counts(B, N, Nk, C, head
             finally:
                 ops.TIMER = None
             torch.cuda.synchronize()
-            assert list(timer.summary()) == ["sr_attention" if mode == "f32" else "sr_attention_bf16x3"]
+            assert list(timer.summary()) == ["sr_attention" if mode == "f32" else "sr_attention_bf16x3"]   # the entry point taken
             dq, dkv = ops.sr_attention_bwd(qd, kvd, out, dout.to(dev), lse, heads)
             assert maxabs(out.cpu().double(), ref.detach()) <= tol_out * float(ref.abs().max()), (mode, B, N, Nk, C, heads)
             for mine, r in ((dq, q64.grad), (dkv, kv64.grad)):
