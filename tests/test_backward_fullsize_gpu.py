@@ -198,3 +198,44 @@ def test_parameter_gradients_at_480x640_mit_b3_vs_oracle():
     for k, v in m.state_dict().items():          # running statistics after one train-mode forward
         if "running_" in k:
             assert float((v.cpu() - sd[k]).abs().max()) <= 1e-5 * max(1.0, float(sd[k].abs().max())), k
+
+
+def test_sr_attention_seeded_shape_sweep():
+    """24 seeded random shapes (tiny and ragged query / key counts, both head dims, several heads, batch > 1) of the spatial-
+    reduction attention forward + backward in both arithmetic modes against torch in float64."""
+    import random
+
+    rnd = random.Random(20261005)
+    dev = _dev()
+    prev = ops.CONFIG["gemm_precision"]
+    try:
+        for it in range(24):
+            hd = rnd.choice([32, 64])
+            heads = rnd.choice([1, 2, 3, 5])
+            C = hd * heads
+            B = rnd.randint(1, 3)
+            N = rnd.choice([1, 5, 31, 32, 33, 100, 255, 256, 257, 300, 700])
+            Nk = rnd.choice([1, 7, 31, 32, 33, 64, 100, 159, 160, 161, 300, 316, 320])
+            g = torch.Generator().manual_seed(8000 + it)
+            q = torch.randn(B, N, C, generator=g)
+            kv = torch.randn(B, Nk, 2 * C, generator=g)
+            dout = torch.randn(B, N, C, generator=g)
+            q64 = q.double().requires_grad_(True)
+            kv64 = kv.double().requires_grad_(True)
+            qh = q64.reshape(B, N, heads, hd).permute(0, 2, 1, 3)
+            kvh = kv64.reshape(B, Nk, 2, heads, hd).permute(2, 0, 3, 1, 4)
+            attn = ((qh @ kvh[0].transpose(-2, -1)) * hd ** -0.5).softmax(dim=-1)
+            ref = (attn @ kvh[1]).transpose(1, 2).reshape(B, N, C)
+            (ref * dout.double()).sum().backward()
+            for mode, tol_out, tol_grad in (("f32", 3e-6, 3e-5), ("auto", 4e-5, 2e-4)):
+                ops.set_gemm_precision(mode)
+                out, lse = ops.sr_attention(q.to(dev), kv.to(dev), heads, want_lse=True)
+                dq, dkv = ops.sr_attention_bwd(q.to(dev), kv.to(dev), out, dout.to(dev), lse, heads)
+                tag = (it, mode, B, N, Nk, C, heads)
+                assert torch.isfinite(out).all() and torch.isfinite(dq).all() and torch.isfinite(dkv).all(), tag
+                # scale floor 1.0 = the magnitude of the N(0,1) operands: with one key the softmax is constant and dq is exactly 0
+                assert maxabs(out.cpu().double(), ref.detach()) <= tol_out * max(1.0, float(ref.detach().abs().max())), tag
+                assert maxabs(dq.cpu().double(), q64.grad) <= tol_grad * max(1.0, float(q64.grad.abs().max())), tag
+                assert maxabs(dkv.cpu().double(), kv64.grad) <= tol_grad * max(1.0, float(kv64.grad.abs().max())), tag
+    finally:
+        ops.set_gemm_precision(prev)
