@@ -155,7 +155,8 @@ def test_graph_capture_replay_is_bit_identical():
         g(ir2[:, :, :32], vis2)
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 512, 2048), (1201, 320, 64), (4803, 64, 256), (77, 9, 256), (19200, 64, 64)])
+@pytest.mark.parametrize("M,N,K", [(300, 512, 2048), (1201, 320, 64), (4803, 64, 256), (77, 9, 256), (19200, 64, 64),
+                                   (257, 40, 100), (1000, 33, 300), (513, 130, 520)])   # ragged N / K in every wave-tile variant
 def test_linear_weight_and_bias_gradient(M, N, K):
     """Training step, plan item 3: dW = dY^T X and db = column sums of dY (odd token counts, N / K that are not multiples
     of the 32 x 128 tile) against fp64 torch on the CPU."""
