@@ -343,11 +343,12 @@ def test_dataset_prefetcher_feeds_the_harness(tmp_path):
     assert names == [["000.png", "001.png"], ["002.png"]]
 
 
+@pytest.mark.parametrize("shape", [(2, 21, 27), (1, 19, 150)])   # one 64-pixel chunk per row / three chunks with a ragged last one
 @pytest.mark.parametrize("kh,dil,nsrc,act", [(3, 1, 1, 0), (3, 1, 3, 1), (3, 2, 2, 2), (1, 1, 3, 0), (5, 1, 1, 1), (7, 1, 1, 0), (5, 2, 1, 2)])
-def test_dense_conv_weight_gradient(kh, dil, nsrc, act):
+def test_dense_conv_weight_gradient(kh, dil, nsrc, act, shape):
     """First kernel of the training step (plan item 2): dW of y = act(conv(cat(srcs), W) * scale + shift) * alpha
     against torch's autograd on the CPU (odd width, rows not a multiple of the 8-row workgroup)."""
-    B, H, W = 2, 21, 27
+    B, H, W = shape
     g = torch.Generator().manual_seed(kh * 100 + dil * 10 + nsrc + act)
     xs = [torch.randn(B, 32, H, W, generator=g) for _ in range(nsrc)]
     w = (torch.randn(32, 32 * nsrc, kh, kh, generator=g) * 0.05).requires_grad_(True)
