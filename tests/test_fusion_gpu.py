@@ -214,6 +214,38 @@ def test_dense_conv_3x3_kernel_variants_are_dispatched_and_correct(nsrc, nres, a
         assert maxabs(partial.sum(0).cpu().double(), ref.double().sum((0, 2, 3))) <= 1e-5 * sc * H * W
 
 
+@pytest.mark.parametrize("nres,act,in_act", [(0, 1, 0), (2, 0, 1)])
+def test_dense_conv_resident_kernel_batched_ragged(nres, act, in_act):
+    """conv_bf16x3_res on a second shape class: batch 3 (tile ranges of the 8 XCDs straddle image boundaries), H = 258 (2 rows in the
+    last 4-row tile), W = 704 (full 32-pixel tiles), against torch on the CPU."""
+    from paif_amd import ops
+
+    B, H, W = 3, 258, 704      # 3 x 33 x 22 = 2178 tiles of 8 x 32
+    g = torch.Generator().manual_seed(9300 + 10 * nres + act + 3 * in_act)
+    x = torch.randn(B, 32, H, W, generator=g)
+    rs = [torch.randn(B, 32, H, W, generator=g) for _ in range(nres)]
+    w = torch.randn(32, 32, 3, 3, generator=g) * 0.05
+    scale, shift = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.1
+    slope, in_slope = torch.tensor([0.2]), torch.tensor([0.3])
+    xin = torch.where(x >= 0, x, x * in_slope) if in_act == 1 else x
+    ref = torch.nn.functional.conv2d(xin, w, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    ref = torch.where(ref >= 0, ref, ref * slope) if act == 1 else ref
+    ref = ref * 0.5 + sum(rs) if rs else ref * 0.5
+    dev = _dev()
+    timer = ops.KernelTimer(lambda tag: True)
+    ops.TIMER = timer
+    try:
+        wpk = ops.pack_conv_weight(w.to(dev), 1, 32, 3, precision="bf16x3")
+        y = ops.conv2d([ops.to_nhwc(x.to(dev))], wpk, 3, scale=scale.to(dev), shift=shift.to(dev), act=act,
+                       prelu=slope.to(dev) if act == 1 else None, alpha=0.5, res=tuple(ops.to_nhwc(r.to(dev)) for r in rs),
+                       in_act=in_act, in_prelu=in_slope.to(dev) if in_act == 1 else None)
+    finally:
+        ops.TIMER = None
+    torch.cuda.synchronize()
+    assert list(timer.summary()) == ["conv_bf16x3_res<3, 1, 1, 4>"], list(timer.summary())
+    assert maxabs(y.permute(0, 3, 1, 2).cpu(), ref) <= 1e-4 * float(ref.abs().max())
+
+
 def test_dense_conv_seeded_shape_sweep():
     """40 seeded random configurations (shape, kernel size, dilation, sources, residuals, activation, affine on/off) of the
     dense conv: the split-bf16 kernel the library picks against the exact-fp32 MFMA kernel, and -- on the small shapes --
