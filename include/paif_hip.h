@@ -128,6 +128,9 @@ typedef struct {
   float in_alpha;        /* in_act 3/4/5: scalar factor (that layer's alpha) */
   const float* epi_aux;  /* epi_dact: tensor gating the output */
   int epi_dact;          /* 0 none; 1: out *= (epi_aux >= 0 ? 1 : *prelu); 2: out *= (epi_aux > 0), before residuals */
+  int reverse_tiles;     /* 1: walk the tiles from the end of each XCD's range.  Results do not depend on it; a caller that alternates it
+                            between consecutive layers ("serpentine") lets a layer start with the inputs its producer wrote last, which
+                            are still in L2 / MALL (+0.7 % on the fusion forward).  Not honoured by the wave-specialised kernel */
 } paif_conv_desc;
 /* in_act: 0 none, 1 PReLU, 2 ReLU, 3 src*in_alpha*in_scale[c]*(in_aux>=0?1:*in_prelu), 4 ...*(in_aux>0), 5 src*in_alpha*in_scale[c] */
 #define PAIF_CONV_F32 0

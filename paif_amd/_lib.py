@@ -21,7 +21,7 @@ class ConvDesc(Structure):
         ("in_act", c_int), ("in_prelu", F), ("scale", F), ("shift", F), ("act", c_int), ("prelu", F),
         ("alpha", c_float), ("res", F * 3), ("out", F), ("cout", c_int), ("pool_partial", F),
         ("precision", c_int), ("aux_out", F), ("in_aux", F), ("in_scale", F), ("in_alpha", c_float), ("epi_aux", F),
-        ("epi_dact", c_int),
+        ("epi_dact", c_int), ("reverse_tiles", c_int),
     ]
 
 

@@ -58,6 +58,7 @@ struct ConvArgs {
   float alpha, in_alpha;
   int nsrc, in_act, act, cout, epi_dact;
   int B, H, W, tilesX, tilesY, nblk;
+  int reverse;             // 1: tiles are walked from the end of each XCD range (serpentine order across consecutive layers)
 };
 
 // Transform applied to a staged float4 (channels 4q..4q+3 of one pixel):
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(NTHREADS, HOOKS ? 2 : 3) void conv_mfma_f32(ConvArg
   const int h = lane >> 5;
   const int p = lane & 31;
 
-  const int tile_id = paif::xcd_remap(blockIdx.x, a.nblk);  // (b, ty, tx) row-major
+  const int tile_id = paif::xcd_remap(blockIdx.x, a.nblk, a.reverse);  // (b, ty, tx) row-major
   int t = tile_id;
   const int tx = t % a.tilesX;
   t /= a.tilesX;
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(NTHREADS, (HOOKS || KH >= 5 || DIL == 2) ? 2 : PAIF
   const int hh = lane >> 5;
   const int p = lane & 31;
 
-  const int tile_id = paif::xcd_remap(blockIdx.x, a.nblk);
+  const int tile_id = paif::xcd_remap(blockIdx.x, a.nblk, a.reverse);
   int t = tile_id;
   const int tx = t % a.tilesX;
   t /= a.tilesX;
@@ -704,7 +705,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bf16x3_ms(ConvArgs a) {
   const int hh = lane >> 5;
   const int p = lane & 31;
 
-  const int tile_id = paif::xcd_remap(blockIdx.x, a.nblk);
+  const int tile_id = paif::xcd_remap(blockIdx.x, a.nblk, a.reverse);
   int t = tile_id;
   const int tx = t % a.tilesX;
   t /= a.tilesX;
@@ -907,9 +908,11 @@ __global__ __launch_bounds__(RT * 64, RT == 4 ? 2 : 1) void conv_bf16x3_res(Conv
   // this workgroup's tiles: XCD x (hardware deals workgroups round-robin over the 8 XCDs) owns tiles [x*tpx, (x+1)*tpx)
   const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, nwg = gridDim.x >> 3;
   const int tpx = (ntiles + 7) >> 3;
-  const int t_end = min(ntiles, (xcd + 1) * tpx);
-  int tile = xcd * tpx + wg;
-  if (tile >= t_end) return;           // block-uniform
+  const int t_beg = xcd * tpx, t_end = min(ntiles, (xcd + 1) * tpx);
+  if (t_beg + wg >= t_end) return;     // block-uniform
+  // logical position p = wg, wg + nwg, ... of this XCD's range; tile = t_beg + p, or counted from the end when reversed
+  int pos = wg;
+  int tile = a.reverse ? t_end - 1 - pos : t_beg + pos;
 
   f32x16 acc[1];
 #pragma unroll
@@ -1049,8 +1052,8 @@ __global__ __launch_bounds__(RT * 64, RT == 4 ? 2 : 1) void conv_bf16x3_res(Conv
   PAIF_TRACE_DECL
   int par = 0;                         // LDS buffer of the current unit
   for (;;) {
-    const int tile_next = tile + nwg;
-    const bool more = tile_next < t_end;
+    const bool more = t_beg + pos + nwg < t_end;
+    const int tile_next = a.reverse ? tile - nwg : tile + nwg;
 #pragma unroll
     for (int s = 0; s < NSRC; ++s) {
       u32x4 vn[NIT];
@@ -1108,6 +1111,7 @@ __global__ __launch_bounds__(RT * 64, RT == 4 ? 2 : 1) void conv_bf16x3_res(Conv
       return;
     }
     tile = tile_next;
+    pos += nwg;
   }
 }
 
@@ -1691,6 +1695,7 @@ int paif_conv2d_fwd(const paif_conv_desc* d, int B, int H, int W, paif_stream_t 
   PAIF_REQUIRE(d->epi_dact != 1 || d->prelu, PAIF_EINVAL, "conv2d: epi_dact=PReLU without slope");
   a.B = B; a.H = H; a.W = W;
   a.tilesX = (W + TW - 1) / TW; a.tilesY = (H + TH - 1) / TH; a.nblk = B * a.tilesX * a.tilesY;
+  a.reverse = d->reverse_tiles ? 1 : 0;
   hipStream_t st = paif::as_stream(stream);
   PAIF_REQUIRE(d->cin == 32 || d->cin == 16, PAIF_ENOSUP, "conv2d: cin=%d", d->cin);
   PAIF_REQUIRE(d->precision == PAIF_CONV_F32 || d->precision == PAIF_CONV_BF16X3, PAIF_EINVAL, "conv2d: precision=%d", d->precision);

@@ -32,10 +32,11 @@ static inline hipStream_t as_stream(paif_stream_t s) { return reinterpret_cast<h
 // XCD-aware bijective remap of a linear workgroup id: blocks b and b+8 share an XCD (round-robin
 // dispatch, MI355X_MICROARCH "Workgroup dispatch"), so give each XCD a CONTIGUOUS chunk of tiles:
 // spatially adjacent tiles (which share halo pixels) then hit the same 4 MiB L2.  Speed only.
-__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+__device__ __forceinline__ int xcd_remap(int bid, int nblk, int reverse = 0) {
   const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
   const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return base + k;
+  const int cnt = (xcd < r) ? q + 1 : q;
+  return base + (reverse ? cnt - 1 - k : k);   // reverse: each XCD walks its tile range from the end
 }
 
 __device__ __forceinline__ float prelu_f(float v, float a) { return v >= 0.f ? v : a * v; }

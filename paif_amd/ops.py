@@ -31,7 +31,8 @@ ACT_GELU = 1  # paif_gemm_fwd's act code 1 is GELU (the conv's code 1 is PReLU)
 # 1.8e-5 (f32) / 2.2e-5 (auto) / 4.2e-5 (bf16x3) against the reference's own fp32 floor of 3.8e-5, argmax agreement 100 % in all three.
 # With the round-2 kernels split-bf16 is the faster GEMM for every shape without split-K (tools/gemm_shapes_b16.py: another ~2 % on
 # configs[2]); "auto" keeps K < 256 exact because that is what keeps the default inside the reference's own fp32 noise floor.
-CONFIG = {"conv_precision": "bf16x3", "gemm_precision": "auto"}
+CONFIG = {"conv_precision": "bf16x3", "gemm_precision": "auto", "serpentine": True}
+_SERP = [0]    # tile-direction parity of the next dense-conv launch
 _PREC_CODE = {"f32": 0, "bf16x3": 1}
 
 
@@ -397,6 +398,9 @@ def conv2d(srcs, wpk, kh, dil=1, cin=32, cout=32, in_act=ACT_NONE, in_prelu=None
     aux = torch.empty_like(out) if want_aux else None
     d.aux_out, d.in_aux, d.in_scale, d.in_alpha = _p(aux), _p(in_aux), _p(in_scale), in_alpha
     d.epi_aux, d.epi_dact = _p(epi_aux), epi_dact
+    if CONFIG.get("serpentine", True):     # consecutive dense-conv launches walk their tiles in opposite directions (paif_hip.h)
+        _SERP[0] ^= 1
+        d.reverse_tiles = _SERP[0]
     e0 = None
     if TIMER is not None:   # name the kernel this launch takes, as rocprofv3 will list it
         tag = conv2d_kernel_name(d, B, H, W)
