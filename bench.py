@@ -33,6 +33,7 @@ import torch  # noqa: E402
 H, W, B_PER_GPU = 480, 640, 8
 MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: "Peak FP32 (matrix) 157.3 TFLOPS"
 HBM_PEAK_GBS = 8000.0             # same guide: "HBM3E peak BW 8.0 TB/s spec" (6.29 TB/s measured float4 copy)
+SPLIT_BF16_PEAK_TFLOPS = 2500.0 / 3   # same guide: bf16 MFMA ~2.5 PF dense; a split-bf16 product costs 3 bf16 MFMAs
 # dominant kernel = the 3x3 dense convs: 76 % of the fusion FLOPs
 
 
@@ -54,8 +55,10 @@ def main():
                          "event path on one GPU; needs the torch.distributed.run environment")
     ap.add_argument("--attack-iters", type=int, default=5, help="PGD iterations inside the training step (robust_test.py:42 default)")
     ap.add_argument("--backbone", default="mit_b3")
-    ap.add_argument("--cpu-baseline-full", action="store_true", help="BASELINE.md 3b protocol for both batch sizes (3 warm-up + 5 timed at "
-                    "B=1 and B=8: several minutes of CPU time); default = that protocol at B=1, one timed forward at B=8")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="fusion workload: the BASELINE.md 3b protocol (3 warm-up + 5 "
+                    "timed) at B=8 as well as at B=1 (several minutes of CPU time); default = B=1 only")
+    ap.add_argument("--sustain-seconds", type=float, default=3.0,
+                    help="after the K timed steps, loop the same step for at least this long and report `sustained_value` (0 = skip)")
     ap.add_argument("--graph", action="store_true",
                     help="fusion / fusion_seg: replay one captured hipGraph per step in the timed region (the clean-eval harness's default "
                          "mode).  `value` is then the graph-replay rate; the roofline blocks come from an eager, HIP-event-instrumented pass of "
@@ -141,6 +144,8 @@ def main():
             ops.DROP_RNG.reseed(20261003, rank=rank, step=state["step"])
             opt.zero_grad()
             loss = net._loss_coupled((ops.add(ir, d_ir.detach()), ir), (ops.add(vis, d_vis.detach()), vis), mask, lab)
+            if reducer is not None:
+                reducer.begin()          # armed for THIS backward only (the attack's reverse passes above never mark milestones)
             loss.backward()
             if reducer is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -207,6 +212,19 @@ def main():
     assert torch.isfinite(out).all()
     from paif_amd.dist_utils import max_over_ranks
     dt = max_over_ranks(dt, dist, dev)
+    # sustained pass: the K timed steps above last ~0.15 s on the headline workload -- a burst right after an
+    # idle period, the most favourable thermal / power state.  The same step is then looped for >= --sustain-seconds (default 3 s)
+    # and reported as `sustained_value`; `value` stays the contract's K-step figure.
+    sustained = None
+    if args.sustain_seconds > 0 and not args.graph:
+        n_s = int(args.sustain_seconds / max(dt / args.steps, 1e-6)) + 1
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(n_s):
+            step()
+        barrier()
+        dts = max_over_ranks(time.perf_counter() - t1, dist, dev)
+        sustained = (n_s, dts)
 
     if rank == 0:
         pairs = bpg * world * args.steps
@@ -235,8 +253,13 @@ def main():
             tf, gb = fl_ / (ms_ * 1e-3) / 1e12, by_ / (ms_ * 1e-3) / 1e9
             if (tag.startswith("conv_") or tag.startswith("dense conv")) and "bf16x3" in tag:
                 # split-bf16 convs: 3 bf16 MFMA passes -> effective matrix peak 2500/3 = 833 TF algorithmic; at 72-108 FLOP/B
-                # (fp32 storage) the HBM roof binds (833e12 / 8e12 = 104 FLOP/B)
-                blk = {"bound": "hbm", "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS, "algorithmic_tflops": tf}
+                # (fp32 storage, k <= 3) the HBM roof binds (833e12 / 8e12 = 104 FLOP/B); the 5x5 / 7x7 convs (K = 800 / 1568:
+                # 200-390 FLOP/B) are matrix-pipe bound and are priced against the 833 TF algorithmic peak
+                if fl_ / max(by_, 1) > SPLIT_BF16_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
+                    blk = {"bound": "mfma", "achieved": tf, "peak": SPLIT_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / SPLIT_BF16_PEAK_TFLOPS,
+                           "algorithmic_gbs": gb, "note": "split-bf16: 3 bf16 MFMAs per product -> 2500/3 TF algorithmic peak"}
+                else:
+                    blk = {"bound": "hbm", "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS, "algorithmic_tflops": tf}
             elif tag.startswith("gf_"):
                 blk = {"bound": "hbm", "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS, "algorithmic_tflops": tf,
                        "note": "VALU-issue bound (two 9x9 box-filter stages per pixel-channel), see DESIGN.md"}
@@ -244,7 +267,7 @@ def main():
                 blk = {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS}
             else:
                 # GEMMs / attention, aggregated over all shapes of the step: report against the roof that binds the aggregate
-                peak_tf = MFMA_F32_PEAK_TFLOPS if not tag.endswith("bf16x3") else 2500.0 / 3
+                peak_tf = MFMA_F32_PEAK_TFLOPS if not tag.endswith("bf16x3") else SPLIT_BF16_PEAK_TFLOPS
                 f_m, f_h = tf / peak_tf, gb / HBM_PEAK_GBS
                 if f_m >= f_h:
                     blk = {"bound": "mfma", "achieved": tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": f_m, "algorithmic_gbs": gb}
@@ -284,6 +307,8 @@ def main():
         except (OSError, ValueError, KeyError) as e:
             traffic_note = "pmc_traffic.json unreadable: %s" % e
         roof["traffic"] = traffic
+        roof["traffic_source"] = ("profiles/pmc_traffic.json: rocprofv3 --pmc passes of this same command run by the builder (tools/pmc_traffic.py), "
+                                  "tied to the kernel-source hash; PMC counters cannot be read inside an un-profiled run")
         if traffic_note:
             roof["traffic_note"] = traffic_note
         others = [roof_block(k) for k in sorted(summ, key=lambda k: -summ[k][1]) if k != DOM][:4]
@@ -317,8 +342,12 @@ def main():
             res["steps_per_s"] = args.steps / dt
             if state.get("events"):
                 res["allreduce_exposed_ms_per_step"] = sum(a.elapsed_time(b) for a, b in state["events"][-args.steps:]) / args.steps
-        if world == 1 and not args.no_cpu_baseline and args.workload == "fusion":
-            res["cpu_baseline"] = cpu_baseline(ir_np, vis_np, args.cpu_baseline_full)
+        if sustained is not None:
+            res["sustained_value"] = bpg * world * sustained[0] / sustained[1]
+            res["sustained"] = {"steps": sustained[0], "seconds": sustained[1], "ms_per_step": sustained[1] / sustained[0] * 1e3,
+                                "note": "the same step looped for >= %.0f s right after the timed region; `value` is the K-step figure" % args.sustain_seconds}
+        if world == 1 and not args.no_cpu_baseline and args.workload in ("fusion", "fusion_seg", "pgd"):
+            res["cpu_baseline"] = cpu_baseline(args.workload, ir_np, vis_np, lab_np, args.cpu_baseline_full, args.backbone)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
@@ -357,46 +386,89 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(ir_np, vis_np, full=False):
+def cpu_baseline(workload, ir_np, vis_np, lab_np, full=False, backbone="mit_b3"):
     """The CPU oracle (fp32 torch port of the reference's path, pinned to the reference by tests/test_oracle_golden.py) on the
-    host cores this job may use.  BASELINE.md 3b protocol: 3 warm-up + 5 timed forwards at B=1; B=8 gets the same protocol
-    with --cpu-baseline-full, otherwise ONE timed forward (it costs ~8x a B=1 forward and the default run must stay within
-    minutes).  value = best-B pairs/s."""
+    host cores this job may use, for the workload being benchmarked ((i) fusion forward, (ii) fusion + seg
+    forward, (iii) PGD-10).  Bounded samples, all at B=1 (the reference's own harness batch size, test_original.py:111):
+      fusion      3 warm-up + 5 timed forwards (the 3b protocol); --cpu-baseline-full adds the same protocol at B=8
+      fusion_seg  1 warm-up + 3 timed forwards of fusion + mit_b3
+      pgd         ONE timed PGD iteration (forward + input-gradient backward through both networks, after one warm-up
+                  iteration) and one timed forward; a PGD-10 evaluation of a pair = 10 iterations + 1 forward, so
+                  value = 1 / (10 * t_iter + t_fwd)  (a full PGD-10 pair costs ~1-2 minutes on these cores)"""
     from oracle import paif_oracle as O
     from paif_amd import synthetic as S
-    from paif_amd.core.model_fusion_auto import Network_Fusion_Searched
+    from paif_amd.core.model_fusion_auto import Network_Fusion_Searched, Network_MM_Searched
     from paif_amd.genotypes import FUSION_AT
 
     cores = host_cores()
     torch.set_num_threads(cores)
-    net = Network_Fusion_Searched(32, None, FUSION_AT)
+    logical = os.cpu_count() or 0
+    base = {"unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port", "cpu_model": cpu_model(), "logical_cpus": logical,
+            "cpu_quota": cores}
+    env = "torch %s CPU, %d threads (= the job's CPU quota on a host with %d logical CPUs)" % (torch.__version__, torch.get_num_threads(), logical)
+    if workload == "fusion":
+        net = Network_Fusion_Searched(32, None, FUSION_AT)
+        S.load_formula_weights(net)
+        sd = {k: v.clone() for k, v in net.state_dict().items()}
+
+        def rate(B, warm, reps):
+            ir, vis = torch.from_numpy(ir_np[:B]), torch.from_numpy(vis_np[:B])
+
+            def fwd():
+                with torch.no_grad():
+                    ycc = O.rgb2ycrcb(vis)
+                    return O.fusion_forward(ir, ycc[:, 0:1], sd)
+
+            for _ in range(warm):
+                fwd()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fwd()
+            return B * reps / (time.perf_counter() - t0)
+
+        by = {"1": rate(1, 3, 5)}
+        if full:
+            by["8"] = rate(8, 3, 5)
+        base.update({"value": max(by.values()), "by_batch": by,
+                     "sample": "oracle fusion forward %dx%d fp32, %s; 3 warm-up + 5 timed forwards at B=1%s" % (
+                         ir_np.shape[2], ir_np.shape[3], env, " and at B=8; value = best batch size" if full else "")})
+        return base
+    net = Network_MM_Searched(32, FUSION_AT, None, None, backbone, num_classes=9)
     S.load_formula_weights(net)
     sd = {k: v.clone() for k, v in net.state_dict().items()}
+    ir, vis, lab = torch.from_numpy(ir_np[:1]), torch.from_numpy(vis_np[:1]), torch.from_numpy(lab_np[:1])
 
-    def rate(B, warm, reps):
-        ir, vis = torch.from_numpy(ir_np[:B]), torch.from_numpy(vis_np[:B])
+    def fwd_time(warm, reps):
+        with torch.no_grad():
+            for _ in range(warm):
+                O.model_forward(ir, vis, sd, backbone)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                O.model_forward(ir, vis, sd, backbone)
+        return (time.perf_counter() - t0) / reps
 
-        def fwd():
-            with torch.no_grad():
-                ycc = O.rgb2ycrcb(vis)
-                return O.fusion_forward(ir, ycc[:, 0:1], sd)
-
-        for _ in range(warm):
-            fwd()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            fwd()
-        return B * reps / (time.perf_counter() - t0)
-
-    r1 = rate(1, 3, 5)
-    r8 = rate(8, 3, 5) if full else rate(8, 0, 1)
-    logical = os.cpu_count() or 0
-    return {"value": max(r1, r8), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "by_batch": {"1": r1, "8": r8},
-            "cpu_model": cpu_model(), "logical_cpus": logical, "cpu_quota": cores,
-            "sample": "oracle fusion forward 480x640 fp32, torch %s CPU, %d threads (= the job's CPU quota on a host with %d logical CPUs); "
-                      "B=1: 3 warm-up + 5 timed; B=8: %s; value = best batch size" % (
-                          torch.__version__, torch.get_num_threads(), logical, "3 warm-up + 5 timed" if full else "1 timed forward, no warm-up")}
+    if workload == "fusion_seg":
+        tf = fwd_time(1, 3)
+        base.update({"value": 1.0 / tf, "seconds_per_pair": tf,
+                     "sample": "oracle fusion + %s SegFormer forward %dx%d fp32 at B=1, %s; 1 warm-up + 3 timed forwards" % (
+                         backbone, ir_np.shape[2], ir_np.shape[3], env)})
+        return base
+    # pgd: one attack iteration = forward + backward w.r.t. the inputs (the oracle's autograd; the reference additionally
+    # fills .grad of all 44.9 M parameters, attack/attack.py:501 -- not charged to it here)
+    eps = 8 / 255.
+    d0i = torch.from_numpy(S.make_delta0(0, ir_np[:1].shape, eps))
+    d0v = torch.from_numpy(S.make_delta0(100, vis_np[:1].shape, eps))
+    fwd = lambda a, b: O.model_forward(a, b, sd, backbone)
+    O.attack_both(fwd, vis, ir, lab, d0i, d0v, eps, 2 / 255., 1, "PGD")          # warm-up iteration
+    t0 = time.perf_counter()
+    O.attack_both(fwd, vis, ir, lab, d0i, d0v, eps, 2 / 255., 1, "PGD")
+    t_iter = time.perf_counter() - t0
+    tf = fwd_time(0, 1)
+    base.update({"value": 1.0 / (10 * t_iter + tf), "seconds_per_iteration": t_iter, "seconds_per_forward": tf,
+                 "sample": "oracle PGD at %dx%d fp32, B=1, %s, %s: ONE timed attack iteration (forward + input-gradient backward; one warm-up "
+                           "iteration before it) + one timed forward; value = 1 / (10 iterations + 1 forward)" % (
+                               ir_np.shape[2], ir_np.shape[3], backbone, env)})
+    return base
 
 
 if __name__ == "__main__":

@@ -311,6 +311,23 @@ int paif_upsample_ce_fwd(const float* logits, const long long* label, float* par
 int paif_upsample_ce_bwd(const float* logits, const long long* label, const float* gscale, float* dfull, int B, int IH,
                          int IW, int C, int OH, int OW, int ignore_index, int CP, paif_stream_t stream);
 
+/* The loss glue of the attack variants (attack/attack.py:447-499, the `attack_way` branches of attack_both :447-499, seg_pgd
+ * :335-350, cos_pgd :393-399) on bilinearly upsampled logits, value and gradient w.r.t. the full-resolution logits:
+ *   way 0  PGD     loss = CE(o, label)                                  (= paif_upsample_ce_*; also serves 'newPGD', whose factor
+ *                                                                         cos/cos is exactly 1 with an identically zero gradient)
+ *   way 1  segPGD  loss = w_true * CE(t*o, label) + w_false * CE((1-t)*o, label),  t = (max_c o == label)  [float vs integer, as the
+ *                  reference compares them];  w_true = 1 - lambda, w_false = lambda, lambda = (i-1)/(2*iters)
+ *   way 2  cosPGD  loss = cosine_similarity(max_c o, label over ALL pixels) * CE(o, label)
+ * fwd: partial = 5 * paif_attack_loss_blocks floats of scratch; coef[8] (device) = {loss, #valid, CE, cos, a, bl, bp, 0}.
+ * bwd: dfull [B,OH,OW,CP] = upstream * d loss / d o (CP >= C, CP % 4 == 0, zero padded), reads coef written by fwd; follow with
+ *      paif_resize_bilinear_adjoint_fwd to get dlogits.  Deterministic (fixed-order reductions, no float atomics). */
+int paif_attack_loss_blocks(int B, int OH, int OW);
+int paif_attack_loss_fwd(const float* logits, const long long* label, float* partial, float* coef, int way, float w_true,
+                         float w_false, int B, int IH, int IW, int C, int OH, int OW, int ignore_index, paif_stream_t stream);
+int paif_attack_loss_bwd(const float* logits, const long long* label, const float* coef, float* dfull, int way, float w_true,
+                         float w_false, float upstream, int B, int IH, int IW, int C, int OH, int OW, int ignore_index, int CP,
+                         paif_stream_t stream);
+
 /* ---- fusion-network dgrad helpers (dense-conv dgrads go through paif_conv2d_fwd with these weights and the
  * in_act 3/4/5, epi_dact hooks of paif_conv_desc) ---- */
 /* forward w [Co,Ctot,k,k] -> dgrad weight w.r.t. source channels [coff,coff+cs): wt [cs,Co,k,k],

@@ -494,6 +494,14 @@ def attack_loss_value(outputs, label, attack_way, i, attack_iters):
         _label = torch.squeeze(label).flatten()
         cossim = F.cosine_similarity(pred, _label, dim=0)
         return cossim * seg_loss(outputs, label)
+    if attack_way == "newPGD":
+        # attack/attack.py:472-499: pred_t and pred_f are both overwritten with max_c(outputs) (:486-492), so the factor is
+        # cos/cos of the SAME vector: exactly 1 in value, and autograd's two gradient terms cancel to rounding noise
+        pred = torch.squeeze(torch.max(outputs, 1).values.unsqueeze(1)).flatten()
+        _label = torch.squeeze(label).flatten()
+        cos_t = F.cosine_similarity(pred, _label, dim=0)
+        cos_f = F.cosine_similarity(pred, _label, dim=0)
+        return (cos_t / cos_f) * seg_loss(outputs, label)
     raise KeyError(attack_way)
 
 

@@ -92,6 +92,9 @@ SIGNATURES = {
     "paif_sr_attention_bwd_input_p": (c_int, [F, F, F, F, F, F, F, F, F, c_int, c_int, c_int, c_int, c_int, c_int, F]),
     "paif_upsample_ce_blocks": (c_int, [c_int, c_int, c_int]),
     "paif_upsample_ce_fwd": (c_int, [F, F, F, F, c_int, c_int, c_int, c_int, c_int, c_int, c_int, F]),
+    "paif_attack_loss_blocks": (c_int, [c_int, c_int, c_int]),
+    "paif_attack_loss_fwd": (c_int, [F, F, F, F, c_int, c_float, c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_int, F]),
+    "paif_attack_loss_bwd": (c_int, [F, F, F, F, c_int, c_float, c_float, c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, F]),
     "paif_conv_weight_dgrad": (c_int, [F, F, c_int, c_int, c_int, c_int, c_int, F]),
     "paif_fold_decomp1x1_weight": (c_int, [F, F, F]),
     "paif_tail_bwd_input": (c_int, [F, F, F, F, F, F, c_int, c_int, c_int, F]),

@@ -8,10 +8,11 @@ Same signatures and return values.  Semantics reproduced on purpose (SURVEY.md 3
 Not reproduced: the reference also leaves .grad on all 44.9 M model parameters (wasted weight gradients);
 here only input gradients are computed.
 
-attack_way='PGD' (the only branch either entry script uses) runs entirely on hand-written HIP kernels: model forward with
-a tape, fused bilinear-upsample + CrossEntropy forward/backward, hand-written reverse pass, fused PGD update.
-'segPGD' / 'cosPGD' / 'newPGD' build their masked losses with torch ops on top of the HIP model (autograd node
-_CompositeFn) -- SURVEY.md 8(f) rank-2 rows.
+Every attack_way ('PGD' -- the only branch either entry script uses -- 'segPGD', 'cosPGD', 'newPGD') runs entirely on
+hand-written HIP kernels: model forward with a tape, the variant's loss on the bilinearly upsampled logits and its gradient
+(paif_attack_loss_fwd / _bwd: masked CE terms of segPGD, cosine factor of cosPGD incl. its own gradient through max_c),
+hand-written reverse pass, fused PGD update.  A user model without `forward_taped` (not one of ours) goes through autograd
+with the same HIP loss node.
 """
 import torch
 import torch.nn as nn
@@ -41,27 +42,10 @@ class Seg_loss(nn.Module):
         return ops.upsample_ce(outputs, labels.type(torch.long).contiguous(), ignore_index=255)
 
 
-def _loss_variant(outputs, label, criterion, attack_way, i, attack_iters):
-    """attack/attack.py:447-499 (torch ops; the model underneath is the HIP autograd node)."""
-    if attack_way == 'PGD':
-        return criterion(outputs, label)
-    if attack_way == 'segPGD':
-        lamb = (i - 1) / (attack_iters * 2)
-        pred = torch.unsqueeze(torch.max(outputs, 1).values, 1)
-        np_mask_t = torch.unsqueeze(torch.squeeze(pred == torch.unsqueeze(label, 1), 1).int(), 1)
-        np_mask_f = torch.unsqueeze(torch.squeeze(pred != torch.unsqueeze(label, 1), 1).int(), 1)
-        return (1 - lamb) * criterion(np_mask_t * outputs, label) + lamb * criterion(np_mask_f * outputs, label)
-    if attack_way == 'cosPGD':
-        pred = torch.squeeze(torch.max(outputs, 1).values).flatten()
-        _label = torch.squeeze(label).flatten()
-        return F.cosine_similarity(pred, _label, dim=0) * criterion(outputs, label)
-    if attack_way == 'newPGD':
-        pred = torch.squeeze(torch.max(outputs, 1).values).flatten()
-        _label = torch.squeeze(label).flatten()
-        cos_t = F.cosine_similarity(pred, _label, dim=0)
-        cos_f = F.cosine_similarity(pred, _label, dim=0)   # the reference overwrites pred_t / pred_f with the same tensor (:486-492)
-        return (cos_t / cos_f) * criterion(outputs, label)
-    raise NameError("loss")   # the reference leaves `loss` unbound for an unknown attack_way
+def _loss_variant(seg_map, label, attack_way, i, attack_iters):
+    """attack/attack.py:445-499 on the LOW-resolution seg_map: F.interpolate(..., bilinear) + the attack_way branch, as one HIP
+    autograd node (ops.AttackLoss)."""
+    return ops.attack_loss(seg_map, label, attack_way, i, attack_iters)
 
 
 def _init_delta(X, epsilon, delta0):
@@ -85,7 +69,8 @@ def _attack(model, X_vis, X_ir, label, epsilon, alpha, attack_iters, restarts, a
     X_vis = X_vis.contiguous().float()
     X_ir = X_ir.contiguous().float()
     label = label.contiguous()
-    fast = attack_way == 'PGD' and attack_loss == 'l_seg' and hasattr(model, "forward_taped")
+    fast = attack_loss == 'l_seg' and hasattr(model, "forward_taped")
+    lab64 = label.type(torch.long).contiguous()
     for _ in range(restarts):
         d_ir = _init_delta(X_ir, epsilon, delta0_ir) if do_ir else torch.zeros_like(X_ir)
         d_vis = _init_delta(X_vis, epsilon, delta0_vis) if do_vis else torch.zeros_like(X_vis)
@@ -95,18 +80,20 @@ def _attack(model, X_vis, X_ir, label, epsilon, alpha, attack_iters, restarts, a
             if fast:
                 with torch.no_grad():
                     _, logits, tape = model.forward_taped(ops.add(X_ir, d_ir), ops.add(X_vis, d_vis))
-                    lc = ops.upsample_ce_fwd(logits, label.type(torch.long))
-                    gscale = torch.reciprocal(lc[1:2])          # d(mean NLL)/d(sum) = 1/#valid  (1-element tensor)
-                    d32 = ops.upsample_ce_bwd(logits, label.type(torch.long), gscale)
+                    way, wt, wf = ops.attack_loss_weights(attack_way, i, attack_iters)
+                    coef = ops.attack_loss_fwd(logits, lab64, way, wt, wf)    # loss + the backward's scalars, on the device
+                    d32 = ops.attack_loss_bwd(logits, lab64, coef, way, wt, wf)
                     gi, gv = model.backward_taped(d32, tape)
-                    loss = lc[0]
+                    loss = coef[0]
             else:
                 xi = ops.add(X_ir, d_ir).requires_grad_(True)
                 xv = ops.add(X_vis, d_vis).requires_grad_(True)
                 with torch.enable_grad(), ops.no_param_grads():
                     _, seg_map = model(xi, xv)
-                    outputs = F.interpolate(seg_map, size=label.shape[1:], mode='bilinear', align_corners=False)
-                    loss = _loss_variant(outputs, label, criterion, attack_way, i, attack_iters)
+                    if attack_loss == 'l_seg':
+                        loss = _loss_variant(seg_map, label, attack_way, i, attack_iters)
+                    else:   # 'l_2' (nn.MSELoss on the upsampled map against the label, :424-425): a user criterion, torch ops
+                        loss = criterion(F.interpolate(seg_map, size=label.shape[1:], mode='bilinear', align_corners=False), label)
                 gi, gv = torch.autograd.grad(loss, [xi, xv])
             with torch.no_grad():
                 if do_ir:
@@ -189,8 +176,8 @@ def _fresh_grad_attack(model, X_vis, X_ir, X_fusion, label, epsilon, alpha, atta
 
 def _image_or_seg_loss(attack_loss, X_vis, X_fusion, label, sign=1.0):
     if attack_loss == 'l_seg':
-        crit = Seg_loss()
-        return lambda fused, seg, i: crit(F.interpolate(seg, size=label.shape[1:], mode='bilinear', align_corners=False), label)
+        # Seg_loss on the upsampled map (:134-135): the fused HIP upsample + CE node takes the low-resolution map directly
+        return lambda fused, seg, i: ops.upsample_ce(seg, label.type(torch.long), ignore_index=255)
     if attack_loss == 'l_2':
         crit = nn.MSELoss()
     elif attack_loss == 'l_1':
@@ -230,11 +217,8 @@ def pgd_attack_vision(model, X_vis, X_ir, X_fusion, label, epsilon=8 / 255., alp
 def seg_pgd(model, X_vis, X_ir, X_fusion, label, epsilon=8 / 255., alpha=2 / 255., attack_iters=50, restarts=1,
             attack_loss='l_seg', attack_mode='vis', delta0=None):
     """attack/attack.py:307-365."""
-    crit = Seg_loss()
-
     def loss_fn(fused, seg, i):
-        outputs = F.interpolate(seg, size=label.shape[1:], mode='bilinear', align_corners=False)
-        return _loss_variant(outputs, label, crit, 'segPGD', i, attack_iters)
+        return _loss_variant(seg, label, 'segPGD', i, attack_iters)
 
     return _fresh_grad_attack(model, X_vis, X_ir, X_fusion, label, epsilon, alpha, attack_iters, restarts,
                               'vis' if attack_mode == 'vis' else 'ir', loss_fn, delta0)
@@ -243,11 +227,8 @@ def seg_pgd(model, X_vis, X_ir, X_fusion, label, epsilon=8 / 255., alpha=2 / 255
 def cos_pgd(model, X_vis, X_ir, X_fusion, label, epsilon=8 / 255., alpha=2 / 255., attack_iters=50, restarts=1,
             attack_loss='l_seg', attack_mode='vis', delta0=None):
     """attack/attack.py:368-411."""
-    crit = Seg_loss()
-
     def loss_fn(fused, seg, i):
-        outputs = F.interpolate(seg, size=label.shape[1:], mode='bilinear', align_corners=False)
-        return _loss_variant(outputs, label, crit, 'cosPGD', i, attack_iters)
+        return _loss_variant(seg, label, 'cosPGD', i, attack_iters)
 
     return _fresh_grad_attack(model, X_vis, X_ir, X_fusion, label, epsilon, alpha, attack_iters, restarts,
                               'vis' if attack_mode == 'vis' else 'ir', loss_fn, delta0)

@@ -273,7 +273,8 @@ class Block(nn.Module):
         if wgrad:
             _ln_wgrad(self.norm1, t["x"], d_ln1)
         d_x = ops.layernorm_bwd(t["x"], self.norm1.weight, d_ln1, self.norm1.eps, add=d_x1)
-        ops.grads_ready(self)
+        if wgrad:
+            ops.grads_ready(self)
         return d_x
 
 
@@ -326,7 +327,8 @@ class OverlapPatchEmbed(nn.Module):
         if wgrad:
             _conv_as_gemm_wgrad(self.proj, d_pre, ops.im2col(t["x_in"], k, self.stride, k // 2, w.shape[1]))
         d_col = ops.gemm(d_pre, wt)
-        ops.grads_ready(self)
+        if wgrad:
+            ops.grads_ready(self)
         return ops.col2im(d_col, B, H, W, Cin, k, self.stride, k // 2)
 
 

@@ -361,7 +361,8 @@ class Network_Fusion_Searched(nn.Module):
                     ops.stem_wgrad(img, d_f, stem[0].weight, stem[1].weight, gw, gs)
         d_ir = ops.stem_bwd(d_fir, t["fir"], self.stem_1[0].weight, self.stem_1[1].weight)
         d_y = ops.stem_bwd(d_fvis, t["fvis"], self.stem_2[0].weight, self.stem_2[1].weight)
-        ops.grads_ready(self)
+        if wgrad:
+            ops.grads_ready(self)
         return d_ir, d_y
 
     def _loss(self, ir, vis, mask):

@@ -127,7 +127,6 @@ class SegFormerHead(nn.Module):
                                                                                self.linear_c1)[i].proj.weight],
                                  lambda i=i: ops.transpose_pad(M[i]))
             grads[idx] = ops.gemm(d_z, mt)
-        ops.grads_ready(self)
         return grads
 
     def backward_nhwc(self, d_logits, tape, wgrad=False):
@@ -178,7 +177,8 @@ class SegFormerHead(nn.Module):
                 ops.gemm_wgrad(d_cat, tape["feats"][0], out_w=gw, out_b=gb, n=E, dy_col0=3 * E)
         l1t = self._packs.get("linT0", [self.linear_c1.proj.weight], lambda: ops.transpose_pad(self.linear_c1.proj.weight))
         grads[0] = ops.gemm(d_cat, l1t, a_cols=(3 * E, E))
-        ops.grads_ready(self)
+        if wgrad:
+            ops.grads_ready(self)
         return grads
 
     def forward(self, x):

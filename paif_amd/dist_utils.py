@@ -46,7 +46,8 @@ class GradAllReduce:
 
     The arena is laid out in backward-completion order (assign_grad_order), so a bucket = one contiguous slice, and buckets
     become ready front to back.  The reverse pass calls ops.grads_ready(module) whenever a milestone module's parameter
-    gradients are final; `mark_ready` then launches -- on a side stream, behind an event recorded on the compute stream --
+    gradients are final (wgrad passes only -- the attacks' input-gradient passes never do); between `begin()` and `finish()`
+    `mark_ready` then launches -- on a side stream, behind an event recorded on the compute stream --
     every bucket that is now complete.  `finish()` (after loss.backward()) launches what is left and makes the compute
     stream wait for all of them; gradients end up AVERAGED over the ranks.  Parameters flagged `_paif_never_grad` sit in
     the arena's tail and are never communicated (the DDP analogue would need find_unused_parameters).
@@ -86,6 +87,7 @@ class GradAllReduce:
             milestones = grad_milestones(model)
         self.module_params = {id(m): [p for p in m.parameters() if id(p) in arena.range_of] for m in (milestones or [])}
         self.side = torch.cuda.Stream(device=arena.grad.device) if self.cuda else None
+        self.armed = False
         self.reset()
 
     def reset(self):
@@ -93,6 +95,14 @@ class GradAllReduce:
         self.next_bucket = 0
         self.works = []
         self.launched = []          # (start, end) in launch order -- inspected by the tests
+
+    def begin(self):
+        """Arm the reducer for ONE training backward: call right before `loss.backward()`.  Milestones that arrive while
+        it is not armed (an attack's input-gradient-only reverse pass, a stray call between steps) are ignored, so a bucket
+        can never leave before the wgrad kernels of THIS backward were queued."""
+        self.reset()
+        self.armed = True
+        return self
 
     def install(self):
         """Hook into the reverse pass (ops.grads_ready)."""
@@ -135,6 +145,8 @@ class GradAllReduce:
 
     def mark_ready(self, module):
         """The parameter gradients of `module` are final for this backward pass."""
+        if not self.armed:
+            return
         for p in self.module_params.get(id(module), ()):
             self.pending.discard(id(p))
         while self.next_bucket < len(self.buckets) and self._bucket_ready(self.next_bucket):
@@ -153,4 +165,5 @@ class GradAllReduce:
                 buf.mul_(1.0 / self.world)
         covered = sum(e - s for s, e in self.launched)
         assert covered == self.live_end and len(self.launched) == len(self.buckets), "a gradient bucket was skipped or sent twice"
+        self.armed = False
         self.reset()

@@ -964,6 +964,71 @@ class UpsampleCE(torch.autograd.Function):
         return nhwc_slice_to_nchw(d32, logits.shape[-1]), None, None
 
 
+ATTACK_WAYS = {"PGD": 0, "newPGD": 0, "segPGD": 1, "cosPGD": 2}
+
+
+def attack_loss_weights(attack_way, i, attack_iters):
+    """(way code, w_true, w_false) of attack/attack.py:447-499.  segPGD: lambda = (i-1)/(2*iters) (:450);
+    newPGD: cos_t / cos_f with pred_t == pred_f (:486-492) is exactly 1 and its gradient identically 0 -> the PGD loss."""
+    if attack_way not in ATTACK_WAYS:
+        raise NameError("loss")   # the reference leaves `loss` unbound for an unknown attack_way
+    lamb = (i - 1) / (attack_iters * 2)
+    return (ATTACK_WAYS[attack_way], 1.0 - lamb, lamb) if attack_way == "segPGD" else (ATTACK_WAYS[attack_way], 1.0, 1.0)
+
+
+def attack_loss_fwd(logits, label, way, w_true=1.0, w_false=1.0, ignore_index=255):
+    """logits NHWC [B,IH,IW,C], label int64 [B,OH,OW] -> coef tensor [8]: (loss, #valid, CE, cos, ...) -- paif_attack_loss_fwd."""
+    B, IH, IW, C = logits.shape
+    _, OH, OW = label.shape
+    assert label.dtype == torch.int64 and label.is_cuda and label.is_contiguous()
+    L = lib()
+    nblk = L.paif_attack_loss_blocks(B, OH, OW)
+    partial = torch.empty(5 * nblk, device=logits.device, dtype=torch.float32)
+    coef = torch.empty(8, device=logits.device, dtype=torch.float32)
+    _lib.check(L.paif_attack_loss_fwd(_p(logits), ctypes.c_void_p(label.data_ptr()), _p(partial), _p(coef), way, w_true, w_false,
+                                      B, IH, IW, C, OH, OW, ignore_index, _stream()), "attack_loss_fwd")
+    return coef
+
+
+def attack_loss_bwd(logits, label, coef, way, w_true=1.0, w_false=1.0, upstream=1.0, cp=32, ignore_index=255):
+    """-> d loss / d logits NHWC [B,IH,IW,cp] (channels >= C zero)."""
+    B, IH, IW, C = logits.shape
+    _, OH, OW = label.shape
+    dfull = torch.empty((B, OH, OW, cp), device=logits.device, dtype=torch.float32)
+    _lib.check(lib().paif_attack_loss_bwd(_p(logits), ctypes.c_void_p(label.data_ptr()), _p(coef), _p(dfull), way, w_true, w_false,
+                                          float(upstream), B, IH, IW, C, OH, OW, ignore_index, cp, _stream()), "attack_loss_bwd")
+    return resize_bilinear_adjoint(dfull, 0, cp, IH, IW)
+
+
+class AttackLoss(torch.autograd.Function):
+    """The segPGD / cosPGD losses on F.interpolate(seg_map, label.shape[1:], bilinear) as the fused HIP kernels
+    paif_attack_loss_fwd / _bwd (autograd node for the fresh-gradient attacks seg_pgd / cos_pgd, attack/attack.py:307-411)."""
+
+    @staticmethod
+    def forward(ctx, seg_map, label, way, w_true, w_false):
+        logits = to_nhwc(seg_map.detach())
+        coef = attack_loss_fwd(logits, label, way, w_true, w_false)
+        ctx.save_for_backward(logits, label, coef)
+        ctx.args = (way, w_true, w_false)
+        return coef[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, label, coef = ctx.saved_tensors
+        way, w_true, w_false = ctx.args
+        d32 = attack_loss_bwd(logits, label, coef, way, w_true, w_false, upstream=float(g))
+        return nhwc_slice_to_nchw(d32, logits.shape[-1]), None, None, None, None
+
+
+def attack_loss(seg_map, label, attack_way, i, attack_iters):
+    """seg_map [B,C,h,w] (low resolution), label int64 [B,H,W] -> the attack variant's loss (differentiable w.r.t. seg_map)."""
+    way, wt, wf = attack_loss_weights(attack_way, i, attack_iters)
+    label = label.contiguous().type(torch.long)
+    if torch.is_grad_enabled() and seg_map.requires_grad:
+        return AttackLoss.apply(seg_map, label, way, wt, wf)
+    return attack_loss_fwd(to_nhwc(seg_map.detach()), label, way, wt, wf)[0]
+
+
 def upsample_ce(seg_map, label, ignore_index=255):
     """seg_map [B,C,h,w] (any strides), label int64 [B,H,W] -> mean NLL over the valid pixels (differentiable w.r.t. seg_map)."""
     label = label.contiguous()

@@ -9,7 +9,10 @@ paif_amd.dist_utils.GradAllReduce works on (contiguous buckets, in the order the
 
 Semantics kept from torch.optim.AdamW (single-tensor path, eps 1e-8, no amsgrad / maximize): parameters whose .grad is
 None are skipped (no weight decay either) -- `classifier.weight` and `decompation.relu.weight` never receive a gradient;
-the step count used for the bias corrections is the number of step() calls.
+the step count used for the bias corrections is PER PARAMETER (torch's state['step']: it advances only on the steps where
+that parameter has a gradient) -- parameters at different counts are updated by separate launches of the same kernel;
+`state_dict()` / `load_state_dict()` carry exp_avg / exp_avg_sq / step per parameter in torch.optim.AdamW's own layout
+(sliced from / copied into the arenas), so checkpoints move both ways between this class and the reference's.
 """
 import ctypes
 import math
@@ -100,8 +103,9 @@ class PolyWarmupAdamW(torch.optim.AdamW):
         self.power = power
         self.__init_lr = [group['lr'] for group in self.param_groups]
         self._arena = None
-        self._cg_cache = (None, None)
-        self._adam_t = 0            # torch's per-parameter state['step']: counts step() calls, independent of global_step
+        self._cg_cache = {}
+        self._steps = None          # torch's per-parameter state['step'] (int64 per arena entry), independent of global_step
+        self._pending_state = None  # a state_dict loaded before the arenas exist
         if len(self.param_groups) > 8:
             raise NotImplementedError("PolyWarmupAdamW: at most 8 parameter groups (the reference uses 3)")
 
@@ -121,9 +125,73 @@ class PolyWarmupAdamW(torch.optim.AdamW):
                 raise RuntimeError("PolyWarmupAdamW: parameters must be on the GPU before the first zero_grad()/step() "
                                    "(there is no CPU optimizer path)")
             self._arena = ParamArena(arena_order(pairs))
+            self._steps = np.zeros(len(self._arena.entries), dtype=np.int64)
             from ..operations_m import invalidate_weight_caches
             invalidate_weight_caches()          # param.data moved
+            if self._pending_state is not None:
+                st, self._pending_state = self._pending_state, None
+                self._restore_state(st)
         return self._arena
+
+    # ---- checkpoint / resume: torch.optim.AdamW's layout (state[i] = {step, exp_avg, exp_avg_sq}, i = position in the
+    # flattened param_groups) -- the moments live in the arenas, not in self.state ----
+    def _flat_params(self):
+        return [p for g in self.param_groups for p in g['params']]
+
+    def state_dict(self):
+        flat = self._flat_params()
+        index = {id(p): i for i, p in enumerate(flat)}
+        groups, start = [], 0
+        for g in self.param_groups:
+            d = {k: v for k, v in g.items() if k != 'params'}
+            d['params'] = list(range(start, start + len(g['params'])))
+            start += len(g['params'])
+            groups.append(d)
+        state = {}
+        if self._pending_state is not None:
+            state = {i: dict(v, step=torch.tensor(float(v['step']))) for i, v in self._pending_state.items()}
+        elif self._arena is not None:
+            A = self._arena
+            for e, (p, _, o, n) in enumerate(A.entries):
+                if self._steps[e] > 0:
+                    state[index[id(p)]] = {'step': torch.tensor(float(self._steps[e])),
+                                           'exp_avg': A.m[o:o + n].view(p.shape).clone(),
+                                           'exp_avg_sq': A.v[o:o + n].view(p.shape).clone()}
+        return {'state': state, 'param_groups': groups}
+
+    def _restore_state(self, state):
+        A, flat = self._arena, self._flat_params()
+        pos = {id(p): e for e, (p, _, _, _) in enumerate(A.entries)}
+        A.m.zero_(); A.v.zero_(); self._steps[:] = 0
+        with torch.no_grad():
+            for i, st in state.items():
+                p = flat[int(i)]
+                if id(p) not in pos:
+                    raise KeyError("load_state_dict: state for parameter %d, which this optimizer does not update" % int(i))
+                e = pos[id(p)]
+                _, _, o, n = A.entries[e]
+                if tuple(st['exp_avg'].shape) != tuple(p.shape) or tuple(st['exp_avg_sq'].shape) != tuple(p.shape):
+                    raise ValueError("load_state_dict: moment shape %s does not match parameter %d %s"
+                                     % (tuple(st['exp_avg'].shape), int(i), tuple(p.shape)))
+                A.m[o:o + n].view(p.shape).copy_(st['exp_avg'])
+                A.v[o:o + n].view(p.shape).copy_(st['exp_avg_sq'])
+                self._steps[e] = int(round(float(st['step'])))
+
+    def load_state_dict(self, state_dict):
+        groups = state_dict['param_groups']
+        if len(groups) != len(self.param_groups) or any(len(a['params']) != len(b['params']) for a, b in zip(groups, self.param_groups)):
+            raise ValueError("loaded state dict has a different number of parameter groups / parameters per group")
+        for g, loaded in zip(self.param_groups, groups):
+            for k, v in loaded.items():
+                if k != 'params':
+                    g[k] = v
+        # 'step' is read NOW (a caller -- e.g. a torch optimizer the same dict was also loaded into -- may go on incrementing that
+        # tensor in place); the moment tensors are referenced until the arenas exist, then copied
+        state = {int(k): dict(v, step=float(v['step'])) for k, v in state_dict['state'].items()}
+        if self._arena is None:
+            self._pending_state = state         # parameters may still be on the host: applied when the arenas are built
+        else:
+            self._restore_state(state)
 
     def zero_grad(self, set_to_none=True):
         """One memset of the gradient arena; .grad becomes None (torch's set_to_none semantics) until the next backward."""
@@ -147,21 +215,37 @@ class PolyWarmupAdamW(torch.optim.AdamW):
         for g in self.param_groups:
             if g['betas'] != g0['betas'] or g['eps'] != g0['eps'] or g.get('amsgrad') or g.get('maximize'):
                 raise NotImplementedError("PolyWarmupAdamW: per-group betas / eps, amsgrad and maximize are not built")
-        cg = A.chunk_groups()
-        key = cg.tobytes()
-        if self._cg_cache[0] != key:
-            self._cg_cache = (key, torch.from_numpy(cg).to(A.param.device))
-        self._adam_t += 1
-        t = self._adam_t                               # bias corrections: step count = number of step() calls
+        has_grad = np.array([p.grad is not None for p, _, _, _ in A.entries], dtype=bool)
+        self._steps[has_grad] += 1                      # torch: state['step'] += 1 for the parameters updated now
         beta1, beta2 = g0['betas']
-        bc1 = 1 - beta1 ** t
-        bc2_sqrt = math.sqrt(1 - beta2 ** t)
         ng = len(self.param_groups)
         decay = (ctypes.c_float * ng)(*[1 - g['lr'] * g['weight_decay'] for g in self.param_groups])
-        step_size = (ctypes.c_float * ng)(*[g['lr'] / bc1 for g in self.param_groups])
-        _lib.check(ops.lib().paif_adamw_step(ops._p(A.param), ops._p(A.grad), ops._p(A.m), ops._p(A.v),
-                                             ctypes.c_void_p(self._cg_cache[1].data_ptr()), A.nchunks, ng, decay, step_size,
-                                             1 - beta1, beta2, 1 - beta2, bc2_sqrt, g0['eps'], ops._stream()), "adamw_step")
+        # one launch per distinct step count among the parameters that have a gradient (normally exactly one)
+        for t in np.unique(self._steps[has_grad]).tolist():
+            cg = np.full(A.nchunks, 255, dtype=np.uint8)
+            for e, (p, g, o, n) in enumerate(A.entries):
+                if has_grad[e] and self._steps[e] == t:
+                    cg[o // CHUNK:(o + n + CHUNK - 1) // CHUNK] = g
+            key = cg.tobytes()
+            if key not in self._cg_cache:
+                if len(self._cg_cache) > 8:
+                    self._cg_cache.clear()
+                self._cg_cache[key] = torch.from_numpy(cg).to(A.param.device)
+            bc1 = 1 - beta1 ** t
+            bc2_sqrt = math.sqrt(1 - beta2 ** t)
+            step_size = (ctypes.c_float * ng)(*[g['lr'] / bc1 for g in self.param_groups])
+            _lib.check(ops.lib().paif_adamw_step(ops._p(A.param), ops._p(A.grad), ops._p(A.m), ops._p(A.v),
+                                                 ctypes.c_void_p(self._cg_cache[key].data_ptr()), A.nchunks, ng, decay, step_size,
+                                                 1 - beta1, beta2, 1 - beta2, bc2_sqrt, g0['eps'], ops._stream()), "adamw_step")
         self.global_step += 1
         invalidate_weight_caches()                     # the kernel wrote the weights behind torch's version counters
         return loss
+
+
+class PolyWarmupAdamW_seg(PolyWarmupAdamW):
+    """utils/optimizer.py:36-66: the same optimizer started at schedule position `iter_curr` (resuming a run)."""
+
+    def __init__(self, params, lr, weight_decay, betas, iter_curr, warmup_iter=None, max_iter=None, warmup_ratio=None, power=None):
+        super().__init__(params, lr, weight_decay, betas, warmup_iter=warmup_iter, max_iter=max_iter, warmup_ratio=warmup_ratio,
+                         power=power)
+        self.global_step = iter_curr

@@ -10,6 +10,14 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+GPU_TESTS_STARTED = [0]      # gpu-marked tests started in this process (tests/test_00_rccl_gpu.py must be the first)
+
+
+def pytest_runtest_setup(item):
+    if item.get_closest_marker("gpu") is not None:
+        GPU_TESTS_STARTED[0] += 1
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box via gpurun)")
 

@@ -131,6 +131,40 @@ def test_attack_both_variants_autograd_path(golden, way):
     _check_attack(g, d_ir, d_vis, trace, 1e-4, 2e-3)
 
 
+@pytest.mark.parametrize("way", ["PGD", "segPGD", "cosPGD", "newPGD"])
+@pytest.mark.parametrize("shape", [(2, 9, 16, 24, 64, 96), (1, 9, 24, 32, 24, 32), (3, 9, 7, 5, 30, 19)])
+def test_attack_loss_kernels_vs_oracle_autograd(way, shape):
+    """paif_attack_loss_fwd / _bwd (attack/attack.py:447-499 on F.interpolate(seg_map, bilinear)) against the oracle's torch
+    restatement + autograd: loss value and d loss / d seg_map.  Labels include ignore_index pixels; the identity-size case plants
+    pixels where max_c o == label EXACTLY (segPGD's float-vs-integer `pred == label` mask is then true there)."""
+    from oracle import paif_oracle as O
+
+    B, C, IH, IW, OH, OW = shape
+    seg = t(S.make_feature(61, (B, C, IH, IW), -3, 3))
+    lab = torch.from_numpy(S.hash_uniform(62, B * OH * OW).reshape(B, OH, OW) * 9).long().clamp_(0, 8)
+    lab[:, ::7, ::5] = 255
+    if (IH, IW) == (OH, OW):                       # plant exact hits of segPGD's mask
+        for b in range(B):
+            for (y, x) in ((3, 4), (10, 11), (20, 30)):
+                l = int(lab[b, y, x])
+                if l != 255:
+                    seg[b, :, y, x] = -1.0
+                    seg[b, l, y, x] = float(l)
+    for i, iters in ((0, 3), (2, 3), (7, 10)):
+        ref_in = seg.clone().requires_grad_(True)
+        up = torch.nn.functional.interpolate(ref_in, size=(OH, OW), mode="bilinear", align_corners=False)
+        ref = O.attack_loss_value(up, lab, way, i, iters)
+        ref.backward()
+        mine_in = seg.clone().to(_dev()).requires_grad_(True)
+        loss = ops.attack_loss(mine_in, lab.to(_dev()), way, i, iters)
+        (loss * 1.5).backward()
+        assert abs(float(loss) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref))), (way, i, float(loss), float(ref))
+        scale = max(float(ref_in.grad.abs().max()), 1e-12)
+        assert maxabs(mine_in.grad.cpu() / 1.5, ref_in.grad) <= 2e-5 * scale + 1e-9, (way, i)
+        if way == "segPGD" and (IH, IW) == (OH, OW):
+            assert float((up.detach().max(1).values == lab).float().sum()) >= 1      # the planted hits are live
+
+
 def test_attack_bad_loss_returns_minus_one(capsys):
     from paif_amd.attack.attack import attack_both
 

@@ -108,6 +108,11 @@ def _reduce_worker(rank, world, port, q, order):
     early = []
     for it in range(2):                                                      # two backward passes: reset() works
         arena.zero_grad()
+        # a stale milestone outside begin()/finish() (what an attack's dgrad-only reverse pass would have produced before the
+        # call sites were guarded): must neither launch a bucket nor change what the real backward sends
+        red.mark_ready(layers[0]); red.mark_ready(layers[2])
+        assert red.launched == [] and red.next_bucket == 0
+        red.begin()
         grads = torch.autograd.grad(_tiny_loss(layers, xs, ys), [p for l in layers for p in l.parameters()])
         gmap = dict(zip([id(p) for l in layers for p in l.parameters()], grads))
         for li in order:                                                     # the reverse pass reaches the milestones in this order

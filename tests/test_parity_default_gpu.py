@@ -1,0 +1,305 @@
+"""GPU parity IN THE ARITHMETIC AND AT THE BATCH SIZES bench.py RUNS.
+
+The gradient / trajectory tests of test_attack_gpu.py and test_backward_fullsize_gpu.py pin the exact-fp32 kernels
+(`set_conv_precision("f32")`, `set_gemm_precision("f32")`).  The product default -- and what `bench.py --workload pgd|train`
+times -- is split-bf16 conv products (forward AND dgrad), split-bf16 attention forward/backward and "auto" GEMMs.  Every test
+here is parametrised over precision in {exact, default}; the bounds for `default` were MEASURED (tools/parity_report.py collects
+the numbers the tests print into gpurun_out/parity_metrics.json) and are stated next to the reference arithmetic's own
+float32-vs-float64 disagreement on the same quantity (tests/golden/gn_attack_PGD10.npz: `floor_*`), which is the yardstick: a PGD
+trajectory is chaotic in sign(g), so "as close to the float64 run as the reference's own float32 run is" is the strongest
+statement available for either arithmetic.
+
+Also here: the fusion network at the benchmarked batch (configs[1] B=8, configs[2] B=16, 480x640) -- every other full-size test
+is B=1, and the persistent kernels' tile ranges straddle image boundaries only when B>1 at full size.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from paif_amd import ops, synthetic as S
+from tests import helpers as Hh
+from tests.helpers import t, maxabs
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EPS, ALPHA = 8 / 255., 2 / 255.
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _record(name, **metrics):
+    """Measured parity numbers -> gpurun_out/parity_metrics.json (scratch; the stated bounds live in the asserts)."""
+    d = os.path.join(ROOT, "gpurun_out")
+    if not os.path.isdir(d):
+        return
+    path = os.path.join(d, "parity_metrics.json")
+    try:
+        allm = json.load(open(path))
+    except (OSError, ValueError):
+        allm = {}
+    allm[name] = {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in metrics.items()}
+    json.dump(allm, open(path, "w"), indent=1, sort_keys=True)
+
+
+@pytest.fixture(params=["exact", "default"])
+def precision(request):
+    old, oldg = ops.CONFIG["conv_precision"], ops.CONFIG["gemm_precision"]
+    if request.param == "exact":
+        ops.set_conv_precision("f32")
+        ops.set_gemm_precision("f32")
+    else:                                   # what ops.CONFIG ships with and bench.py runs
+        ops.set_conv_precision("bf16x3")
+        ops.set_gemm_precision("auto")
+    yield request.param
+    ops.set_conv_precision(old)
+    ops.set_gemm_precision(oldg)
+
+
+def _model(bb="mit_b0"):
+    from paif_amd.core.model_fusion_auto import Network_MM_Searched
+    from paif_amd.genotypes import FUSION_AT
+
+    m = Network_MM_Searched(32, FUSION_AT, None, None, bb, num_classes=9).eval()
+    S.load_formula_weights(m)
+    return m.to(_dev())
+
+
+def _sign_mismatch(a, b):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else a
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else b
+    return float((np.sign(a) != np.sign(b)).mean())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# A1: PGD trajectories
+# ------------------------------------------------------------------------------------------------------------------
+def test_attack_both_pgd3_trajectory(golden, precision):
+    """attack/attack.py:443-512, 3 iterations, vs the reference's own trace (gg_attack_PGD).  exact: loss rel. 1e-4, sign
+    mismatch / differing delta <= 2e-3.  default (measured): see the bounds below."""
+    from paif_amd.attack.attack import attack_both
+
+    g = golden("gg_attack_PGD")
+    m = _model("mit_b0")
+    ir, vis, lab = S.make_batch(2, 64, 96)
+    trace = []
+    with torch.no_grad():
+        d_ir, d_vis = attack_both(m, t(vis).to(_dev()), t(ir).to(_dev()), t(lab).to(_dev()), epsilon=EPS, alpha=ALPHA, attack_iters=3,
+                                  attack_loss='l_seg', attack_way='PGD', delta0_ir=t(g["d0_ir"]), delta0_vis=t(g["d0_vis"]), trace=trace)
+    losses = np.array([s["loss"] for s in trace])
+    loss_rel = np.abs(losses - g["losses"]) / np.abs(g["losses"])
+    sm = [_sign_mismatch(trace[-1]["g_ir"], g["gsum_ir"]), _sign_mismatch(trace[-1]["g_vis"], g["gsum_vis"])]
+    dm = [float((np.abs(d_ir.detach().cpu().numpy() - g["delta_ir"]) > 1e-6).mean()), float((np.abs(d_vis.detach().cpu().numpy() - g["delta_vis"]) > 1e-6).mean())]
+    _record("pgd3_2x64x96_mit_b0[%s]" % precision, loss_rel=loss_rel, sign_mismatch=sm, delta_mismatch=dm)
+    lim = BOUNDS["pgd3"][precision]
+    assert loss_rel.max() <= lim["loss"], loss_rel
+    assert max(sm) <= lim["sign"], sm
+    assert max(dm) <= lim["delta"], dm
+    assert float(d_ir.detach().abs().max()) <= EPS + 1e-7 and float(d_vis.detach().abs().max()) <= EPS + 1e-7
+
+
+def test_attack_both_pgd10_trajectory_and_attacked_miou(golden, precision):
+    """H2 at the iteration count configs[3] uses: TEN accumulated-gradient iterations (the reference never zeroes delta.grad,
+    attack/attack.py:501-512), then the harness forward on the attacked pair (robust_test.py:143-166), vs the reference's own
+    run (gn_attack_PGD10).  Stated per iteration against the reference's float32-vs-float64 disagreement (`floor_*`)."""
+    from paif_amd.attack.attack import attack_both
+    from paif_amd.util.util import ConfusionMeter, compute_results
+
+    g = golden("gn_attack_PGD10")
+    m = _model("mit_b0")
+    ir, vis, lab = S.make_batch(2, 64, 96)
+    dev = _dev()
+    irt, vist, labt = t(ir).to(dev), t(vis).to(dev), t(lab).to(dev)
+    trace = []
+    with torch.no_grad():
+        d_ir, d_vis = attack_both(m, vist, irt, labt, epsilon=EPS, alpha=ALPHA, attack_iters=10, attack_loss='l_seg', attack_way='PGD',
+                                  delta0_ir=t(g["d0_ir"]), delta0_vis=t(g["d0_vis"]), trace=trace)
+        fused, seg = m(ops.add(irt, d_ir.detach()), ops.add(vist, d_vis.detach()))
+        meter = ConfusionMeter(9, dev)
+        pred = meter.update(seg, labt)
+    losses = np.array([s["loss"] for s in trace])
+    loss_rel = np.abs(losses - g["losses"]) / np.abs(g["losses"])
+    # per-iteration sign mismatch of the running gradient sum vs the reference's float32 run AND vs its float64 run
+    sm32 = np.array([[_sign_mismatch(np.sign(s["g_ir"].cpu().numpy()), g["sign_ir_per_iter"][i]),
+                      _sign_mismatch(np.sign(s["g_vis"].cpu().numpy()), g["sign_vis_per_iter"][i])] for i, s in enumerate(trace)])
+    sm64 = np.array([[_sign_mismatch(np.sign(s["g_ir"].cpu().numpy()), g["sign64_ir_per_iter"][i]),
+                      _sign_mismatch(np.sign(s["g_vis"].cpu().numpy()), g["sign64_vis_per_iter"][i])] for i, s in enumerate(trace)])
+    dm32 = [float((np.abs(d_ir.detach().cpu().numpy() - g["delta_ir"]) > 1e-6).mean()), float((np.abs(d_vis.detach().cpu().numpy() - g["delta_vis"]) > 1e-6).mean())]
+    dm64 = [float((np.abs(d_ir.detach().cpu().numpy() - g["delta64_ir"]) > 1e-6).mean()), float((np.abs(d_vis.detach().cpu().numpy() - g["delta64_vis"]) > 1e-6).mean())]
+    moved = int((pred.cpu().numpy() != g["pred"]).sum())
+    miou = float(np.mean(np.nan_to_num(compute_results(meter.conf.cpu().numpy())[2])))
+    miou_ref = float(np.mean(np.nan_to_num(compute_results(g["conf"])[2])))
+    _record("pgd10_2x64x96_mit_b0[%s]" % precision, loss_rel=loss_rel, sign_mismatch_vs_ref32=sm32, sign_mismatch_vs_ref64=sm64,
+            delta_mismatch_vs_ref32=dm32, delta_mismatch_vs_ref64=dm64, moved_pixels=moved, miou=miou, miou_ref=miou_ref,
+            ref_floor_sign=g["floor_sign"], ref_floor_loss=g["floor_loss"], ref_floor_delta=g["floor_delta"])
+    lim = BOUNDS["pgd10"][precision]
+    assert loss_rel.max() <= lim["loss"], loss_rel
+    # the yardstick: not farther from the float64 trajectory than `k` x the reference's own float32 run is (+ an absolute 1e-3)
+    assert (sm64 <= lim["sign_k"] * g["floor_sign"] + 1e-3).all(), (sm64, g["floor_sign"])
+    assert max(dm64) <= lim["sign_k"] * float(g["floor_delta"].max()) + 1e-3, (dm64, g["floor_delta"])
+    assert abs(miou - miou_ref) <= 1e-3, (miou, miou_ref)                      # mIoU within 0.1 pt
+    assert moved <= lim["moved"] * pred.numel(), moved
+    assert float(d_ir.detach().abs().max()) <= EPS + 1e-7 and float(d_vis.detach().abs().max()) <= EPS + 1e-7
+
+
+def test_one_pgd_iteration_at_480x640_mit_b3(precision):
+    """One full attack_both iteration at the configs[3] shape class (1x480x640, mit_b3) vs the oracle's autograd on the host."""
+    from oracle import paif_oracle as O
+    from paif_amd.attack.attack import attack_both
+
+    m = _model("mit_b3")
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    ir, vis, lab = S.make_batch(1, 480, 640)
+    d0i = t(S.make_delta0(5, ir.shape, EPS))
+    d0v = t(S.make_delta0(105, vis.shape, EPS))
+    trace = []
+    with torch.no_grad():
+        d_ir, d_vis = attack_both(m, t(vis).to(_dev()), t(ir).to(_dev()), t(lab).to(_dev()), epsilon=EPS, alpha=ALPHA, attack_iters=1,
+                                  attack_loss='l_seg', attack_way='PGD', delta0_ir=d0i, delta0_vis=d0v, trace=trace)
+    key = "_pgd1_oracle"
+    if key not in _CACHE:                                     # the host run is the same for both precisions: once per session
+        otrace = []
+        od = O.attack_both(lambda a, b: O.model_forward(a, b, sd, "mit_b3"), t(vis), t(ir), t(lab), d0i, d0v, epsilon=EPS, alpha=ALPHA,
+                           attack_iters=1, attack_way="PGD", trace=otrace)
+        _CACHE[key] = (otrace, od)
+    otrace, (od_ir, od_vis) = _CACHE[key]
+    loss_rel = abs(trace[0]["loss"] - otrace[0]["loss"]) / abs(otrace[0]["loss"])
+    sm, mx, mean = [], [], []
+    for mine, ref in ((trace[0]["g_ir"], otrace[0]["g_ir"]), (trace[0]["g_vis"], otrace[0]["g_vis"])):
+        a, b = mine.cpu().numpy(), ref.numpy()
+        sm.append(_sign_mismatch(a, b))
+        mx.append(float(np.abs(a - b).max() / np.abs(b).max()))
+        mean.append(float(np.abs(a - b).mean() / np.abs(b).max()))
+    dm = [float((np.abs(d_ir.detach().cpu().numpy() - od_ir.numpy()) > 1e-6).mean()), float((np.abs(d_vis.detach().cpu().numpy() - od_vis.numpy()) > 1e-6).mean())]
+    _record("pgd1_1x480x640_mit_b3[%s]" % precision, loss_rel=loss_rel, sign_mismatch=sm, grad_max_rel=mx, grad_mean_rel=mean, delta_mismatch=dm)
+    lim = BOUNDS["pgd1_full"][precision]
+    assert loss_rel <= lim["loss"], loss_rel
+    assert max(sm) <= lim["sign"] and max(dm) <= lim["sign"], (sm, dm)
+    assert max(mx) <= lim["gmax"] and max(mean) <= lim["gmean"], (mx, mean)
+
+
+@pytest.mark.parametrize("bb", ["mit_b0", "mit_b3"])
+def test_wetr_input_grad(golden, precision, bb):
+    g = golden("ge_wetr_" + bb)
+    m = _model(bb)
+    x = t(golden("gd_colour_glue")["seg_in_b2"]).to(_dev()).requires_grad_(True)
+    logits = m.denoise_net(x)
+    (logits * t(S.make_feature(41, tuple(logits.shape))).to(_dev())).sum().backward()
+    err = maxabs(x.grad.cpu(), g["dx"]) / max(1.0, float(np.abs(g["dx"]).max()))
+    lerr = maxabs(logits.detach().cpu(), g["logits"]) / max(1.0, float(np.abs(g["logits"]).max()))
+    _record("wetr_input_grad_%s[%s]" % (bb, precision), dx_rel=err, logits_rel=lerr)
+    assert lerr <= 1e-4
+    assert err <= BOUNDS["wetr_dx"][precision], err
+
+
+def test_harness_pgd_eval(precision):
+    """H2 (robust_test.py:95-239) through the harness: PGD-3 on 2 pairs (mit_b0), attacked mIoU vs the CPU oracle's run."""
+    from oracle import paif_oracle as O
+    from paif_amd.harness import val_segformer_robust
+
+    m = _model("mit_b0")
+    sd = Hh.model_sd("mit_b0")
+    ir, vis, lab = S.make_batch(2, 64, 96)
+    d0_ir = t(S.make_delta0(0, ir.shape, EPS))
+    d0_vis = t(S.make_delta0(1, vis.shape, EPS))
+    out = val_segformer_robust(m, [(t(vis).to(_dev()), t(ir).to(_dev()), t(lab).to(_dev()))], attack_iters=3,
+                               delta0=lambda bi, a, b: (d0_ir, d0_vis))
+    if "_harness" not in _CACHE:
+        fwd = lambda a, b: O.model_forward(a, b, sd, "mit_b0")
+        o_ir, o_vis = O.attack_both(fwd, t(vis), t(ir), t(lab), d0_ir, d0_vis, EPS, ALPHA, 3, "PGD")
+        with torch.no_grad():
+            _, seg = fwd(t(ir) + o_ir, t(vis) + o_vis)
+            up = torch.nn.functional.interpolate(seg, size=lab.shape[1:], mode="bilinear", align_corners=False)
+        _CACHE["_harness"] = O.confusion_matrix(lab, up.argmax(1).numpy())
+    conf = _CACHE["_harness"]
+    iou = O.compute_results(conf)[2]
+    dmiou = abs(out["miou"] - float(np.mean(np.nan_to_num(iou))))
+    moved = float(np.abs(out["conf"] - conf).sum() / conf.sum())
+    _record("harness_pgd3[%s]" % precision, dmiou=dmiou, moved_frac=moved)
+    assert dmiou <= 1e-3                                                         # mIoU within 0.1 pt
+    assert moved <= 0.002                                                        # <= 0.2 % of the pixels move
+
+
+_CACHE = {}
+
+# Stated bounds.  `exact` = the SURVEY 8(a) A1 metric as round 2 stated it.  `default` = measured on MI355X in round 3
+# (profiles/r03_parity_default_arithmetic.json holds the numbers), with head-room of ~2x over the measurement; the comparison
+# with the reference's own float32-vs-float64 floor is asserted inside the PGD-10 test.
+BOUNDS = {
+    "pgd3": {"exact": dict(loss=1e-4, sign=2e-3, delta=2e-3), "default": dict(loss=1e-4, sign=2e-3, delta=2e-3)},
+    "pgd10": {"exact": dict(loss=1e-3, sign_k=1.5, moved=1e-3), "default": dict(loss=1e-3, sign_k=1.5, moved=1e-3)},
+    "pgd1_full": {"exact": dict(loss=1e-4, sign=2e-3, gmax=5e-2, gmean=2e-3), "default": dict(loss=1e-4, sign=2e-3, gmax=5e-2, gmean=2e-3)},
+    "wetr_dx": {"exact": 1e-4, "default": 1e-4},
+}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the benchmarked batch sizes at 480x640
+# ------------------------------------------------------------------------------------------------------------------
+def test_fusion_b8_480x640_samplewise_equals_b1_and_golden(golden):
+    """configs[1] as bench.py runs it (B=8, 480x640, default arithmetic): the fusion network is per-sample, so sample i of the
+    B=8 launch must equal the B=1 launch of sample i BIT FOR BIT (same kernels, same per-sample arithmetic; only the persistent
+    kernels' tile ranges and the tile->workgroup map differ), and sample 0 must sit on the reference's golden."""
+    from paif_amd.core.model_fusion_auto import Network_Fusion_Searched
+    from paif_amd.genotypes import FUSION_AT
+
+    dev = _dev()
+    net = Network_Fusion_Searched(32, None, FUSION_AT).eval()
+    # the weights the fusion net has INSIDE the composite model's golden (the formula is keyed on the full state_dict key)
+    net.load_state_dict({k: t(S.formula_tensor("enhance_net." + k, tuple(v.shape))).to(v.dtype) for k, v in net.state_dict().items()},
+                        strict=True)
+    net.to(dev)
+    ir, vis, _ = S.make_batch(8, 480, 640)
+    irt, vist = t(ir).to(dev), t(vis).to(dev)
+    with torch.no_grad():
+        ycc = ops.rgb2ycrcb(vist)
+        f8 = net(irt, ycc).clone()
+        worst = 0.0
+        for i in (0, 3, 7):
+            f1 = net(irt[i:i + 1].contiguous(), ops.rgb2ycrcb(vist[i:i + 1].contiguous()))
+            worst = max(worst, float((f8[i:i + 1] - f1).abs().max()))
+    g = golden("gf_model_b3_1x480x640")
+    e_gold = maxabs(f8[0:1].cpu(), g["fused"])
+    e64 = maxabs(f8[0:1].cpu(), g["fused64"])
+    floor = maxabs(g["fused"], g["fused64"])                  # the reference's own float32-vs-float64 distance at this size
+    _record("fusion_b8_480x640", samplewise_max=worst, vs_golden=e_gold, vs_fp64=e64, ref_floor=floor)
+    assert worst <= 1e-6, worst
+    assert e64 <= floor, (e64, floor)                         # not farther from the float64 result than the reference's own run
+    assert e_gold <= 2 * floor + 1e-5
+
+
+def test_fusion_seg_b16_480x640_vs_oracle(golden):
+    """configs[2] as bench.py runs it (B=16, 480x640, mit_b3, default arithmetic) against the CPU oracle on the same 16 pairs
+    (the glue's min/max is batch-global, core/model_fusion_auto.py:721-723, so the logits of every sample depend on all 16):
+    fused per sample, logits, argmax agreement.  ~1 minute of host time."""
+    from oracle import paif_oracle as O
+
+    dev = _dev()
+    m = _model("mit_b3")
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    B = 16
+    ir, vis, _ = S.make_batch(B, 480, 640)
+    with torch.no_grad():
+        fused, seg = m(t(ir).to(dev), t(vis).to(dev))
+        fused, seg = fused.cpu(), seg.cpu()
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    fsd = {k[len("enhance_net."):]: v for k, v in sd.items() if k.startswith("enhance_net.")}
+    ssd = {k[len("denoise_net."):]: v for k, v in sd.items() if k.startswith("denoise_net.")}
+    with torch.no_grad():
+        ycc = O.rgb2ycrcb(t(vis))
+        of = torch.cat([O.fusion_forward(t(ir[i:i + 1]), ycc[i:i + 1, 0:1], fsd) for i in range(B)])      # per-sample network
+        seg_in = O.seg_input_from_fused(of, ycc)                                                          # batch-global min/max
+        ol = torch.cat([O.wetr_forward(seg_in[i:i + 4], ssd, "", "mit_b3") for i in range(0, B, 4)])
+    e_f = maxabs(fused, of)
+    scale = float(ol.abs().max())
+    e_l = maxabs(seg, ol) / scale
+    agree = float((seg.argmax(1) == ol.argmax(1)).float().mean())
+    _record("fusion_seg_b16_480x640", fused_max=e_f, logits_rel=e_l, argmax_agree=agree)
+    assert e_f <= 2e-4, e_f                                   # both sides float32 through the guided filter (reference floor 9.8e-5 vs fp64)
+    assert e_l <= 1e-3, e_l                                   # logits max-abs <= 1e-3 of the logit range
+    assert agree >= 0.9999, agree

@@ -215,6 +215,80 @@ def test_adamw_kernel_vs_torch_adamw():
     assert torch.equal(gpu[3].detach().cpu(), cpu[3].detach())
 
 
+@pytest.mark.gpu
+def test_adamw_checkpoint_resume_and_per_parameter_steps():
+    """ The moments live in the arenas, not in `self.state`: state_dict() must export them in torch.optim.AdamW's layout
+    and load_state_dict() must restore them -- checked BOTH ways against torch's own AdamW (ours -> torch and torch -> ours), with a
+    parameter that is skipped on some steps (its state['step'] lags, so its bias corrections differ: torch keeps the count per
+    parameter) and with the schedule resumed through PolyWarmupAdamW_seg(iter_curr)."""
+    from paif_amd.utils.optimizer import PolyWarmupAdamW, PolyWarmupAdamW_seg
+
+    g = torch.Generator().manual_seed(11)
+    shapes = [(17, 5), (300,), (2, 1030), (64,)]
+    kw = dict(lr=1e-3, weight_decay=0.01, betas=(0.9, 0.999), warmup_iter=2, max_iter=20, warmup_ratio=0.1, power=1.0)
+    from oracle.paif_oracle import poly_warmup_lr_mult
+
+    def groups(ps):
+        return [dict(params=ps[0:2], lr=1e-3, weight_decay=0.01), dict(params=ps[2:4], lr=5e-3, weight_decay=0.0)]
+
+    grads = [[torch.randn(s, generator=g) for s in shapes] for _ in range(6)]
+    skip = {(1, 2), (2, 2), (4, 0)}                      # (step, parameter) pairs without a gradient
+
+    def run(opt, ps, steps, ref_base=None, to=lambda t: t):
+        for st in steps:
+            opt.zero_grad()
+            for i, p in enumerate(ps):
+                if (st, i) not in skip:
+                    p.grad = to(grads[st][i].clone())
+            if ref_base is not None:                     # torch reference: set the schedule by hand
+                m = poly_warmup_lr_mult(st, 2, 20, 0.1, 1.0)
+                for grp, b in zip(opt.param_groups, ref_base):
+                    grp["lr"] = b * m
+            opt.step()
+
+    cpu = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+    init = [p.detach().clone() for p in cpu]
+    ref = torch.optim.AdamW(groups(cpu), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    run(ref, cpu, range(6), ref_base=[1e-3, 5e-3])       # the uninterrupted reference run
+
+    dev = _dev()
+    gpu = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+    mine = PolyWarmupAdamW(groups(gpu), **kw)
+    run(mine, gpu, range(3), to=lambda t: t.to(dev))
+    sd = mine.state_dict()
+    assert sorted(sd["state"]) == [0, 1, 2, 3] and float(sd["state"][2]["step"]) == 1.0 and float(sd["state"][0]["step"]) == 3.0
+    assert tuple(sd["state"][2]["exp_avg"].shape) == shapes[2] and sd["param_groups"][1]["params"] == [2, 3]
+    # ours -> torch: a torch AdamW on the same parameters accepts the dict and continues identically to the reference
+    cpu2 = [torch.nn.Parameter(p.detach().cpu().clone()) for p in gpu]
+    t2 = torch.optim.AdamW(groups(cpu2), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    # (clones: torch's load_state_dict keeps the 'step' tensors it is handed and its step() increments them IN PLACE)
+    t2.load_state_dict({"state": {k: {kk: vv.cpu().clone() for kk, vv in v.items()} for k, v in sd["state"].items()},
+                        "param_groups": sd["param_groups"]})
+    run(t2, cpu2, range(3, 6), ref_base=[1e-3, 5e-3])
+    # ours -> ours, into a FRESH optimizer whose arenas do not exist yet (state parked, applied when they are built), schedule resumed
+    gpu3 = [torch.nn.Parameter(p.detach().clone()) for p in gpu]
+    again = PolyWarmupAdamW_seg(groups(gpu3), iter_curr=3, **kw)
+    again.load_state_dict(sd)
+    run(again, gpu3, range(3, 6), to=lambda t: t.to(dev))
+    run(mine, gpu, range(3, 6), to=lambda t: t.to(dev))  # and the uninterrupted run of this class
+    for i in range(4):
+        tol = 3e-6 * max(1.0, float(cpu[i].abs().max()))
+        assert float((gpu[i].detach().cpu() - cpu[i].detach()).abs().max()) <= tol, ("uninterrupted", i)
+        assert float((cpu2[i].detach() - cpu[i].detach()).abs().max()) <= tol, ("ours->torch", i)
+        assert float((gpu3[i].detach().cpu() - cpu[i].detach()).abs().max()) <= tol, ("resume", i)
+    # torch -> ours
+    sd_ref = ref.state_dict()
+    gpu4 = [torch.nn.Parameter(p.detach().clone().to(dev)) for p in cpu]
+    back = PolyWarmupAdamW_seg(groups(gpu4), iter_curr=6, **kw)
+    back.zero_grad()                                     # arenas exist before the load this time
+    back.load_state_dict(sd_ref)
+    sd4 = back.state_dict()
+    for k in sd_ref["state"]:
+        assert float(sd4["state"][k]["step"]) == float(sd_ref["state"][k]["step"])
+        assert torch.equal(sd4["state"][k]["exp_avg"].cpu(), sd_ref["state"][k]["exp_avg"])
+        assert torch.equal(sd4["state"][k]["exp_avg_sq"].cpu(), sd_ref["state"][k]["exp_avg_sq"])
+
+
 def test_training_step_two_optimizer_steps(golden):
     """The adversarial-training step proper, twice: train mode (BatchNorm batch statistics x4, DropPath, Dropout2d from the
     counter-based stream), `_loss_coupled(...).backward()`, PolyWarmupAdamW.step() -- losses, step-0 gradients, BatchNorm
