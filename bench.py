@@ -63,6 +63,10 @@ def main():
                     help="fusion / fusion_seg: replay one captured hipGraph per step in the timed region (the clean-eval harness's default "
                          "mode).  `value` is then the graph-replay rate; the roofline blocks come from an eager, HIP-event-instrumented pass of "
                          "the same K steps run right after the timed region and say so (`roofline_source`)")
+    ap.add_argument("--attack-precision", choices=["exact", "fast"], default="exact",
+                    help="pgd / train: arithmetic INSIDE the attack loop.  exact (default, the product default) = fp32-exact conv / GEMM / attention "
+                         "kernels: the only arithmetic that keeps the PGD-10 trajectory on the reference's (SURVEY 8(a) A1; tests/"
+                         "test_parity_default_gpu.py); fast = the split-bf16 kernels there too (trajectory diverges: sign mismatch 2.5e-2 by iteration 10)")
     ap.add_argument("--conv-precision", choices=["f32", "bf16x3"], default="bf16x3",
                     help="arithmetic of the dense convs: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs, fp32 accumulate)")
     args = ap.parse_args()
@@ -90,6 +94,7 @@ def main():
 
     ops.set_conv_precision(args.conv_precision)
     ops.set_gemm_precision(args.gemm_precision)
+    ops.set_attack_precision(args.attack_precision)
     DOMINANT = "dense conv 3x3 dil 1, forward (%s)" % args.conv_precision   # family tag of the 12 dense 3x3 convs of a step
     bpg = 16 if args.workload == "fusion_seg" else B_PER_GPU
     if args.workload == "fusion":
@@ -262,7 +267,8 @@ def main():
                     blk = {"bound": "hbm", "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS, "algorithmic_tflops": tf}
             elif tag.startswith("gf_"):
                 blk = {"bound": "hbm", "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS, "algorithmic_tflops": tf,
-                       "note": "VALU-issue bound (two 9x9 box-filter stages per pixel-channel), see DESIGN.md"}
+                       "note": "gf_mfma_kernel: horizontal box sums on the matrix cores, one wave per SIMD, instruction-issue bound; "
+                               "gf_fused_kernel (PAIF_GF_ENGINE=valu): all-VALU form -- see DESIGN.md"}
             elif tag.startswith("conv_") or tag.startswith("dense conv"):
                 blk = {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS}
             else:
@@ -319,7 +325,10 @@ def main():
             "dtype": ("f32" if args.conv_precision == "f32" else "f32 (storage and accumulation f32; conv products as split-bf16: 3x bf16 MFMA)")
                      + ("" if args.workload == "fusion" else "; SegFormer GEMMs: %s" % {"f32": "exact fp32 MFMA", "bf16x3": "split-bf16",
                                                                                       "auto": "exact fp32 MFMA, split-bf16 where K >= 256"}[args.gemm_precision]
-                        + "; attention products: %s" % ("exact fp32 MFMA" if args.gemm_precision == "f32" else "split-bf16")),
+                        + "; attention products: %s" % ("exact fp32 MFMA" if args.gemm_precision == "f32" else "split-bf16")
+                        + ("" if args.workload not in ("pgd", "train") else
+                           "; INSIDE the attack loop: %s" % ("exact fp32 MFMA for convs, GEMMs and attention (attack precision 'exact')"
+                                                            if args.attack_precision == "exact" else "the same split-bf16 kernels (attack precision 'fast')"))),
             "data": "synthetic",
             "config": {"workload": {"fusion": "configs[1]: fusion-net forward (RGB2YCrCb + Network_Fusion_Searched, C=32, shipped genotype)",
                                     "fusion_seg": "configs[2]: fusion + mit_b3 SegFormer end-to-end inference",

@@ -71,6 +71,13 @@ def _attack(model, X_vis, X_ir, label, epsilon, alpha, attack_iters, restarts, a
     label = label.contiguous()
     fast = attack_loss == 'l_seg' and hasattr(model, "forward_taped")
     lab64 = label.type(torch.long).contiguous()
+    with ops.attack_arithmetic():          # exact-fp32 kernels for the whole loop unless ops.set_attack_precision("fast")
+        return _attack_loop(model, X_vis, X_ir, label, lab64, epsilon, alpha, attack_iters, restarts, attack_loss, attack_way, do_ir, do_vis,
+                            delta0_ir, delta0_vis, trace, criterion, fast)
+
+
+def _attack_loop(model, X_vis, X_ir, label, lab64, epsilon, alpha, attack_iters, restarts, attack_loss, attack_way, do_ir, do_vis,
+                 delta0_ir, delta0_vis, trace, criterion, fast):
     for _ in range(restarts):
         d_ir = _init_delta(X_ir, epsilon, delta0_ir) if do_ir else torch.zeros_like(X_ir)
         d_vis = _init_delta(X_vis, epsilon, delta0_vis) if do_vis else torch.zeros_like(X_vis)
@@ -159,6 +166,11 @@ def trans_format(image_fusion, images_vis):
 
 def _fresh_grad_attack(model, X_vis, X_ir, X_fusion, label, epsilon, alpha, attack_iters, restarts, mode, loss_fn, delta0):
     X = (X_vis if mode == 'vis' else X_ir).contiguous().float()
+    with ops.attack_arithmetic():
+        return _fresh_grad_loop(model, X, X_vis, X_ir, epsilon, alpha, attack_iters, restarts, mode, loss_fn, delta0)
+
+
+def _fresh_grad_loop(model, X, X_vis, X_ir, epsilon, alpha, attack_iters, restarts, mode, loss_fn, delta0):
     delta = None
     for _ in range(restarts):
         delta = _init_delta(X, epsilon, delta0)

@@ -1,0 +1,350 @@
+// Guided filter (radius 4, 1-channel guide, 32-channel NHWC target, both eps) -- inference form, fused (the coefficient maps
+// A, b never touch HBM), with the HORIZONTAL 9-tap box sums on the matrix cores.
+// Replaces the reference's two GuidedFilter(4, eps) calls of Cell_Decom.decomposition (core/model_fusion_auto.py:522-535;
+// third-party guided_filter_pytorch.GuidedFilter, algorithm per oracle/shims/guided_filter_pytorch).
+//
+// Why (profiles/r02_pmc_fusion.txt): the all-VALU kernel (guided_filter.hip) was the largest single kernel
+// of the headline step at 14.6 % of the HBM roof -- per eps 377 VALU instructions and 36 ds_read_b128 per thread-row, two
+// barriers per row with two waves per SIMD to cover the LDS round trips, stage 1 computed twice (once per eps), matrix cores idle.
+// Here:
+//   * a lane owns 4 ADJACENT COLUMNS of ONE channel; a wave = 16 columns x 16 channels; a workgroup = 4 waves = a 64-column
+//     strip of ONE 16-channel half, ONE WAVE PER SIMD with the whole 512-entry register file: the 9-row windows of all six
+//     quantities (y, g*y, and A, b for both eps) stay in registers as rings of 3-row partial sums (4 adds per row and quantity,
+//     direct sums of the nine terms, no running add/subtract); stage 1 is computed once for both eps;
+//   * the horizontal 9-column sum is  S[m][c] = sum_k Band[m][k] * V[k][c]  on v_mfma_f32_16x16x32_f16: M = the wave's 16 output
+//     columns, N = 16 channels, K = 16 columns x (hi, lo).  A lane's four vertical sums, each split into an f16 pair hi = rtz(v),
+//     lo = rn(v - hi) (22 significant bits; products with the 0/1 band are exact, accumulation is fp32), ARE its B-operand
+//     fragment -- no data movement.  The accumulator comes back with exactly the lane's own 4 columns (D row = 4*(lane>>4) + reg),
+//     so stage 2 consumes it in place.  Only the 4 + 4 halo columns of a wave cross waves: one 16-byte fragment per edge lane and
+//     quantity through LDS (before: every value, nine times);
+//   * stage 1 of row r and stage 2 of row r-5 share ONE barrier per row;
+//   * inputs stream through LDS by LDS-DMA (buffer_load_dword ... lds) with no VGPR cost; every vector-memory instruction of the
+//     loop is issued unconditionally (masked lanes / warm-up rows store out of range of the buffer descriptor and are dropped by
+//     the hardware), so the s_waitcnt vmcnt(N) that retires a row is a compile-time constant; every LDS access of the loop is
+//     inline asm (hipcc would drain vmcnt in front of each ds_read it can see while an LDS-DMA is in flight).
+//   * the two 16-channel halves of a tile are blocks b and b + 8: the same XCD under round-robin dispatch, so the half-lines one of
+//     them fetches are L2 hits for the other (speed only).
+// f16 range: a 9-row sum beyond 65504 cannot be split.  The kernel tracks max|v| and raises *flag; the host wrapper then runs
+// the all-VALU kernel (predicated on the flag) over the same output -- results are always those of an fp32 box filter.
+#include <stdint.h>
+#include <type_traits>
+
+#include "paif_common.h"
+
+namespace paif_gf_mfma {
+
+constexpr int R = 4;
+constexpr int SC = 64;            // input columns per workgroup
+constexpr int SO = SC - 4 * R;    // 48 output columns
+constexpr int PF = 6;             // input rows in flight per lane = the unroll factor = the partial-sum ring size (static slots)
+constexpr int PD = PF + 3;        // plane ring depth (see the slot-reuse argument at the DMA issue)
+constexpr int NQ = 6;             // exchanged quantities: sum y, sum g*y, A0, b0, A1, b1
+constexpr int ZSLOT = 8;          // halo slot that stays zero (outside neighbours of the strip's edge waves)
+constexpr int VM_ITER = 2 + 4 + 8;  // vector-memory instructions per wave and iteration: 2 plane DMAs, 4 input DMAs, 8 stores
+constexpr unsigned RSRC_W3 = 0x00020000u;
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// LDS map (byte offsets inside the kernel's only __shared__ object, which therefore starts at LDS address 0)
+constexpr int Y_OFF = 0;
+constexpr int Y_BYTES = PF * 4 * 4 * 64 * 4;              // [PF][4 waves][4 cols][64 lanes] float       24,576
+constexpr int P_OFF = Y_OFF + Y_BYTES;
+constexpr int P_BYTES = PD * 8 * 64 * 4;                  // [PD][8 planes (7 used)][64 cols] float      18,432
+constexpr int H_OFF = P_OFF + P_BYTES;
+constexpr int H_QTY = (ZSLOT + 1) * 256;                  // one quantity: 9 slots x 16 channels x 16 B
+constexpr int H_BUF = NQ * H_QTY;                         // one buffer (iteration parity)
+constexpr int H_BYTES = 2 * H_BUF;                        //                                              27,648
+constexpr int LDS_BYTES = H_OFF + H_BYTES;
+
+#define GF_VMWAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((n) > 63 ? 63 : (n)) : "memory")
+#define GF_RD32(dst, addr, off) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#define GF_RD128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#define GF_WR128(addr, val, off) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(val), "n"(off) : "memory")
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ void dma4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_off) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(uintptr_t)lds_off, 4, voff, soff, 0, 0);
+}
+
+// four fp32 values (the lane's 4 columns) -> B-operand fragment [hi(c0,c1), lo(c0,c1), hi(c2,c3), lo(c2,c3)]
+__device__ __forceinline__ u32x4 split4(f32x4 v, float& vmax) {
+  // max |v| seen (two v_max3_f32 with |.| source modifiers; a NaN operand is ignored -- it propagates to the output by itself)
+  asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(vmax) : "v"(vmax), "v"(v[0]), "v"(v[1]));
+  asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(vmax) : "v"(vmax), "v"(v[2]), "v"(v[3]));
+  const half2v h01 = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(v[0], v[1]));
+  const half2v h23 = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(v[2], v[3]));
+  const half2v l01 = {(_Float16)(v[0] - (float)h01[0]), (_Float16)(v[1] - (float)h01[1])};
+  const half2v l23 = {(_Float16)(v[2] - (float)h23[0]), (_Float16)(v[3] - (float)h23[1])};
+  u32x4 f;
+  f[0] = __builtin_bit_cast(unsigned, h01); f[1] = __builtin_bit_cast(unsigned, l01);
+  f[2] = __builtin_bit_cast(unsigned, h23); f[3] = __builtin_bit_cast(unsigned, l23);
+  return f;
+}
+
+__device__ __forceinline__ f32x4 band_mfma(u32x4 a_own, u32x4 b_own, u32x4 a_halo, u32x4 b_halo) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a_own), __builtin_bit_cast(half8, b_own), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a_halo), __builtin_bit_cast(half8, b_halo), acc, 0, 0, 0);
+  return acc;
+}
+
+// band operand: lane (m = lane & 15, gk = lane >> 4) holds A[m][k = 8 gk + j], j = 4p + 2t + s  <->  column colbase + 2p + s
+__device__ __forceinline__ u32x4 band_operand(int m, int colbase, bool live) {
+  u32x4 d;
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      unsigned v = 0;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int col = colbase + 2 * p + s;
+        const bool on = live && (m - col <= R) && (col - m <= R);
+        v |= (on ? 0x3C00u : 0u) << (16 * s);      // f16 1.0
+      }
+      d[2 * p + t] = v;
+    }
+  return d;
+}
+
+// 9-row window of one quantity (4 columns) as three 3-row partial sums p(i) + p(i-3) + p(i-6), p(i) = x(i) + x(i-1) + x(i-2):
+// six slots (p(i-1) .. p(i-6); p(i) replaces p(i-6) once that has been read) + the two previous rows -- direct sums of the nine
+// terms, 4 adds per row; 8 register quadruples
+struct Ring {
+  f32x4 p[PF];
+  f32x4 a1, a2;
+};
+
+template <int K>
+__device__ __forceinline__ f32x4 ring_push(Ring& rg, f32x4 x) {
+  const f32x4 p = (rg.a2 + rg.a1) + x;
+  const f32x4 v = (p + rg.p[(K + 3) % PF]) + rg.p[K];
+  rg.p[K] = p; rg.a2 = rg.a1; rg.a1 = x;
+  return v;
+}
+
+// One (16-channel half, batch image, 64-column strip, row segment) per workgroup of 4 waves.
+//   planes: [4][B*H*W] = mean_g, 1/(var_g + eps0), 1/(var_g + eps1), 1/n  (gf_guide_stats_kernel)
+__global__ __launch_bounds__(256, 1) void gf_mfma_kernel(const float* __restrict__ guide, const float* __restrict__ y,
+                                                         const float* __restrict__ planes, float* __restrict__ lf,
+                                                         unsigned* __restrict__ flag, int B, int H, int W, int nstrip, int nseg,
+                                                         int frows, int ntiles) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+  asm volatile("" ::"v"((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem) : "memory");   // only asm touches it
+
+  const int tid = threadIdx.x, l = tid & 63;
+  const int q = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave = 16-column group of the strip (wave-uniform on purpose)
+  const int c = l & 15, g = l >> 4;
+  // blocks b and b + 8 (same XCD under round-robin dispatch) are the two channel halves of one tile
+  const int bid = blockIdx.x;
+  const int chh = (bid >> 3) & 1;
+  int t = (bid >> 4) * 8 + (bid & 7);
+  if (t >= ntiles) return;
+  const int strip = t % nstrip; t /= nstrip;
+  const int seg = t % nseg;
+  const int b = t / nseg;
+  const int X0 = strip * SO - 2 * R;
+  const int lc0 = 16 * q + 4 * g;                       // strip-local first column of this lane
+  const int col0 = X0 + lc0;
+  const int ybeg = seg * frows, yend = min(H, ybeg + frows);
+  const size_t npix = (size_t)B * H * W;
+  const size_t img = (size_t)b * H * W;
+
+  // ---- per-lane constants ----
+  bool cin[4];
+  unsigned yoff[4], soff[4];                            // byte offsets inside an image row: DMA source (clamped) / store (or out of range)
+  const bool store_cols = lc0 >= 2 * R && lc0 < SC - 2 * R;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    cin[i] = col0 + i >= 0 && col0 + i < W;
+    yoff[i] = (unsigned)((min(max(col0 + i, 0), W - 1) * 32 + 16 * chh + c) * 4);
+    soff[i] = (store_cols && cin[i]) ? yoff[i] : 0xFFFFFFFFu;
+  }
+  const u32x4 a_own = band_operand(l & 15, 4 * (l >> 4), true);
+  const u32x4 a_halo = band_operand(l & 15, (l >> 4) == 0 ? -4 : 16, (l >> 4) < 2);
+  // halo slots: publish own fragment as L (lanes g == 0) / R (g == 3); read left neighbour's R (g == 0), right neighbour's L (g == 1)
+  const bool pub = g == 0 || g == 3;
+  const int rd_slot = g == 0 ? (q > 0 ? (q - 1) * 2 + 1 : ZSLOT) : g == 1 ? (q < 3 ? (q + 1) * 2 : ZSLOT) : ZSLOT;
+  const unsigned a_pub = H_OFF + (q * 2 + (g == 3 ? 1 : 0)) * 256 + c * 16;
+  const unsigned a_rd = H_OFF + rd_slot * 256 + c * 16;
+  const unsigned a_y = Y_OFF + q * 1024 + l * 4;
+  const unsigned a_pl = P_OFF + lc0 * 4;
+  // plane set of an iteration (8 slots): g(r), rn(r-4), mg(r-4), rden0(r-4), rden1(r-4), g(r-9), rn(r-9), dummy;
+  // wave q stages slots 2q and 2q+1 (one image row of the strip's 64 columns each)
+  const float* const p_mg = planes, * const p_rd0 = planes + npix, * const p_rd1 = planes + 2 * npix, * const p_rn = planes + 3 * npix;
+  const float* const srcA = q == 0 ? guide : q == 1 ? p_mg : q == 2 ? p_rd1 : p_rn;
+  const float* const srcB = q == 0 ? p_rn : q == 1 ? p_rd0 : q == 2 ? guide : guide;
+  const int offA = q == 0 ? 0 : q == 3 ? -(2 * R + 1) : -R;
+  const int offB = q == 2 ? -(2 * R + 1) : q == 3 ? 0 : -R;
+  const unsigned rowbytes_pl = (unsigned)W * 4u, rowbytes = (unsigned)W * 128u;
+  const __amdgpu_buffer_rsrc_t rs_pa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(srcA + img), 0, (int)((size_t)H * rowbytes_pl), RSRC_W3);
+  const __amdgpu_buffer_rsrc_t rs_pb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(srcB + img), 0, (int)((size_t)H * rowbytes_pl), RSRC_W3);
+  const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(y + img * 32), 0, (int)((size_t)H * rowbytes), RSRC_W3);
+  // stores: one descriptor per eps over the image (rebuilt per row with num_records = 0 for a warm-up / tail row)
+  float* const o0 = lf + img * 32, * const o1 = lf + (npix + img) * 32;
+  const int out_bytes = (int)((size_t)H * rowbytes);
+  const unsigned pcol = (unsigned)min(max(X0 + l, 0), W - 1) * 4u;
+
+  // zero the permanent zero slot of both halo buffers
+  if (tid < 2 * NQ * 16) *reinterpret_cast<uint4*>(smem + H_OFF + (tid >> 4) * H_QTY + ZSLOT * 256 + (tid & 15) * 16) = make_uint4(0, 0, 0, 0);
+
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  Ring ry, rgy, rA0, rB0, rA1, rB1;
+#pragma unroll
+  for (int k = 0; k < PF; ++k) { ry.p[k] = zero4; rgy.p[k] = zero4; rA0.p[k] = zero4; rB0.p[k] = zero4; rA1.p[k] = zero4; rB1.p[k] = zero4; }
+  ry.a1 = ry.a2 = rgy.a1 = rgy.a2 = rA0.a1 = rA0.a2 = rB0.a1 = rB0.a2 = rA1.a1 = rA1.a2 = rB1.a1 = rB1.a2 = zero4;
+  f32x4 wA0 = zero4, wB0 = zero4, wA1 = zero4, wB1 = zero4;           // vertical (A, b) window sums of the previous iteration
+  float vmax = 0.f;
+
+  const int r0 = ybeg - 2 * R;                           // first streamed input row
+  const int n_it = ((yend - ybeg) + 4 * R + 1 + PF - 1) / PF * PF;
+
+  auto issue_planes = [&](int it_target, int pslot) {    // planes of iteration it_target -> ring slot pslot = it_target % PD
+    const int ra = min(max(r0 + it_target + offA, 0), H - 1), rb = min(max(r0 + it_target + offB, 0), H - 1);
+    const unsigned slot = P_OFF + (pslot * 8 + 2 * q) * 256;
+    dma4(rs_pa, pcol, (unsigned)ra * rowbytes_pl, slot);
+    dma4(rs_pb, pcol, (unsigned)rb * rowbytes_pl, slot + 256);
+  };
+  auto issue_y = [&](int it_target, int slot) {          // input row of iteration it_target -> ring slot (static)
+    const unsigned so = (unsigned)min(max(r0 + it_target, 0), H - 1) * rowbytes;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma4(rs_y, yoff[i], so, Y_OFF + ((slot * 4 + q) * 4 + i) * 256);
+  };
+
+  // ---- prologue: planes(0); then {planes(j+1), y(j)} for j = 0..PF-1 -> 2 + 6 PF DMAs in flight ----
+  issue_planes(0, 0);
+#pragma unroll
+  for (int j = 0; j < PF; ++j) { issue_planes(j + 1, j + 1); issue_y(j, j); }
+  int ps_rd = 0, ps_wr = PF + 1;                         // plane ring slots: read by this iteration / filled for iteration it + PF + 1
+  GF_VMWAIT(6 * PF);                                     // planes(0) landed
+  lds_barrier();                                         // ... and are visible to every wave (so is the zero slot)
+
+  auto step = [&](auto ktag, auto first_tag, int itb) {
+    constexpr int k = decltype(ktag)::value;
+    constexpr bool FIRST = decltype(first_tag)::value;
+    const int it = itb + k;
+    const int r = r0 + it;
+    // retire y(it) and planes(it+1): issued PF iterations ago, followed by that iteration's 8 stores and PF-1 iterations of
+    // VM_ITER vector-memory instructions (in the first PF iterations: by the rest of the prologue, 6 per row, and k iterations);
+    // vmcnt saturates at 63: the wait is then stricter than needed (~4.5 iterations stay in flight), never laxer
+    GF_VMWAIT(FIRST ? 6 * (PF - 1 - k) + VM_ITER * k : 8 + VM_ITER * (PF - 1));
+    const unsigned a_pit = a_pl + (unsigned)ps_rd * 2048u;
+    float y0, y1, y2, y3;
+    f32x4 gv;
+    GF_RD32(y0, a_y, k * 4096 + 0 * 256);
+    GF_RD32(y1, a_y, k * 4096 + 1 * 256);
+    GF_RD32(y2, a_y, k * 4096 + 2 * 256);
+    GF_RD32(y3, a_y, k * 4096 + 3 * 256);
+    GF_RD128(gv, a_pit, 0);                              // guide(r, 4 columns)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(gv)::"memory");   // slot k is free again
+    issue_planes(it + PF + 1, ps_wr);
+    issue_y(it + PF, k);
+    ps_rd = ps_rd == PD - 1 ? 0 : ps_rd + 1;
+    ps_wr = ps_wr == PD - 1 ? 0 : ps_wr + 1;
+    const bool rin = r >= 0 && r < H;
+    f32x4 yy;
+    yy[0] = (rin && cin[0]) ? y0 : 0.f;
+    yy[1] = (rin && cin[1]) ? y1 : 0.f;
+    yy[2] = (rin && cin[2]) ? y2 : 0.f;
+    yy[3] = (rin && cin[3]) ? y3 : 0.f;
+    const u32x4 f_y = split4(ring_push<k>(ry, yy), vmax);
+    const u32x4 f_gy = split4(ring_push<k>(rgy, gv * yy), vmax);
+    const u32x4 f_a0 = split4(wA0, vmax);
+    const u32x4 f_b0 = split4(wB0, vmax);
+    const u32x4 f_a1 = split4(wA1, vmax);
+    const u32x4 f_b1 = split4(wB1, vmax);
+    constexpr int HB = (k & 1) * H_BUF;                  // PF is even: the iteration's parity is static
+    if (pub) {
+      GF_WR128(a_pub, f_y, HB + 0 * H_QTY);
+      GF_WR128(a_pub, f_gy, HB + 1 * H_QTY);
+      GF_WR128(a_pub, f_a0, HB + 2 * H_QTY);
+      GF_WR128(a_pub, f_b0, HB + 3 * H_QTY);
+      GF_WR128(a_pub, f_a1, HB + 4 * H_QTY);
+      GF_WR128(a_pub, f_b1, HB + 5 * H_QTY);
+    }
+    lds_barrier();
+    // ---- stage 2: LF_e(r - 9) = (box(A_e) * g + box(b_e)) / n.  Eight store INSTRUCTIONS per iteration whatever the masks say:
+    // a lane without a valid output (strip halo column, column outside the image) carries an out-of-range offset, a warm-up /
+    // tail row a zero-length descriptor -- the hardware drops those stores ----
+    {
+      u32x4 h_a0, h_b0, h_a1, h_b1;
+      f32x4 g2, rn2;
+      GF_RD128(h_a0, a_rd, HB + 2 * H_QTY);
+      GF_RD128(h_b0, a_rd, HB + 3 * H_QTY);
+      GF_RD128(h_a1, a_rd, HB + 4 * H_QTY);
+      GF_RD128(h_b1, a_rd, HB + 5 * H_QTY);
+      GF_RD128(g2, a_pit, 5 * 256);                      // output row r - 9
+      GF_RD128(rn2, a_pit, 6 * 256);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h_a0), "+v"(h_b0), "+v"(h_a1), "+v"(h_b1), "+v"(g2), "+v"(rn2)::"memory");
+      const f32x4 s_a0 = band_mfma(a_own, f_a0, a_halo, h_a0);
+      const f32x4 s_b0 = band_mfma(a_own, f_b0, a_halo, h_b0);
+      const f32x4 s_a1 = band_mfma(a_own, f_a1, a_halo, h_a1);
+      const f32x4 s_b1 = band_mfma(a_own, f_b1, a_halo, h_b1);
+      const int ro = r - (2 * R + 1);
+      const bool rowv = ro >= ybeg && ro < yend;
+      const unsigned so = (unsigned)max(ro, 0) * rowbytes;
+      const f32x4 out0 = (s_a0 * g2 + s_b0) * rn2;
+      const f32x4 out1 = (s_a1 * g2 + s_b1) * rn2;
+      const int nrec = rowv ? out_bytes : 0;             // zero-length descriptor: every store of this row is dropped
+      const __amdgpu_buffer_rsrc_t ro0 = __builtin_amdgcn_make_buffer_rsrc(o0, 0, nrec, RSRC_W3);
+      const __amdgpu_buffer_rsrc_t ro1 = __builtin_amdgcn_make_buffer_rsrc(o1, 0, nrec, RSRC_W3);
+      // (the element is copied to a scalar first: __builtin_bit_cast applied to a vector-element lvalue reads element 0)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const float o = out0[i]; __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), ro0, soff[i], so, 2); }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const float o = out1[i]; __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), ro1, soff[i], so, 2); }
+    }
+    // ---- stage 1: (A_e, b_e) of row r - 4, then their 9-row window sums for the next iteration ----
+    {
+      u32x4 h_y, h_gy;
+      f32x4 rn1, mg1, rd0, rd1;
+      GF_RD128(h_y, a_rd, HB + 0 * H_QTY);
+      GF_RD128(h_gy, a_rd, HB + 1 * H_QTY);
+      GF_RD128(rn1, a_pit, 1 * 256);                     // stage-1 row r - 4
+      GF_RD128(mg1, a_pit, 2 * 256);
+      GF_RD128(rd0, a_pit, 3 * 256);
+      GF_RD128(rd1, a_pit, 4 * 256);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h_y), "+v"(h_gy), "+v"(rn1), "+v"(mg1), "+v"(rd0), "+v"(rd1)::"memory");
+      const f32x4 s_y = band_mfma(a_own, f_y, a_halo, h_y);
+      const f32x4 s_gy = band_mfma(a_own, f_gy, a_halo, h_gy);
+      const int r1 = r - R;
+      const bool in1 = r1 >= 0 && r1 < H;
+      f32x4 rn;                                                   // outside the image the coefficients are zero padding
+      rn[0] = (in1 && cin[0]) ? rn1[0] : 0.f;
+      rn[1] = (in1 && cin[1]) ? rn1[1] : 0.f;
+      rn[2] = (in1 && cin[2]) ? rn1[2] : 0.f;
+      rn[3] = (in1 && cin[3]) ? rn1[3] : 0.f;
+      const f32x4 my = s_y * rn;
+      const f32x4 cov = s_gy * rn - mg1 * my;
+      const f32x4 A0 = cov * rd0, A1 = cov * rd1;
+      wA0 = ring_push<k>(rA0, A0);
+      wB0 = ring_push<k>(rB0, my - A0 * mg1);
+      wA1 = ring_push<k>(rA1, A1);
+      wB1 = ring_push<k>(rB1, my - A1 * mg1);
+    }
+  };
+  auto body = [&](auto first_tag, int itb) {
+    step(std::integral_constant<int, 0>{}, first_tag, itb);
+    step(std::integral_constant<int, 1>{}, first_tag, itb);
+    step(std::integral_constant<int, 2>{}, first_tag, itb);
+    step(std::integral_constant<int, 3>{}, first_tag, itb);
+    step(std::integral_constant<int, 4>{}, first_tag, itb);
+    step(std::integral_constant<int, 5>{}, first_tag, itb);
+  };
+  static_assert(PF == 6, "the unrolled body lists PF = 6 steps");
+
+  body(std::true_type{}, 0);
+  for (int itb = PF; itb < n_it; itb += PF) body(std::false_type{}, itb);
+
+  GF_VMWAIT(0);                                          // no LDS-DMA may land after the workgroup's LDS is released
+  // a 9-row sum beyond the f16 range cannot be split: tell the host wrapper's fallback launch
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, m));
+  if (l == 0 && !(vmax < 65000.f)) atomicOr(flag, 1u);
+}
+
+}  // namespace paif_gf_mfma

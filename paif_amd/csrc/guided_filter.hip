@@ -235,11 +235,14 @@ __device__ __forceinline__ void lds_barrier() {
 // In the fused kernel these were recomputed by all 8 channel-quad lanes of every column in every workgroup (17 % of
 // its VALU instructions, a fifth of its LDS operations and one of its three divisions per row).
 constexpr int GT = 32, GH = GT + 2 * R;   // 32 x 32 output tile, 40 x 40 halo tile
-__global__ __launch_bounds__(256) void gf_guide_stats_kernel(const float* __restrict__ guide, float2* __restrict__ gs, float eps0,
-                                                             float eps1, int B, int H, int W, int tilesX, int tilesY) {
+// Output: four [B*H*W] planes -- mean_g, 1/(var_g + eps0), 1/(var_g + eps1), 1/n -- each read as 16-byte column groups by the
+// matrix-core kernel (gf_mfma.hip); block 0 also clears the f16-range flag behind the planes.
+__global__ __launch_bounds__(256) void gf_guide_stats_kernel(const float* __restrict__ guide, float* __restrict__ gs, unsigned* __restrict__ flag,
+                                                             float eps0, float eps1, int B, int H, int W, int tilesX, int tilesY) {
   __shared__ float sG[GH][GH + 1];
   __shared__ float sH[GH][GT + 1], sH2[GH][GT + 1];
   int t = blockIdx.x;
+  if (t == 0 && threadIdx.x == 0) *flag = 0u;
   const int tx = t % tilesX; t /= tilesX;
   const int ty = t % tilesY;
   const int b = t / tilesY;
@@ -274,8 +277,10 @@ __global__ __launch_bounds__(256) void gf_guide_stats_kernel(const float* __rest
     const float mg = s * rn;
     const float var = ss * rn - mg * mg;
     const size_t pix = (size_t)b * H * W + (size_t)yy * W + xx;
-    gs[pix] = make_float2(mg, 1.0f / (var + eps0));
-    gs[npix + pix] = make_float2(mg, 1.0f / (var + eps1));
+    gs[pix] = mg;
+    gs[npix + pix] = 1.0f / (var + eps0);
+    gs[2 * npix + pix] = 1.0f / (var + eps1);
+    gs[3 * npix + pix] = rn;
   }
 }
 
@@ -310,9 +315,10 @@ template <typename V> __device__ __forceinline__ V vfma(float s, V a, V c) {
 
 template <typename V, int NL>
 __global__ __launch_bounds__(FC * NL) void gf_fused_kernel(const float* __restrict__ guide, const float* __restrict__ y,
-                                                           const float2* __restrict__ gs, float* __restrict__ lf, int B, int H, int W,
-                                                           int nstrip, int nseg, int frows) {
+                                                           const float* __restrict__ gs, const unsigned* __restrict__ only_if, float* __restrict__ lf,
+                                                           int B, int H, int W, int nstrip, int nseg, int frows) {
   constexpr int VW = VecOps<V>::VW;
+  if (only_if != nullptr && *only_if == 0u) return;      // fallback launch behind the matrix-core kernel: runs only when it raised the flag
   __shared__ V s_a[2][FC][NL];
   __shared__ V s_b[2][FC][NL];
   const int xi = threadIdx.x / NL;
@@ -329,7 +335,8 @@ __global__ __launch_bounds__(FC * NL) void gf_fused_kernel(const float* __restri
   const int ybeg = seg * frows, yend = min(H, ybeg + frows);   // frows = output rows per workgroup (chosen at launch)
   const size_t img = (size_t)b * H * W;
   float* out = lf + (size_t)e * ((size_t)B * H * W * 32);
-  const float2* gse = gs + (size_t)e * ((size_t)B * H * W);
+  const float* gmean = gs;                                            // planes: mean_g, 1/(var+eps0), 1/(var+eps1), 1/n
+  const float* grden = gs + (size_t)(1 + e) * ((size_t)B * H * W);
 
   // 1/n of the border-clipped window, n = cy * cx: cx is fixed per thread and cy takes the values 5..9 -- the five
   // reciprocals are formed once (exact divisions, same values as before) instead of one division per row and stage
@@ -365,7 +372,8 @@ __global__ __launch_bounds__(FC * NL) void gf_fused_kernel(const float* __restri
     const size_t px = img + (size_t)min(max(r0 + p, 0), H - 1) * W + colc;
     pv[p] = *reinterpret_cast<const V*>(y + px * 32);
     pg[p] = guide[px];
-    ps[p] = gse[img + (size_t)min(max(r0 + p - R, 0), H - 1) * W + colc];
+    const size_t sx = img + (size_t)min(max(r0 + p - R, 0), H - 1) * W + colc;
+    ps[p] = make_float2(gmean[sx], grden[sx]);
   }
   for (int rr = r0; rr < r1; rr += K) {
 #pragma unroll
@@ -380,7 +388,8 @@ __global__ __launch_bounds__(FC * NL) void gf_fused_kernel(const float* __restri
         const size_t px = img + (size_t)min(max(row + PF, 0), H - 1) * W + colc;
         pv[k % PF] = *reinterpret_cast<const V*>(y + px * 32);
         pg[k % PF] = guide[px];
-        ps[k % PF] = gse[img + (size_t)min(max(row + PF - R, 0), H - 1) * W + colc];
+        const size_t sx = img + (size_t)min(max(row + PF - R, 0), H - 1) * W + colc;
+        ps[k % PF] = make_float2(gmean[sx], grden[sx]);
       }
       const int irow = row - R;               // stage-1 row whose 9-row window is complete
       if (irow < ybeg - R) continue;          // block-uniform
@@ -455,16 +464,24 @@ __global__ __launch_bounds__(FC * NL) void gf_fused_kernel(const float* __restri
 
 }  // namespace
 
-extern "C" size_t paif_guided_filter_fused_workspace_floats(int B, int H, int W) { return (size_t)4 * B * H * W; }
+namespace paif_gf_mfma {
+__global__ void gf_mfma_kernel(const float* __restrict__ guide, const float* __restrict__ y, const float* __restrict__ planes,
+                               float* __restrict__ lf, unsigned* __restrict__ flag, int B, int H, int W, int nstrip, int nseg, int frows,
+                               int ntiles);
+}
+
+// workspace: four per-pixel planes + one 256-byte line holding the f16-range flag
+extern "C" size_t paif_guided_filter_fused_workspace_floats(int B, int H, int W) { return (size_t)4 * B * H * W + 64; }
 
 extern "C" int paif_guided_filter_fused_fwd(const float* guide, const float* y, float* lf, float eps0, float eps1, float* workspace, int B,
                                             int H, int W, paif_stream_t stream) {
   PAIF_REQUIRE(guide && y && lf && workspace && B > 0, PAIF_EINVAL, "guided_filter_fused: bad arguments");
   PAIF_REQUIRE(H > 2 * R + 1 && W > 2 * R + 1, PAIF_EINVAL, "guided_filter: H,W must exceed 2r+1 = %d (got %dx%d)", K, H, W);
   const int nstrip = (W + FO - 1) / FO;
-  // Rows per workgroup: `resident` workgroups fit a CU (8 waves at ~250 VGPRs for the float4 forms, 16 waves for float2), so
-  // the launch runs in rounds of 256 * resident workgroups and a workgroup costs (rows + 4R halo) row-iterations: pick the
-  // split with the fewest rounds x (rows + 16).
+  // engine: "mfma" (default; horizontal box sums on the matrix cores, gf_mfma.hip) or "valu" (the all-VALU kernel below, also the
+  // fallback the mfma engine's f16-range flag selects).  PAIF_GF_ENGINE / PAIF_GF_FORM are A/B knobs.
+  const char* eng = getenv("PAIF_GF_ENGINE");           // read per call: the tests run both engines in one process
+  const int engine = (eng && !strcmp(eng, "valu")) ? 0 : 1;
   static const int form = [] {
     const char* e = getenv("PAIF_GF_FORM");
     if (!e) return 0;
@@ -472,25 +489,51 @@ extern "C" int paif_guided_filter_fused_fwd(const float* guide, const float* y, 
   }();
   const int zgroups = form == 0 ? 1 : form == 1 ? 2 : form == 2 ? 4 : 1;
   const int resident = form == 0 ? 1 : form == 1 ? 2 : form == 2 ? 4 : 1;
-  int nseg = 1;
-  long best = -1;
-  for (int n = 1; n <= 16 && n <= H; ++n) {
-    const int rows = (H + n - 1) / n;
-    const long blocks = (long)B * nstrip * n * 2 * zgroups;
-    const long cost = ((blocks + 256 * resident - 1) / (256 * resident)) * (rows + 4 * R);
-    if (best < 0 || cost < best) { best = cost; nseg = n; }
-  }
-  const int frows = (H + nseg - 1) / nseg;
   hipStream_t st = paif::as_stream(stream);
-  float2* gs = reinterpret_cast<float2*>(workspace);
+  const size_t npix = (size_t)B * H * W;
+  unsigned* flag = reinterpret_cast<unsigned*>(workspace + 4 * npix);
   const int gtx = (W + GT - 1) / GT, gty = (H + GT - 1) / GT;
-  hipLaunchKernelGGL(gf_guide_stats_kernel, dim3(B * gtx * gty), dim3(256), 0, st, guide, gs, eps0, eps1, B, H, W, gtx, gty);
+  hipLaunchKernelGGL(gf_guide_stats_kernel, dim3(B * gtx * gty), dim3(256), 0, st, guide, workspace, flag, eps0, eps1, B, H, W, gtx, gty);
   PAIF_LAUNCH_CHECK("guided_filter_fused(stats)");
+  // Rows per workgroup: one workgroup per CU is resident (8 waves at <= 256 VGPRs), a workgroup costs (rows + warm-up) row
+  // iterations: pick the split with the fewest rounds x iterations.
+  auto pick = [&](int warm, int res, int zg, int& nseg) {
+    long best = -1;
+    nseg = 1;
+    for (int n = 1; n <= 16 && n <= H; ++n) {
+      const int rows = (H + n - 1) / n;
+      const long blocks = (long)B * nstrip * n * 2 * zg;
+      const long cost = ((blocks + 256 * res - 1) / (256 * res)) * (rows + warm);
+      if (best < 0 || cost < best) { best = cost; nseg = n; }
+    }
+  };
+  if (engine == 1) {
+    // one 4-wave workgroup (one wave per SIMD, the whole register file) per CU; a workgroup costs rows + 17 warm-up iterations
+    // (rounded up to 6); tiles x 2 channel halves, the halves of a tile 8 block ids apart (same XCD)
+    int nseg = 1;
+    long best = -1;
+    for (int n = 1; n <= 24 && n <= H; ++n) {
+      const int rows = (H + n - 1) / n;
+      const long blocks = (long)B * nstrip * n * 2;
+      const long cost = ((blocks + 255) / 256) * ((rows + 4 * R + 1 + 5) / 6 * 6);
+      if (best < 0 || cost < best) { best = cost; nseg = n; }
+    }
+    const int frows = (H + nseg - 1) / nseg;
+    const int ntiles = B * nstrip * nseg;
+    const int grid = (ntiles + 7) / 8 * 16;
+    hipLaunchKernelGGL(paif_gf_mfma::gf_mfma_kernel, dim3(grid), dim3(256), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip, nseg, frows,
+                       ntiles);
+    PAIF_LAUNCH_CHECK("guided_filter_fused(mfma)");
+  }
+  int nseg;
+  pick(4 * R, resident, zgroups, nseg);
+  const int frows = (H + nseg - 1) / nseg;
+  const unsigned* only_if = engine == 1 ? flag : nullptr;
   const dim3 grid(B * nstrip * nseg, 2, zgroups);
-  if (form == 0) hipLaunchKernelGGL((gf_fused_kernel<float4, 8>), grid, dim3(FC * 8), 0, st, guide, y, gs, lf, B, H, W, nstrip, nseg, frows);
-  else if (form == 1) hipLaunchKernelGGL((gf_fused_kernel<float4, 4>), grid, dim3(FC * 4), 0, st, guide, y, gs, lf, B, H, W, nstrip, nseg, frows);
-  else if (form == 2) hipLaunchKernelGGL((gf_fused_kernel<float4, 2>), grid, dim3(FC * 2), 0, st, guide, y, gs, lf, B, H, W, nstrip, nseg, frows);
-  else hipLaunchKernelGGL((gf_fused_kernel<float2, 16>), grid, dim3(FC * 16), 0, st, guide, y, gs, lf, B, H, W, nstrip, nseg, frows);
+  if (form == 0) hipLaunchKernelGGL((gf_fused_kernel<float4, 8>), grid, dim3(FC * 8), 0, st, guide, y, workspace, only_if, lf, B, H, W, nstrip, nseg, frows);
+  else if (form == 1) hipLaunchKernelGGL((gf_fused_kernel<float4, 4>), grid, dim3(FC * 4), 0, st, guide, y, workspace, only_if, lf, B, H, W, nstrip, nseg, frows);
+  else if (form == 2) hipLaunchKernelGGL((gf_fused_kernel<float4, 2>), grid, dim3(FC * 2), 0, st, guide, y, workspace, only_if, lf, B, H, W, nstrip, nseg, frows);
+  else hipLaunchKernelGGL((gf_fused_kernel<float2, 16>), grid, dim3(FC * 16), 0, st, guide, y, workspace, only_if, lf, B, H, W, nstrip, nseg, frows);
   PAIF_LAUNCH_CHECK("guided_filter_fused");
   return 0;
 }

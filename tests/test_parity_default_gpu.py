@@ -1,10 +1,11 @@
 """GPU parity IN THE ARITHMETIC AND AT THE BATCH SIZES bench.py RUNS.
 
 The gradient / trajectory tests of test_attack_gpu.py and test_backward_fullsize_gpu.py pin the exact-fp32 kernels
-(`set_conv_precision("f32")`, `set_gemm_precision("f32")`).  The product default -- and what `bench.py --workload pgd|train`
-times -- is split-bf16 conv products (forward AND dgrad), split-bf16 attention forward/backward and "auto" GEMMs.  Every test
-here is parametrised over precision in {exact, default}; the bounds for `default` were MEASURED (tools/parity_report.py collects
-the numbers the tests print into gpurun_out/parity_metrics.json) and are stated next to the reference arithmetic's own
+(`set_conv_precision("f32")`, `set_gemm_precision("f32")`).  Until round 3 the product default -- and what `bench.py --workload
+pgd|train` timed -- was split-bf16 conv products (forward AND dgrad), split-bf16 attention forward/backward and "auto" GEMMs inside
+the attack loop as well.  Every test here is parametrised over precision in {exact, default, fast} (see the fixture); the numbers
+were MEASURED on MI355X (each test writes them to gpurun_out/parity_metrics.json; the round-3 record is committed as
+profiles/r03_parity_default_arithmetic.json) and are stated next to the reference arithmetic's own
 float32-vs-float64 disagreement on the same quantity (tests/golden/gn_attack_PGD10.npz: `floor_*`), which is the yardstick: a PGD
 trajectory is chaotic in sign(g), so "as close to the float64 run as the reference's own float32 run is" is the strongest
 statement available for either arithmetic.
@@ -47,18 +48,23 @@ def _record(name, **metrics):
     json.dump(allm, open(path, "w"), indent=1, sort_keys=True)
 
 
-@pytest.fixture(params=["exact", "default"])
+@pytest.fixture(params=["exact", "default", "fast"])
 def precision(request):
-    old, oldg = ops.CONFIG["conv_precision"], ops.CONFIG["gemm_precision"]
+    """exact   = every kernel fp32-exact (what test_attack_gpu.py / test_backward_fullsize_gpu.py pin);
+    default = what ops.CONFIG ships with and bench.py runs: split-bf16 convs / "auto" GEMMs for plain forwards and backwards, and
+              -- since the round-3 finding below -- the ATTACK LOOPS on the exact kernels (CONFIG["attack_precision"] = "exact");
+    fast    = ops.set_attack_precision("fast"): the attack loops in split-bf16 too (bench.py --attack-precision fast)."""
+    old = dict(ops.CONFIG)
     if request.param == "exact":
         ops.set_conv_precision("f32")
         ops.set_gemm_precision("f32")
-    else:                                   # what ops.CONFIG ships with and bench.py runs
+        ops.set_attack_precision("exact")
+    else:
         ops.set_conv_precision("bf16x3")
         ops.set_gemm_precision("auto")
+        ops.set_attack_precision("exact" if request.param == "default" else "fast")
     yield request.param
-    ops.set_conv_precision(old)
-    ops.set_gemm_precision(oldg)
+    ops.CONFIG.update(old)
 
 
 def _model(bb="mit_b0"):
@@ -138,12 +144,22 @@ def test_attack_both_pgd10_trajectory_and_attacked_miou(golden, precision):
             delta_mismatch_vs_ref32=dm32, delta_mismatch_vs_ref64=dm64, moved_pixels=moved, miou=miou, miou_ref=miou_ref,
             ref_floor_sign=g["floor_sign"], ref_floor_loss=g["floor_loss"], ref_floor_delta=g["floor_delta"])
     lim = BOUNDS["pgd10"][precision]
+    assert abs(miou - miou_ref) <= 1e-3, (miou, miou_ref)                      # mIoU within 0.1 pt, every arithmetic
+    assert moved <= lim["moved"] * pred.numel(), moved
+    if precision == "fast":
+        # THE FINDING (round 3): with split-bf16 conv products inside the attack loop the trajectory leaves the reference's:
+        # measured sign mismatch 2.4e-4 (iteration 1) -> 9e-4 (3) -> 3.5e-3 (5) -> 2.5e-2 (10), differing delta 5.3 %, loss
+        # 3.3e-3 -- 60x the reference's own float32-vs-float64 disagreement (floor_sign <= 4.1e-4).  Not a tolerance: the
+        # product default is "exact" because of it; what is asserted here is the measured envelope (x2) so that a
+        # regression of the fast mode is still caught, and that the A1 bound holds for the first three iterations.
+        assert (sm64[:3] <= 2e-3).all() and loss_rel[:3].max() <= 1e-4, (sm64, loss_rel)
+        assert sm64.max() <= 5e-2 and max(dm64) <= 0.11 and loss_rel.max() <= 1e-2, (sm64, dm64, loss_rel)
+        return
     assert loss_rel.max() <= lim["loss"], loss_rel
-    # the yardstick: not farther from the float64 trajectory than `k` x the reference's own float32 run is (+ an absolute 1e-3)
+    # the yardstick: not farther from the float64 trajectory than `k` x the reference's own float32 run is (+ an absolute 1e-3):
+    # SURVEY 8(a) A1's <= 1e-3 per iteration on top of the reference arithmetic's own floor
     assert (sm64 <= lim["sign_k"] * g["floor_sign"] + 1e-3).all(), (sm64, g["floor_sign"])
     assert max(dm64) <= lim["sign_k"] * float(g["floor_delta"].max()) + 1e-3, (dm64, g["floor_delta"])
-    assert abs(miou - miou_ref) <= 1e-3, (miou, miou_ref)                      # mIoU within 0.1 pt
-    assert moved <= lim["moved"] * pred.numel(), moved
     assert float(d_ir.detach().abs().max()) <= EPS + 1e-7 and float(d_vis.detach().abs().max()) <= EPS + 1e-7
 
 
@@ -230,11 +246,16 @@ _CACHE = {}
 # Stated bounds.  `exact` = the SURVEY 8(a) A1 metric as round 2 stated it.  `default` = measured on MI355X in round 3
 # (profiles/r03_parity_default_arithmetic.json holds the numbers), with head-room of ~2x over the measurement; the comparison
 # with the reference's own float32-vs-float64 floor is asserted inside the PGD-10 test.
+_A1 = dict(loss=1e-4, sign=2e-3, delta=2e-3)
 BOUNDS = {
-    "pgd3": {"exact": dict(loss=1e-4, sign=2e-3, delta=2e-3), "default": dict(loss=1e-4, sign=2e-3, delta=2e-3)},
-    "pgd10": {"exact": dict(loss=1e-3, sign_k=1.5, moved=1e-3), "default": dict(loss=1e-3, sign_k=1.5, moved=1e-3)},
-    "pgd1_full": {"exact": dict(loss=1e-4, sign=2e-3, gmax=5e-2, gmean=2e-3), "default": dict(loss=1e-4, sign=2e-3, gmax=5e-2, gmean=2e-3)},
-    "wetr_dx": {"exact": 1e-4, "default": 1e-4},
+    # measured (fast): loss 2.6e-5, sign 9e-4, delta 1.5e-3
+    "pgd3": {"exact": _A1, "default": _A1, "fast": dict(loss=1e-4, sign=2e-3, delta=3e-3)},
+    # measured (exact / default): loss 6.3e-5 (the reference's own float32 run: 6.0e-5), sign vs float64 <= 8.1e-5, delta 8.1e-5
+    "pgd10": {"exact": dict(loss=2e-4, sign_k=1.5, moved=1e-3), "default": dict(loss=2e-4, sign_k=1.5, moved=1e-3), "fast": dict(moved=1e-3)},
+    # one iteration at 480x640 (vs the oracle's float32 autograd, itself ~2e-4 from its float64): measured sign 2.1e-4 / 2.6e-4 (fast)
+    "pgd1_full": {k: dict(loss=1e-4, sign=2e-3, gmax=5e-2, gmean=2e-3) for k in ("exact", "default", "fast")},
+    # plain autograd through the SegFormer in the default arithmetic: measured 2.6e-6 (exact 5e-7)
+    "wetr_dx": {"exact": 1e-4, "default": 1e-4, "fast": 1e-4},
 }
 
 
