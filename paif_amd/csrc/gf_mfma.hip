@@ -36,11 +36,22 @@ namespace paif_gf_mfma {
 constexpr int R = 4;
 constexpr int SC = 64;            // input columns per workgroup
 constexpr int SO = SC - 4 * R;    // 48 output columns
-constexpr int PF = 6;             // input rows in flight per lane = the unroll factor = the partial-sum ring size (static slots)
-constexpr int PD = PF + 3;        // plane ring depth (see the slot-reuse argument at the DMA issue)
+constexpr int PF = 6;             // the unroll factor = the partial-sum ring size (static ring slots)
+#ifndef GF_PFY
+#define GF_PFY 6
+#endif
+#ifndef GF_XPOSE
+#define GF_XPOSE 0
+#endif
+constexpr int PFY = GF_PFY;       // input rows in flight per wave (LDS-DMA ring depth; slots are a running counter)
+constexpr bool XPOSE = GF_XPOSE;  // stores: 1 = 16 bytes per lane through a wave-private LDS transposition (2 per iteration), 0 = 8 dword stores
+constexpr int PD = PFY + 3;       // plane ring depth (see the slot-reuse argument at the DMA issue)
 constexpr int NQ = 6;             // exchanged quantities: sum y, sum g*y, A0, b0, A1, b1
 constexpr int ZSLOT = 8;          // halo slot that stays zero (outside neighbours of the strip's edge waves)
-constexpr int VM_ITER = 2 + 4 + 8;  // vector-memory instructions per wave and iteration: 2 plane DMAs, 4 input DMAs, 8 stores
+// vector-memory instructions per wave and iteration: plane DMAs (1 x 16 B per lane when W % 4 == 0, else 2 x 4 B), 1 input DMA
+// (16 B per lane: the wave's 16 columns x 16 channels), 2 stores (16 B per lane, one per eps)
+constexpr int NSTORE = XPOSE ? 2 : 8;
+template <bool AL4> struct VmIter { static constexpr int planes = AL4 ? 1 : 2, value = planes + 1 + NSTORE; };
 constexpr unsigned RSRC_W3 = 0x00020000u;
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -50,24 +61,34 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // LDS map (byte offsets inside the kernel's only __shared__ object, which therefore starts at LDS address 0)
 constexpr int Y_OFF = 0;
-constexpr int Y_BYTES = PF * 4 * 4 * 64 * 4;              // [PF][4 waves][4 cols][64 lanes] float       24,576
+constexpr int Y_BYTES = PFY * 4 * 1024;                   // [PFY][4 waves][16 cols][16 channels] float  49,152
 constexpr int P_OFF = Y_OFF + Y_BYTES;
-constexpr int P_BYTES = PD * 8 * 64 * 4;                  // [PD][8 planes (7 used)][64 cols] float      18,432
+constexpr int P_SLOT = 12 * 256;                          // one iteration's plane set: 12 slots of 64 columns
+constexpr int P_BYTES = PD * P_SLOT;                      // [PD][12][64 cols] float                      46,080
 constexpr int H_OFF = P_OFF + P_BYTES;
 constexpr int H_QTY = (ZSLOT + 1) * 256;                  // one quantity: 9 slots x 16 channels x 16 B
 constexpr int H_BUF = NQ * H_QTY;                         // one buffer (iteration parity)
 constexpr int H_BYTES = 2 * H_BUF;                        //                                              27,648
-constexpr int LDS_BYTES = H_OFF + H_BYTES;
+constexpr int T_OFF = H_OFF + H_BYTES;                    // per-wave output transposition: [4 waves][2 eps][16 cols][16 ch] float
+constexpr int T_BYTES = 4 * 2048;
+constexpr int LDS_BYTES = T_OFF + T_BYTES;
 
-#define GF_VMWAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((n) > 63 ? 63 : (n)) : "memory")
+#ifndef GF_VMCAP
+#define GF_VMCAP 63
+#endif
+#define GF_VMWAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((n) > GF_VMCAP ? GF_VMCAP : (n)) : "memory")
 #define GF_RD32(dst, addr, off) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
 #define GF_RD128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
 #define GF_WR128(addr, val, off) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(val), "n"(off) : "memory")
+#define GF_WR32(addr, val, off) asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "v"(val), "n"(off) : "memory")
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ void dma4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_off) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(uintptr_t)lds_off, 4, voff, soff, 0, 0);
+}
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_off) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(uintptr_t)lds_off, 16, voff, soff, 0, 0);
 }
 
 // four fp32 values (the lane's 4 columns) -> B-operand fragment [hi(c0,c1), lo(c0,c1), hi(c2,c3), lo(c2,c3)]
@@ -75,13 +96,18 @@ __device__ __forceinline__ u32x4 split4(f32x4 v, float& vmax) {
   // max |v| seen (two v_max3_f32 with |.| source modifiers; a NaN operand is ignored -- it propagates to the output by itself)
   asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(vmax) : "v"(vmax), "v"(v[0]), "v"(v[1]));
   asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(vmax) : "v"(vmax), "v"(v[2]), "v"(v[3]));
-  const half2v h01 = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(v[0], v[1]));
-  const half2v h23 = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(v[2], v[3]));
-  const half2v l01 = {(_Float16)(v[0] - (float)h01[0]), (_Float16)(v[1] - (float)h01[1])};
-  const half2v l23 = {(_Float16)(v[2] - (float)h23[0]), (_Float16)(v[3] - (float)h23[1])};
+  // hi = rtz_f16(v) (packed convert); lo = rn_f16(v - hi) in ONE instruction per value: v_fma_mix{lo,hi}_f16 evaluates
+  // fma(hi as f16, -1.0, v) in fp32 (exact: v - hi has at most 13 significant bits) and rounds it into one half of the result
   u32x4 f;
-  f[0] = __builtin_bit_cast(unsigned, h01); f[1] = __builtin_bit_cast(unsigned, l01);
-  f[2] = __builtin_bit_cast(unsigned, h23); f[3] = __builtin_bit_cast(unsigned, l23);
+  f[0] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v[0], v[1]));
+  f[2] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v[2], v[3]));
+  unsigned l01, l23;
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l01) : "v"(f[0]), "v"(v[0]));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l01) : "v"(f[0]), "v"(v[1]));
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l23) : "v"(f[2]), "v"(v[2]));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l23) : "v"(f[2]), "v"(v[3]));
+  f[1] = l01;
+  f[3] = l23;
   return f;
 }
 
@@ -129,10 +155,13 @@ __device__ __forceinline__ f32x4 ring_push(Ring& rg, f32x4 x) {
 
 // One (16-channel half, batch image, 64-column strip, row segment) per workgroup of 4 waves.
 //   planes: [4][B*H*W] = mean_g, 1/(var_g + eps0), 1/(var_g + eps1), 1/n  (gf_guide_stats_kernel)
+//   AL4: W % 4 == 0 -- a lane's 4 columns of a plane are one aligned 16-byte piece (one plane DMA per wave and iteration)
+template <bool AL4>
 __global__ __launch_bounds__(256, 1) void gf_mfma_kernel(const float* __restrict__ guide, const float* __restrict__ y,
                                                          const float* __restrict__ planes, float* __restrict__ lf,
                                                          unsigned* __restrict__ flag, int B, int H, int W, int nstrip, int nseg,
                                                          int frows, int ntiles) {
+  constexpr int VM_ITER = VmIter<AL4>::value;
   __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
   asm volatile("" ::"v"((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem) : "memory");   // only asm touches it
 
@@ -156,14 +185,17 @@ __global__ __launch_bounds__(256, 1) void gf_mfma_kernel(const float* __restrict
 
   // ---- per-lane constants ----
   bool cin[4];
-  unsigned yoff[4], soff[4];                            // byte offsets inside an image row: DMA source (clamped) / store (or out of range)
-  const bool store_cols = lc0 >= 2 * R && lc0 < SC - 2 * R;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    cin[i] = col0 + i >= 0 && col0 + i < W;
-    yoff[i] = (unsigned)((min(max(col0 + i, 0), W - 1) * 32 + 16 * chh + c) * 4);
-    soff[i] = (store_cols && cin[i]) ? yoff[i] : 0xFFFFFFFFu;
-  }
+  for (int i = 0; i < 4; ++i) cin[i] = col0 + i >= 0 && col0 + i < W;
+  // input DMA / output store geometry: lane -> (column l >> 2 of the wave's 16, channel quad l & 3): 16 bytes of one pixel
+  const int pc = X0 + 16 * q + (l >> 2);
+  const unsigned yoff16 = (unsigned)((min(max(pc, 0), W - 1) * 32 + 16 * chh + 4 * (l & 3)) * 4);
+  const int plc = 16 * q + (l >> 2);                    // strip-local column of the stored pixel
+  const unsigned soff16 = (plc >= 2 * R && plc < SC - 2 * R && pc >= 0 && pc < W) ? (unsigned)((pc * 32 + 16 * chh + 4 * (l & 3)) * 4) : 0xFFFFFFFFu;
+  unsigned soff[4];                                     // direct-store path: (column 4g + i, channel c) or out of range
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    soff[i] = (lc0 >= 2 * R && lc0 < SC - 2 * R && cin[i]) ? (unsigned)(((col0 + i) * 32 + 16 * chh + c) * 4) : 0xFFFFFFFFu;
   const u32x4 a_own = band_operand(l & 15, 4 * (l >> 4), true);
   const u32x4 a_halo = band_operand(l & 15, (l >> 4) == 0 ? -4 : 16, (l >> 4) < 2);
   // halo slots: publish own fragment as L (lanes g == 0) / R (g == 3); read left neighbour's R (g == 0), right neighbour's L (g == 1)
@@ -171,23 +203,34 @@ __global__ __launch_bounds__(256, 1) void gf_mfma_kernel(const float* __restrict
   const int rd_slot = g == 0 ? (q > 0 ? (q - 1) * 2 + 1 : ZSLOT) : g == 1 ? (q < 3 ? (q + 1) * 2 : ZSLOT) : ZSLOT;
   const unsigned a_pub = H_OFF + (q * 2 + (g == 3 ? 1 : 0)) * 256 + c * 16;
   const unsigned a_rd = H_OFF + rd_slot * 256 + c * 16;
-  const unsigned a_y = Y_OFF + q * 1024 + l * 4;
+  const unsigned a_y = Y_OFF + q * 1024 + g * 256 + c * 4;       // y(column 4g + i, channel c) of a ring slot: + i * 64
   const unsigned a_pl = P_OFF + lc0 * 4;
-  // plane set of an iteration (8 slots): g(r), rn(r-4), mg(r-4), rden0(r-4), rden1(r-4), g(r-9), rn(r-9), dummy;
-  // wave q stages slots 2q and 2q+1 (one image row of the strip's 64 columns each)
-  const float* const p_mg = planes, * const p_rd0 = planes + npix, * const p_rd1 = planes + 2 * npix, * const p_rn = planes + 3 * npix;
-  const float* const srcA = q == 0 ? guide : q == 1 ? p_mg : q == 2 ? p_rd1 : p_rn;
-  const float* const srcB = q == 0 ? p_rn : q == 1 ? p_rd0 : q == 2 ? guide : guide;
-  const int offA = q == 0 ? 0 : q == 3 ? -(2 * R + 1) : -R;
-  const int offB = q == 2 ? -(2 * R + 1) : q == 3 ? 0 : -R;
+  const unsigned a_tw = T_OFF + q * 2048 + g * 256 + c * 4;      // transposition: write (eps, column 4g + i, channel c): + eps * 1024 + i * 64
+  const unsigned a_tr = T_OFF + q * 2048 + l * 16;               // read back 16 bytes = (column l >> 2, channels 4 (l & 3) ..): + eps * 1024
   const unsigned rowbytes_pl = (unsigned)W * 4u, rowbytes = (unsigned)W * 128u;
-  const __amdgpu_buffer_rsrc_t rs_pa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(srcA + img), 0, (int)((size_t)H * rowbytes_pl), RSRC_W3);
-  const __amdgpu_buffer_rsrc_t rs_pb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(srcB + img), 0, (int)((size_t)H * rowbytes_pl), RSRC_W3);
+  const unsigned plane_bytes = (unsigned)(npix * 4);
+  const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(guide + img), 0, (int)((size_t)H * rowbytes_pl), RSRC_W3);
+  const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(planes + img), 0, (int)(3 * (size_t)plane_bytes + (size_t)H * rowbytes_pl), RSRC_W3);
   const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(y + img * 32), 0, (int)((size_t)H * rowbytes), RSRC_W3);
-  // stores: one descriptor per eps over the image (rebuilt per row with num_records = 0 for a warm-up / tail row)
   float* const o0 = lf + img * 32, * const o1 = lf + (npix + img) * 32;
   const int out_bytes = (int)((size_t)H * rowbytes);
-  const unsigned pcol = (unsigned)min(max(X0 + l, 0), W - 1) * 4u;
+  // Plane staging: 12 slots of 64 columns per iteration --
+  //   0..3 = {rn, mg, rden0, rden1}(r-4)   4 = g(r)   5 = g(r-9)   6, 7 = copies of 4, 5   8 = rn(r-9)   9..11 = copies / spare
+  // AL4: ONE 16-byte DMA per wave fills four consecutive slots (lane group j = l >> 4 -> slot base + j, 4 columns per lane):
+  //   wave 0 -> 0..3, wave 1 -> 4..7 (lane groups alternate between rows r and r-9), waves 2 and 3 -> 8..11 (the same data twice:
+  //   every wave must issue the same number of vector-memory instructions);
+  // else two 4-byte DMAs per wave, one column per lane: wave 0 -> 0, 1; wave 1 -> 2, 3; wave 2 -> 4, 5; wave 3 -> 8, 9.
+  // Plane byte offsets inside the planes buffer: mg 0, rden0 1, rden1 2, rn 3 (x plane_bytes).
+  const int j16 = l >> 4;
+  const unsigned colb4 = (unsigned)min(max(X0 + 4 * (l & 15), 0), max(W - 4, 0)) * 4u;
+  const unsigned colb1 = (unsigned)min(max(X0 + l, 0), W - 1) * 4u;
+  const unsigned pl_plane4 = q == 0 ? (j16 == 0 ? 3u : j16 == 1 ? 0u : j16 == 2 ? 1u : 2u) : q == 1 ? 0u : 3u;
+  const unsigned pl_voff4 = (q == 1 ? 0u : pl_plane4 * plane_bytes) + colb4;
+  const bool pl_second_row = (j16 & 1) != 0;              // wave 1: odd lane groups fetch row r-9, even ones row r
+  const unsigned pa_voff = (q == 0 ? 3u * plane_bytes : q == 1 ? 1u * plane_bytes : q == 2 ? 0u : 3u * plane_bytes) + colb1;
+  const unsigned pb_voff = (q == 0 ? 0u : q == 1 ? 2u * plane_bytes : q == 2 ? 0u : 3u * plane_bytes) + colb1;
+  const bool pl_guide = AL4 ? q == 1 : q == 2;
+  const unsigned pl_dst = AL4 ? (q == 0 ? 0u : q == 1 ? 4u : 8u) * 256u : (q == 0 ? 0u : q == 1 ? 2u : q == 2 ? 4u : 8u) * 256u;
 
   // zero the permanent zero slot of both halo buffers
   if (tid < 2 * NQ * 16) *reinterpret_cast<uint4*>(smem + H_OFF + (tid >> 4) * H_QTY + ZSLOT * 256 + (tid & 15) * 16) = make_uint4(0, 0, 0, 0);
@@ -204,47 +247,61 @@ __global__ __launch_bounds__(256, 1) void gf_mfma_kernel(const float* __restrict
   const int n_it = ((yend - ybeg) + 4 * R + 1 + PF - 1) / PF * PF;
 
   auto issue_planes = [&](int it_target, int pslot) {    // planes of iteration it_target -> ring slot pslot = it_target % PD
-    const int ra = min(max(r0 + it_target + offA, 0), H - 1), rb = min(max(r0 + it_target + offB, 0), H - 1);
-    const unsigned slot = P_OFF + (pslot * 8 + 2 * q) * 256;
-    dma4(rs_pa, pcol, (unsigned)ra * rowbytes_pl, slot);
-    dma4(rs_pb, pcol, (unsigned)rb * rowbytes_pl, slot + 256);
+    const unsigned base = P_OFF + pslot * P_SLOT + pl_dst;
+    const int rr = r0 + it_target;
+    const unsigned s_m4 = (unsigned)min(max(rr - R, 0), H - 1) * rowbytes_pl;            // rows r-4, r, r-9 (clamped)
+    const unsigned s_0 = (unsigned)min(max(rr, 0), H - 1) * rowbytes_pl;
+    const unsigned s_m9 = (unsigned)min(max(rr - (2 * R + 1), 0), H - 1) * rowbytes_pl;
+    const __amdgpu_buffer_rsrc_t rs = pl_guide ? rs_g : rs_p;
+    if (AL4) {
+      const unsigned sa = q == 0 ? s_m4 : q == 1 ? s_0 : s_m9, sb = q == 0 ? s_m4 : s_m9;   // wave-uniform
+      dma16(rs, pl_voff4 + (pl_second_row ? sb : sa), 0, base);
+    } else {
+      const unsigned sa = q <= 1 ? s_m4 : q == 2 ? s_0 : s_m9, sb = q <= 1 ? s_m4 : s_m9;
+      dma4(rs, pa_voff, sa, base);
+      dma4(rs, pb_voff, sb, base + 256);
+    }
   };
-  auto issue_y = [&](int it_target, int slot) {          // input row of iteration it_target -> ring slot (static)
-    const unsigned so = (unsigned)min(max(r0 + it_target, 0), H - 1) * rowbytes;
+  auto issue_y = [&](int it_target, int yslot) {         // input row of iteration it_target: 16 columns x 16 channels = 1 KB
+    dma16(rs_y, yoff16, (unsigned)min(max(r0 + it_target, 0), H - 1) * rowbytes, Y_OFF + (yslot * 4 + q) * 1024);
+  };
+  auto dropped_stores = [&]() {                          // two stores through a zero-length descriptor: issued, counted, dropped
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(o0, 0, 0, RSRC_W3);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dma4(rs_y, yoff[i], so, Y_OFF + ((slot * 4 + q) * 4 + i) * 256);
+    for (int i = 0; i < NSTORE; ++i) __builtin_amdgcn_raw_buffer_store_b32(0u, rz, 0, 0, 0);
   };
 
-  // ---- prologue: planes(0); then {planes(j+1), y(j)} for j = 0..PF-1 -> 2 + 6 PF DMAs in flight ----
+  // ---- prologue: planes(0); then {planes(j+1), y(j), two dropped stores} for j = 0..PFY-1: the same vector-memory pattern as a
+  // loop iteration, so that ONE wait constant is valid from the first iteration on ----
   issue_planes(0, 0);
-#pragma unroll
-  for (int j = 0; j < PF; ++j) { issue_planes(j + 1, j + 1); issue_y(j, j); }
-  int ps_rd = 0, ps_wr = PF + 1;                         // plane ring slots: read by this iteration / filled for iteration it + PF + 1
-  GF_VMWAIT(6 * PF);                                     // planes(0) landed
+#pragma unroll 1
+  for (int j = 0; j < PFY; ++j) { issue_planes(j + 1, j + 1); issue_y(j, j); dropped_stores(); }
+  GF_VMWAIT(VM_ITER * PFY);                              // planes(0) landed
   lds_barrier();                                         // ... and are visible to every wave (so is the zero slot)
+  int ps_rd = 0, ps_wr = PFY + 1, ys = 0;                // ring slots: planes read now / planes filled now / input row read and refilled now
 
-  auto step = [&](auto ktag, auto first_tag, int itb) {
+  auto step = [&](auto ktag, int itb) {
     constexpr int k = decltype(ktag)::value;
-    constexpr bool FIRST = decltype(first_tag)::value;
     const int it = itb + k;
     const int r = r0 + it;
-    // retire y(it) and planes(it+1): issued PF iterations ago, followed by that iteration's 8 stores and PF-1 iterations of
-    // VM_ITER vector-memory instructions (in the first PF iterations: by the rest of the prologue, 6 per row, and k iterations);
-    // vmcnt saturates at 63: the wait is then stricter than needed (~4.5 iterations stay in flight), never laxer
-    GF_VMWAIT(FIRST ? 6 * (PF - 1 - k) + VM_ITER * k : 8 + VM_ITER * (PF - 1));
-    const unsigned a_pit = a_pl + (unsigned)ps_rd * 2048u;
+    // retire y(it) and planes(it+1): issued PFY iterations ago, followed by that iteration's 2 stores and PFY-1 iterations of
+    // VM_ITER vector-memory instructions
+    GF_VMWAIT(NSTORE + VM_ITER * (PFY - 1));
+    const unsigned a_pit = a_pl + (unsigned)ps_rd * (unsigned)P_SLOT;
+    const unsigned a_yit = a_y + (unsigned)ys * 4096u;
     float y0, y1, y2, y3;
     f32x4 gv;
-    GF_RD32(y0, a_y, k * 4096 + 0 * 256);
-    GF_RD32(y1, a_y, k * 4096 + 1 * 256);
-    GF_RD32(y2, a_y, k * 4096 + 2 * 256);
-    GF_RD32(y3, a_y, k * 4096 + 3 * 256);
-    GF_RD128(gv, a_pit, 0);                              // guide(r, 4 columns)
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(gv)::"memory");   // slot k is free again
-    issue_planes(it + PF + 1, ps_wr);
-    issue_y(it + PF, k);
+    GF_RD32(y0, a_yit, 0 * 64);
+    GF_RD32(y1, a_yit, 1 * 64);
+    GF_RD32(y2, a_yit, 2 * 64);
+    GF_RD32(y3, a_yit, 3 * 64);
+    GF_RD128(gv, a_pit, 4 * 256);                        // guide(r, 4 columns)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(gv)::"memory");   // the y slot is free again
+    issue_planes(it + PFY + 1, ps_wr);
+    issue_y(it + PFY, ys);
     ps_rd = ps_rd == PD - 1 ? 0 : ps_rd + 1;
     ps_wr = ps_wr == PD - 1 ? 0 : ps_wr + 1;
+    ys = ys == PFY - 1 ? 0 : ys + 1;
     const bool rin = r >= 0 && r < H;
     f32x4 yy;
     yy[0] = (rin && cin[0]) ? y0 : 0.f;
@@ -267,9 +324,10 @@ __global__ __launch_bounds__(256, 1) void gf_mfma_kernel(const float* __restrict
       GF_WR128(a_pub, f_b1, HB + 5 * H_QTY);
     }
     lds_barrier();
-    // ---- stage 2: LF_e(r - 9) = (box(A_e) * g + box(b_e)) / n.  Eight store INSTRUCTIONS per iteration whatever the masks say:
-    // a lane without a valid output (strip halo column, column outside the image) carries an out-of-range offset, a warm-up /
-    // tail row a zero-length descriptor -- the hardware drops those stores ----
+    // ---- stage 2: LF_e(r - 9) = (box(A_e) * g + box(b_e)) / n, transposed through a wave-private LDS tile so that a lane stores
+    // 16 bytes (4 channels of one pixel).  Two store INSTRUCTIONS per iteration whatever the masks say: a lane without a valid
+    // output (strip halo column, column outside the image) carries an out-of-range offset, a warm-up / tail row a zero-length
+    // descriptor -- the hardware drops those stores ----
     {
       u32x4 h_a0, h_b0, h_a1, h_b1;
       f32x4 g2, rn2;
@@ -278,37 +336,62 @@ __global__ __launch_bounds__(256, 1) void gf_mfma_kernel(const float* __restrict
       GF_RD128(h_a1, a_rd, HB + 4 * H_QTY);
       GF_RD128(h_b1, a_rd, HB + 5 * H_QTY);
       GF_RD128(g2, a_pit, 5 * 256);                      // output row r - 9
-      GF_RD128(rn2, a_pit, 6 * 256);
+      GF_RD128(rn2, a_pit, 8 * 256);
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h_a0), "+v"(h_b0), "+v"(h_a1), "+v"(h_b1), "+v"(g2), "+v"(rn2)::"memory");
       const f32x4 s_a0 = band_mfma(a_own, f_a0, a_halo, h_a0);
       const f32x4 s_b0 = band_mfma(a_own, f_b0, a_halo, h_b0);
       const f32x4 s_a1 = band_mfma(a_own, f_a1, a_halo, h_a1);
       const f32x4 s_b1 = band_mfma(a_own, f_b1, a_halo, h_b1);
-      const int ro = r - (2 * R + 1);
-      const bool rowv = ro >= ybeg && ro < yend;
-      const unsigned so = (unsigned)max(ro, 0) * rowbytes;
       const f32x4 out0 = (s_a0 * g2 + s_b0) * rn2;
       const f32x4 out1 = (s_a1 * g2 + s_b1) * rn2;
-      const int nrec = rowv ? out_bytes : 0;             // zero-length descriptor: every store of this row is dropped
-      const __amdgpu_buffer_rsrc_t ro0 = __builtin_amdgcn_make_buffer_rsrc(o0, 0, nrec, RSRC_W3);
-      const __amdgpu_buffer_rsrc_t ro1 = __builtin_amdgcn_make_buffer_rsrc(o1, 0, nrec, RSRC_W3);
-      // (the element is copied to a scalar first: __builtin_bit_cast applied to a vector-element lvalue reads element 0)
+      if (XPOSE) {
+        const float a0 = out0[0], a1 = out0[1], a2 = out0[2], a3 = out0[3], b0 = out1[0], b1 = out1[1], b2 = out1[2], b3 = out1[3];
+        GF_WR32(a_tw, a0, 0 * 64); GF_WR32(a_tw, a1, 1 * 64); GF_WR32(a_tw, a2, 2 * 64); GF_WR32(a_tw, a3, 3 * 64);
+        GF_WR32(a_tw, b0, 1024 + 0 * 64); GF_WR32(a_tw, b1, 1024 + 1 * 64); GF_WR32(a_tw, b2, 1024 + 2 * 64); GF_WR32(a_tw, b3, 1024 + 3 * 64);
+      } else {
+        const int ro = r - (2 * R + 1);
+        const bool rowv = ro >= ybeg && ro < yend;
+        const unsigned so = (unsigned)max(ro, 0) * rowbytes;
+        const int nrec = rowv ? out_bytes : 0;           // zero-length descriptor: every store of this row is dropped
+        const __amdgpu_buffer_rsrc_t ro0 = __builtin_amdgcn_make_buffer_rsrc(o0, 0, nrec, RSRC_W3);
+        const __amdgpu_buffer_rsrc_t ro1 = __builtin_amdgcn_make_buffer_rsrc(o1, 0, nrec, RSRC_W3);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { const float o = out0[i]; __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), ro0, soff[i], so, 2); }
+        for (int i = 0; i < 4; ++i) { const float o = out0[i]; __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), ro0, soff[i], so, 2); }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { const float o = out1[i]; __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), ro1, soff[i], so, 2); }
+        for (int i = 0; i < 4; ++i) { const float o = out1[i]; __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), ro1, soff[i], so, 2); }
+      }
     }
     // ---- stage 1: (A_e, b_e) of row r - 4, then their 9-row window sums for the next iteration ----
     {
-      u32x4 h_y, h_gy;
+      u32x4 h_y, h_gy, t0, t1;
       f32x4 rn1, mg1, rd0, rd1;
+      if (XPOSE) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the tile is written (wave-private: no barrier)
+        GF_RD128(t0, a_tr, 0);
+        GF_RD128(t1, a_tr, 1024);
+      } else {
+        t0 = u32x4{0, 0, 0, 0}; t1 = t0;
+      }
       GF_RD128(h_y, a_rd, HB + 0 * H_QTY);
       GF_RD128(h_gy, a_rd, HB + 1 * H_QTY);
-      GF_RD128(rn1, a_pit, 1 * 256);                     // stage-1 row r - 4
-      GF_RD128(mg1, a_pit, 2 * 256);
-      GF_RD128(rd0, a_pit, 3 * 256);
-      GF_RD128(rd1, a_pit, 4 * 256);
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h_y), "+v"(h_gy), "+v"(rn1), "+v"(mg1), "+v"(rd0), "+v"(rd1)::"memory");
+      GF_RD128(rn1, a_pit, 0 * 256);                     // stage-1 row r - 4
+      GF_RD128(mg1, a_pit, 1 * 256);
+      GF_RD128(rd0, a_pit, 2 * 256);
+      GF_RD128(rd1, a_pit, 3 * 256);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t0), "+v"(t1), "+v"(h_y), "+v"(h_gy), "+v"(rn1), "+v"(mg1), "+v"(rd0), "+v"(rd1)::"memory");
+      if (XPOSE) {
+        const int ro = r - (2 * R + 1);
+        const bool rowv = ro >= ybeg && ro < yend;
+        const unsigned so = (unsigned)max(ro, 0) * rowbytes;
+        const int nrec = rowv ? out_bytes : 0;           // zero-length descriptor: every store of this row is dropped
+        __builtin_amdgcn_raw_buffer_store_b128(t0, __builtin_amdgcn_make_buffer_rsrc(o0, 0, nrec, RSRC_W3), soff16, so, 2);
+        __builtin_amdgcn_raw_buffer_store_b128(t1, __builtin_amdgcn_make_buffer_rsrc(o1, 0, nrec, RSRC_W3), soff16, so, 2);
+        // A 128-bit store reads its data registers quad by quad AFTER issue; hipcc (ROCm 7.2, gfx950) places no wait state
+        // before a VALU write that reuses them -- observed: element 1 of the last lane quad of every 16 lanes stored the NEXT
+        // value (W % 4 != 0 build only: the other build happened to schedule differently).  Keep the registers live across
+        // two wait states.
+        asm volatile("s_nop 2" : "+v"(t0), "+v"(t1));
+      }
       const f32x4 s_y = band_mfma(a_own, f_y, a_halo, h_y);
       const f32x4 s_gy = band_mfma(a_own, f_gy, a_halo, h_gy);
       const int r1 = r - R;
@@ -327,18 +410,15 @@ __global__ __launch_bounds__(256, 1) void gf_mfma_kernel(const float* __restrict
       wB1 = ring_push<k>(rB1, my - A1 * mg1);
     }
   };
-  auto body = [&](auto first_tag, int itb) {
-    step(std::integral_constant<int, 0>{}, first_tag, itb);
-    step(std::integral_constant<int, 1>{}, first_tag, itb);
-    step(std::integral_constant<int, 2>{}, first_tag, itb);
-    step(std::integral_constant<int, 3>{}, first_tag, itb);
-    step(std::integral_constant<int, 4>{}, first_tag, itb);
-    step(std::integral_constant<int, 5>{}, first_tag, itb);
-  };
   static_assert(PF == 6, "the unrolled body lists PF = 6 steps");
-
-  body(std::true_type{}, 0);
-  for (int itb = PF; itb < n_it; itb += PF) body(std::false_type{}, itb);
+  for (int itb = 0; itb < n_it; itb += PF) {
+    step(std::integral_constant<int, 0>{}, itb);
+    step(std::integral_constant<int, 1>{}, itb);
+    step(std::integral_constant<int, 2>{}, itb);
+    step(std::integral_constant<int, 3>{}, itb);
+    step(std::integral_constant<int, 4>{}, itb);
+    step(std::integral_constant<int, 5>{}, itb);
+  }
 
   GF_VMWAIT(0);                                          // no LDS-DMA may land after the workgroup's LDS is released
   // a 9-row sum beyond the f16 range cannot be split: tell the host wrapper's fallback launch
@@ -346,5 +426,8 @@ __global__ __launch_bounds__(256, 1) void gf_mfma_kernel(const float* __restrict
   for (int m = 32; m >= 1; m >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, m));
   if (l == 0 && !(vmax < 65000.f)) atomicOr(flag, 1u);
 }
+
+template __global__ void gf_mfma_kernel<true>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
+template __global__ void gf_mfma_kernel<false>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
 
 }  // namespace paif_gf_mfma

@@ -465,9 +465,12 @@ __global__ __launch_bounds__(FC * NL) void gf_fused_kernel(const float* __restri
 }  // namespace
 
 namespace paif_gf_mfma {
+template <bool AL4>
 __global__ void gf_mfma_kernel(const float* __restrict__ guide, const float* __restrict__ y, const float* __restrict__ planes,
                                float* __restrict__ lf, unsigned* __restrict__ flag, int B, int H, int W, int nstrip, int nseg, int frows,
                                int ntiles);
+extern template __global__ void gf_mfma_kernel<true>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
+extern template __global__ void gf_mfma_kernel<false>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
 }
 
 // workspace: four per-pixel planes + one 256-byte line holding the f16-range flag
@@ -521,8 +524,12 @@ extern "C" int paif_guided_filter_fused_fwd(const float* guide, const float* y, 
     const int frows = (H + nseg - 1) / nseg;
     const int ntiles = B * nstrip * nseg;
     const int grid = (ntiles + 7) / 8 * 16;
-    hipLaunchKernelGGL(paif_gf_mfma::gf_mfma_kernel, dim3(grid), dim3(256), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip, nseg, frows,
-                       ntiles);
+    if (W % 4 == 0 && W >= 4)
+      hipLaunchKernelGGL(paif_gf_mfma::gf_mfma_kernel<true>, dim3(grid), dim3(256), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip, nseg,
+                         frows, ntiles);
+    else
+      hipLaunchKernelGGL(paif_gf_mfma::gf_mfma_kernel<false>, dim3(grid), dim3(256), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip, nseg,
+                         frows, ntiles);
     PAIF_LAUNCH_CHECK("guided_filter_fused(mfma)");
   }
   int nseg;

@@ -453,3 +453,60 @@ def test_unknown_and_malformed_primitives():
         MixedOp(32, "Nope_3_1")
     with pytest.raises(IndexError):
         MixedOp(32, "DilConv_3")
+
+
+@pytest.mark.parametrize("shape", [(1, 24, 32), (2, 64, 96), (1, 50, 131), (3, 37, 49), (2, 11, 10), (1, 100, 47), (1, 130, 200)])
+def test_guided_filter_matrix_core_engine_vs_valu_engine_and_oracle(shape):
+    """csrc/gf_mfma.hip (horizontal box sums as f16 hi/lo band-matrix MFMAs, the default engine) against the all-VALU kernel
+    (PAIF_GF_ENGINE=valu) and the float64 oracle, incl. ragged widths (W % 4 != 0 takes the 4-byte plane staging), strips
+    hanging over the image edge, several row segments and B > 1.  Core/model_fusion_auto.py:522-535."""
+    import os
+
+    from oracle import paif_oracle as O
+
+    B, H, W = shape
+    x = t(S.make_smooth_feature(71, B, 32, H, W))
+    xn = ops.to_nhwc(x.to(_dev()))
+    guide = ops.channel_residue(xn)
+    old = os.environ.get("PAIF_GF_ENGINE")
+    try:
+        os.environ["PAIF_GF_ENGINE"] = "valu"
+        a = ops.guided_filter_pair(guide, xn).clone()
+        os.environ["PAIF_GF_ENGINE"] = "mfma"
+        b = ops.guided_filter_pair(guide, xn).clone()
+    finally:
+        if old is None:
+            os.environ.pop("PAIF_GF_ENGINE", None)
+        else:
+            os.environ["PAIF_GF_ENGINE"] = old
+    assert maxabs(a, b) <= 5e-6
+    x64 = x.double()
+    res = O.get_residue(x64)
+    for e, eps in enumerate((0.001, 0.0001)):
+        ref = O.guided_filter(res, x64, 4, eps)
+        err_m = maxabs(b[e].permute(0, 3, 1, 2).cpu().double(), ref)
+        err_v = maxabs(a[e].permute(0, 3, 1, 2).cpu().double(), ref)
+        assert err_m <= max(2.0 * err_v, 2e-6), (shape, eps, err_m, err_v)      # as close to float64 as the fp32 direct sums
+
+
+def test_guided_filter_f16_range_fallback():
+    """A 9-row vertical sum beyond the f16 range (65504) cannot be split into an f16 pair: the matrix-core kernel raises its
+    flag and the predicated all-VALU launch behind it rewrites the output -- bit-identical to the VALU engine."""
+    import os
+
+    B, H, W = 1, 40, 70
+    x = t(S.make_smooth_feature(73, B, 32, H, W)).to(_dev())
+    guide = ops.channel_residue(ops.to_nhwc(x))
+    xn = ops.to_nhwc(x * 3.0e4)
+    old = os.environ.get("PAIF_GF_ENGINE")
+    try:
+        os.environ["PAIF_GF_ENGINE"] = "valu"
+        a = ops.guided_filter_pair(guide, xn).clone()
+        os.environ["PAIF_GF_ENGINE"] = "mfma"
+        b = ops.guided_filter_pair(guide, xn).clone()
+    finally:
+        if old is None:
+            os.environ.pop("PAIF_GF_ENGINE", None)
+        else:
+            os.environ["PAIF_GF_ENGINE"] = old
+    assert torch.isfinite(b).all() and torch.equal(a, b)
