@@ -463,6 +463,7 @@ def test_guided_filter_matrix_core_engine_vs_valu_engine_and_oracle(shape):
     import os
 
     from oracle import paif_oracle as O
+    from paif_amd import ops
 
     B, H, W = shape
     x = t(S.make_smooth_feature(71, B, 32, H, W))
@@ -493,6 +494,8 @@ def test_guided_filter_f16_range_fallback():
     """A 9-row vertical sum beyond the f16 range (65504) cannot be split into an f16 pair: the matrix-core kernel raises its
     flag and the predicated all-VALU launch behind it rewrites the output -- bit-identical to the VALU engine."""
     import os
+
+    from paif_amd import ops
 
     B, H, W = 1, 40, 70
     x = t(S.make_smooth_feature(73, B, 32, H, W)).to(_dev())
