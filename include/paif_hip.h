@@ -131,10 +131,33 @@ typedef struct {
   int reverse_tiles;     /* 1: walk the tiles from the end of each XCD's range.  Results do not depend on it; a caller that alternates it
                             between consecutive layers ("serpentine") lets a layer start with the inputs its producer wrote last, which
                             are still in L2 / MALL (+0.7 % on the fusion forward).  Not honoured by the wave-specialised kernel */
+  int storage;           /* PAIF_ST_*: storage of the 32-channel activation maps (src / res / out are then `unsigned short` bf16 data behind
+                            the float* fields).  BASELINE configs[1] "bf16": fp32 accumulate, bf16 maps, round-to-nearest-even on store.
+                            Built for the split-bf16 kernels of the inference forward (no gradient hooks) */
 } paif_conv_desc;
+#define PAIF_ST_F32 0          /* fp32 maps in, fp32 maps out (default) */
+#define PAIF_ST_BF16 1         /* bf16 in, bf16 out */
+#define PAIF_ST_F32_BF16 2     /* fp32 in, bf16 out: the 1x1 behind the fp32 guided-filter block */
 /* in_act: 0 none, 1 PReLU, 2 ReLU, 3 src*in_alpha*in_scale[c]*(in_aux>=0?1:*in_prelu), 4 ...*(in_aux>0), 5 src*in_alpha*in_scale[c] */
 #define PAIF_CONV_F32 0
 #define PAIF_CONV_BF16X3 1
+
+/* ---- bf16-stored activation maps (PAIF_ST_BF16; BASELINE configs[1] "...bf16..."): the elementwise kernels of the fusion
+ * network's inference forward on bf16 32-channel maps (bf16 data behind the float* of x / out / ir / vis / agg / o / r / a / b),
+ * fp32 arithmetic, round-to-nearest-even on store.  Same reference sites as their fp32 twins (DilConv depthwise operations_m.py:499;
+ * ChannelPool + spatial_attn_layer_M blend core/model_fusion_auto.py:1352-1368,631-632; eca_layer operations_m.py:353-367;
+ * stem_out.1/.2 + tanh core/model_fusion_auto.py:616-635; Cell_Chain's `inp + ops(inp)` :445).
+ * paif_cast_storage_fwd converts n elements fp32 -> bf16 (to_bf16 = 1) or back (0); n % 4 == 0. ---- */
+int paif_dwconv_fwd_bf16(const float* x, const float* w, float* out, int k, int dil, int in_relu, int B, int H, int W,
+                         paif_stream_t stream);
+int paif_channel_pool2_fwd_bf16(const float* ir, const float* vis, float* comp, int B, int H, int W, paif_stream_t stream);
+int paif_spa_blend_fwd_bf16(const float* comp, const float* w, const float* ir, const float* vis, float* agg, int B, int H, int W,
+                            paif_stream_t stream);
+int paif_eca_finish_fwd_bf16(const float* o, const float* r, const float* pool_partial, const float* w1d, int k,
+                             const float* prelu, float* gate, float* out, int B, int H, int W, paif_stream_t stream);
+int paif_tail_fwd_bf16(const float* x, const float* w, const float* prelu, float* fused, int B, int H, int W, paif_stream_t stream);
+int paif_add_fwd_bf16(const float* a, const float* b, float* out, size_t n, paif_stream_t stream);
+int paif_cast_storage_fwd(const float* src, float* dst, size_t n, int to_bf16, paif_stream_t stream);
 
 int paif_conv2d_blocks(int B, int H, int W);
 int paif_conv2d_fwd(const paif_conv_desc* d, int B, int H, int W, paif_stream_t stream);

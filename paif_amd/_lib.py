@@ -21,7 +21,7 @@ class ConvDesc(Structure):
         ("in_act", c_int), ("in_prelu", F), ("scale", F), ("shift", F), ("act", c_int), ("prelu", F),
         ("alpha", c_float), ("res", F * 3), ("out", F), ("cout", c_int), ("pool_partial", F),
         ("precision", c_int), ("aux_out", F), ("in_aux", F), ("in_scale", F), ("in_alpha", c_float), ("epi_aux", F),
-        ("epi_dact", c_int), ("reverse_tiles", c_int),
+        ("epi_dact", c_int), ("reverse_tiles", c_int), ("storage", c_int),
     ]
 
 
@@ -92,6 +92,13 @@ SIGNATURES = {
     "paif_sr_attention_bwd_input_p": (c_int, [F, F, F, F, F, F, F, F, F, c_int, c_int, c_int, c_int, c_int, c_int, F]),
     "paif_upsample_ce_blocks": (c_int, [c_int, c_int, c_int]),
     "paif_upsample_ce_fwd": (c_int, [F, F, F, F, c_int, c_int, c_int, c_int, c_int, c_int, c_int, F]),
+    "paif_dwconv_fwd_bf16": (c_int, [F, F, F, c_int, c_int, c_int, c_int, c_int, c_int, F]),
+    "paif_channel_pool2_fwd_bf16": (c_int, [F, F, F, c_int, c_int, c_int, F]),
+    "paif_spa_blend_fwd_bf16": (c_int, [F, F, F, F, F, c_int, c_int, c_int, F]),
+    "paif_eca_finish_fwd_bf16": (c_int, [F, F, F, F, c_int, F, F, F, c_int, c_int, c_int, F]),
+    "paif_tail_fwd_bf16": (c_int, [F, F, F, F, c_int, c_int, c_int, F]),
+    "paif_add_fwd_bf16": (c_int, [F, F, F, c_size_t, F]),
+    "paif_cast_storage_fwd": (c_int, [F, F, c_size_t, c_int, F]),
     "paif_attack_loss_blocks": (c_int, [c_int, c_int, c_int]),
     "paif_attack_loss_fwd": (c_int, [F, F, F, F, c_int, c_float, c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_int, F]),
     "paif_attack_loss_bwd": (c_int, [F, F, F, F, c_int, c_float, c_float, c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, F]),

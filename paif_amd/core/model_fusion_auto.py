@@ -295,7 +295,8 @@ class Network_Fusion_Searched(nn.Module):
         wg = ops.want_param_grads(self)
         if torch.is_grad_enabled() and (ir.requires_grad or vis.requires_grad or wg):
             return _FusionFn.apply(ir, vis, self, wg, grad_anchor(ir.device))
-        with torch.no_grad():
+        # ops.set_storage("bf16"): bf16 maps behind the guided-filter block (eval mode: the train-mode BatchNorm path is fp32 only)
+        with torch.no_grad(), ops.bf16_activations(enable=not self.training):
             return self.forward_impl(ir, vis, inter=inter)
 
     def forward_impl(self, ir, vis, inter=None, tape=None):

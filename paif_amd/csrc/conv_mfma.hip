@@ -59,6 +59,7 @@ struct ConvArgs {
   int nsrc, in_act, act, cout, epi_dact;
   int B, H, W, tilesX, tilesY, nblk;
   int reverse;             // 1: tiles are walked from the end of each XCD range (serpentine order across consecutive layers)
+  int st;                  // activation storage (paif_common.h): 0 fp32/fp32, 1 bf16/bf16, 2 fp32 in / bf16 out
 };
 
 // Transform applied to a staged float4 (channels 4q..4q+3 of one pixel):
@@ -139,7 +140,7 @@ __device__ __forceinline__ EpiParams load_epi_params(const ConvArgs& a, int lane
 
 // CH: elements per lane whose residual loads are in flight together (NITER = all, the default; the persistent kernel,
 // which holds a prefetched halo tile in registers across its epilogue, uses half)
-template <bool FULL, bool HOOKS, int NRES, int SEGS, int CH = SEGS * 32 * 8 / 64>
+template <bool FULL, bool HOOKS, int NRES, int SEGS, int CH = SEGS * 32 * 8 / 64, int BFO = 0>
 __device__ __forceinline__ float4 epilogue_lds_n(const ConvArgs& a, const EpiParams& ep_par, const f32x16 (&acc)[SEGS],
                                                  float* lds, int b, int y0, int x0, int wave, int lane) {
   float* ep = lds + wave * (SEGS * 32 * 32);
@@ -184,9 +185,9 @@ __device__ __forceinline__ float4 epilogue_lds_n(const ConvArgs& a, const EpiPar
     size_t off;
     const bool ok = locate(it, off);
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    r0[it - it0] = (nres > 0 && ok) ? paif::load_nt(a.res[0] + off) : z4;
-    r1[it - it0] = (nres > 1 && ok) ? paif::load_nt(a.res[1] + off) : z4;
-    r2[it - it0] = (nres > 2 && ok) ? paif::load_nt(a.res[2] + off) : z4;
+    r0[it - it0] = (nres > 0 && ok) ? paif::ldq_nt<BFO>(a.res[0], off) : z4;
+    r1[it - it0] = (nres > 1 && ok) ? paif::ldq_nt<BFO>(a.res[1], off) : z4;
+    r2[it - it0] = (nres > 2 && ok) ? paif::ldq_nt<BFO>(a.res[2], off) : z4;
     ea[it - it0] = (HOOKS && a.epi_dact && ok) ? *reinterpret_cast<const float4*>(a.epi_aux + off) : z4;
   }
 #pragma unroll
@@ -214,7 +215,7 @@ __device__ __forceinline__ float4 epilogue_lds_n(const ConvArgs& a, const EpiPar
     if (nres > 1) { v.x += r1[it - it0].x; v.y += r1[it - it0].y; v.z += r1[it - it0].z; v.w += r1[it - it0].w; }
     if (nres > 2) { v.x += r2[it - it0].x; v.y += r2[it - it0].y; v.z += r2[it - it0].z; v.w += r2[it - it0].w; }
     if (ok) {
-      paif::store_nt(a.out + off, v);
+      paif::stq_nt<BFO>(a.out, off, v);
       psum.x += v.x; psum.y += v.y; psum.z += v.z; psum.w += v.w;
     }
   }
@@ -222,14 +223,14 @@ __device__ __forceinline__ float4 epilogue_lds_n(const ConvArgs& a, const EpiPar
   return psum;   // per-lane partial channel sums of quad q (for the ECA pool)
 }
 
-template <bool FULL, bool HOOKS, int SEGS = SEGS_PER_WAVE, int CH = SEGS * 32 * 8 / 64>
+template <bool FULL, bool HOOKS, int SEGS = SEGS_PER_WAVE, int CH = SEGS * 32 * 8 / 64, int BFO = 0>
 __device__ __forceinline__ float4 epilogue_lds(const ConvArgs& a, const EpiParams& ep_par, const f32x16 (&acc)[SEGS], float* lds,
                                                int b, int y0, int x0, int wave, int lane) {
   // residuals are packed from index 0; the count is launch-uniform
-  if (!a.res[0]) return epilogue_lds_n<FULL, HOOKS, 0, SEGS, CH>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
-  if (!a.res[1]) return epilogue_lds_n<FULL, HOOKS, 1, SEGS, CH>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
-  if (!a.res[2]) return epilogue_lds_n<FULL, HOOKS, 2, SEGS, CH>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
-  return epilogue_lds_n<FULL, HOOKS, 3, SEGS, CH>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
+  if (!a.res[0]) return epilogue_lds_n<FULL, HOOKS, 0, SEGS, CH, BFO>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
+  if (!a.res[1]) return epilogue_lds_n<FULL, HOOKS, 1, SEGS, CH, BFO>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
+  if (!a.res[2]) return epilogue_lds_n<FULL, HOOKS, 2, SEGS, CH, BFO>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
+  return epilogue_lds_n<FULL, HOOKS, 3, SEGS, CH, BFO>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
 }
 
 template <int KH, int DIL, int CIN, bool HOOKS>
@@ -387,7 +388,7 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
   return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
 }
 
-template <int KH, int DIL, bool HOOKS>
+template <int KH, int DIL, bool HOOKS, int ST = 0>
 #ifndef PAIF_LB
 #define PAIF_LB 3
 #endif
@@ -457,7 +458,7 @@ __global__ __launch_bounds__(NTHREADS, (HOOKS || KH >= 5 || DIL == 2) ? 2 : PAIF
         inb[u] = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         const int gyc = min(max(gy, 0), a.H - 1), gxc = min(max(gx, 0), a.W - 1);
         go[u] = ((size_t)(b * a.H + gyc) * a.W + gxc) * CIN + q * 4;
-        v[u] = *reinterpret_cast<const float4*>(src + go[u]);
+        v[u] = paif::ldq<paif::st_in(ST)>(src, go[u]);
         xa[u] = v[u];
       }
       if (HOOKS && (a.in_act == 3 || a.in_act == 4)) {   // launch-uniform
@@ -579,8 +580,8 @@ __global__ __launch_bounds__(NTHREADS, (HOOKS || KH >= 5 || DIL == 2) ? 2 : PAIF
   const EpiParams ep_par = load_epi_params<HOOKS>(a, lane);   // in flight across the barrier
   __syncthreads();  // every wave has finished reading the staged tile: its LDS is reused by the epilogue
   float4 ps;
-  if (full) ps = epilogue_lds<true, HOOKS>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
-  else ps = epilogue_lds<false, HOOKS>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
+  if (full) ps = epilogue_lds<true, HOOKS, SEGS_PER_WAVE, SEGS_PER_WAVE * 32 * 8 / 64, paif::st_out(ST)>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
+  else ps = epilogue_lds<false, HOOKS, SEGS_PER_WAVE, SEGS_PER_WAVE * 32 * 8 / 64, paif::st_out(ST)>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
   if (a.pool_partial) {
     // lanes with equal (lane & 7) hold the same channel quad for different pixels: reduce over the 8 pixel lanes,
     // then over the 4 waves through LDS (fixed order -> deterministic)
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(NTHREADS, (HOOKS || KH >= 5 || DIL == 2) ? 2 : PAIF
   }
 }
 
-template <int KH, int DIL, bool HOOKS>
+template <int KH, int DIL, bool HOOKS, int ST = 0>
 int launch_bf16x3_h(const ConvArgs& a, hipStream_t st) {
   constexpr int P = DIL * (KH - 1) / 2;
   constexpr size_t tile_bytes = (size_t)(TH + 2 * P) * (TW + 2 * P) * 144;
@@ -603,14 +604,14 @@ int launch_bf16x3_h(const ConvArgs& a, hipStream_t st) {
   constexpr size_t lds_bytes = tile_bytes > epi_bytes ? tile_bytes : epi_bytes;
   static_assert(lds_bytes <= 160 * 1024, "tile does not fit LDS");
   if (lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_bf16x3<KH, DIL, HOOKS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_bf16x3<KH, DIL, HOOKS, ST>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) {
       paif::set_error("conv2d(bf16x3): cannot raise dynamic LDS to %zu: %s", lds_bytes, hipGetErrorString(e));
       return (int)e;
     }
   }
-  hipLaunchKernelGGL((conv_mfma_bf16x3<KH, DIL, HOOKS>), dim3(a.nblk), dim3(NTHREADS), lds_bytes, st, a);
+  hipLaunchKernelGGL((conv_mfma_bf16x3<KH, DIL, HOOKS, ST>), dim3(a.nblk), dim3(NTHREADS), lds_bytes, st, a);
   PAIF_LAUNCH_CHECK("conv2d(bf16x3)");
   return 0;
 }
@@ -662,6 +663,27 @@ __device__ __forceinline__ void split_bf16x4(float4 t, uint2& hi, uint2& lo) {
 }
 
 
+// A staged 4-channel quad as it travels in registers between the global load and the LDS write: the fp32 quad, or the
+// bf16 quad of a bf16-stored map (half the prefetch registers; its split is the identity: hi = the stored bits, lo = 0)
+template <int BF> struct RawQ { typedef float4 T; };
+template <> struct RawQ<1> { typedef uint2 T; };
+template <int BF> __device__ __forceinline__ typename RawQ<BF>::T ldraw(const char* p) {
+  return *reinterpret_cast<const typename RawQ<BF>::T*>(p);
+}
+template <int BF> __device__ __forceinline__ typename RawQ<BF>::T ldraw_nt(const char* p) {
+  if constexpr (BF) {
+    typedef unsigned u32x2_nt __attribute__((ext_vector_type(2)));
+    const u32x2_nt v = __builtin_nontemporal_load(reinterpret_cast<const u32x2_nt*>(p));
+    return make_uint2(v.x, v.y);
+  } else {
+    return paif::load_nt(reinterpret_cast<const float*>(p));
+  }
+}
+__device__ __forceinline__ void split_raw(float4 t, uint2& hi, uint2& lo) { split_bf16x4(t, hi, lo); }
+__device__ __forceinline__ void split_raw(uint2 t, uint2& hi, uint2& lo) { hi = t; lo = make_uint2(0u, 0u); }
+__device__ __forceinline__ float4 raw_zero(float4) { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ uint2 raw_zero(uint2) { return make_uint2(0u, 0u); }
+
 // ---------------------------------------------------------------------------------------------------
 // Multi-source form of the tile-per-workgroup split-bf16 kernel (forward, no hooks, no in-activation, cout == 32):
 // the sources of the virtual concat (RDB conv2 / conv3: 2 and 3 sources) are software-pipelined INSIDE one instruction
@@ -684,8 +706,11 @@ __device__ __forceinline__ void split_bf16x4(float4 t, uint2& hi, uint2& lo) {
 #define PAIF_TRACE(i)
 #define PAIF_TRACE_END
 #endif
-template <int KH, int DIL, int NSRC>
+template <int KH, int DIL, int NSRC, int ST = 0>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_bf16x3_ms(ConvArgs a) {
+  constexpr int BFI = paif::st_in(ST);
+  constexpr unsigned ES = BFI ? 2u : 4u;               // bytes per stored input element
+  typedef typename RawQ<BFI>::T raw_t;
   constexpr int CIN = 32;
   constexpr int P = DIL * (KH - 1) / 2;
   constexpr int TWH = TW + 2 * P;
@@ -735,24 +760,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bf16x3_ms(ConvArgs a) {
     const int tyy = pix / TWH, txx = pix - tyy * TWH;
     const int gy = y0 - P + tyy, gx = x0 - P + txx;
     const int gyc = min(max(gy, 0), a.H - 1), gxc = min(max(gx, 0), a.W - 1);
-    goff[u] = (unsigned)(((b * a.H + gyc) * a.W + gxc) * CIN + q * 4) * 4u;
+    goff[u] = (unsigned)(((b * a.H + gyc) * a.W + gxc) * CIN + q * 4) * ES;
     dst[u] = pix * PSB + q * 8;
     if (gy < 0 || gy >= a.H || gx < 0 || gx >= a.W) padmask |= 1u << u;
   }
   constexpr bool LAST_PARTIAL = (TOTAL % NTHREADS) != 0;
   const bool last_valid = tid + (NIT - 1) * NTHREADS < TOTAL;
-  auto issueA = [&](const float* __restrict__ src, float4 (&v)[NIT]) {
+  auto issueA = [&](const float* __restrict__ src, raw_t (&v)[NIT]) {
     const char* base = reinterpret_cast<const char*>(src);
 #pragma unroll
-    for (int u = 0; u < NIT; ++u) v[u] = *reinterpret_cast<const float4*>(base + goff[u]);   // unconditional, clamped
+    for (int u = 0; u < NIT; ++u) v[u] = ldraw<BFI>(base + goff[u]);   // unconditional, clamped
   };
-  auto convertA = [&](float4 (&v)[NIT]) {
+  auto convertA = [&](raw_t (&v)[NIT]) {
 #pragma unroll
     for (int u = 0; u < NIT; ++u) {
-      float4 t4 = v[u];
-      if (padmask & (1u << u)) t4 = make_float4(0.f, 0.f, 0.f, 0.f);      // zero padding by select
+      raw_t t4 = v[u];
+      if (padmask & (1u << u)) t4 = raw_zero(t4);      // zero padding by select
       uint2 hi, lo;
-      split_bf16x4(t4, hi, lo);
+      split_raw(t4, hi, lo);
       if (!LAST_PARTIAL || u + 1 < NIT || last_valid) {
         *reinterpret_cast<uint2*>(ldsb + dst[u]) = hi;
         *reinterpret_cast<uint2*>(ldsb + dst[u] + 64) = lo;
@@ -821,7 +846,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bf16x3_ms(ConvArgs a) {
 #pragma unroll
   for (int g = 0; g < D; ++g) fetchB(g);
   {
-    float4 v0[NIT];
+    raw_t v0[NIT];
     issueA(a.src[0], v0);
     convertA(v0);
   }
@@ -830,7 +855,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bf16x3_ms(ConvArgs a) {
   PAIF_MS_STAMP(2);
 #pragma unroll
   for (int s = 0; s < NSRC; ++s) {
-    float4 vn[NIT];
+    raw_t vn[NIT];
     if (s + 1 < NSRC) issueA(a.src[s + 1], vn);          // the next source's halo tile: in flight during this source's MFMA loop
     __builtin_amdgcn_sched_barrier(0);
     mma_source(s);
@@ -849,8 +874,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bf16x3_ms(ConvArgs a) {
   const EpiParams ep_par = load_epi_params<false>(a, lane);
   __syncthreads();  // every wave has finished reading the staged tile: its LDS is reused by the epilogue
   float4 ps;
-  if (full) ps = epilogue_lds<true, false>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
-  else ps = epilogue_lds<false, false>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
+  if (full) ps = epilogue_lds<true, false, SEGS_PER_WAVE, SEGS_PER_WAVE * 32 * 8 / 64, paif::st_out(ST)>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
+  else ps = epilogue_lds<false, false, SEGS_PER_WAVE, SEGS_PER_WAVE * 32 * 8 / 64, paif::st_out(ST)>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
   (void)ps;
   PAIF_MS_STAMP(15);
 }
@@ -880,8 +905,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bf16x3_ms(ConvArgs a) {
 #define PAIF_RES_ROWS 4
 #endif
 
-template <int KH, int DIL, int NSRC, int RT>
+template <int KH, int DIL, int NSRC, int RT, int ST = 0>
 __global__ __launch_bounds__(RT * 64, RT == 4 ? 2 : 1) void conv_bf16x3_res(ConvArgs a, int ntiles, int tilesY) {
+  constexpr int BFI = paif::st_in(ST);
+  constexpr unsigned ES = BFI ? 2u : 4u;               // bytes per stored input element
+  typedef typename std::conditional<BFI != 0, unsigned __attribute__((ext_vector_type(2))), u32x4>::type rawv_t;
   constexpr int RES_THREADS = RT * 64;   // one wave per tile row
   constexpr int TH = RT;                 // shadows the file-wide tile height
   constexpr int CIN = 32;
@@ -925,7 +953,7 @@ __global__ __launch_bounds__(RT * 64, RT == 4 ? 2 : 1) void conv_bf16x3_res(Conv
   __amdgpu_buffer_rsrc_t rsrc[NSRC];
 #pragma unroll
   for (int s = 0; s < NSRC; ++s)
-    rsrc[s] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src[s]), 0, a.B * a.H * a.W * (CIN * 4), RSRC_W3);
+    rsrc[s] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src[s]), 0, a.B * a.H * a.W * (int)(CIN * ES), RSRC_W3);
   const __amdgpu_buffer_rsrc_t rsrc_w =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(a.wpk), 0, NSRC * NTAP * NKS * 2 * 1024, RSRC_W3);
 
@@ -946,7 +974,7 @@ __global__ __launch_bounds__(RT * 64, RT == 4 ? 2 : 1) void conv_bf16x3_res(Conv
   auto setup = [&](int b, int y0, int x0) {
     int t = tid;
     asm volatile("" : "+v"(t));
-    const unsigned qoff = (unsigned)(t & (QPP - 1)) * 16u;   // RES_THREADS % QPP == 0: the channel quad is the same in every slot
+    const unsigned qoff = (unsigned)(t & (QPP - 1)) * (4u * ES);   // RES_THREADS % QPP == 0: the channel quad is the same in every slot
     padmask = 0;
 #pragma unroll
     for (int u = 0; u < NIT; ++u) {
@@ -954,18 +982,21 @@ __global__ __launch_bounds__(RT * 64, RT == 4 ? 2 : 1) void conv_bf16x3_res(Conv
       const int tyy = pix / TWH, txx = pix - tyy * TWH;
       const int gy = y0 - P + tyy, gx = x0 - P + txx;
       const int gyc = min(max(gy, 0), a.H - 1), gxc = min(max(gx, 0), a.W - 1);
-      goff[u] = (unsigned)((b * a.H + gyc) * a.W + gxc) * (CIN * 4u) + qoff;
+      goff[u] = (unsigned)((b * a.H + gyc) * a.W + gxc) * (CIN * ES) + qoff;
       if (gy != gyc || gx != gxc) padmask |= 1u << u;
     }
     // materialise the mask here: otherwise the compiler defers it into the conversion as compares of gy/gyc/gx/gxc and
     // keeps those 4 x NIT values alive through the MFMA phase
     asm volatile("" : "+v"(padmask));
   };
-  auto issueA = [&](int s, u32x4 (&v)[NIT]) {
+  auto issueA = [&](int s, rawv_t (&v)[NIT]) {
 #pragma unroll
-    for (int u = 0; u < NIT; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc[s], goff[u], 0, 0);   // unconditional, clamped
+    for (int u = 0; u < NIT; ++u) {   // unconditional, clamped
+      if constexpr (BFI) v[u] = __builtin_amdgcn_raw_buffer_load_b64(rsrc[s], goff[u], 0, 0);
+      else v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc[s], goff[u], 0, 0);
+    }
   };
-  auto convert_n = [&](u32x4 (&v)[NIT], char* buf, auto with_act) {
+  auto convert_n = [&](rawv_t (&v)[NIT], char* buf, auto with_act) {
     int t = tid;
     asm volatile("" : "+v"(t));
     const bool last_valid = t + (NIT - 1) * RES_THREADS < TOTAL;
@@ -973,7 +1004,9 @@ __global__ __launch_bounds__(RT * 64, RT == 4 ? 2 : 1) void conv_bf16x3_res(Conv
 #pragma unroll
     for (int u = 0; u < NIT; ++u) {
       const int dstu = slot_pix(t, u) * PSB + q8;
-      float4 t4 = make_float4(__uint_as_float(v[u].x), __uint_as_float(v[u].y), __uint_as_float(v[u].z), __uint_as_float(v[u].w));
+      float4 t4;
+      if constexpr (BFI) t4 = paif::bf16x4_to_f32(make_uint2(v[u][0], v[u][1]));
+      else t4 = make_float4(__uint_as_float(v[u][0]), __uint_as_float(v[u][1]), __uint_as_float(v[u][2]), __uint_as_float(v[u][3]));
       if constexpr (decltype(with_act)::value) {
         t4.x = paif::prelu_f(t4.x, in_slope); t4.y = paif::prelu_f(t4.y, in_slope);
         t4.z = paif::prelu_f(t4.z, in_slope); t4.w = paif::prelu_f(t4.w, in_slope);
@@ -987,7 +1020,7 @@ __global__ __launch_bounds__(RT * 64, RT == 4 ? 2 : 1) void conv_bf16x3_res(Conv
       }
     }
   };
-  auto convertA = [&](u32x4 (&v)[NIT], char* buf) {
+  auto convertA = [&](rawv_t (&v)[NIT], char* buf) {
     if (a.in_act) convert_n(v, buf, std::true_type{});    // launch-uniform: one branch per tile, not one per element
     else convert_n(v, buf, std::false_type{});
   };
@@ -1036,7 +1069,7 @@ __global__ __launch_bounds__(RT * 64, RT == 4 ? 2 : 1) void conv_bf16x3_res(Conv
 #pragma unroll
   for (int tap = 0; tap < NTAP; ++tap) fetchB(0, tap);
   {
-    u32x4 v0[NIT];
+    rawv_t v0[NIT];
     issueA(0, v0);
     convertA(v0, ldsb);
   }
@@ -1056,7 +1089,7 @@ __global__ __launch_bounds__(RT * 64, RT == 4 ? 2 : 1) void conv_bf16x3_res(Conv
     const int tile_next = a.reverse ? tile - nwg : tile + nwg;
 #pragma unroll
     for (int s = 0; s < NSRC; ++s) {
-      u32x4 vn[NIT];
+      rawv_t vn[NIT];
       int bn = b, yn = y0, xn = x0;
       if (s == NSRC - 1) {             // the next unit is source 0 of the next tile (the last tile re-fetches itself: unused)
         locate(more ? tile_next : tile, bn, yn, xn);
@@ -1078,8 +1111,8 @@ __global__ __launch_bounds__(RT * 64, RT == 4 ? 2 : 1) void conv_bf16x3_res(Conv
         ep_par.sh = *reinterpret_cast<const float4*>(epp + 256 + lane_e * 4);
         ep_par.slope = epp[512];
         float4 ps;                     // private per-wave LDS region: no barrier between the MFMAs and the epilogue
-        if (full) ps = epilogue_lds<true, false, 1, 2>(a, ep_par, acc, epi, b, y0, x0, wave_e, lane_e);
-        else ps = epilogue_lds<false, false, 1, 2>(a, ep_par, acc, epi, b, y0, x0, wave_e, lane_e);
+        if (full) ps = epilogue_lds<true, false, 1, 2, paif::st_out(ST)>(a, ep_par, acc, epi, b, y0, x0, wave_e, lane_e);
+        else ps = epilogue_lds<false, false, 1, 2, paif::st_out(ST)>(a, ep_par, acc, epi, b, y0, x0, wave_e, lane_e);
         if (a.pool_partial) {          // launch-uniform; fixed-order reduction -> deterministic
 #pragma unroll
           for (int m = 8; m < 64; m <<= 1) {
@@ -1115,7 +1148,7 @@ __global__ __launch_bounds__(RT * 64, RT == 4 ? 2 : 1) void conv_bf16x3_res(Conv
   }
 }
 
-template <int KH, int DIL, int NSRC>
+template <int KH, int DIL, int NSRC, int ST = 0>
 int launch_bf16x3_res(const ConvArgs& a, hipStream_t st) {
   constexpr int RT = PAIF_RES_ROWS;
   constexpr int P = DIL * (KH - 1) / 2;
@@ -1123,7 +1156,7 @@ int launch_bf16x3_res(const ConvArgs& a, hipStream_t st) {
   static_assert(lds_bytes * (RT == 4 ? 2 : 1) <= 160 * 1024, "two halo-tile buffers + the epilogue regions do not fit LDS");
   static bool raised = false;   // once per instantiation (one device per process)
   if (!raised) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_res<KH, DIL, NSRC, RT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_res<KH, DIL, NSRC, RT, ST>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) {
       paif::set_error("conv2d(bf16x3 resident): cannot raise dynamic LDS to %zu: %s", lds_bytes, hipGetErrorString(e));
@@ -1132,20 +1165,20 @@ int launch_bf16x3_res(const ConvArgs& a, hipStream_t st) {
     raised = true;
   }
   const int tilesY = (a.H + RT - 1) / RT;
-  hipLaunchKernelGGL((conv_bf16x3_res<KH, DIL, NSRC, RT>), dim3(RT == 4 ? 512 : 256), dim3(RT * 64), lds_bytes, st, a,
+  hipLaunchKernelGGL((conv_bf16x3_res<KH, DIL, NSRC, RT, ST>), dim3(RT == 4 ? 512 : 256), dim3(RT * 64), lds_bytes, st, a,
                      a.B * tilesY * a.tilesX, tilesY);
   PAIF_LAUNCH_CHECK("conv2d(bf16x3 resident)");
   return 0;
 }
 
-template <int KH, int DIL, int NSRC>
+template <int KH, int DIL, int NSRC, int ST = 0>
 int launch_bf16x3_ms(const ConvArgs& a, hipStream_t st) {
   constexpr int P = DIL * (KH - 1) / 2;
   constexpr size_t tile_bytes = (size_t)(TH + 2 * P) * (TW + 2 * P) * 144;
   constexpr size_t epi_bytes = (size_t)TH * 32 * 32 * 4;
   constexpr size_t lds_bytes = tile_bytes > epi_bytes ? tile_bytes : epi_bytes;
   static_assert(lds_bytes <= 64 * 1024, "ms form: expected a tile under 64 KiB");
-  hipLaunchKernelGGL((conv_bf16x3_ms<KH, DIL, NSRC>), dim3(a.nblk), dim3(NTHREADS), lds_bytes, st, a);
+  hipLaunchKernelGGL((conv_bf16x3_ms<KH, DIL, NSRC, ST>), dim3(a.nblk), dim3(NTHREADS), lds_bytes, st, a);
   PAIF_LAUNCH_CHECK("conv2d(bf16x3 ms)");
   return 0;
 }
@@ -1161,8 +1194,11 @@ static inline bool ms_enabled() {
 
 constexpr int WS_THREADS = 12 * 64;
 
-template <int KH, int DIL>
+template <int KH, int DIL, int ST = 0>
 __global__ __launch_bounds__(WS_THREADS, 1) void conv_bf16x3_ws(ConvArgs a, int ntiles) {
+  constexpr int BFI = paif::st_in(ST), BFO = paif::st_out(ST);
+  constexpr unsigned ES = BFI ? 2u : 4u;               // bytes per stored input element
+  typedef typename RawQ<BFI>::T raw_t;
   static_assert(TH == 8, "the MFMA-wave mapping assumes 8-row tiles");
   constexpr int CIN = 32;
   constexpr int P = DIL * (KH - 1) / 2;
@@ -1200,7 +1236,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_bf16x3_ws(ConvArgs a, int 
   if (wave >= 8) {
     // ------------------------------- loaders -------------------------------
     const int pt = tid - 8 * 64;
-    const unsigned q16 = (unsigned)(pt & 7) * 16u;
+    const unsigned q16 = (unsigned)(pt & 7) * (4u * ES);
     constexpr int TOTAL = THH * TWH * QPP;
     constexpr int NIT = (TOTAL + 255) / 256;
     // per-lane tile coordinates of its NIT elements: fixed for the whole launch
@@ -1216,30 +1252,30 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_bf16x3_ws(ConvArgs a, int 
     const bool live_last = pt + (NIT - 1) * 256 < TOTAL;
     // Every load is unconditional on a clamped stage / address (a load under a branch makes hipcc wait at the
     // join); the in-image mask travels with the register set and zero padding is applied at the LDS write.
-    auto issue = [&](int st, float4 (&v)[NIT], unsigned& mask) {
+    auto issue = [&](int st, raw_t (&v)[NIT], unsigned& mask) {
       st = min(st, S - 1);
       const int i = st / nsrc, s = st - i * nsrc;
       int b, y0, x0;
       tile_of(i, b, y0, x0);
-      const char* base = reinterpret_cast<const char*>(a.src[s]) + (size_t)b * a.H * a.W * (CIN * 4);
+      const char* base = reinterpret_cast<const char*>(a.src[s]) + (size_t)b * a.H * a.W * (CIN * ES);
       const int y0p = y0 - P, x0p = x0 - P;
       unsigned m = 0;
 #pragma unroll
       for (int u = 0; u < NIT; ++u) {
         const int gy = y0p + tyy[u], gx = x0p + txx[u];
         const int gyc = min(max(gy, 0), a.H - 1), gxc = min(max(gx, 0), a.W - 1);
-        const unsigned off = ((unsigned)(gyc * a.W + gxc) << 7) + q16;   // < 4 GiB per image: checked at launch
-        v[u] = KH == 1 ? paif::load_nt(reinterpret_cast<const float*>(base + off)) : *reinterpret_cast<const float4*>(base + off);
+        const unsigned off = (unsigned)(gyc * a.W + gxc) * (CIN * ES) + q16;   // < 4 GiB per image: checked at launch
+        v[u] = KH == 1 ? ldraw_nt<BFI>(base + off) : ldraw<BFI>(base + off);
         m |= (gy == gyc && gx == gxc) ? (1u << u) : 0u;
       }
       mask = m;
     };
-    auto commit = [&](int st, const float4 (&v)[NIT], unsigned mask) {
+    auto commit = [&](int st, const raw_t (&v)[NIT], unsigned mask) {
       char* buf = ldsb + (st & 1) * TILE_BYTES;
 #pragma unroll
       for (int u = 0; u < NIT; ++u) {
         uint2 hi, lo;
-        split_bf16x4(v[u], hi, lo);
+        split_raw(v[u], hi, lo);
         if (!((mask >> u) & 1u)) hi = lo = make_uint2(0u, 0u);
         if (u < NIT - 1 || live_last) {
           *reinterpret_cast<uint2*>(buf + ldo[u]) = hi;
@@ -1250,7 +1286,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_bf16x3_ws(ConvArgs a, int 
     if (S > 0) {
       // straight-line pair body + peeled odd tail: with a conditional second half the wait-count pass must assume
       // set B is still pending at the loop header and drains vmcnt(0) there, which kills the prefetch
-      float4 va[NIT], vb[NIT];
+      raw_t va[NIT], vb[NIT];
       unsigned ma, mb;
       issue(0, va, ma);
       const int npair = S >> 1;
@@ -1373,7 +1409,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_bf16x3_ws(ConvArgs a, int 
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const int yy = min(y0 + j, a.H - 1) - y0;
-            r[k][j] = paif::load_nt(a.res[k] + base + (size_t)yy * a.W * 32 + lo);
+            r[k][j] = paif::ldq_nt<BFO>(a.res[k], base + (size_t)yy * a.W * 32 + lo);
           }
       };
       if (cnt > 0) request(0);
@@ -1403,7 +1439,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_bf16x3_ws(ConvArgs a, int 
 #pragma unroll
               for (int k = 0; k < NR; ++k) { v.x += r[k][j].x; v.y += r[k][j].y; v.z += r[k][j].z; v.w += r[k][j].w; }
               if (colok && y0 + j < a.H)
-                paif::store_nt(a.out + base + (size_t)j * a.W * 32 + lane_off, v);
+                paif::stq_nt<BFO>(a.out, base + (size_t)j * a.W * 32 + lane_off, v);
             }
             if (NR > 0) request(i2 + 1);
           }
@@ -1420,14 +1456,14 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_bf16x3_ws(ConvArgs a, int 
   }
 }
 
-template <int KH, int DIL>
+template <int KH, int DIL, int ST = 0>
 int launch_bf16x3_ws(const ConvArgs& a, hipStream_t st) {
   constexpr int P = DIL * (KH - 1) / 2;
   constexpr size_t lds_bytes = 2 * (size_t)(TH + 2 * P) * (TW + 2 * P) * 144 + 8 * 32 * 32 * 4;
   static_assert(lds_bytes <= 160 * 1024, "two tile buffers + the parked tile do not fit LDS");
   static bool raised = false;   // once per instantiation (one device per process)
   if (!raised) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_ws<KH, DIL>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_ws<KH, DIL, ST>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) {
       paif::set_error("conv2d(bf16x3 ws): cannot raise dynamic LDS to %zu: %s", lds_bytes, hipGetErrorString(e));
@@ -1435,7 +1471,7 @@ int launch_bf16x3_ws(const ConvArgs& a, hipStream_t st) {
     }
     raised = true;
   }
-  hipLaunchKernelGGL((conv_bf16x3_ws<KH, DIL>), dim3(256), dim3(WS_THREADS), lds_bytes, st, a, a.nblk);
+  hipLaunchKernelGGL((conv_bf16x3_ws<KH, DIL, ST>), dim3(256), dim3(WS_THREADS), lds_bytes, st, a, a.nblk);
   PAIF_LAUNCH_CHECK("conv2d(bf16x3 ws)");
   return 0;
 }
@@ -1498,24 +1534,42 @@ static inline ConvVariant bf16x3_variant(const ConvArgs& a, int kh, int dil) {
   return CV_PLAIN;
 }
 
-template <int KH, int DIL>
-int launch_bf16x3(const ConvArgs& a, hipStream_t st) {
+template <int KH, int DIL, int ST>
+int launch_bf16x3_st(const ConvArgs& a, hipStream_t st) {
   switch (bf16x3_variant(a, KH, DIL)) {
-    case CV_HOOKS: return launch_bf16x3_h<KH, DIL, true>(a, st);
+    case CV_HOOKS:
+      if constexpr (ST == 0) return launch_bf16x3_h<KH, DIL, true>(a, st);
+      paif::set_error("conv2d: the gradient hooks (in_act >= 3, aux_out, epi_dact) are built for fp32 storage only");
+      return PAIF_ENOSUP;
     case CV_WS:
 #if PAIF_TH == 8
-      if constexpr (KH <= 3) return launch_bf16x3_ws<KH, DIL>(a, st);
+      if constexpr (KH <= 3) return launch_bf16x3_ws<KH, DIL, ST>(a, st);
 #endif
       break;
     case CV_RES:
-      if constexpr (KH == 3 && DIL == 1) return launch_bf16x3_res<3, 1, 1>(a, st);
+      if constexpr (KH == 3 && DIL == 1) return launch_bf16x3_res<3, 1, 1, ST>(a, st);
       break;
     case CV_MS:
-      if constexpr (KH == 3 && DIL == 1) return a.nsrc == 2 ? launch_bf16x3_ms<3, 1, 2>(a, st) : launch_bf16x3_ms<3, 1, 3>(a, st);
+      if constexpr (KH == 3 && DIL == 1) return a.nsrc == 2 ? launch_bf16x3_ms<3, 1, 2, ST>(a, st) : launch_bf16x3_ms<3, 1, 3, ST>(a, st);
       break;
     default: break;
   }
-  return launch_bf16x3_h<KH, DIL, false>(a, st);
+  return launch_bf16x3_h<KH, DIL, false, ST>(a, st);
+}
+
+// bf16 storage is built for the kernel shapes of the inference forward (1x1, 3x3 dil 1 / 2, 7x7); fp32 in / bf16 out only for
+// the 1x1 behind the fp32 guided-filter block
+template <int KH, int DIL>
+int launch_bf16x3(const ConvArgs& a, hipStream_t st) {
+  if (a.st == 0) return launch_bf16x3_st<KH, DIL, 0>(a, st);
+  if constexpr ((KH == 1 || KH == 3 || KH == 7) && (DIL == 1 || (KH == 3 && DIL == 2))) {
+    if (a.st == 1) return launch_bf16x3_st<KH, DIL, 1>(a, st);
+    if constexpr (KH == 1) {
+      if (a.st == 2) return launch_bf16x3_st<KH, DIL, 2>(a, st);
+    }
+  }
+  paif::set_error("conv2d: storage %d is not built for the %dx%d dilation-%d kernel", a.st, KH, KH, DIL);
+  return PAIF_ENOSUP;
 }
 
 // w [cout][nsrc*32][kh][kh] fp32 -> wpk[src][tap][ks][hi|lo][64 lanes][8 bf16]
@@ -1658,12 +1712,13 @@ int paif_conv2d_kernel_name(const paif_conv_desc* d, int B, int H, int W, char* 
     snprintf(buf, buflen, "conv_mfma_f32<%d, %d, %d, %s>", d->kh, d->dil, d->cin, needs_hooks(a) ? "true" : "false");
     return 0;
   }
+  // the names rocprofv3 prints: every template argument, the storage code last
   switch (bf16x3_variant(a, d->kh, d->dil)) {
-    case CV_WS: snprintf(buf, buflen, "conv_bf16x3_ws<%d, %d>", d->kh, d->dil); break;
-    case CV_RES: snprintf(buf, buflen, "conv_bf16x3_res<%d, %d, %d, %d>", d->kh, d->dil, d->nsrc, PAIF_RES_ROWS); break;
-    case CV_MS: snprintf(buf, buflen, "conv_bf16x3_ms<%d, %d, %d>", d->kh, d->dil, d->nsrc); break;
-    case CV_HOOKS: snprintf(buf, buflen, "conv_mfma_bf16x3<%d, %d, true>", d->kh, d->dil); break;
-    default: snprintf(buf, buflen, "conv_mfma_bf16x3<%d, %d, false>", d->kh, d->dil); break;
+    case CV_WS: snprintf(buf, buflen, "conv_bf16x3_ws<%d, %d, %d>", d->kh, d->dil, d->storage); break;
+    case CV_RES: snprintf(buf, buflen, "conv_bf16x3_res<%d, %d, %d, %d, %d>", d->kh, d->dil, d->nsrc, PAIF_RES_ROWS, d->storage); break;
+    case CV_MS: snprintf(buf, buflen, "conv_bf16x3_ms<%d, %d, %d, %d>", d->kh, d->dil, d->nsrc, d->storage); break;
+    case CV_HOOKS: snprintf(buf, buflen, "conv_mfma_bf16x3<%d, %d, true, %d>", d->kh, d->dil, d->storage); break;
+    default: snprintf(buf, buflen, "conv_mfma_bf16x3<%d, %d, false, %d>", d->kh, d->dil, d->storage); break;
   }
   return 0;
 }
@@ -1696,6 +1751,9 @@ int paif_conv2d_fwd(const paif_conv_desc* d, int B, int H, int W, paif_stream_t 
   a.B = B; a.H = H; a.W = W;
   a.tilesX = (W + TW - 1) / TW; a.tilesY = (H + TH - 1) / TH; a.nblk = B * a.tilesX * a.tilesY;
   a.reverse = d->reverse_tiles ? 1 : 0;
+  a.st = d->storage;
+  PAIF_REQUIRE(d->storage >= 0 && d->storage <= 2, PAIF_EINVAL, "conv2d: storage=%d", d->storage);
+  PAIF_REQUIRE(d->storage == 0 || (d->precision == PAIF_CONV_BF16X3 && d->cin == 32), PAIF_ENOSUP, "conv2d: bf16 storage needs the split-bf16 kernels (cin 32)");
   hipStream_t st = paif::as_stream(stream);
   PAIF_REQUIRE(d->cin == 32 || d->cin == 16, PAIF_ENOSUP, "conv2d: cin=%d", d->cin);
   PAIF_REQUIRE(d->precision == PAIF_CONV_F32 || d->precision == PAIF_CONV_BF16X3, PAIF_EINVAL, "conv2d: precision=%d", d->precision);

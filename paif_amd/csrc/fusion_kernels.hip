@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
 // depthwise k x k (groups = 32), optional ReLU on the input; taps come from L1/L2 (each float4 is
 // re-read by the k*k neighbouring pixels' threads of the same or an adjacent wave).
 // ---------------------------------------------------------------------------------------------
-template <int K, int DIL>
+template <int K, int DIL, int BF = 0>
 __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      float* __restrict__ out, int in_relu, int B, int H, int W) {
   constexpr int P = DIL * (K - 1) / 2;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
     const int xx0 = (int)(pix % W);
     const size_t rowid = pix / W;
     const int yy0 = (int)(rowid % H);
-    const float* base = x + (rowid - yy0) * W * 32 + q * 4;
+    const size_t base = (rowid - yy0) * W * 32 + q * 4;      // element offset (fp32 or bf16 storage: paif_common.h)
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     // Loads are unconditional on clamped coordinates and padding is a select afterwards: a load under a branch is
     // waited for at the join, which serialised the k*k taps' latencies (1.85 TB/s); one tap row (k loads) is in
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
 #pragma unroll
         for (int dx = 0; dx < K; ++dx) {
           const int xx = min(max(xx0 + dx * DIL - P, 0), W - 1);
-          v[r][dx] = *reinterpret_cast<const float4*>(base + ((size_t)yy * W + xx) * 32);
+          v[r][dx] = paif::ldq<BF>(x, base + ((size_t)yy * W + xx) * 32);
         }
       }
 #pragma unroll
@@ -182,19 +182,20 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
         }
       }
     }
-    paif::store_nt(out + pix * 32 + q * 4, acc);
+    paif::stq_nt<BF>(out, pix * 32 + q * 4, acc);
   }
 }
 
 // ---------------------------------------------------------------------------------------------
 // ChannelPool(ir, vis): (max_c ir, mean_c ir, max_c vis, mean_c vis) -> float4 per pixel
 // ---------------------------------------------------------------------------------------------
+template <int BF = 0>
 __global__ __launch_bounds__(256) void channel_pool2_kernel(const float* __restrict__ ir, const float* __restrict__ vis,
                                                             float* __restrict__ comp, size_t npix) {
   const int q = threadIdx.x & 7;
   for (size_t pix = (size_t)blockIdx.x * 32 + (threadIdx.x >> 3); pix < npix; pix += (size_t)gridDim.x * 32) {
-    const float4 a = paif::load_nt(ir + pix * 32 + q * 4);
-    const float4 b = paif::load_nt(vis + pix * 32 + q * 4);
+    const float4 a = paif::ldq_nt<BF>(ir, pix * 32 + q * 4);
+    const float4 b = paif::ldq_nt<BF>(vis, pix * 32 + q * 4);
     float mxa = fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), sa = (a.x + a.y) + (a.z + a.w);
     float mxb = fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)), sb = (b.x + b.y) + (b.z + b.w);
 #pragma unroll
@@ -222,6 +223,7 @@ __global__ __launch_bounds__(256) void channel_residue_kernel(const float* __res
 }
 
 // scale = sigmoid(conv5x5 4->1 (comp)); agg = scale*ir + (1-scale)*vis
+template <int BF = 0>
 __global__ __launch_bounds__(256) void spa_blend_kernel(const float* __restrict__ comp, const float* __restrict__ w,
                                                         const float* __restrict__ ir, const float* __restrict__ vis,
                                                         float* __restrict__ agg, float* __restrict__ scale_out, int B,
@@ -250,15 +252,15 @@ __global__ __launch_bounds__(256) void spa_blend_kernel(const float* __restrict_
 #pragma unroll
     for (int m = 1; m < 8; m <<= 1) s += __shfl_xor(s, m);
     const float sc = 1.0f / (1.0f + expf(-s));
-    const float4 a = paif::load_nt(ir + pix * 32 + q * 4);
-    const float4 b = paif::load_nt(vis + pix * 32 + q * 4);
+    const float4 a = paif::ldq_nt<BF>(ir, pix * 32 + q * 4);
+    const float4 b = paif::ldq_nt<BF>(vis, pix * 32 + q * 4);
     const float om = 1.0f - sc;
     float4 o;
     o.x = __fadd_rn(__fmul_rn(sc, a.x), __fmul_rn(om, b.x));
     o.y = __fadd_rn(__fmul_rn(sc, a.y), __fmul_rn(om, b.y));
     o.z = __fadd_rn(__fmul_rn(sc, a.z), __fmul_rn(om, b.z));
     o.w = __fadd_rn(__fmul_rn(sc, a.w), __fmul_rn(om, b.w));
-    paif::store_nt(agg + pix * 32 + q * 4, o);
+    paif::stq_nt<BF>(agg, pix * 32 + q * 4, o);
     if (scale_out && q == 0) scale_out[pix] = sc;
   }
 }
@@ -297,6 +299,7 @@ __global__ __launch_bounds__(1024) void eca_scale_kernel(const float* __restrict
   }
 }
 
+template <int BF = 0>
 __global__ __launch_bounds__(256) void eca_apply_kernel(const float* __restrict__ o, const float* __restrict__ r,
                                                         const float* __restrict__ s, const float* __restrict__ prelu,
                                                         float* __restrict__ out, float* __restrict__ u_out, size_t pix_per_img,
@@ -306,13 +309,13 @@ __global__ __launch_bounds__(256) void eca_apply_kernel(const float* __restrict_
   for (size_t pix = (size_t)blockIdx.x * 32 + (threadIdx.x >> 3); pix < npix; pix += (size_t)gridDim.x * 32) {
     const size_t b = pix / pix_per_img;
     const float4 sv = *reinterpret_cast<const float4*>(s + b * 32 + q * 4);
-    const float4 ov = paif::load_nt(o + pix * 32 + q * 4);
-    const float4 rv = paif::load_nt(r + pix * 32 + q * 4);
+    const float4 ov = paif::ldq_nt<BF>(o, pix * 32 + q * 4);
+    const float4 rv = paif::ldq_nt<BF>(r, pix * 32 + q * 4);
     float4 u4;
     u4.x = __fadd_rn(__fmul_rn(ov.x, sv.x), rv.x); u4.y = __fadd_rn(__fmul_rn(ov.y, sv.y), rv.y);
     u4.z = __fadd_rn(__fmul_rn(ov.z, sv.z), rv.z); u4.w = __fadd_rn(__fmul_rn(ov.w, sv.w), rv.w);
-    if (u_out) paif::store_nt(u_out + pix * 32 + q * 4, u4);
-    paif::store_nt(out + pix * 32 + q * 4,
+    if (u_out) paif::stq_nt<BF>(u_out, pix * 32 + q * 4, u4);
+    paif::stq_nt<BF>(out, pix * 32 + q * 4,
                    make_float4(paif::prelu_f(u4.x, slope), paif::prelu_f(u4.y, slope), paif::prelu_f(u4.z, slope), paif::prelu_f(u4.w, slope)));
   }
 }
@@ -320,6 +323,7 @@ __global__ __launch_bounds__(256) void eca_apply_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------------------------
 // tail: 3x3 conv 16->1 + PReLU + tanh.  x NHWC16; 4 lanes per pixel (one float4 each), taps from L1.
 // ---------------------------------------------------------------------------------------------
+template <int BF = 0>
 __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                    const float* __restrict__ prelu, float* __restrict__ fused,
                                                    float* __restrict__ z_out, int B, int H, int W) {
@@ -335,7 +339,7 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ x, 
     const int x0 = (int)(pix % W);
     const size_t rowid = pix / W;
     const int y0 = (int)(rowid % H);
-    const float* base = x + (rowid - y0) * W * 16 + q * 4;
+    const size_t base = (rowid - y0) * W * 16 + q * 4;       // element offset
     float s = 0.f;
     // all 9 taps in flight: unconditional loads on clamped coordinates, padding by select (see dwconv_kernel)
     float4 v[9];
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ x, 
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
         const int yy = min(max(y0 + dy - 1, 0), H - 1), xx = min(max(x0 + dx - 1, 0), W - 1);
-        v[dy * 3 + dx] = *reinterpret_cast<const float4*>(base + ((size_t)yy * W + xx) * 16);
+        v[dy * 3 + dx] = paif::ldq<BF>(x, base + ((size_t)yy * W + xx) * 16);
       }
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy)
@@ -372,6 +376,19 @@ __global__ void add_kernel(const float4* __restrict__ a, const float4* __restric
     o[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
   }
   if (blockIdx.x == 0 && threadIdx.x < tail) ot[threadIdx.x] = at[threadIdx.x] + bt[threadIdx.x];
+}
+
+// elementwise add / casts on bf16-stored maps (4 elements per thread)
+__global__ void add_bf16_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 x = paif::ldq<1>(a, i * 4), y = paif::ldq<1>(b, i * 4);
+    paif::stq<1>(o, i * 4, make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w));
+  }
+}
+template <int TO_BF>
+__global__ void cast_storage_kernel(const float* __restrict__ a, float* __restrict__ o, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+    paif::stq_nt<TO_BF>(o, i * 4, paif::ldq_nt<1 - TO_BF>(a, i * 4));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -557,7 +574,7 @@ int paif_dwconv_fwd(const float* x, const float* w, float* out, int k, int dil, 
 int paif_channel_pool2_fwd(const float* ir, const float* vis, float* comp, int B, int H, int W, paif_stream_t stream) {
   PAIF_REQUIRE(ir && vis && comp && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "channel_pool2: bad arguments");
   const size_t npix = (size_t)B * H * W;
-  hipLaunchKernelGGL(channel_pool2_kernel, dim3(grid_for(npix, 32)), dim3(256), 0, paif::as_stream(stream), ir, vis, comp,
+  hipLaunchKernelGGL(channel_pool2_kernel<0>, dim3(grid_for(npix, 32)), dim3(256), 0, paif::as_stream(stream), ir, vis, comp,
                      npix);
   PAIF_LAUNCH_CHECK("channel_pool2");
   return 0;
@@ -574,7 +591,7 @@ int paif_channel_residue_fwd(const float* x, float* guide, int B, int H, int W, 
 int paif_spa_blend_fwd(const float* comp, const float* w, const float* ir, const float* vis, float* agg, float* scale_out,
                        int B, int H, int W, paif_stream_t stream) {
   PAIF_REQUIRE(comp && w && ir && vis && agg && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "spa_blend: bad arguments");
-  hipLaunchKernelGGL(spa_blend_kernel, dim3(grid_for((size_t)B * H * W, 32)), dim3(256), 0, paif::as_stream(stream), comp,
+  hipLaunchKernelGGL(spa_blend_kernel<0>, dim3(grid_for((size_t)B * H * W, 32)), dim3(256), 0, paif::as_stream(stream), comp,
                      w, ir, vis, agg, scale_out, B, H, W);
   PAIF_LAUNCH_CHECK("spa_blend");
   return 0;
@@ -592,7 +609,7 @@ int paif_eca_finish_fwd(const float* o, const float* r, const float* pool_partia
                      1.0f / ((float)H * (float)W), s);
   PAIF_LAUNCH_CHECK("eca_scale");
   const size_t npix = (size_t)B * H * W;
-  hipLaunchKernelGGL(eca_apply_kernel, dim3(grid_for(npix, 32)), dim3(256), 0, st, o, r, s, prelu, out, u_out, (size_t)H * W, npix);
+  hipLaunchKernelGGL(eca_apply_kernel<0>, dim3(grid_for(npix, 32)), dim3(256), 0, st, o, r, s, prelu, out, u_out, (size_t)H * W, npix);
   PAIF_LAUNCH_CHECK("eca_apply");
   return 0;
 }
@@ -600,7 +617,7 @@ int paif_eca_finish_fwd(const float* o, const float* r, const float* pool_partia
 int paif_tail_fwd(const float* x, const float* w, const float* prelu, float* fused, float* z_out, int B, int H, int W,
                   paif_stream_t stream) {
   PAIF_REQUIRE(x && w && prelu && fused && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "tail: bad arguments");
-  hipLaunchKernelGGL(tail_kernel, dim3(grid_for((size_t)B * H * W, 64)), dim3(256), 0, paif::as_stream(stream), x, w, prelu,
+  hipLaunchKernelGGL(tail_kernel<0>, dim3(grid_for((size_t)B * H * W, 64)), dim3(256), 0, paif::as_stream(stream), x, w, prelu,
                      fused, z_out, B, H, W);
   PAIF_LAUNCH_CHECK("tail");
   return 0;
@@ -614,6 +631,79 @@ int paif_add_fwd(const float* a, const float* b, float* out, size_t n, paif_stre
                      reinterpret_cast<const float4*>(a), reinterpret_cast<const float4*>(b), reinterpret_cast<float4*>(out), n4,
                      a + n4 * 4, b + n4 * 4, out + n4 * 4, tail);
   PAIF_LAUNCH_CHECK("add");
+  return 0;
+}
+
+// ---- bf16-stored activation maps (BASELINE configs[1] "bf16"; include/paif_hip.h PAIF_ST_BF16): the same kernels with 8-byte
+// loads / round-to-nearest-even stores; fp32 arithmetic.  x / out / ir / vis / agg / o / r are bf16 data behind the float* ----
+int paif_dwconv_fwd_bf16(const float* x, const float* w, float* out, int k, int dil, int in_relu, int B, int H, int W, paif_stream_t stream) {
+  PAIF_REQUIRE(x && w && out && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "dwconv(bf16): bad arguments");
+  const dim3 g(grid_for((size_t)B * H * W, 32)), blk(256);
+  hipStream_t st = paif::as_stream(stream);
+  switch (k * 10 + dil) {
+    case 31: hipLaunchKernelGGL((dwconv_kernel<3, 1, 1>), g, blk, 0, st, x, w, out, in_relu, B, H, W); break;
+    case 32: hipLaunchKernelGGL((dwconv_kernel<3, 2, 1>), g, blk, 0, st, x, w, out, in_relu, B, H, W); break;
+    case 51: hipLaunchKernelGGL((dwconv_kernel<5, 1, 1>), g, blk, 0, st, x, w, out, in_relu, B, H, W); break;
+    default:
+      paif::set_error("dwconv(bf16): kernel %d dil %d not built", k, dil);
+      return PAIF_ENOSUP;
+  }
+  PAIF_LAUNCH_CHECK("dwconv(bf16)");
+  return 0;
+}
+
+int paif_channel_pool2_fwd_bf16(const float* ir, const float* vis, float* comp, int B, int H, int W, paif_stream_t stream) {
+  PAIF_REQUIRE(ir && vis && comp && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "channel_pool2(bf16): bad arguments");
+  const size_t npix = (size_t)B * H * W;
+  hipLaunchKernelGGL(channel_pool2_kernel<1>, dim3(grid_for(npix, 32)), dim3(256), 0, paif::as_stream(stream), ir, vis, comp, npix);
+  PAIF_LAUNCH_CHECK("channel_pool2(bf16)");
+  return 0;
+}
+
+int paif_spa_blend_fwd_bf16(const float* comp, const float* w, const float* ir, const float* vis, float* agg, int B, int H, int W,
+                            paif_stream_t stream) {
+  PAIF_REQUIRE(comp && w && ir && vis && agg && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "spa_blend(bf16): bad arguments");
+  hipLaunchKernelGGL(spa_blend_kernel<1>, dim3(grid_for((size_t)B * H * W, 32)), dim3(256), 0, paif::as_stream(stream), comp, w, ir, vis, agg,
+                     (float*)nullptr, B, H, W);
+  PAIF_LAUNCH_CHECK("spa_blend(bf16)");
+  return 0;
+}
+
+int paif_eca_finish_fwd_bf16(const float* o, const float* r, const float* pool_partial, const float* w1d, int k, const float* prelu,
+                             float* gate, float* out, int B, int H, int W, paif_stream_t stream) {
+  PAIF_REQUIRE(o && r && pool_partial && w1d && prelu && gate && out && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "eca_finish(bf16): bad arguments");
+  PAIF_REQUIRE(k >= 1 && k <= 9 && (k & 1), PAIF_ENOSUP, "eca_finish: k=%d", k);
+  hipStream_t st = paif::as_stream(stream);
+  hipLaunchKernelGGL(eca_scale_kernel, dim3(B), dim3(1024), 0, st, pool_partial, w1d, k, paif_conv2d_blocks(1, H, W), 1.0f / ((float)H * (float)W), gate);
+  PAIF_LAUNCH_CHECK("eca_scale");
+  const size_t npix = (size_t)B * H * W;
+  hipLaunchKernelGGL(eca_apply_kernel<1>, dim3(grid_for(npix, 32)), dim3(256), 0, st, o, r, gate, prelu, out, (float*)nullptr, (size_t)H * W, npix);
+  PAIF_LAUNCH_CHECK("eca_apply(bf16)");
+  return 0;
+}
+
+int paif_tail_fwd_bf16(const float* x, const float* w, const float* prelu, float* fused, int B, int H, int W, paif_stream_t stream) {
+  PAIF_REQUIRE(x && w && prelu && fused && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "tail(bf16): bad arguments");
+  hipLaunchKernelGGL(tail_kernel<1>, dim3(grid_for((size_t)B * H * W, 64)), dim3(256), 0, paif::as_stream(stream), x, w, prelu, fused,
+                     (float*)nullptr, B, H, W);
+  PAIF_LAUNCH_CHECK("tail(bf16)");
+  return 0;
+}
+
+int paif_add_fwd_bf16(const float* a, const float* b, float* out, size_t n, paif_stream_t stream) {
+  PAIF_REQUIRE(a && b && out && n % 4 == 0, PAIF_EINVAL, "add(bf16): null pointer or n %% 4 != 0");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(add_bf16_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, paif::as_stream(stream), a, b, out, n / 4);
+  PAIF_LAUNCH_CHECK("add(bf16)");
+  return 0;
+}
+
+int paif_cast_storage_fwd(const float* src, float* dst, size_t n, int to_bf16, paif_stream_t stream) {
+  PAIF_REQUIRE(src && dst && n % 4 == 0, PAIF_EINVAL, "cast_storage: null pointer or n %% 4 != 0");
+  if (n == 0) return 0;
+  if (to_bf16) hipLaunchKernelGGL(cast_storage_kernel<1>, dim3(grid_for(n / 4, 256)), dim3(256), 0, paif::as_stream(stream), src, dst, n / 4);
+  else hipLaunchKernelGGL(cast_storage_kernel<0>, dim3(grid_for(n / 4, 256)), dim3(256), 0, paif::as_stream(stream), src, dst, n / 4);
+  PAIF_LAUNCH_CHECK("cast_storage");
   return 0;
 }
 

@@ -70,4 +70,53 @@ __device__ __forceinline__ void store_nt(float* p, float v) { __builtin_nontempo
 #endif
 __device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + __expf(-v)); }
 
+// ---------------------------------------------------------------------------------------------
+// Activation STORAGE (BASELINE configs[1]: "bf16"): a 32-channel NHWC map is held either as fp32 (BF = 0, the default) or as
+// bf16 (BF = 1: 64 bytes per pixel, round-to-nearest-even on store); arithmetic is fp32 / split-bf16 MFMA either way.
+// A kernel's storage template parameter ST names the pair: 0 = fp32 in / fp32 out, 1 = bf16 in / bf16 out,
+// 2 = fp32 in / bf16 out (the first layer behind the fp32 guided-filter block).  Pointers stay typed `float*` in the
+// argument structs; the helpers address `eoff` ELEMENTS from the base in the storage's element size.
+// ---------------------------------------------------------------------------------------------
+constexpr int st_in(int ST) { return ST == 1 ? 1 : 0; }
+constexpr int st_out(int ST) { return ST >= 1 ? 1 : 0; }
+
+__device__ __forceinline__ float4 bf16x4_to_f32(uint2 u) {
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                     __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ uint2 f32_to_bf16x4(float4 v) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t a = {v.x, v.y}, b = {v.z, v.w};
+  return make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16x2_t)),
+                    __builtin_bit_cast(unsigned, __builtin_convertvector(b, bf16x2_t)));
+}
+template <int BF> __device__ __forceinline__ float4 ldq(const float* base, size_t eoff) {
+  if constexpr (BF) return bf16x4_to_f32(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + eoff));
+  else return *reinterpret_cast<const float4*>(base + eoff);
+}
+template <int BF> __device__ __forceinline__ float4 ldq_nt(const float* base, size_t eoff) {
+  if constexpr (BF) {
+    typedef unsigned u32x2_nt __attribute__((ext_vector_type(2)));
+    const u32x2_nt v = __builtin_nontemporal_load(reinterpret_cast<const u32x2_nt*>(reinterpret_cast<const unsigned short*>(base) + eoff));
+    return bf16x4_to_f32(make_uint2(v.x, v.y));
+  } else {
+    return load_nt(base + eoff);
+  }
+}
+template <int BF> __device__ __forceinline__ void stq(float* base, size_t eoff, float4 v) {
+  if constexpr (BF) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + eoff) = f32_to_bf16x4(v);
+  else *reinterpret_cast<float4*>(base + eoff) = v;
+}
+template <int BF> __device__ __forceinline__ void stq_nt(float* base, size_t eoff, float4 v) {
+  if constexpr (BF) {
+    typedef unsigned u32x2_nt __attribute__((ext_vector_type(2)));
+    const uint2 u = f32_to_bf16x4(v);
+    const u32x2_nt vv = {u.x, u.y};
+    __builtin_nontemporal_store(vv, reinterpret_cast<u32x2_nt*>(reinterpret_cast<unsigned short*>(base) + eoff));
+  } else {
+    store_nt(base + eoff, v);
+  }
+}
+
 }  // namespace paif

@@ -66,24 +66,39 @@ def test_dense_conv_dispatch_rules_on_the_host():
         return buf.value.decode()
 
     # bench shape (9600 tiles of 8 x 32)
-    assert name(nsrc=1) == "conv_bf16x3_res<3, 1, 1, 4>"
-    assert name(nsrc=1, nres=3) == "conv_bf16x3_res<3, 1, 1, 4>"
-    assert name(nsrc=1, in_act=1) == "conv_bf16x3_res<3, 1, 1, 4>"
-    assert name(nsrc=1, pool=True) == "conv_mfma_bf16x3<3, 1, false>"
-    assert name(nsrc=2) == "conv_bf16x3_ms<3, 1, 2>"
-    assert name(nsrc=3, nres=3) == "conv_bf16x3_ms<3, 1, 3>"
-    assert name(nsrc=3, in_act=1) == "conv_mfma_bf16x3<3, 1, false>"        # multi-source form: no input activation
-    assert name(nsrc=1, hooks=True) == "conv_mfma_bf16x3<3, 1, true>"       # dgrad hooks: tile-per-workgroup kernel
-    assert name(kh=1, nsrc=3) == "conv_bf16x3_ws<1, 1>"
-    assert name(kh=1, nsrc=3, nres=1) == "conv_mfma_bf16x3<1, 1, false>"
-    assert name(kh=3, dil=2, nsrc=1) == "conv_bf16x3_ws<3, 2>"
-    assert name(kh=3, dil=2, nsrc=2) == "conv_mfma_bf16x3<3, 2, false>"
-    assert name(kh=7) == "conv_mfma_bf16x3<7, 1, false>"
-    assert name(kh=5, dil=2) == "conv_mfma_bf16x3<5, 2, false>"
+    assert name(nsrc=1) == "conv_bf16x3_res<3, 1, 1, 4, 0>"
+    assert name(nsrc=1, nres=3) == "conv_bf16x3_res<3, 1, 1, 4, 0>"
+    assert name(nsrc=1, in_act=1) == "conv_bf16x3_res<3, 1, 1, 4, 0>"
+    assert name(nsrc=1, pool=True) == "conv_mfma_bf16x3<3, 1, false, 0>"
+    assert name(nsrc=2) == "conv_bf16x3_ms<3, 1, 2, 0>"
+    assert name(nsrc=3, nres=3) == "conv_bf16x3_ms<3, 1, 3, 0>"
+    assert name(nsrc=3, in_act=1) == "conv_mfma_bf16x3<3, 1, false, 0>"        # multi-source form: no input activation
+    assert name(nsrc=1, hooks=True) == "conv_mfma_bf16x3<3, 1, true, 0>"       # dgrad hooks: tile-per-workgroup kernel
+    assert name(kh=1, nsrc=3) == "conv_bf16x3_ws<1, 1, 0>"
+    assert name(kh=1, nsrc=3, nres=1) == "conv_mfma_bf16x3<1, 1, false, 0>"
+    assert name(kh=3, dil=2, nsrc=1) == "conv_bf16x3_ws<3, 2, 0>"
+    assert name(kh=3, dil=2, nsrc=2) == "conv_mfma_bf16x3<3, 2, false, 0>"
+    assert name(kh=7) == "conv_mfma_bf16x3<7, 1, false, 0>"
+    assert name(kh=5, dil=2) == "conv_mfma_bf16x3<5, 2, false, 0>"
     # small images: fewer than 1024 / 2048 tiles -> no persistent forms
-    assert name(nsrc=1, B=2, H=64, W=96) == "conv_mfma_bf16x3<3, 1, false>"
-    assert name(kh=1, nsrc=3, B=2, H=64, W=96) == "conv_mfma_bf16x3<1, 1, false>"
-    assert name(nsrc=2, B=2, H=64, W=96) == "conv_bf16x3_ms<3, 1, 2>"      # the multi-source form has no size threshold
+    assert name(nsrc=1, B=2, H=64, W=96) == "conv_mfma_bf16x3<3, 1, false, 0>"
+    assert name(kh=1, nsrc=3, B=2, H=64, W=96) == "conv_mfma_bf16x3<1, 1, false, 0>"
+    assert name(nsrc=2, B=2, H=64, W=96) == "conv_bf16x3_ms<3, 1, 2, 0>"      # the multi-source form has no size threshold
+    # bf16 activation storage: the same dispatch, the storage code is the kernels' last template argument
+    def name_st(st, **kw):
+        d_kh = kw.get("kh", 3)
+        d = _lib.ConvDesc()
+        one = ctypes.c_void_p(16)
+        for i in range(3):
+            d.src[i] = one if i < kw.get("nsrc", 1) else None
+        d.nsrc, d.cin, d.cout, d.kh, d.dil, d.precision, d.storage = kw.get("nsrc", 1), 32, 32, d_kh, kw.get("dil", 1), 1, st
+        d.wpk, d.out = one, one
+        buf = ctypes.create_string_buffer(96)
+        assert L.paif_conv2d_kernel_name(ctypes.byref(d), 8, 480, 640, buf, len(buf)) == 0
+        return buf.value.decode()
+
+    assert name_st(1, nsrc=3) == "conv_bf16x3_ms<3, 1, 3, 1>"
+    assert name_st(2, kh=1, nsrc=3) == "conv_bf16x3_ws<1, 1, 2>"
     # exact arithmetic
     assert name(precision=0) == "conv_mfma_f32<3, 1, 32, false>"
     assert name(precision=0, cin=16, cout=16) == "conv_mfma_f32<3, 1, 16, false>"
