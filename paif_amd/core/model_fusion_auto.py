@@ -543,7 +543,8 @@ class _CompositeBase(nn.Module):
             return _CompositeFn.apply(ir, vis, self, wg, grad_anchor(ir.device))
         with torch.no_grad():
             ycc = ops.rgb2ycrcb(vis)
-            fused = self.enhance_net.forward_impl(ir[:, 0:1, :, :], ycc)
+            with ops.bf16_activations(enable=not self.enhance_net.training):     # ops.set_storage("bf16"), inference only
+                fused = self.enhance_net.forward_impl(ir[:, 0:1, :, :], ycc)
             seg_in = ops.seg_input_from_fused(fused, ycc, minmax_sync=self._minmax_sync())   # clamp, BATCH-GLOBAL min-max, x255, mean/std
             seg_map = self.denoise_net(seg_in)
         return fused, seg_map

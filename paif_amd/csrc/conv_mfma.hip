@@ -479,7 +479,7 @@ __global__ __launch_bounds__(NTHREADS, (HOOKS || KH >= 5 || DIL == 2) ? 2 : PAIF
           lo.x = pack_bf16(t4.x - (float)hx, t4.y - (float)hy);
           lo.y = pack_bf16(t4.z - (float)hz, t4.w - (float)hw);
           *reinterpret_cast<uint2*>(ldsb + dst[u]) = hi;
-          *reinterpret_cast<uint2*>(ldsb + dst[u] + 64) = lo;
+          if constexpr (!paif::st_lo0(ST)) *reinterpret_cast<uint2*>(ldsb + dst[u] + 64) = lo;
         }
       }
     }
@@ -509,14 +509,16 @@ __global__ __launch_bounds__(NTHREADS, (HOOKS || KH >= 5 || DIL == 2) ? 2 : PAIF
 #pragma unroll
       for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) {
         A.h[sg] = *reinterpret_cast<const bf16x8*>(ldsb + abase[sg] + toff);
-        A.l[sg] = *reinterpret_cast<const bf16x8*>(ldsb + abase[sg] + toff + 64);
+        if constexpr (!paif::st_lo0(ST)) A.l[sg] = *reinterpret_cast<const bf16x8*>(ldsb + abase[sg] + toff + 64);
       }
     };
     auto mma_step = [&](const AStep& A, int slot, int ks) {
       const bf16x8 bh = __builtin_bit_cast(bf16x8, bw[slot][2 * ks]);
       const bf16x8 bl = __builtin_bit_cast(bf16x8, bw[slot][2 * ks + 1]);
+      if constexpr (!paif::st_lo0(ST)) {
 #pragma unroll
-      for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.l[sg], bh, acc[sg], 0, 0, 0);
+        for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.l[sg], bh, acc[sg], 0, 0, 0);
+      }
 #pragma unroll
       for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h[sg], bl, acc[sg], 0, 0, 0);
 #pragma unroll
@@ -780,7 +782,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bf16x3_ms(ConvArgs a) {
       split_raw(t4, hi, lo);
       if (!LAST_PARTIAL || u + 1 < NIT || last_valid) {
         *reinterpret_cast<uint2*>(ldsb + dst[u]) = hi;
-        *reinterpret_cast<uint2*>(ldsb + dst[u] + 64) = lo;
+        if constexpr (!paif::st_lo0(ST)) *reinterpret_cast<uint2*>(ldsb + dst[u] + 64) = lo;
       }
     }
   };
@@ -809,14 +811,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bf16x3_ms(ConvArgs a) {
 #pragma unroll
     for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) {
       A.h[sg] = *reinterpret_cast<const bf16x8*>(ldsb + abase[sg] + toff);
-      A.l[sg] = *reinterpret_cast<const bf16x8*>(ldsb + abase[sg] + toff + 64);
+      if constexpr (!paif::st_lo0(ST)) A.l[sg] = *reinterpret_cast<const bf16x8*>(ldsb + abase[sg] + toff + 64);
     }
   };
   auto mma_step = [&](const AStep& A, int g, int ks) {
     const bf16x8 bh = __builtin_bit_cast(bf16x8, bw[g % D][2 * ks]);
     const bf16x8 bl = __builtin_bit_cast(bf16x8, bw[g % D][2 * ks + 1]);
+    if constexpr (!paif::st_lo0(ST)) {
 #pragma unroll
-    for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.l[sg], bh, acc[sg], 0, 0, 0);
+      for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.l[sg], bh, acc[sg], 0, 0, 0);
+    }
 #pragma unroll
     for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h[sg], bl, acc[sg], 0, 0, 0);
 #pragma unroll
@@ -1016,7 +1020,7 @@ __global__ __launch_bounds__(RT * 64, RT == 4 ? 2 : 1) void conv_bf16x3_res(Conv
       split_bf16x4(t4, hi, lo);
       if (!LAST_PARTIAL || u + 1 < NIT || last_valid) {
         *reinterpret_cast<uint2*>(buf + dstu) = hi;
-        *reinterpret_cast<uint2*>(buf + dstu + 64) = lo;
+        if constexpr (!paif::st_lo0(ST)) *reinterpret_cast<uint2*>(buf + dstu + 64) = lo;
       }
     }
   };
@@ -1039,7 +1043,7 @@ __global__ __launch_bounds__(RT * 64, RT == 4 ? 2 : 1) void conv_bf16x3_res(Conv
     const int dy = tap / KH, dx = tap - dy * KH;
     const int toff = (dy * DIL * TWH + dx * DIL) * PSB + 32 * ks;
     A.h = *reinterpret_cast<const bf16x8*>(buf + abase + toff);
-    A.l = *reinterpret_cast<const bf16x8*>(buf + abase + toff + 64);
+    if constexpr (!paif::st_lo0(ST)) A.l = *reinterpret_cast<const bf16x8*>(buf + abase + toff + 64);
   };
   // one source from `buf`: the A operand runs two K steps (>= 192 MFMA cycles) ahead in a 3-slot register ring, issue
   // order pinned (see conv_mfma_bf16x3): one 3-MFMA dependent chain per wave leaves only that much time per step
@@ -1054,7 +1058,7 @@ __global__ __launch_bounds__(RT * 64, RT == 4 ? 2 : 1) void conv_bf16x3_res(Conv
       __builtin_amdgcn_sched_barrier(0);
       const bf16x8 bh = __builtin_bit_cast(bf16x8, bw[tap][2 * ks]);
       const bf16x8 bl = __builtin_bit_cast(bf16x8, bw[tap][2 * ks + 1]);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[step % 3].l, bh, acc[0], 0, 0, 0);
+      if constexpr (!paif::st_lo0(ST)) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[step % 3].l, bh, acc[0], 0, 0, 0);
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[step % 3].h, bl, acc[0], 0, 0, 0);
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[step % 3].h, bh, acc[0], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
@@ -1279,7 +1283,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_bf16x3_ws(ConvArgs a, int 
         if (!((mask >> u) & 1u)) hi = lo = make_uint2(0u, 0u);
         if (u < NIT - 1 || live_last) {
           *reinterpret_cast<uint2*>(buf + ldo[u]) = hi;
-          *reinterpret_cast<uint2*>(buf + ldo[u] + 64) = lo;
+          if constexpr (!paif::st_lo0(ST)) *reinterpret_cast<uint2*>(buf + ldo[u] + 64) = lo;
         }
       }
     };
@@ -1358,8 +1362,10 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_bf16x3_ws(ConvArgs a, int 
 #pragma unroll
             for (int sg = 0; sg < 2; ++sg) {
               const bf16x8 ah = *reinterpret_cast<const bf16x8*>(buf + abase[sg] + toff + 32 * ks);
-              const bf16x8 al = *reinterpret_cast<const bf16x8*>(buf + abase[sg] + toff + 64 + 32 * ks);
-              acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[sg], 0, 0, 0);
+              if constexpr (!paif::st_lo0(ST)) {
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(buf + abase[sg] + toff + 64 + 32 * ks);
+                acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[sg], 0, 0, 0);
+              }
               acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[sg], 0, 0, 0);
               acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[sg], 0, 0, 0);
             }
@@ -1563,7 +1569,7 @@ template <int KH, int DIL>
 int launch_bf16x3(const ConvArgs& a, hipStream_t st) {
   if (a.st == 0) return launch_bf16x3_st<KH, DIL, 0>(a, st);
   if constexpr ((KH == 1 || KH == 3 || KH == 7) && (DIL == 1 || (KH == 3 && DIL == 2))) {
-    if (a.st == 1) return launch_bf16x3_st<KH, DIL, 1>(a, st);
+    if (a.st == 1) return a.in_act == 1 ? launch_bf16x3_st<KH, DIL, 3>(a, st) : launch_bf16x3_st<KH, DIL, 1>(a, st);
     if constexpr (KH == 1) {
       if (a.st == 2) return launch_bf16x3_st<KH, DIL, 2>(a, st);
     }

@@ -77,8 +77,12 @@ __device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + __ex
 // 2 = fp32 in / bf16 out (the first layer behind the fp32 guided-filter block).  Pointers stay typed `float*` in the
 // argument structs; the helpers address `eoff` ELEMENTS from the base in the storage's element size.
 // ---------------------------------------------------------------------------------------------
-constexpr int st_in(int ST) { return ST == 1 ? 1 : 0; }
+constexpr int st_in(int ST) { return (ST == 1 || ST == 3) ? 1 : 0; }
 constexpr int st_out(int ST) { return ST >= 1 ? 1 : 0; }
+// ST 1: the staged A operand IS the stored bf16 value (no input activation, or ReLU), so its split-bf16 low half is exactly
+// zero: the kernels drop the lo x W_hi MFMA (2 of 3 MFMAs) and the low half's LDS traffic.  ST 3 (internal): bf16 in / out with
+// an input PReLU, whose result is not a bf16 value -- the full split is kept.
+constexpr bool st_lo0(int ST) { return ST == 1; }
 
 __device__ __forceinline__ float4 bf16x4_to_f32(uint2 u) {
   return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
