@@ -278,9 +278,14 @@ def main():
                 # split-bf16 convs: 3 bf16 MFMA passes -> effective matrix peak 2500/3 = 833 TF algorithmic; at 72-108 FLOP/B
                 # (fp32 storage, k <= 3) the HBM roof binds (833e12 / 8e12 = 104 FLOP/B); the 5x5 / 7x7 convs (K = 800 / 1568:
                 # 200-390 FLOP/B) are matrix-pipe bound and are priced against the 833 TF algorithmic peak
-                if fl_ / max(by_, 1) > SPLIT_BF16_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
-                    blk = {"bound": "mfma", "achieved": tf, "peak": SPLIT_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / SPLIT_BF16_PEAK_TFLOPS,
-                           "algorithmic_gbs": gb, "note": "split-bf16: 3 bf16 MFMAs per product -> 2500/3 TF algorithmic peak"}
+                # bf16-stored inputs (storage code 1, the kernels' last template argument; the family under --storage bf16): the stored
+                # operand's low half is zero, 2 bf16 MFMAs per product -> 2500/2 TF algorithmic peak
+                two = (tag.endswith(", 1>") or (tag == DOMINANT and args.storage == "bf16" and args.workload in ("fusion", "fusion_seg")))
+                peak_tf = 2500.0 / 2 if two else SPLIT_BF16_PEAK_TFLOPS
+                if fl_ / max(by_, 1) > peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9):
+                    blk = {"bound": "mfma", "achieved": tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": tf / peak_tf, "algorithmic_gbs": gb,
+                           "hbm_frac": gb / HBM_PEAK_GBS,
+                           "note": "split-bf16: %d bf16 MFMAs per product -> 2500/%d TF algorithmic peak" % ((2, 2) if two else (3, 3))}
                 else:
                     blk = {"bound": "hbm", "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS, "algorithmic_tflops": tf}
             elif tag.startswith("gf_"):
@@ -308,34 +313,50 @@ def main():
             return blk
 
         roof = roof_block(DOM)
-        roof["traffic"] = None
-        n = roof["launches"]
-        # PMC counters cannot be read live: `traffic` comes from the committed rocprofv3 --pmc summary of this same command,
-        # and ONLY while that summary still describes the kernel being benchmarked (hash of its source) -- otherwise null + why
-        traffic, traffic_note = None, None
+        # PMC counters cannot be read live: `traffic` comes from the committed rocprofv3 --pmc summary of this same command
+        # (profiles/pmc_traffic.json, one section per workload / storage), and the line says when that summary was measured on
+        # different kernel sources
+        pmc_sec, traffic_note = None, None
+        wkey = args.workload + ("/" + args.storage if args.workload in ("fusion", "fusion_seg") else "")
         try:
-            rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            mem = members.get(DOM, [DOM])
-            missing = [k for k in mem if k not in rec]
-            if missing:
-                traffic_note = "no PMC record for %s" % ", ".join(missing)
-            elif args.workload != "fusion":
-                traffic_note = "PMC record is for the configs[1] workload"
-            elif any(rec[k].get("kernel_source_sha16") != kernel_source_sha16() for k in mem):
-                traffic_note = "stale: profiles/pmc_traffic.json was measured on kernel source %s, the library is built from %s" % (
-                    rec[mem[0]].get("kernel_source_sha16"), kernel_source_sha16())
-            else:   # HBM bytes per launch, averaged over the launches of the family as `achieved` is
-                traffic = int(sum(rec[k]["traffic_bytes"] * per_kernel[k][0] for k in mem) / sum(per_kernel[k][0] for k in mem))
-                for kk in roof.get("kernels", []):
-                    kk["traffic"] = rec[kk["kernel"]]["traffic_bytes"]
-        except (OSError, ValueError, KeyError) as e:
+            pmc_all = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            pmc_sec = pmc_all.get(wkey)
+            if pmc_sec is None:
+                traffic_note = "no PMC section for %s" % wkey
+            elif pmc_sec.get("_kernel_source_sha16") != kernel_source_sha16():
+                traffic_note = "profiles/pmc_traffic.json[%s] was measured on kernel sources %s, the library is built from %s" % (
+                    wkey, pmc_sec.get("_kernel_source_sha16"), kernel_source_sha16())
+        except (OSError, ValueError) as e:
             traffic_note = "pmc_traffic.json unreadable: %s" % e
-        roof["traffic"] = traffic
-        roof["traffic_source"] = ("profiles/pmc_traffic.json: rocprofv3 --pmc passes of this same command run by the builder (tools/pmc_traffic.py), "
-                                  "tied to the kernel-source hash; PMC counters cannot be read inside an un-profiled run")
+
+        def pmc_lookup(tag):
+            """HBM bytes per launch of a timer tag: the record of that kernel (all instantiations of a bare name, launch-weighted);
+            the guided-filter tag also times its statistics kernel and gets both."""
+            if not pmc_sec:
+                return None
+            names = [tag.split(" (")[0]] + (["gf_guide_stats_kernel"] if "gf_guide_stats_kernel" in tag else [])
+            total = 0.0
+            for nm in names:
+                hits = [v for k, v in pmc_sec.items() if not k.startswith("_") and (k == nm or k.startswith(nm + "<"))]
+                if not hits:
+                    return None
+                total += sum(h["traffic_bytes"] * h["launches_fetch_pass"] for h in hits) / sum(h["launches_fetch_pass"] for h in hits)
+            return int(total)
+
+        def add_traffic(blk):
+            mem = members.get(blk["kernel"], [blk["kernel"]])
+            vals = [(pmc_lookup(k), per_kernel[k][0]) for k in mem if k in per_kernel]
+            blk["traffic"] = int(sum(v * n_ for v, n_ in vals) / sum(n_ for _, n_ in vals)) if vals and all(v is not None for v, _ in vals) else None
+            for kk in blk.get("kernels", []):
+                kk["traffic"] = pmc_lookup(kk["kernel"])
+            return blk
+
+        add_traffic(roof)
+        roof["traffic_source"] = ("profiles/pmc_traffic.json[%s]: rocprofv3 --pmc passes of this same command run by the builder "
+                                  "(tools/pmc_run.sh + tools/pmc_traffic.py); PMC counters cannot be read inside an un-profiled run" % wkey)
         if traffic_note:
             roof["traffic_note"] = traffic_note
-        others = [roof_block(k) for k in sorted(summ, key=lambda k: -summ[k][1]) if k != DOM][:4]
+        others = [add_traffic(roof_block(k)) for k in sorted(summ, key=lambda k: -summ[k][1]) if k != DOM][:4]
         res = {
             "metric": "fused image-pairs/sec at 480x640 bs=%d per GPU (%s)" % (bpg, {"fusion": "fusion-net forward", "fusion_seg": "fusion + SegFormer forward", "pgd": "PGD-10 adversarial eval", "train": "adversarial-training step"}[args.workload]),
             "value": pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -403,11 +424,13 @@ def host_cores():
 
 
 def kernel_source_sha16():
-    """Identity of the dominant kernel's source (the dense-conv file + the shared header): ties a PMC record to a build."""
+    """Identity of the kernel sources (every file under paif_amd/csrc): ties a PMC section to a build."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("paif_amd/csrc/conv_mfma.hip", "paif_amd/csrc/paif_common.h"):
-        h.update(open(os.path.join(ROOT, f), "rb").read())
+    csrc = os.path.join(ROOT, "paif_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith(".hip") or f.endswith(".h"):
+            h.update(open(os.path.join(csrc, f), "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -96,7 +96,18 @@ def main():
     loss_b, grad_b, early, launched = backward(red, d_ir2, d_vis2)
     ops.GRAD_READY[0] = None
     milestones = len(red.module_params)
+    # global_minmax=True (SURVEY 8(e) optional mode): the glue's batch-global min/max goes through a 2-float all-reduce(MIN) on the
+    # device; over a 1-rank group it must reproduce the plain forward bit for bit (and the oracle's batch-global semantics, which
+    # tests/test_seg_gpu.py pins for the plain forward)
+    net.eval()
+    with torch.no_grad():
+        f_plain, s_plain = net(ir, vis)
+        net.global_minmax = True
+        f_glob, s_glob = net(ir, vis)
+        net.global_minmax = False
+    gm_equal = bool(torch.equal(f_plain, f_glob) and torch.equal(s_plain, s_glob))
     out = {
+        "global_minmax_equals_plain_forward": gm_equal,
         "backend": dist.get_backend(), "world": dist.get_world_size(), "device": torch.cuda.get_device_name(0),
         "buckets": len(red.buckets), "bucket_floats": [e - s for s, e in red.buckets],
         "marks_during_attack": marks_during_attack, "launched_during_attack": launched_during_attack,

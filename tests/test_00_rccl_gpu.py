@@ -44,3 +44,4 @@ def test_bucketed_allreduce_on_a_one_rank_rccl_group():
     assert o["launched_before_backward_returned"] >= 1, o             # overlap: buckets leave while the reverse pass is still running
     assert o["delta_equal"] and o["loss_a"] == o["loss_b"], o
     assert o["grad_max_abs_diff"] == 0.0, o                           # AVG over one rank: bit-identical gradients
+    assert o["global_minmax_equals_plain_forward"], o                 # the 2-float MIN all-reduce of the optional global_minmax mode
