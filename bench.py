@@ -67,7 +67,7 @@ def main():
                     help="pgd / train: arithmetic INSIDE the attack loop.  exact (default, the product default) = fp32-exact conv / GEMM / attention "
                          "kernels: the only arithmetic that keeps the PGD-10 trajectory on the reference's (SURVEY 8(a) A1; tests/"
                          "test_parity_default_gpu.py); fast = the split-bf16 kernels there too (trajectory diverges: sign mismatch 2.5e-2 by iteration 10)")
-    ap.add_argument("--storage", choices=["f32", "bf16"], default="bf16",
+    ap.add_argument("--storage", choices=["f32", "bf16", "bf16_split"], default="bf16",
                     help="activation storage of the fusion network's inference forward (fusion / fusion_seg workloads): f32 = every map fp32 "
                          "(parity at the fp32 tolerance); bf16 (default) = what BASELINE configs[1] names: the 32-channel maps behind the guided-filter "
                          "block held as bf16, fp32 accumulate (tolerance: SURVEY 8(d) bf16 clause, tests/test_bf16_storage_gpu.py).  The line "
@@ -226,17 +226,20 @@ def main():
     # sustained pass: the K timed steps above last ~0.15 s on the headline workload -- a burst right after an
     # idle period, the most favourable thermal / power state.  The same step is then looped for >= --sustain-seconds (default 3 s)
     # and reported as `sustained_value`; `value` stays the contract's K-step figure.
-    other_storage = None
+    other_storage = []
     if args.workload in ("fusion", "fusion_seg") and not args.graph:
-        ops.set_storage("bf16" if args.storage == "f32" else "f32")
-        for _ in range(2):
-            step()
-        barrier()
-        t2 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        barrier()
-        other_storage = (ops.CONFIG["storage"], max_over_ranks(time.perf_counter() - t2, dist, dev))
+        for mode in ops.STORAGE_MODES:
+            if mode == args.storage:
+                continue
+            ops.set_storage(mode)
+            for _ in range(2):
+                step()
+            barrier()
+            t2 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            barrier()
+            other_storage.append((mode, max_over_ranks(time.perf_counter() - t2, dist, dev)))
         ops.set_storage(args.storage)
     sustained = None
     if args.sustain_seconds > 0 and not args.graph:
@@ -280,12 +283,19 @@ def main():
                 # 200-390 FLOP/B) are matrix-pipe bound and are priced against the 833 TF algorithmic peak
                 # bf16-stored inputs (storage code 1, the kernels' last template argument; the family under --storage bf16): the stored
                 # operand's low half is zero, 2 bf16 MFMAs per product -> 2500/2 TF algorithmic peak
-                two = (tag.endswith(", 1>") or (tag == DOMINANT and args.storage == "bf16" and args.workload in ("fusion", "fusion_seg")))
-                peak_tf = 2500.0 / 2 if two else SPLIT_BF16_PEAK_TFLOPS
+                # storage code = the kernels' last template argument (paif_common.h): MFMAs per product 3 (fp32 maps, or an input PReLU
+                # on bf16 maps) / 2 (bf16 maps: the stored operand's low half is zero; or plain bf16 weights on fp32 maps) / 1 (bf16 maps and
+                # plain bf16 weights: --storage bf16) -> 2500/n TF algorithmic peak
+                m_ = re.search(r", (\d)>$", tag)
+                if tag == DOMINANT:
+                    nm = {"f32": 3, "bf16_split": 2, "bf16": 1}[args.storage] if args.workload in ("fusion", "fusion_seg") else 3
+                else:
+                    nm = {0: 3, 1: 2, 2: 3, 3: 3, 4: 1, 5: 2, 6: 1}[int(m_.group(1))] if m_ else 3
+                peak_tf = 2500.0 / nm
                 if fl_ / max(by_, 1) > peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9):
                     blk = {"bound": "mfma", "achieved": tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": tf / peak_tf, "algorithmic_gbs": gb,
                            "hbm_frac": gb / HBM_PEAK_GBS,
-                           "note": "split-bf16: %d bf16 MFMAs per product -> 2500/%d TF algorithmic peak" % ((2, 2) if two else (3, 3))}
+                           "note": "%d bf16 MFMA%s per product -> 2500/%d TF algorithmic peak" % (nm, "" if nm == 1 else "s", nm)}
                 else:
                     blk = {"bound": "hbm", "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS, "algorithmic_tflops": tf}
             elif tag.startswith("gf_"):
@@ -363,7 +373,8 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32" if args.conv_precision == "f32" else
                       ("f32 (storage and accumulation f32; conv products as split-bf16: 3x bf16 MFMA)" if args.storage == "f32" or args.workload in ("pgd", "train")
-                       else "bf16 storage / f32 accumulate (conv products as split-bf16 MFMA; stems and guided filter fp32)"))
+                       else ("bf16 (maps and conv weights bf16, one bf16 MFMA per product, f32 accumulate; stems and guided filter fp32)" if args.storage == "bf16"
+                             else "bf16 storage / f32 accumulate (conv weights split-bf16 hi + lo: 2 MFMAs per product; stems and guided filter fp32)")))
                      + ("" if args.workload == "fusion" else "; SegFormer GEMMs: %s" % {"f32": "exact fp32 MFMA", "bf16x3": "split-bf16",
                                                                                       "auto": "exact fp32 MFMA, split-bf16 where K >= 256"}[args.gemm_precision]
                         + "; attention products: %s" % ("exact fp32 MFMA" if args.gemm_precision == "f32" else "split-bf16")
@@ -381,7 +392,7 @@ def main():
                                    + ", 480x640, bs=%d/GPU, %s, conv precision %s" % (
                                        bpg, "fp32 storage" if args.storage == "f32" or args.workload in ("pgd", "train") else
                                        "bf16 storage of the 32-channel maps behind the guided-filter block (fp32 stems / guided filter / accumulation)",
-                                       args.conv_precision),
+                                       args.conv_precision if args.storage != "bf16" or args.workload in ("pgd", "train") else "bf16 (bf16 weights, 1 MFMA per product)"),
                        "batch_per_gpu": bpg,
                        "parallelism": ("dp%d: batch sharded, weights replicated, 179.5 MB fp32 gradient all-reduce (25 MB buckets) per step" % world
                                        if args.workload == "train" else "replicas x%d (no data-path collective)" % world)},
@@ -395,9 +406,11 @@ def main():
             res["steps_per_s"] = args.steps / dt
             if state.get("events"):
                 res["allreduce_exposed_ms_per_step"] = sum(a.elapsed_time(b) for a, b in state["events"][-args.steps:]) / args.steps
-        if other_storage is not None:
-            res["other_storage"] = {"storage": other_storage[0], "value": pairs / other_storage[1], "ms_per_step": other_storage[1] / args.steps * 1e3,
-                                    "note": "the same K steps with the other activation storage (ops.set_storage), run right after the timed region"}
+        if other_storage:
+            res["other_storage"] = [{"storage": m_, "value": pairs / t_, "ms_per_step": t_ / args.steps * 1e3} for m_, t_ in other_storage]
+            res["other_storage_note"] = ("the same K steps in the other storage modes (ops.set_storage), run right after the timed region: f32 = fp32 maps, "
+                                         "split-bf16 products (3 MFMAs, fp32-level parity); bf16_split = bf16 maps, split-bf16 weights (2 MFMAs); "
+                                         "bf16 = bf16 maps and weights, one bf16 MFMA per product (BASELINE configs[1])")
         if sustained is not None:
             res["sustained_value"] = bpg * world * sustained[0] / sustained[1]
             res["sustained"] = {"steps": sustained[0], "seconds": sustained[1], "ms_per_step": sustained[1] / sustained[0] * 1e3,

@@ -119,8 +119,9 @@ typedef struct {
   float* out;            /* NHWC [B,H,W,cout] */
   int cout;              /* 32 or 16 */
   float* pool_partial;   /* optional */
-  int precision;         /* PAIF_CONV_F32 (exact fp32 MFMA) or PAIF_CONV_BF16X3 (split-bf16, ~1e-5 rel.);
-                            wpk must have been packed for the same precision */
+  int precision;         /* PAIF_CONV_F32 (exact fp32 MFMA), PAIF_CONV_BF16X3 (split-bf16, ~1e-5 rel.) or PAIF_CONV_BF16 (plain bf16
+                            MFMA, fp32 accumulate: bf16-stored maps only, weights rounded to bf16 = the hi half of the BF16X3 pack);
+                            wpk must have been packed for the same precision (BF16 takes the BF16X3 pack) */
   /* ---- backward-pass support (all optional / zero for a plain forward) ---- */
   float* aux_out;        /* forward: also store the pre-activation z = conv*scale+shift (saved for dgrad) */
   const float* in_aux;   /* dgrad staging, in_act 3/4: the saved pre-activation of the layer being back-propagated */
@@ -141,6 +142,7 @@ typedef struct {
 /* in_act: 0 none, 1 PReLU, 2 ReLU, 3 src*in_alpha*in_scale[c]*(in_aux>=0?1:*in_prelu), 4 ...*(in_aux>0), 5 src*in_alpha*in_scale[c] */
 #define PAIF_CONV_F32 0
 #define PAIF_CONV_BF16X3 1
+#define PAIF_CONV_BF16 2        /* storage != PAIF_ST_F32 only: one bf16 MFMA per product (BASELINE configs[1] "bf16") */
 
 /* ---- bf16-stored activation maps (PAIF_ST_BF16; BASELINE configs[1] "...bf16..."): the elementwise kernels of the fusion
  * network's inference forward on bf16 32-channel maps (bf16 data behind the float* of x / out / ir / vis / agg / o / r / a / b),

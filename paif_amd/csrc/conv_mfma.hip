@@ -60,6 +60,7 @@ struct ConvArgs {
   int B, H, W, tilesX, tilesY, nblk;
   int reverse;             // 1: tiles are walked from the end of each XCD range (serpentine order across consecutive layers)
   int st;                  // activation storage (paif_common.h): 0 fp32/fp32, 1 bf16/bf16, 2 fp32 in / bf16 out
+  int wl0;                 // 1: plain bf16 weights (PAIF_CONV_BF16): the kernels' storage codes 4 / 5 / 6
 };
 
 // Transform applied to a staged float4 (channels 4q..4q+3 of one pixel):
@@ -496,7 +497,8 @@ __global__ __launch_bounds__(NTHREADS, (HOOKS || KH >= 5 || DIL == 2) ? 2 : PAIF
     uint4 bw[BRING][NKS * 2];
     auto fetch = [&](int tap, int slot) {
 #pragma unroll
-      for (int i = 0; i < NKS * 2; ++i) bw[slot][i] = wsrc[(tap * NKS * 2 + i) * 64];
+      for (int i = 0; i < NKS * 2; ++i)
+        if (!(paif::st_wl0(ST) && (i & 1))) bw[slot][i] = wsrc[(tap * NKS * 2 + i) * 64];
     };
     // A operand of one K=16 step (hi and lo halves of this wave's two row segments), double-buffered in registers: the
     // reads of step i+1 are issued before the MFMAs of step i and pinned there with sched_barrier.  Left to itself the
@@ -519,8 +521,10 @@ __global__ __launch_bounds__(NTHREADS, (HOOKS || KH >= 5 || DIL == 2) ? 2 : PAIF
 #pragma unroll
         for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.l[sg], bh, acc[sg], 0, 0, 0);
       }
+      if constexpr (!paif::st_wl0(ST)) {
 #pragma unroll
       for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h[sg], bl, acc[sg], 0, 0, 0);
+      }
 #pragma unroll
       for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h[sg], bh, acc[sg], 0, 0, 0);
     };
@@ -797,7 +801,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bf16x3_ms(ConvArgs a) {
   auto fetchB = [&](int g) {
 #pragma unroll
     for (int i = 0; i < NKS * 2; ++i)
-      bw[g % D][i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.wpk) + (size_t)(g * NKS * 2 + i) * 1024 + lane16);
+      if (!(paif::st_wl0(ST) && (i & 1)))
+        bw[g % D][i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.wpk) + (size_t)(g * NKS * 2 + i) * 1024 + lane16);
   };
   // A operand of one K=16 step: hi and lo halves of this wave's two row segments.  The reads of step i+1 are issued
   // before the MFMAs of step i and pinned there (sched_barrier): left to itself the scheduler sinks every ds_read to
@@ -821,8 +826,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bf16x3_ms(ConvArgs a) {
 #pragma unroll
       for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.l[sg], bh, acc[sg], 0, 0, 0);
     }
+    if constexpr (!paif::st_wl0(ST)) {
 #pragma unroll
     for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h[sg], bl, acc[sg], 0, 0, 0);
+    }
 #pragma unroll
     for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h[sg], bh, acc[sg], 0, 0, 0);
   };
@@ -1034,7 +1041,7 @@ __global__ __launch_bounds__(RT * 64, RT == 4 ? 2 : 1) void conv_bf16x3_res(Conv
   auto fetchB = [&](int s, int tap) {
 #pragma unroll
     for (int i = 0; i < NKS * 2; ++i)
-      bw[tap][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16, ((s * NTAP + tap) * NKS * 2 + i) * 1024, 0);
+      if (!(paif::st_wl0(ST) && (i & 1))) bw[tap][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16, ((s * NTAP + tap) * NKS * 2 + i) * 1024, 0);
   };
   struct AStep { bf16x8 h, l; };
   constexpr int NSTEP = NTAP * NKS;
@@ -1059,7 +1066,9 @@ __global__ __launch_bounds__(RT * 64, RT == 4 ? 2 : 1) void conv_bf16x3_res(Conv
       const bf16x8 bh = __builtin_bit_cast(bf16x8, bw[tap][2 * ks]);
       const bf16x8 bl = __builtin_bit_cast(bf16x8, bw[tap][2 * ks + 1]);
       if constexpr (!paif::st_lo0(ST)) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[step % 3].l, bh, acc[0], 0, 0, 0);
+      if constexpr (!paif::st_wl0(ST)) {
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[step % 3].h, bl, acc[0], 0, 0, 0);
+      }
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[step % 3].h, bh, acc[0], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       if (NSRC > 1 && ks == NKS - 1) fetchB((s + 1) % NSRC, tap);    // this tap's registers: next source, same tap
@@ -1335,7 +1344,8 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_bf16x3_ws(ConvArgs a, int 
 #pragma unroll
     for (int t = 0; t < BR; ++t)
 #pragma unroll
-      for (int j = 0; j < NKS * 2; ++j) bw[t][j] = wbase[(t * NKS * 2 + j) * 64];
+      for (int j = 0; j < NKS * 2; ++j)
+        if (!(paif::st_wl0(ST) && (j & 1))) bw[t][j] = wbase[(t * NKS * 2 + j) * 64];
     int s = 0;
     for (int g = 0; g <= S + 1; ++g) {
       const bool work = g >= 1 && g <= S;
@@ -1366,7 +1376,9 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_bf16x3_ws(ConvArgs a, int 
                 const bf16x8 al = *reinterpret_cast<const bf16x8*>(buf + abase[sg] + toff + 64 + 32 * ks);
                 acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[sg], 0, 0, 0);
               }
+              if constexpr (!paif::st_wl0(ST)) {
               acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[sg], 0, 0, 0);
+              }
               acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[sg], 0, 0, 0);
             }
           }
@@ -1374,7 +1386,8 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_bf16x3_ws(ConvArgs a, int 
             const int nt = tap + BR;
             const uint4* wsrc = nt < NTAP ? wcur + (size_t)nt * NKS * 2 * 64 : wnxt + (size_t)(nt - NTAP) * NKS * 2 * 64;
 #pragma unroll
-            for (int j = 0; j < NKS * 2; ++j) bw[tap % BR][j] = wsrc[j * 64];
+            for (int j = 0; j < NKS * 2; ++j)
+              if (!(paif::st_wl0(ST) && (j & 1))) bw[tap % BR][j] = wsrc[j * 64];
           }
         }
       }
@@ -1565,13 +1578,27 @@ int launch_bf16x3_st(const ConvArgs& a, hipStream_t st) {
 
 // bf16 storage is built for the kernel shapes of the inference forward (1x1, 3x3 dil 1 / 2, 7x7); fp32 in / bf16 out only for
 // the 1x1 behind the fp32 guided-filter block
+// kernel storage code (template argument ST, paif_common.h) of a launch
+static inline int kernel_st(const ConvArgs& a) {
+  const int base = a.st == 1 ? (a.in_act == 1 ? 3 : 1) : a.st;
+  return (a.wl0 && base) ? base + 3 : base;
+}
+
 template <int KH, int DIL>
 int launch_bf16x3(const ConvArgs& a, hipStream_t st) {
-  if (a.st == 0) return launch_bf16x3_st<KH, DIL, 0>(a, st);
+  const int code = kernel_st(a);
+  if (code == 0) return launch_bf16x3_st<KH, DIL, 0>(a, st);
   if constexpr ((KH == 1 || KH == 3 || KH == 7) && (DIL == 1 || (KH == 3 && DIL == 2))) {
-    if (a.st == 1) return a.in_act == 1 ? launch_bf16x3_st<KH, DIL, 3>(a, st) : launch_bf16x3_st<KH, DIL, 1>(a, st);
+    switch (code) {
+      case 1: return launch_bf16x3_st<KH, DIL, 1>(a, st);
+      case 3: return launch_bf16x3_st<KH, DIL, 3>(a, st);
+      case 4: return launch_bf16x3_st<KH, DIL, 4>(a, st);
+      case 6: return launch_bf16x3_st<KH, DIL, 6>(a, st);
+      default: break;
+    }
     if constexpr (KH == 1) {
-      if (a.st == 2) return launch_bf16x3_st<KH, DIL, 2>(a, st);
+      if (code == 2) return launch_bf16x3_st<KH, DIL, 2>(a, st);
+      if (code == 5) return launch_bf16x3_st<KH, DIL, 5>(a, st);
     }
   }
   paif::set_error("conv2d: storage %d is not built for the %dx%d dilation-%d kernel", a.st, KH, KH, DIL);
@@ -1692,7 +1719,7 @@ int paif_conv2d_blocks(int B, int H, int W) { return B * ((H + TH - 1) / TH) * (
 size_t paif_conv_wpk_floats(int nsrc, int cin, int kh) { return (size_t)nsrc * kh * kh * (cin / 8) * 256; }
 
 int paif_conv2d_is_persistent(const paif_conv_desc* d, int B, int H, int W) {
-  if (!d || d->precision != PAIF_CONV_BF16X3 || d->cin != 32 || B <= 0 || H <= 0 || W <= 0) return 0;
+  if (!d || (d->precision != PAIF_CONV_BF16X3 && d->precision != PAIF_CONV_BF16) || d->cin != 32 || B <= 0 || H <= 0 || W <= 0) return 0;
   ConvArgs a{};
   for (int s = 0; s < 3; ++s) a.res[s] = d->res[s];
   a.pool_partial = d->pool_partial; a.nsrc = d->nsrc; a.in_act = d->in_act; a.cout = d->cout;
@@ -1710,7 +1737,9 @@ int paif_conv2d_kernel_name(const paif_conv_desc* d, int B, int H, int W, char* 
   a.aux_out = d->aux_out; a.epi_dact = d->epi_dact;
   a.B = B; a.H = H; a.W = W;
   a.nblk = B * ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
-  if (d->precision != PAIF_CONV_BF16X3) {
+  a.st = d->storage; a.wl0 = d->precision == PAIF_CONV_BF16 ? 1 : 0;
+  const int code = kernel_st(a);
+  if (d->precision != PAIF_CONV_BF16X3 && d->precision != PAIF_CONV_BF16) {
     snprintf(buf, buflen, "conv_mfma_f32<%d, %d, %d, %s>", d->kh, d->dil, d->cin, needs_hooks(a) ? "true" : "false");
     return 0;
   }
@@ -1720,11 +1749,11 @@ int paif_conv2d_kernel_name(const paif_conv_desc* d, int B, int H, int W, char* 
   }
   // the names rocprofv3 prints: every template argument, the storage code last
   switch (bf16x3_variant(a, d->kh, d->dil)) {
-    case CV_WS: snprintf(buf, buflen, "conv_bf16x3_ws<%d, %d, %d>", d->kh, d->dil, d->storage); break;
-    case CV_RES: snprintf(buf, buflen, "conv_bf16x3_res<%d, %d, %d, %d, %d>", d->kh, d->dil, d->nsrc, PAIF_RES_ROWS, d->storage); break;
-    case CV_MS: snprintf(buf, buflen, "conv_bf16x3_ms<%d, %d, %d, %d>", d->kh, d->dil, d->nsrc, d->storage); break;
-    case CV_HOOKS: snprintf(buf, buflen, "conv_mfma_bf16x3<%d, %d, true, %d>", d->kh, d->dil, d->storage); break;
-    default: snprintf(buf, buflen, "conv_mfma_bf16x3<%d, %d, false, %d>", d->kh, d->dil, d->storage); break;
+    case CV_WS: snprintf(buf, buflen, "conv_bf16x3_ws<%d, %d, %d>", d->kh, d->dil, code); break;
+    case CV_RES: snprintf(buf, buflen, "conv_bf16x3_res<%d, %d, %d, %d, %d>", d->kh, d->dil, d->nsrc, PAIF_RES_ROWS, code); break;
+    case CV_MS: snprintf(buf, buflen, "conv_bf16x3_ms<%d, %d, %d, %d>", d->kh, d->dil, d->nsrc, code); break;
+    case CV_HOOKS: snprintf(buf, buflen, "conv_mfma_bf16x3<%d, %d, true, %d>", d->kh, d->dil, code); break;
+    default: snprintf(buf, buflen, "conv_mfma_bf16x3<%d, %d, false, %d>", d->kh, d->dil, code); break;
   }
   return 0;
 }
@@ -1758,13 +1787,17 @@ int paif_conv2d_fwd(const paif_conv_desc* d, int B, int H, int W, paif_stream_t 
   a.tilesX = (W + TW - 1) / TW; a.tilesY = (H + TH - 1) / TH; a.nblk = B * a.tilesX * a.tilesY;
   a.reverse = d->reverse_tiles ? 1 : 0;
   a.st = d->storage;
+  a.wl0 = d->precision == PAIF_CONV_BF16 ? 1 : 0;
   PAIF_REQUIRE(d->storage >= 0 && d->storage <= 2, PAIF_EINVAL, "conv2d: storage=%d", d->storage);
-  PAIF_REQUIRE(d->storage == 0 || (d->precision == PAIF_CONV_BF16X3 && d->cin == 32), PAIF_ENOSUP, "conv2d: bf16 storage needs the split-bf16 kernels (cin 32)");
+  PAIF_REQUIRE(d->storage == 0 || ((d->precision == PAIF_CONV_BF16X3 || d->precision == PAIF_CONV_BF16) && d->cin == 32), PAIF_ENOSUP,
+               "conv2d: bf16 storage needs the split-bf16 kernels (cin 32)");
+  PAIF_REQUIRE(d->precision != PAIF_CONV_BF16 || d->storage != 0, PAIF_ENOSUP, "conv2d: precision bf16 is built for bf16-stored maps only");
   hipStream_t st = paif::as_stream(stream);
   PAIF_REQUIRE(d->cin == 32 || d->cin == 16, PAIF_ENOSUP, "conv2d: cin=%d", d->cin);
-  PAIF_REQUIRE(d->precision == PAIF_CONV_F32 || d->precision == PAIF_CONV_BF16X3, PAIF_EINVAL, "conv2d: precision=%d", d->precision);
+  PAIF_REQUIRE(d->precision == PAIF_CONV_F32 || d->precision == PAIF_CONV_BF16X3 || d->precision == PAIF_CONV_BF16, PAIF_EINVAL,
+               "conv2d: precision=%d", d->precision);
   const int key = d->kh * 100 + d->dil * 10 + (d->cin == 32 ? 0 : 1);
-  if (d->precision == PAIF_CONV_BF16X3) {
+  if (d->precision == PAIF_CONV_BF16X3 || d->precision == PAIF_CONV_BF16) {
     switch (key) {
       case 110: return launch_bf16x3<1, 1>(a, st);
       case 310: return launch_bf16x3<3, 1>(a, st);

@@ -77,12 +77,17 @@ __device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + __ex
 // 2 = fp32 in / bf16 out (the first layer behind the fp32 guided-filter block).  Pointers stay typed `float*` in the
 // argument structs; the helpers address `eoff` ELEMENTS from the base in the storage's element size.
 // ---------------------------------------------------------------------------------------------
-constexpr int st_in(int ST) { return (ST == 1 || ST == 3) ? 1 : 0; }
+// Kernel storage codes (template argument ST): 0 fp32 in / out | 1 bf16 in / out | 2 fp32 in, bf16 out | 3 (internal) bf16 in / out
+// behind an input PReLU.  +3 (4, 5, 6): the same with the WEIGHTS taken as plain bf16 (their split-bf16 low half dropped:
+// precision PAIF_CONV_BF16, the plain bf16 MFMA of BASELINE configs[1]).
+constexpr int st_base(int ST) { return ST >= 4 ? ST - 3 : ST; }
+constexpr int st_in(int ST) { return (st_base(ST) == 1 || st_base(ST) == 3) ? 1 : 0; }
 constexpr int st_out(int ST) { return ST >= 1 ? 1 : 0; }
-// ST 1: the staged A operand IS the stored bf16 value (no input activation, or ReLU), so its split-bf16 low half is exactly
-// zero: the kernels drop the lo x W_hi MFMA (2 of 3 MFMAs) and the low half's LDS traffic.  ST 3 (internal): bf16 in / out with
-// an input PReLU, whose result is not a bf16 value -- the full split is kept.
-constexpr bool st_lo0(int ST) { return ST == 1; }
+constexpr bool st_wl0(int ST) { return ST >= 4; }
+// ST 1 / 4: the staged A operand IS the stored bf16 value (no input activation, or ReLU), so its split-bf16 low half is exactly
+// zero: the kernels drop the lo x W_hi MFMA and the low half's LDS traffic.  ST 3: bf16 in / out with an input PReLU, whose result
+// is not a bf16 value -- the full split is kept; ST 6 (plain bf16 arithmetic) rounds that result to bf16 (nearest-even) instead.
+constexpr bool st_lo0(int ST) { return ST == 1 || ST == 4 || ST == 6; }
 
 __device__ __forceinline__ float4 bf16x4_to_f32(uint2 u) {
   return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),

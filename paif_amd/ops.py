@@ -13,6 +13,7 @@ boundary: an NHWC tensor viewed as [B,C,H,W] is exactly torch's channels_last fo
 is kept without copies between our own ops.
 """
 import ctypes
+import os
 
 import torch
 
@@ -51,9 +52,16 @@ CONFIG = {"conv_precision": "bf16x3", "gemm_precision": "auto", "serpentine": Tr
 _ACT_BF16 = [False]    # True while an inference forward of the fusion network runs in bf16 storage (set by the model)
 
 
+STORAGE_MODES = ("f32", "bf16", "bf16_split")
+
+
 def set_storage(mode):
-    if mode not in ("f32", "bf16"):
-        raise ValueError("storage must be 'f32' or 'bf16'")
+    """Activation storage of the fusion network's inference forward.
+    "f32":        fp32 maps, split-bf16 products (3 bf16 MFMAs, fp32-level parity) -- the API default.
+    "bf16":       BASELINE configs[1]: bf16 maps AND bf16 weights, one bf16 MFMA per product, fp32 accumulate (PAIF_CONV_BF16).
+    "bf16_split": bf16 maps, weights kept as split-bf16 hi + lo (2 MFMAs per product: only the maps are rounded)."""
+    if mode not in STORAGE_MODES:
+        raise ValueError("storage must be one of %s" % (STORAGE_MODES,))
     CONFIG["storage"] = mode
 
 
@@ -65,12 +73,13 @@ class bf16_activations:
 
     def __enter__(self):
         self.old = _ACT_BF16[0]
-        _ACT_BF16[0] = self.enable and CONFIG["storage"] == "bf16" and CONFIG["conv_precision"] == "bf16x3"
+        _ACT_BF16[0] = self.enable and CONFIG["storage"] in ("bf16", "bf16_split") and CONFIG["conv_precision"] == "bf16x3"
 
     def __exit__(self, *a):
         _ACT_BF16[0] = self.old
 _SERP = [0]    # tile-direction parity of the next dense-conv launch
 _PREC_CODE = {"f32": 0, "bf16x3": 1}
+PREC_BF16 = 2          # include/paif_hip.h PAIF_CONV_BF16 (conv descriptors with bf16-stored maps only)
 
 
 def set_gemm_precision(mode):
@@ -478,6 +487,8 @@ def conv2d(srcs, wpk, kh, dil=1, cin=32, cout=32, in_act=ACT_NONE, in_prelu=None
         assert tuple(r.shape) == (B, H, W, cout)
     d.nsrc, d.cin, d.wpk, d.kh, d.dil = len(srcs), cin, _p(wpk.data), kh, dil
     d.precision = _PREC_CODE[wpk.precision]
+    if storage and wpk.precision == "bf16x3" and CONFIG["storage"] == "bf16":
+        d.precision = PREC_BF16            # plain bf16 weights: the hi half of the split-bf16 pack
     d.in_act, d.in_prelu = in_act, _p(in_prelu)
     d.scale, d.shift = _p(scale), _p(shift)
     d.act, d.prelu, d.alpha = act, _p(prelu), alpha

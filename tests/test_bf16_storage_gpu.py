@@ -55,7 +55,10 @@ def test_cast_round_trip_is_round_to_nearest_even():
     (7, 1, 1, 0, 0, 32, False),      # 7x7 (tile-per-workgroup kernel, dynamic LDS > 64 KB)
     (3, 1, 1, 0, 0, 16, False),      # 32 -> 16 (stem_out.0)
 ])
-def test_dense_conv_bf16_storage_matches_fp32_storage(kh, dil, nsrc, nres, act, cout, in_f32):
+@pytest.mark.parametrize("mode", ["bf16_split", "bf16"])
+def test_dense_conv_bf16_storage_matches_fp32_storage(kh, dil, nsrc, nres, act, cout, in_f32, mode):
+    """mode bf16_split: bf16 maps, split-bf16 weights (storage codes 1 / 2); mode bf16: plain bf16 weights too (codes 4 / 5, one MFMA
+    per product) -- on bf16-representable weights its products are exact as well, so the same bound holds."""
     B, H, W = 2, 333, 517            # ragged, > 2048 tiles of 4 x 32 and > 1024 of 8 x 32: every persistent form is eligible
     g = torch.Generator().manual_seed(kh * 100 + dil * 10 + nsrc + 7 * nres)
     dev = _dev()
@@ -68,13 +71,15 @@ def test_dense_conv_bf16_storage_matches_fp32_storage(kh, dil, nsrc, nres, act, 
         a, b = _rounded(ops.to_nhwc(torch.randn(B, cout, H, W, generator=g).to(dev)))
         rs32.append(a); rsb.append(b)
     w = (torch.randn(cout, 32 * nsrc, kh, kh, generator=g) * 0.05).to(dev)
+    if mode == "bf16":
+        w = w.to(torch.bfloat16).float()
     scale, shift = (torch.rand(32, generator=g) + 0.5).to(dev), (torch.randn(32, generator=g) * 0.1).to(dev)
     slope = torch.tensor([0.2], device=dev)
     wpk = ops.pack_conv_weight(w, nsrc, 32, kh, precision="bf16x3")
     kw = dict(scale=scale, shift=shift, act=act, prelu=slope if act == 1 else None, alpha=0.5, cout=cout)
     ref = ops.conv2d(xs32, wpk, kh, dil=dil, res=tuple(rs32), **kw)
+    ops.set_storage(mode)
     if in_f32:
-        ops.set_storage("bf16")
         with ops.bf16_activations():
             out = ops.conv2d(xs32, wpk, kh, dil=dil, res=tuple(rsb), **kw)
     else:
@@ -84,6 +89,33 @@ def test_dense_conv_bf16_storage_matches_fp32_storage(kh, dil, nsrc, nres, act, 
     tol = BF_EPS * ref.abs() * 1.01 + 1e-30
     assert bool((err <= tol).all()), (float(err.max()), float((err / ref.abs().clamp_min(1e-6)).max()))
     assert torch.equal(out, ref.to(torch.bfloat16)) or float((out != ref.to(torch.bfloat16)).float().mean()) < 1e-3
+
+
+@pytest.mark.parametrize("mode", ["bf16_split", "bf16"])
+@pytest.mark.parametrize("kh", [1, 3])
+def test_dense_conv_bf16_storage_input_prelu(kh, mode):
+    """Input PReLU on a bf16-stored source (RDB conv1 of the second chain, DilConv's 1x1).  bf16_split (storage code 3): the PReLU result
+    keeps its full split -> the fp32-storage kernel's result up to the output rounding.  bf16 (code 6): the PReLU result is rounded to
+    bf16 (nearest-even) like every other operand -> equal, to the same bound, to the fp32 kernel fed that rounded map."""
+    B, H, W = 2, 141, 203
+    g = torch.Generator().manual_seed(17 + kh)
+    dev = _dev()
+    x32, xb = _rounded(ops.to_nhwc(torch.randn(B, 32, H, W, generator=g).to(dev)))
+    w = (torch.randn(32, 32, kh, kh, generator=g) * 0.05).to(dev)
+    if mode == "bf16":
+        w = w.to(torch.bfloat16).float()
+    slope = torch.tensor([0.2], device=dev)
+    wpk = ops.pack_conv_weight(w, 1, 32, kh, precision="bf16x3")
+    if mode == "bf16":
+        xin = torch.where(x32 >= 0, x32, x32 * slope).to(torch.bfloat16).float()
+        ref = ops.conv2d([xin], wpk, kh)
+    else:
+        ref = ops.conv2d([x32], wpk, kh, in_act=ops.ACT_PRELU, in_prelu=slope)
+    ops.set_storage(mode)
+    out = ops.conv2d([xb], wpk, kh, in_act=ops.ACT_PRELU, in_prelu=slope)
+    assert out.dtype == torch.bfloat16
+    err = (out.float() - ref).abs()
+    assert bool((err <= BF_EPS * ref.abs() * 1.01 + 1e-6).all()), float(err.max())
 
 
 def test_elementwise_kernels_bf16_storage():
@@ -142,7 +174,7 @@ def test_fusion_forward_bf16_storage_tolerance_clause(golden):
     ir, vis, lab = S.make_batch(1, 480, 640)
     irt, vist, labt = t(ir).to(dev), t(vis).to(dev), t(lab).to(dev)
     res = {}
-    for mode in ("f32", "bf16"):
+    for mode in ops.STORAGE_MODES:
         ops.set_storage(mode)
         with torch.no_grad():
             fused, seg = m(irt, vist)
@@ -150,21 +182,23 @@ def test_fusion_forward_bf16_storage_tolerance_clause(golden):
         pred = meter.update(seg, labt)
         res[mode] = dict(fused=fused.cpu(), seg=seg.cpu(), pred=pred.cpu(), miou=float(np.mean(np.nan_to_num(compute_results(meter.conf.cpu().numpy())[2]))))
     ops.set_storage("f32")
-    d64 = (res["bf16"]["fused"].double() - t(g["fused64"]).double()).abs()
     d32 = (res["f32"]["fused"].double() - t(g["fused64"]).double()).abs()
-    agree_ref = float((res["bf16"]["pred"].numpy() == g["pred"]).mean())
-    agree_f32 = float((res["bf16"]["pred"] == res["f32"]["pred"]).float().mean())
-    report = dict(fused_max_abs_vs_fp64=float(d64.max()), fused_mean_abs_vs_fp64=float(d64.mean()), fp32_storage_max_abs_vs_fp64=float(d32.max()),
-                  argmax_agreement_vs_reference=agree_ref, argmax_agreement_vs_fp32_storage=agree_f32,
-                  miou_bf16=res["bf16"]["miou"], miou_f32=res["f32"]["miou"],
-                  logits_max_abs=float((res["bf16"]["seg"] - res["f32"]["seg"]).abs().max()), logit_range=float(res["f32"]["seg"].abs().max()))
+    report = dict(fp32_storage_max_abs_vs_fp64=float(d32.max()), miou_f32=res["f32"]["miou"], logit_range=float(res["f32"]["seg"].abs().max()))
+    for mode in ("bf16", "bf16_split"):     # bf16: maps + weights (the benchmarked configuration); bf16_split: maps only
+        d64 = (res[mode]["fused"].double() - t(g["fused64"]).double()).abs()
+        report[mode] = dict(fused_max_abs_vs_fp64=float(d64.max()), fused_mean_abs_vs_fp64=float(d64.mean()),
+                            argmax_agreement_vs_reference=float((res[mode]["pred"].numpy() == g["pred"]).mean()),
+                            argmax_agreement_vs_fp32_storage=float((res[mode]["pred"] == res["f32"]["pred"]).float().mean()),
+                            miou=res[mode]["miou"], logits_max_abs=float((res[mode]["seg"] - res["f32"]["seg"]).abs().max()))
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out_dir):
         json.dump(report, open(os.path.join(out_dir, "bf16_storage_report.json"), "w"), indent=1)
     print("bf16 storage:", report)
-    assert agree_ref >= 0.999 and agree_f32 >= 0.999, report
-    assert abs(res["bf16"]["miou"] - res["f32"]["miou"]) <= 1e-3, report
-    assert report["fused_max_abs_vs_fp64"] <= 3e-2 and report["fused_mean_abs_vs_fp64"] <= 3e-3, report     # measured: see profiles/
+    for mode in ("bf16", "bf16_split"):
+        r = report[mode]
+        assert r["argmax_agreement_vs_reference"] >= 0.999 and r["argmax_agreement_vs_fp32_storage"] >= 0.999, report
+        assert abs(r["miou"] - report["miou_f32"]) <= 1e-3, report
+        assert r["fused_max_abs_vs_fp64"] <= 3e-2 and r["fused_mean_abs_vs_fp64"] <= 3e-3, report     # measured: see profiles/
 
 
 def test_bf16_storage_is_inference_only():

@@ -28,6 +28,6 @@ python3 bench.py --graph --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r0
 for f in fusion fusion_seg pgd pgd_fast train fusion_graph; do python3 -c "
 import json,sys
 try:
-    d=json.loads(open('gpurun_out/r03_bench_$f.json').read().strip().splitlines()[-1]); print('$f', round(d['value'],2), round(d['ms_per_step'],3), d.get('other_storage',{}).get('value'), d.get('cpu_baseline',{}).get('value'), d['roofline'].get('frac'), d['roofline'].get('traffic'))
+    d=json.loads(open('gpurun_out/r03_bench_$f.json').read().strip().splitlines()[-1]); print('$f', round(d['value'],2), round(d['ms_per_step'],3), [o["value"] for o in d.get("other_storage",[])], d.get('cpu_baseline',{}).get('value'), d['roofline'].get('frac'), d['roofline'].get('traffic'))
 except Exception as e: print('$f', 'ERR', e)
 "; done
