@@ -258,6 +258,8 @@ def main():
 
         def family(tag):
             # the dense 3x3 dilation-1 forward convs are one kernel family (instantiations by source count / pool)
+            if tag.startswith("conv3x3_bf16_dma<"):      # the LDS-DMA form (bf16 maps + bf16 weights)
+                return DOMINANT
             m = re.match(r"conv_(mfma_bf16x3|bf16x3_ms|bf16x3_res|mfma_f32)<3, 1\b(.*)>$", tag)
             if m and "true" not in m.group(2) and not (m.group(1) == "mfma_f32" and ", 16," in tag):
                 return DOMINANT
@@ -277,7 +279,7 @@ def main():
         def roof_block(tag):
             n_, ms_, fl_, by_ = summ[tag]
             tf, gb = fl_ / (ms_ * 1e-3) / 1e12, by_ / (ms_ * 1e-3) / 1e9
-            if (tag.startswith("conv_") or tag.startswith("dense conv")) and "bf16x3" in tag:
+            if (tag.startswith("conv_") or tag.startswith("dense conv") or tag.startswith("conv3x3_bf16_dma")) and ("bf16x3" in tag or "bf16_dma" in tag):
                 # split-bf16 convs: 3 bf16 MFMA passes -> effective matrix peak 2500/3 = 833 TF algorithmic; at 72-108 FLOP/B
                 # (fp32 storage, k <= 3) the HBM roof binds (833e12 / 8e12 = 104 FLOP/B); the 5x5 / 7x7 convs (K = 800 / 1568:
                 # 200-390 FLOP/B) are matrix-pipe bound and are priced against the 833 TF algorithmic peak
@@ -290,7 +292,7 @@ def main():
                 if tag == DOMINANT:
                     nm = {"f32": 3, "bf16_split": 2, "bf16": 1}[args.storage] if args.workload in ("fusion", "fusion_seg") else 3
                 else:
-                    nm = {0: 3, 1: 2, 2: 3, 3: 3, 4: 1, 5: 2, 6: 1}[int(m_.group(1))] if m_ else 3
+                    nm = 1 if "bf16_dma" in tag else ({0: 3, 1: 2, 2: 3, 3: 3, 4: 1, 5: 2, 6: 1}[int(m_.group(1))] if m_ else 3)
                 peak_tf = 2500.0 / nm
                 if fl_ / max(by_, 1) > peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9):
                     blk = {"bound": "mfma", "achieved": tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": tf / peak_tf, "algorithmic_gbs": gb,

@@ -1,0 +1,24 @@
+// Interface between the dense-conv dispatcher (conv_mfma.hip) and the LDS-DMA 3x3 kernel (conv_dma.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace paif_conv_dma {
+
+struct Args {
+  const void* src[3];   // NHWC-32 bf16 maps (the virtual concat)
+  const void* res[3];   // NHWC-32 bf16 residual maps
+  const void* wpk;      // split-bf16 weight pack [src][tap][ks][hi|lo][64 lanes][8 bf16]: the hi halves are used
+  const float* scale;   // per-cout (NULL = 1)
+  const float* shift;   // per-cout (NULL = 0)
+  const float* prelu;   // 1 float (act == 1)
+  void* out;            // NHWC-32 bf16
+  float alpha;
+  int nsrc, nres, act;
+  int B, H, W, reverse;
+};
+
+// true if the kernel is built for this source / residual count and the tensors fit its 32-bit addressing
+bool eligible(int nsrc, int nres, int B, int H, int W, float alpha);
+int launch(const Args& a, hipStream_t st);
+
+}  // namespace paif_conv_dma

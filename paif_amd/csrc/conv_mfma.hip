@@ -19,6 +19,7 @@
 // core/model_fusion_auto.py conv1x1_lf/hf (:501-502), stem_out.0 (:616).
 #include <stdlib.h>
 
+#include "conv_dma.h"
 #include "paif_common.h"
 #include <type_traits>
 
@@ -1036,12 +1037,16 @@ __global__ __launch_bounds__(RT * 64, RT == 4 ? 2 : 1) void conv_bf16x3_res(Conv
     else convert_n(v, buf, std::false_type{});
   };
 
-  u32x4 bw[NTAP][NKS * 2];             // the B operand of one source
+  // the B operand of one source; with plain bf16 weights (half the registers: 72 per source) of EVERY source -- loaded once per
+  // launch, no refills behind the halo prefetch
+  constexpr int NB = paif::st_wl0(ST) ? NSRC : 1;
+  u32x4 bw[NB][NTAP][NKS * 2];
   const unsigned lane16 = (unsigned)lane * 16u;
   auto fetchB = [&](int s, int tap) {
 #pragma unroll
     for (int i = 0; i < NKS * 2; ++i)
-      if (!(paif::st_wl0(ST) && (i & 1))) bw[tap][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16, ((s * NTAP + tap) * NKS * 2 + i) * 1024, 0);
+      if (!(paif::st_wl0(ST) && (i & 1)))
+        bw[NB > 1 ? s : 0][tap][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16, ((s * NTAP + tap) * NKS * 2 + i) * 1024, 0);
   };
   struct AStep { bf16x8 h, l; };
   constexpr int NSTEP = NTAP * NKS;
@@ -1063,15 +1068,15 @@ __global__ __launch_bounds__(RT * 64, RT == 4 ? 2 : 1) void conv_bf16x3_res(Conv
       const int tap = step / NKS, ks = step - tap * NKS;
       if (step + 2 < NSTEP) readA(A[(step + 2) % 3], buf, step + 2);
       __builtin_amdgcn_sched_barrier(0);
-      const bf16x8 bh = __builtin_bit_cast(bf16x8, bw[tap][2 * ks]);
-      const bf16x8 bl = __builtin_bit_cast(bf16x8, bw[tap][2 * ks + 1]);
+      const bf16x8 bh = __builtin_bit_cast(bf16x8, bw[NB > 1 ? s : 0][tap][2 * ks]);
       if constexpr (!paif::st_lo0(ST)) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[step % 3].l, bh, acc[0], 0, 0, 0);
       if constexpr (!paif::st_wl0(ST)) {
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[step % 3].h, bl, acc[0], 0, 0, 0);
+        const bf16x8 bl = __builtin_bit_cast(bf16x8, bw[0][tap][2 * ks + 1]);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[step % 3].h, bl, acc[0], 0, 0, 0);
       }
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[step % 3].h, bh, acc[0], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (NSRC > 1 && ks == NKS - 1) fetchB((s + 1) % NSRC, tap);    // this tap's registers: next source, same tap
+      if (NSRC > 1 && NB == 1 && ks == NKS - 1) fetchB((s + 1) % NSRC, tap);    // this tap's registers: next source, same tap
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -1080,7 +1085,9 @@ __global__ __launch_bounds__(RT * 64, RT == 4 ? 2 : 1) void conv_bf16x3_res(Conv
   locate(tile, b, y0, x0);
   setup(b, y0, x0);
 #pragma unroll
-  for (int tap = 0; tap < NTAP; ++tap) fetchB(0, tap);
+  for (int s = 0; s < NB; ++s)
+#pragma unroll
+    for (int tap = 0; tap < NTAP; ++tap) fetchB(s, tap);
   {
     rawv_t v0[NIT];
     issueA(0, v0);
@@ -1517,7 +1524,11 @@ static inline bool res_eligible(const ConvArgs& a) {
     const char* e = getenv("PAIF_CONV_RES");  // PAIF_CONV_RES=0: tile-per-workgroup kernels everywhere (A/B runs)
     return !(e && e[0] == '0');
   }();
-  return on && a.nsrc == 1 && a.nblk >= 2048 && a.cout == 32 && a.in_act <= 2 && (PAIF_RES_ROWS == 8 || !a.pool_partial) &&
+  static const int ms_res = [] {
+    const char* e = getenv("PAIF_CONV_RES_NSRC");   // experiment: largest source count the resident form takes with plain bf16 weights
+    return e ? atoi(e) : 1;
+  }();
+  return on && (a.nsrc == 1 || (a.wl0 && a.st == 1 && a.in_act == 0 && a.nsrc <= ms_res)) && a.nblk >= 2048 && a.cout == 32 && a.in_act <= 2 && (PAIF_RES_ROWS == 8 || !a.pool_partial) &&
          (size_t)a.B * a.H * a.W * 128 < ((size_t)1 << 31);   // buffer resources: 32-bit byte counts and offsets
 }
 
@@ -1540,9 +1551,14 @@ static inline bool takes_ws(const ConvArgs& a, int kh, int dil) {
 }
 
 // which split-bf16 kernel a launch takes (one place: the dispatcher and paif_conv2d_kernel_name use it)
-enum ConvVariant { CV_PLAIN, CV_HOOKS, CV_WS, CV_RES, CV_MS };
+enum ConvVariant { CV_PLAIN, CV_HOOKS, CV_WS, CV_RES, CV_MS, CV_DMA };
+static inline int res_count(const ConvArgs& a) { return a.res[0] ? (a.res[1] ? (a.res[2] ? 3 : 2) : 1) : 0; }
 static inline ConvVariant bf16x3_variant(const ConvArgs& a, int kh, int dil) {
   if (needs_hooks(a)) return CV_HOOKS;
+  // bf16 maps + plain bf16 weights, 3x3 dilation 1, 32 -> 32 per source: the LDS-DMA kernel (conv_dma.hip)
+  if (kh == 3 && dil == 1 && a.st == 1 && a.wl0 && a.in_act == 0 && a.cout == 32 && !a.pool_partial &&
+      paif_conv_dma::eligible(a.nsrc, res_count(a), a.B, a.H, a.W, a.alpha))
+    return CV_DMA;
   if (takes_ws(a, kh, dil)) return CV_WS;
   if (kh == 3 && dil == 1) {
     if (res_eligible(a)) return CV_RES;
@@ -1556,6 +1572,13 @@ static inline ConvVariant bf16x3_variant(const ConvArgs& a, int kh, int dil) {
 template <int KH, int DIL, int ST>
 int launch_bf16x3_st(const ConvArgs& a, hipStream_t st) {
   switch (bf16x3_variant(a, KH, DIL)) {
+    case CV_DMA: {
+      paif_conv_dma::Args d{};
+      for (int s = 0; s < 3; ++s) { d.src[s] = a.src[s]; d.res[s] = a.res[s]; }
+      d.wpk = a.wpk; d.scale = a.scale; d.shift = a.shift; d.prelu = a.prelu; d.out = a.out; d.alpha = a.alpha;
+      d.nsrc = a.nsrc; d.nres = res_count(a); d.act = a.act; d.B = a.B; d.H = a.H; d.W = a.W; d.reverse = a.reverse;
+      return paif_conv_dma::launch(d, st);
+    }
     case CV_HOOKS:
       if constexpr (ST == 0) return launch_bf16x3_h<KH, DIL, true>(a, st);
       paif::set_error("conv2d: the gradient hooks (in_act >= 3, aux_out, epi_dact) are built for fp32 storage only");
@@ -1566,7 +1589,13 @@ int launch_bf16x3_st(const ConvArgs& a, hipStream_t st) {
 #endif
       break;
     case CV_RES:
-      if constexpr (KH == 3 && DIL == 1) return launch_bf16x3_res<3, 1, 1, ST>(a, st);
+      if constexpr (KH == 3 && DIL == 1) {
+        if constexpr (ST == 4) {
+          if (a.nsrc == 2) return launch_bf16x3_res<3, 1, 2, ST>(a, st);
+          if (a.nsrc == 3) return launch_bf16x3_res<3, 1, 3, ST>(a, st);
+        }
+        return launch_bf16x3_res<3, 1, 1, ST>(a, st);
+      }
       break;
     case CV_MS:
       if constexpr (KH == 3 && DIL == 1) return a.nsrc == 2 ? launch_bf16x3_ms<3, 1, 2, ST>(a, st) : launch_bf16x3_ms<3, 1, 3, ST>(a, st);
@@ -1737,7 +1766,7 @@ int paif_conv2d_kernel_name(const paif_conv_desc* d, int B, int H, int W, char* 
   a.aux_out = d->aux_out; a.epi_dact = d->epi_dact;
   a.B = B; a.H = H; a.W = W;
   a.nblk = B * ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
-  a.st = d->storage; a.wl0 = d->precision == PAIF_CONV_BF16 ? 1 : 0;
+  a.st = d->storage; a.wl0 = d->precision == PAIF_CONV_BF16 ? 1 : 0; a.alpha = d->alpha;
   const int code = kernel_st(a);
   if (d->precision != PAIF_CONV_BF16X3 && d->precision != PAIF_CONV_BF16) {
     snprintf(buf, buflen, "conv_mfma_f32<%d, %d, %d, %s>", d->kh, d->dil, d->cin, needs_hooks(a) ? "true" : "false");
@@ -1749,6 +1778,7 @@ int paif_conv2d_kernel_name(const paif_conv_desc* d, int B, int H, int W, char* 
   }
   // the names rocprofv3 prints: every template argument, the storage code last
   switch (bf16x3_variant(a, d->kh, d->dil)) {
+    case CV_DMA: snprintf(buf, buflen, "conv3x3_bf16_dma<%d, %d>", d->nsrc, res_count(a)); break;
     case CV_WS: snprintf(buf, buflen, "conv_bf16x3_ws<%d, %d, %d>", d->kh, d->dil, code); break;
     case CV_RES: snprintf(buf, buflen, "conv_bf16x3_res<%d, %d, %d, %d, %d>", d->kh, d->dil, d->nsrc, PAIF_RES_ROWS, code); break;
     case CV_MS: snprintf(buf, buflen, "conv_bf16x3_ms<%d, %d, %d, %d>", d->kh, d->dil, d->nsrc, code); break;
