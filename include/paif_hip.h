@@ -71,6 +71,10 @@ int paif_minmax_normalize_fwd(const float* rgb, const float* minmax_partial, int
  * device; feat NHWC [B,H,W,32]; guide [B,H,W] (may be NULL). */
 int paif_stem_fwd(const float* img, size_t img_bstride, const float* w, const float* prelu, float* feat, float* guide,
                   int B, int H, int W, paif_stream_t stream);
+/* Same, and the map once more as bf16 (feat_bf16: [B,H,W,32] `unsigned short` data, round-to-nearest-even): in the bf16 storage mode
+ * the fp32 map feeds the fp32 guided-filter block, its bf16 twin the residual inputs of the bf16-stored layers. */
+int paif_stem_fwd_twin(const float* img, size_t img_bstride, const float* w, const float* prelu, float* feat, float* feat_bf16,
+                       float* guide, int B, int H, int W, paif_stream_t stream);
 /* Cell_Decom.get_residue on an existing NHWC [B,H,W,32] map (:517-521): guide = max_c - min_c. */
 int paif_channel_residue_fwd(const float* x, float* guide, int B, int H, int W, paif_stream_t stream);
 

@@ -37,6 +37,7 @@ SIGNATURES = {
     "paif_fused_uint8_fwd": (c_int, [F, F, c_int, F, c_int, c_int, c_int, F]),
     "paif_minmax_normalize_fwd": (c_int, [F, F, c_int, F, F, c_int, c_int, c_int, F]),
     "paif_stem_fwd": (c_int, [F, c_size_t, F, F, F, F, c_int, c_int, c_int, F]),
+    "paif_stem_fwd_twin": (c_int, [F, c_size_t, F, F, F, F, F, c_int, c_int, c_int, F]),
     "paif_channel_residue_fwd": (c_int, [F, F, c_int, c_int, c_int, F]),
     "paif_guided_filter_ab_fwd": (c_int, [F, F, F, c_float, c_float, c_int, c_int, c_int, F]),
     "paif_guided_filter_lf_fwd": (c_int, [F, F, F, c_int, c_int, c_int, F]),

@@ -74,7 +74,7 @@ constexpr int STEM_CHUNK = 128;
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                    const float* __restrict__ prelu, float* __restrict__ feat,
                                                    float* __restrict__ guide, int B, int H, int W,
-                                                   size_t img_bstride, int chunks) {
+                                                   size_t img_bstride, int chunks, unsigned short* __restrict__ feat16) {
   const int q = threadIdx.x & 7;
   float wr[4][9];
 #pragma unroll
@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
   const float* r2 = base + (size_t)min(y + 1, H - 1) * W;
   const bool top = y == 0, bot = y == H - 1;
   float* frow = feat + (size_t)row * W * 32;
+  unsigned short* frow16 = feat16 ? feat16 + (size_t)row * W * 32 : nullptr;   // optional bf16 twin of the map (bf16 storage mode)
   float* grow = guide ? guide + (size_t)row * W : nullptr;
 #pragma unroll
   for (int it = 0; it < STEM_CHUNK / 32; ++it) {
@@ -115,6 +116,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
       o[c] = paif::prelu_f(s, slope);
     }
     if (x < W) paif::store_nt(frow + (size_t)x * 32 + q * 4, make_float4(o[0], o[1], o[2], o[3]));
+    if (frow16 && x < W) *reinterpret_cast<uint2*>(frow16 + (size_t)x * 32 + q * 4) = paif::f32_to_bf16x4(make_float4(o[0], o[1], o[2], o[3]));
     if (grow) {
       float mx = fmaxf(fmaxf(o[0], o[1]), fmaxf(o[2], o[3]));
       float mn = fminf(fminf(o[0], o[1]), fminf(o[2], o[3]));
@@ -183,6 +185,57 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
       }
     }
     paif::stq_nt<BF>(out, pix * 32 + q * 4, acc);
+  }
+}
+
+// bf16-stored maps, 3x3: a lane owns 8 channels (16 bytes) of one pixel -- every tap is one 16-byte load, a wave's load covers 16
+// consecutive pixels (1 KB contiguous): half the load instructions per pixel of the 4-channel form (165 -> see profiles/).
+template <int DIL>
+__global__ __launch_bounds__(256) void dwconv3_bf16_kernel(const unsigned short* __restrict__ x, const float* __restrict__ w,
+                                                           unsigned short* __restrict__ out, int in_relu, int B, int H, int W) {
+  const int q = threadIdx.x & 3;
+  float wr[8][9];
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wr[c][k] = w[(8 * q + c) * 9 + k];
+  const size_t npix = (size_t)B * H * W;
+  for (size_t pix = (size_t)blockIdx.x * 64 + (threadIdx.x >> 2); pix < npix; pix += (size_t)gridDim.x * 64) {
+    const int xx0 = (int)(pix % W);
+    const size_t rowid = pix / W;
+    const int yy0 = (int)(rowid % H);
+    const size_t base = (rowid - yy0) * W * 32 + q * 8;
+    uint4 v[9];          // unconditional loads on clamped coordinates, padding by select (see dwconv_kernel)
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int yy = min(max(yy0 + (dy - 1) * DIL, 0), H - 1), xx = min(max(xx0 + (dx - 1) * DIL, 0), W - 1);
+        v[dy * 3 + dx] = *reinterpret_cast<const uint4*>(x + base + ((size_t)yy * W + xx) * 32);
+      }
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int yy = yy0 + (dy - 1) * DIL, xx = xx0 + (dx - 1) * DIL;
+        const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const int k = dy * 3 + dx;
+        const unsigned u[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float lo = __uint_as_float(u[e] << 16), hi = __uint_as_float(u[e] & 0xffff0000u);
+          if (in_relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+          if (!ok) lo = hi = 0.f;
+          acc[2 * e] = fmaf(lo, wr[2 * e][k], acc[2 * e]);
+          acc[2 * e + 1] = fmaf(hi, wr[2 * e + 1][k], acc[2 * e + 1]);
+        }
+      }
+    const uint2 o0 = paif::f32_to_bf16x4(make_float4(acc[0], acc[1], acc[2], acc[3]));
+    const uint2 o1 = paif::f32_to_bf16x4(make_float4(acc[4], acc[5], acc[6], acc[7]));
+    typedef unsigned u32x4_nt __attribute__((ext_vector_type(4)));
+    const u32x4_nt ov = {o0.x, o0.y, o1.x, o1.y};
+    __builtin_nontemporal_store(ov, reinterpret_cast<u32x4_nt*>(out + pix * 32 + q * 8));
   }
 }
 
@@ -538,16 +591,27 @@ int paif_ycrcb2rgb_fwd(const float* ycc, float* rgb, int B, int H, int W, paif_s
   return 0;
 }
 
-int paif_stem_fwd(const float* img, size_t img_bstride, const float* w, const float* prelu, float* feat, float* guide,
-                  int B, int H, int W, paif_stream_t stream) {
+static int stem_launch(const float* img, size_t img_bstride, const float* w, const float* prelu, float* feat, float* guide,
+                       unsigned short* feat16, int B, int H, int W, paif_stream_t stream) {
   PAIF_REQUIRE(img && w && prelu && feat && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "stem: bad arguments");
   PAIF_REQUIRE(img_bstride >= (size_t)H * W, PAIF_EINVAL, "stem: batch stride %zu < H*W", img_bstride);
   const int chunks = (W + STEM_CHUNK - 1) / STEM_CHUNK;
   PAIF_REQUIRE((size_t)B * H * chunks < ((size_t)1 << 31), PAIF_EINVAL, "stem: %dx%dx%d is too large for one launch", B, H, W);
   hipLaunchKernelGGL(stem_kernel, dim3((unsigned)(B * H * chunks)), dim3(256), 0, paif::as_stream(stream), img, w,
-                     prelu, feat, guide, B, H, W, img_bstride, chunks);
+                     prelu, feat, guide, B, H, W, img_bstride, chunks, feat16);
   PAIF_LAUNCH_CHECK("stem");
   return 0;
+}
+
+int paif_stem_fwd(const float* img, size_t img_bstride, const float* w, const float* prelu, float* feat, float* guide,
+                  int B, int H, int W, paif_stream_t stream) {
+  return stem_launch(img, img_bstride, w, prelu, feat, guide, nullptr, B, H, W, stream);
+}
+
+int paif_stem_fwd_twin(const float* img, size_t img_bstride, const float* w, const float* prelu, float* feat, float* feat_bf16,
+                       float* guide, int B, int H, int W, paif_stream_t stream) {
+  PAIF_REQUIRE(feat_bf16, PAIF_EINVAL, "stem_twin: null bf16 map");
+  return stem_launch(img, img_bstride, w, prelu, feat, guide, reinterpret_cast<unsigned short*>(feat_bf16), B, H, W, stream);
 }
 
 int paif_dwconv_fwd(const float* x, const float* w, float* out, int k, int dil, int in_relu, int B, int H, int W,
@@ -640,9 +704,12 @@ int paif_dwconv_fwd_bf16(const float* x, const float* w, float* out, int k, int 
   PAIF_REQUIRE(x && w && out && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "dwconv(bf16): bad arguments");
   const dim3 g(grid_for((size_t)B * H * W, 32)), blk(256);
   hipStream_t st = paif::as_stream(stream);
+  const dim3 g8(grid_for((size_t)B * H * W, 64));
+  const unsigned short* x16 = reinterpret_cast<const unsigned short*>(x);
+  unsigned short* o16 = reinterpret_cast<unsigned short*>(out);
   switch (k * 10 + dil) {
-    case 31: hipLaunchKernelGGL((dwconv_kernel<3, 1, 1>), g, blk, 0, st, x, w, out, in_relu, B, H, W); break;
-    case 32: hipLaunchKernelGGL((dwconv_kernel<3, 2, 1>), g, blk, 0, st, x, w, out, in_relu, B, H, W); break;
+    case 31: hipLaunchKernelGGL((dwconv3_bf16_kernel<1>), g8, blk, 0, st, x16, w, o16, in_relu, B, H, W); break;
+    case 32: hipLaunchKernelGGL((dwconv3_bf16_kernel<2>), g8, blk, 0, st, x16, w, o16, in_relu, B, H, W); break;
     case 51: hipLaunchKernelGGL((dwconv_kernel<5, 1, 1>), g, blk, 0, st, x, w, out, in_relu, B, H, W); break;
     default:
       paif::set_error("dwconv(bf16): kernel %d dil %d not built", k, dil);

@@ -77,6 +77,11 @@ class bf16_activations:
 
     def __exit__(self, *a):
         _ACT_BF16[0] = self.old
+        if not self.old:
+            _TWINS.clear()
+
+
+_TWINS = {}    # data_ptr of an fp32 map -> (the map, its bf16 twin written by the producing kernel); lives for one bf16 forward
 _SERP = [0]    # tile-direction parity of the next dense-conv launch
 _PREC_CODE = {"f32": 0, "bf16x3": 1}
 PREC_BF16 = 2          # include/paif_hip.h PAIF_CONV_BF16 (conv descriptors with bf16-stored maps only)
@@ -245,6 +250,10 @@ def cast_storage(x, to_bf16):
     want = torch.bfloat16 if to_bf16 else torch.float32
     if x.dtype == want:
         return x
+    if to_bf16:
+        tw = _TWINS.get(x.data_ptr())
+        if tw is not None and tw[0] is x:     # the producer already wrote this map's bf16 twin
+            return tw[1]
     assert x.numel() % 4 == 0
     out = torch.empty(x.shape, device=x.device, dtype=want)
     _lib.check(lib().paif_cast_storage_fwd(_pa(x.contiguous()), _pa(out), x.numel(), int(to_bf16), _stream()), "cast_storage")
@@ -367,6 +376,12 @@ def stem(img, w, prelu, want_guide=True):
     guide = torch.empty((B, H, W), device=img.device, dtype=torch.float32) if want_guide else None
     if img.dtype != torch.float32 or not img.is_cuda:
         raise RuntimeError("stem: need a float32 CUDA tensor")
+    if _ACT_BF16[0]:     # bf16 storage: the bf16 twin of the map, for the layers that take it as a residual input (cast_storage finds it)
+        twin = torch.empty((B, H, W, 32), device=img.device, dtype=torch.bfloat16)
+        _lib.check(lib().paif_stem_fwd_twin(ctypes.c_void_p(img.data_ptr()), bstride, _p(w), _p(prelu), _p(feat), _pa(twin), _p(guide),
+                                            B, H, W, _stream()), "stem")
+        _TWINS[feat.data_ptr()] = (feat, twin)
+        return feat, guide
     _lib.check(lib().paif_stem_fwd(ctypes.c_void_p(img.data_ptr()), bstride, _p(w), _p(prelu), _p(feat), _p(guide),
                                    B, H, W, _stream()), "stem")
     return feat, guide
