@@ -292,15 +292,25 @@ __global__ __launch_bounds__(256) void spa_blend_kernel(const float* __restrict_
     const int y0 = (int)(rowid % H);
     const float* cbase = comp + (rowid - y0) * W * 4;
     // 25 taps split over the 8 lanes of the pixel: lane q takes taps q, q+8, q+16, (q+24)
+    // Loads are unconditional on clamped coordinates (all four in flight; a load under a branch is waited for at the join) and
+    // padding / the missing 4th tap of lanes 1..7 are selects: a masked tap adds fma(0, w, s) = s, the sum is unchanged bit for bit
     float s = 0.f;
-    for (int tap = q; tap < 25; tap += 8) {
+    float4 cv[4];
+    bool ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int tap = min(q + 8 * i, 24);
       const int dy = tap / 5, dx = tap - dy * 5;
       const int yy = y0 + dy - 2, xx = x0 + dx - 2;
-      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-        const float4 c = *reinterpret_cast<const float4*>(cbase + ((size_t)yy * W + xx) * 4);
-        s = fmaf(c.x, ws[tap], s); s = fmaf(c.y, ws[25 + tap], s);
-        s = fmaf(c.z, ws[50 + tap], s); s = fmaf(c.w, ws[75 + tap], s);
-      }
+      ok[i] = q + 8 * i < 25 && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      cv[i] = *reinterpret_cast<const float4*>(cbase + ((size_t)min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)) * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int tap = min(q + 8 * i, 24);
+      const float4 c = ok[i] ? cv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      s = fmaf(c.x, ws[tap], s); s = fmaf(c.y, ws[25 + tap], s);
+      s = fmaf(c.z, ws[50 + tap], s); s = fmaf(c.w, ws[75 + tap], s);
     }
 #pragma unroll
     for (int m = 1; m < 8; m <<= 1) s += __shfl_xor(s, m);

@@ -16,7 +16,7 @@ for i, ln in enumerate(L):
     if s.endswith(':') and s.startswith('_Z'):
         fn = s; pend = []
     if not s or s.startswith(';') or s.startswith('.'): continue
-    if s.startswith('ds_read_b128'):
+    if s.startswith('ds_read_b128') or s.startswith('ds_read_b32') or s.startswith('ds_read_b64'):
         d = regs(s.split(',')[0])
         pend.append(d[0]); continue
     if 's_waitcnt' in s and 'lgkmcnt' in s:
