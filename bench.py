@@ -189,8 +189,8 @@ def main():
     # HIP events around every dense-conv / GEMM / attention launch of the timed region (on the launch stream)
     timer = ops.KernelTimer(lambda tag: True)
     if args.graph:
-        if args.workload not in ("fusion", "fusion_seg"):
-            raise SystemExit("--graph: only the inference workloads are captured")
+        if args.workload not in ("fusion", "fusion_seg", "pgd"):
+            raise SystemExit("--graph: the inference workloads and the PGD evaluation are captured (the training step is not)")
         gstream = torch.cuda.Stream()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.stream(gstream):
