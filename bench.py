@@ -279,7 +279,7 @@ def main():
         def roof_block(tag):
             n_, ms_, fl_, by_ = summ[tag]
             tf, gb = fl_ / (ms_ * 1e-3) / 1e12, by_ / (ms_ * 1e-3) / 1e9
-            if (tag.startswith("conv_") or tag.startswith("dense conv") or tag.startswith("conv3x3_bf16_dma")) and ("bf16x3" in tag or "bf16_dma" in tag):
+            if (tag.startswith("conv_") or tag.startswith("dense conv") or tag.startswith("conv3x3_bf16_dma") or tag.startswith("conv7x7_bf16_dma")) and ("bf16x3" in tag or "bf16_dma" in tag):
                 # split-bf16 convs: 3 bf16 MFMA passes -> effective matrix peak 2500/3 = 833 TF algorithmic; at 72-108 FLOP/B
                 # (fp32 storage, k <= 3) the HBM roof binds (833e12 / 8e12 = 104 FLOP/B); the 5x5 / 7x7 convs (K = 800 / 1568:
                 # 200-390 FLOP/B) are matrix-pipe bound and are priced against the 833 TF algorithmic peak

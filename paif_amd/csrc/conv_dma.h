@@ -13,12 +13,13 @@ struct Args {
   const float* prelu;   // 1 float (act == 1)
   void* out;            // NHWC-32 bf16
   float alpha;
-  int nsrc, nres, act;
+  int nsrc, nres, act, kh;   // kh: 3 or 7
   int B, H, W, reverse;
 };
 
 // true if the kernel is built for this source / residual count and the tensors fit its 32-bit addressing
 bool eligible(int nsrc, int nres, int B, int H, int W, float alpha);
+bool eligible7(int nsrc, int nres, int B, int H, int W, float alpha);   // the 7x7 form: one source, no residual maps
 int launch(const Args& a, hipStream_t st);
 
 }  // namespace paif_conv_dma

@@ -405,6 +405,269 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_dma(Args a, int ntiles, i
   CD_VMWAIT(0);          // no LDS-DMA may land after the workgroup's LDS is released
 }
 
+// ---------------------------------------------------------------------------------------------------
+// 7 x 7, one source, no residual maps (ResidualModule / ECA k = 7 of the searched cell).  The register-staged kernel is bound by its
+// WEIGHT traffic: 98 KB of B operand per wave and tile from L2 (the 32 KB L1 cannot hold it): 14.7 MB per CU and launch at 64 B/clk
+// = 110 us of the 268 it takes -- and by one A fragment per MFMA (LDS cycles = MFMA cycles).  Here, same architecture as the 3 x 3:
+//   * the weights never move again: k-step 0 of all 49 taps in registers (196), k-step 1 in LDS (49 KB, loaded once per launch);
+//   * a wave's 2 output rows read 8 input rows per (horizontal tap, k-step) and each fragment feeds up to 7 vertical taps:
+//     8 (+7 B) ds_read_b128 per 14 MFMAs;
+//   * a stage (= a tile: 196 MFMAs per wave, 3 us) is long enough for a 2-slot ring (one tile ahead).
+// ---------------------------------------------------------------------------------------------------
+namespace k7 {
+constexpr int P = 3;
+constexpr int TWH = TW + 2 * P, THH = TH + 2 * P;   // 38 x 14 halo
+constexpr int NPIX = TWH * THH;                     // 532 pixels x 64 B
+constexpr int DPW = 9;                              // 4 x 9 x 1 KB = 36 KB >= 34,048 B
+constexpr int SLOT = 4 * DPW * 1024;
+constexpr int NSLOT = 2;
+constexpr int ROWB = TWH * 64;
+constexpr int WB_OFF = NSLOT * SLOT;                // k-step 1 of the weights: [49 taps][64 lanes][16 B]
+constexpr int WB_BYTES = 49 * 1024;
+constexpr int PARK_OFF = WB_OFF + WB_BYTES;
+constexpr int LDS_BYTES = PARK_OFF + 4 * PARK_WAVE;
+static_assert(LDS_BYTES <= 160 * 1024, "7x7: ring + weights + transposition buffers exceed LDS");
+static_assert(4 * DPW * 64 >= NPIX * 4, "7x7: DMA instructions do not cover the halo tile");
+}  // namespace k7
+
+#define CD_WR128(addr, val, off) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(val), "n"(off) : "memory")
+
+__global__ __launch_bounds__(256, 1) void conv7x7_bf16_dma(Args a, int ntiles, int tilesX, int tilesY) {
+  constexpr int P = k7::P, TWH = k7::TWH, NPIX = k7::NPIX, DPW = k7::DPW, SLOT = k7::SLOT, ROWB = k7::ROWB, WB_OFF = k7::WB_OFF,
+                PARK_OFF = k7::PARK_OFF;   // shadow the 3x3 kernel's file-scope constants
+  __shared__ __attribute__((aligned(16))) unsigned char smem[k7::LDS_BYTES];
+  asm volatile("" ::"v"((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem) : "memory");   // only asm touches it
+
+  const int tid = threadIdx.x, l = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = l & 31, hh = l >> 5;
+  const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, nwg = gridDim.x >> 3;
+  const int tpx = (ntiles + 7) >> 3;
+  const int t_beg = xcd * tpx, t_end = min(ntiles, t_beg + tpx);
+  const int cnt = t_beg + wg < t_end ? (t_end - t_beg - wg + nwg - 1) / nwg : 0;
+  if (cnt == 0) return;
+  const int H = a.H, W = a.W;
+  auto pack_tile = [&](int k) -> unsigned {
+    const int pos = wg + min(k, cnt - 1) * nwg;
+    int t = a.reverse ? t_end - 1 - pos : t_beg + pos;
+    const int tx = t % tilesX;
+    t /= tilesX;
+    const int ty = t % tilesY;
+    return ((unsigned)(t / tilesY) << 22) | ((unsigned)ty << 11) | (unsigned)tx;
+  };
+  const unsigned tab0 = pack_tile(l), tab1 = pack_tile(l + 64);
+  auto tile_of = [&](int k, int& b, int& y0, int& x0) -> bool {
+    const bool ok = k >= 0 && k < cnt;
+    const int kk = ok ? k : 0;
+    const unsigned lo = __builtin_amdgcn_readlane(tab0, kk & 63), hi = __builtin_amdgcn_readlane(tab1, kk & 63);
+    const unsigned pk = kk < 64 ? lo : hi;
+    b = pk >> 22; y0 = ((pk >> 11) & 2047) * TH; x0 = (pk & 2047) * TW;
+    return ok;
+  };
+  const int map_bytes = a.B * H * W * 64;
+  const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.src[0]), 0, map_bytes, RSRC_W3);
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, map_bytes, RSRC_W3);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wpk), 0, 49 * 2 * 2 * 1024, RSRC_W3);
+
+  // ---- weights: k-step 0 -> registers, k-step 1 -> LDS (thread t moves 16-byte pieces t, t + 256, ... of the 49 KB) ----
+  u32x4 bw0[49];
+#pragma unroll
+  for (int tap = 0; tap < 49; ++tap) bw0[tap] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)l * 16u, ((tap * 2 + 0) * 2) * 1024, 0);
+#pragma unroll 1
+  for (int i = tid; i < 49 * 64; i += 256) {
+    const int tap = i >> 6, ln = i & 63;
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)ln * 16u, ((tap * 2 + 1) * 2) * 1024, 0);
+    const unsigned dst = WB_OFF + (unsigned)i * 16u;
+    CD_WR128(dst, v, 0);
+  }
+  float esc[8], esh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = 8 * (l & 3) + j;
+    esc[j] = (a.scale ? a.scale[c] : 1.f) * a.alpha;
+    esh[j] = (a.shift ? a.shift[c] : 0.f) * a.alpha;
+  }
+  const float e_slope = a.act == 1 ? *a.prelu : (a.act == 2 ? 0.f : 1.f);
+
+  int d_rel[DPW], d_rc[DPW];
+#pragma unroll
+  for (int i = 0; i < DPW; ++i) {
+    const int n = (w * DPW + i) * 64 + l;
+    const int pi = n >> 2;
+    const int r = pi / TWH, c = pi - r * TWH;
+    d_rel[i] = (r * W + c) * 64 + (((n & 3) ^ ((c >> 2) & 3)) * 16);
+    d_rc[i] = pi < NPIX ? (r | (c << 8)) : -1;
+  }
+  unsigned d_voff[DPW];
+  auto target = [&](int k) {
+    int b, y0, x0;
+    const bool ok = tile_of(k, b, y0, x0);
+    const int org = ((b * H + y0 - P) * W + x0 - P) * 64;
+#pragma unroll
+    for (int i = 0; i < DPW; ++i) {
+      const int gy = y0 - P + (d_rc[i] & 0xff), gx = x0 - P + (d_rc[i] >> 8);
+      const bool in = ok && d_rc[i] >= 0 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      d_voff[i] = in ? (unsigned)(org + d_rel[i]) : OOB;
+    }
+  };
+  unsigned a_rd[7][2];
+#pragma unroll
+  for (int dx = 0; dx < 7; ++dx)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int c = p + dx;
+      a_rd[dx][ks] = (unsigned)(2 * w * ROWB + c * 64 + (((2 * ks + hh) ^ ((c >> 2) & 3)) * 16));
+    }
+  const unsigned a_wb = WB_OFF + (unsigned)l * 16u;                                  // + tap * 1024
+  const unsigned a_pw = PARK_OFF + w * PARK_WAVE + (4 * hh * 32 + p) * 4;
+  const unsigned a_pr = PARK_OFF + w * PARK_WAVE + (l >> 2) * 128 + (l & 3) * 32;
+  const unsigned e_lane = (unsigned)l * 16u;
+
+  f32x16 acc[2];
+  u32x4 t[4][2];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) t[it][0] = t[it][1] = u32x4{0, 0, 0, 0};
+  float ev[8];
+  auto epi = [&](auto mtag, bool pok, int pb, int py0, int px0) {
+    constexpr int M = decltype(mtag)::value;
+    constexpr int it = M / 9, j = M % 9;
+    if constexpr (j < 8) {
+      const unsigned raw = j < 4 ? t[it][0][j & 3] : t[it][1][j & 3];
+      float v = __builtin_fmaf(__uint_as_float(raw), esc[j], esh[j]);
+      ev[j] = __builtin_fmaf(e_slope, fminf(v, 0.f), fmaxf(v, 0.f));
+    } else {
+      const uint2 o0 = paif::f32_to_bf16x4(make_float4(ev[0], ev[1], ev[2], ev[3]));
+      const uint2 o1 = paif::f32_to_bf16x4(make_float4(ev[4], ev[5], ev[6], ev[7]));
+      const int y = py0 + 2 * w + (it >> 1), x = px0 + (it & 1) * 16 + (l >> 2);
+      const unsigned soff = (unsigned)(((pb * H + y) * W + px0 + (it & 1) * 16) * 64);
+      u32x4 od = {o0.x, o0.y, o1.x, o1.y};
+      __builtin_amdgcn_raw_buffer_store_b128(od, rs_out, (pok && y < H && x < W) ? e_lane : OOB, soff, 2);
+      asm volatile("s_nop 2" : "+v"(od));
+    }
+  };
+
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this thread's share of the LDS-resident weights is written
+  target(0);
+#pragma unroll
+  for (int i = 0; i < DPW; ++i) dma16(rs_src, d_voff[i], (unsigned)((w * DPW + i) * 1024));   // tile 0 -> slot 0
+  int cur = 0;
+  for (int k = 0; k < cnt; ++k) {
+    const unsigned sb = (unsigned)cur * SLOT;
+    CD_VMWAIT(0);                                        // tile k has landed (PF = 1: no younger load may be outstanding)
+    asm volatile("s_barrier" ::: "memory");              // ... everybody's share too; slot cur ^ 1 is free; the LDS weights are in
+    unsigned ad[7][2];
+#pragma unroll
+    for (int dx = 0; dx < 7; ++dx)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) ad[dx][ks] = a_rd[dx][ks] + sb;
+    u32x4 A[2][8], BL[7];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      CD_RD128(t[it][0], a_pr, it * 2048);
+      CD_RD128(t[it][1], a_pr, it * 2048 + 16);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) CD_RD128(A[0][r], ad[0][0], r * ROWB);
+    target(k + 1);
+#pragma unroll
+    for (int i = 0; i < DPW; ++i) dma16(rs_src, d_voff[i], (unsigned)((cur ^ 1) * SLOT + (w * DPW + i) * 1024));
+    int pb, py0, px0;
+    const bool pok = tile_of(k - 1, pb, py0, px0);
+    auto mma = [&](auto gitag, auto dytag, auto jtag) {
+      constexpr int gi = decltype(gitag)::value, dy = decltype(dytag)::value, j = decltype(jtag)::value;
+      constexpr int dx = gi >> 1, ks = gi & 1;
+      const bf16x8 av = __builtin_bit_cast(bf16x8, A[gi & 1][j + dy]);
+      const bf16x8 bv = ks == 0 ? __builtin_bit_cast(bf16x8, bw0[dy * 7 + dx]) : __builtin_bit_cast(bf16x8, BL[dy]);
+      if constexpr (gi == 0 && dy == 0) {
+        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, z, 0, 0, 0);
+      } else {
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[j], 0, 0, 0);
+      }
+      constexpr int m = gi * 14 + dy * 2 + j;
+      if constexpr (m < 36) epi(std::integral_constant<int, m>{}, pok, pb, py0, px0);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto group = [&](auto gitag) {
+      constexpr int gi = decltype(gitag)::value;
+      if constexpr (gi + 1 < 14) {                         // the next group's operands: 8 A fragments (+ 7 B fragments of k-step 1)
+        constexpr int dx1 = (gi + 1) >> 1, ks1 = (gi + 1) & 1;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) CD_RD128(A[(gi + 1) & 1][r], ad[dx1][ks1], r * ROWB);
+        if constexpr (ks1 == 1) {
+#pragma unroll
+          for (int dy = 0; dy < 7; ++dy) CD_RD128(BL[dy], a_wb, (dy * 7 + dx1) * 1024);
+        }
+      }
+      // wait for THIS group's operands: everything but what was just issued (LDS operations complete in order)
+      if constexpr (gi == 0) {
+        asm volatile("s_waitcnt lgkmcnt(15)"
+                     : "+v"(A[0][0]), "+v"(A[0][1]), "+v"(A[0][2]), "+v"(A[0][3]), "+v"(A[0][4]), "+v"(A[0][5]), "+v"(A[0][6]), "+v"(A[0][7]),
+                       "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[1][0]), "+v"(t[1][1]), "+v"(t[2][0]), "+v"(t[2][1]), "+v"(t[3][0])::"memory");
+        asm volatile("" : "+v"(t[3][1])::"memory");        // (an asm statement takes 30 operands at most)
+      } else if constexpr (gi + 1 >= 14) {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(A[1][0]), "+v"(A[1][1]), "+v"(A[1][2]), "+v"(A[1][3]), "+v"(A[1][4]), "+v"(A[1][5]), "+v"(A[1][6]), "+v"(A[1][7]),
+                       "+v"(BL[0]), "+v"(BL[1]), "+v"(BL[2]), "+v"(BL[3]), "+v"(BL[4]), "+v"(BL[5]), "+v"(BL[6])::"memory");
+      } else if constexpr ((gi & 1) == 1) {               // k-step 1: A[1] and BL, 8 reads (the next k-step-0 group) stay outstanding
+        asm volatile("s_waitcnt lgkmcnt(8)"
+                     : "+v"(A[1][0]), "+v"(A[1][1]), "+v"(A[1][2]), "+v"(A[1][3]), "+v"(A[1][4]), "+v"(A[1][5]), "+v"(A[1][6]), "+v"(A[1][7]),
+                       "+v"(BL[0]), "+v"(BL[1]), "+v"(BL[2]), "+v"(BL[3]), "+v"(BL[4]), "+v"(BL[5]), "+v"(BL[6])::"memory");
+      } else {                                             // k-step 0: A[0]; the 15 reads of the next k-step-1 group stay outstanding
+        asm volatile("s_waitcnt lgkmcnt(15)"
+                     : "+v"(A[0][0]), "+v"(A[0][1]), "+v"(A[0][2]), "+v"(A[0][3]), "+v"(A[0][4]), "+v"(A[0][5]), "+v"(A[0][6]), "+v"(A[0][7])::"memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      typedef std::integral_constant<int, 0> J0;
+      typedef std::integral_constant<int, 1> J1;
+#define CD_DY(d) mma(gitag, std::integral_constant<int, d>{}, J0{}); mma(gitag, std::integral_constant<int, d>{}, J1{});
+      CD_DY(0) CD_DY(1) CD_DY(2) CD_DY(3) CD_DY(4) CD_DY(5) CD_DY(6)
+#undef CD_DY
+    };
+#define CD_G(g) group(std::integral_constant<int, g>{});
+    CD_G(0) CD_G(1) CD_G(2) CD_G(3) CD_G(4) CD_G(5) CD_G(6) CD_G(7) CD_G(8) CD_G(9) CD_G(10) CD_G(11) CD_G(12) CD_G(13)
+#undef CD_G
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = acc[j][r];
+        CD_WR32(a_pw, v, (j * 32 + (r & 3) + 8 * (r >> 2)) * 128);
+      }
+    cur ^= 1;
+  }
+  // the last tile's epilogue
+  {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      CD_RD128(t[it][0], a_pr, it * 2048);
+      CD_RD128(t[it][1], a_pr, it * 2048 + 16);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[1][0]), "+v"(t[1][1]), "+v"(t[2][0]), "+v"(t[2][1]), "+v"(t[3][0]), "+v"(t[3][1])::"memory");
+    int pb, py0, px0;
+    const bool pok = tile_of(cnt - 1, pb, py0, px0);
+#define CD_M(m) epi(std::integral_constant<int, m>{}, pok, pb, py0, px0);
+    CD_M(0) CD_M(1) CD_M(2) CD_M(3) CD_M(4) CD_M(5) CD_M(6) CD_M(7) CD_M(8) CD_M(9) CD_M(10) CD_M(11)
+    CD_M(12) CD_M(13) CD_M(14) CD_M(15) CD_M(16) CD_M(17) CD_M(18) CD_M(19) CD_M(20) CD_M(21) CD_M(22) CD_M(23)
+    CD_M(24) CD_M(25) CD_M(26) CD_M(27) CD_M(28) CD_M(29) CD_M(30) CD_M(31) CD_M(32) CD_M(33) CD_M(34) CD_M(35)
+#undef CD_M
+  }
+  CD_VMWAIT(0);
+}
+
+int launch_7(const Args& a, hipStream_t st) {
+  const int tilesX = (a.W + TW - 1) / TW, tilesY = (a.H + TH - 1) / TH;
+  hipLaunchKernelGGL(conv7x7_bf16_dma, dim3(256), dim3(256), 0, st, a, a.B * tilesX * tilesY, tilesX, tilesY);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    paif::set_error("conv2d(bf16 dma 7x7): launch failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
 template <int NSRC, int NRES>
 int launch_n(const Args& a, hipStream_t st) {
   const int tilesX = (a.W + TW - 1) / TW, tilesY = (a.H + TH - 1) / TH;
@@ -431,7 +694,10 @@ bool eligible(int nsrc, int nres, int B, int H, int W, float alpha) {
   return tiles >= 1024 && tiles <= 128 * 256 && B < 1024 && H < 2048 * TH && W < 2048 * TW && (long long)B * H * W * 64 < (1ll << 31);
 }
 
+bool eligible7(int nsrc, int nres, int B, int H, int W, float alpha) { return nsrc == 1 && nres == 0 && eligible(1, 0, B, H, W, alpha); }
+
 int launch(const Args& a, hipStream_t st) {
+  if (a.kh == 7) return launch_7(a, st);
   switch (a.nsrc * 10 + a.nres) {
     case 10: return launch_n<1, 0>(a, st);
     case 11: return launch_n<1, 1>(a, st);

@@ -1556,8 +1556,9 @@ static inline int res_count(const ConvArgs& a) { return a.res[0] ? (a.res[1] ? (
 static inline ConvVariant bf16x3_variant(const ConvArgs& a, int kh, int dil) {
   if (needs_hooks(a)) return CV_HOOKS;
   // bf16 maps + plain bf16 weights, 3x3 dilation 1, 32 -> 32 per source: the LDS-DMA kernel (conv_dma.hip)
-  if (kh == 3 && dil == 1 && a.st == 1 && a.wl0 && a.in_act == 0 && a.cout == 32 && !a.pool_partial &&
-      paif_conv_dma::eligible(a.nsrc, res_count(a), a.B, a.H, a.W, a.alpha))
+  if (dil == 1 && a.st == 1 && a.wl0 && a.in_act == 0 && a.cout == 32 && !a.pool_partial &&
+      ((kh == 3 && paif_conv_dma::eligible(a.nsrc, res_count(a), a.B, a.H, a.W, a.alpha)) ||
+       (kh == 7 && paif_conv_dma::eligible7(a.nsrc, res_count(a), a.B, a.H, a.W, a.alpha))))
     return CV_DMA;
   if (takes_ws(a, kh, dil)) return CV_WS;
   if (kh == 3 && dil == 1) {
@@ -1576,7 +1577,7 @@ int launch_bf16x3_st(const ConvArgs& a, hipStream_t st) {
       paif_conv_dma::Args d{};
       for (int s = 0; s < 3; ++s) { d.src[s] = a.src[s]; d.res[s] = a.res[s]; }
       d.wpk = a.wpk; d.scale = a.scale; d.shift = a.shift; d.prelu = a.prelu; d.out = a.out; d.alpha = a.alpha;
-      d.nsrc = a.nsrc; d.nres = res_count(a); d.act = a.act; d.B = a.B; d.H = a.H; d.W = a.W; d.reverse = a.reverse;
+      d.nsrc = a.nsrc; d.nres = res_count(a); d.act = a.act; d.B = a.B; d.H = a.H; d.W = a.W; d.reverse = a.reverse; d.kh = KH;
       return paif_conv_dma::launch(d, st);
     }
     case CV_HOOKS:
@@ -1778,7 +1779,10 @@ int paif_conv2d_kernel_name(const paif_conv_desc* d, int B, int H, int W, char* 
   }
   // the names rocprofv3 prints: every template argument, the storage code last
   switch (bf16x3_variant(a, d->kh, d->dil)) {
-    case CV_DMA: snprintf(buf, buflen, "conv3x3_bf16_dma<%d, %d>", d->nsrc, res_count(a)); break;
+    case CV_DMA:
+      if (d->kh == 7) snprintf(buf, buflen, "conv7x7_bf16_dma");
+      else snprintf(buf, buflen, "conv3x3_bf16_dma<%d, %d>", d->nsrc, res_count(a));
+      break;
     case CV_WS: snprintf(buf, buflen, "conv_bf16x3_ws<%d, %d, %d>", d->kh, d->dil, code); break;
     case CV_RES: snprintf(buf, buflen, "conv_bf16x3_res<%d, %d, %d, %d, %d>", d->kh, d->dil, d->nsrc, PAIF_RES_ROWS, code); break;
     case CV_MS: snprintf(buf, buflen, "conv_bf16x3_ms<%d, %d, %d, %d>", d->kh, d->dil, d->nsrc, code); break;

@@ -86,7 +86,7 @@ def test_dense_conv_bf16_storage_matches_fp32_storage(kh, dil, nsrc, nres, act, 
         out = ops.conv2d(xsb, wpk, kh, dil=dil, res=tuple(rsb), **kw)
     assert out.dtype == torch.bfloat16 and ref.dtype == torch.float32
     err = (out.float() - ref).abs()
-    if mode == "bf16" and kh == 3 and dil == 1 and cout == 32:
+    if mode == "bf16" and dil == 1 and cout == 32 and (kh == 3 or (kh == 7 and nsrc == 1 and nres == 0)):
         # conv_dma.hip: another accumulation order than the reference kernel's -- see test_conv3x3_bf16_dma_kernel
         tol = BF_EPS * ref.abs() * 1.01 + 1e-5
         assert float((err > tol).float().mean()) < 1e-4 and bool((err <= 2 * tol).all()), float(err.max())
@@ -155,6 +155,32 @@ def test_conv3x3_bf16_dma_kernel(nsrc, nres, act, shape):
     tol = BF_EPS * ref.abs() * 1.01 + 1e-5          # + the fp32 accumulation noise itself where the terms cancel (values are O(1))
     # the accumulation order differs from the reference kernel's (vertical taps innermost): a pre-rounding value within ~1e-7 of a
     # rounding boundary may land on the other bf16 neighbour -- a full ulp, on a vanishing fraction of the elements
+    bad = err > tol
+    assert float(bad.float().mean()) < 1e-4 and bool((err <= 2 * tol).all()), (int(bad.sum()), float(err.max()), torch.nonzero(bad)[:8].tolist())
+
+
+@pytest.mark.parametrize("act", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(2, 333, 517), (1, 480, 640), (5, 64, 1000)])
+def test_conv7x7_bf16_dma_kernel(act, shape):
+    """The 7x7 form of the LDS-DMA kernel (weights: k-step 0 in registers, k-step 1 in LDS; 2-slot tile ring)."""
+    B, H, W = shape
+    g = torch.Generator().manual_seed(77 + act)
+    dev = _dev()
+    x32, xb = _rounded(ops.to_nhwc(torch.randn(B, 32, H, W, generator=g).to(dev)))
+    w = (torch.randn(32, 32, 7, 7, generator=g) * 0.02).to(dev).to(torch.bfloat16).float()
+    scale, shift = (torch.rand(32, generator=g) + 0.5).to(dev), (torch.randn(32, generator=g) * 0.1).to(dev)
+    slope = torch.tensor([0.2], device=dev)
+    wpk = ops.pack_conv_weight(w, 1, 32, 7, precision="bf16x3")
+    kw = dict(scale=scale, shift=shift, act=act, prelu=slope if act == 1 else None, alpha=0.5)
+    ref = ops.conv2d([x32], wpk, 7, **kw)
+    ops.set_storage("bf16")
+    d = _lib_desc([xb], wpk, [])
+    d.kh = 7
+    assert ops.conv2d_kernel_name(d, B, H, W) == "conv7x7_bf16_dma"
+    out = ops.conv2d([xb], wpk, 7, **kw)
+    torch.cuda.synchronize()
+    err = (out.float() - ref).abs()
+    tol = BF_EPS * ref.abs() * 1.01 + 1e-5
     bad = err > tol
     assert float(bad.float().mean()) < 1e-4 and bool((err <= 2 * tol).all()), (int(bad.sum()), float(err.max()), torch.nonzero(bad)[:8].tolist())
 

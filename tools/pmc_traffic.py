@@ -44,7 +44,7 @@ allrec["_note"] = ("HBM bytes per launch from rocprofv3 --pmc passes of `bench.p
                    "(bench.py reports a stale one as such).")
 sec = {"_kernel_source_sha16": kernel_source_sha16(), "_round": 3}
 for k, d in tot.items():
-    if not re.match(r"(conv_|conv3x3_|gf_|gemm_|sr_attention|attn_bwd|dwconv|layernorm|stem_|spa_|eca_|tail_|channel_|head_sum|im2col|col2im|upsample|resize)", k):
+    if not re.match(r"(conv_|conv3x3_|conv7x7_|gf_|gemm_|sr_attention|attn_bwd|dwconv|layernorm|stem_|spa_|eca_|tail_|channel_|head_sum|im2col|col2im|upsample|resize)", k):
         continue
     fs = d["FETCH_SIZE"] / max(1, cnt[(k, "FETCH_SIZE")])
     ws = d["WRITE_SIZE"] / max(1, cnt[(k, "WRITE_SIZE")])
