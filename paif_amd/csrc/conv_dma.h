@@ -14,11 +14,13 @@ struct Args {
   void* out;            // NHWC-32 bf16
   float alpha;
   int nsrc, nres, act, kh;   // kh: 3 or 7
+  int cout;                  // 32, or 16 (3x3, one source, no residual maps)
   int B, H, W, reverse;
 };
 
 // true if the kernel is built for this source / residual count and the tensors fit its 32-bit addressing
 bool eligible(int nsrc, int nres, int B, int H, int W, float alpha);
+bool eligible16(int nsrc, int nres, int B, int H, int W, float alpha);  // 3x3 with 16 output channels: one source, no residual maps
 bool eligible7(int nsrc, int nres, int B, int H, int W, float alpha);   // the 7x7 form: one source, no residual maps
 int launch(const Args& a, hipStream_t st);
 

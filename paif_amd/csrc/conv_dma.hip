@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_dma(Args a, int ntiles, i
   __amdgpu_buffer_rsrc_t rs_res[NRES > 0 ? NRES : 1];
 #pragma unroll
   for (int r = 0; r < NRES; ++r) rs_res[r] = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.res[r]), 0, map_bytes, RSRC_W3);
-  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, map_bytes, RSRC_W3);
+  const int opitch = a.cout * 2;                         // bytes per output pixel: 32 channels, or 16 (stem_out.0; one source, no residual maps)
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.B * H * W * opitch, RSRC_W3);
   const __amdgpu_buffer_rsrc_t rs_null = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, 0, RSRC_W3);
 
   // ---- B operand: [source][tap][k-step], lane (n = l & 31, k = 8 (l >> 5) + j) -- the hi halves of the split-bf16 pack ----
@@ -151,8 +152,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_dma(Args a, int ntiles, i
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int c = 8 * (l & 3) + j;
-    esc[j] = (a.scale ? a.scale[c] : 1.f) * a.alpha;
-    esh[j] = (a.shift ? a.shift[c] : 0.f) * a.alpha;
+    esc[j] = ((a.scale && c < a.cout) ? a.scale[c] : 1.f) * a.alpha;
+    esh[j] = ((a.shift && c < a.cout) ? a.shift[c] : 0.f) * a.alpha;
   }
   const float e_slope = a.act == 1 ? *a.prelu : (a.act == 2 ? 0.f : 1.f);
 
@@ -192,7 +193,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_dma(Args a, int ntiles, i
   // ---- epilogue geometry ----
   const unsigned a_pw = PARK_OFF + w * PARK_WAVE + (4 * hh * 32 + p) * 4;          // + (sg * 32 + (r & 3) + 8 * (r >> 2)) * 128
   const unsigned a_pr = PARK_OFF + w * PARK_WAVE + (l >> 2) * 128 + (l & 3) * 32;   // + it * 2048 (+ 16): pixel 16 it + (l >> 2), 8 channels
-  const unsigned e_lane = (unsigned)l * 16u;                                      // (pixel l >> 2, chunk l & 3) inside 16 pixels
+  const unsigned e_lane = (unsigned)l * 16u;                                      // (pixel l >> 2, chunk l & 3) inside 16 pixels of a 32-channel map
+  const unsigned o_lane = 8 * (l & 3) < a.cout ? (unsigned)((l >> 2) * opitch + (l & 3) * 16) : OOB;   // the same in the OUTPUT map
 
   // residual maps of a tile (this wave's 2 rows): 4 x 16 B per lane and map
   u32x4 rr[U][NRES > 0 ? NRES : 1][4];
@@ -237,9 +239,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_dma(Args a, int ntiles, i
       const uint2 o0 = paif::f32_to_bf16x4(make_float4(ev[0], ev[1], ev[2], ev[3]));
       const uint2 o1 = paif::f32_to_bf16x4(make_float4(ev[4], ev[5], ev[6], ev[7]));
       const int y = py0 + 2 * w + (it >> 1), x = px0 + (it & 1) * 16 + (l >> 2);
-      const unsigned soff = (unsigned)(((pb * H + y) * W + px0 + (it & 1) * 16) * 64);
+      const unsigned soff = (unsigned)(((pb * H + y) * W + px0 + (it & 1) * 16) * opitch);
       u32x4 od = {o0.x, o0.y, o1.x, o1.y};
-      __builtin_amdgcn_raw_buffer_store_b128(od, rs_out, (!(CD_EXP & 1) && pok && y < H && x < W) ? e_lane : OOB, soff, 2);
+      __builtin_amdgcn_raw_buffer_store_b128(od, rs_out, (!(CD_EXP & 1) && pok && y < H && x < W) ? o_lane : OOB, soff, 2);
       asm volatile("s_nop 2" : "+v"(od));                 // 128-bit store data: WAR hazard hipcc does not pad (gf_mfma.hip)
     }
   };
@@ -694,6 +696,7 @@ bool eligible(int nsrc, int nres, int B, int H, int W, float alpha) {
   return tiles >= 1024 && tiles <= 128 * 256 && B < 1024 && H < 2048 * TH && W < 2048 * TW && (long long)B * H * W * 64 < (1ll << 31);
 }
 
+bool eligible16(int nsrc, int nres, int B, int H, int W, float alpha) { return nsrc == 1 && nres == 0 && eligible(1, 0, B, H, W, alpha); }
 bool eligible7(int nsrc, int nres, int B, int H, int W, float alpha) { return nsrc == 1 && nres == 0 && eligible(1, 0, B, H, W, alpha); }
 
 int launch(const Args& a, hipStream_t st) {

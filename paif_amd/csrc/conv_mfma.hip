@@ -1556,9 +1556,10 @@ static inline int res_count(const ConvArgs& a) { return a.res[0] ? (a.res[1] ? (
 static inline ConvVariant bf16x3_variant(const ConvArgs& a, int kh, int dil) {
   if (needs_hooks(a)) return CV_HOOKS;
   // bf16 maps + plain bf16 weights, 3x3 dilation 1, 32 -> 32 per source: the LDS-DMA kernel (conv_dma.hip)
-  if (dil == 1 && a.st == 1 && a.wl0 && a.in_act == 0 && a.cout == 32 && !a.pool_partial &&
-      ((kh == 3 && paif_conv_dma::eligible(a.nsrc, res_count(a), a.B, a.H, a.W, a.alpha)) ||
-       (kh == 7 && paif_conv_dma::eligible7(a.nsrc, res_count(a), a.B, a.H, a.W, a.alpha))))
+  if (dil == 1 && a.st == 1 && a.wl0 && a.in_act == 0 && !a.pool_partial &&
+      ((kh == 3 && a.cout == 32 && paif_conv_dma::eligible(a.nsrc, res_count(a), a.B, a.H, a.W, a.alpha)) ||
+       (kh == 3 && a.cout == 16 && paif_conv_dma::eligible16(a.nsrc, res_count(a), a.B, a.H, a.W, a.alpha)) ||
+       (kh == 7 && a.cout == 32 && paif_conv_dma::eligible7(a.nsrc, res_count(a), a.B, a.H, a.W, a.alpha))))
     return CV_DMA;
   if (takes_ws(a, kh, dil)) return CV_WS;
   if (kh == 3 && dil == 1) {
@@ -1577,7 +1578,7 @@ int launch_bf16x3_st(const ConvArgs& a, hipStream_t st) {
       paif_conv_dma::Args d{};
       for (int s = 0; s < 3; ++s) { d.src[s] = a.src[s]; d.res[s] = a.res[s]; }
       d.wpk = a.wpk; d.scale = a.scale; d.shift = a.shift; d.prelu = a.prelu; d.out = a.out; d.alpha = a.alpha;
-      d.nsrc = a.nsrc; d.nres = res_count(a); d.act = a.act; d.B = a.B; d.H = a.H; d.W = a.W; d.reverse = a.reverse; d.kh = KH;
+      d.nsrc = a.nsrc; d.nres = res_count(a); d.act = a.act; d.B = a.B; d.H = a.H; d.W = a.W; d.reverse = a.reverse; d.kh = KH; d.cout = a.cout;
       return paif_conv_dma::launch(d, st);
     }
     case CV_HOOKS:

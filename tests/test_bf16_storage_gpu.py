@@ -86,7 +86,7 @@ def test_dense_conv_bf16_storage_matches_fp32_storage(kh, dil, nsrc, nres, act, 
         out = ops.conv2d(xsb, wpk, kh, dil=dil, res=tuple(rsb), **kw)
     assert out.dtype == torch.bfloat16 and ref.dtype == torch.float32
     err = (out.float() - ref).abs()
-    if mode == "bf16" and dil == 1 and cout == 32 and (kh == 3 or (kh == 7 and nsrc == 1 and nres == 0)):
+    if mode == "bf16" and dil == 1 and ((kh == 3 and (cout == 32 or (nsrc == 1 and nres == 0))) or (kh == 7 and cout == 32 and nsrc == 1 and nres == 0)):
         # conv_dma.hip: another accumulation order than the reference kernel's -- see test_conv3x3_bf16_dma_kernel
         tol = BF_EPS * ref.abs() * 1.01 + 1e-5
         assert float((err > tol).float().mean()) < 1e-4 and bool((err <= 2 * tol).all()), float(err.max())
@@ -183,6 +183,26 @@ def test_conv7x7_bf16_dma_kernel(act, shape):
     tol = BF_EPS * ref.abs() * 1.01 + 1e-5
     bad = err > tol
     assert float(bad.float().mean()) < 1e-4 and bool((err <= 2 * tol).all()), (int(bad.sum()), float(err.max()), torch.nonzero(bad)[:8].tolist())
+
+
+def test_conv_dma_kernels_more_than_64_tiles_per_workgroup():
+    """B = 16 at 480x640: 19,200 tiles = 75 per workgroup -- the second half of the per-lane tile table (configs[2]'s shape)."""
+    B, H, W = 16, 480, 640
+    g = torch.Generator().manual_seed(4242)
+    dev = _dev()
+    x32, xb = _rounded(ops.to_nhwc(torch.randn(B, 32, H, W, generator=g).to(dev)))
+    for kh, sc in ((3, 0.05), (7, 0.02)):
+        w = (torch.randn(32, 32, kh, kh, generator=g) * sc).to(dev).to(torch.bfloat16).float()
+        wpk = ops.pack_conv_weight(w, 1, 32, kh, precision="bf16x3")
+        ops.set_storage("f32")
+        ref = ops.conv2d([x32], wpk, kh)
+        ops.set_storage("bf16")
+        out = ops.conv2d([xb], wpk, kh)
+        torch.cuda.synchronize()
+        err = (out.float() - ref).abs()
+        tol = BF_EPS * ref.abs() * 1.01 + 1e-5
+        assert float((err > tol).float().mean()) < 1e-4 and bool((err <= 2 * tol).all()), (kh, float(err.max()))
+        del ref, out, err, tol
 
 
 def _lib_desc(srcs, wpk, res):
