@@ -147,6 +147,8 @@ typedef struct {
 #define PAIF_CONV_F32 0
 #define PAIF_CONV_BF16X3 1
 #define PAIF_CONV_BF16 2        /* storage != PAIF_ST_F32 only: one bf16 MFMA per product (BASELINE configs[1] "bf16") */
+#define PAIF_CONV_BF16X6 3      /* fp32 storage, cin = 32: three bf16 pieces per operand, six MFMAs per product: fp32-level parity (2^-25 per
+                                   product) at 6/16 of the exact fp32 MFMA's matrix-pipe time; the arithmetic of the attack loops */
 
 /* ---- bf16-stored activation maps (PAIF_ST_BF16; BASELINE configs[1] "...bf16..."): the elementwise kernels of the fusion
  * network's inference forward on bf16 32-channel maps (bf16 data behind the float* of x / out / ir / vis / agg / o / r / a / b),
@@ -183,6 +185,9 @@ int paif_pack_conv_weight(const float* w, float* wpk, int cout, int nsrc, int ci
 /* Same weights for precision = PAIF_CONV_BF16X3 (cin = 32 only): each value split into bf16 hi + bf16 lo,
  * wpk[src][tap][k16][hi|lo][64 lanes][8 bf16] (same size in bytes as the fp32 packing). */
 int paif_pack_conv_weight_bf16x3(const float* w, float* wpk, int cout, int nsrc, int kh, paif_stream_t stream);
+/* Three-piece packs for PAIF_CONV_BF16X6: 1.5 x paif_conv_wpk_floats(...) floats. */
+int paif_pack_conv_weight_bf16x6(const float* w, float* wpk, int cout, int nsrc, int kh, paif_stream_t stream);
+int paif_pack_decomp1x1_weight_bf16x6(const float* w, float* wpk, paif_stream_t stream);
 int paif_pack_decomp1x1_weight_bf16x3(const float* w, float* wpk, paif_stream_t stream);
 /* Cell_Decom's 1x1 over cat[LF1,LF2,x-LF1,x-LF2] (core/model_fusion_auto.py:512-513) folded to a 1x1
  * over [x, LF1, LF2]: (Wh1+Wh2) x + (Wl1-Wh1) LF1 + (Wl2-Wh2) LF2.  w [32,128,1,1] -> wpk for nsrc=3. */

@@ -51,7 +51,9 @@ SIGNATURES = {
     "paif_pack_conv_weight": (c_int, [F, F, c_int, c_int, c_int, c_int, F]),
     "paif_pack_decomp1x1_weight": (c_int, [F, F, F]),
     "paif_pack_conv_weight_bf16x3": (c_int, [F, F, c_int, c_int, c_int, F]),
+    "paif_pack_conv_weight_bf16x6": (c_int, [F, F, c_int, c_int, c_int, F]),
     "paif_pack_decomp1x1_weight_bf16x3": (c_int, [F, F, F]),
+    "paif_pack_decomp1x1_weight_bf16x6": (c_int, [F, F, F]),
     "paif_bn_fold": (c_int, [F, F, F, F, c_float, F, F, c_int, F]),
     "paif_dwconv_fwd": (c_int, [F, F, F, c_int, c_int, c_int, c_int, c_int, c_int, F]),
     "paif_channel_pool2_fwd": (c_int, [F, F, F, c_int, c_int, c_int, F]),

@@ -390,18 +390,21 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
   return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
 }
 
-template <int KH, int DIL, bool HOOKS, int ST = 0>
+// NP = 3 ("bf16x6", fp32 storage only): every operand as THREE bf16 pieces (hi + mid + lo = the fp32 value to 2^-27) and the six
+// products down to 2^-25 relative -- fp32-level parity at 6 bf16 MFMAs per product (the exact fp32 MFMA costs 16 of their cycles).
+template <int KH, int DIL, bool HOOKS, int ST = 0, int NP = 2>
 #ifndef PAIF_LB
 #define PAIF_LB 3
 #endif
 // two workgroups per CU (256 VGPRs) for the gradient-hook kernels and the wide halos (k >= 5, dilation 2: at three the
 // staging batch spills 84-220 B/lane and the kernels measure 5-25 % slower), three for the 1x1 / 3x3 dilation-1 kernels
-__global__ __launch_bounds__(NTHREADS, (HOOKS || KH >= 5 || DIL == 2) ? 2 : PAIF_LB) void conv_mfma_bf16x3(ConvArgs a) {
+__global__ __launch_bounds__(NTHREADS, (HOOKS || KH >= 5 || DIL == 2 || NP == 3) ? 2 : PAIF_LB) void conv_mfma_bf16x3(ConvArgs a) {
   constexpr int CIN = 32;
   constexpr int P = DIL * (KH - 1) / 2;
   constexpr int TWH = TW + 2 * P;
   constexpr int THH = TH + 2 * P;
-  constexpr int PSB = 144;             // pixel record in bytes
+  static_assert(NP == 2 || (NP == 3 && ST == 0), "the three-piece split is built for fp32 storage");
+  constexpr int PSB = NP == 3 ? 208 : 144;   // pixel record in bytes: NP x 64 + 16 (13 / 9 sixteen-byte slots: odd -> conflict-free b128)
   constexpr int QPP = CIN / 4;
   constexpr int NKS = CIN / 16;        // K=16 steps per tap
   constexpr int NTAP = KH * KH;
@@ -481,13 +484,20 @@ __global__ __launch_bounds__(NTHREADS, (HOOKS || KH >= 5 || DIL == 2) ? 2 : PAIF
           lo.x = pack_bf16(t4.x - (float)hx, t4.y - (float)hy);
           lo.y = pack_bf16(t4.z - (float)hz, t4.w - (float)hw);
           *reinterpret_cast<uint2*>(ldsb + dst[u]) = hi;
-          if constexpr (!paif::st_lo0(ST)) *reinterpret_cast<uint2*>(ldsb + dst[u] + 64) = lo;
+          if constexpr (NP == 3) {      // lo computed above is the MIDDLE piece; the third: what is left of the residual
+            const float rx = (t4.x - (float)hx) - __uint_as_float(lo.x << 16), ry = (t4.y - (float)hy) - __uint_as_float(lo.x & 0xffff0000u);
+            const float rz = (t4.z - (float)hz) - __uint_as_float(lo.y << 16), rw = (t4.w - (float)hw) - __uint_as_float(lo.y & 0xffff0000u);
+            *reinterpret_cast<uint2*>(ldsb + dst[u] + 64) = lo;
+            *reinterpret_cast<uint2*>(ldsb + dst[u] + 128) = make_uint2(pack_bf16(rx, ry), pack_bf16(rz, rw));
+          } else if constexpr (!paif::st_lo0(ST)) {
+            *reinterpret_cast<uint2*>(ldsb + dst[u] + 64) = lo;
+          }
         }
       }
     }
     __syncthreads();
 
-    const uint4* wsrc = reinterpret_cast<const uint4*>(a.wpk) + (size_t)s * NTAP * NKS * 2 * 64 + lane;
+    const uint4* wsrc = reinterpret_cast<const uint4*>(a.wpk) + (size_t)s * NTAP * NKS * NP * 64 + lane;
     // B operand: a statically indexed 3-slot register ring, two taps ahead.  A rolled loop with `bcur = bnxt` copies
     // a pending load and therefore waits for the prefetch at the end of every tap (it only ever overlapped one tap's 12
     // MFMAs with the L2 latency).  The tap loop runs in groups of 3 (slot = position in the group; every k*k is 3n or
@@ -495,17 +505,17 @@ __global__ __launch_bounds__(NTHREADS, (HOOKS || KH >= 5 || DIL == 2) ? 2 : PAIF
     // (full unrolling of 49 taps costs minutes of compile time per instantiation).
     static_assert(NTAP % 3 == 0 || NTAP % 3 == 1, "tap count must be 3n or 3n+1");
     constexpr int BRING = NTAP >= 3 ? 3 : 1;
-    uint4 bw[BRING][NKS * 2];
+    uint4 bw[BRING][NKS * NP];
     auto fetch = [&](int tap, int slot) {
 #pragma unroll
-      for (int i = 0; i < NKS * 2; ++i)
-        if (!(paif::st_wl0(ST) && (i & 1))) bw[slot][i] = wsrc[(tap * NKS * 2 + i) * 64];
+      for (int i = 0; i < NKS * NP; ++i)
+        if (!(paif::st_wl0(ST) && (i & 1))) bw[slot][i] = wsrc[(tap * NKS * NP + i) * 64];
     };
     // A operand of one K=16 step (hi and lo halves of this wave's two row segments), double-buffered in registers: the
     // reads of step i+1 are issued before the MFMAs of step i and pinned there with sched_barrier.  Left to itself the
     // scheduler sinks every ds_read (and the B prefetch) to just above its first use to save registers, and each MFMA
     // group then eats the full LDS / L2 latency (measured: 9.9k -> 5.6k cycles per 3x3 source on the MFMA phase).
-    struct AStep { bf16x8 h[SEGS_PER_WAVE], l[SEGS_PER_WAVE]; };
+    struct AStep { bf16x8 h[SEGS_PER_WAVE], l[SEGS_PER_WAVE], t[NP == 3 ? SEGS_PER_WAVE : 1]; };
     auto readA = [&](AStep& A, int tap, int ks) {
       const int dy = tap / KH, dx = tap - dy * KH;
       const int toff = (dy * DIL * TWH + dx * DIL) * PSB + 32 * ks;
@@ -513,9 +523,27 @@ __global__ __launch_bounds__(NTHREADS, (HOOKS || KH >= 5 || DIL == 2) ? 2 : PAIF
       for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) {
         A.h[sg] = *reinterpret_cast<const bf16x8*>(ldsb + abase[sg] + toff);
         if constexpr (!paif::st_lo0(ST)) A.l[sg] = *reinterpret_cast<const bf16x8*>(ldsb + abase[sg] + toff + 64);
+        if constexpr (NP == 3) A.t[sg] = *reinterpret_cast<const bf16x8*>(ldsb + abase[sg] + toff + 128);
       }
     };
     auto mma_step = [&](const AStep& A, int slot, int ks) {
+      if constexpr (NP == 3) {     // h = hi, l = mid, t = lo of both operands; smallest products first
+        const bf16x8 b0 = __builtin_bit_cast(bf16x8, bw[slot][3 * ks]), b1 = __builtin_bit_cast(bf16x8, bw[slot][3 * ks + 1]),
+                     b2 = __builtin_bit_cast(bf16x8, bw[slot][3 * ks + 2]);
+#pragma unroll
+        for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h[sg], b2, acc[sg], 0, 0, 0);
+#pragma unroll
+        for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.t[sg], b0, acc[sg], 0, 0, 0);
+#pragma unroll
+        for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.l[sg], b1, acc[sg], 0, 0, 0);
+#pragma unroll
+        for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h[sg], b1, acc[sg], 0, 0, 0);
+#pragma unroll
+        for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.l[sg], b0, acc[sg], 0, 0, 0);
+#pragma unroll
+        for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h[sg], b0, acc[sg], 0, 0, 0);
+        return;
+      }
       const bf16x8 bh = __builtin_bit_cast(bf16x8, bw[slot][2 * ks]);
       const bf16x8 bl = __builtin_bit_cast(bf16x8, bw[slot][2 * ks + 1]);
       if constexpr (!paif::st_lo0(ST)) {
@@ -603,22 +631,22 @@ __global__ __launch_bounds__(NTHREADS, (HOOKS || KH >= 5 || DIL == 2) ? 2 : PAIF
   }
 }
 
-template <int KH, int DIL, bool HOOKS, int ST = 0>
+template <int KH, int DIL, bool HOOKS, int ST = 0, int NP = 2>
 int launch_bf16x3_h(const ConvArgs& a, hipStream_t st) {
   constexpr int P = DIL * (KH - 1) / 2;
-  constexpr size_t tile_bytes = (size_t)(TH + 2 * P) * (TW + 2 * P) * 144;
+  constexpr size_t tile_bytes = (size_t)(TH + 2 * P) * (TW + 2 * P) * (NP == 3 ? 208 : 144);
   constexpr size_t epi_bytes = (size_t)TH * 32 * 32 * 4;
   constexpr size_t lds_bytes = tile_bytes > epi_bytes ? tile_bytes : epi_bytes;
   static_assert(lds_bytes <= 160 * 1024, "tile does not fit LDS");
   if (lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_bf16x3<KH, DIL, HOOKS, ST>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_bf16x3<KH, DIL, HOOKS, ST, NP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) {
       paif::set_error("conv2d(bf16x3): cannot raise dynamic LDS to %zu: %s", lds_bytes, hipGetErrorString(e));
       return (int)e;
     }
   }
-  hipLaunchKernelGGL((conv_mfma_bf16x3<KH, DIL, HOOKS, ST>), dim3(a.nblk), dim3(NTHREADS), lds_bytes, st, a);
+  hipLaunchKernelGGL((conv_mfma_bf16x3<KH, DIL, HOOKS, ST, NP>), dim3(a.nblk), dim3(NTHREADS), lds_bytes, st, a);
   PAIF_LAUNCH_CHECK("conv2d(bf16x3)");
   return 0;
 }
@@ -1615,6 +1643,16 @@ static inline int kernel_st(const ConvArgs& a) {
   return (a.wl0 && base) ? base + 3 : base;
 }
 
+// three-piece split (PAIF_CONV_BF16X6): the tile-per-workgroup kernel, with or without the gradient hooks; fp32 storage
+template <int KH, int DIL>
+int launch_bf16x6(const ConvArgs& a, hipStream_t st) {
+  if (a.st != 0) {
+    paif::set_error("conv2d: precision bf16x6 is built for fp32-stored maps");
+    return PAIF_ENOSUP;
+  }
+  return needs_hooks(a) ? launch_bf16x3_h<KH, DIL, true, 0, 3>(a, st) : launch_bf16x3_h<KH, DIL, false, 0, 3>(a, st);
+}
+
 template <int KH, int DIL>
 int launch_bf16x3(const ConvArgs& a, hipStream_t st) {
   const int code = kernel_st(a);
@@ -1652,6 +1690,49 @@ __global__ void pack_weight_bf16x3_kernel(const float* __restrict__ w, unsigned 
     const __bf16 hi = (__bf16)v;
     const __bf16 out = part == 0 ? hi : (__bf16)(v - (float)hi);
     wpk[idx] = __builtin_bit_cast(unsigned short, out);
+  }
+}
+
+// three-piece form (bf16x6): wpk[src][tap][ks][hi|mid|lo][64 lanes][8 bf16]
+__device__ __forceinline__ unsigned short bf16x6_piece(float v, int part) {
+  const __bf16 hi = (__bf16)v;
+  const float r1 = v - (float)hi;
+  const __bf16 mid = (__bf16)r1;
+  const __bf16 out = part == 0 ? hi : (part == 1 ? mid : (__bf16)(r1 - (float)mid));
+  return __builtin_bit_cast(unsigned short, out);
+}
+__global__ void pack_weight_bf16x6_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpk, int cout, int nsrc, int kh) {
+  const int ntap = kh * kh;
+  const int total = nsrc * ntap * 2 * 3 * 64 * 8;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int j = idx & 7, lane = (idx >> 3) & 63;
+    int rest = idx >> 9;
+    const int part = rest % 3; rest /= 3;
+    const int ks = rest & 1; rest >>= 1;
+    const int tap = rest % ntap;
+    const int s = rest / ntap;
+    const int n = lane & 31, hh = lane >> 5;
+    const int c = s * 32 + 16 * ks + 8 * hh + j;
+    const float v = (n < cout) ? w[((size_t)n * (nsrc * 32) + c) * ntap + tap] : 0.f;
+    wpk[idx] = bf16x6_piece(v, part);
+  }
+}
+__global__ void pack_decomp1x1_bf16x6_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpk) {
+  const int total = 3 * 2 * 3 * 64 * 8;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int j = idx & 7, lane = (idx >> 3) & 63;
+    int rest = idx >> 9;
+    const int part = rest % 3; rest /= 3;
+    const int ks = rest & 1;
+    const int s = rest >> 1;
+    const int n = lane & 31, hh = lane >> 5;
+    const int c = 16 * ks + 8 * hh + j;
+    const float* wn = w + n * 128;
+    float v;
+    if (s == 0) v = wn[64 + c] + wn[96 + c];
+    else if (s == 1) v = wn[c] - wn[64 + c];
+    else v = wn[32 + c] - wn[96 + c];
+    wpk[idx] = bf16x6_piece(v, part);
   }
 }
 
@@ -1770,6 +1851,10 @@ int paif_conv2d_kernel_name(const paif_conv_desc* d, int B, int H, int W, char* 
   a.nblk = B * ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
   a.st = d->storage; a.wl0 = d->precision == PAIF_CONV_BF16 ? 1 : 0; a.alpha = d->alpha;
   const int code = kernel_st(a);
+  if (d->precision == PAIF_CONV_BF16X6 && d->cin == 32) {
+    snprintf(buf, buflen, "conv_mfma_bf16x3<%d, %d, %s, 0, 3>", d->kh, d->dil, needs_hooks(a) ? "true" : "false");
+    return 0;
+  }
   if (d->precision != PAIF_CONV_BF16X3 && d->precision != PAIF_CONV_BF16) {
     snprintf(buf, buflen, "conv_mfma_f32<%d, %d, %d, %s>", d->kh, d->dil, d->cin, needs_hooks(a) ? "true" : "false");
     return 0;
@@ -1829,9 +1914,22 @@ int paif_conv2d_fwd(const paif_conv_desc* d, int B, int H, int W, paif_stream_t 
   PAIF_REQUIRE(d->precision != PAIF_CONV_BF16 || d->storage != 0, PAIF_ENOSUP, "conv2d: precision bf16 is built for bf16-stored maps only");
   hipStream_t st = paif::as_stream(stream);
   PAIF_REQUIRE(d->cin == 32 || d->cin == 16, PAIF_ENOSUP, "conv2d: cin=%d", d->cin);
-  PAIF_REQUIRE(d->precision == PAIF_CONV_F32 || d->precision == PAIF_CONV_BF16X3 || d->precision == PAIF_CONV_BF16, PAIF_EINVAL,
-               "conv2d: precision=%d", d->precision);
+  PAIF_REQUIRE(d->precision == PAIF_CONV_F32 || d->precision == PAIF_CONV_BF16X3 || d->precision == PAIF_CONV_BF16 ||
+                   d->precision == PAIF_CONV_BF16X6, PAIF_EINVAL, "conv2d: precision=%d", d->precision);
+  PAIF_REQUIRE(d->precision != PAIF_CONV_BF16X6 || d->cin == 32, PAIF_ENOSUP, "conv2d: bf16x6 needs 32-channel sources");
   const int key = d->kh * 100 + d->dil * 10 + (d->cin == 32 ? 0 : 1);
+  if (d->precision == PAIF_CONV_BF16X6) {
+    switch (key) {
+      case 110: return launch_bf16x6<1, 1>(a, st);
+      case 310: return launch_bf16x6<3, 1>(a, st);
+      case 320: return launch_bf16x6<3, 2>(a, st);
+      case 510: return launch_bf16x6<5, 1>(a, st);
+      case 710: return launch_bf16x6<7, 1>(a, st);
+      default: break;
+    }
+    paif::set_error("conv2d(bf16x6): kernel %dx%d dil %d cin %d not built", d->kh, d->kh, d->dil, d->cin);
+    return PAIF_ENOSUP;
+  }
   if (d->precision == PAIF_CONV_BF16X3 || d->precision == PAIF_CONV_BF16) {
     switch (key) {
       case 110: return launch_bf16x3<1, 1>(a, st);
@@ -1869,6 +1967,25 @@ int paif_pack_conv_weight_bf16x3(const float* w, float* wpk, int cout, int nsrc,
   hipLaunchKernelGGL(pack_weight_bf16x3_kernel, dim3((total + 255) / 256), dim3(256), 0, paif::as_stream(stream), w,
                      reinterpret_cast<unsigned short*>(wpk), cout, nsrc, kh);
   PAIF_LAUNCH_CHECK("pack_conv_weight_bf16x3");
+  return 0;
+}
+
+int paif_pack_conv_weight_bf16x6(const float* w, float* wpk, int cout, int nsrc, int kh, paif_stream_t stream) {
+  PAIF_REQUIRE(w && wpk, PAIF_EINVAL, "pack_conv_weight_bf16x6: null pointer");
+  PAIF_REQUIRE(cout >= 1 && cout <= 32 && nsrc >= 1 && nsrc <= 3 && kh >= 1 && kh <= 7, PAIF_ENOSUP,
+               "pack_conv_weight_bf16x6: cout=%d nsrc=%d kh=%d", cout, nsrc, kh);
+  const int total = nsrc * kh * kh * 3072;
+  hipLaunchKernelGGL(pack_weight_bf16x6_kernel, dim3((total + 255) / 256), dim3(256), 0, paif::as_stream(stream), w,
+                     reinterpret_cast<unsigned short*>(wpk), cout, nsrc, kh);
+  PAIF_LAUNCH_CHECK("pack_conv_weight_bf16x6");
+  return 0;
+}
+
+int paif_pack_decomp1x1_weight_bf16x6(const float* w, float* wpk, paif_stream_t stream) {
+  PAIF_REQUIRE(w && wpk, PAIF_EINVAL, "pack_decomp1x1_weight_bf16x6: null pointer");
+  hipLaunchKernelGGL(pack_decomp1x1_bf16x6_kernel, dim3(36), dim3(256), 0, paif::as_stream(stream), w,
+                     reinterpret_cast<unsigned short*>(wpk));
+  PAIF_LAUNCH_CHECK("pack_decomp1x1_weight_bf16x6");
   return 0;
 }
 

@@ -306,8 +306,22 @@ __device__ __forceinline__ void split_store(char* dst, float4 t4) {
   *reinterpret_cast<uint2*>(dst + 64) = lo;
 }
 
-template <bool MASKED>
+// NP = 3 ("bf16x6"): every operand as three bf16 pieces (hi + mid + lo = the fp32 value to 2^-27), six products down to 2^-25
+// relative: fp32-level parity at 6 bf16 MFMAs per product (precision code 3; the attack loops' GEMM arithmetic where K >= 256).
+__device__ __forceinline__ void split_store3(char* dst, float4 t4) {
+  const __bf16 hx = (__bf16)t4.x, hy = (__bf16)t4.y, hz = (__bf16)t4.z, hw = (__bf16)t4.w;
+  const float rx = t4.x - (float)hx, ry = t4.y - (float)hy, rz = t4.z - (float)hz, rw = t4.w - (float)hw;
+  const __bf16 mx = (__bf16)rx, my = (__bf16)ry, mz = (__bf16)rz, mw = (__bf16)rw;
+  const __bf16 lx = (__bf16)(rx - (float)mx), ly = (__bf16)(ry - (float)my), lz = (__bf16)(rz - (float)mz), lw = (__bf16)(rw - (float)mw);
+  auto pk = [](__bf16 a, __bf16 b) { return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16); };
+  *reinterpret_cast<uint2*>(dst) = make_uint2(pk(hx, hy), pk(hz, hw));
+  *reinterpret_cast<uint2*>(dst + 64) = make_uint2(pk(mx, my), pk(mz, mw));
+  *reinterpret_cast<uint2*>(dst + 128) = make_uint2(pk(lx, ly), pk(lz, lw));
+}
+
+template <bool MASKED, int NP = 2>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16x3(GemmArgs a) {
+  constexpr int RB = NP == 3 ? 208 : 144;   // bytes per staged row of a 32-wide K tile (shadows the two-piece constant)
   __shared__ __align__(16) char sA[BM * RB];
   __shared__ __align__(16) char sW[BN * RB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, p = lane & 31;
@@ -361,26 +375,53 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16x3(GemmArgs a) {
         }
         if (scaled) { t.x *= vs.x; t.y *= vs.y; t.z *= vs.z; t.w *= vs.w; }
       }
-      split_store(sA + (srow + 32 * i) * RB + sq * 8, t);
+      if constexpr (NP == 3) split_store3(sA + (srow + 32 * i) * RB + sq * 8, t);
+      else split_store(sA + (srow + 32 * i) * RB + sq * 8, t);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) split_store(sW + (srow + 32 * i) * RB + sq * 8, vw[i]);
+    for (int i = 0; i < 2; ++i) {
+      if constexpr (NP == 3) split_store3(sW + (srow + 32 * i) * RB + sq * 8, vw[i]);
+      else split_store(sW + (srow + 32 * i) * RB + sq * 8, vw[i]);
+    }
     __syncthreads();
     if (k0 + BK < kend) gload(k0 + BK);   // block-uniform
-    struct Ops { bf16x8 ah, al, wh[2], wl[2]; };
+    struct Ops { bf16x8 ah, al, wh[2], wl[2], at, wt[2]; };
     auto rd = [&](Ops& o, int ks) {
       o.ah = *reinterpret_cast<const bf16x8*>(sA + abase + 32 * ks);
       o.al = *reinterpret_cast<const bf16x8*>(sA + abase + 64 + 32 * ks);
+      if constexpr (NP == 3) o.at = *reinterpret_cast<const bf16x8*>(sA + abase + 128 + 32 * ks);
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         o.wh[t] = *reinterpret_cast<const bf16x8*>(sW + wbase + t * 32 * RB + 32 * ks);
         o.wl[t] = *reinterpret_cast<const bf16x8*>(sW + wbase + t * 32 * RB + 64 + 32 * ks);
+        if constexpr (NP == 3) o.wt[t] = *reinterpret_cast<const bf16x8*>(sW + wbase + t * 32 * RB + 128 + 32 * ks);
       }
     };
     Ops o0, o1;
     rd(o0, 0);
     rd(o1, 1);
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (NP == 3) {   // h = hi, l = mid, t = lo; smallest products first
+      auto six = [&](const Ops& o) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.ah, o.wt[t], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.at, o.wh[t], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.al, o.wl[t], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.ah, o.wl[t], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.al, o.wh[t], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.ah, o.wh[t], acc[t], 0, 0, 0);
+      };
+      six(o0);
+      __builtin_amdgcn_sched_barrier(0);
+      six(o1);
+      __builtin_amdgcn_sched_barrier(0);
+      continue;
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o0.al, o0.wh[t], acc[t], 0, 0, 0);
 #pragma unroll
@@ -434,7 +475,7 @@ extern "C" int paif_gemm_fwd(const float* A, int lda, const float* W, const floa
 extern "C" int paif_gemm_masked_fwd(const float* A, int lda, const float* a_mask, const float* a_scale, const float* W,
                                     const float* scale, const float* shift, int act, const float* res, int ldres, float* C,
                                     int ldc, int M, int N, int K, int precision, paif_stream_t stream) {
-  PAIF_REQUIRE(precision == 0 || precision == 1, PAIF_EINVAL, "gemm: precision=%d", precision);
+  PAIF_REQUIRE(precision == 0 || precision == 1 || precision == 3, PAIF_EINVAL, "gemm: precision=%d", precision);
   PAIF_REQUIRE(A && W && C, PAIF_EINVAL, "gemm: null pointer");
   PAIF_REQUIRE(M > 0 && N > 0 && K > 0, PAIF_EINVAL, "gemm: empty shape %dx%dx%d", M, N, K);
   PAIF_REQUIRE(K % 32 == 0, PAIF_ENOSUP, "gemm: K=%d must be a multiple of 32 (pad the operands)", K);
@@ -455,7 +496,10 @@ extern "C" int paif_gemm_masked_fwd(const float* A, int lda, const float* a_mask
   const bool pro = a_mask || a_scale;
   const dim3 grid(a.nblk), blk(256);
   hipStream_t st = paif::as_stream(stream);
-  if (precision == 1) {
+  if (precision == 3) {
+    if (pro) hipLaunchKernelGGL((gemm_mfma_bf16x3<true, 3>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((gemm_mfma_bf16x3<false, 3>), grid, blk, 0, st, a);
+  } else if (precision == 1) {
     if (pro) hipLaunchKernelGGL(gemm_mfma_bf16x3<true>, grid, blk, 0, st, a);
     else hipLaunchKernelGGL(gemm_mfma_bf16x3<false>, grid, blk, 0, st, a);
   } else {
@@ -495,7 +539,7 @@ extern "C" int paif_gemm_splitk_fwd(const float* A, int lda, const float* W, con
 extern "C" int paif_gemm_splitk_fwd_p(const float* A, int lda, const float* W, const float* scale, const float* shift, int act,
                                       const float* res, int ldres, float* C, int ldc, int M, int N, int K, int splits,
                                       float* workspace, int precision, paif_stream_t stream) {
-  PAIF_REQUIRE(precision == 0 || precision == 1, PAIF_EINVAL, "gemm_splitk: precision=%d", precision);
+  PAIF_REQUIRE(precision == 0 || precision == 1 || precision == 3, PAIF_EINVAL, "gemm_splitk: precision=%d", precision);
   PAIF_REQUIRE(A && W && C && workspace, PAIF_EINVAL, "gemm_splitk: null pointer");
   PAIF_REQUIRE(M > 0 && N > 0 && K > 0 && K % 32 == 0, PAIF_EINVAL, "gemm_splitk: shape %dx%dx%d", M, N, K);
   PAIF_REQUIRE(splits >= 2 && (K / BK) % splits == 0, PAIF_EINVAL, "gemm_splitk: splits=%d does not divide %d k-tiles", splits,
@@ -514,7 +558,8 @@ extern "C" int paif_gemm_splitk_fwd_p(const float* A, int lda, const float* W, c
   hipStream_t st = paif::as_stream(stream);
   PAIF_REQUIRE((size_t)M * lda < ((size_t)1 << 32) && (size_t)N * K < ((size_t)1 << 32), PAIF_ENOSUP,
                "gemm_splitk: operands exceed the 32-bit element offsets");
-  if (precision == 1) hipLaunchKernelGGL(gemm_mfma_bf16x3<false>, dim3(a.nblk, splits), dim3(256), 0, st, a);
+  if (precision == 3) hipLaunchKernelGGL((gemm_mfma_bf16x3<false, 3>), dim3(a.nblk, splits), dim3(256), 0, st, a);
+  else if (precision == 1) hipLaunchKernelGGL(gemm_mfma_bf16x3<false>, dim3(a.nblk, splits), dim3(256), 0, st, a);
   else hipLaunchKernelGGL(gemm_mfma_f32<false>, dim3(a.nblk, splits), dim3(256), 0, st, a);
   PAIF_LAUNCH_CHECK("gemm_splitk");
   const size_t total = (size_t)M * N;

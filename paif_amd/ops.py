@@ -48,7 +48,7 @@ ACT_GELU = 1  # paif_gemm_fwd's act code 1 is GELU (the conv's code 1 is PReLU)
 # and every 1-channel plane stay fp32 (SURVEY hard part 1).  Taped (gradient) passes always run fp32 storage.  Tolerance of this
 # mode: SURVEY 8(d) bf16 clause (max / mean |fused - reference| reported, argmax agreement >= 99.9 %, mIoU within 0.1 pt):
 # tests/test_bf16_storage_gpu.py.
-CONFIG = {"conv_precision": "bf16x3", "gemm_precision": "auto", "serpentine": True, "attack_precision": "exact", "storage": "f32"}
+CONFIG = {"conv_precision": "bf16x3", "gemm_precision": "auto", "serpentine": True, "attack_precision": "bf16x6", "storage": "f32"}
 _ACT_BF16 = [False]    # True while an inference forward of the fusion network runs in bf16 storage (set by the model)
 
 
@@ -83,15 +83,15 @@ class bf16_activations:
 
 _TWINS = {}    # data_ptr of an fp32 map -> (the map, its bf16 twin written by the producing kernel); lives for one bf16 forward
 _SERP = [0]    # tile-direction parity of the next dense-conv launch
-_PREC_CODE = {"f32": 0, "bf16x3": 1}
+_PREC_CODE = {"f32": 0, "bf16x3": 1, "bf16x6": 3}
 PREC_BF16 = 2          # include/paif_hip.h PAIF_CONV_BF16 (conv descriptors with bf16-stored maps only)
 
 
 def set_gemm_precision(mode):
     """Arithmetic of the SegFormer GEMMs: "f32" (exact fp32 MFMA), "bf16x3" (split-bf16: 3 bf16 MFMAs, ~1e-5 relative),
     or "auto": split-bf16 where the GEMM is matrix-pipe bound at fp32 (K >= 256 and M >= 2048), exact fp32 elsewhere."""
-    if mode not in _PREC_CODE and mode != "auto":
-        raise ValueError("gemm precision must be one of %s or 'auto'" % sorted(_PREC_CODE))
+    if mode not in ("f32", "bf16x3", "auto", "bf16x6", "auto6"):
+        raise ValueError("gemm precision must be 'f32', 'bf16x3', 'auto', 'bf16x6' or 'auto6'")
     CONFIG["gemm_precision"] = mode
 
 
@@ -102,10 +102,11 @@ def set_conv_precision(mode):
 
 
 def set_attack_precision(mode):
-    """Arithmetic of the attack loops: "exact" (default; fp32-exact kernels, meets the A1 trajectory metric) or "fast"
-    (whatever set_conv_precision / set_gemm_precision select -- split-bf16 by default; ~1.5x faster, trajectory diverges)."""
-    if mode not in ("exact", "fast"):
-        raise ValueError("attack precision must be 'exact' or 'fast'")
+    """Arithmetic of the attack loops: "exact" (fp32-exact MFMA kernels everywhere), "bf16x6" (convs as three-piece bf16 splits, six
+    MFMAs per product, 2^-25 per product: fp32-level parity at 6/16 of the fp32 MFMA's matrix-pipe time; GEMMs / attention exact) or
+    "fast" (whatever set_conv_precision / set_gemm_precision select -- split-bf16 by default; ~1.5x faster, trajectory diverges)."""
+    if mode not in ("exact", "bf16x6", "fast"):
+        raise ValueError("attack precision must be 'exact', 'bf16x6' or 'fast'")
     CONFIG["attack_precision"] = mode
 
 
@@ -114,8 +115,11 @@ class attack_arithmetic:
 
     def __enter__(self):
         self.old = (CONFIG["conv_precision"], CONFIG["gemm_precision"])
-        if CONFIG.get("attack_precision", "exact") == "exact":
+        mode = CONFIG.get("attack_precision", "bf16x6")
+        if mode == "exact":
             CONFIG["conv_precision"], CONFIG["gemm_precision"] = "f32", "f32"
+        elif mode == "bf16x6":
+            CONFIG["conv_precision"], CONFIG["gemm_precision"] = "bf16x6", "auto6"
 
     def __exit__(self, *a):
         CONFIG["conv_precision"], CONFIG["gemm_precision"] = self.old
@@ -426,9 +430,12 @@ def pack_conv_weight(w, nsrc, cin, kh, precision=None):
     if cin != 32:
         precision = "f32"  # the split-bf16 kernel is built for 32-channel sources
     L = lib()
-    wpk = torch.empty(L.paif_conv_wpk_floats(nsrc, cin, kh), device=w.device, dtype=torch.float32)
+    nfl = L.paif_conv_wpk_floats(nsrc, cin, kh)
+    wpk = torch.empty(nfl * 3 // 2 if precision == "bf16x6" else nfl, device=w.device, dtype=torch.float32)
     wc = w.detach().contiguous()
-    if precision == "bf16x3":
+    if precision == "bf16x6":
+        _lib.check(L.paif_pack_conv_weight_bf16x6(_p(wc), _p(wpk), cout, nsrc, kh, _stream()), "pack_conv_weight_bf16x6")
+    elif precision == "bf16x3":
         _lib.check(L.paif_pack_conv_weight_bf16x3(_p(wc), _p(wpk), cout, nsrc, kh, _stream()), "pack_conv_weight_bf16x3")
     else:
         _lib.check(L.paif_pack_conv_weight(_p(wc), _p(wpk), cout, nsrc, cin, kh, _stream()), "pack_conv_weight")
@@ -439,9 +446,12 @@ def pack_decomp1x1_weight(w, precision=None):
     assert tuple(w.shape) == (32, 128, 1, 1)
     precision = precision or CONFIG["conv_precision"]
     L = lib()
-    wpk = torch.empty(L.paif_conv_wpk_floats(3, 32, 1), device=w.device, dtype=torch.float32)
+    nfl = L.paif_conv_wpk_floats(3, 32, 1)
+    wpk = torch.empty(nfl * 3 // 2 if precision == "bf16x6" else nfl, device=w.device, dtype=torch.float32)
     wc = w.detach().contiguous()
-    if precision == "bf16x3":
+    if precision == "bf16x6":
+        _lib.check(L.paif_pack_decomp1x1_weight_bf16x6(_p(wc), _p(wpk), _stream()), "pack_decomp1x1_weight_bf16x6")
+    elif precision == "bf16x3":
         _lib.check(L.paif_pack_decomp1x1_weight_bf16x3(_p(wc), _p(wpk), _stream()), "pack_decomp1x1_weight_bf16x3")
     else:
         _lib.check(L.paif_pack_decomp1x1_weight(_p(wc), _p(wpk), _stream()), "pack_decomp1x1_weight")
@@ -716,6 +726,8 @@ def gemm(a, w, scale=None, shift=None, act=ACT_NONE, res=None, out=None, out_col
         splits = L.paif_gemm_splitk_plan(M, N, K)   # small grid + long k loop (small batch): spread k over the idle CUs
     if prec == "auto":   # with or without split-K (its partial products take the same arithmetic, the reduction is fp32)
         prec = "bf16x3" if (K >= 256 and M >= 2048) else "f32"
+    elif prec == "auto6":  # the attack loops: three-piece splits (fp32-level parity) where the exact GEMM is matrix-pipe bound
+        prec = "bf16x6" if (K >= 256 and M >= 2048) else "f32"
     tag = "gemm_mfma_%s" % prec
     e0 = TIMER.start(tag) if TIMER is not None else None
     if splits > 1:
@@ -783,7 +795,7 @@ def sr_attention_bwd(q, kv, o, dout, lse, heads):
     dq = torch.empty_like(q)
     dkv = torch.empty_like(kv)
     partial = torch.empty((nchunk, B, Nk, 2 * C), device=q.device, dtype=torch.float32)
-    split = 0 if CONFIG["gemm_precision"] == "f32" else 1     # arithmetic follows the GEMMs (sr_attention)
+    split = 0 if CONFIG["gemm_precision"] in ("f32", "bf16x6", "auto6") else 1     # arithmetic follows the GEMMs (sr_attention); exact where they are fp32-level
     _lib.check(L.paif_sr_attention_bwd_input_p(_p(q), _p(kv), _p(o), _p(dout.contiguous()), _p(lse), _p(delta), _p(dq), _p(dkv), _p(partial),
                                                B, N, Nk, C, heads, split, _stream()), "sr_attention_bwd")
     return dq, dkv
@@ -1259,7 +1271,7 @@ def sr_attention(q, kv, heads, want_lse=False):
     out = torch.empty_like(q)
     lse = torch.empty((B, heads, N), device=q.device, dtype=torch.float32) if want_lse else None
     # arithmetic follows the GEMMs: exact fp32 MFMA under set_gemm_precision("f32") (all gradient-parity tests), split-bf16 otherwise
-    split = CONFIG["gemm_precision"] != "f32"
+    split = CONFIG["gemm_precision"] not in ("f32", "bf16x6", "auto6")
     tag = "sr_attention_bf16x3" if split else "sr_attention"
     e0 = TIMER.start(tag) if TIMER is not None else None
     fn = lib().paif_sr_attention_bf16x3_fwd if split else lib().paif_sr_attention_fwd

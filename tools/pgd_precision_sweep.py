@@ -16,8 +16,9 @@ S.load_formula_weights(m)
 m = m.to(dev)
 ir, vis, lab = S.make_batch(2, 64, 96)
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
-for conv in ("f32", "bf16x3"):
-    for gemm in ("f32", "auto", "bf16x3"):
+ops.set_attack_precision("fast")      # the loop runs whatever the two settings below say
+for conv in ("f32", "bf16x6", "bf16x3"):
+    for gemm in ("f32", "auto6", "bf16x6", "auto", "bf16x3"):
         ops.set_conv_precision(conv)
         ops.set_gemm_precision(gemm)
         trace = []
