@@ -290,10 +290,14 @@ def main():
                 # on bf16 maps) / 2 (bf16 maps: the stored operand's low half is zero; or plain bf16 weights on fp32 maps) / 1 (bf16 maps and
                 # plain bf16 weights: --storage bf16) -> 2500/n TF algorithmic peak
                 m_ = re.search(r", (\d)>$", tag)
+                m5 = re.match(r"conv_mfma_bf16x3<\d, \d, (?:true|false), (\d), (\d)>$", tag)   # <KH, DIL, HOOKS, storage code, pieces>
                 if tag == DOMINANT:
                     nm = {"f32": 3, "bf16_split": 2, "bf16": 1}[args.storage] if args.workload in ("fusion", "fusion_seg") else 3
                 else:
-                    nm = 1 if "bf16_dma" in tag else ({0: 3, 1: 2, 2: 3, 3: 3, 4: 1, 5: 2, 6: 1}[int(m_.group(1))] if m_ else 3)
+                    if m5:
+                        nm = 6 if m5.group(2) == "3" else {0: 3, 1: 2, 2: 3, 3: 3, 4: 1, 5: 2, 6: 1}[int(m5.group(1))]
+                    else:
+                        nm = 1 if "bf16_dma" in tag else ({0: 3, 1: 2, 2: 3, 3: 3, 4: 1, 5: 2, 6: 1}[int(m_.group(1))] if m_ else 3)
                 peak_tf = 2500.0 / nm
                 if fl_ / max(by_, 1) > peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9):
                     blk = {"bound": "mfma", "achieved": tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": tf / peak_tf, "algorithmic_gbs": gb,

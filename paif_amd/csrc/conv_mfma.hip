@@ -1872,8 +1872,8 @@ int paif_conv2d_kernel_name(const paif_conv_desc* d, int B, int H, int W, char* 
     case CV_WS: snprintf(buf, buflen, "conv_bf16x3_ws<%d, %d, %d>", d->kh, d->dil, code); break;
     case CV_RES: snprintf(buf, buflen, "conv_bf16x3_res<%d, %d, %d, %d, %d>", d->kh, d->dil, d->nsrc, PAIF_RES_ROWS, code); break;
     case CV_MS: snprintf(buf, buflen, "conv_bf16x3_ms<%d, %d, %d, %d>", d->kh, d->dil, d->nsrc, code); break;
-    case CV_HOOKS: snprintf(buf, buflen, "conv_mfma_bf16x3<%d, %d, true, %d>", d->kh, d->dil, code); break;
-    default: snprintf(buf, buflen, "conv_mfma_bf16x3<%d, %d, false, %d>", d->kh, d->dil, code); break;
+    case CV_HOOKS: snprintf(buf, buflen, "conv_mfma_bf16x3<%d, %d, true, %d, 2>", d->kh, d->dil, code); break;
+    default: snprintf(buf, buflen, "conv_mfma_bf16x3<%d, %d, false, %d, 2>", d->kh, d->dil, code); break;
   }
   return 0;
 }

@@ -206,7 +206,7 @@ def test_dense_conv_3x3_kernel_variants_are_dispatched_and_correct(nsrc, nres, a
         ops.TIMER = None
     torch.cuda.synchronize()
     y, partial = out if pool else (out, None)
-    want = ("conv_mfma_bf16x3<3, 1, false, 0>" if pool else "conv_bf16x3_res<3, 1, 1, 4, 0>") if nsrc == 1 else "conv_bf16x3_ms<3, 1, %d, 0>" % nsrc
+    want = ("conv_mfma_bf16x3<3, 1, false, 0, 2>" if pool else "conv_bf16x3_res<3, 1, 1, 4, 0>") if nsrc == 1 else "conv_bf16x3_ms<3, 1, %d, 0>" % nsrc
     assert list(timer.summary()) == [want], list(timer.summary())
     sc = float(ref.abs().max())
     assert maxabs(y.permute(0, 3, 1, 2).cpu(), ref) <= 1e-4 * sc

@@ -22,11 +22,12 @@ python3 bench.py --steps 20 --warmup 5 > gpurun_out/r03_bench_fusion.json 2> gpu
 python3 bench.py --workload fusion_seg --steps 10 --warmup 3 > gpurun_out/r03_bench_fusion_seg.json 2> gpurun_out/r03_bench_fusion_seg.err
 python3 bench.py --workload pgd --steps 3 --warmup 1 --sustain-seconds 0 > gpurun_out/r03_bench_pgd.json 2> gpurun_out/r03_bench_pgd.err
 python3 bench.py --workload pgd --attack-precision fast --steps 3 --warmup 1 --sustain-seconds 0 --no-cpu-baseline > gpurun_out/r03_bench_pgd_fast.json 2> gpurun_out/r03_bench_pgd_fast.err
+python3 bench.py --workload pgd --attack-precision exact --steps 3 --warmup 1 --sustain-seconds 0 --no-cpu-baseline > gpurun_out/r03_bench_pgd_exact.json 2> gpurun_out/r03_bench_pgd_exact.err
 python3 bench.py --workload train --steps 3 --warmup 1 --sustain-seconds 0 > gpurun_out/r03_bench_train.json 2> gpurun_out/r03_bench_train.err
 python3 bench.py --graph --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r03_bench_fusion_graph.json 2> gpurun_out/r03_bench_fusion_graph.err
 python3 - <<'PY'
 import json
-for f in ["fusion", "fusion_seg", "pgd", "pgd_fast", "train", "fusion_graph"]:
+for f in ["fusion", "fusion_seg", "pgd", "pgd_fast", "pgd_exact", "train", "fusion_graph"]:
     try:
         d = json.loads(open("gpurun_out/r03_bench_%s.json" % f).read().strip().splitlines()[-1])
         print(f, round(d["value"], 2), round(d["ms_per_step"], 3), [(o["storage"], round(o["value"], 1)) for o in d.get("other_storage", [])],
