@@ -93,6 +93,10 @@ int paif_guided_filter_lf_fwd(const float* guide, const float* ab, float* lf, in
 size_t paif_guided_filter_fused_workspace_floats(int B, int H, int W);
 int paif_guided_filter_fused_fwd(const float* guide, const float* y, float* lf, float eps0, float eps1, float* workspace,
                                  int B, int H, int W, paif_stream_t stream);
+/* Same, the two low-frequency maps written as bf16 (`lf`: [2][B,H,W,32] `unsigned short` data, round to nearest even): the bf16
+ * configuration holds the maps behind the guided-filter block as bf16; statistics, A, b and every sum stay fp32. */
+int paif_guided_filter_fused_fwd_bf16(const float* guide, const float* y, float* lf, float eps0, float eps1, float* workspace, int B,
+                                      int H, int W, paif_stream_t stream);
 
 /* Dense k x k convolution, stride 1, "same" zero padding (pad = dil*(k-1)/2), Cout <= 32, inputs =
  * virtual concat of up to 3 NHWC sources of `cin` channels each, fp32 MFMA (v_mfma_f32_32x32x2_f32)

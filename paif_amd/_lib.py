@@ -43,6 +43,7 @@ SIGNATURES = {
     "paif_guided_filter_lf_fwd": (c_int, [F, F, F, c_int, c_int, c_int, F]),
     "paif_guided_filter_fused_workspace_floats": (c_size_t, [c_int, c_int, c_int]),
     "paif_guided_filter_fused_fwd": (c_int, [F, F, F, c_float, c_float, F, c_int, c_int, c_int, F]),
+    "paif_guided_filter_fused_fwd_bf16": (c_int, [F, F, F, c_float, c_float, F, c_int, c_int, c_int, F]),
     "paif_conv2d_blocks": (c_int, [c_int, c_int, c_int]),
     "paif_conv2d_fwd": (c_int, [POINTER(ConvDesc), c_int, c_int, c_int, F]),
     "paif_conv2d_is_persistent": (c_int, [POINTER(ConvDesc), c_int, c_int, c_int]),

@@ -118,11 +118,11 @@ class Cell_Decom(nn.Module):
     def get_residue(self, tensor):
         return ops.to_nchw_view(ops.channel_residue(ops.to_nhwc(tensor)).unsqueeze(-1))
 
-    def decomposition_nhwc(self, x, guide=None, want_ab=False):
+    def decomposition_nhwc(self, x, guide=None, want_ab=False, out_bf16=False):
         """-> lf [2,B,H,W,32] (LF for eps 1e-3, 1e-4)."""
         if guide is None:
             guide = ops.channel_residue(x)
-        return ops.guided_filter_pair(guide, x, tuple(self.eps_list), want_ab=want_ab)
+        return ops.guided_filter_pair(guide, x, tuple(self.eps_list), want_ab=want_ab, out_bf16=out_bf16)
 
     @staticmethod
     def _cat_lf_hf(x, lf):
@@ -143,9 +143,12 @@ class Cell_Decom(nn.Module):
             g_ir = ops.channel_residue(fir)
         if g_vis is None:
             g_vis = ops.channel_residue(fvis)
+        # bf16 configuration (inference): the guided filter writes its two maps as bf16 and the folded 1x1 takes them with the stem
+        # map's bf16 twin -- everything behind the filter's fp32 statistics / A / b is a bf16 map
+        lf16 = tape is None and feats is None and ops._ACT_BF16[0]
         if tape is None:
-            lf_ir = self.decomposition_nhwc(fir, g_ir)
-            lf_vis = self.decomposition_nhwc(fvis, g_vis)
+            lf_ir = self.decomposition_nhwc(fir, g_ir, out_bf16=lf16)
+            lf_vis = self.decomposition_nhwc(fvis, g_vis, out_bf16=lf16)
         else:
             lf_ir, ab_ir = self.decomposition_nhwc(fir, g_ir, want_ab=True)
             lf_vis, ab_vis = self.decomposition_nhwc(fvis, g_vis, want_ab=True)
@@ -153,8 +156,9 @@ class Cell_Decom(nn.Module):
         w_hf = self._packs.get("hf", [self.conv1x1_hf.weight], lambda: ops.pack_decomp1x1_weight(self.conv1x1_hf.weight))
         if feats is not None:
             feats.update(lf_ir=lf_ir, lf_vis=lf_vis, g_ir=g_ir, g_vis=g_vis)
-        lf = ops.conv2d([fir, lf_ir[0], lf_ir[1]], w_lf, 1, 1, shift=self.conv1x1_lf.bias)
-        hf = ops.conv2d([fvis, lf_vis[0], lf_vis[1]], w_hf, 1, 1, shift=self.conv1x1_hf.bias)
+        x_ir, x_vis = (ops.cast_storage(fir, True), ops.cast_storage(fvis, True)) if lf16 else (fir, fvis)   # the stems' bf16 twins
+        lf = ops.conv2d([x_ir, lf_ir[0], lf_ir[1]], w_lf, 1, 1, shift=self.conv1x1_lf.bias)
+        hf = ops.conv2d([x_vis, lf_vis[0], lf_vis[1]], w_hf, 1, 1, shift=self.conv1x1_hf.bias)
         t1 = None if tape is None else []
         t2 = None if tape is None else []
         ir_feature = self.chain.forward_nhwc(lf, (fir,), t1)      # lf_re + inp_ir

@@ -156,7 +156,11 @@ __device__ __forceinline__ f32x4 ring_push(Ring& rg, f32x4 x) {
 // One (16-channel half, batch image, 64-column strip, row segment) per workgroup of 4 waves.
 //   planes: [4][B*H*W] = mean_g, 1/(var_g + eps0), 1/(var_g + eps1), 1/n  (gf_guide_stats_kernel)
 //   AL4: W % 4 == 0 -- a lane's 4 columns of a plane are one aligned 16-byte piece (one plane DMA per wave and iteration)
-template <bool AL4>
+// BFO: the two low-frequency maps are written as bf16 (round to nearest even): the bf16 configuration's storage of the maps behind this
+// block (the statistics, A, b and every sum stay fp32).  A lane holds ONE channel of 4 columns: lanes c and c ^ 1 exchange two columns
+// (one DPP quad permute per value) so that each stores dwords = channel pairs (c & ~1, c | 1) -- 4 dword stores per row instead of 8;
+// eight 2-byte stores per row made the kernel 11 % slower.
+template <bool AL4, bool BFO>
 __global__ __launch_bounds__(256, 1) void gf_mfma_kernel(const float* __restrict__ guide, const float* __restrict__ y,
                                                          const float* __restrict__ planes, float* __restrict__ lf,
                                                          unsigned* __restrict__ flag, int B, int H, int W, int nstrip, int nseg,
@@ -196,6 +200,13 @@ __global__ __launch_bounds__(256, 1) void gf_mfma_kernel(const float* __restrict
 #pragma unroll
   for (int i = 0; i < 4; ++i)
     soff[i] = (lc0 >= 2 * R && lc0 < SC - 2 * R && cin[i]) ? (unsigned)(((col0 + i) * 32 + 16 * chh + c) * 4) : 0xFFFFFFFFu;
+  const bool odd = (c & 1) != 0;                         // BFO: even lanes store columns 0, 1, odd lanes columns 2, 3 of the channel pair
+  unsigned soff2[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int i = odd ? 2 + j : j;
+    soff2[j] = (lc0 >= 2 * R && lc0 < SC - 2 * R && (odd ? cin[2 + j] : cin[j])) ? (unsigned)(((col0 + i) * 32 + 16 * chh + (c & ~1)) * 2) : 0xFFFFFFFFu;
+  }
   const u32x4 a_own = band_operand(l & 15, 4 * (l >> 4), true);
   const u32x4 a_halo = band_operand(l & 15, (l >> 4) == 0 ? -4 : 16, (l >> 4) < 2);
   // halo slots: publish own fragment as L (lanes g == 0) / R (g == 3); read left neighbour's R (g == 0), right neighbour's L (g == 1)
@@ -212,8 +223,11 @@ __global__ __launch_bounds__(256, 1) void gf_mfma_kernel(const float* __restrict
   const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(guide + img), 0, (int)((size_t)H * rowbytes_pl), RSRC_W3);
   const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(planes + img), 0, (int)(3 * (size_t)plane_bytes + (size_t)H * rowbytes_pl), RSRC_W3);
   const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(y + img * 32), 0, (int)((size_t)H * rowbytes), RSRC_W3);
-  float* const o0 = lf + img * 32, * const o1 = lf + (npix + img) * 32;
-  const int out_bytes = (int)((size_t)H * rowbytes);
+  static_assert(!(XPOSE && BFO), "bf16 outputs use the direct-store path");
+  constexpr unsigned OES = BFO ? 2u : 4u;                 // bytes per stored output element
+  const unsigned rowbytes_o = (unsigned)W * 32u * OES;
+  char* const o0 = reinterpret_cast<char*>(lf) + img * 32 * OES, * const o1 = reinterpret_cast<char*>(lf) + (npix + img) * 32 * OES;
+  const int out_bytes = (int)((size_t)H * rowbytes_o);
   // Plane staging: 12 slots of 64 columns per iteration --
   //   0..3 = {rn, mg, rden0, rden1}(r-4)   4 = g(r)   5 = g(r-9)   6, 7 = copies of 4, 5   8 = rn(r-9)   9..11 = copies / spare
   // AL4: ONE 16-byte DMA per wave fills four consecutive slots (lane group j = l >> 4 -> slot base + j, 4 columns per lane):
@@ -352,14 +366,32 @@ __global__ __launch_bounds__(256, 1) void gf_mfma_kernel(const float* __restrict
       } else {
         const int ro = r - (2 * R + 1);
         const bool rowv = ro >= ybeg && ro < yend;
-        const unsigned so = (unsigned)max(ro, 0) * rowbytes;
+        const unsigned so = (unsigned)max(ro, 0) * rowbytes_o;
         const int nrec = rowv ? out_bytes : 0;           // zero-length descriptor: every store of this row is dropped
         const __amdgpu_buffer_rsrc_t ro0 = __builtin_amdgcn_make_buffer_rsrc(o0, 0, nrec, RSRC_W3);
         const __amdgpu_buffer_rsrc_t ro1 = __builtin_amdgcn_make_buffer_rsrc(o1, 0, nrec, RSRC_W3);
+        if constexpr (BFO) {
+          auto pair_store = [&](const f32x4& ov, const __amdgpu_buffer_rsrc_t& rs) {
+            typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+            typedef float f32x2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { const float o = out0[i]; __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), ro0, soff[i], so, 2); }
+            for (int j = 0; j < 2; ++j) {
+              const float a = ov[j], b = ov[2 + j];
+              // partner lane (c ^ 1): quad permute [1, 0, 3, 2]
+              const float pa = __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(a), 0xB1, 0xF, 0xF, true));
+              const float pb = __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(b), 0xB1, 0xF, 0xF, true));
+              const f32x2_t v = {odd ? pb : a, odd ? b : pa};     // (channel c & ~1, channel c | 1) of column j (even lanes) / 2 + j (odd)
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t)), rs, soff2[j], so, 2);
+            }
+          };
+          pair_store(out0, ro0);
+          pair_store(out1, ro1);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { const float o = out1[i]; __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), ro1, soff[i], so, 2); }
+          for (int i = 0; i < 4; ++i) { const float o = out0[i]; __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), ro0, soff[i], so, 2); }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { const float o = out1[i]; __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), ro1, soff[i], so, 2); }
+        }
       }
     }
     // ---- stage 1: (A_e, b_e) of row r - 4, then their 9-row window sums for the next iteration ----
@@ -383,7 +415,7 @@ __global__ __launch_bounds__(256, 1) void gf_mfma_kernel(const float* __restrict
       if (XPOSE) {
         const int ro = r - (2 * R + 1);
         const bool rowv = ro >= ybeg && ro < yend;
-        const unsigned so = (unsigned)max(ro, 0) * rowbytes;
+        const unsigned so = (unsigned)max(ro, 0) * rowbytes_o;
         const int nrec = rowv ? out_bytes : 0;           // zero-length descriptor: every store of this row is dropped
         __builtin_amdgcn_raw_buffer_store_b128(t0, __builtin_amdgcn_make_buffer_rsrc(o0, 0, nrec, RSRC_W3), soff16, so, 2);
         __builtin_amdgcn_raw_buffer_store_b128(t1, __builtin_amdgcn_make_buffer_rsrc(o1, 0, nrec, RSRC_W3), soff16, so, 2);
@@ -428,7 +460,9 @@ __global__ __launch_bounds__(256, 1) void gf_mfma_kernel(const float* __restrict
   if (l == 0 && !(vmax < 65000.f)) atomicOr(flag, 1u);
 }
 
-template __global__ void gf_mfma_kernel<true>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
-template __global__ void gf_mfma_kernel<false>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
+template __global__ void gf_mfma_kernel<true, false>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
+template __global__ void gf_mfma_kernel<false, false>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
+template __global__ void gf_mfma_kernel<true, true>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
+template __global__ void gf_mfma_kernel<false, true>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
 
 }  // namespace paif_gf_mfma

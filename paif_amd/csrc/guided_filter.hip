@@ -316,8 +316,9 @@ template <typename V> __device__ __forceinline__ V vfma(float s, V a, V c) {
 template <typename V, int NL>
 __global__ __launch_bounds__(FC * NL) void gf_fused_kernel(const float* __restrict__ guide, const float* __restrict__ y,
                                                            const float* __restrict__ gs, const unsigned* __restrict__ only_if, float* __restrict__ lf,
-                                                           int B, int H, int W, int nstrip, int nseg, int frows) {
+                                                           int B, int H, int W, int nstrip, int nseg, int frows, int out_bf16) {
   constexpr int VW = VecOps<V>::VW;
+  unsigned short* const lf16 = reinterpret_cast<unsigned short*>(lf);   // out_bf16: the same element indices in a bf16 buffer
   if (only_if != nullptr && *only_if == 0u) return;      // fallback launch behind the matrix-core kernel: runs only when it raised the flag
   __shared__ V s_a[2][FC][NL];
   __shared__ V s_b[2][FC][NL];
@@ -335,6 +336,7 @@ __global__ __launch_bounds__(FC * NL) void gf_fused_kernel(const float* __restri
   const int ybeg = seg * frows, yend = min(H, ybeg + frows);   // frows = output rows per workgroup (chosen at launch)
   const size_t img = (size_t)b * H * W;
   float* out = lf + (size_t)e * ((size_t)B * H * W * 32);
+  unsigned short* out16 = lf16 + (blockIdx.z * NL + ql) * VW + (size_t)e * ((size_t)B * H * W * 32);
   const float* gmean = gs;                                            // planes: mean_g, 1/(var+eps0), 1/(var+eps1), 1/n
   const float* grden = gs + (size_t)(1 + e) * ((size_t)B * H * W);
 
@@ -456,7 +458,12 @@ __global__ __launch_bounds__(FC * NL) void gf_fused_kernel(const float* __restri
         const float* pb = reinterpret_cast<const float*>(&bb);
 #pragma unroll
         for (int i = 0; i < VW; ++i) po[i] = fmaf(pa[i] * rn, g0, pb[i] * rn);
-        paif::store_nt(out + px * 32, o);
+        if (out_bf16) {   // launch-uniform
+#pragma unroll
+          for (int i = 0; i < VW; ++i) out16[px * 32 + i] = __builtin_bit_cast(unsigned short, (__bf16)po[i]);
+        } else {
+          paif::store_nt(out + px * 32, o);
+        }
       }
     }
   }
@@ -465,19 +472,21 @@ __global__ __launch_bounds__(FC * NL) void gf_fused_kernel(const float* __restri
 }  // namespace
 
 namespace paif_gf_mfma {
-template <bool AL4>
+template <bool AL4, bool BFO>
 __global__ void gf_mfma_kernel(const float* __restrict__ guide, const float* __restrict__ y, const float* __restrict__ planes,
                                float* __restrict__ lf, unsigned* __restrict__ flag, int B, int H, int W, int nstrip, int nseg, int frows,
                                int ntiles);
-extern template __global__ void gf_mfma_kernel<true>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
-extern template __global__ void gf_mfma_kernel<false>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
+extern template __global__ void gf_mfma_kernel<true, false>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
+extern template __global__ void gf_mfma_kernel<false, false>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
+extern template __global__ void gf_mfma_kernel<true, true>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
+extern template __global__ void gf_mfma_kernel<false, true>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
 }
 
 // workspace: four per-pixel planes + one 256-byte line holding the f16-range flag
 extern "C" size_t paif_guided_filter_fused_workspace_floats(int B, int H, int W) { return (size_t)4 * B * H * W + 64; }
 
-extern "C" int paif_guided_filter_fused_fwd(const float* guide, const float* y, float* lf, float eps0, float eps1, float* workspace, int B,
-                                            int H, int W, paif_stream_t stream) {
+static int gf_fused_launch(const float* guide, const float* y, float* lf, float eps0, float eps1, float* workspace, int B, int H, int W,
+                           int out_bf16, paif_stream_t stream) {
   PAIF_REQUIRE(guide && y && lf && workspace && B > 0, PAIF_EINVAL, "guided_filter_fused: bad arguments");
   PAIF_REQUIRE(H > 2 * R + 1 && W > 2 * R + 1, PAIF_EINVAL, "guided_filter: H,W must exceed 2r+1 = %d (got %dx%d)", K, H, W);
   const int nstrip = (W + FO - 1) / FO;
@@ -524,12 +533,19 @@ extern "C" int paif_guided_filter_fused_fwd(const float* guide, const float* y, 
     const int frows = (H + nseg - 1) / nseg;
     const int ntiles = B * nstrip * nseg;
     const int grid = (ntiles + 7) / 8 * 16;
-    if (W % 4 == 0 && W >= 4)
-      hipLaunchKernelGGL(paif_gf_mfma::gf_mfma_kernel<true>, dim3(grid), dim3(256), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip, nseg,
-                         frows, ntiles);
+    const bool al4 = W % 4 == 0 && W >= 4;
+    if (al4 && !out_bf16)
+      hipLaunchKernelGGL((paif_gf_mfma::gf_mfma_kernel<true, false>), dim3(grid), dim3(256), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip,
+                         nseg, frows, ntiles);
+    else if (!out_bf16)
+      hipLaunchKernelGGL((paif_gf_mfma::gf_mfma_kernel<false, false>), dim3(grid), dim3(256), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip,
+                         nseg, frows, ntiles);
+    else if (al4)
+      hipLaunchKernelGGL((paif_gf_mfma::gf_mfma_kernel<true, true>), dim3(grid), dim3(256), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip,
+                         nseg, frows, ntiles);
     else
-      hipLaunchKernelGGL(paif_gf_mfma::gf_mfma_kernel<false>, dim3(grid), dim3(256), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip, nseg,
-                         frows, ntiles);
+      hipLaunchKernelGGL((paif_gf_mfma::gf_mfma_kernel<false, true>), dim3(grid), dim3(256), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip,
+                         nseg, frows, ntiles);
     PAIF_LAUNCH_CHECK("guided_filter_fused(mfma)");
   }
   int nseg;
@@ -537,10 +553,21 @@ extern "C" int paif_guided_filter_fused_fwd(const float* guide, const float* y, 
   const int frows = (H + nseg - 1) / nseg;
   const unsigned* only_if = engine == 1 ? flag : nullptr;
   const dim3 grid(B * nstrip * nseg, 2, zgroups);
-  if (form == 0) hipLaunchKernelGGL((gf_fused_kernel<float4, 8>), grid, dim3(FC * 8), 0, st, guide, y, workspace, only_if, lf, B, H, W, nstrip, nseg, frows);
-  else if (form == 1) hipLaunchKernelGGL((gf_fused_kernel<float4, 4>), grid, dim3(FC * 4), 0, st, guide, y, workspace, only_if, lf, B, H, W, nstrip, nseg, frows);
-  else if (form == 2) hipLaunchKernelGGL((gf_fused_kernel<float4, 2>), grid, dim3(FC * 2), 0, st, guide, y, workspace, only_if, lf, B, H, W, nstrip, nseg, frows);
-  else hipLaunchKernelGGL((gf_fused_kernel<float2, 16>), grid, dim3(FC * 16), 0, st, guide, y, workspace, only_if, lf, B, H, W, nstrip, nseg, frows);
+  if (form == 0) hipLaunchKernelGGL((gf_fused_kernel<float4, 8>), grid, dim3(FC * 8), 0, st, guide, y, workspace, only_if, lf, B, H, W, nstrip, nseg, frows, out_bf16);
+  else if (form == 1) hipLaunchKernelGGL((gf_fused_kernel<float4, 4>), grid, dim3(FC * 4), 0, st, guide, y, workspace, only_if, lf, B, H, W, nstrip, nseg, frows, out_bf16);
+  else if (form == 2) hipLaunchKernelGGL((gf_fused_kernel<float4, 2>), grid, dim3(FC * 2), 0, st, guide, y, workspace, only_if, lf, B, H, W, nstrip, nseg, frows, out_bf16);
+  else hipLaunchKernelGGL((gf_fused_kernel<float2, 16>), grid, dim3(FC * 16), 0, st, guide, y, workspace, only_if, lf, B, H, W, nstrip, nseg, frows, out_bf16);
   PAIF_LAUNCH_CHECK("guided_filter_fused");
   return 0;
+}
+
+extern "C" int paif_guided_filter_fused_fwd(const float* guide, const float* y, float* lf, float eps0, float eps1, float* workspace, int B,
+                                            int H, int W, paif_stream_t stream) {
+  return gf_fused_launch(guide, y, lf, eps0, eps1, workspace, B, H, W, 0, stream);
+}
+
+// same, the two low-frequency maps written as bf16 (`lf`: [2][B,H,W,32] unsigned short data): the bf16 configuration
+extern "C" int paif_guided_filter_fused_fwd_bf16(const float* guide, const float* y, float* lf, float eps0, float eps1, float* workspace, int B,
+                                                 int H, int W, paif_stream_t stream) {
+  return gf_fused_launch(guide, y, lf, eps0, eps1, workspace, B, H, W, 1, stream);
 }

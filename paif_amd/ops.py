@@ -399,23 +399,27 @@ def channel_residue(x):
     return g
 
 
-def guided_filter_pair(guide, y, eps=(0.001, 0.0001), want_ab=False):
+def guided_filter_pair(guide, y, eps=(0.001, 0.0001), want_ab=False, out_bf16=False):
     """Returns lf [2,B,H,W,32] for the two eps (r = 4) (and the coefficient maps ab [4,B,H,W,32] for the
-    backward pass).  AssertionError if H or W <= 9, like the reference's guided_filter_pytorch."""
+    backward pass).  AssertionError if H or W <= 9, like the reference's guided_filter_pytorch.
+    out_bf16 (inference, fused form): the two maps as bf16 -- the bf16 configuration's storage of the maps behind this block."""
     B, H, W, C = y.shape
     assert C == 32
     assert H > 9 and W > 9, "guided filter needs H, W > 2r+1 = 9"
-    lf = torch.empty((2, B, H, W, 32), device=y.device, dtype=torch.float32)
     L = lib()
     if not want_ab and CONFIG.get("gf_fused", True):
+        lf = torch.empty((2, B, H, W, 32), device=y.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
         ws = torch.empty(L.paif_guided_filter_fused_workspace_floats(B, H, W), device=y.device, dtype=torch.float32)
         import os
         tag = ("gf_fused_kernel" if os.environ.get("PAIF_GF_ENGINE") == "valu" else "gf_mfma_kernel") + " (+ gf_guide_stats_kernel)"
         e0 = TIMER.start(tag) if TIMER is not None else None
-        _lib.check(L.paif_guided_filter_fused_fwd(_p(guide), _p(y), _p(lf), eps[0], eps[1], _p(ws), B, H, W, _stream()), "guided_filter_fused")
+        fn = L.paif_guided_filter_fused_fwd_bf16 if out_bf16 else L.paif_guided_filter_fused_fwd
+        _lib.check(fn(_p(guide), _p(y), _pa(lf), eps[0], eps[1], _p(ws), B, H, W, _stream()), "guided_filter_fused")
         if e0 is not None:   # algorithmic traffic: guide + y read once, the two low-frequency maps written once; ~650 FLOP per pixel-channel
-            TIMER.stop(tag, e0, 650 * B * H * W * 32, 4 * B * H * W * (1 + 32 + 64))
+            TIMER.stop(tag, e0, 650 * B * H * W * 32, B * H * W * (4 * (1 + 32) + (2 if out_bf16 else 4) * 64))
         return lf
+    assert not out_bf16, "bf16 low-frequency maps are an inference (fused-form) output"
+    lf = torch.empty((2, B, H, W, 32), device=y.device, dtype=torch.float32)
     ab = torch.empty((4, B, H, W, 32), device=y.device, dtype=torch.float32)
     _lib.check(L.paif_guided_filter_ab_fwd(_p(guide), _p(y), _p(ab), eps[0], eps[1], B, H, W, _stream()), "guided_filter_ab")
     _lib.check(L.paif_guided_filter_lf_fwd(_p(guide), _p(ab), _p(lf), B, H, W, _stream()), "guided_filter_lf")

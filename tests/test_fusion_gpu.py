@@ -490,6 +490,33 @@ def test_guided_filter_matrix_core_engine_vs_valu_engine_and_oracle(shape):
         assert err_m <= max(2.0 * err_v, 2e-6), (shape, eps, err_m, err_v)      # as close to float64 as the fp32 direct sums
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 50, 131), (3, 37, 49), (1, 100, 47), (1, 130, 200)])
+@pytest.mark.parametrize("engine", ["mfma", "valu"])
+def test_guided_filter_bf16_output_is_the_rounded_fp32_output(shape, engine):
+    """The bf16-output form of the fused guided filter (paif_guided_filter_fused_fwd_bf16: the bf16 configuration's storage of the two
+    low-frequency maps; channel pairs exchanged by DPP and stored as dwords) computes the same fp32 values and rounds them to nearest
+    even -- bit-identical to the fp32-output kernel's result cast to bf16, both engines, ragged widths, the overflow fallback too."""
+    import os
+
+    from paif_amd import ops
+
+    B, H, W = shape
+    xn = ops.to_nhwc(t(S.make_smooth_feature(79, B, 32, H, W)).to(_dev()))
+    guide = ops.channel_residue(xn)
+    old = os.environ.get("PAIF_GF_ENGINE")
+    try:
+        os.environ["PAIF_GF_ENGINE"] = engine
+        for scale in (1.0, 3.0e4):                      # 3e4: a 9-row sum leaves the f16 range -> flag -> predicated VALU launch
+            a = ops.guided_filter_pair(guide, xn * scale)
+            b = ops.guided_filter_pair(guide, xn * scale, out_bf16=True)
+            assert b.dtype == torch.bfloat16 and torch.equal(b, a.to(torch.bfloat16)), (shape, engine, scale)
+    finally:
+        if old is None:
+            os.environ.pop("PAIF_GF_ENGINE", None)
+        else:
+            os.environ["PAIF_GF_ENGINE"] = old
+
+
 def test_guided_filter_f16_range_fallback():
     """A 9-row vertical sum beyond the f16 range (65504) cannot be split into an f16 pair: the matrix-core kernel raises its
     flag and the predicated all-VALU launch behind it rewrites the output -- bit-identical to the VALU engine."""
