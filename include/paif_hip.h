@@ -459,6 +459,18 @@ int paif_layernorm_wgrad(const float* x, const float* dy, float* dgamma, float* 
  * x, y: [B,1,H,W] planes.  window1d: the 11 fp32 Gaussian weights (sigma 1.5, normalised) as the reference builds them.
  * partial[2*blocks]: per-workgroup scratch; means[2] = (mean of the SSIM map, mean of |y - x|), reduced on the device in
  * block order (double). */
+/* ---- image-space attack losses (attack/attack.py:75-100, 132-133, 216-218) ---- */
+/* out[b][c] = x[b][c] * scale[c] + shift[c] on NCHW planes (shift may be NULL): trans_format = this on the SegFormer-normalised image
+ * ((s * sd + mean) / 255 = the min-max normalised RGB), and its adjoint. */
+int paif_channel_affine_nchw_fwd(const float* x, const float* scale, const float* shift, float* out, int B, int C, int H, int W,
+                                 paif_stream_t stream);
+/* nn.MSELoss (kind 0) / nn.L1Loss (kind 1), "mean" reduction, of a [B,C,H,W] against target [B,Ct,H,W], Ct = C or 1 (broadcast over the
+ * channels, as torch does).  partial: paif_image_loss_blocks() floats; loss: 1 float.  bwd: da = g * d loss / d a. */
+int paif_image_loss_blocks(void);
+int paif_image_loss_fwd(const float* a, const float* target, int kind, int B, int C, int Ct, int H, int W, float* partial, float* loss,
+                        paif_stream_t stream);
+int paif_image_loss_bwd(const float* a, const float* target, int kind, int B, int C, int Ct, int H, int W, float g, float* da,
+                        paif_stream_t stream);
 int paif_ssim_l1_blocks(int B, int H, int W);
 int paif_ssim_l1_fwd(const float* x, const float* y, const float* window1d, float* partial, float* means, int B, int H, int W,
                      paif_stream_t stream);

@@ -70,6 +70,10 @@ SIGNATURES = {
     "paif_gemm_wgrad": (c_int, [F, c_int, F, c_int, F, F, c_int, c_int, c_int, c_int, F, c_int, F]),
     "paif_layernorm_wgrad_blocks": (c_int, [c_int]),
     "paif_layernorm_wgrad": (c_int, [F, F, F, F, F, c_int, c_int, c_float, c_int, F]),
+    "paif_channel_affine_nchw_fwd": (c_int, [F, F, F, F, c_int, c_int, c_int, c_int, F]),
+    "paif_image_loss_blocks": (c_int, []),
+    "paif_image_loss_fwd": (c_int, [F, F, c_int, c_int, c_int, c_int, c_int, c_int, F, F, F]),
+    "paif_image_loss_bwd": (c_int, [F, F, c_int, c_int, c_int, c_int, c_int, c_int, c_float, F, F]),
     "paif_ssim_l1_blocks": (c_int, [c_int, c_int, c_int]),
     "paif_ssim_l1_fwd": (c_int, [F, F, F, F, F, c_int, c_int, c_int, F]),
     "paif_ssim_l1_bwd_input": (c_int, [F, F, F, F, F, F, c_int, c_int, c_int, F]),

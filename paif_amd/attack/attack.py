@@ -145,23 +145,15 @@ def attack_ir(model, X_vis, X_ir, X_fusion, label, epsilon=8 / 255., alpha=2 / 2
 # ---------------------------------------------------------------------------------------------
 # Single-modality attacks that neither entry script calls (attack/attack.py:117-411).
 # They take a FRESH gradient every iteration (torch.autograd.grad, no accumulation).  The model forward/backward is
-# the HIP autograd node; the loss glue on top (trans_format, masked / cosine losses) is torch on the device.
+# the HIP autograd node, and so is the loss glue on top (trans_format, image-space / masked / cosine losses: ops.TransFormat,
+# ops.ImageLoss, ops.AttackLoss).
 # fgsm_ir (:247-304) is not provided: it cannot run in the reference either (UnboundLocalError on `black_X` at :295
 # without the mask, undefined `map_generate3` in get_ir_mask (:232-244) with it).
 # ---------------------------------------------------------------------------------------------
 def trans_format(image_fusion, images_vis):
-    """attack/attack.py:75-100: recompose RGB from the fused Y + the visible Cr/Cb, clamp, global min-max (torch ops:
-    differentiable w.r.t. image_fusion; only the image-space losses l_2 / l_1 of the unused attacks need it)."""
-    with torch.no_grad():
-        ycc = ops.rgb2ycrcb(images_vis.contiguous())
-    mat = torch.tensor([[1.0, 1.0, 1.0], [1.403, -0.714, 0.0], [0.0, -0.344, 1.773]], device=image_fusion.device)
-    bias = torch.tensor([0.0 / 255, -0.5, -0.5], device=image_fusion.device)
-    x = torch.cat((image_fusion, ycc[:, 1:2], ycc[:, 2:]), dim=1)
-    B, _, H, W = x.shape
-    rgb = (x.permute(0, 2, 3, 1).reshape(-1, 3) + bias).mm(mat).reshape(B, H, W, 3).permute(0, 3, 1, 2)
-    rgb = torch.where(rgb > 1, torch.ones_like(rgb), rgb)
-    rgb = torch.where(rgb < 0, torch.zeros_like(rgb), rgb)
-    return (rgb - torch.min(rgb)) / (torch.max(rgb) - torch.min(rgb))
+    """attack/attack.py:75-100: recompose RGB from the fused Y + the visible Cr/Cb, clamp, global min-max -- a HIP autograd node
+    (ops.TransFormat: the composite model's own fusion->seg glue kernels + a per-channel affine), differentiable w.r.t. image_fusion."""
+    return ops.trans_format(image_fusion, images_vis)
 
 
 def _fresh_grad_attack(model, X_vis, X_ir, X_fusion, label, epsilon, alpha, attack_iters, restarts, mode, loss_fn, delta0):
@@ -190,11 +182,9 @@ def _image_or_seg_loss(attack_loss, X_vis, X_fusion, label, sign=1.0):
     if attack_loss == 'l_seg':
         # Seg_loss on the upsampled map (:134-135): the fused HIP upsample + CE node takes the low-resolution map directly
         return lambda fused, seg, i: ops.upsample_ce(seg, label.type(torch.long), ignore_index=255)
-    if attack_loss == 'l_2':
-        crit = nn.MSELoss()
-    elif attack_loss == 'l_1':
-        crit = nn.L1Loss()
-    elif attack_loss == 'l_ssim':
+    if attack_loss in ('l_2', 'l_1'):        # nn.MSELoss() / nn.L1Loss() on the recomposed image (:132-133): HIP loss + gradient kernels
+        return lambda fused, seg, i: ops.image_loss(trans_format(fused, X_vis), X_fusion, attack_loss, sign)
+    if attack_loss == 'l_ssim':
         # pytorch_ssim.SSIM()(robust_output, X_fusion) (attack/attack.py:136-137): every channel uses the same 11x11 window
         # and the result is the mean over everything, so [B,3,H,W] is evaluated as 3B single-channel images (HIP SSIM
         # forward / gradient kernels).  X_fusion must have the recomposed image's 3 channels, as in pytorch_ssim.

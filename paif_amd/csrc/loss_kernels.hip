@@ -212,3 +212,100 @@ extern "C" int paif_ssim_l1_fwd(const float* x, const float* y, const float* win
   PAIF_LAUNCH_CHECK("ssim_l1_finish");
   return 0;
 }
+
+
+// ---------------------------------------------------------------------------------------------------
+// Image-space attack losses (attack/attack.py:75-100, 132-133, 216-218: nn.MSELoss / nn.L1Loss on trans_format(fused, vis) against
+// X_fusion, "mean" reduction, the target broadcast over the channels when it has one) -- the glue of the single-modality attacks
+// that neither entry script calls, as HIP kernels so that those attacks are all-HIP too.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+// out[b][c][i] = x[b][c][i] * scale[c] + shift[c]   (NCHW planes; trans_format = this on the SegFormer-normalised image, and its adjoint)
+__global__ __launch_bounds__(256) void channel_affine_nchw_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, float* __restrict__ out, int C, size_t HW,
+                                                                  size_t total) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (int)((i / HW) % C);
+    out[i] = fmaf(x[i], scale[c], shift ? shift[c] : 0.f);
+  }
+}
+
+constexpr int IL_BLOCKS = 1024;
+// kind 0: (a - t)^2, kind 1: |a - t|; per-block partial sums in a fixed order, finished by one thread (deterministic)
+__global__ __launch_bounds__(256) void image_loss_kernel(const float* __restrict__ a, const float* __restrict__ t, int kind, int C, int Ct,
+                                                         size_t HW, size_t total, float* __restrict__ partial) {
+  float s = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t b = i / ((size_t)C * HW), r = i - b * (size_t)C * HW;
+    const size_t ti = Ct == C ? i : b * HW + (r % HW);
+    const float d = a[i] - t[ti];
+    s += kind == 0 ? d * d : fabsf(d);
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+  __shared__ float sw[4];
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+}
+__global__ void image_loss_finish_kernel(const float* __restrict__ partial, int n, float inv_n, float* __restrict__ loss) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += partial[i];
+    *loss = s * inv_n;
+  }
+}
+// da = g * d(mean loss)/da: kind 0: 2 (a - t) / n, kind 1: sign(a - t) / n   (g: the upstream scalar gradient x the caller's sign)
+__global__ __launch_bounds__(256) void image_loss_bwd_kernel(const float* __restrict__ a, const float* __restrict__ t, int kind, int C, int Ct,
+                                                             size_t HW, size_t total, float g_over_n, float* __restrict__ da) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t b = i / ((size_t)C * HW), r = i - b * (size_t)C * HW;
+    const size_t ti = Ct == C ? i : b * HW + (r % HW);
+    const float d = a[i] - t[ti];
+    da[i] = kind == 0 ? 2.f * d * g_over_n : (d > 0.f ? g_over_n : (d < 0.f ? -g_over_n : 0.f));
+  }
+}
+
+inline int il_grid(size_t total) {
+  const size_t g = (total + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > (size_t)IL_BLOCKS ? (size_t)IL_BLOCKS : g));
+}
+
+}  // namespace
+
+extern "C" int paif_channel_affine_nchw_fwd(const float* x, const float* scale, const float* shift, float* out, int B, int C, int H, int W,
+                                            paif_stream_t stream) {
+  PAIF_REQUIRE(x && scale && out && B > 0 && C > 0 && H > 0 && W > 0, PAIF_EINVAL, "channel_affine_nchw: bad arguments");
+  const size_t HW = (size_t)H * W, total = (size_t)B * C * HW;
+  hipLaunchKernelGGL(channel_affine_nchw_kernel, dim3(il_grid(total)), dim3(256), 0, paif::as_stream(stream), x, scale, shift, out, C, HW, total);
+  PAIF_LAUNCH_CHECK("channel_affine_nchw");
+  return 0;
+}
+
+extern "C" int paif_image_loss_blocks(void) { return IL_BLOCKS; }
+
+extern "C" int paif_image_loss_fwd(const float* a, const float* target, int kind, int B, int C, int Ct, int H, int W, float* partial, float* loss,
+                                   paif_stream_t stream) {
+  PAIF_REQUIRE(a && target && partial && loss && B > 0 && C > 0 && H > 0 && W > 0, PAIF_EINVAL, "image_loss: bad arguments");
+  PAIF_REQUIRE((kind == 0 || kind == 1) && (Ct == C || Ct == 1), PAIF_EINVAL, "image_loss: kind=%d, target channels %d vs %d", kind, Ct, C);
+  const size_t HW = (size_t)H * W, total = (size_t)B * C * HW;
+  const int g = il_grid(total);
+  hipStream_t st = paif::as_stream(stream);
+  hipLaunchKernelGGL(image_loss_kernel, dim3(g), dim3(256), 0, st, a, target, kind, C, Ct, HW, total, partial);
+  PAIF_LAUNCH_CHECK("image_loss");
+  hipLaunchKernelGGL(image_loss_finish_kernel, dim3(1), dim3(64), 0, st, partial, g, 1.0f / (float)total, loss);
+  PAIF_LAUNCH_CHECK("image_loss_finish");
+  return 0;
+}
+
+extern "C" int paif_image_loss_bwd(const float* a, const float* target, int kind, int B, int C, int Ct, int H, int W, float g, float* da,
+                                   paif_stream_t stream) {
+  PAIF_REQUIRE(a && target && da && B > 0 && C > 0 && H > 0 && W > 0, PAIF_EINVAL, "image_loss_bwd: bad arguments");
+  PAIF_REQUIRE((kind == 0 || kind == 1) && (Ct == C || Ct == 1), PAIF_EINVAL, "image_loss_bwd: kind=%d, target channels %d vs %d", kind, Ct, C);
+  const size_t HW = (size_t)H * W, total = (size_t)B * C * HW;
+  hipLaunchKernelGGL(image_loss_bwd_kernel, dim3(il_grid(total)), dim3(256), 0, paif::as_stream(stream), a, target, kind, C, Ct, HW, total,
+                     g / (float)total, da);
+  PAIF_LAUNCH_CHECK("image_loss_bwd");
+  return 0;
+}

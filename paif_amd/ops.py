@@ -1184,6 +1184,95 @@ def attack_loss(seg_map, label, attack_way, i, attack_iters):
     return attack_loss_fwd(to_nhwc(seg_map.detach()), label, way, wt, wf)[0]
 
 
+# ---- image-space attack losses (attack/attack.py:75-100, 132-133, 216-218): all-HIP autograd nodes ----
+_SEG_MEAN = (123.675, 116.28, 103.53)
+_SEG_STD = (58.395, 57.12, 57.375)
+_TF_CONST = {}
+
+
+def _tf_consts(device):
+    k = str(device)
+    if k not in _TF_CONST:
+        sd = torch.tensor([v / 255.0 for v in _SEG_STD], device=device, dtype=torch.float32)
+        mean = torch.tensor([v / 255.0 for v in _SEG_MEAN], device=device, dtype=torch.float32)
+        _TF_CONST[k] = (sd, mean)
+    return _TF_CONST[k]
+
+
+def channel_affine_nchw(x, scale, shift=None):
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    out = torch.empty_like(x)
+    _lib.check(lib().paif_channel_affine_nchw_fwd(_p(x), _p(scale), _p(shift), _p(out), B, C, H, W, _stream()), "channel_affine_nchw")
+    return out
+
+
+class TransFormat(torch.autograd.Function):
+    """attack/attack.py:75-100 `trans_format(image_fusion, images_vis)`: RGB from the fused Y and the visible image's Cr / Cb, clamp to
+    [0, 1], batch-global min-max -- the composite model's own fusion->seg glue without its mean / std step, so it is that glue
+    (paif_recompose_clamp_fwd + paif_minmax_normalize_fwd; backward paif_glue_bwd_input) and one per-channel affine each way."""
+
+    @staticmethod
+    def forward(ctx, fused, ycc):
+        fused = fused.detach().contiguous()
+        seg_in, mm = seg_input_from_fused(fused, ycc, return_minmax=True)
+        sd, mean = _tf_consts(fused.device)
+        ctx.save_for_backward(fused, ycc, mm)
+        return channel_affine_nchw(seg_in, sd, mean)          # (s * sd + mean) / 255 = (rgb - min) / (max - min)
+
+    @staticmethod
+    def backward(ctx, g):
+        fused, ycc, mm = ctx.saved_tensors
+        sd, _ = _tf_consts(fused.device)
+        dfused, _ = glue_bwd(channel_affine_nchw(g, sd), fused, ycc, mm)
+        return dfused, None
+
+
+def trans_format(fused, vis):
+    """fused [B,1,H,W] (may require grad), vis RGB [B,3,H,W] -> [B,3,H,W] in [0, 1]."""
+    with torch.no_grad():
+        ycc = rgb2ycrcb(vis.contiguous())
+    if torch.is_grad_enabled() and fused.requires_grad:
+        return TransFormat.apply(fused, ycc)
+    seg_in = seg_input_from_fused(fused.detach().contiguous(), ycc)
+    sd, mean = _tf_consts(fused.device)
+    return channel_affine_nchw(seg_in, sd, mean)
+
+
+class ImageLoss(torch.autograd.Function):
+    """sign * nn.MSELoss()(a, target) (kind 0) / nn.L1Loss() (kind 1), mean reduction, target [B,C,H,W] or [B,1,H,W] (broadcast)."""
+
+    @staticmethod
+    def forward(ctx, a, target, kind, sign):
+        a = a.detach().contiguous()
+        target = target.detach().contiguous()
+        B, C, H, W = a.shape
+        Ct = target.shape[1]
+        assert target.shape[0] == B and tuple(target.shape[2:]) == (H, W) and Ct in (1, C), (tuple(a.shape), tuple(target.shape))
+        L = lib()
+        partial = torch.empty(L.paif_image_loss_blocks(), device=a.device, dtype=torch.float32)
+        loss = torch.empty(1, device=a.device, dtype=torch.float32)
+        _lib.check(L.paif_image_loss_fwd(_p(a), _p(target), kind, B, C, Ct, H, W, _p(partial), _p(loss), _stream()), "image_loss")
+        ctx.save_for_backward(a, target)
+        ctx.args = (kind, sign)
+        return loss[0] * sign if sign != 1.0 else loss[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        a, target = ctx.saved_tensors
+        kind, sign = ctx.args
+        B, C, H, W = a.shape
+        da = torch.empty_like(a)
+        _lib.check(lib().paif_image_loss_bwd(_p(a), _p(target), kind, B, C, target.shape[1], H, W, float(g) * sign, _p(da), _stream()),
+                   "image_loss_bwd")
+        return da, None, None, None
+
+
+def image_loss(a, target, kind, sign=1.0):
+    """kind: "l_2" (MSE) or "l_1" (L1), as the reference's criteria; differentiable w.r.t. a."""
+    return ImageLoss.apply(a, target, {"l_2": 0, "l_1": 1}[kind], float(sign))
+
+
 def upsample_ce(seg_map, label, ignore_index=255):
     """seg_map [B,C,h,w] (any strides), label int64 [B,H,W] -> mean NLL over the valid pixels (differentiable w.r.t. seg_map)."""
     label = label.contiguous()

@@ -5,6 +5,8 @@ Parity metric for attacks (SURVEY.md 8(a) A1 -- sign(g) is discrete, so elementw
 test): loss trajectory rel. err, sign-mismatch fraction of the accumulated gradient, fraction of delta elements that
 differ, |delta| <= eps.  Gradients pass through A = cov/(var+1e-4): the reference's own fp32-vs-fp64 floor on
 d fused/d ir is 6e-3 at scale 1.7, so gradient tolerances are stated against an fp64 oracle run."""
+import warnings
+
 import numpy as np
 import pytest
 import torch
@@ -286,6 +288,52 @@ def test_single_modality_attacks(golden, name):
     a, ref = d.detach().cpu().numpy(), g[name + ".delta"]
     assert a.shape == ref.shape and np.abs(a).max() <= eps + 1e-7
     assert (np.abs(a - ref) > 1e-6).mean() <= 5e-3
+
+
+def _trans_format_torch(fused, vis):
+    """attack/attack.py:75-100 in plain torch ops (the test's fp32 reference of the HIP node)."""
+    ycc = ops.rgb2ycrcb(vis.contiguous())
+    mat = torch.tensor([[1.0, 1.0, 1.0], [1.403, -0.714, 0.0], [0.0, -0.344, 1.773]], device=fused.device)
+    bias = torch.tensor([0.0, -0.5, -0.5], device=fused.device)
+    x = torch.cat((fused, ycc[:, 1:2], ycc[:, 2:]), dim=1)
+    B, _, H, W = x.shape
+    rgb = (x.permute(0, 2, 3, 1).reshape(-1, 3) + bias).mm(mat).reshape(B, H, W, 3).permute(0, 3, 1, 2)
+    rgb = rgb.clamp(0, 1)
+    return (rgb - rgb.min()) / (rgb.max() - rgb.min())
+
+
+@pytest.mark.parametrize("kind", ["l_2", "l_1"])
+@pytest.mark.parametrize("ct", [3, 1])
+def test_image_space_loss_nodes(kind, ct):
+    """trans_format + nn.MSELoss / nn.L1Loss (attack/attack.py:75-100, 132-133) as HIP autograd nodes against torch autograd;
+    the target is the 3-channel recomposed image or the 1-channel fused image (broadcast, as torch does)."""
+    from paif_amd.attack.attack import trans_format
+
+    gen = torch.Generator().manual_seed(3)
+    B, H, W = 2, 40, 72
+    fused = (torch.rand(B, 1, H, W, generator=gen) * 1.3 - 0.15).to(_dev())     # some pixels leave [0, 1]: the clamp's gradient is 0
+    vis = torch.rand(B, 3, H, W, generator=gen).to(_dev())
+    target = torch.rand(B, ct, H, W, generator=gen).to(_dev())
+    crit = torch.nn.MSELoss() if kind == "l_2" else torch.nn.L1Loss()
+
+    f0 = fused.clone().requires_grad_(True)
+    tf0 = _trans_format_torch(f0, vis)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")                                           # torch warns about the broadcast target
+        l0 = -1.0 * crit(tf0, target)
+    g0, = torch.autograd.grad(l0, f0)
+
+    f1 = fused.clone().requires_grad_(True)
+    tf1 = trans_format(f1, vis)
+    l1 = ops.image_loss(tf1, target, kind, -1.0)
+    g1, = torch.autograd.grad(l1, f1)
+
+    assert maxabs(tf1.detach(), tf0.detach()) <= 5e-7
+    assert maxabs(trans_format(fused, vis), tf0.detach()) <= 5e-7               # the no-grad form
+    assert abs(float(l1) - float(l0)) <= 2e-6 * max(1.0, abs(float(l0)))
+    # the arg-min / arg-max pixels carry the min-max gradient (a sum over the image): compare at that scale
+    assert maxabs(g1, g0) <= 1e-5 * max(1e-6, float(g0.abs().max()))
+    assert float(g1.abs().max()) > 0
 
 
 def test_fgsm_ir_is_unrunnable_like_the_reference():
