@@ -191,6 +191,11 @@ int paif_pack_conv_weight(const float* w, float* wpk, int cout, int nsrc, int ci
 int paif_pack_conv_weight_bf16x3(const float* w, float* wpk, int cout, int nsrc, int kh, paif_stream_t stream);
 /* Three-piece packs for PAIF_CONV_BF16X6: 1.5 x paif_conv_wpk_floats(...) floats. */
 int paif_pack_conv_weight_bf16x6(const float* w, float* wpk, int cout, int nsrc, int kh, paif_stream_t stream);
+/* dw [cin][1][kh][kh] (depthwise) and pw [cout][cin][1][1] (the 1x1 behind it) -> out [cout][cin][kh][kh] = pw * dw: the dense
+ * kernel of  conv1x1(dwconv(x))  (operations_m.py:494-506 DilConv: ReLU -> depthwise -> conv1x1 -> BN), packed afterwards with
+ * paif_pack_conv_weight*.  Used by the bf16 inference forward: one paif_conv2d_fwd (in_act = ReLU) instead of
+ * paif_dwconv_fwd_bf16 + a 1x1, the depthwise map never goes to HBM. */
+int paif_compose_dw_pw_weight(const float* dw, const float* pw, float* out, int cout, int cin, int kh, paif_stream_t stream);
 int paif_pack_decomp1x1_weight_bf16x6(const float* w, float* wpk, paif_stream_t stream);
 int paif_pack_decomp1x1_weight_bf16x3(const float* w, float* wpk, paif_stream_t stream);
 /* Cell_Decom's 1x1 over cat[LF1,LF2,x-LF1,x-LF2] (core/model_fusion_auto.py:512-513) folded to a 1x1

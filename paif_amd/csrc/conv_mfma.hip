@@ -718,6 +718,14 @@ __device__ __forceinline__ void split_raw(float4 t, uint2& hi, uint2& lo) { spli
 __device__ __forceinline__ void split_raw(uint2 t, uint2& hi, uint2& lo) { hi = t; lo = make_uint2(0u, 0u); }
 __device__ __forceinline__ float4 raw_zero(float4) { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ uint2 raw_zero(uint2) { return make_uint2(0u, 0u); }
+// ReLU of a staged quad.  bf16 pairs: as signed 16-bit integers every negative value (sign bit) is below 0 -- one packed max
+__device__ __forceinline__ float4 raw_relu(float4 t) { return make_float4(fmaxf(t.x, 0.f), fmaxf(t.y, 0.f), fmaxf(t.z, 0.f), fmaxf(t.w, 0.f)); }
+__device__ __forceinline__ uint2 raw_relu(uint2 t) {
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  const s16x2 z = {0, 0};
+  const s16x2 a = __builtin_elementwise_max(__builtin_bit_cast(s16x2, t.x), z), b = __builtin_elementwise_max(__builtin_bit_cast(s16x2, t.y), z);
+  return make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+}
 
 // ---------------------------------------------------------------------------------------------------
 // Multi-source form of the tile-per-workgroup split-bf16 kernel (forward, no hooks, no in-activation, cout == 32):
@@ -1318,12 +1326,13 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_bf16x3_ws(ConvArgs a, int 
       }
       mask = m;
     };
+    const bool in_relu = a.in_act == 2;   // launch-uniform
     auto commit = [&](int st, const raw_t (&v)[NIT], unsigned mask) {
       char* buf = ldsb + (st & 1) * TILE_BYTES;
 #pragma unroll
       for (int u = 0; u < NIT; ++u) {
         uint2 hi, lo;
-        split_raw(v[u], hi, lo);
+        split_raw(in_relu ? raw_relu(v[u]) : v[u], hi, lo);
         if (!((mask >> u) & 1u)) hi = lo = make_uint2(0u, 0u);
         if (u < NIT - 1 || live_last) {
           *reinterpret_cast<uint2*>(buf + ldo[u]) = hi;
@@ -1539,7 +1548,7 @@ static inline bool ws_enabled() {
   return on;
 }
 static inline bool ws_eligible(const ConvArgs& a) {
-  return ws_enabled() && a.nblk >= 1024 && !a.pool_partial && a.cout == 32 && a.in_act == 0 &&
+  return ws_enabled() && a.nblk >= 1024 && !a.pool_partial && a.cout == 32 && (a.in_act == 0 || a.in_act == 2) &&
          (size_t)a.H * a.W * 128 < ((size_t)1 << 32);
 }
 
@@ -1571,8 +1580,8 @@ static inline bool needs_hooks(const ConvArgs& a) { return a.in_act >= 3 || a.au
 static inline bool takes_ws(const ConvArgs& a, int kh, int dil) {
 #if PAIF_TH == 8
   if (needs_hooks(a) || kh > 3 || !ws_eligible(a)) return false;
-  if (kh == 1) return !a.res[0];
-  return dil == 2 && a.nsrc == 1;
+  if (kh == 1) return !a.res[0] && a.in_act == 0;
+  return dil == 2 && a.nsrc == 1;   // in_act: none or ReLU (the composed DilConv)
 #else
   return false;
 #endif
@@ -1690,6 +1699,16 @@ __global__ void pack_weight_bf16x3_kernel(const float* __restrict__ w, unsigned 
     const __bf16 hi = (__bf16)v;
     const __bf16 out = part == 0 ? hi : (__bf16)(v - (float)hi);
     wpk[idx] = __builtin_bit_cast(unsigned short, out);
+  }
+}
+
+// depthwise k x k followed by a 1x1 (operations_m.py:494-506 DilConv) as ONE dense k x k conv: W[co][ci][tap] = pw[co][ci] * dw[ci][tap]
+__global__ void compose_dw_pw_kernel(const float* __restrict__ dw, const float* __restrict__ pw, float* __restrict__ out, int cout,
+                                     int cin, int ntap) {
+  const int total = cout * cin * ntap;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int tap = idx % ntap, ci = (idx / ntap) % cin, co = idx / (ntap * cin);
+    out[idx] = pw[co * cin + ci] * dw[ci * ntap + tap];
   }
 }
 
@@ -1978,6 +1997,14 @@ int paif_pack_conv_weight_bf16x6(const float* w, float* wpk, int cout, int nsrc,
   hipLaunchKernelGGL(pack_weight_bf16x6_kernel, dim3((total + 255) / 256), dim3(256), 0, paif::as_stream(stream), w,
                      reinterpret_cast<unsigned short*>(wpk), cout, nsrc, kh);
   PAIF_LAUNCH_CHECK("pack_conv_weight_bf16x6");
+  return 0;
+}
+
+int paif_compose_dw_pw_weight(const float* dw, const float* pw, float* out, int cout, int cin, int kh, paif_stream_t stream) {
+  PAIF_REQUIRE(dw && pw && out && cout >= 1 && cin >= 1 && kh >= 1 && kh <= 7, PAIF_EINVAL, "compose_dw_pw_weight: bad arguments");
+  const int total = cout * cin * kh * kh;
+  hipLaunchKernelGGL(compose_dw_pw_kernel, dim3((total + 255) / 256), dim3(256), 0, paif::as_stream(stream), dw, pw, out, cout, cin, kh * kh);
+  PAIF_LAUNCH_CHECK("compose_dw_pw_weight");
   return 0;
 }
 

@@ -14,10 +14,8 @@ inline int grid_for(size_t work_items, int per_block) {
   return (int)g;
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float gelu_grad(float x) {
-  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
-}
+__device__ __forceinline__ float gelu_erf(float x) { return paif::gelu_erf_fast(x); }   // paif_common.h: branch-free erf, <= 1.2 ulp
+__device__ __forceinline__ float gelu_grad(float x) { return paif::gelu_grad_fast(x); }
 
 // ---------------------------------------------------------------------------------------------
 // LayerNorm backward w.r.t. the input:  dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
@@ -156,6 +154,78 @@ __global__ __launch_bounds__(256) void dwconv3_bwd_kernel(const float* __restric
       o = make_float4(d4.x * gelu_grad(acc.x), d4.y * gelu_grad(acc.y), d4.z * gelu_grad(acc.z), d4.w * gelu_grad(acc.w));
     }
     *reinterpret_cast<float4*>(y + pix * C + q * 4) = o;
+  }
+}
+
+// Row-walking form of the same two passes (C % 256 == 0; seg_kernels.hip dwconv3_bias_gelu_rows_kernel has the forward): a lane
+// owns one channel quad of one column and walks BR_ROWS output rows, the 3-row x 3-tap window in registers (static slots) --
+// 3 loads per output instead of 9 and no per-pixel 64-bit div / mod.
+#ifndef PAIF_DW_ROWS
+#define PAIF_DW_ROWS 8
+#endif
+#ifndef PAIF_DW_AHEAD
+#define PAIF_DW_AHEAD 2
+#endif
+constexpr int BR_ROWS = PAIF_DW_ROWS, BR_COLS = 4, BR_AHEAD = PAIF_DW_AHEAD;
+template <int MODE>
+__global__ __launch_bounds__(256) void dwconv3_bwd_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, const float* __restrict__ dy,
+                                                               float* __restrict__ y, int B, int H, int W, int C, int qchunks, int ctiles,
+                                                               int strips) {
+  int t = blockIdx.x;
+  const int qc = t % qchunks; t /= qchunks;
+  const int ct = t % ctiles; t /= ctiles;
+  const int st = t % strips;
+  const int b = t / strips;
+  const int q = qc * 64 + (threadIdx.x & 63);
+  const int xx0 = ct * BR_COLS + (threadIdx.x >> 6);
+  float wr[4][9];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wr[c][k] = w[(size_t)(4 * q + c) * 9 + (MODE == 2 ? 8 - k : k)];
+  float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (MODE == 1) b4 = *reinterpret_cast<const float4*>(bias + 4 * q);
+  const int ybeg = st * BR_ROWS, yend = min(H, ybeg + BR_ROWS);
+  const bool colv = xx0 < W;
+  const int xc[3] = {min(max(xx0 - 1, 0), W - 1), min(xx0, W - 1), min(xx0 + 1, W - 1)};
+  const bool xok[3] = {xx0 - 1 >= 0, true, xx0 + 1 < W};
+  const float* img = x + (size_t)b * H * W * C + q * 4;
+  constexpr int NW = 3 + BR_AHEAD;        // slot (row + 1 - ybeg) % NW holds input row `row`
+  float4 win[NW][3];
+  auto load_row = [&](int yy, float4 (&dst)[3]) {
+    const int yc = min(max(yy, 0), H - 1);
+    const bool rok = yy >= 0 && yy < H;
+#pragma unroll
+    for (int dx_ = 0; dx_ < 3; ++dx_) {
+      float4 v = *reinterpret_cast<const float4*>(img + ((size_t)yc * W + xc[dx_]) * C);      // unconditional, clamped
+      if (!(rok && xok[dx_])) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      dst[dx_] = v;
+    }
+  };
+#pragma unroll
+  for (int s = 0; s < NW - 1; ++s) load_row(ybeg - 1 + s, win[s]);
+  const size_t ooff = ((size_t)b * H * W + min(xx0, W - 1)) * C + q * 4;
+#pragma unroll
+  for (int i = 0; i < BR_ROWS; ++i) {
+    const int yy = ybeg + i;
+    if (yy >= yend) break;                                     // workgroup-uniform
+    load_row(yy + 1 + BR_AHEAD, win[(i + NW - 1) % NW]);
+    float4 d4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (MODE == 1) d4 = *reinterpret_cast<const float4*>(dy + ooff + (size_t)min(yy, H - 1) * W * C);   // unconditional, clamped
+    float4 acc = b4;
+#pragma unroll
+    for (int dy_ = 0; dy_ < 3; ++dy_)
+#pragma unroll
+      for (int dx_ = 0; dx_ < 3; ++dx_) {
+        const float4 v = win[(i + dy_) % NW][dx_];
+        const int k = dy_ * 3 + dx_;
+        acc.x = fmaf(v.x, wr[0][k], acc.x); acc.y = fmaf(v.y, wr[1][k], acc.y);
+        acc.z = fmaf(v.z, wr[2][k], acc.z); acc.w = fmaf(v.w, wr[3][k], acc.w);
+      }
+    float4 o = acc;
+    if (MODE == 1) o = make_float4(d4.x * gelu_grad(acc.x), d4.y * gelu_grad(acc.y), d4.z * gelu_grad(acc.z), d4.w * gelu_grad(acc.w));
+    if (colv) *reinterpret_cast<float4*>(y + ooff + (size_t)yy * W * C) = o;
   }
 }
 
@@ -362,6 +432,16 @@ int paif_dwconv3_bias_gelu_bwd_input(const float* x, const float* w, const float
   const int pix_per_block = (int)((npix + pblocks - 1) / pblocks);
   pblocks = (npix + pix_per_block - 1) / pix_per_block;
   hipStream_t st = paif::as_stream(stream);
+  if (C % 256 == 0) {
+    const int ctiles = (W + BR_COLS - 1) / BR_COLS, strips = (H + BR_ROWS - 1) / BR_ROWS;
+    const size_t nblk = (size_t)B * strips * ctiles * qchunks;
+    PAIF_REQUIRE(nblk < ((size_t)1 << 31), PAIF_EINVAL, "dwconv3_bias_gelu_bwd: %dx%dx%dx%d is too large for one launch", B, H, W, C);
+    hipLaunchKernelGGL(dwconv3_bwd_rows_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, st, x, w, bias, dy, tmp, B, H, W, C, qchunks, ctiles, strips);
+    PAIF_LAUNCH_CHECK("dwconv3_bias_gelu_bwd(1)");
+    hipLaunchKernelGGL(dwconv3_bwd_rows_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, st, tmp, w, bias, dy, dx, B, H, W, C, qchunks, ctiles, strips);
+    PAIF_LAUNCH_CHECK("dwconv3_bias_gelu_bwd(2)");
+    return 0;
+  }
   hipLaunchKernelGGL(dwconv3_bwd_kernel<1>, dim3((unsigned)(pblocks * qchunks)), dim3(256), 0, st, x, w, bias, dy, tmp, B, H, W, C,
                      pix_per_block);
   PAIF_LAUNCH_CHECK("dwconv3_bias_gelu_bwd(1)");

@@ -446,6 +446,17 @@ def pack_conv_weight(w, nsrc, cin, kh, precision=None):
     return PackedWeight(wpk, precision)
 
 
+def compose_dw_pw_weight(dw, pw):
+    """dw [C,1,k,k] (depthwise), pw [Co,C,1,1] -> [Co,C,k,k]: the dense kernel of conv1x1(dwconv(.)) (operations_m.py:494-506)."""
+    C, _, k, _ = dw.shape
+    Co = pw.shape[0]
+    assert tuple(dw.shape) == (C, 1, k, k) and tuple(pw.shape) == (Co, C, 1, 1)
+    out = torch.empty((Co, C, k, k), device=dw.device, dtype=torch.float32)
+    _lib.check(lib().paif_compose_dw_pw_weight(_p(dw.detach().contiguous()), _p(pw.detach().contiguous()), _p(out), Co, C, k, _stream()),
+               "compose_dw_pw_weight")
+    return out
+
+
 def pack_decomp1x1_weight(w, precision=None):
     assert tuple(w.shape) == (32, 128, 1, 1)
     precision = precision or CONFIG["conv_precision"]

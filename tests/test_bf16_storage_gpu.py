@@ -241,6 +241,43 @@ def test_elementwise_kernels_bf16_storage():
     assert maxabs(ops.tail(tb, wt, slope), ops.tail(t32, wt, slope)) == 0.0                    # fp32 output from identical values
 
 
+@pytest.mark.parametrize("mode", ["bf16_split", "bf16"])
+@pytest.mark.parametrize("nres", [0, 2])
+def test_dilconv_as_one_dense_conv(mode, nres):
+    """operations_m.py:494-506 DilConv (ReLU -> depthwise 3x3 dil 2 -> conv1x1 -> BN, + x) in the bf16 inference forward: ONE dense
+    dilated conv with the composed weight pw[co][ci] * dw[ci][tap].  Reference: the module's fp32-storage forward (exact depthwise in
+    fp32, then the 1x1).  Bound: the rounding of the bf16 output plus, in mode bf16, that of the composed bf16 weights over the 288
+    products (statistical: a few 2^-9 of the accumulated magnitude) -- and never worse than 1.25 x the two-kernel bf16 path's error."""
+    from paif_amd.operations_m import DilConv
+
+    dev = _dev()
+    B, H, W = 2, 150, 210
+    g = torch.Generator().manual_seed(23)
+    m = DilConv(32, 32, 3, 2, affine=True).eval()
+    sd = m.state_dict()
+    for k_, v in sd.items():
+        if v.dtype.is_floating_point:
+            r = torch.randn(v.shape, generator=g)
+            sd[k_] = (r.abs() + 0.5) if k_.endswith("running_var") else r * (0.3 if "weight" in k_ and v.dim() == 4 else 0.5)
+    m.load_state_dict(sd)
+    m = m.to(dev)
+    x32, xb = _rounded(ops.to_nhwc(torch.randn(B, 32, H, W, generator=g).to(dev)))
+    res32, resb = zip(*[_rounded(ops.to_nhwc(torch.randn(B, 32, H, W, generator=g).to(dev))) for _ in range(nres)]) if nres else ((), ())
+    ref = m.forward_nhwc(x32, res=tuple(res32))
+    assert ref.dtype == torch.float32
+    ops.set_storage(mode)
+    ops.CONFIG["dilconv_dense"] = False
+    two = m.forward_nhwc(xb, res=tuple(resb))
+    ops.CONFIG["dilconv_dense"] = True
+    one = m.forward_nhwc(xb, res=tuple(resb))
+    assert one.dtype == torch.bfloat16 and two.dtype == torch.bfloat16
+    e_one, e_two = (one.float() - ref).abs(), (two.float() - ref).abs()
+    scale = float(ref.abs().mean())
+    assert float(e_one.mean()) <= 1.25 * float(e_two.mean()) + 1e-7, (float(e_one.mean()), float(e_two.mean()))
+    assert float(e_one.max()) <= 2.0 ** -6 * float(ref.abs().max()), (float(e_one.max()), float(ref.abs().max()))
+    assert float(e_one.mean()) <= 2.0 ** -8 * scale, (float(e_one.mean()), scale)
+
+
 def _fusion_net():
     from paif_amd.core.model_fusion_auto import Network_Fusion_Searched
     from paif_amd.genotypes import FUSION_AT

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from paif_amd import synthetic as S
+from paif_amd import ops, synthetic as S
 from tests import helpers as Hh
 from tests.helpers import t, maxabs
 
@@ -153,6 +153,31 @@ def test_graph_capture_replay_is_bit_identical():
     assert torch.equal(f_e, f_g) and torch.equal(s_e, s_g)
     with pytest.raises(ValueError):
         g(ir2[:, :, :32], vis2)
+
+
+@pytest.mark.parametrize("shape", [(2, 15, 20, 2048), (2, 30, 40, 1280), (1, 37, 53, 256), (3, 5, 3, 512), (1, 13, 9, 64), (2, 7, 11, 40)])
+def test_mlp_dwconv_bias_gelu_vs_torch(shape):
+    """Mlp.dwconv (3x3 depthwise, bias) + GELU (core/mix_transformer.py:376-387, :49) against F.conv2d(groups=C) + F.gelu in fp32:
+    the row-walking kernel (C % 256 == 0; ragged heights / widths, fewer rows than a strip) and the per-pixel one (other widths)."""
+    B, H, W, C = shape
+    g = torch.Generator().manual_seed(H * W + C)
+    x = torch.randn(B, H * W, C, generator=g).to(_dev()) * 1.5
+    w = (torch.randn(C, 1, 3, 3, generator=g) * 0.4).to(_dev())
+    bias = (torch.randn(C, generator=g) * 0.3).to(_dev())
+    out = ops.dwconv3_bias_gelu(x.reshape(B, H, W, C), w, bias)
+    ref = torch.nn.functional.gelu(torch.nn.functional.conv2d(x.reshape(B, H, W, C).permute(0, 3, 1, 2), w, bias, padding=1, groups=C))
+    ref = ref.permute(0, 2, 3, 1)
+    assert out.shape == ref.shape
+    assert maxabs(out, ref) <= 2e-6 * max(1.0, float(ref.abs().max()))
+    # input gradient (and the gradient at the conv output, the operand of the weight / bias gradients) against torch autograd
+    xr = x.reshape(B, H, W, C).clone().requires_grad_(True)
+    pre = torch.nn.functional.conv2d(xr.permute(0, 3, 1, 2), w, bias, padding=1, groups=C)
+    pre.retain_grad()
+    dy = torch.randn(B, H, W, C, generator=g).to(_dev())
+    (torch.nn.functional.gelu(pre).permute(0, 2, 3, 1) * dy).sum().backward()
+    dx, dpre = ops.dwconv3_bias_gelu_bwd(x.reshape(B, H, W, C), w, bias, dy, want_dpre=True)
+    assert maxabs(dpre, pre.grad.permute(0, 2, 3, 1)) <= 3e-6 * max(1.0, float(pre.grad.abs().max()))
+    assert maxabs(dx, xr.grad) <= 3e-6 * max(1.0, float(xr.grad.abs().max()))
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 512, 2048), (1201, 320, 64), (4803, 64, 256), (77, 9, 256), (19200, 64, 64),
