@@ -1250,8 +1250,8 @@ static inline bool ms_enabled() {
 
 constexpr int WS_THREADS = 12 * 64;
 
-template <int KH, int DIL, int ST = 0>
-__global__ __launch_bounds__(WS_THREADS, 1) void conv_bf16x3_ws(ConvArgs a, int ntiles) {
+template <int KH, int DIL, int ST, bool RELU>
+__device__ __forceinline__ void conv_ws_body(const ConvArgs& a, int ntiles) {
   constexpr int BFI = paif::st_in(ST), BFO = paif::st_out(ST);
   constexpr unsigned ES = BFI ? 2u : 4u;               // bytes per stored input element
   typedef typename RawQ<BFI>::T raw_t;
@@ -1326,13 +1326,13 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_bf16x3_ws(ConvArgs a, int 
       }
       mask = m;
     };
-    const bool in_relu = a.in_act == 2;   // launch-uniform
     auto commit = [&](int st, const raw_t (&v)[NIT], unsigned mask) {
       char* buf = ldsb + (st & 1) * TILE_BYTES;
 #pragma unroll
       for (int u = 0; u < NIT; ++u) {
         uint2 hi, lo;
-        split_raw(in_relu ? raw_relu(v[u]) : v[u], hi, lo);
+        if constexpr (RELU) split_raw(raw_relu(v[u]), hi, lo);   // in_act = ReLU: the composed DilConv (conv_bf16x3_wsr)
+        else split_raw(v[u], hi, lo);
         if (!((mask >> u) & 1u)) hi = lo = make_uint2(0u, 0u);
         if (u < NIT - 1 || live_last) {
           *reinterpret_cast<uint2*>(buf + ldo[u]) = hi;
@@ -1520,19 +1520,40 @@ __global__ __launch_bounds__(WS_THREADS, 1) void conv_bf16x3_ws(ConvArgs a, int 
 }
 
 template <int KH, int DIL, int ST = 0>
+__global__ __launch_bounds__(WS_THREADS, 1) void conv_bf16x3_ws(ConvArgs a, int ntiles) { conv_ws_body<KH, DIL, ST, false>(a, ntiles); }
+// the same kernel with ReLU on the loaded tile (in_act = 2): DilConv of the bf16 forward as one dense dilated conv
+template <int KH, int DIL, int ST = 0>
+__global__ __launch_bounds__(WS_THREADS, 1) void conv_bf16x3_wsr(ConvArgs a, int ntiles) { conv_ws_body<KH, DIL, ST, true>(a, ntiles); }
+
+template <int KH, int DIL, int ST = 0>
 int launch_bf16x3_ws(const ConvArgs& a, hipStream_t st) {
   constexpr int P = DIL * (KH - 1) / 2;
   constexpr size_t lds_bytes = 2 * (size_t)(TH + 2 * P) * (TW + 2 * P) * 144 + 8 * 32 * 32 * 4;
   static_assert(lds_bytes <= 160 * 1024, "two tile buffers + the parked tile do not fit LDS");
   static bool raised = false;   // once per instantiation (one device per process)
+  constexpr bool HAS_RELU = KH == 3 && DIL == 2 && paif::st_in(ST) == 1;   // the ReLU form is built for the bf16-stored dilated 3x3
   if (!raised) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_ws<KH, DIL, ST>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if constexpr (HAS_RELU) {
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_wsr<KH, DIL, ST>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes);
+    }
     if (e != hipSuccess) {
       paif::set_error("conv2d(bf16x3 ws): cannot raise dynamic LDS to %zu: %s", lds_bytes, hipGetErrorString(e));
       return (int)e;
     }
     raised = true;
+  }
+  if (a.in_act == 2) {
+    if constexpr (HAS_RELU) {
+      hipLaunchKernelGGL((conv_bf16x3_wsr<KH, DIL, ST>), dim3(256), dim3(WS_THREADS), lds_bytes, st, a, a.nblk);
+      PAIF_LAUNCH_CHECK("conv2d(bf16x3 wsr)");
+      return 0;
+    }
+    paif::set_error("conv2d(bf16x3 ws): input ReLU is built for the bf16-stored dilation-2 3x3 only");
+    return PAIF_ENOSUP;
   }
   hipLaunchKernelGGL((conv_bf16x3_ws<KH, DIL, ST>), dim3(256), dim3(WS_THREADS), lds_bytes, st, a, a.nblk);
   PAIF_LAUNCH_CHECK("conv2d(bf16x3 ws)");
@@ -1548,7 +1569,7 @@ static inline bool ws_enabled() {
   return on;
 }
 static inline bool ws_eligible(const ConvArgs& a) {
-  return ws_enabled() && a.nblk >= 1024 && !a.pool_partial && a.cout == 32 && (a.in_act == 0 || a.in_act == 2) &&
+  return ws_enabled() && a.nblk >= 1024 && !a.pool_partial && a.cout == 32 && (a.in_act == 0 || (a.in_act == 2 && a.st == 1)) &&
          (size_t)a.H * a.W * 128 < ((size_t)1 << 32);
 }
 
@@ -1888,7 +1909,7 @@ int paif_conv2d_kernel_name(const paif_conv_desc* d, int B, int H, int W, char* 
       if (d->kh == 7) snprintf(buf, buflen, "conv7x7_bf16_dma");
       else snprintf(buf, buflen, "conv3x3_bf16_dma<%d, %d>", d->nsrc, res_count(a));
       break;
-    case CV_WS: snprintf(buf, buflen, "conv_bf16x3_ws<%d, %d, %d>", d->kh, d->dil, code); break;
+    case CV_WS: snprintf(buf, buflen, "conv_bf16x3_ws%s<%d, %d, %d>", d->in_act == 2 ? "r" : "", d->kh, d->dil, code); break;
     case CV_RES: snprintf(buf, buflen, "conv_bf16x3_res<%d, %d, %d, %d, %d>", d->kh, d->dil, d->nsrc, PAIF_RES_ROWS, code); break;
     case CV_MS: snprintf(buf, buflen, "conv_bf16x3_ms<%d, %d, %d, %d>", d->kh, d->dil, d->nsrc, code); break;
     case CV_HOOKS: snprintf(buf, buflen, "conv_mfma_bf16x3<%d, %d, true, %d, 2>", d->kh, d->dil, code); break;

@@ -92,6 +92,7 @@ def test_dense_conv_dispatch_rules_on_the_host():
         for i in range(3):
             d.src[i] = one if i < kw.get("nsrc", 1) else None
         d.nsrc, d.cin, d.cout, d.kh, d.dil, d.precision, d.storage = kw.get("nsrc", 1), 32, 32, d_kh, kw.get("dil", 1), 1, st
+        d.in_act = kw.get("in_act", 0)
         d.wpk, d.out = one, one
         buf = ctypes.create_string_buffer(96)
         assert L.paif_conv2d_kernel_name(ctypes.byref(d), 8, 480, 640, buf, len(buf)) == 0
@@ -99,6 +100,9 @@ def test_dense_conv_dispatch_rules_on_the_host():
 
     assert name_st(1, nsrc=3) == "conv_bf16x3_ms<3, 1, 3, 1>"
     assert name_st(2, kh=1, nsrc=3) == "conv_bf16x3_ws<1, 1, 2>"
+    assert name_st(1, dil=2) == "conv_bf16x3_ws<3, 2, 1>"
+    assert name_st(1, dil=2, in_act=2) == "conv_bf16x3_wsr<3, 2, 1>"            # input ReLU: the composed DilConv of the bf16 forward
+    assert name(kh=3, dil=2, nsrc=1, in_act=2) == "conv_mfma_bf16x3<3, 2, false, 0, 2>"   # fp32 storage: no ReLU form of the persistent kernel
     # exact arithmetic
     assert name(precision=0) == "conv_mfma_f32<3, 1, 32, false>"
     assert name(precision=0, cin=16, cout=16) == "conv_mfma_f32<3, 1, 16, false>"
