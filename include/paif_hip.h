@@ -196,6 +196,15 @@ int paif_pack_conv_weight_bf16x6(const float* w, float* wpk, int cout, int nsrc,
  * paif_pack_conv_weight*.  Used by the bf16 inference forward: one paif_conv2d_fwd (in_act = ReLU) instead of
  * paif_dwconv_fwd_bf16 + a 1x1, the depthwise map never goes to HBM. */
 int paif_compose_dw_pw_weight(const float* dw, const float* pw, float* out, int cout, int cin, int kh, paif_stream_t stream);
+
+/* stem_out of the fusion network (core/model_fusion_auto.py:616-620, :640: conv3x3 32->16, conv3x3 16->1, PReLU, tanh) on a bf16-stored
+ * NHWC-32 map as one launch pair: the two linear convs composed into a 5x5 32->1 conv evaluated on the matrix cores with the TAPS as the
+ * M dimension (three-piece bf16 weights: fp32-level products), and the outermost pixel ring -- where the reference's zero padding of the
+ * 16-channel map breaks the composition -- corrected by its closed-form surplus (5-tap edge convs).  paif_stem_out_pack builds the weights
+ * (paif_stem_out_pack_floats() floats) from w1 [16][32][3][3] and w2 [1][16][3][3].  x: bf16 data behind the float*; fused [B][1][H][W] fp32. */
+int paif_stem_out_pack_floats(void);
+int paif_stem_out_pack(const float* w1, const float* w2, float* wpk, paif_stream_t stream);
+int paif_stem_out_fwd_bf16(const float* x, const float* wpk, const float* prelu, float* fused, int B, int H, int W, paif_stream_t stream);
 int paif_pack_decomp1x1_weight_bf16x6(const float* w, float* wpk, paif_stream_t stream);
 int paif_pack_decomp1x1_weight_bf16x3(const float* w, float* wpk, paif_stream_t stream);
 /* Cell_Decom's 1x1 over cat[LF1,LF2,x-LF1,x-LF2] (core/model_fusion_auto.py:512-513) folded to a 1x1

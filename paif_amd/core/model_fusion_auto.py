@@ -323,6 +323,12 @@ class Network_Fusion_Searched(nn.Module):
         else:
             agg, scale = self.spa.blend_nhwc(ir_feature, vis_feature, want_scale=True)
         feature2 = self.chain.forward_nhwc(agg, (), t_chain)
+        if (tape is None and inter is None and feature2.dtype == torch.bfloat16 and feature2.shape[1] >= 3 and feature2.shape[2] >= 3
+                and ops.CONFIG.get("stem_out_fused", True)):
+            # bf16 inference forward: both stem_out convs + PReLU + tanh as one launch pair (csrc/stem_out.hip)
+            so = self.stem_out
+            wso = self._packs.get("so_fused", [so[0].weight, so[1].weight], lambda: ops.stem_out_pack(so[0].weight, so[1].weight))
+            return ops.stem_out_fused(feature2, wso, so[2].weight)
         w0 = self._packs.get("so0", [self.stem_out[0].weight], lambda: ops.pack_conv_weight(self.stem_out[0].weight, 1, 32, 3))
         t16 = ops.conv2d([feature2], w0, 3, 1, cout=16)
         if tape is None:

@@ -678,6 +678,25 @@ def tail_bwd(dfused, fused, z, w, prelu):
     return dt16
 
 
+def stem_out_pack(w1, w2):
+    """Weight operand of stem_out_fused: w1 [16,32,3,3], w2 [1,16,3,3] -> the composed 5x5 32->1 kernel as three-piece bf16 MFMA operands."""
+    assert tuple(w1.shape) == (16, 32, 3, 3) and tuple(w2.shape) == (1, 16, 3, 3)
+    L = lib()
+    wpk = torch.empty(L.paif_stem_out_pack_floats(), device=w1.device, dtype=torch.float32)
+    _lib.check(L.paif_stem_out_pack(_p(w1.detach().contiguous()), _p(w2.detach().contiguous()), _p(wpk), _stream()), "stem_out_pack")
+    return wpk
+
+
+def stem_out_fused(x, wpk, prelu):
+    """bf16 NHWC-32 map -> fused [B,1,H,W] fp32: conv3x3 32->16, conv3x3 16->1, PReLU, tanh (core/model_fusion_auto.py:616-620, :640) in one
+    launch pair; the 16-channel map never goes to HBM."""
+    B, H, W, C = x.shape
+    assert C == 32 and x.dtype == torch.bfloat16
+    fused = torch.empty((B, 1, H, W), device=x.device, dtype=torch.float32)
+    _lib.check(lib().paif_stem_out_fwd_bf16(_pa(x), _p(wpk), _p(prelu), _p(fused), B, H, W, _stream()), "stem_out_fused")
+    return fused
+
+
 def tail(x16, w, prelu, save=False):
     B, H, W, C = x16.shape
     assert C == 16

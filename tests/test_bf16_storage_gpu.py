@@ -278,6 +278,30 @@ def test_dilconv_as_one_dense_conv(mode, nres):
     assert float(e_one.mean()) <= 2.0 ** -8 * scale, (float(e_one.mean()), scale)
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 37, 53), (3, 8, 32), (1, 9, 33), (2, 3, 3), (1, 480, 640)])
+def test_stem_out_as_one_kernel(shape):
+    """stem_out (core/model_fusion_auto.py:616-620, :640: conv3x3 32->16, conv3x3 16->1, PReLU, tanh) of the bf16 forward as one launch
+    pair: the composed 5x5 conv on the matrix cores (three-piece weights: fp32-level products) + the exact two-stage border ring.
+    Reference: the two convs in float64 on the same bf16 map (the 16-channel map NOT rounded to bf16 -- the fused form never stores it);
+    bound: fp32 summation noise of 800 products, on every pixel including the ring, ragged tiles and images smaller than a tile."""
+    B, H, W = shape
+    dev = _dev()
+    g = torch.Generator().manual_seed(H * W)
+    x32, xb = _rounded(ops.to_nhwc(torch.randn(B, 32, H, W, generator=g).to(dev)))
+    w1 = (torch.randn(16, 32, 3, 3, generator=g) * 0.08).to(dev)
+    w2 = (torch.randn(1, 16, 3, 3, generator=g) * 0.2).to(dev)
+    slope = torch.tensor([0.3], device=dev)
+    out = ops.stem_out_fused(xb, ops.stem_out_pack(w1, w2), slope)
+    xd = x32.permute(0, 3, 1, 2).double()
+    z = torch.nn.functional.conv2d(torch.nn.functional.conv2d(xd, w1.double(), padding=1), w2.double(), padding=1)
+    ref = torch.tanh(torch.where(z >= 0, z, z * slope.double()))
+    assert out.shape == (B, 1, H, W) and out.dtype == torch.float32
+    err = (out.double() - ref).abs()
+    assert float(err.max()) <= 4e-6, (float(err.max()), [float(err[..., 0, :].max()), float(err[..., -1, :].max()), float(err[..., :, 0].max()),
+                                                        float(err[..., :, -1].max())])
+    assert float(z.abs().max()) > 1.0          # the bound is meaningful: pre-activations of order 1
+
+
 def _fusion_net():
     from paif_amd.core.model_fusion_auto import Network_Fusion_Searched
     from paif_amd.genotypes import FUSION_AT
