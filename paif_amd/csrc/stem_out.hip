@@ -105,16 +105,30 @@ __global__ __launch_bounds__(256) void stem_out_fused_kernel(const unsigned shor
 #pragma unroll
     for (int pc = 0; pc < 3; ++pc) wa[ks][pc] = __builtin_bit_cast(bf16x8, wpk[(ks * 3 + pc) * 64 + lane]);
   const unsigned short* img = x + (size_t)b * H * W * 32;
-  for (int g = wave; g < NG; g += 4) {
+  // a wave takes groups wave, wave + 4, wave + 8, wave + 12: all its loads are issued before the first MFMA (unconditional, clamped;
+  // group slots >= NG re-read the last group and are not stored)
+  constexpr int GPW = (NG + 3) / 4;
+  uint4 v0[GPW], v1[GPW];
+  int hps[GPW];
+  bool oks[GPW];
+#pragma unroll
+  for (int i = 0; i < GPW; ++i) {
+    const int g = min(wave + 4 * i, NG - 1);
     const int hp = g * 32 + n;
     const int hy = hp / HW_, hx = hp - hy * HW_;
     const int gy = y0 - 2 + hy, gx = x0 - 2 + hx;
-    const bool ok = hp < NPX && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    hps[i] = hp;
+    oks[i] = hp < NPX && gy >= 0 && gy < H && gx >= 0 && gx < W;
     const size_t off = ((size_t)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1)) * 32 + hh * 8;
-    uint4 v0 = *reinterpret_cast<const uint4*>(img + off);            // channels 8 hh .. 8 hh + 7        (k step 0); unconditional, clamped
-    uint4 v1 = *reinterpret_cast<const uint4*>(img + off + 16);       // channels 16 + 8 hh .. 16 + 8 hh + 7 (k step 1)
-    if (!ok) v0 = v1 = make_uint4(0u, 0u, 0u, 0u);                    // zero padding of the image / unused slots of the last group
-    const bf16x8 b0 = __builtin_bit_cast(bf16x8, v0), b1 = __builtin_bit_cast(bf16x8, v1);
+    v0[i] = *reinterpret_cast<const uint4*>(img + off);            // channels 8 hh .. 8 hh + 7           (k step 0)
+    v1[i] = *reinterpret_cast<const uint4*>(img + off + 16);       // channels 16 + 8 hh .. 16 + 8 hh + 7 (k step 1)
+  }
+#pragma unroll
+  for (int i = 0; i < GPW; ++i) {
+    if (wave + 4 * i >= NG) break;                                   // wave-uniform
+    if (!oks[i]) v0[i] = v1[i] = make_uint4(0u, 0u, 0u, 0u);         // zero padding of the image / unused slots of the last group
+    const bf16x8 b0 = __builtin_bit_cast(bf16x8, v0[i]), b1 = __builtin_bit_cast(bf16x8, v1[i]);
+    const int hp = hps[i];
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
