@@ -242,6 +242,22 @@ def main():
             barrier()
             other_storage.append((mode, max_over_ranks(time.perf_counter() - t2, dist, dev)))
         ops.set_storage(args.storage)
+    two_stream = None
+    if args.workload in ("fusion", "fusion_seg") and not args.graph:
+        # the same K steps with the two image streams of the fusion network on two HIP streams (ops.CONFIG["two_stream"]): identical
+        # results, kernels of one stream fill the CUs the other's launches leave idle.  Reported beside `value`, not as it: per-launch
+        # durations under co-scheduling measure CU sharing, so the roofline blocks (and the rocprofv3 summary they must agree with) are
+        # those of the single-stream run.
+        ops.CONFIG["two_stream"] = True
+        for _ in range(3):
+            step()
+        barrier()
+        t3 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        two_stream = max_over_ranks(time.perf_counter() - t3, dist, dev)
+        ops.CONFIG["two_stream"] = False
     sustained = None
     if args.sustain_seconds > 0 and not args.graph:
         n_s = int(args.sustain_seconds / max(dt / args.steps, 1e-6)) + 1
@@ -418,6 +434,11 @@ def main():
             res["other_storage_note"] = ("the same K steps in the other storage modes (ops.set_storage), run right after the timed region: f32 = fp32 maps, "
                                          "split-bf16 products (3 MFMAs, fp32-level parity); bf16_split = bf16 maps, split-bf16 weights (2 MFMAs); "
                                          "bf16 = bf16 maps and weights, one bf16 MFMA per product (BASELINE configs[1])")
+        if two_stream is not None:
+            res["two_stream"] = {"value": pairs / two_stream, "ms_per_step": two_stream / args.steps * 1e3,
+                                 "note": "the same K steps with ops.CONFIG['two_stream'] = True (infrared / visible streams of the fusion network on two "
+                                         "HIP streams, bit-identical output), run after the timed region; `value`, the roofline blocks and the committed "
+                                         "rocprofv3 summaries are the single-stream run's, whose per-launch durations measure kernels, not CU sharing"}
         if sustained is not None:
             res["sustained_value"] = bpg * world * sustained[0] / sustained[1]
             res["sustained"] = {"steps": sustained[0], "seconds": sustained[1], "ms_per_step": sustained[1] / sustained[0] * 1e3,

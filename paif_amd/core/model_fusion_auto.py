@@ -169,6 +169,18 @@ class Cell_Decom(nn.Module):
                 tape.update(lf_ir=lf_ir, lf_vis=lf_vis)
         return ir_feature, vis_feature
 
+    def branch_nhwc(self, f, g, which):
+        """One stream of forward_nhwc (inference, no tape): guided-filter decomposition of the stem map f with guide g, the folded 1x1,
+        the stream's chain (+ f).  which: 0 = infrared (conv1x1_lf, chain), 1 = visible (conv1x1_hf, chain2).  The two streams are
+        independent up to the spatial blend: Network_Fusion_Searched runs them on two HIP streams (ops.CONFIG["two_stream"])."""
+        lf16 = ops._ACT_BF16[0]
+        lf = self.decomposition_nhwc(f, g, out_bf16=lf16)
+        conv = self.conv1x1_lf if which == 0 else self.conv1x1_hf
+        w = self._packs.get("lf" if which == 0 else "hf", [conv.weight], lambda: ops.pack_decomp1x1_weight(conv.weight))
+        x = ops.cast_storage(f, True) if lf16 else f
+        y = ops.conv2d([x, lf[0], lf[1]], w, 1, 1, shift=conv.bias)
+        return (self.chain if which == 0 else self.chain2).forward_nhwc(y, (f,), None)
+
     def _stream_backward(self, d_feat, chain, chain_tape, conv, name, feat, guide, ab, lf=None):
         """One stream: d/d(ir_feature) -> d/d(stem feature).  lf (the stream's two LF maps): also the 1x1's parameter gradients."""
         wgrad = lf is not None
@@ -307,6 +319,29 @@ class Network_Fusion_Searched(nn.Module):
         """ir, vis: [B,>=1,H,W] (channel 0 is used, :626-627).  tape (dict): filled for the input-gradient pass."""
         vis = vis[:, 0:1, :, :]
         ir = ir[:, 0:1, :, :]
+        if tape is None and inter is None and ir.is_cuda and ops.CONFIG.get("two_stream", False):
+            # the infrared and the visible stream (stem -> guided filter -> 1x1 -> chain) are independent up to the blend: the visible one
+            # runs on a second HIP stream, so that its kernels fill the CUs the other stream's launches leave idle (a guided-filter launch
+            # holds 224 of the 256 CUs with one workgroup each; every kernel's last round of workgroups leaves a tail)
+            main = torch.cuda.current_stream()
+            side = self.__dict__.get("_side_stream")
+            if side is None or side.device != ir.device:
+                side = self.__dict__["_side_stream"] = torch.cuda.Stream(device=ir.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                fvis, g_vis = ops.stem(vis, self.stem_2[0].weight, self.stem_2[1].weight)
+                vis_feature = self.decompation.branch_nhwc(fvis, g_vis, 1)
+            fir, g_ir = ops.stem(ir, self.stem_1[0].weight, self.stem_1[1].weight)
+            ir_feature = self.decompation.branch_nhwc(fir, g_ir, 0)
+            main.wait_stream(side)
+            # vis_feature lives in the side stream's allocator pool and is consumed here.  Its block can only be handed out again to a
+            # side-stream allocation, i.e. after the next forward's side.wait_stream(main) -- behind everything this stream does with it;
+            # record_stream states that explicitly outside a graph capture (it is not permitted on a capture's private pool)
+            if not torch.cuda.is_current_stream_capturing():
+                vis_feature.record_stream(main)
+            del fvis, g_vis
+            agg = self.spa.blend_nhwc(ir_feature, vis_feature)
+            return self._tail_nhwc(self.chain.forward_nhwc(agg, (), None))
         fir, g_ir = ops.stem(ir, self.stem_1[0].weight, self.stem_1[1].weight)
         fvis, g_vis = ops.stem(vis, self.stem_2[0].weight, self.stem_2[1].weight)
         t_dec = None if tape is None else {}
@@ -323,12 +358,8 @@ class Network_Fusion_Searched(nn.Module):
         else:
             agg, scale = self.spa.blend_nhwc(ir_feature, vis_feature, want_scale=True)
         feature2 = self.chain.forward_nhwc(agg, (), t_chain)
-        if (tape is None and inter is None and feature2.dtype == torch.bfloat16 and feature2.shape[1] >= 3 and feature2.shape[2] >= 3
-                and ops.CONFIG.get("stem_out_fused", True)):
-            # bf16 inference forward: both stem_out convs + PReLU + tanh as one launch pair (csrc/stem_out.hip)
-            so = self.stem_out
-            wso = self._packs.get("so_fused", [so[0].weight, so[1].weight], lambda: ops.stem_out_pack(so[0].weight, so[1].weight))
-            return ops.stem_out_fused(feature2, wso, so[2].weight)
+        if tape is None and inter is None:
+            return self._tail_nhwc(feature2)
         w0 = self._packs.get("so0", [self.stem_out[0].weight], lambda: ops.pack_conv_weight(self.stem_out[0].weight, 1, 32, 3))
         t16 = ops.conv2d([feature2], w0, 3, 1, cout=16)
         if tape is None:
@@ -341,6 +372,16 @@ class Network_Fusion_Searched(nn.Module):
         if inter is not None:
             inter.update(fir=fir, fvis=fvis, ir_feature=ir_feature, vis_feature=vis_feature, agg=agg, feature2=feature2)
         return out
+
+    def _tail_nhwc(self, feature2):
+        """stem_out + tanh of the inference forward (no tape)."""
+        so = self.stem_out
+        if (feature2.dtype == torch.bfloat16 and feature2.shape[1] >= 3 and feature2.shape[2] >= 3 and ops.CONFIG.get("stem_out_fused", True)):
+            # bf16 inference forward: both stem_out convs + PReLU + tanh as one launch pair (csrc/stem_out.hip)
+            wso = self._packs.get("so_fused", [so[0].weight, so[1].weight], lambda: ops.stem_out_pack(so[0].weight, so[1].weight))
+            return ops.stem_out_fused(feature2, wso, so[2].weight)
+        w0 = self._packs.get("so0", [so[0].weight], lambda: ops.pack_conv_weight(so[0].weight, 1, 32, 3))
+        return ops.tail(ops.conv2d([feature2], w0, 3, 1, cout=16), so[1].weight, so[2].weight)
 
     def backward_impl(self, d_fused, tape, wgrad=False):
         """d/d(fused) [B,1,H,W] -> (d/d(ir), d/d(vis channel 0)) as [B,1,H,W] each; wgrad: parameter gradients too."""

@@ -48,7 +48,10 @@ ACT_GELU = 1  # paif_gemm_fwd's act code 1 is GELU (the conv's code 1 is PReLU)
 # and every 1-channel plane stay fp32 (SURVEY hard part 1).  Taped (gradient) passes always run fp32 storage.  Tolerance of this
 # mode: SURVEY 8(d) bf16 clause (max / mean |fused - reference| reported, argmax agreement >= 99.9 %, mIoU within 0.1 pt):
 # tests/test_bf16_storage_gpu.py.
-CONFIG = {"conv_precision": "bf16x3", "gemm_precision": "auto", "serpentine": True, "attack_precision": "bf16x6", "storage": "f32"}
+CONFIG = {"conv_precision": "bf16x3", "gemm_precision": "auto", "serpentine": True, "attack_precision": "bf16x6", "storage": "f32",
+          # inference forward of the fusion network: run the infrared and the visible stream on two HIP streams (identical results; off by
+          # default because per-launch timings -- bench.py's roofline blocks, rocprofv3 averages -- then measure CU sharing, not kernels)
+          "two_stream": False}
 _ACT_BF16 = [False]    # True while an inference forward of the fusion network runs in bf16 storage (set by the model)
 
 

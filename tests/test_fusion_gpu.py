@@ -388,6 +388,49 @@ def test_fusion_net_b2(golden):
     assert maxabs(fused.cpu(), g["fused"]) <= 1e-4
 
 
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_two_stream_forward_is_bit_identical(storage):
+    """ops.CONFIG["two_stream"]: the infrared and the visible stream of the fusion network on two HIP streams (fork at the stems, join at
+    the spatial blend).  Same kernels, same operands: the fused image must be BIT-identical to the single-stream forward -- on repeated
+    calls (the side stream's allocator pool is reused across forwards), with another size in between, and inside a captured hipGraph."""
+    from paif_amd import ops
+
+    old = dict(ops.CONFIG)
+    try:
+        ops.set_storage(storage)
+        net = _fusion_net()
+        outs = {}
+        for shape in ((2, 64, 96), (1, 200, 328)):
+            ir, vis, _ = S.make_batch(*shape)
+            irt = t(ir).to(_dev())
+            ycc = ops.rgb2ycrcb(t(vis).to(_dev()))
+            with torch.no_grad():
+                ops.CONFIG["two_stream"] = False
+                ref = net(irt, ycc).clone()
+                ops.CONFIG["two_stream"] = True
+                for _ in range(4):
+                    got = net(irt, ycc)
+                    assert torch.equal(got, ref)
+            outs[shape] = (irt, ycc, ref)
+        irt, ycc, ref = outs[(2, 64, 96)]
+        with torch.no_grad():
+            assert torch.equal(net(irt, ycc), ref)                 # back to the first size: pool blocks of the other size in between
+            gstream, graph = torch.cuda.Stream(), torch.cuda.CUDAGraph()
+            with torch.cuda.stream(gstream):
+                net(irt, ycc)
+                torch.cuda.synchronize()
+                with torch.cuda.graph(graph, stream=gstream):
+                    gout = net(irt, ycc)
+            torch.cuda.synchronize()
+            for _ in range(3):
+                graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(gout, ref)
+    finally:
+        ops.CONFIG.clear()
+        ops.CONFIG.update(old)
+
+
 def test_colour_glue_and_batch_coupling(golden):
     from paif_amd import ops
 

@@ -31,7 +31,7 @@ for f in ["fusion", "fusion_seg", "pgd", "pgd_fast", "pgd_exact", "train", "fusi
     try:
         d = json.loads(open("gpurun_out/r03_bench_%s.json" % f).read().strip().splitlines()[-1])
         print(f, round(d["value"], 2), round(d["ms_per_step"], 3), [(o["storage"], round(o["value"], 1)) for o in d.get("other_storage", [])],
-              d.get("cpu_baseline", {}).get("value"), d["roofline"].get("frac"), d["roofline"].get("traffic"))
+              d.get("cpu_baseline", {}).get("value"), d["roofline"].get("frac"), d["roofline"].get("traffic"), "two_stream", d.get("two_stream", {}).get("value"))
     except Exception as e:
         print(f, "ERR", e)
 PY

@@ -32,6 +32,13 @@ def run():
     return e0.elapsed_time(e1) / reps
 
 
+with torch.no_grad():
+    ops.CONFIG[key] = False
+    ref = net(ir, ycc).clone()
+    ops.CONFIG[key] = True
+    got = net(ir, ycc).clone()
+torch.cuda.synchronize()
+print("%s: max |on - off| = %.3e" % (key, float((ref - got).abs().max())))
 for rnd in range(3):
     ops.CONFIG[key] = False
     off = run()
