@@ -63,6 +63,11 @@ def main():
                     help="fusion / fusion_seg: replay one captured hipGraph per step in the timed region (the clean-eval harness's default "
                          "mode).  `value` is then the graph-replay rate; the roofline blocks come from an eager, HIP-event-instrumented pass of "
                          "the same K steps run right after the timed region and say so (`roofline_source`)")
+    ap.add_argument("--two-stream", action="store_true",
+                    help="fusion / fusion_seg: run the timed region itself with ops.CONFIG['two_stream'] = True (the two image streams of the fusion "
+                         "network on two HIP streams; bit-identical output, ~+6 %%).  `value` is then the co-scheduled rate and every per-launch "
+                         "duration (roofline blocks, rocprofv3) measures CU sharing as well as the kernel -- the line says so.  Without the flag the "
+                         "two-stream rate is reported beside `value` as `two_stream`")
     ap.add_argument("--attack-precision", choices=["exact", "bf16x6", "fast"], default="bf16x6",
                     help="pgd / train: arithmetic INSIDE the attack loop.  bf16x6 (default, the product default) = convs as three-piece bf16 "
                          "splits (six MFMAs per product, 2^-25 per product: fp32-level parity -- sign mismatch vs the reference's float64 run 0 "
@@ -185,6 +190,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.two_stream:
+        if args.workload not in ("fusion", "fusion_seg"):
+            raise SystemExit("--two-stream: the inference forward of the fusion network (fusion / fusion_seg)")
+        ops.CONFIG["two_stream"] = True
     for _ in range(args.warmup):
         step()
     # HIP events around every dense-conv / GEMM / attention launch of the timed region (on the launch stream)
@@ -243,7 +252,7 @@ def main():
             other_storage.append((mode, max_over_ranks(time.perf_counter() - t2, dist, dev)))
         ops.set_storage(args.storage)
     two_stream = None
-    if args.workload in ("fusion", "fusion_seg") and not args.graph:
+    if args.workload in ("fusion", "fusion_seg") and not args.graph and not args.two_stream:
         # the same K steps with the two image streams of the fusion network on two HIP streams (ops.CONFIG["two_stream"]): identical
         # results, kernels of one stream fill the CUs the other's launches leave idle.  Reported beside `value`, not as it: per-launch
         # durations under co-scheduling measure CU sharing, so the roofline blocks (and the rocprofv3 summary they must agree with) are
@@ -434,6 +443,10 @@ def main():
             res["other_storage_note"] = ("the same K steps in the other storage modes (ops.set_storage), run right after the timed region: f32 = fp32 maps, "
                                          "split-bf16 products (3 MFMAs, fp32-level parity); bf16_split = bf16 maps, split-bf16 weights (2 MFMAs); "
                                          "bf16 = bf16 maps and weights, one bf16 MFMA per product (BASELINE configs[1])")
+        if args.two_stream:
+            res["mode"] = (res["mode"] + "; " if "mode" in res else "") + (
+                "two HIP streams (ops.CONFIG['two_stream']): the infrared and the visible stream of the fusion network are co-scheduled; "
+                "per-launch durations in the roofline blocks include the CU sharing")
         if two_stream is not None:
             res["two_stream"] = {"value": pairs / two_stream, "ms_per_step": two_stream / args.steps * 1e3,
                                  "note": "the same K steps with ops.CONFIG['two_stream'] = True (infrared / visible streams of the fusion network on two "
