@@ -7,16 +7,23 @@ Workload (BASELINE.json configs[1]): the fusion-network forward pass -- RGB2YCrC
 the C ABI.  One process per GPU; replicas only (no data-path collective: the path is per-sample).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N ...             # N > 1 without a torch.distributed.run environment: starts the N ranks itself (below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0 (contract in the task statement): value = whole-job pairs/s, plus
-  roofline     -- dominant kernel = the dense 3x3 dilation-1 forward conv (42 % of the step).  Since round 2 it is three
-                  instantiations picked by source count (conv_bf16x3_res<3, 1, 1, 4>, conv_bf16x3_ms<3, 1, 2|3>, and
-                  conv_mfma_bf16x3<3, 1, false> for the pooled ones): `roofline` aggregates them exactly as round 1's single kernel was
-                  aggregated and `roofline.kernels` lists each one under the name rocprofv3 gives it; HIP-event timed on the launch
-                  stream inside the timed region.  roofline_other: the next kernels by time (guided filter, 7x7, 1x1 ...)
+  roofline     -- dominant kernel family = the dense 3x3 dilation-1 forward convs (12 launches per step): several instantiations picked by
+                  source count and storage mode (fp32 storage: conv_bf16x3_res / conv_bf16x3_ms / conv_mfma_bf16x3; bf16 storage: the
+                  LDS-DMA kernels conv3x3_bf16_dma<NSRC, NRES>); `roofline` aggregates the family and `roofline.kernels` lists each
+                  member under the name rocprofv3 gives it; HIP-event timed on the launch stream inside the timed region.
+                  roofline_other: the next kernels by time (guided filter, 7x7, 1x1 ...)
   cpu_baseline -- the CPU oracle (torch fp32 port of the reference) on the host cores, bounded sample, rank 0, N=1 only
+  parity       -- which storage mode `value` was measured in and what the committed parity report says about it
+
+`--storage` (fusion / fusion_seg): `value` is measured in fp32 storage by default since round 4 -- the configuration that meets BOTH
+clauses of SURVEY 8(d) on the reference's (now multi-class, near-tie) 480x640 map.  The bf16 configuration BASELINE configs[1] names
+keeps mIoU within 0.1 pt but agrees with the reference's argmax on 98.75 % of the pixels, not 99.9 %
+(profiles/r04_bf16_storage_report.json, tests/test_bf16_storage_gpu.py); its rate is in the same line (`other_storage`).
 """
 import argparse
 import json
@@ -56,7 +63,7 @@ def main():
     ap.add_argument("--attack-iters", type=int, default=5, help="PGD iterations inside the training step (robust_test.py:42 default)")
     ap.add_argument("--backbone", default="mit_b3")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="fusion workload: the BASELINE.md 3b protocol (3 warm-up + 5 "
-                    "timed) at B=8 as well as at B=1 (several minutes of CPU time); default = B=1 only")
+                    "timed) at B=1 and at B=8 (several minutes of CPU time); default = a bounded sample of both batch sizes (~30 s)")
     ap.add_argument("--sustain-seconds", type=float, default=3.0,
                     help="after the K timed steps, loop the same step for at least this long and report `sustained_value` (0 = skip)")
     ap.add_argument("--graph", action="store_true",
@@ -73,15 +80,22 @@ def main():
                          "splits (six MFMAs per product, 2^-25 per product: fp32-level parity -- sign mismatch vs the reference's float64 run 0 "
                          "through PGD-10), GEMMs / attention exact fp32 MFMA; exact = fp32-exact MFMA kernels everywhere; fast = the split-bf16 "
                          "kernels there too (trajectory diverges: sign mismatch 2.5e-2 by iteration 10; tests/test_parity_default_gpu.py)")
-    ap.add_argument("--storage", choices=["f32", "bf16", "bf16_split"], default="bf16",
-                    help="activation storage of the fusion network's inference forward (fusion / fusion_seg workloads): f32 = every map fp32 "
-                         "(parity at the fp32 tolerance); bf16 (default) = what BASELINE configs[1] names: the 32-channel maps behind the guided-filter "
-                         "block held as bf16, fp32 accumulate (tolerance: SURVEY 8(d) bf16 clause, tests/test_bf16_storage_gpu.py).  The line "
-                         "also carries the OTHER mode's rate (`other_storage`), measured right after the timed region")
+    ap.add_argument("--storage", choices=["f32", "bf16", "bf16_split"], default="f32",
+                    help="activation storage of the fusion network's inference forward (fusion / fusion_seg workloads): f32 (default since "
+                         "round 4) = every map fp32, parity at the fp32 tolerance: BOTH clauses of SURVEY 8(d) hold on the reference's multi-class "
+                         "480x640 map; bf16 = what BASELINE configs[1] names: the 32-channel maps behind the guided-filter block held as bf16, bf16 "
+                         "weights, one MFMA per product, fp32 accumulate -- mIoU within 0.1 pt, argmax agreement 98.75 %% (< the 99.9 %% clause; "
+                         "tests/test_bf16_storage_gpu.py).  The line also carries the OTHER modes' rates (`other_storage`), measured right after "
+                         "the timed region")
     ap.add_argument("--conv-precision", choices=["f32", "bf16x3"], default="bf16x3",
                     help="arithmetic of the dense convs: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs, fp32 accumulate)")
     args = ap.parse_args()
 
+    if (args.gpus > 1 or os.environ.get("PAIF_BENCH_FORCE_LAUNCH") == "1") and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process has made NO GPU call yet (importing torch and counting devices does not
+        # initialise HIP) -- it starts the N ranks as CHILD processes (never an exec of a GPU-initialised process), relays rank 0's
+        # JSON line and exits with the children's status
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -90,11 +104,15 @@ def main():
                          % (args.gpus, world, args.gpus))
     dev = torch.device("cuda", local_rank)
     dist = None
+    rccl_ranks_seen = None
     if world > 1 or args.force_allreduce:
         # the process group comes up BEFORE this process makes any other GPU call.  RCCL over xGMI: configs 1-3 use it for the
         # barrier + max-over-ranks only (replicas); configs[4] for the bucketed gradient all-reduce
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                       # every rank contributes a one: the sum is the number of ranks RCCL really connected
+        rccl_ranks_seen = int(ones.item())
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path")
     torch.cuda.set_device(local_rank)
@@ -431,6 +449,10 @@ def main():
             "roofline": roof,
             "roofline_other": others,
         }
+        if rccl_ranks_seen is not None:
+            res["rccl_ranks_seen"] = rccl_ranks_seen      # all-reduce of ones over the process group (= world size when RCCL connected every rank)
+        if args.workload in ("fusion", "fusion_seg"):
+            res["parity"] = parity_block(args.storage)
         if args.graph:
             res["mode"] = "hipGraph replay (one captured graph per step)"
             res["roofline_source"] = "eager HIP-event pass of the same %d steps after the timed region" % args.steps
@@ -462,6 +484,62 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` outside torch.distributed.run: run `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a child process, relay its output (rank 0 prints the
+    JSON line) and return its exit status.  The parent never touches the GPU."""
+    import socket
+    import subprocess
+
+    have = torch.cuda.device_count()           # counts devices without initialising HIP on this image
+    if have < n:
+        print("bench.py: --gpus %d but this node exposes %d GPU(s)" % (n, have), file=sys.stderr)
+        return 2
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: required for RCCL between processes on this host driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env.pop("PAIF_BENCH_FORCE_LAUNCH", None)               # (test hook: take the self-launch path at N=1 too)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True)
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln.rstrip("\n")
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        print("bench.py: the ranks exited 0 but rank 0 printed no JSON line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+def parity_block(storage):
+    """What the committed parity report (tests/test_bf16_storage_gpu.py::test_fusion_forward_bf16_storage_tolerance_clause on MI355X,
+    copied to profiles/) says about the storage mode `value` was measured in: SURVEY 8(d)'s two clauses on the reference's 480x640
+    mit_b3 map (calibrated head: 9 classes, median top-2 margin 1.6 % of the logit range)."""
+    out = {"storage": storage, "source": "profiles/r04_bf16_storage_report.json"}
+    try:
+        rep = json.load(open(os.path.join(ROOT, "profiles", "r04_bf16_storage_report.json")))
+        r = rep[storage]
+        out.update({"argmax_agreement_vs_reference": r["argmax_agreement_vs_reference"], "miou_delta_vs_reference": r["miou_delta_vs_reference"],
+                    "logits_max_abs_over_range": r["logits_max_abs_over_range"], "fused_max_abs_vs_fp64": r["fused_max_abs_vs_fp64"],
+                    "clause_argmax_ge_0.999": bool(r["argmax_agreement_vs_reference"] >= 0.999),
+                    "clause_miou_within_0.1pt": bool(abs(r["miou_delta_vs_reference"]) <= 1e-3)})
+        if storage != "f32":
+            out["note"] = ("this storage mode keeps mIoU within 0.1 pt but NOT the 99.9 % argmax clause on the near-tie map; the default "
+                           "(--storage f32) meets both")
+    except (OSError, ValueError, KeyError) as e:
+        out["note"] = "parity report unreadable: %s" % e
+    return out
 
 
 def host_cores():
@@ -538,12 +616,13 @@ def cpu_baseline(workload, ir_np, vis_np, lab_np, full=False, backbone="mit_b3")
                 fwd()
             return B * reps / (time.perf_counter() - t0)
 
-        by = {"1": rate(1, 3, 5)}
-        if full:
-            by["8"] = rate(8, 3, 5)
+        # best of B in {1, 8}.  Default = a bounded sample (~30 s of CPU work): 1 warm-up + 3 timed forwards at B=1, then ONE
+        # timed forward at B=8 (threads and allocator already warm); --cpu-baseline-full = the 3 + 5 protocol at both batch sizes
+        by = {"1": rate(1, 3, 5), "8": rate(8, 3, 5)} if full else {"1": rate(1, 1, 3), "8": rate(8, 0, 1)}
         base.update({"value": max(by.values()), "by_batch": by,
-                     "sample": "oracle fusion forward %dx%d fp32, %s; 3 warm-up + 5 timed forwards at B=1%s" % (
-                         ir_np.shape[2], ir_np.shape[3], env, " and at B=8; value = best batch size" if full else "")})
+                     "sample": "oracle fusion forward %dx%d fp32, %s; %s; value = best batch size" % (
+                         ir_np.shape[2], ir_np.shape[3], env,
+                         "3 warm-up + 5 timed forwards at B=1 and at B=8" if full else "1 warm-up + 3 timed forwards at B=1, then 1 timed forward at B=8")})
         return base
     net = Network_MM_Searched(32, FUSION_AT, None, None, backbone, num_classes=9)
     S.load_formula_weights(net)

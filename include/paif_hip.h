@@ -370,7 +370,9 @@ int paif_upsample_ce_bwd(const float* logits, const long long* label, const floa
  *   way 1  segPGD  loss = w_true * CE(t*o, label) + w_false * CE((1-t)*o, label),  t = (max_c o == label)  [float vs integer, as the
  *                  reference compares them];  w_true = 1 - lambda, w_false = lambda, lambda = (i-1)/(2*iters)
  *   way 2  cosPGD  loss = cosine_similarity(max_c o, label over ALL pixels) * CE(o, label)
- * fwd: partial = 5 * paif_attack_loss_blocks floats of scratch; coef[8] (device) = {loss, #valid, CE, cos, a, bl, bp, 0}.
+ * fwd: partial = 6 * paif_attack_loss_blocks floats of scratch; coef[8] (device) = {loss, #valid, CE, cos, a, bl, bp, nbad}; nbad = the
+ *      number of labels outside [0, C) that are not ignore_index: such a pixel is dropped like an ignored one and never used as an
+ *      index (torch's CrossEntropyLoss raises on it; the attack entry points raise when nbad != 0).
  * bwd: dfull [B,OH,OW,CP] = upstream * d loss / d o (CP >= C, CP % 4 == 0, zero padded), reads coef written by fwd; follow with
  *      paif_resize_bilinear_adjoint_fwd to get dlogits.  Deterministic (fixed-order reductions, no float atomics). */
 int paif_attack_loss_blocks(int B, int OH, int OW);
@@ -420,6 +422,19 @@ int paif_glue_bwd_blocks(int B, int H, int W);
 int paif_glue_bwd_input(const float* dseg, const float* fused, const float* ycc, const float* minmax,
                         const float* dfused_direct, float* partial, float* dfused, float* dcrcb, int B, int H, int W,
                         paif_stream_t stream);
+/* forward_object's extra step on the fused plane, core/model_fusion_auto.py:743-751 (Network_MM_CompModel) / :1074-1082
+ * (Network_MM_Searched): clamp to [0,1] (two torch.where), then (f - min f) / (max f - min f) with BATCH-GLOBAL min / max.
+ * x, out: n = B*H*W floats (in place allowed); partial: 2 * paif_plane_minmax_blocks(n) floats of scratch for the forward,
+ * 4 * paif_plane_minmax_blocks(n) for the backward; minmax_out: the 2 floats (min, max of the clamped plane) the backward needs.
+ * Backward = torch's: the clamp passes gradient where 0 <= x <= 1; the min / max gradients are spread evenly over equal elements. */
+int paif_plane_minmax_blocks(size_t n);
+int paif_plane_clamp_minmax_fwd(const float* x, float* out, float* partial, float* minmax_out, size_t n, paif_stream_t stream);
+int paif_plane_clamp_minmax_bwd_input(const float* dout, const float* x, const float* minmax, float* partial, float* dx, size_t n,
+                                      paif_stream_t stream);
+/* Stand-alone eca_layer.forward (operations_m.py:353-367: AdaptiveAvgPool2d(1) of the map itself): per-image channel sums of
+ * an NHWC [B,H,W,32] map as `chunks` partial sums per image, partial [B][chunks][32] -- with chunks = paif_conv2d_blocks(1,H,W) the
+ * layout paif_eca_finish_fwd reduces (inside ECABasicBlock the conv epilogue produces them). */
+int paif_channel_sum_chunks_fwd(const float* x, float* partial, int chunks, int B, int H, int W, paif_stream_t stream);
 /* backward of paif_rgb2ycrcb_fwd: (dY [B,H,W], dcrcb [B,2,H,W]) -> dvis NCHW [B,3,H,W]. */
 int paif_rgb2ycrcb_bwd_input(const float* dY, const float* dcrcb, float* dvis, int B, int H, int W, paif_stream_t stream);
 /* attack/attack.py:504-512: delta <- clamp(clamp(delta + alpha*sign(grad_sum), -eps, eps), 0 - X, 1 - X), in place. */

@@ -47,7 +47,9 @@ def save(name, **arrays):
     print("wrote %-28s %8.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
 
 
-def build_model(R, backbone, cls="Network_MM_Searched"):
+def build_model(R, backbone, cls="Network_MM_Searched", head=None):
+    """`head`: calibration tag of the segmentation head's last layer (paif_amd/synthetic.py, oracle/calibrate_head.py) --
+    every golden whose argmax / confusion matrix / mIoU is compared carries one, so that the reference's map is multi-class."""
     with ref_import.quiet():
         if cls == "Network_MM_Searched":
             m = R["mfa"].Network_MM_Searched(32, O.FUSION_AT, None, None, backbone, num_classes=9)
@@ -55,8 +57,12 @@ def build_model(R, backbone, cls="Network_MM_Searched"):
             fus = R["mfa"].Network_Fusion_Searched(32, None, O.FUSION_AT)
             m = R["mfa"].Network_MM_CompModel(fus, None, None, backbone, 9, 256, None)
     m.eval()
-    S.load_formula_weights(m)
+    S.load_formula_weights(m, head=head)
     return m
+
+
+def class_share(pred):
+    return (np.bincount(np.asarray(pred).ravel().astype(np.int64), minlength=9) / float(np.asarray(pred).size)).astype(np.float32)
 
 
 def main():
@@ -179,7 +185,7 @@ def main():
          loss_d_ir=npy(irg.grad), loss_d_vis=npy(visg.grad), lower_d_ir=npy(irl.grad), lower_d_vis=npy(visl.grad))
 
     # ---- G-d: colour transforms + clamp / batch-global min-max / normalise ------------------
-    m0 = build_model(R, "mit_b0")
+    m0 = build_model(R, "mit_b0", head=S.head_tag("mit_b0", 2, 64, 96))
     ir, vis, _ = S.make_batch(2, 64, 96)
     with torch.no_grad():
         ycc = mfa.RGB2YCrCb(t(vis))
@@ -198,7 +204,7 @@ def main():
 
     # ---- G-e: WeTr mit_b0 / mit_b3 at 64x96: stage outputs + logits -------------------------
     for bb in ("mit_b0", "mit_b3"):
-        m = m0 if bb == "mit_b0" else build_model(R, bb)
+        m = m0 if bb == "mit_b0" else build_model(R, bb, head=S.head_tag("mit_b3", 4, 64, 96))
         x = t(seg_in_b2)
         xg = x.clone().requires_grad_(True)
         feats = m.denoise_net.encoder(xg)
@@ -229,8 +235,10 @@ def main():
 
     conf = confusion_matrix(lab, npy(pred))
     prec, rec, iou = R["util"].compute_results(conf)
+    print("gf_model_b3_4x64x96: class shares of the reference's prediction", class_share(npy(pred)), "mIoU %.4f" % np.nanmean(iou))
     save("gf_model_b3_4x64x96", fused=npy(f), logits=npy(s), pred=npy(pred).astype(np.uint8), conf=conf,
-         precision=prec, recall=rec, iou=iou)
+         precision=prec, recall=rec, iou=iou, class_share=class_share(npy(pred)))
+    S.load_formula_weights(m3, head=S.head_tag("mit_b3", 1, 480, 640))       # the head fitted on this very pair
     ir, vis, lab = S.make_batch(1, 480, 640)
     with torch.no_grad():
         f, s = m3(t(ir), t(vis))
@@ -244,8 +252,16 @@ def main():
         f64, s64 = m3(t(ir).double(), t(vis).double())
     torch.set_default_dtype(torch.float32)
     m3.float()
+    up64 = torch.nn.functional.interpolate(s64, size=lab.shape[1:], mode="bilinear", align_corners=False)
+    pred64 = up64.argmax(1)
+    conf = confusion_matrix(lab, npy(pred))
+    conf64 = confusion_matrix(lab, npy(pred64))
+    print("gf_model_b3_1x480x640: class shares", class_share(npy(pred)), "mIoU %.5f (float64 run %.5f), pixels the reference's "
+          "float32 and float64 runs disagree on: %d" % (np.nanmean(R["util"].compute_results(conf)[2]),
+                                                        np.nanmean(R["util"].compute_results(conf64)[2]), int((npy(pred) != npy(pred64)).sum())))
     save("gf_model_b3_1x480x640", fused=npy(f).astype(np.float32), logits=npy(s),
-         pred=npy(pred).astype(np.uint8), fused64=npy(f64).astype(np.float32), logits64=npy(s64).astype(np.float32))
+         pred=npy(pred).astype(np.uint8), fused64=npy(f64).astype(np.float32), logits64=npy(s64).astype(np.float32),
+         pred64=npy(pred64).astype(np.uint8), conf=conf, conf64=conf64, class_share=class_share(npy(pred)))
 
     # ---- G-g: attack_both (3 iters, mit_b0, 2 x 64x96), PGD / segPGD / cosPGD ------------------
     ir, vis, lab = S.make_batch(2, 64, 96)

@@ -74,7 +74,7 @@ def main():
     R = ref_import.load()
     torch.set_num_threads(8)
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
-    m0 = build_model(R, "mit_b0")
+    m0 = build_model(R, "mit_b0", head=S.head_tag("mit_b0", 2, 64, 96))
     ir, vis, lab = (t(a) for a in S.make_batch(2, 64, 96))
     torch.manual_seed(1234)
     d0_ir = torch.zeros_like(ir).uniform_(-EPS, EPS)
@@ -99,6 +99,10 @@ def main():
         up64 = torch.nn.functional.interpolate(s64, size=lab.shape[1:], mode="bilinear", align_corners=False)
         pred64 = up64.argmax(1)
 
+    with torch.no_grad():                                       # the same model on the CLEAN pair: what the attack destroys
+        _, seg_c = m0(ir, vis)
+        pred_clean = torch.nn.functional.interpolate(seg_c, size=lab.shape[1:], mode="bilinear", align_corners=False).argmax(1)
+    conf_clean = O.confusion_matrix(lab.numpy(), pred_clean.numpy())
     conf = O.confusion_matrix(lab.numpy(), r32["pred"].numpy())
     conf64 = O.confusion_matrix(lab.numpy(), pred64.numpy())
     iou = O.compute_results(conf)[2]
@@ -115,12 +119,16 @@ def main():
     print("  sign-mismatch fraction (ir, vis) per iteration:\n", np.array2string(floor_sign, precision=5))
     print("  differing delta elements (ir, vis):", floor_delta, " moved pixels:", int((npy(r32["pred"]) != npy(pred64)).sum()),
           " mIoU %.5f vs %.5f" % (float(np.nanmean(iou)), float(np.nanmean(iou64))))
+    share = lambda p: (np.bincount(npy(p).ravel(), minlength=9) / float(npy(p).size)).astype(np.float32)
+    print("  clean prediction: class shares", share(pred_clean), "mIoU %.5f;  attacked: class shares" % float(np.nanmean(O.compute_results(conf_clean)[2])),
+          share(r32["pred"]), " pixels the attack moved:", int((npy(pred_clean) != npy(r32["pred"])).sum()), "of", npy(pred_clean).size)
     save("gn_attack_PGD10", d0_ir=npy(d0_ir), d0_vis=npy(d0_vis), delta_ir=npy(r32["d_ir"]), delta_vis=npy(r32["d_vis"]),
          gsum_ir=npy(r32["g_ir"]), gsum_vis=npy(r32["g_vis"]), losses=r32["losses"],
          sign_ir_per_iter=np.stack([sign(s["g_ir"]) for s in tr32]), sign_vis_per_iter=np.stack([sign(s["g_vis"]) for s in tr32]),
          sign64_ir_per_iter=np.stack([sign(s["g_ir"]) for s in tr64]), sign64_vis_per_iter=np.stack([sign(s["g_vis"]) for s in tr64]),
          losses64=np.array([s["loss"] for s in tr64]), delta64_ir=npy(od_ir).astype(np.float32), delta64_vis=npy(od_vis).astype(np.float32),
          pred=npy(r32["pred"]).astype(np.uint8), pred64=npy(pred64).astype(np.uint8), conf=conf, conf64=conf64,
+         pred_clean=npy(pred_clean).astype(np.uint8), conf_clean=conf_clean, class_share=share(r32["pred"]), class_share_clean=share(pred_clean),
          logits=npy(r32["logits"]), fused=npy(r32["fused"]),
          floor_sign=floor_sign, floor_loss=floor_loss, floor_delta=floor_delta)
 

@@ -471,6 +471,26 @@ def model_forward(ir, vis, sd, backbone="mit_b3", geno=FUSION_AT, inter=None):
     return fused, seg
 
 
+def model_forward_object(ir, vis, sd, backbone="mit_b3", geno=FUSION_AT):
+    """Network_MM_CompModel.forward_object / Network_MM_Searched.forward_object (core/model_fusion_auto.py:736-766 / :1067-1097):
+    the fused plane is clamped to [0,1] and min-max normalised over the whole batch BEFORE the recomposition; that plane is what
+    the method returns next to the segmentation map."""
+    ycc = rgb2ycrcb(vis)
+    fused = fusion_forward(ir[:, 0:1], ycc[:, 0:1], sd, "enhance_net.", geno)
+    ones, zeros = torch.ones_like(fused), torch.zeros_like(fused)
+    fused = torch.where(fused > ones, ones, fused)
+    fused = torch.where(fused < zeros, zeros, fused)
+    fused = (fused - torch.min(fused)) / (torch.max(fused) - torch.min(fused))
+    seg = wetr_forward(seg_input_from_fused(fused, ycc), sd, "denoise_net.", backbone)
+    return fused, seg
+
+
+def detection_loss(ir, vis, labels, sd, backbone="mit_b3"):
+    """_detection_loss (core/model_fusion_auto.py:796-800 / :1123-1128): CrossEntropyLoss(ignore_index=255) on forward_object's map."""
+    _, seg = model_forward_object(ir, vis, sd, backbone)
+    return F.cross_entropy(F.interpolate(seg, size=labels.shape[1:], mode="bilinear", align_corners=False), labels.long(), ignore_index=255)
+
+
 # --------------------------------------------------------------------------------------
 # attack -- attack/attack.py
 # --------------------------------------------------------------------------------------

@@ -129,6 +129,10 @@ SIGNATURES = {
     "paif_spa1_bwd_input": (c_int, [F, F, F, F, F, c_int, F, F, F, F, c_int, c_int, c_int, F]),
     "paif_glue_bwd_blocks": (c_int, [c_int, c_int, c_int]),
     "paif_glue_bwd_input": (c_int, [F, F, F, F, F, F, F, F, c_int, c_int, c_int, F]),
+    "paif_plane_minmax_blocks": (c_int, [c_size_t]),
+    "paif_plane_clamp_minmax_fwd": (c_int, [F, F, F, F, c_size_t, F]),
+    "paif_plane_clamp_minmax_bwd_input": (c_int, [F, F, F, F, F, c_size_t, F]),
+    "paif_channel_sum_chunks_fwd": (c_int, [F, F, c_int, c_int, c_int, c_int, F]),
     "paif_rgb2ycrcb_bwd_input": (c_int, [F, F, F, c_int, c_int, c_int, F]),
     "paif_pgd_step": (c_int, [F, F, F, c_float, c_float, c_size_t, F]),
     "paif_axpy": (c_int, [F, F, c_float, c_size_t, F]),

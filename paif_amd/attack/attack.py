@@ -89,6 +89,9 @@ def _attack_loop(model, X_vis, X_ir, label, lab64, epsilon, alpha, attack_iters,
                     _, logits, tape = model.forward_taped(ops.add(X_ir, d_ir), ops.add(X_vis, d_vis))
                     way, wt, wf = ops.attack_loss_weights(attack_way, i, attack_iters)
                     coef = ops.attack_loss_fwd(logits, lab64, way, wt, wf)    # loss + the backward's scalars, on the device
+                    if i == 0 and not torch.cuda.is_current_stream_capturing() and float(coef[7]) != 0.0:
+                        # torch's CrossEntropyLoss (the reference's Seg_loss) raises on such a mask; the kernel never indexes with it
+                        raise RuntimeError("attack: %d label value(s) outside [0, %d) that are not ignore_index 255" % (int(coef[7]), logits.shape[-1]))
                     d32 = ops.attack_loss_bwd(logits, lab64, coef, way, wt, wf)
                     gi, gv = model.backward_taped(d32, tape)
                     loss = coef[0]

@@ -601,11 +601,15 @@ class _CompositeBase(nn.Module):
         return fused, seg_map
 
     # ---- taped forward / hand-written reverse pass (input gradients only) -------------------------
-    def forward_taped(self, ir, vis):
-        """-> (fused [B,1,H,W], logits NHWC [B,H/4,W/4,ncls], tape)."""
+    def forward_taped(self, ir, vis, object_glue=False):
+        """-> (fused [B,1,H,W], logits NHWC [B,H/4,W/4,ncls], tape).  object_glue: forward_object's form (:743-751) -- the fused
+        plane is clamped to [0,1] and min-max normalised (batch-global) before the recomposition, and THAT plane is returned."""
         tape = dict(fus={}, seg={}, ir_shape=tuple(ir.shape))
         ycc = ops.rgb2ycrcb(vis)
         fused = self.enhance_net.forward_impl(ir[:, 0:1, :, :], ycc, tape=tape["fus"])
+        if object_glue:
+            tape["fused_raw"] = fused
+            fused, tape["plane_minmax"] = ops.plane_clamp_minmax(fused)
         seg_in, mm = ops.seg_input_from_fused(fused, ycc, return_minmax=True)
         logits = self.denoise_net.forward_nhwc(ops.nchw_to_nhwc(seg_in), tape["seg"])
         tape.update(ycc=ycc, fused=fused, minmax=mm)
@@ -616,6 +620,8 @@ class _CompositeBase(nn.Module):
         wgrad: parameter gradients of both networks too (the tape must come from forward_taped under tape_mode("wgrad"))."""
         d_seg_in = ops.nhwc_to_nchw(self.denoise_net.backward_nhwc(d_logits32, tape["seg"], wgrad))
         d_f, dcrcb = ops.glue_bwd(d_seg_in, tape["fused"], tape["ycc"], tape["minmax"], d_fused)
+        if "fused_raw" in tape:                                   # forward_object: back through the plane's clamp + min-max
+            d_f = ops.plane_clamp_minmax_bwd(d_f, tape["fused_raw"], tape["plane_minmax"])
         d_ir1, d_y = self.enhance_net.backward_impl(d_f, tape["fus"], wgrad)
         d_vis = ops.rgb2ycrcb_bwd(d_y, dcrcb)
         shp = tape["ir_shape"]
@@ -631,7 +637,18 @@ class _CompositeBase(nn.Module):
             return self.enhance_net.forward(ir[:, 0:1, :, :], ops.rgb2ycrcb(vis))
 
     def forward_object(self, ir, vis):
-        raise NotImplementedError("forward_object (second min-max on the fused plane, :743-772) is only used by _detection_loss; not built")
+        """:736-766 / :1067-1097 -- the segmentation objective on a fused plane that is first clamped to [0,1] and min-max
+        normalised over the batch (the name is historical: no detection head is involved) -> (that plane, seg_map)."""
+        wg = ops.want_param_grads(self)
+        if torch.is_grad_enabled() and (ir.requires_grad or vis.requires_grad or wg):
+            return _CompositeFn.apply(ir, vis, self, wg, grad_anchor(ir.device), True)
+        with torch.no_grad():
+            ycc = ops.rgb2ycrcb(vis)
+            with ops.bf16_activations(enable=not self.enhance_net.training):
+                fused = self.enhance_net.forward_impl(ir[:, 0:1, :, :], ycc)
+            fused, _ = ops.plane_clamp_minmax(fused)
+            seg_map = self.denoise_net(ops.seg_input_from_fused(fused, ycc, minmax_sync=self._minmax_sync()))
+        return fused, seg_map
 
     # ---- training-API losses (:1093-1128): values, input gradients and parameter gradients (the models' autograd nodes +
     # the loss gradient kernels); `loss.backward()` fills param.grad like in the reference.
@@ -671,8 +688,10 @@ class _CompositeBase(nn.Module):
 
     _fusion_loss_wogan = _fusion_loss
 
-    def _detection_loss(self, *a, **k):
-        raise NotImplementedError("_detection_loss needs forward_object (second min-max on the fused plane, :743-772); not built")
+    def _detection_loss(self, ir, vis, labels):
+        """:796-800 / :1123-1128: seg_loss on forward_object's map."""
+        _, seg_map = self.forward_object(ir, vis)
+        return self._seg_term(seg_map, labels)
 
     def enhance_net_parameters(self):
         return self.enhance_net.parameters()
@@ -687,9 +706,9 @@ class _CompositeFn(torch.autograd.Function):
     gradients of both networks are accumulated straight into param.grad by the wgrad kernels."""
 
     @staticmethod
-    def forward(ctx, ir, vis, module, wgrad, anchor):
+    def forward(ctx, ir, vis, module, wgrad, anchor, object_glue=False):
         with ops.tape_mode("wgrad" if wgrad else "dgrad"):
-            fused, logits, tape = module.forward_taped(ir.detach(), vis.detach())
+            fused, logits, tape = module.forward_taped(ir.detach(), vis.detach(), object_glue)
         ctx.tape, ctx.module, ctx.wgrad = tape, module, wgrad
         return fused, ops.nhwc_to_nchw(logits)
 
@@ -698,7 +717,7 @@ class _CompositeFn(torch.autograd.Function):
         d32 = ops.nchw_to_nhwc_pad(d_seg, 32)
         d_ir, d_vis = ctx.module.backward_taped(d32, ctx.tape, d_fused.contiguous(), ctx.wgrad)
         ctx.tape = None
-        return d_ir, d_vis, None, None, None
+        return d_ir, d_vis, None, None, None, None
 
 
 def grad_milestones(model):

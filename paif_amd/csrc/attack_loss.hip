@@ -19,7 +19,7 @@
 namespace {
 
 constexpr int AL_MAXC = 32;
-constexpr int AL_NPART = 5;   // weighted nll sum, #valid, <p,l>, <p,p>, <l,l>
+constexpr int AL_NPART = 6;   // weighted nll sum, #valid, <p,l>, <p,p>, <l,l>, #labels outside [0,C) that are not ignore_index
 
 inline int al_grid(size_t n) {
   size_t b = (n + 255) / 256;
@@ -37,6 +37,7 @@ __device__ __forceinline__ void al_src_index(float scale, int o, int isz, int& i
 // coef (device, written by the finish kernel, read by the backward kernel):
 //   [0] loss  [1] #valid  [2] plain CE  [3] cos  [4] a = d loss / d nll_pixel base (1/Nv, times cos for way 2)
 //   [5] bl = CE / (|p||l|)   [6] bp = CE * cos / |p|^2        (way 2:  d loss / d pred_i = bl * label_i - bp * pred_i)
+//   [7] number of labels outside [0, C) that are not ignore_index (0 for a well-formed mask)
 template <bool BWD>
 __global__ __launch_bounds__(256) void attack_loss_kernel(const float* __restrict__ logits, const long long* __restrict__ label,
                                                           float* __restrict__ partial, float* __restrict__ dfull,
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(256) void attack_loss_kernel(const float* __restric
   const size_t total = (size_t)B * OH * OW;
   const float sy = (float)IH / (float)OH, sx = (float)IW / (float)OW;
   const float logC = logf((float)C);
-  float acc[AL_NPART] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  float acc[AL_NPART] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float a = 0.f, bl = 0.f, bp = 0.f;
   if (BWD) { a = coef[4] * upstream; bl = coef[5] * upstream; bp = coef[6] * upstream; }
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -54,7 +55,11 @@ __global__ __launch_bounds__(256) void attack_loss_kernel(const float* __restric
     const int oy = (int)(t % OH);
     const int b = (int)(t / OH);
     const long long lab = label[i];
-    const bool valid = lab != (long long)ignore;
+    // a label outside [0, C) that is not ignore_index (torch's cross entropy raises on it): never used as an index -- the pixel is
+    // dropped like an ignored one and COUNTED (coef[7]); the attack entry points validate the label range once per call on the host
+    const bool bad = lab != (long long)ignore && (lab < 0 || lab >= (long long)C);
+    const bool valid = lab != (long long)ignore && !bad;
+    if (!BWD && bad) acc[5] += 1.f;
     if (!valid && way != 2) {
       if (BWD) for (int c = 0; c < CP; ++c) dfull[i * CP + c] = 0.f;
       continue;
@@ -145,7 +150,7 @@ __global__ void attack_loss_finish_kernel(const float* __restrict__ partial, int
       bl = mean / n12;                      // d cos / d p_i = l_i / n12 - cos * p_i / <p,p>   (clamp inactive)
       bp = mean * cosv / w1;
     }
-    coef[0] = loss; coef[1] = nv; coef[2] = mean; coef[3] = cosv; coef[4] = a; coef[5] = bl; coef[6] = bp; coef[7] = 0.f;
+    coef[0] = loss; coef[1] = nv; coef[2] = mean; coef[3] = cosv; coef[4] = a; coef[5] = bl; coef[6] = bp; coef[7] = (float)acc[5];
   }
 }
 

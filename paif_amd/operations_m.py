@@ -55,19 +55,25 @@ def invalidate_weight_caches():
 
 
 class _PackCache:
-    """Packed-weight cache keyed on (data_ptr, version, device) of the source parameter(s) + the global weights generation
-    (invalidate_weight_caches)."""
+    """Packed-weight cache: one entry per (name, conv precision), valid for (data_ptr, version, device) of the source parameter(s) +
+    the global weights generation (invalidate_weight_caches).  The precision is part of the SLOT, not of the validity key: the attack
+    loops switch the arithmetic (ops.attack_arithmetic: bf16x3 <-> bf16x6) around every call, and both packs must survive that --
+    otherwise every attack + clean forward rebuilt ~150 packs twice per batch, and under a hipGraph capture the rebuilt pack would
+    live in capture-pool memory that holds garbage until the first replay."""
 
     def __init__(self):
         self._store = {}
 
     def get(self, name, params, builder):
-        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in params) + (ops.CONFIG["conv_precision"],
-                                                                                   ops.CONFIG.get("weights_generation", 0))
-        hit = self._store.get(name)
+        slot = (name, ops.CONFIG["conv_precision"])
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in params) + (ops.CONFIG.get("weights_generation", 0),)
+        hit = self._store.get(slot)
         if hit is None or hit[0] != key:
+            if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("weight pack %r (%s) is missing while a hipGraph is being captured: run one eager step in this "
+                                   "arithmetic first (the pack kernels and their buffers must not live inside the capture)" % slot)
             hit = (key, builder())
-            self._store[name] = hit
+            self._store[slot] = hit
         return hit[1]
 
 
@@ -398,7 +404,7 @@ def _bn_split(bn, c, act, slope, res):
 def _bn_scale_shift(bn, cache=None, name="bn"):
     """Eval-mode BatchNorm folded to per-channel scale/shift (cached on parameter/buffer versions)."""
     if bn.training:
-        raise NotImplementedError("train-mode BatchNorm (batch statistics) is part of the training step, not built yet; call .eval()")
+        raise RuntimeError("_bn_scale_shift folds RUNNING statistics: train-mode BatchNorm goes through _bn_split (batch statistics)")
 
     def build():
         if bn.affine:
@@ -493,7 +499,13 @@ class eca_layer(nn.Module):
         self.conv = Conv1dParams(1, 1, kernel_size=k_size, padding=(k_size - 1) // 2, bias=False)
 
     def forward(self, x):
-        raise NotImplementedError("eca_layer runs fused inside ECABasicBlock (conv2 epilogue pool + eca_finish kernel)")
+        """Stand-alone call (operations_m.py:353-367); inside ECABasicBlock the same arithmetic runs fused (conv2's epilogue pools,
+        eca_finish applies the gate).  Inference only, like every stand-alone helper of the import surface."""
+        ops.require_no_grad(x)
+        if x.shape[1] != 32:
+            raise NotImplementedError("eca_layer: the HIP kernels are built for the 32-channel maps of the search space")
+        with torch.no_grad():
+            return ops.to_nchw_view(ops.eca_layer_fwd(ops.to_nhwc(x), self.conv.weight, self.k_size))
 
 
 class ECABasicBlock(_HipOp):
@@ -607,7 +619,16 @@ class ChannelPool(nn.Module):
     """operations_m.py:148-150 (1-argument form, only inside spatial_attn_layer)."""
 
     def forward(self, x):
-        raise NotImplementedError("ChannelPool(1-arg) is only reachable through SPAattention (not built yet)")
+        """cat(max_c x, mean_c x) -> [B,2,H,W]; inside Spatial_BasicBlock it runs fused in the spa1 kernel, whose pooled map this
+        stand-alone call returns."""
+        ops.require_no_grad(x)
+        if x.shape[1] != 32:
+            raise NotImplementedError("ChannelPool: the HIP kernels are built for the 32-channel maps of the search space")
+        with torch.no_grad():
+            xh = ops.to_nhwc(x)
+            one = torch.ones(1, device=x.device, dtype=torch.float32)
+            comp = ops.spa1(xh, torch.zeros_like(xh), torch.zeros(1, 2, 3, 3, device=x.device), 3, one, save=True, want_comp=True)[3]
+            return comp.permute(0, 3, 1, 2).contiguous()
 
 
 class spatial_attn_layer(nn.Module):
@@ -619,7 +640,16 @@ class spatial_attn_layer(nn.Module):
         self.spatial = BasicConv(2, 1, kernel_size, relu=False)
 
     def forward(self, x):
-        raise NotImplementedError("spatial_attn_layer is only reachable through SPAattention (not built yet)")
+        """x * sigmoid(conv_k(ChannelPool(x)))  (operations_m.py:159-164): the fused block's spa1 kernel with a zero residual and
+        PReLU slope 1 (= identity)."""
+        ops.require_no_grad(x)
+        if x.shape[1] != 32:
+            raise NotImplementedError("spatial_attn_layer: the HIP kernels are built for the 32-channel maps of the search space")
+        with torch.no_grad():
+            xh = ops.to_nhwc(x)
+            one = torch.ones(1, device=x.device, dtype=torch.float32)
+            k = self.spatial.conv.weight.shape[-1]
+            return ops.to_nchw_view(ops.spa1(xh, torch.zeros_like(xh), self.spatial.conv.weight, k, one))
 
 
 def _selfpath(*a, **k):

@@ -33,13 +33,17 @@ ACT_GELU = 1  # paif_gemm_fwd's act code 1 is GELU (the conv's code 1 is PReLU)
 # With the round-2 kernels split-bf16 is the faster GEMM for every shape without split-K (tools/gemm_shapes_b16.py: another ~2 % on
 # configs[2]); "auto" keeps K < 256 exact because that is what keeps the default inside the reference's own fp32 noise floor.
 #
-# Arithmetic of the ATTACKS (attack_both / attack_vis / attack_ir and the single-modality variants): "exact" (default) runs the
-# whole attack loop -- taped forward AND input-gradient reverse pass -- on the exact-fp32 kernels whatever the two settings above
-# say; "fast" leaves them in force.  Measured in round 3 (tests/test_parity_default_gpu.py, tools/pgd_precision_sweep.py; PGD-10,
-# 2x64x96, mit_b0, against the reference's float64 run): sign(running gradient sum) is a chaotic map, and the split-bf16 conv
-# products (~1e-5 relative) put 2.4e-4 of the elements on the other side of zero in iteration 1, 2.5e-2 by iteration 10 (differing
-# delta elements 5.3 %, loss trajectory 3.3e-3) -- the reference's own float32-vs-float64 disagreement is 0 / 4.1e-4 / 0.13 % / 6e-5,
-# and the exact kernels sit at 0 / 8e-5.  The SURVEY 8(a) A1 metric (<= 1e-3 per iteration) therefore holds in "exact" only.
+# Arithmetic of the ATTACKS (attack_both / attack_vis / attack_ir and the single-modality variants), CONFIG["attack_precision"]:
+#   "bf16x6" (DEFAULT) -- the whole attack loop (taped forward AND input-gradient reverse pass) at fp32-level precision: convs and the
+#              K >= 256 GEMMs as three-piece bf16 splits (six MFMAs per product, 2^-25 per product), the other GEMMs and attention on the
+#              exact-fp32 kernels, whatever the two settings above say.  SURVEY 8(a) A1 (sign mismatch <= 1e-3 per iteration) HOLDS:
+#              measured sign mismatch against the reference's float64 run 0 in every iteration through PGD-10;
+#   "exact"  -- opt-in: every kernel of the loop fp32-exact (fp32 MFMA, 157 TF): A1 holds (0 ... 8e-5 at iteration 10), 20 % slower;
+#   "fast"   -- opt-in: the settings above stay in force inside the loop (split-bf16 conv products, ~1e-5 relative): sign(running
+#              gradient sum) is a chaotic map and 2.4e-4 of the elements sit on the other side of zero in iteration 1, 2.5e-2 by
+#              iteration 10 (differing delta elements 5.3 %, loss trajectory 3.3e-3; the reference's own float32-vs-float64
+#              disagreement: 0 / 4.1e-4 / 0.13 % / 6e-5) -- A1 holds for the first three iterations only.
+# Measured in round 3 (tests/test_parity_default_gpu.py, tools/pgd_precision_sweep.py; PGD-10, 2x64x96, mit_b0).
 #
 # Activation STORAGE of the fusion network's inference forward (BASELINE configs[1] names "bf16"): "f32" (default: every map
 # fp32, parity at the fp32 tolerance) or "bf16": the 32-channel maps behind the guided-filter block (everything from the two
@@ -114,7 +118,9 @@ def set_attack_precision(mode):
 
 
 class attack_arithmetic:
-    """Context of an attack loop: switches the conv / GEMM arithmetic to exact fp32 when CONFIG['attack_precision'] == 'exact'."""
+    """Context of an attack loop: switches the conv / GEMM arithmetic to CONFIG['attack_precision'] -- "bf16x6" (the DEFAULT:
+    three-piece bf16 splits for the convs and the K >= 256 GEMMs, exact fp32 MFMA for the rest; fp32-level parity), "exact" (opt-in:
+    fp32-exact kernels everywhere) or "fast" (opt-in: leave set_conv_precision / set_gemm_precision in force)."""
 
     def __enter__(self):
         self.old = (CONFIG["conv_precision"], CONFIG["gemm_precision"])
@@ -624,6 +630,19 @@ def eca_finish(o, r, partial, w1d, k, prelu, save=False):
     _lib.check(lib().paif_eca_finish_fwd(_p(o), _p(r), _p(partial), _p(w1d.detach().contiguous()), k, _p(prelu), _p(gate), _p(out),
                                          _p(u), B, H, W, _stream()), "eca_finish")
     return (out, u, gate) if save else out
+
+
+def eca_layer_fwd(x, w1d, k):
+    """Stand-alone eca_layer.forward (operations_m.py:353-367) on an NHWC fp32 map: x * sigmoid(conv1d_k(avgpool(x))) -- the pooling
+    kernel + the fused block's own finish kernel (zero residual, PReLU slope 1 = identity)."""
+    B, H, W, C = x.shape
+    assert C == 32 and x.dtype == torch.float32
+    L = lib()
+    chunks = L.paif_conv2d_blocks(1, H, W)
+    partial = torch.empty((B, chunks, 32), device=x.device, dtype=torch.float32)
+    _lib.check(L.paif_channel_sum_chunks_fwd(_p(x), _p(partial), chunks, B, H, W, _stream()), "channel_sum_chunks")
+    one = torch.ones(1, device=x.device, dtype=torch.float32)
+    return eca_finish(x, torch.zeros_like(x), partial, w1d, k, one)
 
 
 def eca_bwd(dout, u, o, gate, w1d, k, prelu, want_partial=False):
@@ -1165,13 +1184,14 @@ def attack_loss_weights(attack_way, i, attack_iters):
 
 
 def attack_loss_fwd(logits, label, way, w_true=1.0, w_false=1.0, ignore_index=255):
-    """logits NHWC [B,IH,IW,C], label int64 [B,OH,OW] -> coef tensor [8]: (loss, #valid, CE, cos, ...) -- paif_attack_loss_fwd."""
+    """logits NHWC [B,IH,IW,C], label int64 [B,OH,OW] -> coef tensor [8]: (loss, #valid, CE, cos, ..., [7] = number of labels outside
+    [0, C) that are not ignore_index: dropped like ignored pixels, never used as an index) -- paif_attack_loss_fwd."""
     B, IH, IW, C = logits.shape
     _, OH, OW = label.shape
     assert label.dtype == torch.int64 and label.is_cuda and label.is_contiguous()
     L = lib()
     nblk = L.paif_attack_loss_blocks(B, OH, OW)
-    partial = torch.empty(5 * nblk, device=logits.device, dtype=torch.float32)
+    partial = torch.empty(6 * nblk, device=logits.device, dtype=torch.float32)
     coef = torch.empty(8, device=logits.device, dtype=torch.float32)
     _lib.check(L.paif_attack_loss_fwd(_p(logits), ctypes.c_void_p(label.data_ptr()), _p(partial), _p(coef), way, w_true, w_false,
                                       B, IH, IW, C, OH, OW, ignore_index, _stream()), "attack_loss_fwd")
@@ -1459,6 +1479,30 @@ def glue_bwd(dseg, fused, ycc, minmax, dfused_direct=None):
     _lib.check(L.paif_glue_bwd_input(_p(dseg.contiguous()), _p(fused), _p(ycc), _p(minmax), _p(dfused_direct), _p(partial), _p(dfused),
                                      _p(dcrcb), B, H, W, _stream()), "glue_bwd")
     return dfused, dcrcb
+
+
+def plane_clamp_minmax(x):
+    """forward_object's extra step (core/model_fusion_auto.py:743-751): clamp to [0,1], batch-global min-max.
+    x [B,1,H,W] -> (normalised plane, the 2 floats (min, max) the backward needs)."""
+    x = x.contiguous()
+    L = lib()
+    n = x.numel()
+    partial = torch.empty(2 * L.paif_plane_minmax_blocks(n), device=x.device, dtype=torch.float32)
+    out = torch.empty_like(x)
+    mm = torch.empty(2, device=x.device, dtype=torch.float32)
+    _lib.check(L.paif_plane_clamp_minmax_fwd(_p(x), _p(out), _p(partial), _p(mm), n, _stream()), "plane_clamp_minmax")
+    return out, mm
+
+
+def plane_clamp_minmax_bwd(dout, x, mm):
+    x = x.contiguous()
+    L = lib()
+    n = x.numel()
+    partial = torch.empty(4 * L.paif_plane_minmax_blocks(n), device=x.device, dtype=torch.float32)
+    dx = torch.empty_like(x)
+    _lib.check(L.paif_plane_clamp_minmax_bwd_input(_p(dout.contiguous()), _p(x), _p(mm), _p(partial), _p(dx), n, _stream()),
+               "plane_clamp_minmax_bwd")
+    return dx
 
 
 def rgb2ycrcb_bwd(dY, dcrcb):

@@ -10,6 +10,7 @@ Input contract mirrored from the reference dataset class (TaskFusion_dataset2.py
 vis = RGB uint8 / 255 -> float32 [3,H,W]; ir = gray uint8 / 255 -> float32 [1,H,W];
 label = int64 [H,W] in {0..8} (255 = ignore).
 """
+import os
 import zlib
 
 import numpy as np
@@ -79,12 +80,60 @@ def formula_state_dict(shapes, salt=0):
     return {k: formula_tensor(k, s, salt) for k, s in shapes.items()}
 
 
-def load_formula_weights(module, salt=0, strict=True):
-    """Fill a torch module's state_dict from the formula (strict key check)."""
+# Calibrated segmentation head ---------------------------------------------------------------------------------------
+# With formula weights everywhere the SegFormer head predicts ONE class on every pixel (the class means of its last layer
+# swamp the spatial variation), which makes argmax / confusion-matrix / mIoU parity checks vacuous.  oracle/calibrate_head.py
+# therefore fits `decoder.linear_pred.{weight,bias}` (core/segformer_head.py:57) per parity case by ridge regression of the
+# synthetic labels on the REFERENCE's own head feature and stores the float32 table in synthetic_head.npz: with it the
+# reference's argmax has all 9 classes (>= 5 % each), near-ties along every class boundary and a label-correlated map.
+HEAD_KEYS = ("decoder.linear_pred.weight", "decoder.linear_pred.bias")
+_HEAD_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "synthetic_head.npz")
+_head_cache = {}
+
+
+def head_tag(backbone, B, H, W):
+    """Name of a calibration case: the backbone and the batch it was fitted on, e.g. 'mit_b3_1x480x640'."""
+    return "%s_%dx%dx%d" % (backbone, B, H, W)
+
+
+def calibrated_head(tag):
+    """(weight [9,256,1,1], bias [9]) float32 of a calibration case, plus the reference's class shares on its inputs."""
+    if not _head_cache:
+        _head_cache.update(dict(np.load(_HEAD_FILE)))
+    if tag + ".weight" not in _head_cache:
+        raise KeyError("no calibrated head %r (have: %s)" % (tag, sorted(k[:-7] for k in _head_cache if k.endswith(".weight"))))
+    return _head_cache[tag + ".weight"], _head_cache[tag + ".bias"], _head_cache[tag + ".class_share"]
+
+
+def apply_head(state_dict, tag):
+    """Overwrite the `...decoder.linear_pred.{weight,bias}` entries of a (numpy or torch) state_dict with a calibrated head."""
+    w, b, _ = calibrated_head(tag)
+    hit = 0
+    for k in list(state_dict):
+        for suffix, val in zip(HEAD_KEYS, (w, b)):
+            if k.endswith(suffix):
+                old = state_dict[k]
+                if isinstance(old, np.ndarray):
+                    state_dict[k] = val.copy()
+                else:
+                    import torch
+
+                    state_dict[k] = torch.from_numpy(val.copy()).to(old.dtype)
+                hit += 1
+    if hit != 2:
+        raise KeyError("state_dict has no decoder.linear_pred entries to calibrate")
+    return state_dict
+
+
+def load_formula_weights(module, salt=0, strict=True, head=None):
+    """Fill a torch module's state_dict from the formula (strict key check); `head` = a calibration tag (head_tag(...))
+    replaces the segmentation head's last layer by the fitted table."""
     import torch
 
     sd = module.state_dict()
     new = {k: torch.from_numpy(formula_tensor(k, tuple(v.shape), salt)).to(v.dtype) for k, v in sd.items()}
+    if head is not None:
+        apply_head(new, head)
     module.load_state_dict(new, strict=strict)
     return module
 

@@ -34,12 +34,14 @@ def _exact_convs():
     ops.set_gemm_precision(oldg)
 
 
-def _model(bb="mit_b0"):
+def _model(bb="mit_b0", head="cal"):
+    """head: "cal" = the calibrated segmentation head of the 64x96 cases (multi-class reference maps; tests/helpers.py HEAD64),
+    None = the formula head (goldens gg3_* / gl_* were generated with it)."""
     from oracle.paif_oracle import FUSION_AT
     from paif_amd.core.model_fusion_auto import Network_MM_Searched
 
     m = Network_MM_Searched(32, FUSION_AT, None, None, bb, num_classes=9).eval()
-    S.load_formula_weights(m)
+    S.load_formula_weights(m, head=Hh.HEAD64[bb] if head == "cal" else head)
     return m.to(_dev())
 
 
@@ -193,6 +195,7 @@ def test_seg_loss_and_metrics(golden):
     ir, vis, lab4 = S.make_batch(4, 64, 96)
     meter = ConfusionMeter(9, _dev())
     pred = meter.update(t(gm["logits"]).to(_dev()), t(lab4).to(_dev()))
+    Hh.assert_multiclass(gm["pred"], min_classes=9)
     assert (pred.cpu().numpy() == gm["pred"]).mean() >= 0.9999
     conf = O.confusion_matrix(lab4, pred.cpu().numpy())
     assert (meter.conf.cpu().numpy() == conf).all()
@@ -228,8 +231,14 @@ def test_harness_clean_eval_config1(golden):
     ir, vis, lab = S.make_batch(4, 64, 96)
     # the reference loader uses batch_size 1, but the golden was captured on the batch of 4 (min-max is batch-global)
     out = val_segformer_robust2(m, [(t(vis).to(_dev()), t(ir).to(_dev()), t(lab).to(_dev()))])
-    assert (out["conf"] == g["conf"]).all()
-    np.testing.assert_array_equal(np.nan_to_num(out["iou"], nan=-1), np.nan_to_num(g["iou"], nan=-1))
+    # the pin is discriminating: the reference's map has all 9 classes (>= 5 % of the pixels each) and a median top-2 logit
+    # margin of 3.5 % of the logit range, so a confusion matrix only matches if the logits do -- near-tie pixels (fp32 exact-conv
+    # arithmetic vs the reference's fp32) may land on the other side: <= 0.1 % of the pixels, mIoU within 0.1 pt
+    Hh.assert_multiclass(g["pred"], min_classes=9)
+    moved = int(np.abs(out["conf"] - g["conf"]).sum()) // 2
+    assert moved <= 1e-3 * g["conf"].sum(), moved
+    assert abs(float(np.nanmean(out["iou"])) - float(np.nanmean(g["iou"]))) <= 1e-3
+    assert float(np.nanmax(np.abs(out["iou"] - g["iou"]))) <= 5e-3
     assert maxabs(out["fused"][0].cpu(), g["fused"]) <= 1e-4
     # default = hipGraph replay; the eager path gives bit-identical results, over several batches and a shape change
     batches = [(t(vis[i:i + 1]).to(_dev()), t(ir[i:i + 1]).to(_dev()), t(lab[i:i + 1]).to(_dev())) for i in range(3)]
@@ -244,7 +253,7 @@ def test_harness_pgd_eval_vs_oracle():
     from paif_amd.harness import val_segformer_robust
 
     m = _model("mit_b0")
-    sd = Hh.model_sd("mit_b0")
+    sd = Hh.model_sd("mit_b0", Hh.HEAD64["mit_b0"])
     ir, vis, lab = S.make_batch(2, 64, 96)
     eps = 8 / 255.
     d0_ir = t(S.make_delta0(0, ir.shape, eps))
@@ -258,6 +267,7 @@ def test_harness_pgd_eval_vs_oracle():
         up = torch.nn.functional.interpolate(seg, size=lab.shape[1:], mode="bilinear", align_corners=False)
     conf = O.confusion_matrix(lab, up.argmax(1).numpy())
     iou = O.compute_results(conf)[2]
+    Hh.assert_multiclass(up.argmax(1).numpy(), min_classes=2)                     # the attacked map is not one class
     assert abs(out["miou"] - float(np.mean(np.nan_to_num(iou)))) <= 1e-3          # mIoU within 0.1 pt
     assert np.abs(out["conf"] - conf).sum() <= 0.002 * conf.sum()                 # <= 0.2 % of the pixels move
 
@@ -456,7 +466,7 @@ def test_round2_attack_branches(golden):
     from paif_amd.attack import attack as A
 
     g = golden("gg3_attacks_round2")
-    m = _model("mit_b0")
+    m = _model("mit_b0", head=None)
     ir, vis, lab = S.make_batch(2, 64, 96)
     irt, vist, labt = t(ir).to(_dev()), t(vis).to(_dev()), t(lab).to(_dev())
     eps, alpha = 8 / 255., 2 / 255.

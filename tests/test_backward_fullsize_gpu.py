@@ -118,7 +118,7 @@ def test_one_pgd_iteration_at_480x640_mit_b3_vs_oracle():
     from paif_amd.genotypes import FUSION_AT
 
     m = Network_MM_Searched(32, FUSION_AT, None, None, "mit_b3", num_classes=9).eval()
-    S.load_formula_weights(m)
+    S.load_formula_weights(m, head=S.head_tag("mit_b3", 1, 480, 640))     # calibrated head: a multi-class, label-correlated map
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     m.to(_dev())
     ir, vis, lab = S.make_batch(1, 480, 640)

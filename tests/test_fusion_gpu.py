@@ -583,3 +583,40 @@ def test_guided_filter_f16_range_fallback():
         else:
             os.environ["PAIF_GF_ENGINE"] = old
     assert torch.isfinite(b).all() and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("shape", [(2, 24, 40), (1, 37, 53)])
+def test_standalone_forwards_of_the_import_surface(shape):
+    """`eca_layer.forward`, `spatial_attn_layer.forward` and the 1-argument `ChannelPool.forward` (operations_m.py:148-164, 340-367)
+    called on their own -- inside the searched blocks they run fused; stand-alone they reuse the same kernels.  Against a plain torch
+    fp32 restatement of the reference's lines, on ragged sizes."""
+    import torch.nn.functional as F
+
+    from paif_amd.operations_m import ChannelPool, eca_layer, spatial_attn_layer
+
+    B, H, W = shape
+    dev = _dev()
+    x = t(S.make_feature(77, (B, 32, H, W), -2, 2)).to(dev)
+    for k in (3, 5):
+        eca = eca_layer(32, 32, 1, k_size=k)
+        S.load_formula_weights(eca, salt=k)
+        eca.to(dev)
+        with torch.no_grad():
+            y = eca(x)
+            gate = torch.sigmoid(F.conv1d(x.mean((2, 3)).unsqueeze(1), eca.conv.weight, padding=(k - 1) // 2)).squeeze(1)
+            ref = x * gate[:, :, None, None]
+        assert y.shape == x.shape and maxabs(y.cpu(), ref.cpu()) <= 2e-6
+        spa = spatial_attn_layer(k)
+        S.load_formula_weights(spa, salt=10 + k)
+        spa.to(dev)
+        with torch.no_grad():
+            z = spa(x)
+            comp = torch.cat((x.max(1, keepdim=True)[0], x.mean(1, keepdim=True)), 1)
+            ref = x * torch.sigmoid(F.conv2d(comp, spa.spatial.conv.weight, padding=k // 2))
+        assert maxabs(z.cpu(), ref.cpu()) <= 5e-6
+    with torch.no_grad():
+        c = ChannelPool()(x)
+    assert tuple(c.shape) == (B, 2, H, W)
+    assert maxabs(c[:, 0].cpu(), x.max(1)[0].cpu()) == 0.0 and maxabs(c[:, 1].cpu(), x.mean(1).cpu()) <= 1e-6
+    with pytest.raises(NotImplementedError):
+        eca_layer(32, 32, 1)(x.requires_grad_(True))            # forward-only helpers refuse to drop gradients silently

@@ -25,15 +25,26 @@ def _scale(a):
 _models = {}
 
 
-def _model(bb):
+def _model(bb, head="cal"):
+    """head: "cal" = the calibrated segmentation head of the 64x96 goldens (tests/helpers.py HEAD64), or an explicit tag."""
     from oracle.paif_oracle import FUSION_AT
     from paif_amd.core.model_fusion_auto import Network_MM_Searched
 
-    if bb not in _models:
+    tag = Hh.HEAD64[bb] if head == "cal" else head
+    if (bb, tag) not in _models:
         m = Network_MM_Searched(32, FUSION_AT, None, None, bb, num_classes=9).eval()
-        S.load_formula_weights(m)
-        _models[bb] = m.to(_dev())
-    return _models[bb]
+        S.load_formula_weights(m, head=tag)
+        _models[(bb, tag)] = m.to(_dev())
+    return _models[(bb, tag)]
+
+
+def _margin_stats(up_ref, pred, pred_ref):
+    """Where two argmax maps disagree, how close was the reference's decision?  Returns (agreement, the largest reference top-2
+    margin among the disagreeing pixels, the logit range)."""
+    srt = np.sort(up_ref, axis=1)
+    margin = srt[:, -1] - srt[:, -2]
+    dis = pred != pred_ref
+    return float(1.0 - dis.mean()), (float(margin[dis].max()) if dis.any() else 0.0), float(up_ref.max() - up_ref.min())
 
 
 @pytest.mark.parametrize("bb", ["mit_b0", "mit_b3"])
@@ -81,16 +92,24 @@ def test_full_model_config1_4x64x96(golden):
     assert maxabs(seg.cpu(), g["logits"]) <= 2e-4 * _scale(g["logits"])
     up = torch.nn.functional.interpolate(seg.cpu(), size=lab.shape[1:], mode="bilinear", align_corners=False)
     pred = up.argmax(1).numpy()
-    assert (pred == g["pred"]).mean() >= 0.999
+    # the golden map is discriminating (all 9 classes >= 5 % of the pixels, median top-2 margin 3.5 % of the logit range)
+    Hh.assert_multiclass(g["pred"], min_classes=9)
+    up_ref = torch.nn.functional.interpolate(t(g["logits"]), size=lab.shape[1:], mode="bilinear", align_corners=False).numpy()
+    agree, worst_margin, rng = _margin_stats(up_ref, pred, g["pred"])
+    assert agree >= 0.999, agree
+    assert worst_margin <= 4e-4 * rng, (worst_margin, rng)     # only pixels the reference itself decides by < 2x the logit tolerance move
     conf = O.confusion_matrix(lab, pred)
     iou = O.compute_results(conf)[2]
     assert abs(np.nanmean(iou) - np.nanmean(g["iou"])) <= 1e-3  # mIoU within 0.1 pt
+    assert float(np.nanmean(g["iou"])) >= 0.2                   # ... of a label-correlated prediction, not of chance
 
 
 def test_full_model_480x640(golden):
+    from oracle import paif_oracle as O
+
     g = golden("gf_model_b3_1x480x640")
-    m = _model("mit_b3")
-    ir, vis, _ = S.make_batch(1, 480, 640)
+    m = _model("mit_b3", head=Hh.HEAD480)
+    ir, vis, lab = S.make_batch(1, 480, 640)
     with torch.no_grad():
         fused, seg = m(t(ir).to(_dev()), t(vis).to(_dev()))
     floor_f = maxabs(g["fused"], g["fused64"])
@@ -101,7 +120,22 @@ def test_full_model_480x640(golden):
     assert maxabs(seg.cpu(), g["logits"]) <= 1e-3 * rng
     assert maxabs(seg.cpu(), g["logits64"]) <= max(3.0 * floor_l, 1e-4)
     up = torch.nn.functional.interpolate(seg.cpu(), size=(480, 640), mode="bilinear", align_corners=False)
-    assert (up.argmax(1).numpy() == g["pred"]).mean() >= 0.999
+    pred = up.argmax(1).numpy()
+    # the golden map is discriminating: all 9 classes >= 5 % of the pixels, median top-2 margin 1.65 % of the logit range; the
+    # reference's own float32 and float64 runs disagree on 5 of its 307,200 pixels
+    share = Hh.assert_multiclass(g["pred"], min_classes=9)
+    np.testing.assert_allclose(share, g["class_share"], atol=1e-7)
+    up_ref = torch.nn.functional.interpolate(t(g["logits64"]), size=(480, 640), mode="bilinear", align_corners=False).numpy()
+    agree, worst_margin, rng = _margin_stats(up_ref, pred, g["pred64"])
+    floor_px = int((g["pred"] != g["pred64"]).sum())
+    # measured (default arithmetic: split-bf16 convs, "auto" GEMMs): 56 pixels vs the reference's float64 map (its own float32 run: 5),
+    # every one of them a pixel the float64 run decides by < 1e-4 of the logit range
+    assert int(round((1.0 - agree) * pred.size)) <= 100, (agree, floor_px)
+    assert worst_margin <= 1e-4 * rng, (worst_margin, rng)
+    assert (pred == g["pred"]).mean() >= 0.9997
+    conf = O.confusion_matrix(lab, pred)
+    miou, miou_ref = float(np.nanmean(O.compute_results(conf)[2])), float(np.nanmean(O.compute_results(g["conf"])[2]))
+    assert abs(miou - miou_ref) <= 1e-3 and miou_ref >= 0.25, (miou, miou_ref)    # mIoU within 0.1 pt of a label-correlated map
 
 
 def test_train_mode_forward_matches_oracle():

@@ -12,7 +12,7 @@ import torch
 
 from paif_amd import ops, synthetic as S
 from tests import helpers as Hh
-from tests.helpers import t
+from tests.helpers import t, maxabs
 from tests.test_oracle_training import (BETAS, DROP_SEED, GROUP_LR_WD, LR, NEVER, SCHED, START_STEP, WD, group_of, movement_mismatch,
                                         training_inputs)
 
@@ -365,3 +365,55 @@ def test_split_bf16_training_step_stays_within_the_fp32_noise():
     # split-bf16 products are ~1e-5 relative per conv; through the guided filter that becomes ~2e-3 of the gradient scale on
     # d fused / d input and up to ~3e-2 on the parameters in front of it
     _compare_grads(m, g64, g32, "split-bf16", floor_mult=4.0, rel=3e-3, rel_fusion=5e-2, rel_scalar=0.15)
+
+
+@pytest.mark.parametrize("cls", ["Network_MM_Searched", "Network_MM_CompModel"])
+def test_forward_object_and_detection_loss(golden, cls):
+    """G1, the two methods round 3 left raising: `forward_object` (core/model_fusion_auto.py:736-766 / :1067-1097: the fused plane
+    clamped to [0,1] and min-max normalised over the batch before the recomposition -- 90 % of this case's pixels sit on the clamp)
+    and `_detection_loss` (:796-800 / :1123-1128) on both composite classes, against the reference's own outputs: plane, logits,
+    loss, input gradients (vs the float64 oracle, floor = the oracle's float32 run) and parameter-gradient samples."""
+    from oracle import paif_oracle as O
+    from paif_amd.core.model_fusion_auto import Network_Fusion_Searched, Network_MM_CompModel, Network_MM_Searched
+    from paif_amd.genotypes import FUSION_AT
+
+    g = golden("go_forward_object_2x64x96")
+    ce = torch.nn.CrossEntropyLoss(ignore_index=255)
+    if cls == "Network_MM_Searched":
+        m = Network_MM_Searched(32, FUSION_AT, None, ce, "mit_b0", num_classes=9)
+    else:
+        m = Network_MM_CompModel(Network_Fusion_Searched(32, None, FUSION_AT), None, ce, "mit_b0", 9, 256, None)
+    m.eval()
+    S.load_formula_weights(m, head=Hh.HEAD64["mit_b0"])
+    m = m.to(_dev())
+    ir, vis, lab = S.make_batch(2, 64, 96)
+    d = lambda a: t(a).to(_dev())
+    with torch.no_grad():
+        fused, seg = m.forward_object(d(ir), d(vis))
+    assert float(fused.min()) == 0.0 and float(fused.max()) == 1.0
+    assert maxabs(fused.cpu(), g["fused"]) <= 1e-4 and maxabs(seg.cpu(), g["logits"]) <= 1e-4
+    irt, vist = d(ir).requires_grad_(True), d(vis).requires_grad_(True)
+    loss = m._detection_loss(irt, vist, d(lab))
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
+    # input gradients: float64 oracle as the yardstick, the oracle's own float32 run as the floor
+    grads = {}
+    for dtype in (torch.float64, torch.float32):
+        sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in Hh.model_sd("mit_b0", Hh.HEAD64["mit_b0"]).items()}
+        i_, v_ = t(ir).to(dtype).requires_grad_(True), t(vis).to(dtype).requires_grad_(True)
+        O.detection_loss(i_, v_, t(lab), sd, "mit_b0").backward()
+        grads[dtype] = (i_.grad, v_.grad)
+    for mine, k in ((irt.grad, 0), (vist.grad, 1)):
+        ref = grads[torch.float64][k]
+        floor = float((grads[torch.float32][k].double() - ref).abs().max())
+        assert float((mine.cpu().double() - ref).abs().max()) <= 1.5 * floor + 1e-5 * float(ref.abs().max()), (k, floor)
+    # parameter gradients against the reference's samples
+    for k, p in m.named_parameters():
+        if k + "#none" in g:
+            assert p.grad is None, k
+            continue
+        ref = g[k + "#s"]
+        a = p.grad.detach().cpu().reshape(-1).numpy()[S.sample_indices(p.numel())]
+        scale = max(float(np.abs(ref).max()), float(g[k + "#n"]) / np.sqrt(p.numel()), 1e-12)
+        tol = (5e-2 if k.startswith("enhance_net.") else 2e-3) * scale + 1e-7     # fusion-net gradients pass through A = cov/(var+eps)
+        assert np.abs(a - ref).max() <= tol, (k, float(np.abs(a - ref).max()), scale)
