@@ -482,6 +482,14 @@ extern template __global__ void gf_mfma_kernel<true, true>(const float*, const f
 extern template __global__ void gf_mfma_kernel<false, true>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
 }
 
+namespace paif_gf2 {
+template <bool BFO>
+__global__ void gf2_kernel(const float* __restrict__ guide, const float* __restrict__ y, const float* __restrict__ planes, float* __restrict__ lf,
+                           unsigned* __restrict__ flag, int B, int H, int W, int nstrip, int nslots, int rows_per_slot, int total_rows);
+extern template __global__ void gf2_kernel<false>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
+extern template __global__ void gf2_kernel<true>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
+}
+
 // workspace: four per-pixel planes + one 256-byte line holding the f16-range flag
 extern "C" size_t paif_guided_filter_fused_workspace_floats(int B, int H, int W) { return (size_t)4 * B * H * W + 64; }
 
@@ -492,8 +500,12 @@ static int gf_fused_launch(const float* guide, const float* y, float* lf, float 
   const int nstrip = (W + FO - 1) / FO;
   // engine: "mfma" (default; horizontal box sums on the matrix cores, gf_mfma.hip) or "valu" (the all-VALU kernel below, also the
   // fallback the mfma engine's f16-range flag selects).  PAIF_GF_ENGINE / PAIF_GF_FORM are A/B knobs.
-  const char* eng = getenv("PAIF_GF_ENGINE");           // read per call: the tests run both engines in one process
-  const int engine = (eng && !strcmp(eng, "valu")) ? 0 : 1;
+  const char* eng = getenv("PAIF_GF_ENGINE");           // read per call: the tests run every engine in one process
+  // "mfma2" (default, round 4: gf_mfma2.hip, two waves per SIMD) | "mfma" (round 3: gf_mfma.hip, one wave per SIMD) | "valu"
+  int engine = (eng && !strcmp(eng, "valu")) ? 0 : (eng && !strcmp(eng, "mfma")) ? 1 : 2;
+  // the round-4 engine addresses rows with wrapping 32-bit per-lane offsets that the buffer range check filters: every per-image
+  // byte size must stay below 2^31 - 2^20
+  if (engine == 2 && ((size_t)(B + 1) * H * W * 128 >= 0x7FF00000ull || (size_t)B * nstrip * H >= 0x7FFFFFFFull)) engine = 1;
   static const int form = [] {
     const char* e = getenv("PAIF_GF_FORM");
     if (!e) return 0;
@@ -519,6 +531,27 @@ static int gf_fused_launch(const float* guide, const float* y, float* lf, float 
       if (best < 0 || cost < best) { best = cost; nseg = n; }
     }
   };
+  if (engine == 2) {
+    // one 8-wave workgroup per CU (two waves per SIMD), ONE round: the B * nstrip full-height strips laid end to end and cut into
+    // equal runs of rows, one per workgroup pair (the two channel halves, 8 block ids apart: same XCD); runs of >= 96 rows
+    static const int cus = [] {
+      int dev = 0, n = 256;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+      return n > 1 ? n : 2;
+    }();
+    const long total_rows = (long)B * nstrip * H;
+    int nslots = (int)(total_rows / 96);
+    nslots = nslots < 1 ? 1 : (nslots > cus / 2 ? cus / 2 : nslots);
+    const int rows_per_slot = (int)((total_rows + nslots - 1) / nslots);
+    const int grid = (nslots + 7) / 8 * 16;
+    if (out_bf16)
+      hipLaunchKernelGGL((paif_gf2::gf2_kernel<true>), dim3(grid), dim3(512), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip, nslots,
+                         rows_per_slot, (int)total_rows);
+    else
+      hipLaunchKernelGGL((paif_gf2::gf2_kernel<false>), dim3(grid), dim3(512), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip, nslots,
+                         rows_per_slot, (int)total_rows);
+    PAIF_LAUNCH_CHECK("guided_filter_fused(mfma2)");
+  }
   if (engine == 1) {
     // one 4-wave workgroup (one wave per SIMD, the whole register file) per CU; a workgroup costs rows + 17 warm-up iterations
     // (rounded up to 6); tiles x 2 channel halves, the halves of a tile 8 block ids apart (same XCD)
@@ -551,7 +584,7 @@ static int gf_fused_launch(const float* guide, const float* y, float* lf, float 
   int nseg;
   pick(4 * R, resident, zgroups, nseg);
   const int frows = (H + nseg - 1) / nseg;
-  const unsigned* only_if = engine == 1 ? flag : nullptr;
+  const unsigned* only_if = engine >= 1 ? flag : nullptr;
   const dim3 grid(B * nstrip * nseg, 2, zgroups);
   if (form == 0) hipLaunchKernelGGL((gf_fused_kernel<float4, 8>), grid, dim3(FC * 8), 0, st, guide, y, workspace, only_if, lf, B, H, W, nstrip, nseg, frows, out_bf16);
   else if (form == 1) hipLaunchKernelGGL((gf_fused_kernel<float4, 4>), grid, dim3(FC * 4), 0, st, guide, y, workspace, only_if, lf, B, H, W, nstrip, nseg, frows, out_bf16);

@@ -498,11 +498,13 @@ def test_unknown_and_malformed_primitives():
         MixedOp(32, "DilConv_3")
 
 
-@pytest.mark.parametrize("shape", [(1, 24, 32), (2, 64, 96), (1, 50, 131), (3, 37, 49), (2, 11, 10), (1, 100, 47), (1, 130, 200)])
-def test_guided_filter_matrix_core_engine_vs_valu_engine_and_oracle(shape):
-    """csrc/gf_mfma.hip (horizontal box sums as f16 hi/lo band-matrix MFMAs, the default engine) against the all-VALU kernel
-    (PAIF_GF_ENGINE=valu) and the float64 oracle, incl. ragged widths (W % 4 != 0 takes the 4-byte plane staging), strips
-    hanging over the image edge, several row segments and B > 1.  Core/model_fusion_auto.py:522-535."""
+@pytest.mark.parametrize("mengine", ["mfma2", "mfma"])
+@pytest.mark.parametrize("shape", [(1, 24, 32), (2, 64, 96), (1, 50, 131), (3, 37, 49), (2, 11, 10), (1, 100, 47), (1, 130, 200), (1, 480, 640)])
+def test_guided_filter_matrix_core_engine_vs_valu_engine_and_oracle(shape, mengine):
+    """The matrix-core engines -- csrc/gf_mfma2.hip (round 4, the default: two columns per lane, two waves per SIMD) and
+    csrc/gf_mfma.hip (round 3: four columns per lane, one wave per SIMD); horizontal box sums as f16 hi/lo band-matrix MFMAs --
+    against the all-VALU kernel (PAIF_GF_ENGINE=valu) and the float64 oracle, incl. ragged and odd widths, strips hanging over
+    the image edge, several row segments, B > 1 and the bench shape.  Core/model_fusion_auto.py:522-535."""
     import os
 
     from oracle import paif_oracle as O
@@ -516,7 +518,7 @@ def test_guided_filter_matrix_core_engine_vs_valu_engine_and_oracle(shape):
     try:
         os.environ["PAIF_GF_ENGINE"] = "valu"
         a = ops.guided_filter_pair(guide, xn).clone()
-        os.environ["PAIF_GF_ENGINE"] = "mfma"
+        os.environ["PAIF_GF_ENGINE"] = mengine
         b = ops.guided_filter_pair(guide, xn).clone()
     finally:
         if old is None:
@@ -524,6 +526,8 @@ def test_guided_filter_matrix_core_engine_vs_valu_engine_and_oracle(shape):
         else:
             os.environ["PAIF_GF_ENGINE"] = old
     assert maxabs(a, b) <= 5e-6
+    if H * W > 100000:
+        return                                           # the float64 oracle on the host: small shapes only
     x64 = x.double()
     res = O.get_residue(x64)
     for e, eps in enumerate((0.001, 0.0001)):
@@ -534,7 +538,7 @@ def test_guided_filter_matrix_core_engine_vs_valu_engine_and_oracle(shape):
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 96), (1, 50, 131), (3, 37, 49), (1, 100, 47), (1, 130, 200)])
-@pytest.mark.parametrize("engine", ["mfma", "valu"])
+@pytest.mark.parametrize("engine", ["mfma2", "mfma", "valu"])
 def test_guided_filter_bf16_output_is_the_rounded_fp32_output(shape, engine):
     """The bf16-output form of the fused guided filter (paif_guided_filter_fused_fwd_bf16: the bf16 configuration's storage of the two
     low-frequency maps; channel pairs exchanged by DPP and stored as dwords) computes the same fp32 values and rounds them to nearest
@@ -560,8 +564,9 @@ def test_guided_filter_bf16_output_is_the_rounded_fp32_output(shape, engine):
             os.environ["PAIF_GF_ENGINE"] = old
 
 
-def test_guided_filter_f16_range_fallback():
-    """A 9-row vertical sum beyond the f16 range (65504) cannot be split into an f16 pair: the matrix-core kernel raises its
+@pytest.mark.parametrize("mengine", ["mfma2", "mfma"])
+def test_guided_filter_f16_range_fallback(mengine):
+    """A 9-row vertical sum beyond the f16 range (65504) cannot be split into an f16 pair: the matrix-core kernels raise their
     flag and the predicated all-VALU launch behind it rewrites the output -- bit-identical to the VALU engine."""
     import os
 
@@ -575,7 +580,7 @@ def test_guided_filter_f16_range_fallback():
     try:
         os.environ["PAIF_GF_ENGINE"] = "valu"
         a = ops.guided_filter_pair(guide, xn).clone()
-        os.environ["PAIF_GF_ENGINE"] = "mfma"
+        os.environ["PAIF_GF_ENGINE"] = mengine
         b = ops.guided_filter_pair(guide, xn).clone()
     finally:
         if old is None:

@@ -15,4 +15,10 @@ for _ in range(20):
     ops.guided_filter_pair(guide, xn)
 e1.record()
 torch.cuda.synchronize()
-print(os.environ.get("PAIF_LIB", "default"), "%.3f ms" % (e0.elapsed_time(e1) / 20))
+print(os.environ.get("PAIF_LIB", "default"), os.environ.get("PAIF_GF_ENGINE", "mfma2"), "fp32 out %.3f ms" % (e0.elapsed_time(e1) / 20))
+e0.record()
+for _ in range(20):
+    ops.guided_filter_pair(guide, xn, out_bf16=True)
+e1.record()
+torch.cuda.synchronize()
+print(os.environ.get("PAIF_LIB", "default"), os.environ.get("PAIF_GF_ENGINE", "mfma2"), "bf16 out %.3f ms" % (e0.elapsed_time(e1) / 20))
