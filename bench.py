@@ -87,6 +87,9 @@ def main():
                          "weights, one MFMA per product, fp32 accumulate -- mIoU within 0.1 pt, argmax agreement 98.75 %% (< the 99.9 %% clause; "
                          "tests/test_bf16_storage_gpu.py).  The line also carries the OTHER modes' rates (`other_storage`), measured right after "
                          "the timed region")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the passes that run after the timed region (other storage modes, two-stream, sustained): clean rocprofv3 / PMC "
+                         "summaries of ONE configuration")
     ap.add_argument("--conv-precision", choices=["f32", "bf16x3"], default="bf16x3",
                     help="arithmetic of the dense convs: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs, fp32 accumulate)")
     args = ap.parse_args()
@@ -255,7 +258,7 @@ def main():
     # idle period, the most favourable thermal / power state.  The same step is then looped for >= --sustain-seconds (default 3 s)
     # and reported as `sustained_value`; `value` stays the contract's K-step figure.
     other_storage = []
-    if args.workload in ("fusion", "fusion_seg") and not args.graph:
+    if args.workload in ("fusion", "fusion_seg") and not args.graph and not args.no_extras:
         for mode in ops.STORAGE_MODES:
             if mode == args.storage:
                 continue
@@ -270,7 +273,7 @@ def main():
             other_storage.append((mode, max_over_ranks(time.perf_counter() - t2, dist, dev)))
         ops.set_storage(args.storage)
     two_stream = None
-    if args.workload in ("fusion", "fusion_seg") and not args.graph and not args.two_stream:
+    if args.workload in ("fusion", "fusion_seg") and not args.graph and not args.two_stream and not args.no_extras:
         # the same K steps with the two image streams of the fusion network on two HIP streams (ops.CONFIG["two_stream"]): identical
         # results, kernels of one stream fill the CUs the other's launches leave idle.  Reported beside `value`, not as it: per-launch
         # durations under co-scheduling measure CU sharing, so the roofline blocks (and the rocprofv3 summary they must agree with) are
@@ -286,7 +289,7 @@ def main():
         two_stream = max_over_ranks(time.perf_counter() - t3, dist, dev)
         ops.CONFIG["two_stream"] = False
     sustained = None
-    if args.sustain_seconds > 0 and not args.graph:
+    if args.sustain_seconds > 0 and not args.graph and not args.no_extras:
         n_s = int(args.sustain_seconds / max(dt / args.steps, 1e-6)) + 1
         barrier()
         t1 = time.perf_counter()

@@ -205,6 +205,9 @@ int paif_compose_dw_pw_weight(const float* dw, const float* pw, float* out, int 
 int paif_stem_out_pack_floats(void);
 int paif_stem_out_pack(const float* w1, const float* w2, float* wpk, paif_stream_t stream);
 int paif_stem_out_fwd_bf16(const float* x, const float* wpk, const float* prelu, float* fused, int B, int H, int W, paif_stream_t stream);
+/* the same on an fp32 NHWC-32 map (the fp32-storage forward, round 4): x as bf16 hi + lo (2^-17), five MFMAs per k-step -- the operand
+ * split of every dense conv of that path; same packed weights. */
+int paif_stem_out_fwd_f32(const float* x, const float* wpk, const float* prelu, float* fused, int B, int H, int W, paif_stream_t stream);
 int paif_pack_decomp1x1_weight_bf16x6(const float* w, float* wpk, paif_stream_t stream);
 int paif_pack_decomp1x1_weight_bf16x3(const float* w, float* wpk, paif_stream_t stream);
 /* Cell_Decom's 1x1 over cat[LF1,LF2,x-LF1,x-LF2] (core/model_fusion_auto.py:512-513) folded to a 1x1

@@ -376,8 +376,9 @@ class Network_Fusion_Searched(nn.Module):
     def _tail_nhwc(self, feature2):
         """stem_out + tanh of the inference forward (no tape)."""
         so = self.stem_out
-        if (feature2.dtype == torch.bfloat16 and feature2.shape[1] >= 3 and feature2.shape[2] >= 3 and ops.CONFIG.get("stem_out_fused", True)):
-            # bf16 inference forward: both stem_out convs + PReLU + tanh as one launch pair (csrc/stem_out.hip)
+        fused_on = ops.CONFIG.get("stem_out_fused", True) if feature2.dtype == torch.bfloat16 else ops.CONFIG.get("stem_out_fused_f32", True)
+        if feature2.shape[1] >= 3 and feature2.shape[2] >= 3 and fused_on:
+            # inference forward (bf16 maps; since round 4 fp32 maps too): both stem_out convs + PReLU + tanh as one launch pair (csrc/stem_out.hip)
             wso = self._packs.get("so_fused", [so[0].weight, so[1].weight], lambda: ops.stem_out_pack(so[0].weight, so[1].weight))
             return ops.stem_out_fused(feature2, wso, so[2].weight)
         w0 = self._packs.get("so0", [so[0].weight], lambda: ops.pack_conv_weight(so[0].weight, 1, 32, 3))

@@ -28,10 +28,13 @@
 namespace paif_gf2 {
 
 constexpr int R = 4;
-constexpr int SC = 64;            // input columns per workgroup
-constexpr int SO = SC - 4 * R;    // 48 output columns
+#ifndef GF2_NW
+#define GF2_NW 8
+#endif
+constexpr int NW = GF2_NW;        // waves per workgroup, 8 columns each (8: two waves per SIMD; 12: three, <= 168 registers)
+constexpr int SC = 8 * NW;        // input columns per workgroup
+constexpr int SO = SC - 4 * R;    // output columns per workgroup (48 of 64)
 constexpr int PF = 6;             // unroll factor = partial-sum ring size
-constexpr int NW = 8;             // waves per workgroup, 8 columns each
 constexpr int NQ = 6;             // exchanged quantities: sum y, sum g*y, A0, b0, A1, b1
 #ifndef GF2_DP
 #define GF2_DP 3
@@ -117,7 +120,7 @@ __device__ __forceinline__ f32x2 ring_push(Ring& rg, f32x2 x) {
 // BFO: the two maps are written as bf16 (round to nearest even); lanes c and c ^ 1 exchange one column by a DPP quad permute and
 // store channel PAIRS as dwords (one store per eps and row).
 template <bool BFO>
-__global__ __launch_bounds__(512, 2) void gf2_kernel(const float* __restrict__ guide, const float* __restrict__ y,
+__global__ __launch_bounds__(64 * NW, NW / 4) void gf2_kernel(const float* __restrict__ guide, const float* __restrict__ y,
                                                      const float* __restrict__ planes, float* __restrict__ lf,
                                                      unsigned* __restrict__ flag, int B, int H, int W, int nstrip, int nslots,
                                                      int rows_per_slot, int total_rows) {
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(512, 2) void gf2_kernel(const float* __restrict__ g
   const int lc0 = 8 * q + 2 * g;                        // strip-local first column of this lane
   float vmax = 0.f;
   // zero the two permanent zero slots of both halo buffers
-  for (int i = tid; i < 2 * NQ * 2 * 64; i += 512) {
+  for (int i = tid; i < 2 * NQ * 2 * 64; i += 64 * NW) {
     const int ln = i & 63, sl = (i >> 6) & 1, qq = (i >> 7) % NQ, par = i / (128 * NQ);
     hbuf[par][qq][sl ? NW + 1 : 0][ln] = u32x2{0u, 0u};
   }
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(512, 2) void gf2_kernel(const float* __restrict__ g
   const int n_it = ((yend - ybeg) + 4 * R + 1 + PF - 1) / PF * PF;
 
   // 1 / ny per iteration: rny_tab[i] belongs to image row r0 - 9 + i (0 outside the image); 1 / n = (1 / nx) * (1 / ny)
-  for (int i = tid; i < n_it + 8; i += 512) {
+  for (int i = tid; i < n_it + 8; i += 64 * NW) {
     const int row = r0 - (2 * R + 1) + i;
     rny_tab[i] = (row >= 0 && row < H) ? 1.0f / (float)(min(row + R, H - 1) - max(row - R, 0) + 1) : 0.f;
   }

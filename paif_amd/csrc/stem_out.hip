@@ -16,6 +16,7 @@
 // leaves the ring pixels as raw 5x5 sums; stem_out_ring_kernel subtracts the surplus (fp32 weights, 160-352 products per pixel) and
 // applies PReLU + tanh.
 #include <stdint.h>
+#include <type_traits>
 
 #include "paif_common.h"
 
@@ -89,9 +90,14 @@ __global__ void stem_out_ring_pack_kernel(const float* __restrict__ w1, const fl
   wr[idx] = v;
 }
 
-__global__ __launch_bounds__(256) void stem_out_fused_kernel(const unsigned short* __restrict__ x, const uint4* __restrict__ wpk,
+// F32IN (round 4: the fp32-storage forward): x is an fp32 map, taken as bf16 hi + lo (the fp32 value to 2^-17, the operand split of every
+// dense conv of that path): x_hi meets the three weight pieces, x_lo the upper two -- 10 MFMAs per 32 pixels instead of 6.
+template <bool F32IN>
+__global__ __launch_bounds__(256) void stem_out_fused_kernel(const void* __restrict__ xv, const uint4* __restrict__ wpk,
                                                              const float* __restrict__ prelu, float* __restrict__ fused, int B, int H,
                                                              int W, int tilesX, int tilesY) {
+  typedef typename std::conditional<F32IN, float, unsigned short>::type XT;
+  const XT* __restrict__ x = reinterpret_cast<const XT*>(xv);
   __shared__ float G[NTAP * GS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, n = lane & 31;
   int t = paif::xcd_remap(blockIdx.x, gridDim.x);
@@ -104,11 +110,12 @@ __global__ __launch_bounds__(256) void stem_out_fused_kernel(const unsigned shor
   for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
     for (int pc = 0; pc < 3; ++pc) wa[ks][pc] = __builtin_bit_cast(bf16x8, wpk[(ks * 3 + pc) * 64 + lane]);
-  const unsigned short* img = x + (size_t)b * H * W * 32;
+  const XT* img = x + (size_t)b * H * W * 32;
   // a wave takes groups wave, wave + 4, wave + 8, wave + 12: all its loads are issued before the first MFMA (unconditional, clamped;
   // group slots >= NG re-read the last group and are not stored)
   constexpr int GPW = (NG + 3) / 4;
-  uint4 v0[GPW], v1[GPW];
+  constexpr int NV = F32IN ? 2 : 1;                                 // 16-byte pieces per 8 channels
+  uint4 v0[GPW][NV], v1[GPW][NV];
   int hps[GPW];
   bool oks[GPW];
 #pragma unroll
@@ -120,22 +127,54 @@ __global__ __launch_bounds__(256) void stem_out_fused_kernel(const unsigned shor
     hps[i] = hp;
     oks[i] = hp < NPX && gy >= 0 && gy < H && gx >= 0 && gx < W;
     const size_t off = ((size_t)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1)) * 32 + hh * 8;
-    v0[i] = *reinterpret_cast<const uint4*>(img + off);            // channels 8 hh .. 8 hh + 7           (k step 0)
-    v1[i] = *reinterpret_cast<const uint4*>(img + off + 16);       // channels 16 + 8 hh .. 16 + 8 hh + 7 (k step 1)
+#pragma unroll
+    for (int h = 0; h < NV; ++h) {
+      v0[i][h] = *reinterpret_cast<const uint4*>(img + off + 4 * h);            // channels 8 hh .. 8 hh + 7           (k step 0)
+      v1[i][h] = *reinterpret_cast<const uint4*>(img + off + 16 + 4 * h);       // channels 16 + 8 hh .. 16 + 8 hh + 7 (k step 1)
+    }
   }
+  auto split = [](const uint4& a, const uint4& c, bf16x8& hi, bf16x8& lo) {    // 8 fp32 values -> bf16 hi + lo
+    const float f[8] = {__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w),
+                        __uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z), __uint_as_float(c.w)};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      hi[j] = (__bf16)f[j];
+      lo[j] = (__bf16)(f[j] - (float)hi[j]);
+    }
+  };
 #pragma unroll
   for (int i = 0; i < GPW; ++i) {
     if (wave + 4 * i >= NG) break;                                   // wave-uniform
-    if (!oks[i]) v0[i] = v1[i] = make_uint4(0u, 0u, 0u, 0u);         // zero padding of the image / unused slots of the last group
-    const bf16x8 b0 = __builtin_bit_cast(bf16x8, v0[i]), b1 = __builtin_bit_cast(bf16x8, v1[i]);
+    if (!oks[i]) {                                                   // zero padding of the image / unused slots of the last group
+#pragma unroll
+      for (int h = 0; h < NV; ++h) v0[i][h] = v1[i][h] = make_uint4(0u, 0u, 0u, 0u);
+    }
     const int hp = hps[i];
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if constexpr (F32IN) {
+      bf16x8 h0, l0, h1, l1;
+      split(v0[i][0], v0[i][NV - 1], h0, l0);
+      split(v1[i][0], v1[i][NV - 1], h1, l1);
+      // smallest terms first: x_lo * W_mid, x_hi * W_lo, x_lo * W_hi, x_hi * W_mid, x_hi * W_hi  (x_lo * W_lo ~ 2^-34 is dropped)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][1], l0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1][1], l1, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][2], h0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1][2], h1, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][0], l0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1][0], l1, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][1], h0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1][1], h1, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][0], h0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1][0], h1, acc, 0, 0, 0);
+    } else {
+      const bf16x8 b0 = __builtin_bit_cast(bf16x8, v0[i][0]), b1 = __builtin_bit_cast(bf16x8, v1[i][0]);
 #pragma unroll
-    for (int pc = 2; pc >= 0; --pc) {                                  // smallest pieces first
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][pc], b0, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1][pc], b1, acc, 0, 0, 0);
+      for (int pc = 2; pc >= 0; --pc) {                                  // smallest pieces first
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][pc], b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1][pc], b1, acc, 0, 0, 0);
+      }
     }
     // D[m][n]: this lane holds, for pixel n, the taps m = (r & 3) + 8 (r >> 2) + 4 hh: r = 0..11 are taps < 24 for both halves, r = 12 is
     // tap 24 (hh = 0) or 28 (unused)
@@ -157,8 +196,11 @@ __global__ __launch_bounds__(256) void stem_out_fused_kernel(const unsigned shor
 
 // The outermost pixel ring: raw 5x5 sum (left in `fused` by the kernel above) minus the surplus terms, then PReLU + tanh.
 // 8 lanes per pixel, lane q = channels 4q .. 4q + 3.
-__global__ __launch_bounds__(256) void stem_out_ring_kernel(const unsigned short* __restrict__ x, const float* __restrict__ wr,
+template <bool F32IN>
+__global__ __launch_bounds__(256) void stem_out_ring_kernel(const void* __restrict__ xv, const float* __restrict__ wr,
                                                             const float* __restrict__ prelu, float* __restrict__ fused, int B, int H, int W) {
+  typedef typename std::conditional<F32IN, float, unsigned short>::type XT;
+  const XT* __restrict__ x = reinterpret_cast<const XT*>(xv);
   const int q = threadIdx.x & 7;
   const int id = blockIdx.x * 32 + (threadIdx.x >> 3);
   const int per = 2 * W + 2 * (H - 2);
@@ -169,11 +211,15 @@ __global__ __launch_bounds__(256) void stem_out_ring_kernel(const unsigned short
   if (k < W) { py = 0; px = k; }
   else if (k < 2 * W) { py = H - 1; px = k - W; }
   else { const int j = k - 2 * W; py = 1 + (j >> 1); px = (j & 1) ? W - 1 : 0; }
-  const unsigned short* img = x + (size_t)b * H * W * 32 + q * 4;
+  const XT* img = x + (size_t)b * H * W * 32 + q * 4;
   auto dot = [&](const float* w, int yy, int xx) -> float {      // sum over this lane's 4 channels of w[c] * x(yy, xx)[c]; 0 outside the image
     if (yy < 0 || yy >= H || xx < 0 || xx >= W) return 0.f;
-    const uint2 v = *reinterpret_cast<const uint2*>(img + ((size_t)yy * W + xx) * 32);
     const float4 w4 = *reinterpret_cast<const float4*>(w + q * 4);
+    if constexpr (F32IN) {
+      const float4 xf = *reinterpret_cast<const float4*>(img + ((size_t)yy * W + xx) * 32);
+      return fmaf(xf.w, w4.w, fmaf(xf.z, w4.z, fmaf(xf.y, w4.y, xf.x * w4.x)));
+    }
+    const uint2 v = *reinterpret_cast<const uint2*>(img + ((size_t)yy * W + xx) * 32);
     float sacc = __uint_as_float(v.x << 16) * w4.x;
     sacc = fmaf(__uint_as_float(v.x & 0xffff0000u), w4.y, sacc);
     sacc = fmaf(__uint_as_float(v.y << 16), w4.z, sacc);
@@ -213,20 +259,34 @@ int paif_stem_out_pack(const float* w1, const float* w2, float* wpk, paif_stream
   return 0;
 }
 
-int paif_stem_out_fwd_bf16(const float* x, const float* wpk, const float* prelu, float* fused, int B, int H, int W, paif_stream_t stream) {
-  PAIF_REQUIRE(x && wpk && prelu && fused && B > 0, PAIF_EINVAL, "stem_out(bf16): bad arguments");
-  PAIF_REQUIRE(H >= 3 && W >= 3, PAIF_ENOSUP, "stem_out(bf16): %dx%d is smaller than 3x3", H, W);
+static int stem_out_launch(const void* x, bool f32in, const float* wpk, const float* prelu, float* fused, int B, int H, int W, paif_stream_t stream) {
+  PAIF_REQUIRE(x && wpk && prelu && fused && B > 0, PAIF_EINVAL, "stem_out: bad arguments");
+  PAIF_REQUIRE(H >= 3 && W >= 3, PAIF_ENOSUP, "stem_out: %dx%d is smaller than 3x3", H, W);
   const int tilesX = (W + TW - 1) / TW, tilesY = (H + TH - 1) / TH;
-  PAIF_REQUIRE((size_t)B * tilesX * tilesY < ((size_t)1 << 31), PAIF_EINVAL, "stem_out(bf16): %dx%dx%d is too large for one launch", B, H, W);
+  PAIF_REQUIRE((size_t)B * tilesX * tilesY < ((size_t)1 << 31), PAIF_EINVAL, "stem_out: %dx%dx%d is too large for one launch", B, H, W);
   hipStream_t st = paif::as_stream(stream);
-  const unsigned short* x16 = reinterpret_cast<const unsigned short*>(x);
-  hipLaunchKernelGGL(stem_out_fused_kernel, dim3((unsigned)(B * tilesX * tilesY)), dim3(256), 0, st, x16, reinterpret_cast<const uint4*>(wpk),
-                     prelu, fused, B, H, W, tilesX, tilesY);
-  PAIF_LAUNCH_CHECK("stem_out(bf16)");
+  const dim3 grid((unsigned)(B * tilesX * tilesY));
   const int ring = B * (2 * W + 2 * (H - 2));
-  hipLaunchKernelGGL(stem_out_ring_kernel, dim3((unsigned)((ring + 31) / 32)), dim3(256), 0, st, x16, wpk + 1536, prelu, fused, B, H, W);
+  const dim3 rgrid((unsigned)((ring + 31) / 32));
+  if (f32in) {
+    hipLaunchKernelGGL(stem_out_fused_kernel<true>, grid, dim3(256), 0, st, x, reinterpret_cast<const uint4*>(wpk), prelu, fused, B, H, W, tilesX, tilesY);
+    PAIF_LAUNCH_CHECK("stem_out(f32)");
+    hipLaunchKernelGGL(stem_out_ring_kernel<true>, rgrid, dim3(256), 0, st, x, wpk + 1536, prelu, fused, B, H, W);
+  } else {
+    hipLaunchKernelGGL(stem_out_fused_kernel<false>, grid, dim3(256), 0, st, x, reinterpret_cast<const uint4*>(wpk), prelu, fused, B, H, W, tilesX, tilesY);
+    PAIF_LAUNCH_CHECK("stem_out(bf16)");
+    hipLaunchKernelGGL(stem_out_ring_kernel<false>, rgrid, dim3(256), 0, st, x, wpk + 1536, prelu, fused, B, H, W);
+  }
   PAIF_LAUNCH_CHECK("stem_out ring");
   return 0;
+}
+
+int paif_stem_out_fwd_bf16(const float* x, const float* wpk, const float* prelu, float* fused, int B, int H, int W, paif_stream_t stream) {
+  return stem_out_launch(x, false, wpk, prelu, fused, B, H, W, stream);
+}
+
+int paif_stem_out_fwd_f32(const float* x, const float* wpk, const float* prelu, float* fused, int B, int H, int W, paif_stream_t stream) {
+  return stem_out_launch(x, true, wpk, prelu, fused, B, H, W, stream);
 }
 
 }  // extern "C"

@@ -345,9 +345,11 @@ class DilConv(_HipOp):
 
     def forward_nhwc(self, x, res=(), tape=None):
         op = self.op
-        if (x.dtype == torch.bfloat16 and self.k == 3 and tape is None and not op[3].training and ops.CONFIG.get("dilconv_dense", True)):
-            # bf16 inference forward: depthwise + 1x1 as ONE dense k x k conv with W[co][ci][tap] = pw[co][ci] * dw[ci][tap] and the
-            # ReLU as its input activation -- the depthwise map (a 32-channel map written and read back) never goes to HBM
+        dense = ops.CONFIG.get("dilconv_dense", True) if x.dtype == torch.bfloat16 else ops.CONFIG.get("dilconv_dense_f32", True)
+        if self.k == 3 and tape is None and not op[3].training and dense:
+            # inference forward (bf16 maps, and since round 4 fp32 maps too): depthwise + 1x1 as ONE dense k x k conv with
+            # W[co][ci][tap] = pw[co][ci] * dw[ci][tap] (one fp32 rounding of the product, then the usual split) and the ReLU as its input
+            # activation -- the depthwise map (a 32-channel map written and read back) never goes to HBM
             wc = self._packs.get("wc", [op[1].conv.weight, op[2].weight],
                                  lambda: ops.pack_conv_weight(ops.compose_dw_pw_weight(op[1].conv.weight, op[2].weight), 1, 32, self.k))
             scale, shift = _bn_scale_shift(op[3], self._packs)

@@ -713,9 +713,10 @@ def stem_out_fused(x, wpk, prelu):
     """bf16 NHWC-32 map -> fused [B,1,H,W] fp32: conv3x3 32->16, conv3x3 16->1, PReLU, tanh (core/model_fusion_auto.py:616-620, :640) in one
     launch pair; the 16-channel map never goes to HBM."""
     B, H, W, C = x.shape
-    assert C == 32 and x.dtype == torch.bfloat16
+    assert C == 32 and x.dtype in (torch.bfloat16, torch.float32)
     fused = torch.empty((B, 1, H, W), device=x.device, dtype=torch.float32)
-    _lib.check(lib().paif_stem_out_fwd_bf16(_pa(x), _p(wpk), _p(prelu), _p(fused), B, H, W, _stream()), "stem_out_fused")
+    fn = lib().paif_stem_out_fwd_bf16 if x.dtype == torch.bfloat16 else lib().paif_stem_out_fwd_f32
+    _lib.check(fn(_pa(x), _p(wpk), _p(prelu), _p(fused), B, H, W, _stream()), "stem_out_fused")
     return fused
 
 
