@@ -196,6 +196,11 @@ int paif_pack_conv_weight_bf16x6(const float* w, float* wpk, int cout, int nsrc,
  * paif_pack_conv_weight*.  Used by the bf16 inference forward: one paif_conv2d_fwd (in_act = ReLU) instead of
  * paif_dwconv_fwd_bf16 + a 1x1, the depthwise map never goes to HBM. */
 int paif_compose_dw_pw_weight(const float* dw, const float* pw, float* out, int cout, int cin, int kh, paif_stream_t stream);
+/* w [cmid][cin][kh][kh] (a dense conv) and pw [cout][cmid][1][1] (the 1x1 behind it, nothing in between) -> out [cout][cin][kh][kh] =
+ * sum_m pw[.][m] w[m][.][.]: the dense kernel of  conv1x1(conv_kxk(x))  (operations_m.py:451-464 ResidualModule: conv3x3 dil 2 -> conv1x1
+ * -> BN -> PReLU; the 1x1 has no padding, so the composition is exact at the image border too).  Inference forward: one
+ * paif_conv2d_fwd with the BN / PReLU / residual epilogue instead of two launches; the 32-channel map between them never goes to HBM. */
+int paif_compose_pw_conv_weight(const float* pw, const float* w, float* out, int cout, int cmid, int cin, int kh, paif_stream_t stream);
 
 /* stem_out of the fusion network (core/model_fusion_auto.py:616-620, :640: conv3x3 32->16, conv3x3 16->1, PReLU, tanh) on a bf16-stored
  * NHWC-32 map as one launch pair: the two linear convs composed into a 5x5 32->1 conv evaluated on the matrix cores with the TAPS as the

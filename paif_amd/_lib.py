@@ -54,6 +54,7 @@ SIGNATURES = {
     "paif_pack_conv_weight_bf16x3": (c_int, [F, F, c_int, c_int, c_int, F]),
     "paif_pack_conv_weight_bf16x6": (c_int, [F, F, c_int, c_int, c_int, F]),
     "paif_compose_dw_pw_weight": (c_int, [F, F, F, c_int, c_int, c_int, F]),
+    "paif_compose_pw_conv_weight": (c_int, [F, F, F, c_int, c_int, c_int, c_int, F]),
     "paif_stem_out_pack_floats": (c_int, []),
     "paif_stem_out_pack": (c_int, [F, F, F, F]),
     "paif_stem_out_fwd_bf16": (c_int, [F, F, F, F, c_int, c_int, c_int, F]),

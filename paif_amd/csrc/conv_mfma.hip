@@ -1733,6 +1733,20 @@ __global__ void compose_dw_pw_kernel(const float* __restrict__ dw, const float* 
   }
 }
 
+// a k x k conv followed by a 1x1 with nothing in between (operations_m.py:451-464 ResidualModule: conv3x3 dil 2 -> conv1x1 -> BN -> PReLU)
+// as ONE k x k conv: W[co][ci][tap] = sum_m pw[co][m] * w[m][ci][tap]  (exact composition: the 1x1 has no padding); summed in double,
+// rounded to fp32 once
+__global__ void compose_pw_conv_kernel(const float* __restrict__ pw, const float* __restrict__ w, float* __restrict__ out, int cout, int cmid,
+                                       int cin, int ntap) {
+  const int total = cout * cin * ntap;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int rest = idx % (cin * ntap), co = idx / (cin * ntap);
+    double acc = 0.0;
+    for (int m = 0; m < cmid; ++m) acc = fma((double)pw[co * cmid + m], (double)w[(size_t)m * cin * ntap + rest], acc);
+    out[idx] = (float)acc;
+  }
+}
+
 // three-piece form (bf16x6): wpk[src][tap][ks][hi|mid|lo][64 lanes][8 bf16]
 __device__ __forceinline__ unsigned short bf16x6_piece(float v, int part) {
   const __bf16 hi = (__bf16)v;
@@ -2026,6 +2040,14 @@ int paif_compose_dw_pw_weight(const float* dw, const float* pw, float* out, int 
   const int total = cout * cin * kh * kh;
   hipLaunchKernelGGL(compose_dw_pw_kernel, dim3((total + 255) / 256), dim3(256), 0, paif::as_stream(stream), dw, pw, out, cout, cin, kh * kh);
   PAIF_LAUNCH_CHECK("compose_dw_pw_weight");
+  return 0;
+}
+
+int paif_compose_pw_conv_weight(const float* pw, const float* w, float* out, int cout, int cmid, int cin, int kh, paif_stream_t stream) {
+  PAIF_REQUIRE(pw && w && out && cout >= 1 && cmid >= 1 && cin >= 1 && kh >= 1 && kh <= 7, PAIF_EINVAL, "compose_pw_conv_weight: bad arguments");
+  const int total = cout * cin * kh * kh;
+  hipLaunchKernelGGL(compose_pw_conv_kernel, dim3((total + 255) / 256), dim3(256), 0, paif::as_stream(stream), pw, w, out, cout, cmid, cin, kh * kh);
+  PAIF_LAUNCH_CHECK("compose_pw_conv_weight");
   return 0;
 }
 

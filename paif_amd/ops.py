@@ -466,6 +466,18 @@ def compose_dw_pw_weight(dw, pw):
     return out
 
 
+def compose_pw_conv_weight(pw, w):
+    """w [Cm,Ci,k,k] (dense conv), pw [Co,Cm,1,1] (the 1x1 behind it) -> [Co,Ci,k,k]: the dense kernel of conv1x1(conv_kxk(.))
+    (operations_m.py:451-464 ResidualModule)."""
+    Cm, Ci, k, _ = w.shape
+    Co = pw.shape[0]
+    assert tuple(pw.shape) == (Co, Cm, 1, 1)
+    out = torch.empty((Co, Ci, k, k), device=w.device, dtype=torch.float32)
+    _lib.check(lib().paif_compose_pw_conv_weight(_p(pw.detach().contiguous()), _p(w.detach().contiguous()), _p(out), Co, Cm, Ci, k, _stream()),
+               "compose_pw_conv_weight")
+    return out
+
+
 def pack_decomp1x1_weight(w, precision=None):
     assert tuple(w.shape) == (32, 128, 1, 1)
     precision = precision or CONFIG["conv_precision"]
