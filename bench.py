@@ -351,10 +351,10 @@ def main():
                            "note": "%d bf16 MFMA%s per product -> 2500/%d TF algorithmic peak" % (nm, "" if nm == 1 else "s", nm)}
                 else:
                     blk = {"bound": "hbm", "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS, "algorithmic_tflops": tf}
-            elif tag.startswith("gf_"):
+            elif tag.startswith("gf_") or tag.startswith("gf2_"):
                 blk = {"bound": "hbm", "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS, "algorithmic_tflops": tf,
-                       "note": "gf_mfma_kernel: horizontal box sums on the matrix cores, one wave per SIMD, instruction-issue bound; "
-                               "gf_fused_kernel (PAIF_GF_ENGINE=valu): all-VALU form -- see DESIGN.md"}
+                       "note": "gf2_kernel (round 4): two columns per lane, two waves per SIMD, horizontal box sums on the matrix cores, vector-issue "
+                               "bound; gf_mfma_kernel (PAIF_GF_ENGINE=mfma): the round-3 engine; gf_fused_kernel (=valu): all-VALU form -- DESIGN.md 7.1"}
             elif tag.startswith("conv_") or tag.startswith("dense conv"):
                 blk = {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS}
             else:

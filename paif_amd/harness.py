@@ -36,12 +36,25 @@ def write_fused_pngs(images_uint8, names, fused_path):
         Image.fromarray(arr[k]).save(os.path.join(fused_path, name))
 
 
-def val_segformer_robust2(model, batches, n_class=9, graph=True):
+def val_segformer_robust2(model, batches, n_class=9, graph=True, two_stream=True):
     """Clean evaluation (the attack call is commented out in the reference, test_original.py:154-158).
     graph=True (default): the forward is captured once per input shape in a hipGraph and replayed (bit-identical; the
-    reference's loader uses batch_size 1, test_original.py:111, where the ~650 launches of fusion + mit_b3 are launch-bound)."""
+    reference's loader uses batch_size 1, test_original.py:111, where the ~650 launches of fusion + mit_b3 are launch-bound).
+    two_stream=True (default, deployment): the infrared and the visible stream of the fusion network run on two HIP streams
+    (ops.CONFIG["two_stream"]: bit-identical output, the kernels of one stream fill the CUs the other's launches leave idle);
+    bench.py keeps the single-stream form for `value`, whose per-kernel durations then measure kernels, not CU sharing."""
+    from . import ops
     from .graph import GraphedForward
     model.eval()
+    old_ts = ops.CONFIG.get("two_stream", False)
+    ops.CONFIG["two_stream"] = bool(two_stream)
+    try:
+        return _clean_eval(model, batches, n_class, graph, GraphedForward)
+    finally:
+        ops.CONFIG["two_stream"] = old_ts
+
+
+def _clean_eval(model, batches, n_class, graph, GraphedForward):
     meter = None
     fused_all = []
     graphed, gkey = None, None

@@ -420,7 +420,8 @@ def guided_filter_pair(guide, y, eps=(0.001, 0.0001), want_ab=False, out_bf16=Fa
         lf = torch.empty((2, B, H, W, 32), device=y.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
         ws = torch.empty(L.paif_guided_filter_fused_workspace_floats(B, H, W), device=y.device, dtype=torch.float32)
         import os
-        tag = ("gf_fused_kernel" if os.environ.get("PAIF_GF_ENGINE") == "valu" else "gf_mfma_kernel") + " (+ gf_guide_stats_kernel)"
+        eng = os.environ.get("PAIF_GF_ENGINE")
+        tag = ("gf_fused_kernel" if eng == "valu" else "gf_mfma_kernel" if eng == "mfma" else "gf2_kernel") + " (+ gf_guide_stats_kernel)"
         e0 = TIMER.start(tag) if TIMER is not None else None
         fn = L.paif_guided_filter_fused_fwd_bf16 if out_bf16 else L.paif_guided_filter_fused_fwd
         _lib.check(fn(_p(guide), _p(y), _pa(lf), eps[0], eps[1], _p(ws), B, H, W, _stream()), "guided_filter_fused")

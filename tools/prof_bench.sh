@@ -5,7 +5,7 @@ NAME=$1; shift
 OUT=$R/gpurun_out/prof_$NAME
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o $NAME -- python3 $R/bench.py "$@" --no-cpu-baseline --sustain-seconds 0 > $OUT/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o $NAME -- python3 $R/bench.py "$@" --no-cpu-baseline --no-extras > $OUT/bench.log 2>&1
 cd $R
 python3 - <<PY
 import csv, glob
