@@ -70,6 +70,8 @@ def main():
                     help="fusion / fusion_seg: replay one captured hipGraph per step in the timed region (the clean-eval harness's default "
                          "mode).  `value` is then the graph-replay rate; the roofline blocks come from an eager, HIP-event-instrumented pass of "
                          "the same K steps run right after the timed region and say so (`roofline_source`)")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="pgd: time the eager step (since round 4 the PGD evaluation step is replayed from one captured hipGraph by default, +3.5 %)")
     ap.add_argument("--two-stream", action="store_true",
                     help="fusion / fusion_seg: run the timed region itself with ops.CONFIG['two_stream'] = True (the two image streams of the fusion "
                          "network on two HIP streams; bit-identical output, ~+6 %%).  `value` is then the co-scheduled rate and every per-launch "
@@ -93,6 +95,8 @@ def main():
     ap.add_argument("--conv-precision", choices=["f32", "bf16x3"], default="bf16x3",
                     help="arithmetic of the dense convs: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs, fp32 accumulate)")
     args = ap.parse_args()
+    if args.workload == "pgd" and not args.no_graph:
+        args.graph = True          # the whole PGD-10 evaluation step as one hipGraph is the default
 
     if (args.gpus > 1 or os.environ.get("PAIF_BENCH_FORCE_LAUNCH") == "1") and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: this process has made NO GPU call yet (importing torch and counting devices does not
