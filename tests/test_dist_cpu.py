@@ -156,3 +156,20 @@ def test_bucketed_gradient_allreduce_gloo(order):
         else:                        # layer 0 first: nothing is contiguous-ready until layer 2 arrives
             assert early[0] == 0
     assert res[0][2] == res[1][2]    # both ranks launched the same buckets at the same points (no deadlock by construction)
+
+
+def test_bench_self_launch_refuses_without_enough_gpus():
+    """`python bench.py --gpus N` outside a torch.distributed.run environment starts the N ranks itself (bench.self_launch: child
+    processes, the parent never touches the GPU).  On a host that exposes fewer than N GPUs it must say so and exit 2 -- before
+    spawning anything."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    import torch
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(max(n, 2)), "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    assert "GPU(s)" in r.stderr and '"metric"' not in r.stdout
