@@ -499,12 +499,14 @@ def test_unknown_and_malformed_primitives():
 
 
 @pytest.mark.parametrize("mengine", ["mfma2", "mfma"])
-@pytest.mark.parametrize("shape", [(1, 24, 32), (2, 64, 96), (1, 50, 131), (3, 37, 49), (2, 11, 10), (1, 100, 47), (1, 130, 200), (1, 480, 640)])
+@pytest.mark.parametrize("shape", [(1, 24, 32), (2, 64, 96), (1, 50, 131), (3, 37, 49), (2, 11, 10), (1, 100, 47), (1, 130, 200), (1, 480, 640),
+                                   (1, 1100, 40), (1, 12, 700), (5, 97, 33)])
 def test_guided_filter_matrix_core_engine_vs_valu_engine_and_oracle(shape, mengine):
     """The matrix-core engines -- csrc/gf_mfma2.hip (round 4, the default: two columns per lane, two waves per SIMD) and
     csrc/gf_mfma.hip (round 3: four columns per lane, one wave per SIMD); horizontal box sums as f16 hi/lo band-matrix MFMAs --
     against the all-VALU kernel (PAIF_GF_ENGINE=valu) and the float64 oracle, incl. ragged and odd widths, strips hanging over
-    the image edge, several row segments, B > 1 and the bench shape.  Core/model_fusion_auto.py:522-535."""
+    the image edge, several row segments, B > 1, the bench shape, an image taller than one run of rows of the round-4 engine (its
+    per-iteration 1 / ny table: pieces of <= 1000 rows) and one wider than ten strips.  Core/model_fusion_auto.py:522-535."""
     import os
 
     from oracle import paif_oracle as O
@@ -625,3 +627,31 @@ def test_standalone_forwards_of_the_import_surface(shape):
     assert maxabs(c[:, 0].cpu(), x.max(1)[0].cpu()) == 0.0 and maxabs(c[:, 1].cpu(), x.mean(1).cpu()) <= 1e-6
     with pytest.raises(NotImplementedError):
         eca_layer(32, 32, 1)(x.requires_grad_(True))            # forward-only helpers refuse to drop gradients silently
+
+
+def test_guided_filter_round4_engine_long_runs_of_rows():
+    """B = 20 at 480x640: 134,400 strip-rows over 128 workgroup pairs = 1,050 rows per run, more than one piece of the round-4 engine's
+    per-iteration table (<= 1,000 rows): every run is walked as two or three pieces (strip boundary and table limit).  Against the
+    round-3 engine, all 20 images."""
+    import os
+
+    from paif_amd import ops
+
+    B, H, W = 20, 480, 640
+    x1 = t(S.make_smooth_feature(83, 1, 32, H, W)).to(_dev())
+    xn = ops.to_nhwc(x1).repeat(B, 1, 1, 1).contiguous()
+    xn *= torch.linspace(0.5, 1.5, B, device=_dev()).view(B, 1, 1, 1)          # the images differ
+    guide = ops.channel_residue(xn)
+    old = os.environ.get("PAIF_GF_ENGINE")
+    try:
+        os.environ["PAIF_GF_ENGINE"] = "mfma"
+        a = ops.guided_filter_pair(guide, xn).clone()
+        os.environ["PAIF_GF_ENGINE"] = "mfma2"
+        b = ops.guided_filter_pair(guide, xn).clone()
+    finally:
+        if old is None:
+            os.environ.pop("PAIF_GF_ENGINE", None)
+        else:
+            os.environ["PAIF_GF_ENGINE"] = old
+    assert torch.isfinite(b).all()
+    assert maxabs(a, b) <= 5e-6
