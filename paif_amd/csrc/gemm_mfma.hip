@@ -32,7 +32,7 @@ struct GemmArgs {
   int wide;            // 1: N, ldc, ldres multiples of 4 and C / res 16-byte aligned -> float4 epilogue through LDS
 };
 
-__device__ __forceinline__ float gelu_erf(float x) { return paif::gelu_erf_fast(x); }   // paif_common.h: branch-free erf, <= 1.2 ulp
+__device__ __forceinline__ float gelu_erf(float x) { return paif::gelu_erf_fast(x); }   // paif_common.h: x * Phi(x), one polynomial + v_exp_f32
 
 // split-K slab store / fused epilogue of one workgroup tile (shared by all three kernels).
 // Wide form: a row-per-lane dword epilogue is store-ISSUE bound (32 store instructions of 256 B per wave; the stage-1 GEMMs

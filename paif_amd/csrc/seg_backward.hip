@@ -14,7 +14,7 @@ inline int grid_for(size_t work_items, int per_block) {
   return (int)g;
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return paif::gelu_erf_fast(x); }   // paif_common.h: branch-free erf, <= 1.2 ulp
+__device__ __forceinline__ float gelu_erf(float x) { return paif::gelu_erf_fast(x); }   // paif_common.h: x * Phi(x), one polynomial + v_exp_f32
 __device__ __forceinline__ float gelu_grad(float x) { return paif::gelu_grad_fast(x); }
 
 // ---------------------------------------------------------------------------------------------

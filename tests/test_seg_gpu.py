@@ -214,6 +214,36 @@ def test_mlp_dwconv_bias_gelu_vs_torch(shape):
     assert maxabs(dx, xr.grad) <= 3e-6 * max(1.0, float(xr.grad.abs().max()))
 
 
+def test_gelu_and_its_derivative_pointwise_vs_float64():
+    """The GELU of the HIP kernels (paif_common.h: x * Phi(x), Phi(-t) = 2^q(t), one degree-10 polynomial) on a dense grid and on normal
+    samples, read through the MixFFN kernel with a centre-tap depthwise weight (conv(x) = x): against float64 x * Phi(x)
+    (nn.GELU default, core/mix_transformer.py:49) and its derivative.  Bounds = the measured maxima + head-room: absolute 3.8e-7 (the
+    fp32 rounding of the product at |x| = 8), relative 1e-6 for |x| < 3 (the erf form it replaced: 1.8e-5 for x < 0)."""
+    C = 256
+    g = torch.Generator().manual_seed(5)
+    xs = torch.cat([torch.linspace(-8.0, 8.0, 300000), torch.randn(300000, generator=g) * 1.5, torch.linspace(-0.01, 0.01, 20001),
+                    torch.tensor([0.0, -0.0, 20.0, -20.0, 1e-30, -1e-30])])
+    n = (xs.numel() + C - 1) // C * C
+    xs = torch.cat([xs, torch.zeros(n - xs.numel())])
+    H = n // C
+    x = xs.reshape(1, H, 1, C).to(_dev())
+    w = torch.zeros(C, 1, 3, 3); w[:, 0, 1, 1] = 1.0
+    w = w.to(_dev()); bias = torch.zeros(C, device=_dev())
+    y = ops.dwconv3_bias_gelu(x, w, bias).cpu().double().reshape(-1)
+    dx = ops.dwconv3_bias_gelu_bwd(x, w, bias, torch.ones_like(x)).cpu().double().reshape(-1)
+    x64 = xs.double()
+    phi = 0.5 * (1.0 + torch.erf(x64 / 2.0 ** 0.5))
+    ref = x64 * phi
+    dref = phi + x64 * torch.exp(-0.5 * x64 * x64) / (2.0 * np.pi) ** 0.5
+    assert torch.isfinite(y).all() and torch.isfinite(dx).all()
+    err = (y - ref).abs()
+    assert float(err.max()) <= 5e-7, float(err.max())
+    m = (x64.abs() < 3.0) & (x64.abs() > 1e-20)
+    assert float((err[m] / ref[m].abs()).max()) <= 1.5e-6, float((err[m] / ref[m].abs()).max())
+    assert float((dx - dref).abs().max()) <= 3e-7, float((dx - dref).abs().max())
+    assert float(y[x64 == 20.0][0]) == 20.0 and abs(float(y[x64 == -20.0][0])) <= 1e-7
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 512, 2048), (1201, 320, 64), (4803, 64, 256), (77, 9, 256), (19200, 64, 64),
                                    (257, 40, 100), (1000, 33, 300), (513, 130, 520)])   # ragged N / K in every wave-tile variant
 def test_linear_weight_and_bias_gradient(M, N, K):
