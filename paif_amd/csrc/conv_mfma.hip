@@ -740,9 +740,24 @@ __device__ __forceinline__ uint2 raw_relu(uint2 t) {
 // The first D taps of a source were fetched before the A(s+1) prefetch was issued, so they never wait behind it; the
 // later taps do, D taps (>= 2000 cycles of MFMA) after it was issued -- by then the tile has arrived.
 // ---------------------------------------------------------------------------------------------------
-#ifndef PAIF_MS_DEPTH
-#define PAIF_MS_DEPTH 6
+// Round 4: ring depth and occupancy per configuration (measured inside bench.py, fp32 maps, B=8 480x640; each a same-box A/B):
+//   two sources  : depth 2, THREE workgroups per CU (168 VGPRs; 3 x 49 KB of LDS)  298 -> 271 us -- with two sources the exposed load of
+//                  the first tile and the epilogue are 53 % of a workgroup's time (round-2 stamps), two workgroups cannot cover that;
+//   three sources: depth 3, two workgroups (3 do not fit without spilling the loop: 455 us)  432 -> 424 us;
+//   bf16-stored inputs / outputs (ST != 0) and one source keep depth 6, two workgroups (not re-measured).
+// PAIF_MS_DEPTH / PAIF_MS_WGS override both for A/B builds (tools/build_variant.sh).
+template <int NSRC, int ST> struct MsCfg {
+#ifdef PAIF_MS_DEPTH
+  static constexpr int D = PAIF_MS_DEPTH;
+#else
+  static constexpr int D = (ST == 0 && NSRC == 2) ? 2 : (ST == 0 && NSRC == 3) ? 3 : 6;
 #endif
+#ifdef PAIF_MS_WGS
+  static constexpr int WGS = PAIF_MS_WGS;
+#else
+  static constexpr int WGS = (ST == 0 && NSRC == 2) ? 3 : 2;
+#endif
+};
 #ifndef PAIF_MS_STAMP
 #define PAIF_MS_STAMP(i)   // tools/microbench/conv_ms_trace.hip defines these to record per-phase clock stamps
 #define PAIF_TRACE_DECL
@@ -750,7 +765,7 @@ __device__ __forceinline__ uint2 raw_relu(uint2 t) {
 #define PAIF_TRACE_END
 #endif
 template <int KH, int DIL, int NSRC, int ST = 0>
-__global__ __launch_bounds__(NTHREADS, 2) void conv_bf16x3_ms(ConvArgs a) {
+__global__ __launch_bounds__(NTHREADS, (MsCfg<NSRC, ST>::WGS)) void conv_bf16x3_ms(ConvArgs a) {
   constexpr int BFI = paif::st_in(ST);
   constexpr unsigned ES = BFI ? 2u : 4u;               // bytes per stored input element
   typedef typename RawQ<BFI>::T raw_t;
@@ -794,7 +809,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bf16x3_ms(ConvArgs a) {
   // staging slot u of this thread: element idx = tid + u * NTHREADS of the halo tile (pixel-major, 8 channel quads per
   // pixel).  The same 32-bit byte offsets / LDS addresses / padding bits serve every source (identical NHWC-32 shapes).
   unsigned goff[NIT];
-  int dst[NIT];
   unsigned padmask = 0;
 #pragma unroll
   for (int u = 0; u < NIT; ++u) {
@@ -804,7 +818,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bf16x3_ms(ConvArgs a) {
     const int gy = y0 - P + tyy, gx = x0 - P + txx;
     const int gyc = min(max(gy, 0), a.H - 1), gxc = min(max(gx, 0), a.W - 1);
     goff[u] = (unsigned)(((b * a.H + gyc) * a.W + gxc) * CIN + q * 4) * ES;
-    dst[u] = pix * PSB + q * 8;
     if (gy < 0 || gy >= a.H || gx < 0 || gx >= a.W) padmask |= 1u << u;
   }
   constexpr bool LAST_PARTIAL = (TOTAL % NTHREADS) != 0;
@@ -822,14 +835,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bf16x3_ms(ConvArgs a) {
       uint2 hi, lo;
       split_raw(t4, hi, lo);
       if (!LAST_PARTIAL || u + 1 < NIT || last_valid) {
-        *reinterpret_cast<uint2*>(ldsb + dst[u]) = hi;
-        if constexpr (!paif::st_lo0(ST)) *reinterpret_cast<uint2*>(ldsb + dst[u] + 64) = lo;
+        // LDS address recomputed (QPP = 8: a shift, a multiply-add, a mask) instead of kept: 11 registers of a kernel that sits at its limit
+        const int idx = min(tid + u * NTHREADS, TOTAL - 1);
+        char* d = ldsb + (idx >> 3) * PSB + (idx & 7) * 8;
+        *reinterpret_cast<uint2*>(d) = hi;
+        if constexpr (!paif::st_lo0(ST)) *reinterpret_cast<uint2*>(d + 64) = lo;
       }
     }
   };
 
   // B ring: D taps (of the flattened source x tap sequence) resident per lane
-  constexpr int D = PAIF_MS_DEPTH;
+  constexpr int D = MsCfg<NSRC, ST>::D;
   constexpr int NG = NSRC * NTAP;
   uint4 bw[D][NKS * 2];
   // uniform (SGPR) base per load + one 32-bit lane offset: with a per-lane 64-bit pointer the loop-invariant address
