@@ -1613,12 +1613,15 @@ static inline bool needs_hooks(const ConvArgs& a) { return a.in_act >= 3 || a.au
 // profiles/r01_conv_ws_study.txt).  Since the plain kernel stages with unconditional loads (all 11 in flight) it is
 // the faster one for every 3x3 dilation-1 configuration (e.g. 1 source 191 vs 200 us, 3 sources 479 vs 567 us); the
 // persistent form keeps the pure streams: 1x1 without residual maps (119 vs 125, 171 vs 177, 232 vs 237 us -- the
-// device's copy rate) and the dilation-2 3x3 with one source (222 vs 236 us).
+// device's copy rate) and, for bf16-stored maps, the dilation-2 3x3 with one source (222 vs 236 us).
 static inline bool takes_ws(const ConvArgs& a, int kh, int dil) {
 #if PAIF_TH == 8
   if (needs_hooks(a) || kh > 3 || !ws_eligible(a)) return false;
   if (kh == 1) return !a.res[0] && a.in_act == 0;
-  return dil == 2 && a.nsrc == 1;   // in_act: none or ReLU (the composed DilConv)
+  // dilation-2 3x3, one source (the composed DilConv; in_act none or ReLU): bf16-stored maps only.  With fp32 maps the tile-per-workgroup
+  // kernel is the faster one INSIDE the forward (round 4, three alternating bench.py runs each: 6.154 vs 6.173 ms per step); the 222 vs
+  // 236 us that chose the persistent form in round 1 were micro-benchmark times on random inputs, i.e. at the power-capped clock.
+  return dil == 2 && a.nsrc == 1 && a.st != 0;
 #else
   return false;
 #endif
