@@ -88,33 +88,39 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
   const float slope = *prelu;
   // a workgroup walks (row, chunk) items with a grid stride: the 36 weights of a thread are loaded once per workgroup, not once per
   // 128 pixels (19,200 workgroups at B=8 480x640 before)
+  // Round 4: the 3 x (128 + 2) image patch of an item goes through LDS once (zero padding written there: no per-lane selects) and every
+  // lane reads its nine taps from it -- before, each lane issued 9 global loads per pixel (the eight lanes of a pixel the same nine):
+  // 36 vector-memory instructions per thread and item against one 16-byte store per pixel, i.e. the kernel was bound by the
+  // address unit, not by its 325 MB of writes.  Two patch buffers (item parity): one barrier per item.
+  __shared__ float patch[2][3][STEM_CHUNK + 2];
   const int nitems = B * H * chunks;
-  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+  int par = 0;
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x, par ^= 1) {
   const int chunk = item % chunks;
   const int row = item / chunks;       // b * H + y
   const int y = row % H, b = row / H;
   const float* base = img + (size_t)b * img_bstride;
-  // the three source rows (clamped: loads are unconditional, padding by select)
-  const float* r0 = base + (size_t)max(y - 1, 0) * W;
-  const float* r1 = base + (size_t)y * W;
-  const float* r2 = base + (size_t)min(y + 1, H - 1) * W;
-  const bool top = y == 0, bot = y == H - 1;
+  for (int i = threadIdx.x; i < 3 * (STEM_CHUNK + 2); i += 256) {
+    const int r = i / (STEM_CHUNK + 2), c = i - r * (STEM_CHUNK + 2);
+    const int yy = y + r - 1, xx = chunk * STEM_CHUNK + c - 1;
+    const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+    const float v = base[(size_t)min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)];   // unconditional, clamped
+    patch[par][r][c] = ok ? v : 0.f;
+  }
+  __syncthreads();   // the only barrier of an item: a wave that writes buffer p again (two items later) has passed the NEXT item's barrier,
+                     // which every wave reaches only after its reads of p
   float* frow = feat + (size_t)row * W * 32;
   unsigned short* frow16 = feat16 ? feat16 + (size_t)row * W * 32 : nullptr;   // optional bf16 twin of the map (bf16 storage mode)
   float* grow = guide ? guide + (size_t)row * W : nullptr;
 #pragma unroll
   for (int it = 0; it < STEM_CHUNK / 32; ++it) {
-    const int x = chunk * STEM_CHUNK + it * 32 + (threadIdx.x >> 3);
-    const int xc = min(x, W - 1), xl = max(xc - 1, 0), xr = min(xc + 1, W - 1);
+    const int xi = it * 32 + (threadIdx.x >> 3);
+    const int x = chunk * STEM_CHUNK + xi;
     float v[9];
-    v[0] = r0[xl]; v[1] = r0[xc]; v[2] = r0[xr];
-    v[3] = r1[xl]; v[4] = r1[xc]; v[5] = r1[xr];
-    v[6] = r2[xl]; v[7] = r2[xc]; v[8] = r2[xr];
-    const bool lft = xc == 0, rgt = xc == W - 1;
-    if (top) v[0] = v[1] = v[2] = 0.f;
-    if (bot) v[6] = v[7] = v[8] = 0.f;
-    if (lft) v[0] = v[3] = v[6] = 0.f;
-    if (rgt) v[2] = v[5] = v[8] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[r * 3 + c] = patch[par][r][xi + c];
     float o[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {

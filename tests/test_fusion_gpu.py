@@ -138,8 +138,8 @@ def test_dense_conv_persistent_kernel_ragged_edges(kh, dil, nsrc, nres, act):
     (3, 2, 1, 0, 0), (3, 2, 1, 1, 1), (3, 2, 1, 2, 2), (3, 2, 1, 3, 1),      # dilation 2 / one source, residual storer path NR = 0..3
 ])
 def test_dense_conv_persistent_kernel_is_dispatched_and_correct(kh, dil, nsrc, nres, act):
-    """Every configuration the library routes to the persistent wave-specialised kernel (conv_bf16x3_ws), at >= 1024 tiles
-    with ragged edges: the dispatch is ASSERTED (kernel tag of the launch) and the result is checked against
+    """The 1x1 configurations the library routes to the persistent wave-specialised kernel (conv_bf16x3_ws) and the dilation-2 3x3
+    ones it used to (fp32 maps: now the tile-per-workgroup kernel), at >= 1024 tiles with ragged edges: the dispatch is ASSERTED (kernel tag of the launch) and the result is checked against
     torch.nn.functional.conv2d on the CPU -- an independent reference, not the repo's own fp32 kernel."""
     from paif_amd import ops
 
@@ -164,7 +164,10 @@ def test_dense_conv_persistent_kernel_is_dispatched_and_correct(kh, dil, nsrc, n
     finally:
         ops.TIMER = None
     torch.cuda.synchronize()
-    assert list(timer.summary()) == ["conv_bf16x3_ws<%d, %d, 0>" % (kh, dil)], list(timer.summary())
+    # fp32 maps: 1x1 -> the persistent form; dilation-2 3x3 -> the tile-per-workgroup kernel since round 4 (faster inside the forward;
+    # the persistent dilation-2 form serves bf16-stored maps: tests/test_bf16_storage_gpu.py)
+    want = "conv_bf16x3_ws<1, 1, 0>" if kh == 1 else "conv_mfma_bf16x3<3, 2, false, 0, 2>"
+    assert list(timer.summary()) == [want], list(timer.summary())
     assert maxabs(y.permute(0, 3, 1, 2).cpu(), ref) <= 1e-4 * float(ref.abs().max())
 
 
