@@ -76,7 +76,7 @@ def test_dense_conv_dispatch_rules_on_the_host():
     assert name(nsrc=1, hooks=True) == "conv_mfma_bf16x3<3, 1, true, 0, 2>"       # dgrad hooks: tile-per-workgroup kernel
     assert name(kh=1, nsrc=3) == "conv_bf16x3_ws<1, 1, 0>"
     assert name(kh=1, nsrc=3, nres=1) == "conv_mfma_bf16x3<1, 1, false, 0, 2>"
-    assert name(kh=3, dil=2, nsrc=1) == "conv_bf16x3_ws<3, 2, 0>"
+    assert name(kh=3, dil=2, nsrc=1) == "conv_mfma_bf16x3<3, 2, false, 0, 2>"   # fp32 maps: tile-per-workgroup since round 4 (bf16 maps: below)
     assert name(kh=3, dil=2, nsrc=2) == "conv_mfma_bf16x3<3, 2, false, 0, 2>"
     assert name(kh=7) == "conv_mfma_bf16x3<7, 1, false, 0, 2>"
     assert name(kh=5, dil=2) == "conv_mfma_bf16x3<5, 2, false, 0, 2>"
