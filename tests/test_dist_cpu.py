@@ -121,7 +121,9 @@ def _reduce_worker(rank, world, port, q, order):
             red.mark_ready(layers[li])
             early.append(len(red.launched))
         red.finish()
-    out = {i: [p.grad.clone() for p in layers[i].parameters()] for i in range(3)}
+    # numpy arrays: pickled by value.  torch tensors travel through a multiprocessing queue as file descriptors served by the SENDING
+    # process, and the parent may fetch them after this worker has exited (FileNotFoundError on the worker's listener socket)
+    out = {i: [p.grad.detach().clone().numpy() for p in layers[i].parameters()] for i in range(3)}
     q.put((rank, out, early, float(arena.grad[arena.range_of[id(dead)][0]:].abs().sum()), dead.grad is None))
     dist.barrier()
     dist.destroy_process_group()
@@ -149,7 +151,7 @@ def test_bucketed_gradient_allreduce_gloo(order):
     for rank, out, early, dead_sum, dead_none in res:
         for i in range(3):
             for a, b in zip(out[i], refs[i]):
-                assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max()))
+                assert float((torch.from_numpy(a) - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max()))
         assert dead_sum == 0.0 and dead_none
         if order == (2, 1, 0):       # backward order: buckets go out while later layers are still "computing"
             assert early[0] >= 1 and early[1] > early[0]
