@@ -53,8 +53,14 @@ class MixedOp(nn.Module):
     def forward_nhwc(self, x, res=(), tape=None):
         return self._op.forward_nhwc(x, res, tape)
 
-    def backward_nhwc(self, g, t, wgrad=False):
+    def backward_nhwc(self, g, t, wgrad=False, res=()):
+        if res:
+            return self._op.backward_nhwc(g, t, wgrad, res=res)
         return self._op.backward_nhwc(g, t, wgrad)
+
+    @property
+    def bwd_takes_res(self):
+        return getattr(self._op, "bwd_takes_res", False)
 
 
 class Cell_Chain(_HipOp):
@@ -88,9 +94,13 @@ class Cell_Chain(_HipOp):
     def backward_nhwc(self, g, tape, wgrad=False):
         """g = d/d(chain output) -> d/d(inp).  `tape`: this chain's entries in forward order (one per op)."""
         d = g
-        for i in range(self._steps - 1, -1, -1):
+        for i in range(self._steps - 1, 0, -1):
             d = self._ops[i].backward_nhwc(d, tape[i], wgrad)
-        return ops.add(d, g)   # the chain's own residual: out = inp + ops(inp)
+        # the chain's own residual (out = inp + ops(inp)): d/d(inp) = g + ops^T(g).  The first op's last dgrad conv adds g in its epilogue
+        # when the op can (RDB, ECA block: every chain of the shipped genotype); an elementwise pass otherwise
+        if self._ops[0].bwd_takes_res:
+            return self._ops[0].backward_nhwc(d, tape[0], wgrad, res=(g,))
+        return ops.add(self._ops[0].backward_nhwc(d, tape[0], wgrad), g)
 
 
 class Cell_Decom(nn.Module):

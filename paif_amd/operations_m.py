@@ -240,7 +240,9 @@ class ResidualDenseBlock(_HipOp):
         tape.append(dict(x1=x1, x2=x2, z3=z3))
         return out
 
-    def backward_nhwc(self, g, t, wgrad=False):
+    bwd_takes_res = True    # backward_nhwc(..., res=(m,)): m is added to the returned gradient in the last dgrad conv's epilogue
+
+    def backward_nhwc(self, g, t, wgrad=False, res=()):
         a = self.lrelu.weight
         k, d = self.k, self.d
         w1, w2, w3 = self.conv1.conv.weight, self.conv2.conv.weight, self.conv3.conv.weight
@@ -269,7 +271,7 @@ class ResidualDenseBlock(_HipOp):
                     ops.conv2d_wgrad(srcs, dout, k, d, z=z, act=ops.ACT_PRELU, prelu=a, alpha=alpha, out=gw)
             if ds is not None:
                 ops.prelu_bwd(d_x1, t["z1"], a, ds, factor=1.0)
-        return ops.conv2d([d_x1], self._dgrad_w("c1", w1, 0), k, d, res=(d_x,), in_act=ops.IN_DPRELU, in_aux=s1, in_prelu=a)
+        return ops.conv2d([d_x1], self._dgrad_w("c1", w1, 0), k, d, res=(d_x,) + tuple(res), in_act=ops.IN_DPRELU, in_aux=s1, in_prelu=a)
 
 
 class ResidualModule(_HipOp):
@@ -545,13 +547,15 @@ class ECABasicBlock(_HipOp):
             tape.append(dict(r=r, o=o, u=u, gate=gate, x=x, pool=partial) if ops.taping_wgrad() else dict(r=r, o=o, u=u, gate=gate))
         return self._add_res(out, res)
 
-    def backward_nhwc(self, g, t, wgrad=False):
+    bwd_takes_res = True    # see ResidualDenseBlock
+
+    def backward_nhwc(self, g, t, wgrad=False, res=()):
         a = self.relu.weight
         if not wgrad:
             d_o, d_r = ops.eca_bwd(g, t["u"], t["o"], t["gate"], self.se.conv.weight, self.k, a)
             # o = conv2(PReLU(r)):  d_r += conv2^T(d_o) * PReLU'(r)
             d_r = ops.conv2d([d_o], self._dgrad_w("c2", self.conv2.conv.weight), self.k, 1, epi_dact=1, epi_aux=t["r"], prelu=a, res=(d_r,))
-            return ops.conv2d([d_r], self._dgrad_w("c1", self.conv1.weight), 3, 1)
+            return ops.conv2d([d_r], self._dgrad_w("c1", self.conv1.weight), 3, 1, res=tuple(res))
         B, H, W, _ = g.shape
         ds = ops.grad_of(a)
         if ds is not None:
@@ -568,7 +572,7 @@ class ECABasicBlock(_HipOp):
         gw1 = ops.grad_of(self.conv1.weight)
         if gw1 is not None:
             ops.conv2d_wgrad([t["x"]], d_r, 3, 1, out=gw1)
-        return ops.conv2d([d_r], self._dgrad_w("c1", self.conv1.weight), 3, 1)
+        return ops.conv2d([d_r], self._dgrad_w("c1", self.conv1.weight), 3, 1, res=tuple(res))
 
 
 class Spatial_BasicBlock(_HipOp):
