@@ -519,6 +519,29 @@ def main():
         dist.destroy_process_group()
 
 
+def gpu_count():
+    """GPUs of this node WITHOUT a HIP call: KFD topology nodes with SIMDs (/sys), honouring HIP/ROCR_VISIBLE_DEVICES when they are
+    plain index lists; torch.cuda.device_count() only when the topology is not readable."""
+    n = None
+    try:
+        root = "/sys/class/kfd/kfd/topology/nodes"
+        n = 0
+        for d in os.listdir(root):
+            with open(os.path.join(root, d, "properties")) as f:
+                props = dict(ln.split()[:2] for ln in f if len(ln.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except (OSError, ValueError):
+        n = None
+    if n is None:
+        return torch.cuda.device_count()
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and all(x.strip().isdigit() for x in v.split(",") if x.strip()):
+            n = min(n, len([x for x in v.split(",") if x.strip()]))
+    return n
+
+
 def self_launch(n):
     """`python bench.py --gpus N` outside torch.distributed.run: run `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
     --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a child process, relay its output (rank 0 prints the
@@ -526,7 +549,14 @@ def self_launch(n):
     import socket
     import subprocess
 
-    have = torch.cuda.device_count()           # counts devices without initialising HIP on this image
+    # A profiler's preloaded library initialises the GPU before this program starts; starting the ranks from such a process is a
+    # launcher hop from a GPU-initialised process, which this pool forbids: profile one rank (--gpus 1) or profile under the launcher.
+    pre = " ".join(os.environ.get(k, "") for k in ("LD_PRELOAD", "HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES"))
+    if "rocprof" in pre.lower() or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        print("bench.py: --gpus %d under a profiler preload (rocprofv3): refusing to start child ranks from a GPU-initialised process; "
+              "profile with --gpus 1" % n, file=sys.stderr)
+        return 2
+    have = gpu_count()
     if have < n:
         print("bench.py: --gpus %d but this node exposes %d GPU(s)" % (n, have), file=sys.stderr)
         return 2

@@ -57,6 +57,25 @@ def _init_delta(X, epsilon, delta0):
     return ops.pgd_step_(d.contiguous(), d, X, 0.0, float("inf"))
 
 
+def _check_labels(lab64, model):
+    """torch's CrossEntropyLoss (the reference's Seg_loss, attack/attack.py:103-114) raises on a label outside [0, C) that is not
+    ignore_index; the loss kernels never index with such a value (they drop the pixel), so the range is validated here: ONCE per
+    attack call, before the loop.  One host read; impossible while the stream is being captured into a hipGraph -- a caller that
+    captures an attack validates its labels beforehand (bench.py's eager warm-up step does; `validate_labels` is the public form)."""
+    ncls = getattr(getattr(model, "denoise_net", None), "num_classes", None)
+    if ncls is None or torch.cuda.is_current_stream_capturing():
+        return
+    validate_labels(lab64, ncls)
+
+
+def validate_labels(label, num_classes, ignore_index=255):
+    lab = label.type(torch.long)
+    bad = (lab != ignore_index) & ((lab < 0) | (lab >= num_classes))
+    n = int(bad.sum())
+    if n:
+        raise RuntimeError("attack: %d label value(s) outside [0, %d) that are not ignore_index %d" % (n, num_classes, ignore_index))
+
+
 def _attack(model, X_vis, X_ir, label, epsilon, alpha, attack_iters, restarts, attack_loss, attack_way, do_ir, do_vis,
             delta0_ir=None, delta0_vis=None, trace=None):
     if attack_loss == 'l_seg':
@@ -71,6 +90,8 @@ def _attack(model, X_vis, X_ir, label, epsilon, alpha, attack_iters, restarts, a
     label = label.contiguous()
     fast = attack_loss == 'l_seg' and hasattr(model, "forward_taped")
     lab64 = label.type(torch.long).contiguous()
+    if fast:
+        _check_labels(lab64, model)
     with ops.attack_arithmetic():          # exact-fp32 kernels for the whole loop unless ops.set_attack_precision("fast")
         return _attack_loop(model, X_vis, X_ir, label, lab64, epsilon, alpha, attack_iters, restarts, attack_loss, attack_way, do_ir, do_vis,
                             delta0_ir, delta0_vis, trace, criterion, fast)
@@ -89,9 +110,6 @@ def _attack_loop(model, X_vis, X_ir, label, lab64, epsilon, alpha, attack_iters,
                     _, logits, tape = model.forward_taped(ops.add(X_ir, d_ir), ops.add(X_vis, d_vis))
                     way, wt, wf = ops.attack_loss_weights(attack_way, i, attack_iters)
                     coef = ops.attack_loss_fwd(logits, lab64, way, wt, wf)    # loss + the backward's scalars, on the device
-                    if i == 0 and not torch.cuda.is_current_stream_capturing() and float(coef[7]) != 0.0:
-                        # torch's CrossEntropyLoss (the reference's Seg_loss) raises on such a mask; the kernel never indexes with it
-                        raise RuntimeError("attack: %d label value(s) outside [0, %d) that are not ignore_index 255" % (int(coef[7]), logits.shape[-1]))
                     d32 = ops.attack_loss_bwd(logits, lab64, coef, way, wt, wf)
                     gi, gv = model.backward_taped(d32, tape)
                     loss = coef[0]

@@ -386,7 +386,12 @@ class Network_Fusion_Searched(nn.Module):
     def _tail_nhwc(self, feature2):
         """stem_out + tanh of the inference forward (no tape)."""
         so = self.stem_out
-        fused_on = ops.CONFIG.get("stem_out_fused", True) if feature2.dtype == torch.bfloat16 else ops.CONFIG.get("stem_out_fused_f32", True)
+        if feature2.dtype == torch.float32:
+            # fp32 maps: the one-kernel form takes x as bf16 hi + lo (the split-bf16 convs' own operand precision); under
+            # set_conv_precision("f32" | "bf16x6") the two packed convs run at the requested precision instead
+            fused_on = ops.CONFIG.get("stem_out_fused_f32", True) and ops.CONFIG["conv_precision"] == "bf16x3"
+        else:
+            fused_on = ops.CONFIG.get("stem_out_fused", True)
         if feature2.shape[1] >= 3 and feature2.shape[2] >= 3 and fused_on:
             # inference forward (bf16 maps; since round 4 fp32 maps too): both stem_out convs + PReLU + tanh as one launch pair (csrc/stem_out.hip)
             wso = self._packs.get("so_fused", [so[0].weight, so[1].weight], lambda: ops.stem_out_pack(so[0].weight, so[1].weight))
@@ -653,12 +658,16 @@ class _CompositeBase(nn.Module):
         wg = ops.want_param_grads(self)
         if torch.is_grad_enabled() and (ir.requires_grad or vis.requires_grad or wg):
             return _CompositeFn.apply(ir, vis, self, wg, grad_anchor(ir.device), True)
+        if self.global_minmax:
+            # the plane's own min-max (ops.plane_clamp_minmax) is a per-rank kernel pair: with global_minmax the two min-max steps of this
+            # form would use different scopes and no longer reproduce the single-process batch
+            raise NotImplementedError("forward_object: global_minmax=True is built for forward() only")
         with torch.no_grad():
             ycc = ops.rgb2ycrcb(vis)
             with ops.bf16_activations(enable=not self.enhance_net.training):
                 fused = self.enhance_net.forward_impl(ir[:, 0:1, :, :], ycc)
             fused, _ = ops.plane_clamp_minmax(fused)
-            seg_map = self.denoise_net(ops.seg_input_from_fused(fused, ycc, minmax_sync=self._minmax_sync()))
+            seg_map = self.denoise_net(ops.seg_input_from_fused(fused, ycc))
         return fused, seg_map
 
     # ---- training-API losses (:1093-1128): values, input gradients and parameter gradients (the models' autograd nodes +

@@ -93,16 +93,17 @@ __global__ __launch_bounds__(256) void plane_bwd_apply_kernel(const float* __res
                                                               int npartial, float* __restrict__ dx, size_t n) {
   __shared__ float4 tot;
   if (threadIdx.x < 64) {
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    float sx = 0.f, sy = 0.f;
+    double cz = 0.0, cw = 0.0;     // tie counts: per-block values are exact small integers; their total is exact in double (fp32 stops at 2^24 elements)
     for (int i = threadIdx.x; i < npartial; i += 64) {
       const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)i * 4);
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      sx += v.x; sy += v.y; cz += (double)v.z; cw += (double)v.w;
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
-      s.x += __shfl_xor(s.x, m); s.y += __shfl_xor(s.y, m); s.z += __shfl_xor(s.z, m); s.w += __shfl_xor(s.w, m);
+      sx += __shfl_xor(sx, m); sy += __shfl_xor(sy, m); cz += __shfl_xor(cz, m); cw += __shfl_xor(cw, m);
     }
-    if (threadIdx.x == 0) tot = s;
+    if (threadIdx.x == 0) tot = make_float4(sx, sy, (float)cz, (float)cw);
   }
   __syncthreads();
   const float mn = minmax[0], mx = minmax[1];

@@ -486,3 +486,21 @@ def test_round2_attack_branches(golden):
         a, ref = d.detach().cpu().numpy(), g[name + ".delta"]
         assert a.shape == ref.shape and np.abs(a).max() <= eps + 1e-7
         assert (np.abs(a - ref) > 1e-6).mean() <= 5e-3, name
+
+
+def test_attack_rejects_labels_outside_the_class_range():
+    """the reference's CrossEntropyLoss raises on a label outside [0, C) that is not ignore_index 255; the HIP loss kernels
+    drop such a pixel, so the attack validates the mask once at its entry (before the loop, and therefore before any capture)."""
+    from paif_amd.attack.attack import attack_both, validate_labels
+
+    m = _model()
+    ir, vis, lab = S.make_batch(2, 64, 96)
+    bad = lab.copy()
+    bad[0, 3, 5] = 9          # C = 9: the first value past the class range
+    bad[1, 0, 0] = 200
+    kw = dict(epsilon=8 / 255., alpha=2 / 255., attack_iters=1, attack_loss="l_seg", attack_way="PGD")
+    with pytest.raises(RuntimeError, match="2 label value"):
+        attack_both(m, t(vis).to(_dev()), t(ir).to(_dev()), t(bad).to(_dev()), **kw)
+    validate_labels(t(lab).to(_dev()), 9)                         # 255 = ignore_index passes
+    d_ir, d_vis = attack_both(m, t(vis).to(_dev()), t(ir).to(_dev()), t(lab).to(_dev()), **kw)
+    assert float(d_ir.abs().max()) <= 8 / 255. + 1e-7

@@ -175,3 +175,18 @@ def test_bench_self_launch_refuses_without_enough_gpus():
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 2, (r.returncode, r.stderr[-500:])
     assert "GPU(s)" in r.stderr and '"metric"' not in r.stdout
+
+
+def test_bench_self_launch_refuses_under_a_profiler_preload():
+    """under rocprofv3 the preloaded tool library has initialised the GPU before bench.py starts; spawning the ranks from
+    there would be a launcher hop from a GPU-initialised process.  bench.self_launch refuses (exit 2) before spawning anything."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["ROCP_TOOL_LIBRARIES"] = "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    assert "profiler" in r.stderr and '"metric"' not in r.stdout

@@ -331,6 +331,36 @@ def test_fusion_net_intermediates(golden):
     assert maxabs(fused.cpu(), g["fused"]) <= 1e-4
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16x6"])
+def test_fusion_forward_at_exact_conv_precision_keeps_the_tail_exact(golden, precision):
+    """under set_conv_precision("f32" | "bf16x6") the stem_out tail must run at the requested precision too (the
+    one-kernel fp32-map form takes x as bf16 hi + lo: split-bf16 operand precision, 3e-5).  The whole forward is then within
+    1e-5 of the reference's fused plane at 48x64 (split-bf16 default: 1e-4 budget), and the fused tail kernel is not launched."""
+    from paif_amd import ops
+
+    g = golden("gc_fusion_48x64")
+    net = _fusion_net()
+    ir, vis, _ = S.make_batch(1, 48, 64)
+    ycc = ops.rgb2ycrcb(t(vis).to(_dev()))
+    calls = []
+    orig = ops.stem_out_fused
+    ops.stem_out_fused = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    old = ops.CONFIG["conv_precision"]
+    try:
+        ops.set_conv_precision(precision)
+        with torch.no_grad():
+            fused = net(t(ir).to(_dev()), ycc[:, 0:1])
+        assert not calls, "the split-operand stem_out kernel ran under conv precision %s" % precision
+        ops.set_conv_precision("bf16x3")
+        with torch.no_grad():
+            net(t(ir).to(_dev()), ycc[:, 0:1])
+        assert calls, "the default arithmetic takes the one-kernel tail"
+    finally:
+        ops.set_conv_precision(old)
+        ops.stem_out_fused = orig
+    assert maxabs(fused.cpu(), g["fused"]) <= 1e-5
+
+
 def test_showfeatures_forward2(golden):
     """Feature-visualisation path: same parameters as the fusion net (identical state_dict keys),
     forward2 returns the fused image and the decomposition intermediates of the reference."""
