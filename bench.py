@@ -82,7 +82,7 @@ def main():
                          "splits (six MFMAs per product, 2^-25 per product: fp32-level parity -- sign mismatch vs the reference's float64 run 0 "
                          "through PGD-10), GEMMs / attention exact fp32 MFMA; exact = fp32-exact MFMA kernels everywhere; fast = the split-bf16 "
                          "kernels there too (trajectory diverges: sign mismatch 2.5e-2 by iteration 10; tests/test_parity_default_gpu.py)")
-    ap.add_argument("--storage", choices=["f32", "bf16", "bf16_split"], default="f32",
+    ap.add_argument("--storage", choices=["f32", "bf16", "bf16_split", "f16"], default="f32",
                     help="activation storage of the fusion network's inference forward (fusion / fusion_seg workloads): f32 (default since "
                          "round 4) = every map fp32, parity at the fp32 tolerance: BOTH clauses of SURVEY 8(d) hold on the reference's multi-class "
                          "480x640 map; bf16 = what BASELINE configs[1] names: the 32-channel maps behind the guided-filter block held as bf16, bf16 "
@@ -360,15 +360,15 @@ def main():
                 # storage code = the kernels' last template argument (paif_common.h): MFMAs per product 3 (fp32 maps, or an input PReLU
                 # on bf16 maps) / 2 (bf16 maps: the stored operand's low half is zero; or plain bf16 weights on fp32 maps) / 1 (bf16 maps and
                 # plain bf16 weights: --storage bf16) -> 2500/n TF algorithmic peak
-                m_ = re.search(r", (\d)>$", tag)
-                m5 = re.match(r"conv_mfma_bf16x3<\d, \d, (?:true|false), (\d), (\d)>$", tag)   # <KH, DIL, HOOKS, storage code, pieces>
+                m_ = re.search(r", (\d+)>$", tag)
+                m5 = re.match(r"conv_mfma_bf16x3<\d, \d, (?:true|false), (\d+), (\d)>$", tag)   # <KH, DIL, HOOKS, storage code, pieces>
                 if tag == DOMINANT:
-                    nm = {"f32": 3, "bf16_split": 2, "bf16": 1}[args.storage] if args.workload in ("fusion", "fusion_seg") else 3
+                    nm = {"f32": 3, "bf16_split": 2, "bf16": 1, "f16": 1}[args.storage] if args.workload in ("fusion", "fusion_seg") else 3
                 else:
                     if m5:
-                        nm = 6 if m5.group(2) == "3" else {0: 3, 1: 2, 2: 3, 3: 3, 4: 1, 5: 2, 6: 1}[int(m5.group(1))]
+                        nm = 6 if m5.group(2) == "3" else ST_MFMAS[int(m5.group(1))]
                     else:
-                        nm = 1 if "bf16_dma" in tag else ({0: 3, 1: 2, 2: 3, 3: 3, 4: 1, 5: 2, 6: 1}[int(m_.group(1))] if m_ else 3)
+                        nm = 1 if "bf16_dma" in tag else (ST_MFMAS[int(m_.group(1))] if m_ else 3)
                 peak_tf = 2500.0 / nm
                 if fl_ / max(by_, 1) > peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9):
                     blk = {"bound": "mfma", "achieved": tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": tf / peak_tf, "algorithmic_gbs": gb,
@@ -583,6 +583,11 @@ def self_launch(n):
         print("bench.py: the ranks exited 0 but rank 0 printed no JSON line", file=sys.stderr)
         rc = 1
     return rc
+
+
+# MFMAs per product by kernel storage code (paif_common.h; the kernels' last / fourth template argument): fp32 maps 3; bf16 maps 2; plain
+# 16-bit weights 1; fp16 codes = 8 + the bf16 code (9: fp16 maps with fp16 hi + lo weights)
+ST_MFMAS = {0: 3, 1: 2, 2: 3, 3: 3, 4: 1, 5: 2, 6: 1, 7: 1, 9: 2, 12: 1, 14: 1, 15: 1}
 
 
 def parity_block(storage):

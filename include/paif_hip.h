@@ -75,6 +75,9 @@ int paif_stem_fwd(const float* img, size_t img_bstride, const float* w, const fl
  * the fp32 map feeds the fp32 guided-filter block, its bf16 twin the residual inputs of the bf16-stored layers. */
 int paif_stem_fwd_twin(const float* img, size_t img_bstride, const float* w, const float* prelu, float* feat, float* feat_bf16,
                        float* guide, int B, int H, int W, paif_stream_t stream);
+/* the same with the twin as IEEE fp16 (the fp16 storage mode, round 5) */
+int paif_stem_fwd_twin_f16(const float* img, size_t img_bstride, const float* w, const float* prelu, float* feat, float* feat_f16,
+                           float* guide, int B, int H, int W, paif_stream_t stream);
 /* Cell_Decom.get_residue on an existing NHWC [B,H,W,32] map (:517-521): guide = max_c - min_c. */
 int paif_channel_residue_fwd(const float* x, float* guide, int B, int H, int W, paif_stream_t stream);
 
@@ -96,6 +99,12 @@ int paif_guided_filter_fused_fwd(const float* guide, const float* y, float* lf, 
 /* Same, the two low-frequency maps written as bf16 (`lf`: [2][B,H,W,32] `unsigned short` data, round to nearest even): the bf16
  * configuration holds the maps behind the guided-filter block as bf16; statistics, A, b and every sum stay fp32. */
 int paif_guided_filter_fused_fwd_bf16(const float* guide, const float* y, float* lf, float eps0, float eps1, float* workspace, int B,
+                                      int H, int W, paif_stream_t stream);
+/* The fp16 configuration (round 5): the two HIGH-frequency maps HF_e = y - LF_e (core/model_fusion_auto.py:531-532 forms them from the
+ * filter's output anyway) written as IEEE fp16 (`hf`: [2][B,H,W,32] `unsigned short` data, round to nearest even).  |HF| << |LF| ~ |y|:
+ * the fp16 rounding of what the folded 1x1 behind this block reads is ~8x smaller than with LF stored (paif_pack_decomp1x1_hf_weight_f16x2
+ * folds that conv over [x, HF1, HF2]).  Statistics, A, b, every sum and y - LF itself are fp32. */
+int paif_guided_filter_fused_fwd_hf16(const float* guide, const float* y, float* hf, float eps0, float eps1, float* workspace, int B,
                                       int H, int W, paif_stream_t stream);
 
 /* Dense k x k convolution, stride 1, "same" zero padding (pad = dil*(k-1)/2), Cout <= 32, inputs =
@@ -147,10 +156,17 @@ typedef struct {
 #define PAIF_ST_F32 0          /* fp32 maps in, fp32 maps out (default) */
 #define PAIF_ST_BF16 1         /* bf16 in, bf16 out */
 #define PAIF_ST_F32_BF16 2     /* fp32 in, bf16 out: the 1x1 behind the fp32 guided-filter block */
+#define PAIF_ST_F16 3          /* round 5: IEEE fp16 in, fp16 out (`unsigned short` data behind the float* fields, round-to-nearest-even on
+                                  store, fp32 accumulate): 8x finer than bf16 at the same bytes; precision PAIF_CONV_F16 / PAIF_CONV_F16X2 */
+#define PAIF_ST_F16_F32 4      /* fp16 in (sources and residual maps), fp32 out: the conv that writes the forward's last 32-channel map
+                                  (core/model_fusion_auto.py:634, feature2), which feeds the fp32-input stem_out kernel; 3x3 dilation 2 */
 /* in_act: 0 none, 1 PReLU, 2 ReLU, 3 src*in_alpha*in_scale[c]*(in_aux>=0?1:*in_prelu), 4 ...*(in_aux>0), 5 src*in_alpha*in_scale[c] */
 #define PAIF_CONV_F32 0
 #define PAIF_CONV_BF16X3 1
 #define PAIF_CONV_BF16 2        /* storage != PAIF_ST_F32 only: one bf16 MFMA per product (BASELINE configs[1] "bf16") */
+#define PAIF_CONV_F16 4         /* PAIF_ST_F16 / PAIF_ST_F16_F32 only: one fp16 MFMA per product; wpk = the F16X2 pack (its hi pieces are read) */
+#define PAIF_CONV_F16X2 5       /* PAIF_ST_F16 only, 1x1: weights as fp16 hi + lo (two MFMAs per product, 22-bit weights): the folded
+                                   decomposition 1x1, whose weight rounding is the one that moves the segmentation argmax */
 #define PAIF_CONV_BF16X6 3      /* fp32 storage, cin = 32: three bf16 pieces per operand, six MFMAs per product: fp32-level parity (2^-25 per
                                    product) at 6/16 of the exact fp32 MFMA's matrix-pipe time; the arithmetic of the attack loops */
 
@@ -159,7 +175,7 @@ typedef struct {
  * fp32 arithmetic, round-to-nearest-even on store.  Same reference sites as their fp32 twins (DilConv depthwise operations_m.py:499;
  * ChannelPool + spatial_attn_layer_M blend core/model_fusion_auto.py:1352-1368,631-632; eca_layer operations_m.py:353-367;
  * stem_out.1/.2 + tanh core/model_fusion_auto.py:616-635; Cell_Chain's `inp + ops(inp)` :445).
- * paif_cast_storage_fwd converts n elements fp32 -> bf16 (to_bf16 = 1) or back (0); n % 4 == 0. ---- */
+ * paif_cast_storage_fwd converts n elements between fp32 and a 16-bit format; n % 4 == 0. ---- */
 int paif_dwconv_fwd_bf16(const float* x, const float* w, float* out, int k, int dil, int in_relu, int B, int H, int W,
                          paif_stream_t stream);
 int paif_channel_pool2_fwd_bf16(const float* ir, const float* vis, float* comp, int B, int H, int W, paif_stream_t stream);
@@ -169,7 +185,18 @@ int paif_eca_finish_fwd_bf16(const float* o, const float* r, const float* pool_p
                              const float* prelu, float* gate, float* out, int B, int H, int W, paif_stream_t stream);
 int paif_tail_fwd_bf16(const float* x, const float* w, const float* prelu, float* fused, int B, int H, int W, paif_stream_t stream);
 int paif_add_fwd_bf16(const float* a, const float* b, float* out, size_t n, paif_stream_t stream);
-int paif_cast_storage_fwd(const float* src, float* dst, size_t n, int to_bf16, paif_stream_t stream);
+/* mode: 0 bf16 -> fp32, 1 fp32 -> bf16, 2 fp32 -> fp16, 3 fp16 -> fp32 */
+int paif_cast_storage_fwd(const float* src, float* dst, size_t n, int mode, paif_stream_t stream);
+/* ---- the same kernels on IEEE-fp16-stored maps (PAIF_ST_F16, round 5): fp16 data behind the float*, fp32 arithmetic ---- */
+int paif_dwconv_fwd_f16(const float* x, const float* w, float* out, int k, int dil, int in_relu, int B, int H, int W,
+                        paif_stream_t stream);
+int paif_channel_pool2_fwd_f16(const float* ir, const float* vis, float* comp, int B, int H, int W, paif_stream_t stream);
+int paif_spa_blend_fwd_f16(const float* comp, const float* w, const float* ir, const float* vis, float* agg, int B, int H, int W,
+                           paif_stream_t stream);
+int paif_eca_finish_fwd_f16(const float* o, const float* r, const float* pool_partial, const float* w1d, int k,
+                            const float* prelu, float* gate, float* out, int B, int H, int W, paif_stream_t stream);
+int paif_tail_fwd_f16(const float* x, const float* w, const float* prelu, float* fused, int B, int H, int W, paif_stream_t stream);
+int paif_add_fwd_f16(const float* a, const float* b, float* out, size_t n, paif_stream_t stream);
 
 int paif_conv2d_blocks(int B, int H, int W);
 int paif_conv2d_fwd(const paif_conv_desc* d, int B, int H, int W, paif_stream_t stream);
@@ -189,6 +216,8 @@ int paif_pack_conv_weight(const float* w, float* wpk, int cout, int nsrc, int ci
 /* Same weights for precision = PAIF_CONV_BF16X3 (cin = 32 only): each value split into bf16 hi + bf16 lo,
  * wpk[src][tap][k16][hi|lo][64 lanes][8 bf16] (same size in bytes as the fp32 packing). */
 int paif_pack_conv_weight_bf16x3(const float* w, float* wpk, int cout, int nsrc, int kh, paif_stream_t stream);
+/* fp16 pieces (hi = rn(w), lo = rn(w - hi)) in the BF16X3 stream layout, for PAIF_CONV_F16 / PAIF_CONV_F16X2: paif_conv_wpk_floats(...) floats. */
+int paif_pack_conv_weight_f16x2(const float* w, float* wpk, int cout, int nsrc, int kh, paif_stream_t stream);
 /* Three-piece packs for PAIF_CONV_BF16X6: 1.5 x paif_conv_wpk_floats(...) floats. */
 int paif_pack_conv_weight_bf16x6(const float* w, float* wpk, int cout, int nsrc, int kh, paif_stream_t stream);
 /* dw [cin][1][kh][kh] (depthwise) and pw [cout][cin][1][1] (the 1x1 behind it) -> out [cout][cin][kh][kh] = pw * dw: the dense
@@ -215,6 +244,9 @@ int paif_stem_out_fwd_bf16(const float* x, const float* wpk, const float* prelu,
 int paif_stem_out_fwd_f32(const float* x, const float* wpk, const float* prelu, float* fused, int B, int H, int W, paif_stream_t stream);
 int paif_pack_decomp1x1_weight_bf16x6(const float* w, float* wpk, paif_stream_t stream);
 int paif_pack_decomp1x1_weight_bf16x3(const float* w, float* wpk, paif_stream_t stream);
+/* fp16 forward (round 5): the guided filter writes HF_i = x - LF_i (small magnitudes: 8x less fp16 rounding than LF_i), and the same 1x1
+ * folds over [x, HF1, HF2]: (Wl1+Wl2) x + (Wh1-Wl1) HF1 + (Wh2-Wl2) HF2; fp16 hi | lo pieces for PAIF_CONV_F16X2 (nsrc = 3). */
+int paif_pack_decomp1x1_hf_weight_f16x2(const float* w, float* wpk, paif_stream_t stream);
 /* Cell_Decom's 1x1 over cat[LF1,LF2,x-LF1,x-LF2] (core/model_fusion_auto.py:512-513) folded to a 1x1
  * over [x, LF1, LF2]: (Wh1+Wh2) x + (Wl1-Wh1) LF1 + (Wl2-Wh2) LF2.  w [32,128,1,1] -> wpk for nsrc=3. */
 int paif_pack_decomp1x1_weight(const float* w, float* wpk, paif_stream_t stream);

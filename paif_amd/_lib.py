@@ -38,12 +38,14 @@ SIGNATURES = {
     "paif_minmax_normalize_fwd": (c_int, [F, F, c_int, F, F, c_int, c_int, c_int, F]),
     "paif_stem_fwd": (c_int, [F, c_size_t, F, F, F, F, c_int, c_int, c_int, F]),
     "paif_stem_fwd_twin": (c_int, [F, c_size_t, F, F, F, F, F, c_int, c_int, c_int, F]),
+    "paif_stem_fwd_twin_f16": (c_int, [F, c_size_t, F, F, F, F, F, c_int, c_int, c_int, F]),
     "paif_channel_residue_fwd": (c_int, [F, F, c_int, c_int, c_int, F]),
     "paif_guided_filter_ab_fwd": (c_int, [F, F, F, c_float, c_float, c_int, c_int, c_int, F]),
     "paif_guided_filter_lf_fwd": (c_int, [F, F, F, c_int, c_int, c_int, F]),
     "paif_guided_filter_fused_workspace_floats": (c_size_t, [c_int, c_int, c_int]),
     "paif_guided_filter_fused_fwd": (c_int, [F, F, F, c_float, c_float, F, c_int, c_int, c_int, F]),
     "paif_guided_filter_fused_fwd_bf16": (c_int, [F, F, F, c_float, c_float, F, c_int, c_int, c_int, F]),
+    "paif_guided_filter_fused_fwd_hf16": (c_int, [F, F, F, c_float, c_float, F, c_int, c_int, c_int, F]),
     "paif_conv2d_blocks": (c_int, [c_int, c_int, c_int]),
     "paif_conv2d_fwd": (c_int, [POINTER(ConvDesc), c_int, c_int, c_int, F]),
     "paif_conv2d_is_persistent": (c_int, [POINTER(ConvDesc), c_int, c_int, c_int]),
@@ -52,6 +54,7 @@ SIGNATURES = {
     "paif_pack_conv_weight": (c_int, [F, F, c_int, c_int, c_int, c_int, F]),
     "paif_pack_decomp1x1_weight": (c_int, [F, F, F]),
     "paif_pack_conv_weight_bf16x3": (c_int, [F, F, c_int, c_int, c_int, F]),
+    "paif_pack_conv_weight_f16x2": (c_int, [F, F, c_int, c_int, c_int, F]),
     "paif_pack_conv_weight_bf16x6": (c_int, [F, F, c_int, c_int, c_int, F]),
     "paif_compose_dw_pw_weight": (c_int, [F, F, F, c_int, c_int, c_int, F]),
     "paif_compose_pw_conv_weight": (c_int, [F, F, F, c_int, c_int, c_int, c_int, F]),
@@ -60,6 +63,7 @@ SIGNATURES = {
     "paif_stem_out_fwd_bf16": (c_int, [F, F, F, F, c_int, c_int, c_int, F]),
     "paif_stem_out_fwd_f32": (c_int, [F, F, F, F, c_int, c_int, c_int, F]),
     "paif_pack_decomp1x1_weight_bf16x3": (c_int, [F, F, F]),
+    "paif_pack_decomp1x1_hf_weight_f16x2": (c_int, [F, F, F]),
     "paif_pack_decomp1x1_weight_bf16x6": (c_int, [F, F, F]),
     "paif_bn_fold": (c_int, [F, F, F, F, c_float, F, F, c_int, F]),
     "paif_dwconv_fwd": (c_int, [F, F, F, c_int, c_int, c_int, c_int, c_int, c_int, F]),
@@ -112,6 +116,12 @@ SIGNATURES = {
     "paif_eca_finish_fwd_bf16": (c_int, [F, F, F, F, c_int, F, F, F, c_int, c_int, c_int, F]),
     "paif_tail_fwd_bf16": (c_int, [F, F, F, F, c_int, c_int, c_int, F]),
     "paif_add_fwd_bf16": (c_int, [F, F, F, c_size_t, F]),
+    "paif_dwconv_fwd_f16": (c_int, [F, F, F, c_int, c_int, c_int, c_int, c_int, c_int, F]),
+    "paif_channel_pool2_fwd_f16": (c_int, [F, F, F, c_int, c_int, c_int, F]),
+    "paif_spa_blend_fwd_f16": (c_int, [F, F, F, F, F, c_int, c_int, c_int, F]),
+    "paif_eca_finish_fwd_f16": (c_int, [F, F, F, F, c_int, F, F, F, c_int, c_int, c_int, F]),
+    "paif_tail_fwd_f16": (c_int, [F, F, F, F, c_int, c_int, c_int, F]),
+    "paif_add_fwd_f16": (c_int, [F, F, F, c_size_t, F]),
     "paif_cast_storage_fwd": (c_int, [F, F, c_size_t, c_int, F]),
     "paif_attack_loss_blocks": (c_int, [c_int, c_int, c_int]),
     "paif_attack_loss_fwd": (c_int, [F, F, F, F, c_int, c_float, c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_int, F]),

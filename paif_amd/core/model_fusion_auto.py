@@ -50,7 +50,9 @@ class MixedOp(nn.Module):
     def forward(self, x):
         return self._op(x)
 
-    def forward_nhwc(self, x, res=(), tape=None):
+    def forward_nhwc(self, x, res=(), tape=None, out_f32=False):
+        if out_f32 and getattr(self._op, "takes_out_f32", False):
+            return self._op.forward_nhwc(x, res, tape, out_f32=True)
         return self._op.forward_nhwc(x, res, tape)
 
     def backward_nhwc(self, g, t, wgrad=False, res=()):
@@ -84,11 +86,12 @@ class Cell_Chain(_HipOp):
             self._ops += [MixedOp(C, name)]
         self._indices = indices
 
-    def forward_nhwc(self, inp, res=(), tape=None):
+    def forward_nhwc(self, inp, res=(), tape=None, out_f32=False):
+        """out_f32 (fp16-storage inference forward): ask the last op for an fp32 output map (honoured where its kernel exists)."""
         s1 = inp
         for i in range(self._steps):
             last = i == self._steps - 1
-            s1 = self._ops[i].forward_nhwc(s1, ((inp,) + tuple(res)) if last else (), tape)
+            s1 = self._ops[i].forward_nhwc(s1, ((inp,) + tuple(res)) if last else (), tape, out_f32=out_f32 and last)
         return s1
 
     def backward_nhwc(self, g, tape, wgrad=False):
@@ -153,8 +156,8 @@ class Cell_Decom(nn.Module):
             g_ir = ops.channel_residue(fir)
         if g_vis is None:
             g_vis = ops.channel_residue(fvis)
-        # bf16 configuration (inference): the guided filter writes its two maps as bf16 and the folded 1x1 takes them with the stem
-        # map's bf16 twin -- everything behind the filter's fp32 statistics / A / b is a bf16 map
+        # 16-bit configurations (inference): the guided filter writes its two maps as bf16 (fp16: the two HIGH-frequency maps x - LF) and
+        # the folded 1x1 takes them with the stem map's 16-bit twin -- everything behind the filter's fp32 statistics / A / b is a 16-bit map
         lf16 = tape is None and feats is None and ops._ACT_BF16[0]
         if tape is None:
             lf_ir = self.decomposition_nhwc(fir, g_ir, out_bf16=lf16)
@@ -162,8 +165,10 @@ class Cell_Decom(nn.Module):
         else:
             lf_ir, ab_ir = self.decomposition_nhwc(fir, g_ir, want_ab=True)
             lf_vis, ab_vis = self.decomposition_nhwc(fvis, g_vis, want_ab=True)
-        w_lf = self._packs.get("lf", [self.conv1x1_lf.weight], lambda: ops.pack_decomp1x1_weight(self.conv1x1_lf.weight))
-        w_hf = self._packs.get("hf", [self.conv1x1_hf.weight], lambda: ops.pack_decomp1x1_weight(self.conv1x1_hf.weight))
+        # fp16 configuration: the filter wrote HF = x - LF (fp16) and the 1x1 folds over [x, HF1, HF2] with fp16 hi + lo weights
+        pack1, pn = (ops.pack_decomp1x1_hf_weight, "_hf16") if lf16 is torch.float16 else (ops.pack_decomp1x1_weight, "")
+        w_lf = self._packs.get("lf" + pn, [self.conv1x1_lf.weight], lambda: pack1(self.conv1x1_lf.weight))
+        w_hf = self._packs.get("hf" + pn, [self.conv1x1_hf.weight], lambda: pack1(self.conv1x1_hf.weight))
         if feats is not None:
             feats.update(lf_ir=lf_ir, lf_vis=lf_vis, g_ir=g_ir, g_vis=g_vis)
         x_ir, x_vis = (ops.cast_storage(fir, True), ops.cast_storage(fvis, True)) if lf16 else (fir, fvis)   # the stems' bf16 twins
@@ -186,7 +191,8 @@ class Cell_Decom(nn.Module):
         lf16 = ops._ACT_BF16[0]
         lf = self.decomposition_nhwc(f, g, out_bf16=lf16)
         conv = self.conv1x1_lf if which == 0 else self.conv1x1_hf
-        w = self._packs.get("lf" if which == 0 else "hf", [conv.weight], lambda: ops.pack_decomp1x1_weight(conv.weight))
+        pack1, pn = (ops.pack_decomp1x1_hf_weight, "_hf16") if lf16 is torch.float16 else (ops.pack_decomp1x1_weight, "")
+        w = self._packs.get(("lf" if which == 0 else "hf") + pn, [conv.weight], lambda: pack1(conv.weight))
         x = ops.cast_storage(f, True) if lf16 else f
         y = ops.conv2d([x, lf[0], lf[1]], w, 1, 1, shift=conv.bias)
         return (self.chain if which == 0 else self.chain2).forward_nhwc(y, (f,), None)
@@ -351,7 +357,7 @@ class Network_Fusion_Searched(nn.Module):
                 vis_feature.record_stream(main)
             del fvis, g_vis
             agg = self.spa.blend_nhwc(ir_feature, vis_feature)
-            return self._tail_nhwc(self.chain.forward_nhwc(agg, (), None))
+            return self._tail_nhwc(self.chain.forward_nhwc(agg, (), None, out_f32=ops._ACT_BF16[0] is torch.float16))
         fir, g_ir = ops.stem(ir, self.stem_1[0].weight, self.stem_1[1].weight)
         fvis, g_vis = ops.stem(vis, self.stem_2[0].weight, self.stem_2[1].weight)
         t_dec = None if tape is None else {}
@@ -367,14 +373,13 @@ class Network_Fusion_Searched(nn.Module):
             agg, scale, comp = self.spa.blend_nhwc(ir_feature, vis_feature, want_scale=True, want_comp=True)
         else:
             agg, scale = self.spa.blend_nhwc(ir_feature, vis_feature, want_scale=True)
-        feature2 = self.chain.forward_nhwc(agg, (), t_chain)
-        if tape is None and inter is None:
-            return self._tail_nhwc(feature2)
-        w0 = self._packs.get("so0", [self.stem_out[0].weight], lambda: ops.pack_conv_weight(self.stem_out[0].weight, 1, 32, 3))
-        t16 = ops.conv2d([feature2], w0, 3, 1, cout=16)
+        # fp16 storage: the forward's last 32-channel map (largest magnitudes, straight into the fused image) stays fp32
+        feature2 = self.chain.forward_nhwc(agg, (), t_chain, out_f32=tape is None and ops._ACT_BF16[0] is torch.float16)
         if tape is None:
-            out = ops.tail(t16, self.stem_out[1].weight, self.stem_out[2].weight)
+            out = self._tail_nhwc(feature2)
         else:
+            w0 = self._packs.get("so0", [self.stem_out[0].weight], lambda: ops.pack_conv_weight(self.stem_out[0].weight, 1, 32, 3))
+            t16 = ops.conv2d([feature2], w0, 3, 1, cout=16)
             out, z = ops.tail(t16, self.stem_out[1].weight, self.stem_out[2].weight, save=True)
             tape.update(dec=t_dec, chain=t_chain, ir_feature=ir_feature, vis_feature=vis_feature, scale=scale, fused=out, z=z)
             if ops.taping_wgrad():
@@ -386,6 +391,8 @@ class Network_Fusion_Searched(nn.Module):
     def _tail_nhwc(self, feature2):
         """stem_out + tanh of the inference forward (no tape)."""
         so = self.stem_out
+        if feature2.dtype == torch.float16:     # (a genotype whose last op has no fp32-output kernel)
+            feature2 = ops.cast_storage(feature2, torch.float32)
         if feature2.dtype == torch.float32:
             # fp32 maps: the one-kernel form takes x as bf16 hi + lo (the split-bf16 convs' own operand precision); under
             # set_conv_precision("f32" | "bf16x6") the two packed convs run at the requested precision instead
@@ -396,7 +403,11 @@ class Network_Fusion_Searched(nn.Module):
             # inference forward (bf16 maps; since round 4 fp32 maps too): both stem_out convs + PReLU + tanh as one launch pair (csrc/stem_out.hip)
             wso = self._packs.get("so_fused", [so[0].weight, so[1].weight], lambda: ops.stem_out_pack(so[0].weight, so[1].weight))
             return ops.stem_out_fused(feature2, wso, so[2].weight)
-        w0 = self._packs.get("so0", [so[0].weight], lambda: ops.pack_conv_weight(so[0].weight, 1, 32, 3))
+        if feature2.dtype == torch.float32:   # (also the fp32 last map of an fp16-storage forward: a split-bf16 pack whatever the forward's packs are)
+            prec = ops.CONFIG["conv_precision"]
+            w0 = self._packs.get("so0_" + prec, [so[0].weight], lambda: ops.pack_conv_weight(so[0].weight, 1, 32, 3, precision=prec))
+        else:
+            w0 = self._packs.get("so0", [so[0].weight], lambda: ops.pack_conv_weight(so[0].weight, 1, 32, 3))
         return ops.tail(ops.conv2d([feature2], w0, 3, 1, cout=16), so[1].weight, so[2].weight)
 
     def backward_impl(self, d_fused, tape, wgrad=False):

@@ -16,6 +16,7 @@ struct Args {
   int nsrc, nres, act, kh;   // kh: 3 or 7
   int cout;                  // 32, or 16 (3x3, one source, no residual maps)
   int B, H, W, reverse;
+  int f16;                   // 1: the maps and weights are IEEE fp16 (PAIF_ST_F16 / PAIF_CONV_F16; the fp16 hi pieces of the F16X2 pack), else bf16
 };
 
 // true if the kernel is built for this source / residual count and the tensors fit its 32-bit addressing

@@ -33,8 +33,6 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
 constexpr int TW = 32, TH = 8;          // output tile
 constexpr int TWH = TW + 2, THH = TH + 2;
 constexpr int NPIX = TWH * THH;         // 340 halo pixels x 64 B
@@ -86,7 +84,8 @@ struct Sched {
   static constexpr int n1 = DPW * (PF - 1);
 };
 
-template <int NSRC, int NRES>
+// F: 16-bit format of maps and weights (1 bf16, 2 fp16 -- round 5: same data path, v_mfma_f32_32x32x16_f16, fp16 conversions in the epilogue)
+template <int NSRC, int NRES, int F>
 __global__ __launch_bounds__(256, 1) void conv3x3_bf16_dma(Args a, int ntiles, int tilesX, int tilesY) {
   typedef Sched<NSRC, NRES> SC;
   constexpr int U = SC::U, D = SC::D;
@@ -232,12 +231,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_dma(Args a, int ntiles, i
 #pragma unroll
       for (int r = 0; r < NRES; ++r) {
         const unsigned u = rr[SETP][r][it][j >> 1];
-        v += __uint_as_float((j & 1) ? (u & 0xffff0000u) : (u << 16));
+        if constexpr (F == 2) v += (float)__builtin_bit_cast(paif::f16x2_t, u)[j & 1];
+        else v += __uint_as_float((j & 1) ? (u & 0xffff0000u) : (u << 16));
       }
       ev[j] = v;
     } else {
-      const uint2 o0 = paif::f32_to_bf16x4(make_float4(ev[0], ev[1], ev[2], ev[3]));
-      const uint2 o1 = paif::f32_to_bf16x4(make_float4(ev[4], ev[5], ev[6], ev[7]));
+      const uint2 o0 = paif::f32_to_h4<F>(make_float4(ev[0], ev[1], ev[2], ev[3]));
+      const uint2 o1 = paif::f32_to_h4<F>(make_float4(ev[4], ev[5], ev[6], ev[7]));
       const int y = py0 + 2 * w + (it >> 1), x = px0 + (it & 1) * 16 + (l >> 2);
       const unsigned soff = (unsigned)(((pb * H + y) * W + px0 + (it & 1) * 16) * opitch);
       u32x4 od = {o0.x, o0.y, o1.x, o1.y};
@@ -294,12 +294,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_dma(Args a, int ntiles, i
         constexpr int gi = decltype(gitag)::value, dy = decltype(dytag)::value, j = decltype(jtag)::value;
         constexpr int ks = gi / 3, dx = gi % 3;
         if constexpr (!((CD_EXP & 2) && (dy > 0 || j > 0))) {
-          const bf16x8 av = __builtin_bit_cast(bf16x8, A[gi & 1][j + dy]), bv = __builtin_bit_cast(bf16x8, bw[S][dy * 3 + dx][ks]);
+          const u32x4 av = A[gi & 1][j + dy], bv = bw[S][dy * 3 + dx][ks];
           if constexpr (S == 0 && gi == 0 && dy == 0) {    // first product of a tile: C = 0
             const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, z, 0, 0, 0);
+            acc[j] = paif::mfma16<F>(av, bv, z);
           } else {
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[j], 0, 0, 0);
+            acc[j] = paif::mfma16<F>(av, bv, acc[j]);
           }
         }
         if constexpr (S == 0) epi(std::integral_constant<int, gi * 6 + dy * 2 + j>{}, std::integral_constant<int, SETP>{}, pok, pb, py0, px0);
@@ -434,6 +434,7 @@ static_assert(4 * DPW * 64 >= NPIX * 4, "7x7: DMA instructions do not cover the 
 
 #define CD_WR128(addr, val, off) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(val), "n"(off) : "memory")
 
+template <int F>
 __global__ __launch_bounds__(256, 1) void conv7x7_bf16_dma(Args a, int ntiles, int tilesX, int tilesY) {
   constexpr int P = k7::P, TWH = k7::TWH, NPIX = k7::NPIX, DPW = k7::DPW, SLOT = k7::SLOT, ROWB = k7::ROWB, WB_OFF = k7::WB_OFF,
                 PARK_OFF = k7::PARK_OFF;   // shadow the 3x3 kernel's file-scope constants
@@ -538,8 +539,8 @@ __global__ __launch_bounds__(256, 1) void conv7x7_bf16_dma(Args a, int ntiles, i
       float v = __builtin_fmaf(__uint_as_float(raw), esc[j], esh[j]);
       ev[j] = __builtin_fmaf(e_slope, fminf(v, 0.f), fmaxf(v, 0.f));
     } else {
-      const uint2 o0 = paif::f32_to_bf16x4(make_float4(ev[0], ev[1], ev[2], ev[3]));
-      const uint2 o1 = paif::f32_to_bf16x4(make_float4(ev[4], ev[5], ev[6], ev[7]));
+      const uint2 o0 = paif::f32_to_h4<F>(make_float4(ev[0], ev[1], ev[2], ev[3]));
+      const uint2 o1 = paif::f32_to_h4<F>(make_float4(ev[4], ev[5], ev[6], ev[7]));
       const int y = py0 + 2 * w + (it >> 1), x = px0 + (it & 1) * 16 + (l >> 2);
       const unsigned soff = (unsigned)(((pb * H + y) * W + px0 + (it & 1) * 16) * 64);
       u32x4 od = {o0.x, o0.y, o1.x, o1.y};
@@ -578,13 +579,13 @@ __global__ __launch_bounds__(256, 1) void conv7x7_bf16_dma(Args a, int ntiles, i
     auto mma = [&](auto gitag, auto dytag, auto jtag) {
       constexpr int gi = decltype(gitag)::value, dy = decltype(dytag)::value, j = decltype(jtag)::value;
       constexpr int dx = gi >> 1, ks = gi & 1;
-      const bf16x8 av = __builtin_bit_cast(bf16x8, A[gi & 1][j + dy]);
-      const bf16x8 bv = ks == 0 ? __builtin_bit_cast(bf16x8, bw0[dy * 7 + dx]) : __builtin_bit_cast(bf16x8, BL[dy]);
+      const u32x4 av = A[gi & 1][j + dy];
+      const u32x4 bv = ks == 0 ? bw0[dy * 7 + dx] : BL[dy];
       if constexpr (gi == 0 && dy == 0) {
         const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, z, 0, 0, 0);
+        acc[j] = paif::mfma16<F>(av, bv, z);
       } else {
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[j], 0, 0, 0);
+        acc[j] = paif::mfma16<F>(av, bv, acc[j]);
       }
       constexpr int m = gi * 14 + dy * 2 + j;
       if constexpr (m < 36) epi(std::integral_constant<int, m>{}, pok, pb, py0, px0);
@@ -661,7 +662,8 @@ __global__ __launch_bounds__(256, 1) void conv7x7_bf16_dma(Args a, int ntiles, i
 
 int launch_7(const Args& a, hipStream_t st) {
   const int tilesX = (a.W + TW - 1) / TW, tilesY = (a.H + TH - 1) / TH;
-  hipLaunchKernelGGL(conv7x7_bf16_dma, dim3(256), dim3(256), 0, st, a, a.B * tilesX * tilesY, tilesX, tilesY);
+  if (a.f16) hipLaunchKernelGGL(conv7x7_bf16_dma<2>, dim3(256), dim3(256), 0, st, a, a.B * tilesX * tilesY, tilesX, tilesY);
+  else hipLaunchKernelGGL(conv7x7_bf16_dma<1>, dim3(256), dim3(256), 0, st, a, a.B * tilesX * tilesY, tilesX, tilesY);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     paif::set_error("conv2d(bf16 dma 7x7): launch failed: %s", hipGetErrorString(e));
@@ -673,7 +675,8 @@ int launch_7(const Args& a, hipStream_t st) {
 template <int NSRC, int NRES>
 int launch_n(const Args& a, hipStream_t st) {
   const int tilesX = (a.W + TW - 1) / TW, tilesY = (a.H + TH - 1) / TH;
-  hipLaunchKernelGGL((conv3x3_bf16_dma<NSRC, NRES>), dim3(256), dim3(256), 0, st, a, a.B * tilesX * tilesY, tilesX, tilesY);
+  if (a.f16) hipLaunchKernelGGL((conv3x3_bf16_dma<NSRC, NRES, 2>), dim3(256), dim3(256), 0, st, a, a.B * tilesX * tilesY, tilesX, tilesY);
+  else hipLaunchKernelGGL((conv3x3_bf16_dma<NSRC, NRES, 1>), dim3(256), dim3(256), 0, st, a, a.B * tilesX * tilesY, tilesX, tilesY);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     paif::set_error("conv2d(bf16 dma): launch failed: %s", hipGetErrorString(e));

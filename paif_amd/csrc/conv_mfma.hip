@@ -60,8 +60,9 @@ struct ConvArgs {
   int nsrc, in_act, act, cout, epi_dact;
   int B, H, W, tilesX, tilesY, nblk;
   int reverse;             // 1: tiles are walked from the end of each XCD range (serpentine order across consecutive layers)
-  int st;                  // activation storage (paif_common.h): 0 fp32/fp32, 1 bf16/bf16, 2 fp32 in / bf16 out
-  int wl0;                 // 1: plain bf16 weights (PAIF_CONV_BF16): the kernels' storage codes 4 / 5 / 6
+  int st;                  // activation storage (PAIF_ST_*): 0 fp32/fp32, 1 bf16/bf16, 2 fp32 in / bf16 out, 3 fp16/fp16,
+                           // 4 fp16 in (residual maps too) / fp32 out
+  int wl0;                 // 1: plain 16-bit weights (PAIF_CONV_BF16 / PAIF_CONV_F16): the kernels' storage codes 4 / 5 / 6 / 7 (+ 8 for fp16)
 };
 
 // Transform applied to a staged float4 (channels 4q..4q+3 of one pixel):
@@ -142,7 +143,7 @@ __device__ __forceinline__ EpiParams load_epi_params(const ConvArgs& a, int lane
 
 // CH: elements per lane whose residual loads are in flight together (NITER = all, the default; the persistent kernel,
 // which holds a prefetched halo tile in registers across its epilogue, uses half)
-template <bool FULL, bool HOOKS, int NRES, int SEGS, int CH = SEGS * 32 * 8 / 64, int BFO = 0>
+template <bool FULL, bool HOOKS, int NRES, int SEGS, int CH = SEGS * 32 * 8 / 64, int BFO = 0, int BFR = BFO>
 __device__ __forceinline__ float4 epilogue_lds_n(const ConvArgs& a, const EpiParams& ep_par, const f32x16 (&acc)[SEGS],
                                                  float* lds, int b, int y0, int x0, int wave, int lane) {
   float* ep = lds + wave * (SEGS * 32 * 32);
@@ -187,9 +188,9 @@ __device__ __forceinline__ float4 epilogue_lds_n(const ConvArgs& a, const EpiPar
     size_t off;
     const bool ok = locate(it, off);
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    r0[it - it0] = (nres > 0 && ok) ? paif::ldq_nt<BFO>(a.res[0], off) : z4;
-    r1[it - it0] = (nres > 1 && ok) ? paif::ldq_nt<BFO>(a.res[1], off) : z4;
-    r2[it - it0] = (nres > 2 && ok) ? paif::ldq_nt<BFO>(a.res[2], off) : z4;
+    r0[it - it0] = (nres > 0 && ok) ? paif::ldq_nt<BFR>(a.res[0], off) : z4;
+    r1[it - it0] = (nres > 1 && ok) ? paif::ldq_nt<BFR>(a.res[1], off) : z4;
+    r2[it - it0] = (nres > 2 && ok) ? paif::ldq_nt<BFR>(a.res[2], off) : z4;
     ea[it - it0] = (HOOKS && a.epi_dact && ok) ? *reinterpret_cast<const float4*>(a.epi_aux + off) : z4;
   }
 #pragma unroll
@@ -225,14 +226,14 @@ __device__ __forceinline__ float4 epilogue_lds_n(const ConvArgs& a, const EpiPar
   return psum;   // per-lane partial channel sums of quad q (for the ECA pool)
 }
 
-template <bool FULL, bool HOOKS, int SEGS = SEGS_PER_WAVE, int CH = SEGS * 32 * 8 / 64, int BFO = 0>
+template <bool FULL, bool HOOKS, int SEGS = SEGS_PER_WAVE, int CH = SEGS * 32 * 8 / 64, int BFO = 0, int BFR = BFO>
 __device__ __forceinline__ float4 epilogue_lds(const ConvArgs& a, const EpiParams& ep_par, const f32x16 (&acc)[SEGS], float* lds,
                                                int b, int y0, int x0, int wave, int lane) {
   // residuals are packed from index 0; the count is launch-uniform
-  if (!a.res[0]) return epilogue_lds_n<FULL, HOOKS, 0, SEGS, CH, BFO>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
-  if (!a.res[1]) return epilogue_lds_n<FULL, HOOKS, 1, SEGS, CH, BFO>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
-  if (!a.res[2]) return epilogue_lds_n<FULL, HOOKS, 2, SEGS, CH, BFO>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
-  return epilogue_lds_n<FULL, HOOKS, 3, SEGS, CH, BFO>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
+  if (!a.res[0]) return epilogue_lds_n<FULL, HOOKS, 0, SEGS, CH, BFO, BFR>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
+  if (!a.res[1]) return epilogue_lds_n<FULL, HOOKS, 1, SEGS, CH, BFO, BFR>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
+  if (!a.res[2]) return epilogue_lds_n<FULL, HOOKS, 2, SEGS, CH, BFO, BFR>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
+  return epilogue_lds_n<FULL, HOOKS, 3, SEGS, CH, BFO, BFR>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
 }
 
 template <int KH, int DIL, int CIN, bool HOOKS>
@@ -404,6 +405,7 @@ __global__ __launch_bounds__(NTHREADS, (HOOKS || KH >= 5 || DIL == 2 || NP == 3)
   constexpr int TWH = TW + 2 * P;
   constexpr int THH = TH + 2 * P;
   static_assert(NP == 2 || (NP == 3 && ST == 0), "the three-piece split is built for fp32 storage");
+  constexpr int FM = paif::st_fmt16(ST);     // 16-bit format of the MFMA operands (1 bf16, 2 fp16)
   constexpr int PSB = NP == 3 ? 208 : 144;   // pixel record in bytes: NP x 64 + 16 (13 / 9 sixteen-byte slots: odd -> conflict-free b128)
   constexpr int QPP = CIN / 4;
   constexpr int NKS = CIN / 16;        // K=16 steps per tap
@@ -477,6 +479,10 @@ __global__ __launch_bounds__(NTHREADS, (HOOKS || KH >= 5 || DIL == 2 || NP == 3)
       for (int u = 0; u < UB; ++u) {
         if (dst[u] >= 0) {
           const float4 t4 = stage_xform<HOOKS>(a, v[u], xa[u], in_slope, (dst[u] % PSB) >> 3);
+          if constexpr (paif::st_f16(ST)) {   // fp16 maps: the staged operand is ONE fp16 value (stored as such, or rounded after the input PReLU)
+            *reinterpret_cast<uint2*>(ldsb + dst[u]) = paif::f32_to_f16x4(t4);
+            continue;
+          }
           const __bf16 hx = (__bf16)t4.x, hy = (__bf16)t4.y, hz = (__bf16)t4.z, hw = (__bf16)t4.w;
           uint2 hi, lo;
           hi.x = (unsigned)__builtin_bit_cast(unsigned short, hx) | ((unsigned)__builtin_bit_cast(unsigned short, hy) << 16);
@@ -531,31 +537,31 @@ __global__ __launch_bounds__(NTHREADS, (HOOKS || KH >= 5 || DIL == 2 || NP == 3)
         const bf16x8 b0 = __builtin_bit_cast(bf16x8, bw[slot][3 * ks]), b1 = __builtin_bit_cast(bf16x8, bw[slot][3 * ks + 1]),
                      b2 = __builtin_bit_cast(bf16x8, bw[slot][3 * ks + 2]);
 #pragma unroll
-        for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h[sg], b2, acc[sg], 0, 0, 0);
+        for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = paif::mfma16<FM>(A.h[sg], b2, acc[sg]);
 #pragma unroll
-        for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.t[sg], b0, acc[sg], 0, 0, 0);
+        for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = paif::mfma16<FM>(A.t[sg], b0, acc[sg]);
 #pragma unroll
-        for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.l[sg], b1, acc[sg], 0, 0, 0);
+        for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = paif::mfma16<FM>(A.l[sg], b1, acc[sg]);
 #pragma unroll
-        for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h[sg], b1, acc[sg], 0, 0, 0);
+        for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = paif::mfma16<FM>(A.h[sg], b1, acc[sg]);
 #pragma unroll
-        for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.l[sg], b0, acc[sg], 0, 0, 0);
+        for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = paif::mfma16<FM>(A.l[sg], b0, acc[sg]);
 #pragma unroll
-        for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h[sg], b0, acc[sg], 0, 0, 0);
+        for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = paif::mfma16<FM>(A.h[sg], b0, acc[sg]);
         return;
       }
       const bf16x8 bh = __builtin_bit_cast(bf16x8, bw[slot][2 * ks]);
       const bf16x8 bl = __builtin_bit_cast(bf16x8, bw[slot][2 * ks + 1]);
       if constexpr (!paif::st_lo0(ST)) {
 #pragma unroll
-        for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.l[sg], bh, acc[sg], 0, 0, 0);
+        for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = paif::mfma16<FM>(A.l[sg], bh, acc[sg]);
       }
       if constexpr (!paif::st_wl0(ST)) {
 #pragma unroll
-      for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h[sg], bl, acc[sg], 0, 0, 0);
+      for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = paif::mfma16<FM>(A.h[sg], bl, acc[sg]);
       }
 #pragma unroll
-      for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h[sg], bh, acc[sg], 0, 0, 0);
+      for (int sg = 0; sg < SEGS_PER_WAVE; ++sg) acc[sg] = paif::mfma16<FM>(A.h[sg], bh, acc[sg]);
     };
     static_assert(NKS == 2, "the A double buffer alternates on the K step");
     AStep A[2];
@@ -615,8 +621,8 @@ __global__ __launch_bounds__(NTHREADS, (HOOKS || KH >= 5 || DIL == 2 || NP == 3)
   const EpiParams ep_par = load_epi_params<HOOKS>(a, lane);   // in flight across the barrier
   __syncthreads();  // every wave has finished reading the staged tile: its LDS is reused by the epilogue
   float4 ps;
-  if (full) ps = epilogue_lds<true, HOOKS, SEGS_PER_WAVE, SEGS_PER_WAVE * 32 * 8 / 64, paif::st_out(ST)>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
-  else ps = epilogue_lds<false, HOOKS, SEGS_PER_WAVE, SEGS_PER_WAVE * 32 * 8 / 64, paif::st_out(ST)>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
+  if (full) ps = epilogue_lds<true, HOOKS, SEGS_PER_WAVE, SEGS_PER_WAVE * 32 * 8 / 64, paif::st_out(ST), paif::st_res(ST)>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
+  else ps = epilogue_lds<false, HOOKS, SEGS_PER_WAVE, SEGS_PER_WAVE * 32 * 8 / 64, paif::st_out(ST), paif::st_res(ST)>(a, ep_par, acc, lds, b, y0, x0, wave, lane);
   if (a.pool_partial) {
     // lanes with equal (lane & 7) hold the same channel quad for different pixels: reduce over the 8 pixel lanes,
     // then over the 4 waves through LDS (fixed order -> deterministic)
@@ -702,6 +708,7 @@ __device__ __forceinline__ void split_bf16x4(float4 t, uint2& hi, uint2& lo) {
 // bf16 quad of a bf16-stored map (half the prefetch registers; its split is the identity: hi = the stored bits, lo = 0)
 template <int BF> struct RawQ { typedef float4 T; };
 template <> struct RawQ<1> { typedef uint2 T; };
+template <> struct RawQ<2> { typedef uint2 T; };   // fp16 quad
 template <int BF> __device__ __forceinline__ typename RawQ<BF>::T ldraw(const char* p) {
   return *reinterpret_cast<const typename RawQ<BF>::T*>(p);
 }
@@ -718,7 +725,7 @@ __device__ __forceinline__ void split_raw(float4 t, uint2& hi, uint2& lo) { spli
 __device__ __forceinline__ void split_raw(uint2 t, uint2& hi, uint2& lo) { hi = t; lo = make_uint2(0u, 0u); }
 __device__ __forceinline__ float4 raw_zero(float4) { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ uint2 raw_zero(uint2) { return make_uint2(0u, 0u); }
-// ReLU of a staged quad.  bf16 pairs: as signed 16-bit integers every negative value (sign bit) is below 0 -- one packed max
+// ReLU of a staged quad.  bf16 / fp16 pairs (both sign-magnitude): as signed 16-bit integers every negative value (sign bit) is below 0 -- one packed max
 __device__ __forceinline__ float4 raw_relu(float4 t) { return make_float4(fmaxf(t.x, 0.f), fmaxf(t.y, 0.f), fmaxf(t.z, 0.f), fmaxf(t.w, 0.f)); }
 __device__ __forceinline__ uint2 raw_relu(uint2 t) {
   typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -1268,7 +1275,8 @@ constexpr int WS_THREADS = 12 * 64;
 
 template <int KH, int DIL, int ST, bool RELU>
 __device__ __forceinline__ void conv_ws_body(const ConvArgs& a, int ntiles) {
-  constexpr int BFI = paif::st_in(ST), BFO = paif::st_out(ST);
+  constexpr int BFI = paif::st_in(ST), BFO = paif::st_out(ST), BFR = paif::st_res(ST), FM = paif::st_fmt16(ST);
+  static_assert(!paif::st_f16(ST) || BFI != 0, "fp16 storage: the persistent form takes fp16 sources, staged as stored");
   constexpr unsigned ES = BFI ? 2u : 4u;               // bytes per stored input element
   typedef typename RawQ<BFI>::T raw_t;
   static_assert(TH == 8, "the MFMA-wave mapping assumes 8-row tiles");
@@ -1434,12 +1442,12 @@ __device__ __forceinline__ void conv_ws_body(const ConvArgs& a, int ntiles) {
               const bf16x8 ah = *reinterpret_cast<const bf16x8*>(buf + abase[sg] + toff + 32 * ks);
               if constexpr (!paif::st_lo0(ST)) {
                 const bf16x8 al = *reinterpret_cast<const bf16x8*>(buf + abase[sg] + toff + 64 + 32 * ks);
-                acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[sg], 0, 0, 0);
+                acc[sg] = paif::mfma16<FM>(al, bh, acc[sg]);
               }
               if constexpr (!paif::st_wl0(ST)) {
-              acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[sg], 0, 0, 0);
+              acc[sg] = paif::mfma16<FM>(ah, bl, acc[sg]);
               }
-              acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[sg], 0, 0, 0);
+              acc[sg] = paif::mfma16<FM>(ah, bh, acc[sg]);
             }
           }
           {
@@ -1488,7 +1496,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvArgs& a, int ntiles) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const int yy = min(y0 + j, a.H - 1) - y0;
-            r[k][j] = paif::ldq_nt<BFO>(a.res[k], base + (size_t)yy * a.W * 32 + lo);
+            r[k][j] = paif::ldq_nt<BFR>(a.res[k], base + (size_t)yy * a.W * 32 + lo);
           }
       };
       if (cnt > 0) request(0);
@@ -1547,7 +1555,7 @@ int launch_bf16x3_ws(const ConvArgs& a, hipStream_t st) {
   constexpr size_t lds_bytes = 2 * (size_t)(TH + 2 * P) * (TW + 2 * P) * 144 + 8 * 32 * 32 * 4;
   static_assert(lds_bytes <= 160 * 1024, "two tile buffers + the parked tile do not fit LDS");
   static bool raised = false;   // once per instantiation (one device per process)
-  constexpr bool HAS_RELU = KH == 3 && DIL == 2 && paif::st_in(ST) == 1;   // the ReLU form is built for the bf16-stored dilated 3x3
+  constexpr bool HAS_RELU = KH == 3 && DIL == 2 && paif::st_in(ST) != 0 && paif::st_low(ST) != 7;   // the ReLU form is built for the 16-bit-stored dilated 3x3
   if (!raised) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_ws<KH, DIL, ST>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -1584,8 +1592,11 @@ static inline bool ws_enabled() {
   }();
   return on;
 }
+// 16-bit maps in AND out (bf16: 1, fp16: 3) / fp16 maps anywhere
+static inline bool st_h16(const ConvArgs& a) { return a.st == 1 || a.st == 3; }
+static inline bool st_is_f16(const ConvArgs& a) { return a.st >= 3; }
 static inline bool ws_eligible(const ConvArgs& a) {
-  return ws_enabled() && a.nblk >= 1024 && !a.pool_partial && a.cout == 32 && (a.in_act == 0 || (a.in_act == 2 && a.st == 1)) &&
+  return ws_enabled() && a.nblk >= 1024 && !a.pool_partial && a.cout == 32 && (a.in_act == 0 || (a.in_act == 2 && st_h16(a))) &&
          (size_t)a.H * a.W * 128 < ((size_t)1 << 32);
 }
 
@@ -1602,7 +1613,7 @@ static inline bool res_eligible(const ConvArgs& a) {
     const char* e = getenv("PAIF_CONV_RES_NSRC");   // experiment: largest source count the resident form takes with plain bf16 weights
     return e ? atoi(e) : 1;
   }();
-  return on && (a.nsrc == 1 || (a.wl0 && a.st == 1 && a.in_act == 0 && a.nsrc <= ms_res)) && a.nblk >= 2048 && a.cout == 32 && a.in_act <= 2 && (PAIF_RES_ROWS == 8 || !a.pool_partial) &&
+  return on && !st_is_f16(a) && (a.nsrc == 1 || (a.wl0 && a.st == 1 && a.in_act == 0 && a.nsrc <= ms_res)) && a.nblk >= 2048 && a.cout == 32 && a.in_act <= 2 && (PAIF_RES_ROWS == 8 || !a.pool_partial) &&
          (size_t)a.B * a.H * a.W * 128 < ((size_t)1 << 31);   // buffer resources: 32-bit byte counts and offsets
 }
 
@@ -1617,11 +1628,12 @@ static inline bool needs_hooks(const ConvArgs& a) { return a.in_act >= 3 || a.au
 static inline bool takes_ws(const ConvArgs& a, int kh, int dil) {
 #if PAIF_TH == 8
   if (needs_hooks(a) || kh > 3 || !ws_eligible(a)) return false;
+  if (a.st == 4) return dil == 2 && a.nsrc == 1 && a.in_act == 0;  // fp16 in / fp32 out: the last conv of the fp16 forward
   if (kh == 1) return !a.res[0] && a.in_act == 0;
   // dilation-2 3x3, one source (the composed DilConv; in_act none or ReLU): bf16-stored maps only.  With fp32 maps the tile-per-workgroup
   // kernel is the faster one INSIDE the forward (round 4, three alternating bench.py runs each: 6.154 vs 6.173 ms per step); the 222 vs
   // 236 us that chose the persistent form in round 1 were micro-benchmark times on random inputs, i.e. at the power-capped clock.
-  return dil == 2 && a.nsrc == 1 && a.st != 0;
+  return dil == 2 && a.nsrc == 1 && st_h16(a);
 #else
   return false;
 #endif
@@ -1633,13 +1645,13 @@ static inline int res_count(const ConvArgs& a) { return a.res[0] ? (a.res[1] ? (
 static inline ConvVariant bf16x3_variant(const ConvArgs& a, int kh, int dil) {
   if (needs_hooks(a)) return CV_HOOKS;
   // bf16 maps + plain bf16 weights, 3x3 dilation 1, 32 -> 32 per source: the LDS-DMA kernel (conv_dma.hip)
-  if (dil == 1 && a.st == 1 && a.wl0 && a.in_act == 0 && !a.pool_partial &&
+  if (dil == 1 && st_h16(a) && a.wl0 && a.in_act == 0 && !a.pool_partial &&
       ((kh == 3 && a.cout == 32 && paif_conv_dma::eligible(a.nsrc, res_count(a), a.B, a.H, a.W, a.alpha)) ||
        (kh == 3 && a.cout == 16 && paif_conv_dma::eligible16(a.nsrc, res_count(a), a.B, a.H, a.W, a.alpha)) ||
        (kh == 7 && a.cout == 32 && paif_conv_dma::eligible7(a.nsrc, res_count(a), a.B, a.H, a.W, a.alpha))))
     return CV_DMA;
   if (takes_ws(a, kh, dil)) return CV_WS;
-  if (kh == 3 && dil == 1) {
+  if (kh == 3 && dil == 1 && !st_is_f16(a)) {    // (fp16 maps: LDS-DMA, persistent or tile-per-workgroup kernel only)
     if (res_eligible(a)) return CV_RES;
     if (ms_enabled() && a.nsrc >= 2 && a.cout == 32 && a.in_act == 0 && !a.pool_partial &&
         (size_t)a.B * a.H * a.W * 128 < ((size_t)1 << 32))   // 32-bit byte offsets into a source
@@ -1656,6 +1668,7 @@ int launch_bf16x3_st(const ConvArgs& a, hipStream_t st) {
       for (int s = 0; s < 3; ++s) { d.src[s] = a.src[s]; d.res[s] = a.res[s]; }
       d.wpk = a.wpk; d.scale = a.scale; d.shift = a.shift; d.prelu = a.prelu; d.out = a.out; d.alpha = a.alpha;
       d.nsrc = a.nsrc; d.nres = res_count(a); d.act = a.act; d.B = a.B; d.H = a.H; d.W = a.W; d.reverse = a.reverse; d.kh = KH; d.cout = a.cout;
+      d.f16 = paif::st_f16(ST) ? 1 : 0;
       return paif_conv_dma::launch(d, st);
     }
     case CV_HOOKS:
@@ -1668,7 +1681,7 @@ int launch_bf16x3_st(const ConvArgs& a, hipStream_t st) {
 #endif
       break;
     case CV_RES:
-      if constexpr (KH == 3 && DIL == 1) {
+      if constexpr (KH == 3 && DIL == 1 && !paif::st_f16(ST)) {
         if constexpr (ST == 4) {
           if (a.nsrc == 2) return launch_bf16x3_res<3, 1, 2, ST>(a, st);
           if (a.nsrc == 3) return launch_bf16x3_res<3, 1, 3, ST>(a, st);
@@ -1677,7 +1690,7 @@ int launch_bf16x3_st(const ConvArgs& a, hipStream_t st) {
       }
       break;
     case CV_MS:
-      if constexpr (KH == 3 && DIL == 1) return a.nsrc == 2 ? launch_bf16x3_ms<3, 1, 2, ST>(a, st) : launch_bf16x3_ms<3, 1, 3, ST>(a, st);
+      if constexpr (KH == 3 && DIL == 1 && !paif::st_f16(ST)) return a.nsrc == 2 ? launch_bf16x3_ms<3, 1, 2, ST>(a, st) : launch_bf16x3_ms<3, 1, 3, ST>(a, st);
       break;
     default: break;
   }
@@ -1688,8 +1701,11 @@ int launch_bf16x3_st(const ConvArgs& a, hipStream_t st) {
 // the 1x1 behind the fp32 guided-filter block
 // kernel storage code (template argument ST, paif_common.h) of a launch
 static inline int kernel_st(const ConvArgs& a) {
-  const int base = a.st == 1 ? (a.in_act == 1 ? 3 : 1) : a.st;
-  return (a.wl0 && base) ? base + 3 : base;
+  if (a.st == 4) return 15;                                     // fp16 in / fp32 out (plain fp16 weights)
+  const int st = a.st == 3 ? 1 : a.st;                          // fp16 in / out -> the bf16 codes' 1
+  const int base = st == 1 ? (a.in_act == 1 ? 3 : 1) : st;
+  const int code = (a.wl0 && base) ? base + 3 : base;
+  return a.st >= 3 ? code + 8 : code;
 }
 
 // three-piece split (PAIF_CONV_BF16X6): the tile-per-workgroup kernel, with or without the gradient hooks; fp32 storage
@@ -1717,6 +1733,19 @@ int launch_bf16x3(const ConvArgs& a, hipStream_t st) {
     if constexpr (KH == 1) {
       if (code == 2) return launch_bf16x3_st<KH, DIL, 2>(a, st);
       if (code == 5) return launch_bf16x3_st<KH, DIL, 5>(a, st);
+    }
+    // fp16 maps (round 5): one fp16 MFMA per product (12; 14 behind an input PReLU); the folded 1x1 behind the guided filter with
+    // fp16 hi + lo weights (9); the dilation-2 3x3 that writes the forward's last map as fp32 (15)
+    switch (code) {
+      case 12: return launch_bf16x3_st<KH, DIL, 12>(a, st);
+      case 14: return launch_bf16x3_st<KH, DIL, 14>(a, st);
+      default: break;
+    }
+    if constexpr (KH == 1) {
+      if (code == 9) return launch_bf16x3_st<KH, DIL, 9>(a, st);
+    }
+    if constexpr (KH == 3 && DIL == 2) {
+      if (code == 15) return launch_bf16x3_st<KH, DIL, 15>(a, st);
     }
   }
   paif::set_error("conv2d: storage %d is not built for the %dx%d dilation-%d kernel", a.st, KH, KH, DIL);
@@ -1827,6 +1856,44 @@ __global__ void pack_decomp1x1_bf16x3_kernel(const float* __restrict__ w, unsign
   }
 }
 
+// fp16 storage (round 5): the same stream layout [src][tap][ks][hi|lo][64 lanes][8] with fp16 pieces (hi = rn(v), lo = rn(v - hi): 22
+// significant bits); precision PAIF_CONV_F16 reads the hi pieces only
+__device__ __forceinline__ unsigned short f16x2_piece(float v, int part) {
+  const _Float16 hi = (_Float16)v;
+  const _Float16 out = part == 0 ? hi : (_Float16)(v - (float)hi);
+  return __builtin_bit_cast(unsigned short, out);
+}
+__global__ void pack_weight_f16x2_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpk, int cout, int nsrc, int kh) {
+  const int ntap = kh * kh;
+  const int total = nsrc * ntap * 2 * 2 * 64 * 8;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int j = idx & 7, lane = (idx >> 3) & 63, part = (idx >> 9) & 1, ks = (idx >> 10) & 1;
+    int rest = idx >> 11;
+    const int tap = rest % ntap;
+    const int s = rest / ntap;
+    const int n = lane & 31, hh = lane >> 5;
+    const int c = s * 32 + 16 * ks + 8 * hh + j;
+    const float v = (n < cout) ? w[((size_t)n * (nsrc * 32) + c) * ntap + tap] : 0.f;
+    wpk[idx] = f16x2_piece(v, part);
+  }
+}
+// decomposition 1x1 over the sources (x, HF1, HF2) with HF_i = x - LF_i written by the guided filter (fp16 forward):
+//   W . [LF1, LF2, HF1, HF2] = (Wl1 + Wl2) x + (Wh1 - Wl1) HF1 + (Wh2 - Wl2) HF2      (w rows: [Wl1 | Wl2 | Wh1 | Wh2], 32 columns each)
+__global__ void pack_decomp1x1_hf_f16x2_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpk) {
+  const int total = 3 * 2 * 2 * 64 * 8;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int j = idx & 7, lane = (idx >> 3) & 63, part = (idx >> 9) & 1, ks = (idx >> 10) & 1, s = idx >> 11;
+    const int n = lane & 31, hh = lane >> 5;
+    const int c = 16 * ks + 8 * hh + j;
+    const float* wn = w + n * 128;
+    float v;
+    if (s == 0) v = wn[c] + wn[32 + c];
+    else if (s == 1) v = wn[64 + c] - wn[c];
+    else v = wn[96 + c] - wn[32 + c];
+    wpk[idx] = f16x2_piece(v, part);
+  }
+}
+
 template <int KH, int DIL, int CIN, bool HOOKS>
 int launch_h(const ConvArgs& a, hipStream_t st) {
   constexpr int P = DIL * (KH - 1) / 2;
@@ -1904,11 +1971,13 @@ int paif_conv2d_blocks(int B, int H, int W) { return B * ((H + TH - 1) / TH) * (
 size_t paif_conv_wpk_floats(int nsrc, int cin, int kh) { return (size_t)nsrc * kh * kh * (cin / 8) * 256; }
 
 int paif_conv2d_is_persistent(const paif_conv_desc* d, int B, int H, int W) {
-  if (!d || (d->precision != PAIF_CONV_BF16X3 && d->precision != PAIF_CONV_BF16) || d->cin != 32 || B <= 0 || H <= 0 || W <= 0) return 0;
+  if (!d || (d->precision != PAIF_CONV_BF16X3 && d->precision != PAIF_CONV_BF16 && d->precision != PAIF_CONV_F16 && d->precision != PAIF_CONV_F16X2) ||
+      d->cin != 32 || B <= 0 || H <= 0 || W <= 0)
+    return 0;
   ConvArgs a{};
   for (int s = 0; s < 3; ++s) a.res[s] = d->res[s];
   a.pool_partial = d->pool_partial; a.nsrc = d->nsrc; a.in_act = d->in_act; a.cout = d->cout;
-  a.aux_out = d->aux_out; a.epi_dact = d->epi_dact;
+  a.aux_out = d->aux_out; a.epi_dact = d->epi_dact; a.st = d->storage;
   a.H = H; a.W = W;
   a.nblk = B * ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
   return takes_ws(a, d->kh, d->dil) ? 1 : 0;
@@ -1922,13 +1991,13 @@ int paif_conv2d_kernel_name(const paif_conv_desc* d, int B, int H, int W, char* 
   a.aux_out = d->aux_out; a.epi_dact = d->epi_dact;
   a.B = B; a.H = H; a.W = W;
   a.nblk = B * ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
-  a.st = d->storage; a.wl0 = d->precision == PAIF_CONV_BF16 ? 1 : 0; a.alpha = d->alpha;
+  a.st = d->storage; a.wl0 = (d->precision == PAIF_CONV_BF16 || d->precision == PAIF_CONV_F16) ? 1 : 0; a.alpha = d->alpha;
   const int code = kernel_st(a);
   if (d->precision == PAIF_CONV_BF16X6 && d->cin == 32) {
     snprintf(buf, buflen, "conv_mfma_bf16x3<%d, %d, %s, 0, 3>", d->kh, d->dil, needs_hooks(a) ? "true" : "false");
     return 0;
   }
-  if (d->precision != PAIF_CONV_BF16X3 && d->precision != PAIF_CONV_BF16) {
+  if (d->precision != PAIF_CONV_BF16X3 && d->precision != PAIF_CONV_BF16 && d->precision != PAIF_CONV_F16 && d->precision != PAIF_CONV_F16X2) {
     snprintf(buf, buflen, "conv_mfma_f32<%d, %d, %d, %s>", d->kh, d->dil, d->cin, needs_hooks(a) ? "true" : "false");
     return 0;
   }
@@ -1939,8 +2008,8 @@ int paif_conv2d_kernel_name(const paif_conv_desc* d, int B, int H, int W, char* 
   // the names rocprofv3 prints: every template argument, the storage code last
   switch (bf16x3_variant(a, d->kh, d->dil)) {
     case CV_DMA:
-      if (d->kh == 7) snprintf(buf, buflen, "conv7x7_bf16_dma");
-      else snprintf(buf, buflen, "conv3x3_bf16_dma<%d, %d>", d->nsrc, res_count(a));
+      if (d->kh == 7) snprintf(buf, buflen, "conv7x7_bf16_dma<%d>", a.st >= 3 ? 2 : 1);
+      else snprintf(buf, buflen, "conv3x3_bf16_dma<%d, %d, %d>", d->nsrc, res_count(a), a.st >= 3 ? 2 : 1);
       break;
     case CV_WS: snprintf(buf, buflen, "conv_bf16x3_ws%s<%d, %d, %d>", d->in_act == 2 ? "r" : "", d->kh, d->dil, code); break;
     case CV_RES: snprintf(buf, buflen, "conv_bf16x3_res<%d, %d, %d, %d, %d>", d->kh, d->dil, d->nsrc, PAIF_RES_ROWS, code); break;
@@ -1980,15 +2049,22 @@ int paif_conv2d_fwd(const paif_conv_desc* d, int B, int H, int W, paif_stream_t 
   a.tilesX = (W + TW - 1) / TW; a.tilesY = (H + TH - 1) / TH; a.nblk = B * a.tilesX * a.tilesY;
   a.reverse = d->reverse_tiles ? 1 : 0;
   a.st = d->storage;
-  a.wl0 = d->precision == PAIF_CONV_BF16 ? 1 : 0;
-  PAIF_REQUIRE(d->storage >= 0 && d->storage <= 2, PAIF_EINVAL, "conv2d: storage=%d", d->storage);
-  PAIF_REQUIRE(d->storage == 0 || ((d->precision == PAIF_CONV_BF16X3 || d->precision == PAIF_CONV_BF16) && d->cin == 32), PAIF_ENOSUP,
+  a.wl0 = (d->precision == PAIF_CONV_BF16 || d->precision == PAIF_CONV_F16) ? 1 : 0;
+  PAIF_REQUIRE(d->storage >= 0 && d->storage <= 4, PAIF_EINVAL, "conv2d: storage=%d", d->storage);
+  const bool st_bf = d->storage == PAIF_ST_BF16 || d->storage == PAIF_ST_F32_BF16, st_hf = d->storage == PAIF_ST_F16 || d->storage == PAIF_ST_F16_F32;
+  PAIF_REQUIRE(!st_bf || ((d->precision == PAIF_CONV_BF16X3 || d->precision == PAIF_CONV_BF16) && d->cin == 32), PAIF_ENOSUP,
                "conv2d: bf16 storage needs the split-bf16 kernels (cin 32)");
-  PAIF_REQUIRE(d->precision != PAIF_CONV_BF16 || d->storage != 0, PAIF_ENOSUP, "conv2d: precision bf16 is built for bf16-stored maps only");
+  PAIF_REQUIRE(!st_hf || ((d->precision == PAIF_CONV_F16 || d->precision == PAIF_CONV_F16X2) && d->cin == 32), PAIF_ENOSUP,
+               "conv2d: fp16 storage takes precision F16 / F16X2 (cin 32)");
+  PAIF_REQUIRE(d->precision != PAIF_CONV_BF16 || st_bf, PAIF_ENOSUP, "conv2d: precision bf16 is built for bf16-stored maps only");
+  PAIF_REQUIRE((d->precision != PAIF_CONV_F16 && d->precision != PAIF_CONV_F16X2) || st_hf, PAIF_ENOSUP,
+               "conv2d: precision fp16 is built for fp16-stored maps only");
+  PAIF_REQUIRE(d->storage != PAIF_ST_F16_F32 || d->precision == PAIF_CONV_F16, PAIF_ENOSUP, "conv2d: fp16 in / fp32 out takes plain fp16 weights");
   hipStream_t st = paif::as_stream(stream);
   PAIF_REQUIRE(d->cin == 32 || d->cin == 16, PAIF_ENOSUP, "conv2d: cin=%d", d->cin);
   PAIF_REQUIRE(d->precision == PAIF_CONV_F32 || d->precision == PAIF_CONV_BF16X3 || d->precision == PAIF_CONV_BF16 ||
-                   d->precision == PAIF_CONV_BF16X6, PAIF_EINVAL, "conv2d: precision=%d", d->precision);
+                   d->precision == PAIF_CONV_BF16X6 || d->precision == PAIF_CONV_F16 || d->precision == PAIF_CONV_F16X2, PAIF_EINVAL,
+               "conv2d: precision=%d", d->precision);
   PAIF_REQUIRE(d->precision != PAIF_CONV_BF16X6 || d->cin == 32, PAIF_ENOSUP, "conv2d: bf16x6 needs 32-channel sources");
   const int key = d->kh * 100 + d->dil * 10 + (d->cin == 32 ? 0 : 1);
   if (d->precision == PAIF_CONV_BF16X6) {
@@ -2003,7 +2079,7 @@ int paif_conv2d_fwd(const paif_conv_desc* d, int B, int H, int W, paif_stream_t 
     paif::set_error("conv2d(bf16x6): kernel %dx%d dil %d cin %d not built", d->kh, d->kh, d->dil, d->cin);
     return PAIF_ENOSUP;
   }
-  if (d->precision == PAIF_CONV_BF16X3 || d->precision == PAIF_CONV_BF16) {
+  if (d->precision == PAIF_CONV_BF16X3 || d->precision == PAIF_CONV_BF16 || d->precision == PAIF_CONV_F16 || d->precision == PAIF_CONV_F16X2) {
     switch (key) {
       case 110: return launch_bf16x3<1, 1>(a, st);
       case 310: return launch_bf16x3<3, 1>(a, st);
@@ -2040,6 +2116,25 @@ int paif_pack_conv_weight_bf16x3(const float* w, float* wpk, int cout, int nsrc,
   hipLaunchKernelGGL(pack_weight_bf16x3_kernel, dim3((total + 255) / 256), dim3(256), 0, paif::as_stream(stream), w,
                      reinterpret_cast<unsigned short*>(wpk), cout, nsrc, kh);
   PAIF_LAUNCH_CHECK("pack_conv_weight_bf16x3");
+  return 0;
+}
+
+int paif_pack_conv_weight_f16x2(const float* w, float* wpk, int cout, int nsrc, int kh, paif_stream_t stream) {
+  PAIF_REQUIRE(w && wpk, PAIF_EINVAL, "pack_conv_weight_f16x2: null pointer");
+  PAIF_REQUIRE(cout >= 1 && cout <= 32 && nsrc >= 1 && nsrc <= 3 && kh >= 1 && kh <= 7, PAIF_ENOSUP,
+               "pack_conv_weight_f16x2: cout=%d nsrc=%d kh=%d", cout, nsrc, kh);
+  const int total = nsrc * kh * kh * 2048;
+  hipLaunchKernelGGL(pack_weight_f16x2_kernel, dim3((total + 255) / 256), dim3(256), 0, paif::as_stream(stream), w,
+                     reinterpret_cast<unsigned short*>(wpk), cout, nsrc, kh);
+  PAIF_LAUNCH_CHECK("pack_conv_weight_f16x2");
+  return 0;
+}
+
+int paif_pack_decomp1x1_hf_weight_f16x2(const float* w, float* wpk, paif_stream_t stream) {
+  PAIF_REQUIRE(w && wpk, PAIF_EINVAL, "pack_decomp1x1_hf_weight_f16x2: null pointer");
+  hipLaunchKernelGGL(pack_decomp1x1_hf_f16x2_kernel, dim3(24), dim3(256), 0, paif::as_stream(stream), w,
+                     reinterpret_cast<unsigned short*>(wpk));
+  PAIF_LAUNCH_CHECK("pack_decomp1x1_hf_weight_f16x2");
   return 0;
 }
 

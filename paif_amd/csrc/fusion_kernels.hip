@@ -78,7 +78,7 @@ constexpr int STEM_GRID = PAIF_STEM_GRID;   // workgroups of a launch: 16 per CU
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                    const float* __restrict__ prelu, float* __restrict__ feat,
                                                    float* __restrict__ guide, int B, int H, int W,
-                                                   size_t img_bstride, int chunks, unsigned short* __restrict__ feat16) {
+                                                   size_t img_bstride, int chunks, unsigned short* __restrict__ feat16, int twin_f16) {
   const int q = threadIdx.x & 7;
   float wr[4][9];
 #pragma unroll
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
   __syncthreads();   // the only barrier of an item: a wave that writes buffer p again (two items later) has passed the NEXT item's barrier,
                      // which every wave reaches only after its reads of p
   float* frow = feat + (size_t)row * W * 32;
-  unsigned short* frow16 = feat16 ? feat16 + (size_t)row * W * 32 : nullptr;   // optional bf16 twin of the map (bf16 storage mode)
+  unsigned short* frow16 = feat16 ? feat16 + (size_t)row * W * 32 : nullptr;   // optional 16-bit twin of the map (bf16 / fp16 storage modes)
   float* grow = guide ? guide + (size_t)row * W : nullptr;
 #pragma unroll
   for (int it = 0; it < STEM_CHUNK / 32; ++it) {
@@ -130,7 +130,9 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
       o[c] = paif::prelu_f(s, slope);
     }
     if (x < W) paif::store_nt(frow + (size_t)x * 32 + q * 4, make_float4(o[0], o[1], o[2], o[3]));
-    if (frow16 && x < W) *reinterpret_cast<uint2*>(frow16 + (size_t)x * 32 + q * 4) = paif::f32_to_bf16x4(make_float4(o[0], o[1], o[2], o[3]));
+    if (frow16 && x < W)      // the 16-bit twin: bf16, or IEEE fp16 (launch-uniform)
+      *reinterpret_cast<uint2*>(frow16 + (size_t)x * 32 + q * 4) = twin_f16 ? paif::f32_to_f16x4(make_float4(o[0], o[1], o[2], o[3]))
+                                                                             : paif::f32_to_bf16x4(make_float4(o[0], o[1], o[2], o[3]));
     if (grow) {
       float mx = fmaxf(fmaxf(o[0], o[1]), fmaxf(o[2], o[3]));
       float mn = fminf(fminf(o[0], o[1]), fminf(o[2], o[3]));
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
 // of a 4 KB contiguous row segment per workgroup.  (The per-pixel 9-load form re-read its vertical taps from HBM: PMC traffic
 // 1.6 x the map, 153-165 us at B=8 480x640.)
 constexpr int DW_ROWS = 24, DW_COLS = 64;
-template <int DIL>
+template <int DIL, int F = 1>
 __global__ __launch_bounds__(256) void dwconv3_bf16_kernel(const unsigned short* __restrict__ x, const float* __restrict__ w,
                                                            unsigned short* __restrict__ out, int in_relu, int B, int H, int W,
                                                            int ctiles, int strips) {
@@ -260,15 +262,21 @@ __global__ __launch_bounds__(256) void dwconv3_bf16_kernel(const unsigned short*
         const unsigned u[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float lo = __uint_as_float(u[e] << 16), hi = __uint_as_float(u[e] & 0xffff0000u);
+          float lo, hi;
+          if constexpr (F == 2) {
+            const paif::f16x2_t h = __builtin_bit_cast(paif::f16x2_t, u[e]);
+            lo = (float)h[0]; hi = (float)h[1];
+          } else {
+            lo = __uint_as_float(u[e] << 16); hi = __uint_as_float(u[e] & 0xffff0000u);
+          }
           if (in_relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
           acc[2 * e] = fmaf(lo, wr[2 * e][k], acc[2 * e]);
           acc[2 * e + 1] = fmaf(hi, wr[2 * e + 1][k], acc[2 * e + 1]);
         }
       }
     if (colv) {
-      const uint2 o0 = paif::f32_to_bf16x4(make_float4(acc[0], acc[1], acc[2], acc[3]));
-      const uint2 o1 = paif::f32_to_bf16x4(make_float4(acc[4], acc[5], acc[6], acc[7]));
+      const uint2 o0 = paif::f32_to_h4<F>(make_float4(acc[0], acc[1], acc[2], acc[3]));
+      const uint2 o1 = paif::f32_to_h4<F>(make_float4(acc[4], acc[5], acc[6], acc[7]));
       typedef unsigned u32x4_nt __attribute__((ext_vector_type(4)));
       const u32x4_nt ov = {o0.x, o0.y, o1.x, o1.y};
       __builtin_nontemporal_store(ov, reinterpret_cast<u32x4_nt*>(out + (((size_t)b * H + y) * W + xx0) * 32 + q * 8));
@@ -479,16 +487,17 @@ __global__ void add_kernel(const float4* __restrict__ a, const float4* __restric
 }
 
 // elementwise add / casts on bf16-stored maps (4 elements per thread)
+template <int F>
 __global__ void add_bf16_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, size_t n4) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-    const float4 x = paif::ldq<1>(a, i * 4), y = paif::ldq<1>(b, i * 4);
-    paif::stq<1>(o, i * 4, make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w));
+    const float4 x = paif::ldq<F>(a, i * 4), y = paif::ldq<F>(b, i * 4);
+    paif::stq<F>(o, i * 4, make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w));
   }
 }
-template <int TO_BF>
+template <int FI, int FO>     // storage formats in / out (0 fp32, 1 bf16, 2 fp16)
 __global__ void cast_storage_kernel(const float* __restrict__ a, float* __restrict__ o, size_t n4) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
-    paif::stq_nt<TO_BF>(o, i * 4, paif::ldq_nt<1 - TO_BF>(a, i * 4));
+    paif::stq_nt<FO>(o, i * 4, paif::ldq_nt<FI>(a, i * 4));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -639,26 +648,32 @@ int paif_ycrcb2rgb_fwd(const float* ycc, float* rgb, int B, int H, int W, paif_s
 }
 
 static int stem_launch(const float* img, size_t img_bstride, const float* w, const float* prelu, float* feat, float* guide,
-                       unsigned short* feat16, int B, int H, int W, paif_stream_t stream) {
+                       unsigned short* feat16, int twin_f16, int B, int H, int W, paif_stream_t stream) {
   PAIF_REQUIRE(img && w && prelu && feat && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "stem: bad arguments");
   PAIF_REQUIRE(img_bstride >= (size_t)H * W, PAIF_EINVAL, "stem: batch stride %zu < H*W", img_bstride);
   const int chunks = (W + STEM_CHUNK - 1) / STEM_CHUNK;
   PAIF_REQUIRE((size_t)B * H * chunks < ((size_t)1 << 31), PAIF_EINVAL, "stem: %dx%dx%d is too large for one launch", B, H, W);
   hipLaunchKernelGGL(stem_kernel, dim3((unsigned)min(B * H * chunks, STEM_GRID)), dim3(256), 0, paif::as_stream(stream), img, w,
-                     prelu, feat, guide, B, H, W, img_bstride, chunks, feat16);
+                     prelu, feat, guide, B, H, W, img_bstride, chunks, feat16, twin_f16);
   PAIF_LAUNCH_CHECK("stem");
   return 0;
 }
 
 int paif_stem_fwd(const float* img, size_t img_bstride, const float* w, const float* prelu, float* feat, float* guide,
                   int B, int H, int W, paif_stream_t stream) {
-  return stem_launch(img, img_bstride, w, prelu, feat, guide, nullptr, B, H, W, stream);
+  return stem_launch(img, img_bstride, w, prelu, feat, guide, nullptr, 0, B, H, W, stream);
 }
 
 int paif_stem_fwd_twin(const float* img, size_t img_bstride, const float* w, const float* prelu, float* feat, float* feat_bf16,
                        float* guide, int B, int H, int W, paif_stream_t stream) {
   PAIF_REQUIRE(feat_bf16, PAIF_EINVAL, "stem_twin: null bf16 map");
-  return stem_launch(img, img_bstride, w, prelu, feat, guide, reinterpret_cast<unsigned short*>(feat_bf16), B, H, W, stream);
+  return stem_launch(img, img_bstride, w, prelu, feat, guide, reinterpret_cast<unsigned short*>(feat_bf16), 0, B, H, W, stream);
+}
+
+int paif_stem_fwd_twin_f16(const float* img, size_t img_bstride, const float* w, const float* prelu, float* feat, float* feat_f16,
+                           float* guide, int B, int H, int W, paif_stream_t stream) {
+  PAIF_REQUIRE(feat_f16, PAIF_EINVAL, "stem_twin: null fp16 map");
+  return stem_launch(img, img_bstride, w, prelu, feat, guide, reinterpret_cast<unsigned short*>(feat_f16), 1, B, H, W, stream);
 }
 
 int paif_dwconv_fwd(const float* x, const float* w, float* out, int k, int dil, int in_relu, int B, int H, int W,
@@ -745,10 +760,16 @@ int paif_add_fwd(const float* a, const float* b, float* out, size_t n, paif_stre
   return 0;
 }
 
-// ---- bf16-stored activation maps (BASELINE configs[1] "bf16"; include/paif_hip.h PAIF_ST_BF16): the same kernels with 8-byte
-// loads / round-to-nearest-even stores; fp32 arithmetic.  x / out / ir / vis / agg / o / r are bf16 data behind the float* ----
-int paif_dwconv_fwd_bf16(const float* x, const float* w, float* out, int k, int dil, int in_relu, int B, int H, int W, paif_stream_t stream) {
-  PAIF_REQUIRE(x && w && out && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "dwconv(bf16): bad arguments");
+// ---- 16-bit-stored activation maps (bf16: BASELINE configs[1], PAIF_ST_BF16; fp16: PAIF_ST_F16, round 5): the same kernels with
+// 8-byte loads / round-to-nearest-even stores; fp32 arithmetic.  x / out / ir / vis / agg / o / r are 16-bit data behind the float*.
+// One implementation per kernel, templated on the format F (1 bf16, 2 fp16); the extern "C" twins follow. ----
+}  // extern "C"
+
+namespace {
+
+template <int F>
+int dwconv16(const float* x, const float* w, float* out, int k, int dil, int in_relu, int B, int H, int W, paif_stream_t stream) {
+  PAIF_REQUIRE(x && w && out && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "dwconv(16-bit): bad arguments");
   const dim3 g(grid_for((size_t)B * H * W, 32)), blk(256);
   hipStream_t st = paif::as_stream(stream);
   const int ctiles = (W + DW_COLS - 1) / DW_COLS, strips = (H + DW_ROWS - 1) / DW_ROWS;
@@ -756,68 +777,121 @@ int paif_dwconv_fwd_bf16(const float* x, const float* w, float* out, int k, int 
   const unsigned short* x16 = reinterpret_cast<const unsigned short*>(x);
   unsigned short* o16 = reinterpret_cast<unsigned short*>(out);
   switch (k * 10 + dil) {
-    case 31: hipLaunchKernelGGL((dwconv3_bf16_kernel<1>), g8, blk, 0, st, x16, w, o16, in_relu, B, H, W, ctiles, strips); break;
-    case 32: hipLaunchKernelGGL((dwconv3_bf16_kernel<2>), g8, blk, 0, st, x16, w, o16, in_relu, B, H, W, ctiles, strips); break;
-    case 51: hipLaunchKernelGGL((dwconv_kernel<5, 1, 1>), g, blk, 0, st, x, w, out, in_relu, B, H, W); break;
+    case 31: hipLaunchKernelGGL((dwconv3_bf16_kernel<1, F>), g8, blk, 0, st, x16, w, o16, in_relu, B, H, W, ctiles, strips); break;
+    case 32: hipLaunchKernelGGL((dwconv3_bf16_kernel<2, F>), g8, blk, 0, st, x16, w, o16, in_relu, B, H, W, ctiles, strips); break;
+    case 51: hipLaunchKernelGGL((dwconv_kernel<5, 1, F>), g, blk, 0, st, x, w, out, in_relu, B, H, W); break;
     default:
-      paif::set_error("dwconv(bf16): kernel %d dil %d not built", k, dil);
+      paif::set_error("dwconv(16-bit): kernel %d dil %d not built", k, dil);
       return PAIF_ENOSUP;
   }
-  PAIF_LAUNCH_CHECK("dwconv(bf16)");
+  PAIF_LAUNCH_CHECK("dwconv(16-bit)");
   return 0;
 }
 
-int paif_channel_pool2_fwd_bf16(const float* ir, const float* vis, float* comp, int B, int H, int W, paif_stream_t stream) {
-  PAIF_REQUIRE(ir && vis && comp && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "channel_pool2(bf16): bad arguments");
+template <int F>
+int channel_pool2_16(const float* ir, const float* vis, float* comp, int B, int H, int W, paif_stream_t stream) {
+  PAIF_REQUIRE(ir && vis && comp && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "channel_pool2(16-bit): bad arguments");
   const size_t npix = (size_t)B * H * W;
-  hipLaunchKernelGGL(channel_pool2_kernel<1>, dim3(grid_for(npix, 32)), dim3(256), 0, paif::as_stream(stream), ir, vis, comp, npix);
-  PAIF_LAUNCH_CHECK("channel_pool2(bf16)");
+  hipLaunchKernelGGL(channel_pool2_kernel<F>, dim3(grid_for(npix, 32)), dim3(256), 0, paif::as_stream(stream), ir, vis, comp, npix);
+  PAIF_LAUNCH_CHECK("channel_pool2(16-bit)");
   return 0;
 }
 
-int paif_spa_blend_fwd_bf16(const float* comp, const float* w, const float* ir, const float* vis, float* agg, int B, int H, int W,
-                            paif_stream_t stream) {
-  PAIF_REQUIRE(comp && w && ir && vis && agg && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "spa_blend(bf16): bad arguments");
-  hipLaunchKernelGGL(spa_blend_kernel<1>, dim3(grid_for((size_t)B * H * W, 32)), dim3(256), 0, paif::as_stream(stream), comp, w, ir, vis, agg,
+template <int F>
+int spa_blend16(const float* comp, const float* w, const float* ir, const float* vis, float* agg, int B, int H, int W, paif_stream_t stream) {
+  PAIF_REQUIRE(comp && w && ir && vis && agg && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "spa_blend(16-bit): bad arguments");
+  hipLaunchKernelGGL(spa_blend_kernel<F>, dim3(grid_for((size_t)B * H * W, 32)), dim3(256), 0, paif::as_stream(stream), comp, w, ir, vis, agg,
                      (float*)nullptr, B, H, W);
-  PAIF_LAUNCH_CHECK("spa_blend(bf16)");
+  PAIF_LAUNCH_CHECK("spa_blend(16-bit)");
   return 0;
 }
 
-int paif_eca_finish_fwd_bf16(const float* o, const float* r, const float* pool_partial, const float* w1d, int k, const float* prelu,
-                             float* gate, float* out, int B, int H, int W, paif_stream_t stream) {
-  PAIF_REQUIRE(o && r && pool_partial && w1d && prelu && gate && out && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "eca_finish(bf16): bad arguments");
+template <int F>
+int eca_finish16(const float* o, const float* r, const float* pool_partial, const float* w1d, int k, const float* prelu, float* gate,
+                 float* out, int B, int H, int W, paif_stream_t stream) {
+  PAIF_REQUIRE(o && r && pool_partial && w1d && prelu && gate && out && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "eca_finish(16-bit): bad arguments");
   PAIF_REQUIRE(k >= 1 && k <= 9 && (k & 1), PAIF_ENOSUP, "eca_finish: k=%d", k);
   hipStream_t st = paif::as_stream(stream);
   hipLaunchKernelGGL(eca_scale_kernel, dim3(B), dim3(1024), 0, st, pool_partial, w1d, k, paif_conv2d_blocks(1, H, W), 1.0f / ((float)H * (float)W), gate);
   PAIF_LAUNCH_CHECK("eca_scale");
   const size_t npix = (size_t)B * H * W;
-  hipLaunchKernelGGL(eca_apply_kernel<1>, dim3(grid_for(npix, 32)), dim3(256), 0, st, o, r, gate, prelu, out, (float*)nullptr, (size_t)H * W, npix);
-  PAIF_LAUNCH_CHECK("eca_apply(bf16)");
+  hipLaunchKernelGGL(eca_apply_kernel<F>, dim3(grid_for(npix, 32)), dim3(256), 0, st, o, r, gate, prelu, out, (float*)nullptr, (size_t)H * W, npix);
+  PAIF_LAUNCH_CHECK("eca_apply(16-bit)");
   return 0;
 }
 
-int paif_tail_fwd_bf16(const float* x, const float* w, const float* prelu, float* fused, int B, int H, int W, paif_stream_t stream) {
-  PAIF_REQUIRE(x && w && prelu && fused && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "tail(bf16): bad arguments");
-  hipLaunchKernelGGL(tail_kernel<1>, dim3(grid_for((size_t)B * H * W, 64)), dim3(256), 0, paif::as_stream(stream), x, w, prelu, fused,
+template <int F>
+int tail16(const float* x, const float* w, const float* prelu, float* fused, int B, int H, int W, paif_stream_t stream) {
+  PAIF_REQUIRE(x && w && prelu && fused && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "tail(16-bit): bad arguments");
+  hipLaunchKernelGGL(tail_kernel<F>, dim3(grid_for((size_t)B * H * W, 64)), dim3(256), 0, paif::as_stream(stream), x, w, prelu, fused,
                      (float*)nullptr, B, H, W);
-  PAIF_LAUNCH_CHECK("tail(bf16)");
+  PAIF_LAUNCH_CHECK("tail(16-bit)");
   return 0;
 }
 
-int paif_add_fwd_bf16(const float* a, const float* b, float* out, size_t n, paif_stream_t stream) {
-  PAIF_REQUIRE(a && b && out && n % 4 == 0, PAIF_EINVAL, "add(bf16): null pointer or n %% 4 != 0");
+template <int F>
+int add16(const float* a, const float* b, float* out, size_t n, paif_stream_t stream) {
+  PAIF_REQUIRE(a && b && out && n % 4 == 0, PAIF_EINVAL, "add(16-bit): null pointer or n %% 4 != 0");
   if (n == 0) return 0;
-  hipLaunchKernelGGL(add_bf16_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, paif::as_stream(stream), a, b, out, n / 4);
-  PAIF_LAUNCH_CHECK("add(bf16)");
+  hipLaunchKernelGGL(add_bf16_kernel<F>, dim3(grid_for(n / 4, 256)), dim3(256), 0, paif::as_stream(stream), a, b, out, n / 4);
+  PAIF_LAUNCH_CHECK("add(16-bit)");
   return 0;
 }
 
-int paif_cast_storage_fwd(const float* src, float* dst, size_t n, int to_bf16, paif_stream_t stream) {
+}  // namespace
+
+extern "C" {
+
+int paif_dwconv_fwd_bf16(const float* x, const float* w, float* out, int k, int dil, int in_relu, int B, int H, int W, paif_stream_t stream) {
+  return dwconv16<1>(x, w, out, k, dil, in_relu, B, H, W, stream);
+}
+int paif_dwconv_fwd_f16(const float* x, const float* w, float* out, int k, int dil, int in_relu, int B, int H, int W, paif_stream_t stream) {
+  return dwconv16<2>(x, w, out, k, dil, in_relu, B, H, W, stream);
+}
+int paif_channel_pool2_fwd_bf16(const float* ir, const float* vis, float* comp, int B, int H, int W, paif_stream_t stream) {
+  return channel_pool2_16<1>(ir, vis, comp, B, H, W, stream);
+}
+int paif_channel_pool2_fwd_f16(const float* ir, const float* vis, float* comp, int B, int H, int W, paif_stream_t stream) {
+  return channel_pool2_16<2>(ir, vis, comp, B, H, W, stream);
+}
+int paif_spa_blend_fwd_bf16(const float* comp, const float* w, const float* ir, const float* vis, float* agg, int B, int H, int W,
+                            paif_stream_t stream) {
+  return spa_blend16<1>(comp, w, ir, vis, agg, B, H, W, stream);
+}
+int paif_spa_blend_fwd_f16(const float* comp, const float* w, const float* ir, const float* vis, float* agg, int B, int H, int W,
+                           paif_stream_t stream) {
+  return spa_blend16<2>(comp, w, ir, vis, agg, B, H, W, stream);
+}
+int paif_eca_finish_fwd_bf16(const float* o, const float* r, const float* pool_partial, const float* w1d, int k, const float* prelu,
+                             float* gate, float* out, int B, int H, int W, paif_stream_t stream) {
+  return eca_finish16<1>(o, r, pool_partial, w1d, k, prelu, gate, out, B, H, W, stream);
+}
+int paif_eca_finish_fwd_f16(const float* o, const float* r, const float* pool_partial, const float* w1d, int k, const float* prelu,
+                            float* gate, float* out, int B, int H, int W, paif_stream_t stream) {
+  return eca_finish16<2>(o, r, pool_partial, w1d, k, prelu, gate, out, B, H, W, stream);
+}
+int paif_tail_fwd_bf16(const float* x, const float* w, const float* prelu, float* fused, int B, int H, int W, paif_stream_t stream) {
+  return tail16<1>(x, w, prelu, fused, B, H, W, stream);
+}
+int paif_tail_fwd_f16(const float* x, const float* w, const float* prelu, float* fused, int B, int H, int W, paif_stream_t stream) {
+  return tail16<2>(x, w, prelu, fused, B, H, W, stream);
+}
+int paif_add_fwd_bf16(const float* a, const float* b, float* out, size_t n, paif_stream_t stream) { return add16<1>(a, b, out, n, stream); }
+int paif_add_fwd_f16(const float* a, const float* b, float* out, size_t n, paif_stream_t stream) { return add16<2>(a, b, out, n, stream); }
+
+/* mode: 0 bf16 -> fp32, 1 fp32 -> bf16, 2 fp32 -> fp16, 3 fp16 -> fp32 (round to nearest even on the way down) */
+int paif_cast_storage_fwd(const float* src, float* dst, size_t n, int mode, paif_stream_t stream) {
   PAIF_REQUIRE(src && dst && n % 4 == 0, PAIF_EINVAL, "cast_storage: null pointer or n %% 4 != 0");
+  PAIF_REQUIRE(mode >= 0 && mode <= 3, PAIF_EINVAL, "cast_storage: mode=%d", mode);
   if (n == 0) return 0;
-  if (to_bf16) hipLaunchKernelGGL(cast_storage_kernel<1>, dim3(grid_for(n / 4, 256)), dim3(256), 0, paif::as_stream(stream), src, dst, n / 4);
-  else hipLaunchKernelGGL(cast_storage_kernel<0>, dim3(grid_for(n / 4, 256)), dim3(256), 0, paif::as_stream(stream), src, dst, n / 4);
+  const dim3 g(grid_for(n / 4, 256)), blk(256);
+  hipStream_t st = paif::as_stream(stream);
+  switch (mode) {
+    case 0: hipLaunchKernelGGL((cast_storage_kernel<1, 0>), g, blk, 0, st, src, dst, n / 4); break;
+    case 1: hipLaunchKernelGGL((cast_storage_kernel<0, 1>), g, blk, 0, st, src, dst, n / 4); break;
+    case 2: hipLaunchKernelGGL((cast_storage_kernel<0, 2>), g, blk, 0, st, src, dst, n / 4); break;
+    default: hipLaunchKernelGGL((cast_storage_kernel<2, 0>), g, blk, 0, st, src, dst, n / 4); break;
+  }
   PAIF_LAUNCH_CHECK("cast_storage");
   return 0;
 }

@@ -117,9 +117,12 @@ __device__ __forceinline__ f32x2 ring_push(Ring& rg, f32x2 x) {
 
 // One run of rows of the strip list (see WORK DISTRIBUTION below) and one 16-channel half per workgroup of 8 waves.
 //   planes: [3][B*H*W] = mean_g, 1/(var_g + eps0), 1/(var_g + eps1)   (gf_guide_stats_kernel; its fourth plane, 1/n, is not read)
-// BFO: the two maps are written as bf16 (round to nearest even); lanes c and c ^ 1 exchange one column by a DPP quad permute and
-// store channel PAIRS as dwords (one store per eps and row).
-template <bool BFO>
+// OM (output mode): 0 = the two low-frequency maps as fp32; 1 = as bf16 (round to nearest even): lanes c and c ^ 1 exchange one column
+// by a DPP quad permute and store channel PAIRS as dwords (one store per eps and row); 2 (round 5, the fp16 configuration) = the two
+// HIGH-frequency maps HF_e = y - LF_e as IEEE fp16, same store path: |HF| << |LF| ~ |y|, so the fp16 rounding of what the folded 1x1
+// behind this block reads is ~8x smaller (core/model_fusion_auto.py:531-532 forms x - LF anyway).  y(r - 9) comes from an in-lane delay
+// line (a 6-deep and a 3-deep ring, both statically indexed by the unrolled step: 18 registers, 4 moves per row).
+template <int OM>
 __global__ __launch_bounds__(64 * NW, NW / 4) void gf2_kernel(const float* __restrict__ guide, const float* __restrict__ y,
                                                      const float* __restrict__ planes, float* __restrict__ lf,
                                                      unsigned* __restrict__ flag, int B, int H, int W, int nstrip, int nslots,
@@ -171,6 +174,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gf2_kernel(const float* __res
     rnx[i] = cin[i] ? 1.0f / (float)(min(cc + R, W - 1) - max(cc - R, 0) + 1) : 0.f;
   }
   const bool outcol = lc0 >= 2 * R && lc0 < SC - 2 * R;          // the strip's 48 output columns
+  constexpr bool BFO = OM != 0;                                    // 16-bit output (bf16 LF or fp16 HF)
   const bool odd = (c & 1) != 0;                                   // BFO: even lanes store column 0, odd lanes column 1 of the channel pair
   const u32x2 a_own = band_operand(l & 15, 2 * (l >> 4));
   const u32x2 a_halo = band_operand(l & 15, (l >> 4) < 2 ? -4 + 2 * (l >> 4) : 8 + 2 * ((l >> 4) - 2));
@@ -216,6 +220,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gf2_kernel(const float* __res
   for (int k = 0; k < PF; ++k) { ry.p[k] = zero2; rgy.p[k] = zero2; rA0.p[k] = zero2; rB0.p[k] = zero2; rA1.p[k] = zero2; rB1.p[k] = zero2; }
   ry.a1 = ry.a2 = rgy.a1 = rgy.a2 = rA0.a1 = rA0.a2 = rB0.a1 = rB0.a2 = rA1.a1 = rA1.a2 = rB1.a1 = rB1.a2 = zero2;
   f32x2 wA0 = zero2, wB0 = zero2, wA1 = zero2, wB1 = zero2;           // vertical (A, b) window sums of the previous iteration
+  f32x2 yd6[OM == 2 ? PF : 1], yd3[OM == 2 ? 3 : 1];                    // OM 2: y delayed by 6 and by 6 + 3 iterations (the output row's y)
+#pragma unroll
+  for (int k = 0; k < (OM == 2 ? PF : 1); ++k) yd6[k] = zero2;
+#pragma unroll
+  for (int k = 0; k < (OM == 2 ? 3 : 1); ++k) yd3[k] = zero2;
 
   // running offsets (wrapping 32-bit arithmetic on purpose)
   constexpr unsigned NEVER = 0x80000000u;                // + any row offset of the image stays out of range
@@ -303,6 +312,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gf2_kernel(const float* __res
     const int it = itb + k;
     GF2_ST(0);
     const f32x2 yy = {py0[slot], py1[slot] * m1};        // zero outside the image (range-checked loads)
+    f32x2 y9 = yy;
+    if constexpr (OM == 2) {                              // y of the row stage 2 outputs in this iteration (r - 9)
+      const f32x2 y6 = yd6[k];
+      yd6[k] = yy;
+      y9 = yd3[k % 3];
+      yd3[k % 3] = y6;
+    }
     const f32x2 gv = *reinterpret_cast<const f32x2*>(&pbuf[par][0][lc0]), mg1 = *reinterpret_cast<const f32x2*>(&pbuf[par][1][lc0]);
     const f32x2 rd0 = *reinterpret_cast<const f32x2*>(&pbuf[par][2][lc0]), rd1 = *reinterpret_cast<const f32x2*>(&pbuf[par][3][lc0]);
     const f32x2 g2 = *reinterpret_cast<const f32x2*>(&pbuf[par][4][lc0]);
@@ -347,13 +363,17 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gf2_kernel(const float* __res
       const f32x2 out1 = (s_a1 * g2 + s_b1) * rn2;
 #ifndef GF2_NOSTORE    // (diagnostic build without the stores: -DGF2_NOSTORE)
       if constexpr (BFO) {
-        auto pair_store = [&](const f32x2& ov, const __amdgpu_buffer_rsrc_t& rs) {
+        auto pair_store = [&](const f32x2& lfv, const __amdgpu_buffer_rsrc_t& rs) {
           typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+          const f32x2 ov = OM == 2 ? y9 - lfv : lfv;     // OM 2: the high-frequency map
           // even lane keeps its column 0 and takes the partner's (channel c + 1) column 0; odd lane its column 1 and the partner's
           const float give = odd ? ov[0] : ov[1];        // what the partner needs from me: my value of ITS column
           const float got = __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(give), 0xB1, 0xF, 0xF, true));
           const f32x2 v = {odd ? got : ov[0], odd ? ov[1] : got};     // (channel c & ~1, channel c | 1) of the lane's stored column
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t)), rs, vo0, 0, 2);
+          unsigned bits;
+          if constexpr (OM == 2) bits = __builtin_bit_cast(unsigned, __builtin_convertvector(v, paif::f16x2_t));
+          else bits = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+          __builtin_amdgcn_raw_buffer_store_b32(bits, rs, vo0, 0, 2);
         };
         pair_store(out0, ro0);
         pair_store(out1, ro1);
@@ -409,7 +429,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gf2_kernel(const float* __res
   if (l == 0 && !(vmax < 65000.f)) atomicOr(flag, 1u);
 }
 
-template __global__ void gf2_kernel<false>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
-template __global__ void gf2_kernel<true>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
+template __global__ void gf2_kernel<0>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
+template __global__ void gf2_kernel<1>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
+template __global__ void gf2_kernel<2>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
 
 }  // namespace paif_gf2

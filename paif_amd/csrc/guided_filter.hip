@@ -318,7 +318,7 @@ __global__ __launch_bounds__(FC * NL) void gf_fused_kernel(const float* __restri
                                                            const float* __restrict__ gs, const unsigned* __restrict__ only_if, float* __restrict__ lf,
                                                            int B, int H, int W, int nstrip, int nseg, int frows, int out_bf16) {
   constexpr int VW = VecOps<V>::VW;
-  unsigned short* const lf16 = reinterpret_cast<unsigned short*>(lf);   // out_bf16: the same element indices in a bf16 buffer
+  unsigned short* const lf16 = reinterpret_cast<unsigned short*>(lf);   // out_bf16 (1 bf16 LF, 2 fp16 HF = y - LF): the same element indices in a 16-bit buffer
   if (only_if != nullptr && *only_if == 0u) return;      // fallback launch behind the matrix-core kernel: runs only when it raised the flag
   __shared__ V s_a[2][FC][NL];
   __shared__ V s_b[2][FC][NL];
@@ -458,7 +458,12 @@ __global__ __launch_bounds__(FC * NL) void gf_fused_kernel(const float* __restri
         const float* pb = reinterpret_cast<const float*>(&bb);
 #pragma unroll
         for (int i = 0; i < VW; ++i) po[i] = fmaf(pa[i] * rn, g0, pb[i] * rn);
-        if (out_bf16) {   // launch-uniform
+        if (out_bf16 == 2) {   // launch-uniform: the fp16 configuration's high-frequency map (y re-read: this is the rare fallback path)
+          const V yv = *reinterpret_cast<const V*>(y + px * 32);
+          const float* py_ = reinterpret_cast<const float*>(&yv);
+#pragma unroll
+          for (int i = 0; i < VW; ++i) out16[px * 32 + i] = __builtin_bit_cast(unsigned short, (_Float16)(py_[i] - po[i]));
+        } else if (out_bf16) {
 #pragma unroll
           for (int i = 0; i < VW; ++i) out16[px * 32 + i] = __builtin_bit_cast(unsigned short, (__bf16)po[i]);
         } else {
@@ -483,11 +488,12 @@ extern template __global__ void gf_mfma_kernel<false, true>(const float*, const 
 }
 
 namespace paif_gf2 {
-template <bool BFO>
+template <int OM>
 __global__ void gf2_kernel(const float* __restrict__ guide, const float* __restrict__ y, const float* __restrict__ planes, float* __restrict__ lf,
                            unsigned* __restrict__ flag, int B, int H, int W, int nstrip, int nslots, int rows_per_slot, int total_rows);
-extern template __global__ void gf2_kernel<false>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
-extern template __global__ void gf2_kernel<true>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
+extern template __global__ void gf2_kernel<0>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
+extern template __global__ void gf2_kernel<1>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
+extern template __global__ void gf2_kernel<2>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
 }
 
 // workspace: four per-pixel planes + one 256-byte line holding the f16-range flag
@@ -505,7 +511,8 @@ static int gf_fused_launch(const float* guide, const float* y, float* lf, float 
   int engine = (eng && !strcmp(eng, "valu")) ? 0 : (eng && !strcmp(eng, "mfma")) ? 1 : 2;
   // the round-4 engine addresses rows with wrapping 32-bit per-lane offsets that the buffer range check filters: every per-image
   // byte size must stay below 2^31 - 2^20
-  if (engine == 2 && ((size_t)(B + 1) * H * W * 128 >= 0x7FF00000ull || (size_t)B * nstrip * H >= 0x7FFFFFFFull)) engine = 1;
+  if (engine == 2 && ((size_t)(B + 1) * H * W * 128 >= 0x7FF00000ull || (size_t)B * nstrip * H >= 0x7FFFFFFFull)) engine = out_bf16 == 2 ? 0 : 1;
+  if (out_bf16 == 2 && engine == 1) engine = 2;     // the fp16 high-frequency output is built for the round-4 engine and the VALU kernel
   static const int form = [] {
     const char* e = getenv("PAIF_GF_FORM");
     if (!e) return 0;
@@ -544,11 +551,14 @@ static int gf_fused_launch(const float* guide, const float* y, float* lf, float 
     nslots = nslots < 1 ? 1 : (nslots > cus / 2 ? cus / 2 : nslots);
     const int rows_per_slot = (int)((total_rows + nslots - 1) / nslots);
     const int grid = (nslots + 7) / 8 * 16;
-    if (out_bf16)
-      hipLaunchKernelGGL((paif_gf2::gf2_kernel<true>), dim3(grid), dim3(512), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip, nslots,
+    if (out_bf16 == 2)
+      hipLaunchKernelGGL((paif_gf2::gf2_kernel<2>), dim3(grid), dim3(512), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip, nslots,
+                         rows_per_slot, (int)total_rows);
+    else if (out_bf16)
+      hipLaunchKernelGGL((paif_gf2::gf2_kernel<1>), dim3(grid), dim3(512), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip, nslots,
                          rows_per_slot, (int)total_rows);
     else
-      hipLaunchKernelGGL((paif_gf2::gf2_kernel<false>), dim3(grid), dim3(512), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip, nslots,
+      hipLaunchKernelGGL((paif_gf2::gf2_kernel<0>), dim3(grid), dim3(512), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip, nslots,
                          rows_per_slot, (int)total_rows);
     PAIF_LAUNCH_CHECK("guided_filter_fused(mfma2)");
   }
@@ -597,6 +607,12 @@ static int gf_fused_launch(const float* guide, const float* y, float* lf, float 
 extern "C" int paif_guided_filter_fused_fwd(const float* guide, const float* y, float* lf, float eps0, float eps1, float* workspace, int B,
                                             int H, int W, paif_stream_t stream) {
   return gf_fused_launch(guide, y, lf, eps0, eps1, workspace, B, H, W, 0, stream);
+}
+
+// the fp16 configuration (round 5): the two HIGH-frequency maps HF_e = y - LF_e written as IEEE fp16 (`hf`: [2][B,H,W,32] unsigned short data)
+extern "C" int paif_guided_filter_fused_fwd_hf16(const float* guide, const float* y, float* hf, float eps0, float eps1, float* workspace, int B,
+                                                 int H, int W, paif_stream_t stream) {
+  return gf_fused_launch(guide, y, hf, eps0, eps1, workspace, B, H, W, 2, stream);
 }
 
 // same, the two low-frequency maps written as bf16 (`lf`: [2][B,H,W,32] unsigned short data): the bf16 configuration

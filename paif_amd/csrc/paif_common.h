@@ -110,15 +110,22 @@ __device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + __ex
 // ---------------------------------------------------------------------------------------------
 // Kernel storage codes (template argument ST): 0 fp32 in / out | 1 bf16 in / out | 2 fp32 in, bf16 out | 3 (internal) bf16 in / out
 // behind an input PReLU.  +3 (4, 5, 6): the same with the WEIGHTS taken as plain bf16 (their split-bf16 low half dropped:
-// precision PAIF_CONV_BF16, the plain bf16 MFMA of BASELINE configs[1]).
-constexpr int st_base(int ST) { return ST >= 4 ? ST - 3 : ST; }
-constexpr int st_in(int ST) { return (st_base(ST) == 1 || st_base(ST) == 3) ? 1 : 0; }
-constexpr int st_out(int ST) { return ST >= 1 ? 1 : 0; }
-constexpr bool st_wl0(int ST) { return ST >= 4; }
-// ST 1 / 4: the staged A operand IS the stored bf16 value (no input activation, or ReLU), so its split-bf16 low half is exactly
+// precision PAIF_CONV_BF16, the plain bf16 MFMA of BASELINE configs[1]).  7: 16-bit in (residual maps too), fp32 OUT, plain weights
+// (the last conv of the 16-bit forward: its map feeds the fp32-input stem_out kernel).
+// +8 (9, 12, 13, 14, 15): the same codes with the 16-bit format being IEEE fp16 instead of bf16 (round 5: PAIF_ST_F16*; the MFMA is
+// v_mfma_f32_32x32x16_f16, the weight pack holds fp16 hi | lo pieces).  Format values of the helpers below: 0 fp32, 1 bf16, 2 fp16.
+constexpr bool st_f16(int ST) { return ST >= 8; }
+constexpr int st_low(int ST) { return ST & 7; }
+constexpr int st_base(int ST) { return st_low(ST) == 7 ? 1 : (st_low(ST) >= 4 ? st_low(ST) - 3 : st_low(ST)); }
+constexpr int st_fmt16(int ST) { return st_f16(ST) ? 2 : 1; }
+constexpr int st_in(int ST) { return (st_base(ST) == 1 || st_base(ST) == 3) ? st_fmt16(ST) : 0; }
+constexpr int st_out(int ST) { return (st_low(ST) >= 1 && st_low(ST) != 7) ? st_fmt16(ST) : 0; }
+constexpr int st_res(int ST) { return st_low(ST) == 7 ? st_fmt16(ST) : st_out(ST); }   // storage of the residual maps
+constexpr bool st_wl0(int ST) { return st_low(ST) >= 4; }
+// ST 1 / 4 / 7: the staged A operand IS the stored 16-bit value (no input activation, or ReLU), so its split low half is exactly
 // zero: the kernels drop the lo x W_hi MFMA and the low half's LDS traffic.  ST 3: bf16 in / out with an input PReLU, whose result
-// is not a bf16 value -- the full split is kept; ST 6 (plain bf16 arithmetic) rounds that result to bf16 (nearest-even) instead.
-constexpr bool st_lo0(int ST) { return ST == 1 || ST == 4 || ST == 6; }
+// is not a bf16 value -- the full split is kept; ST 6 (plain 16-bit arithmetic) rounds that result to the format (nearest-even) instead.
+constexpr bool st_lo0(int ST) { return st_f16(ST) || st_low(ST) == 1 || st_low(ST) == 4 || st_low(ST) == 6 || st_low(ST) == 7; }   // fp16 operands are never split
 
 __device__ __forceinline__ float4 bf16x4_to_f32(uint2 u) {
   return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
@@ -131,32 +138,73 @@ __device__ __forceinline__ uint2 f32_to_bf16x4(float4 v) {
   return make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16x2_t)),
                     __builtin_bit_cast(unsigned, __builtin_convertvector(b, bf16x2_t)));
 }
+// fp16 (IEEE half) twins of the two conversions: v_cvt_f32_f16 / v_cvt_pk_f16_f32 (round to nearest even)
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4v_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 f16x4_to_f32(uint2 u) {
+  const f32x4v_t v = __builtin_convertvector(__builtin_bit_cast(f16x4_t, u), f32x4v_t);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint2 f32_to_f16x4(float4 v) {
+  const f32x4v_t a = {v.x, v.y, v.z, v.w};
+  return __builtin_bit_cast(uint2, __builtin_convertvector(a, f16x4_t));
+}
+// 16-bit quad <-> fp32 quad in format F (1 bf16, 2 fp16)
+template <int F> __device__ __forceinline__ float4 h4_to_f32(uint2 u) {
+  if constexpr (F == 2) return f16x4_to_f32(u);
+  else return bf16x4_to_f32(u);
+}
+template <int F> __device__ __forceinline__ uint2 f32_to_h4(float4 v) {
+  if constexpr (F == 2) return f32_to_f16x4(v);
+  else return f32_to_bf16x4(v);
+}
+// max(x, 0) on a packed pair of 16-bit values (the ReLU of a stored map, no conversion)
+template <int F> __device__ __forceinline__ unsigned relu_h2(unsigned u) {
+  if constexpr (F == 2) {
+    const f16x2_t z = {(_Float16)0, (_Float16)0};
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(f16x2_t, u), z));
+  } else {   // bf16: the sign bit of each half decides
+    return u & ~((((u >> 15) & 0x00010001u) * 0xffffu));
+  }
+}
+
 template <int BF> __device__ __forceinline__ float4 ldq(const float* base, size_t eoff) {
-  if constexpr (BF) return bf16x4_to_f32(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + eoff));
+  if constexpr (BF) return h4_to_f32<BF>(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + eoff));
   else return *reinterpret_cast<const float4*>(base + eoff);
 }
 template <int BF> __device__ __forceinline__ float4 ldq_nt(const float* base, size_t eoff) {
   if constexpr (BF) {
     typedef unsigned u32x2_nt __attribute__((ext_vector_type(2)));
     const u32x2_nt v = __builtin_nontemporal_load(reinterpret_cast<const u32x2_nt*>(reinterpret_cast<const unsigned short*>(base) + eoff));
-    return bf16x4_to_f32(make_uint2(v.x, v.y));
+    return h4_to_f32<BF>(make_uint2(v.x, v.y));
   } else {
     return load_nt(base + eoff);
   }
 }
 template <int BF> __device__ __forceinline__ void stq(float* base, size_t eoff, float4 v) {
-  if constexpr (BF) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + eoff) = f32_to_bf16x4(v);
+  if constexpr (BF) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + eoff) = f32_to_h4<BF>(v);
   else *reinterpret_cast<float4*>(base + eoff) = v;
 }
 template <int BF> __device__ __forceinline__ void stq_nt(float* base, size_t eoff, float4 v) {
   if constexpr (BF) {
     typedef unsigned u32x2_nt __attribute__((ext_vector_type(2)));
-    const uint2 u = f32_to_bf16x4(v);
+    const uint2 u = f32_to_h4<BF>(v);
     const u32x2_nt vv = {u.x, u.y};
     __builtin_nontemporal_store(vv, reinterpret_cast<u32x2_nt*>(reinterpret_cast<unsigned short*>(base) + eoff));
   } else {
     store_nt(base + eoff, v);
   }
+}
+
+// One 32x32x16 MFMA on 16-bit operands in format F (1 bf16, 2 fp16); operands travel as 8 packed 16-bit values (uint4 bits)
+typedef float mf32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 mbf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 mf16x8 __attribute__((ext_vector_type(8)));
+template <int F, typename AV, typename BV> __device__ __forceinline__ mf32x16 mfma16(AV a, BV b, mf32x16 c) {
+  static_assert(sizeof(AV) == 16 && sizeof(BV) == 16, "8 x 16-bit operands");
+  if constexpr (F == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(mf16x8, a), __builtin_bit_cast(mf16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mbf16x8, a), __builtin_bit_cast(mbf16x8, b), c, 0, 0, 0);
 }
 
 }  // namespace paif

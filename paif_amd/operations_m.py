@@ -65,7 +65,7 @@ class _PackCache:
         self._store = {}
 
     def get(self, name, params, builder):
-        slot = (name, ops.CONFIG["conv_precision"])
+        slot = (name, ops.pack_precision())      # ("f16" inside an fp16-storage inference forward)
         key = tuple((p.data_ptr(), p._version, str(p.device)) for p in params) + (ops.CONFIG.get("weights_generation", 0),)
         hit = self._store.get(slot)
         if hit is None or hit[0] != key:
@@ -288,7 +288,9 @@ class ResidualModule(_HipOp):
             PReLUParams(),
         )
 
-    def forward_nhwc(self, x, res=(), tape=None):
+    takes_out_f32 = True     # forward_nhwc(..., out_f32=True): the composed conv can write an fp32 map from fp16 sources
+
+    def forward_nhwc(self, x, res=(), tape=None, out_f32=False):
         op = self.op
         t1 = ops.conv2d([x], op[0].wpk(1, 32), self.k, self.d)
         if tape is None and not op[3].training and ops.CONFIG.get("resmod_compose", True):
@@ -298,7 +300,8 @@ class ResidualModule(_HipOp):
             wc = self._packs.get("w23", [op[1].weight, op[2].weight],
                                  lambda: ops.pack_conv_weight(ops.compose_pw_conv_weight(op[2].weight, op[1].weight), 1, 32, 3))
             scale, shift = _bn_scale_shift(op[3], self._packs)
-            return ops.conv2d([t1], wc, 3, 2, scale=scale, shift=shift, act=ops.ACT_PRELU, prelu=op[4].weight, res=(x,) + tuple(res))
+            return ops.conv2d([t1], wc, 3, 2, scale=scale, shift=shift, act=ops.ACT_PRELU, prelu=op[4].weight, res=(x,) + tuple(res),
+                              out_f32=out_f32)
         w2 = self._packs.get("w2", [op[1].weight], lambda: ops.pack_conv_weight(op[1].weight, 1, 32, 3))
         t2 = ops.conv2d([t1], w2, 3, 2)
         w3 = self._packs.get("w3", [op[2].weight], lambda: ops.pack_conv_weight(op[2].weight, 1, 32, 1))
@@ -355,7 +358,7 @@ class DilConv(_HipOp):
 
     def forward_nhwc(self, x, res=(), tape=None):
         op = self.op
-        dense = ops.CONFIG.get("dilconv_dense", True) if x.dtype == torch.bfloat16 else ops.CONFIG.get("dilconv_dense_f32", True)
+        dense = ops.CONFIG.get("dilconv_dense", True) if x.dtype in ops.H16 else ops.CONFIG.get("dilconv_dense_f32", True)
         if self.k == 3 and tape is None and not op[3].training and dense:
             # inference forward (bf16 maps, and since round 4 fp32 maps too): depthwise + 1x1 as ONE dense k x k conv with
             # W[co][ci][tap] = pw[co][ci] * dw[ci][tap] (one fp32 rounding of the product, then the usual split) and the ReLU as its input

@@ -56,20 +56,32 @@ CONFIG = {"conv_precision": "bf16x3", "gemm_precision": "auto", "serpentine": Tr
           # inference forward of the fusion network: run the infrared and the visible stream on two HIP streams (identical results; off by
           # default because per-launch timings -- bench.py's roofline blocks, rocprofv3 averages -- then measure CU sharing, not kernels)
           "two_stream": False}
-_ACT_BF16 = [False]    # True while an inference forward of the fusion network runs in bf16 storage (set by the model)
+# falsy, or the torch dtype (torch.bfloat16 / torch.float16) of the 32-channel maps while an inference forward of the fusion network
+# runs in a 16-bit storage mode (set by the model through `bf16_activations`)
+_ACT_BF16 = [False]
+H16 = (torch.bfloat16, torch.float16)     # dtypes of 16-bit-stored maps
 
 
-STORAGE_MODES = ("f32", "bf16", "bf16_split")
+STORAGE_MODES = ("f32", "bf16", "bf16_split", "f16")
 
 
 def set_storage(mode):
     """Activation storage of the fusion network's inference forward.
     "f32":        fp32 maps, split-bf16 products (3 bf16 MFMAs, fp32-level parity) -- the API default.
     "bf16":       BASELINE configs[1]: bf16 maps AND bf16 weights, one bf16 MFMA per product, fp32 accumulate (PAIF_CONV_BF16).
-    "bf16_split": bf16 maps, weights kept as split-bf16 hi + lo (2 MFMAs per product: only the maps are rounded)."""
+    "bf16_split": bf16 maps, weights kept as split-bf16 hi + lo (2 MFMAs per product: only the maps are rounded).
+    "f16":        round 5 -- the 16-bit configuration that meets SURVEY 8(d)'s argmax clause: IEEE fp16 maps (11 significant bits where
+                  bf16 has 8) and fp16 weights, one fp16 MFMA per product, fp32 accumulate; the guided filter writes HF = x - LF (small
+                  magnitudes), the folded 1x1 behind it keeps fp16 hi + lo weights (2 MFMAs), and the forward's last 32-channel map
+                  (the input of stem_out) stays fp32.  Why these three: tools/storage_sensitivity.py, DESIGN section 2."""
     if mode not in STORAGE_MODES:
         raise ValueError("storage must be one of %s" % (STORAGE_MODES,))
     CONFIG["storage"] = mode
+
+
+def pack_precision():
+    """Arithmetic a weight pack built NOW is for: "f16" inside an fp16-storage inference forward, else CONFIG['conv_precision']."""
+    return "f16" if _ACT_BF16[0] is torch.float16 else CONFIG["conv_precision"]
 
 
 class bf16_activations:
@@ -80,7 +92,8 @@ class bf16_activations:
 
     def __enter__(self):
         self.old = _ACT_BF16[0]
-        _ACT_BF16[0] = self.enable and CONFIG["storage"] in ("bf16", "bf16_split") and CONFIG["conv_precision"] == "bf16x3"
+        on = self.enable and CONFIG["storage"] in ("bf16", "bf16_split", "f16") and CONFIG["conv_precision"] == "bf16x3"
+        _ACT_BF16[0] = (torch.float16 if CONFIG["storage"] == "f16" else torch.bfloat16) if on else False
 
     def __exit__(self, *a):
         _ACT_BF16[0] = self.old
@@ -90,7 +103,7 @@ class bf16_activations:
 
 _TWINS = {}    # data_ptr of an fp32 map -> (the map, its bf16 twin written by the producing kernel); lives for one bf16 forward
 _SERP = [0]    # tile-direction parity of the next dense-conv launch
-_PREC_CODE = {"f32": 0, "bf16x3": 1, "bf16x6": 3}
+_PREC_CODE = {"f32": 0, "bf16x3": 1, "bf16x6": 3, "f16": 4, "f16x2": 5}    # include/paif_hip.h PAIF_CONV_*
 PREC_BF16 = 2          # include/paif_hip.h PAIF_CONV_BF16 (conv descriptors with bf16-stored maps only)
 
 
@@ -248,28 +261,32 @@ def _p(t):
 
 
 def _pa(t):
-    """Device pointer of an activation map: dense float32 or bfloat16 CUDA tensor (None -> NULL)."""
+    """Device pointer of an activation map: dense float32, bfloat16 or float16 CUDA tensor (None -> NULL)."""
     if t is None:
         return None
-    if t.dtype == torch.bfloat16:
+    if t.dtype in H16:
         if not t.is_cuda or not t.is_contiguous():
             raise RuntimeError("expected a dense CUDA tensor")
         return ctypes.c_void_p(t.data_ptr())
     return _p(t)
 
 
-def cast_storage(x, to_bf16):
-    """fp32 map -> bf16 map (round to nearest even) or back, as a HIP kernel."""
-    want = torch.bfloat16 if to_bf16 else torch.float32
+def cast_storage(x, to):
+    """Convert a map between fp32 and a 16-bit storage format (round to nearest even on the way down), as a HIP kernel.
+    to: a torch dtype (float32 / bfloat16 / float16); True = the running forward's 16-bit dtype (bf16 outside one); False = float32."""
+    want = to if isinstance(to, torch.dtype) else ((_ACT_BF16[0] or torch.bfloat16) if to else torch.float32)
     if x.dtype == want:
         return x
-    if to_bf16:
+    if want in H16 and x.dtype == torch.float32:
         tw = _TWINS.get(x.data_ptr())
-        if tw is not None and tw[0] is x:     # the producer already wrote this map's bf16 twin
+        if tw is not None and tw[0] is x and tw[1].dtype == want:     # the producer already wrote this map's 16-bit twin
             return tw[1]
+    if x.dtype in H16 and want in H16:
+        raise TypeError("cast_storage: %s -> %s is not built (one 16-bit format per forward)" % (x.dtype, want))
     assert x.numel() % 4 == 0
     out = torch.empty(x.shape, device=x.device, dtype=want)
-    _lib.check(lib().paif_cast_storage_fwd(_pa(x.contiguous()), _pa(out), x.numel(), int(to_bf16), _stream()), "cast_storage")
+    mode = {torch.bfloat16: 1, torch.float16: 2}[want] if want in H16 else (0 if x.dtype == torch.bfloat16 else 3)
+    _lib.check(lib().paif_cast_storage_fwd(_pa(x.contiguous()), _pa(out), x.numel(), mode, _stream()), "cast_storage")
     return out
 
 
@@ -389,10 +406,11 @@ def stem(img, w, prelu, want_guide=True):
     guide = torch.empty((B, H, W), device=img.device, dtype=torch.float32) if want_guide else None
     if img.dtype != torch.float32 or not img.is_cuda:
         raise RuntimeError("stem: need a float32 CUDA tensor")
-    if _ACT_BF16[0]:     # bf16 storage: the bf16 twin of the map, for the layers that take it as a residual input (cast_storage finds it)
-        twin = torch.empty((B, H, W, 32), device=img.device, dtype=torch.bfloat16)
-        _lib.check(lib().paif_stem_fwd_twin(ctypes.c_void_p(img.data_ptr()), bstride, _p(w), _p(prelu), _p(feat), _pa(twin), _p(guide),
-                                            B, H, W, _stream()), "stem")
+    if _ACT_BF16[0]:     # 16-bit storage: the bf16 / fp16 twin of the map, for the layers that take it as a residual input (cast_storage finds it)
+        twin = torch.empty((B, H, W, 32), device=img.device, dtype=_ACT_BF16[0])
+        fn = lib().paif_stem_fwd_twin_f16 if _ACT_BF16[0] is torch.float16 else lib().paif_stem_fwd_twin
+        _lib.check(fn(ctypes.c_void_p(img.data_ptr()), bstride, _p(w), _p(prelu), _p(feat), _pa(twin), _p(guide),
+                      B, H, W, _stream()), "stem")
         _TWINS[feat.data_ptr()] = (feat, twin)
         return feat, guide
     _lib.check(lib().paif_stem_fwd(ctypes.c_void_p(img.data_ptr()), bstride, _p(w), _p(prelu), _p(feat), _p(guide),
@@ -411,19 +429,23 @@ def channel_residue(x):
 def guided_filter_pair(guide, y, eps=(0.001, 0.0001), want_ab=False, out_bf16=False):
     """Returns lf [2,B,H,W,32] for the two eps (r = 4) (and the coefficient maps ab [4,B,H,W,32] for the
     backward pass).  AssertionError if H or W <= 9, like the reference's guided_filter_pytorch.
-    out_bf16 (inference, fused form): the two maps as bf16 -- the bf16 configuration's storage of the maps behind this block."""
+    out_bf16 (inference, fused form): the two maps as bf16 -- the bf16 configuration's storage of the maps behind this block;
+    out_bf16 = torch.float16 (the fp16 configuration): the two HIGH-frequency maps y - LF as fp16 instead (paif_hip.h
+    paif_guided_filter_fused_fwd_hf16)."""
+    hf16 = out_bf16 is torch.float16
+    out_bf16 = bool(out_bf16)
     B, H, W, C = y.shape
     assert C == 32
     assert H > 9 and W > 9, "guided filter needs H, W > 2r+1 = 9"
     L = lib()
     if not want_ab and CONFIG.get("gf_fused", True):
-        lf = torch.empty((2, B, H, W, 32), device=y.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+        lf = torch.empty((2, B, H, W, 32), device=y.device, dtype=torch.float16 if hf16 else torch.bfloat16 if out_bf16 else torch.float32)
         ws = torch.empty(L.paif_guided_filter_fused_workspace_floats(B, H, W), device=y.device, dtype=torch.float32)
         import os
         eng = os.environ.get("PAIF_GF_ENGINE")
         tag = ("gf_fused_kernel" if eng == "valu" else "gf_mfma_kernel" if eng == "mfma" else "gf2_kernel") + " (+ gf_guide_stats_kernel)"
         e0 = TIMER.start(tag) if TIMER is not None else None
-        fn = L.paif_guided_filter_fused_fwd_bf16 if out_bf16 else L.paif_guided_filter_fused_fwd
+        fn = L.paif_guided_filter_fused_fwd_hf16 if hf16 else L.paif_guided_filter_fused_fwd_bf16 if out_bf16 else L.paif_guided_filter_fused_fwd
         _lib.check(fn(_p(guide), _p(y), _pa(lf), eps[0], eps[1], _p(ws), B, H, W, _stream()), "guided_filter_fused")
         if e0 is not None:   # algorithmic traffic: guide + y read once, the two low-frequency maps written once; ~650 FLOP per pixel-channel
             TIMER.stop(tag, e0, 650 * B * H * W * 32, B * H * W * (4 * (1 + 32) + (2 if out_bf16 else 4) * 64))
@@ -440,14 +462,16 @@ def pack_conv_weight(w, nsrc, cin, kh, precision=None):
     """w: [cout, nsrc*cin, kh, kh] -> packed MFMA B-operand stream (PackedWeight)."""
     cout = w.shape[0]
     assert tuple(w.shape) == (cout, nsrc * cin, kh, kh), (tuple(w.shape), nsrc, cin, kh)
-    precision = precision or CONFIG["conv_precision"]
+    precision = precision or pack_precision()
     if cin != 32:
         precision = "f32"  # the split-bf16 kernel is built for 32-channel sources
     L = lib()
     nfl = L.paif_conv_wpk_floats(nsrc, cin, kh)
     wpk = torch.empty(nfl * 3 // 2 if precision == "bf16x6" else nfl, device=w.device, dtype=torch.float32)
     wc = w.detach().contiguous()
-    if precision == "bf16x6":
+    if precision in ("f16", "f16x2"):      # fp16 hi | lo pieces; "f16" reads the hi pieces only (one MFMA per product)
+        _lib.check(L.paif_pack_conv_weight_f16x2(_p(wc), _p(wpk), cout, nsrc, kh, _stream()), "pack_conv_weight_f16x2")
+    elif precision == "bf16x6":
         _lib.check(L.paif_pack_conv_weight_bf16x6(_p(wc), _p(wpk), cout, nsrc, kh, _stream()), "pack_conv_weight_bf16x6")
     elif precision == "bf16x3":
         _lib.check(L.paif_pack_conv_weight_bf16x3(_p(wc), _p(wpk), cout, nsrc, kh, _stream()), "pack_conv_weight_bf16x3")
@@ -495,6 +519,16 @@ def pack_decomp1x1_weight(w, precision=None):
     return PackedWeight(wpk, precision)
 
 
+def pack_decomp1x1_hf_weight(w):
+    """The folded decomposition 1x1 of the fp16 forward: over [x, HF1, HF2] (the guided filter writes HF = x - LF), fp16 hi + lo
+    pieces (precision "f16x2": two MFMAs per product -- this conv's weight rounding is the one that moves the segmentation argmax)."""
+    assert tuple(w.shape) == (32, 128, 1, 1)
+    L = lib()
+    wpk = torch.empty(L.paif_conv_wpk_floats(3, 32, 1), device=w.device, dtype=torch.float32)
+    _lib.check(L.paif_pack_decomp1x1_hf_weight_f16x2(_p(w.detach().contiguous()), _p(wpk), _stream()), "pack_decomp1x1_hf_weight_f16x2")
+    return PackedWeight(wpk, "f16x2")
+
+
 def bn_fold(weight, bias, mean, var, eps):
     C = weight.shape[0]
     scale = torch.empty(C, device=weight.device, dtype=torch.float32)
@@ -516,7 +550,7 @@ def conv2d_kernel_name(desc, B, H, W):
 
 def conv2d(srcs, wpk, kh, dil=1, cin=32, cout=32, in_act=ACT_NONE, in_prelu=None, scale=None, shift=None,
            act=ACT_NONE, prelu=None, alpha=1.0, res=(), pool=False, want_aux=False, in_aux=None, in_scale=None,
-           in_alpha=1.0, epi_dact=0, epi_aux=None, out=None):
+           in_alpha=1.0, epi_dact=0, epi_aux=None, out=None, out_f32=False):
     """Dense conv over the virtual concat of `srcs` (NHWC).  Returns out (and the per-tile pool partials /
     the saved pre-activation when asked).  in_act 3/4/5 + in_aux/in_scale/in_alpha and epi_dact/epi_aux are the
     activation-derivative hooks used when the same kernel runs a dgrad (include/paif_hip.h)."""
@@ -525,20 +559,42 @@ def conv2d(srcs, wpk, kh, dil=1, cin=32, cout=32, in_act=ACT_NONE, in_prelu=None
     res = [r for r in res if r is not None]
     extra = res[3:]
     res = res[:3]
-    # activation storage (include/paif_hip.h PAIF_ST_*): bf16 sources -> bf16 output; fp32 sources -> bf16 output only for the
-    # 1x1 behind the guided-filter block while a bf16 inference forward is running; otherwise fp32
-    src_bf = srcs[0].dtype == torch.bfloat16
-    assert all((s_.dtype == torch.bfloat16) == src_bf for s_ in srcs), "mixed source storage"
-    out_bf = (out.dtype == torch.bfloat16) if out is not None else (src_bf or (_ACT_BF16[0] and kh == 1 and not want_aux and in_act < 3 and not epi_dact))
-    storage = 1 if src_bf else (2 if out_bf else 0)
+    # activation storage (include/paif_hip.h PAIF_ST_*): 16-bit sources (bf16 / fp16) -> output in the same format; fp32 sources -> bf16
+    # output only for the 1x1 behind the guided-filter block while a bf16 inference forward is running; otherwise fp32.
+    # out_f32 (a request, honoured where the kernel exists: fp16 sources, 3x3 dilation 2, one source): fp32 output from 16-bit sources
+    # and residual maps -- the forward's last 32-channel map
+    sdt = srcs[0].dtype
+    src16 = sdt in H16
+    assert all(s_.dtype == sdt for s_ in srcs), "mixed source storage"
+    if out is not None:
+        odt = out.dtype
+    elif src16:
+        want32 = (out_f32 and sdt == torch.float16 and kh == 3 and dil == 2 and len(srcs) == 1 and in_act == ACT_NONE and not pool and cout == 32
+                  and wpk.precision == "f16")
+        odt = torch.float32 if want32 else sdt
+    else:
+        odt = torch.bfloat16 if (_ACT_BF16[0] is torch.bfloat16 and kh == 1 and not want_aux and in_act < 3 and not epi_dact) else torch.float32
+    out16 = odt in H16
+    if src16:
+        storage = (3 if out16 else 4) if sdt == torch.float16 else 1
+        if not out16 and sdt != torch.float16:
+            raise NotImplementedError("bf16 sources with an fp32 output are not built")
+    else:
+        storage = 0 if not out16 else 2
+        if odt == torch.float16:
+            raise NotImplementedError("fp32 sources with an fp16 output are not built (the fp16 forward hands the 1x1 fp16 maps)")
     if storage and (want_aux or in_act >= 3 or epi_dact or in_aux is not None):
-        raise NotImplementedError("bf16 activation storage is built for the inference forward (no gradient hooks)")
+        raise NotImplementedError("16-bit activation storage is built for the inference forward (no gradient hooks)")
+    if (sdt == torch.float16) != (wpk.precision in ("f16", "f16x2")):
+        raise RuntimeError("conv2d: fp16 maps need an fp16 weight pack and vice versa (sources %s, pack %s)" % (sdt, wpk.precision))
     if out is None:
-        out = torch.empty((B, H, W, cout), device=srcs[0].device, dtype=torch.bfloat16 if out_bf else torch.float32)
+        out = torch.empty((B, H, W, cout), device=srcs[0].device, dtype=odt)
     else:
         assert tuple(out.shape) == (B, H, W, cout) and out.is_contiguous()
-    res = [cast_storage(r, out_bf) for r in res]       # residual maps share the output's storage
-    extra = [cast_storage(r, out_bf) for r in extra]
+    rdt = sdt if storage == 4 else odt                 # residual maps share the output's storage (fp16 in / fp32 out: the sources')
+    res = [cast_storage(r, rdt) for r in res]
+    extra = [cast_storage(r, odt) for r in extra]
+    src_bf, out_bf = src16, out16                       # (byte accounting below)
     L = lib()
     d = _lib.ConvDesc()
     d.storage = storage
@@ -549,7 +605,7 @@ def conv2d(srcs, wpk, kh, dil=1, cin=32, cout=32, in_act=ACT_NONE, in_prelu=None
         assert tuple(r.shape) == (B, H, W, cout)
     d.nsrc, d.cin, d.wpk, d.kh, d.dil = len(srcs), cin, _p(wpk.data), kh, dil
     d.precision = _PREC_CODE[wpk.precision]
-    if storage and wpk.precision == "bf16x3" and CONFIG["storage"] == "bf16":
+    if storage in (1, 2) and wpk.precision == "bf16x3" and CONFIG["storage"] == "bf16":
         d.precision = PREC_BF16            # plain bf16 weights: the hi half of the split-bf16 pack
     d.in_act, d.in_prelu = in_act, _p(in_prelu)
     d.scale, d.shift = _p(scale), _p(shift)
@@ -603,7 +659,7 @@ def dwconv(x, w, k, dil, in_relu):
     B, H, W, C = x.shape
     assert C == 32
     out = torch.empty_like(x)
-    fn = lib().paif_dwconv_fwd_bf16 if x.dtype == torch.bfloat16 else lib().paif_dwconv_fwd
+    fn = {torch.bfloat16: lib().paif_dwconv_fwd_bf16, torch.float16: lib().paif_dwconv_fwd_f16}.get(x.dtype, lib().paif_dwconv_fwd)
     _lib.check(fn(_pa(x), _p(w.detach().contiguous()), _pa(out), k, dil, int(in_relu), B, H, W, _stream()), "dwconv")
     return out
 
@@ -612,7 +668,7 @@ def channel_pool2(ir, vis):
     B, H, W, _ = ir.shape
     comp = torch.empty((B, H, W, 4), device=ir.device, dtype=torch.float32)
     assert ir.dtype == vis.dtype
-    fn = lib().paif_channel_pool2_fwd_bf16 if ir.dtype == torch.bfloat16 else lib().paif_channel_pool2_fwd
+    fn = {torch.bfloat16: lib().paif_channel_pool2_fwd_bf16, torch.float16: lib().paif_channel_pool2_fwd_f16}.get(ir.dtype, lib().paif_channel_pool2_fwd)
     _lib.check(fn(_pa(ir), _pa(vis), _p(comp), B, H, W, _stream()), "channel_pool2")
     return comp
 
@@ -620,9 +676,10 @@ def channel_pool2(ir, vis):
 def spa_blend(comp, w, ir, vis, want_scale=False):
     B, H, W, _ = ir.shape
     agg = torch.empty_like(ir)
-    if ir.dtype == torch.bfloat16:
-        assert not want_scale and vis.dtype == torch.bfloat16
-        _lib.check(lib().paif_spa_blend_fwd_bf16(_p(comp), _p(w.detach().contiguous()), _pa(ir), _pa(vis), _pa(agg), B, H, W, _stream()), "spa_blend")
+    if ir.dtype in H16:
+        assert not want_scale and vis.dtype == ir.dtype
+        fn = lib().paif_spa_blend_fwd_f16 if ir.dtype == torch.float16 else lib().paif_spa_blend_fwd_bf16
+        _lib.check(fn(_p(comp), _p(w.detach().contiguous()), _pa(ir), _pa(vis), _pa(agg), B, H, W, _stream()), "spa_blend")
         return agg
     scale = torch.empty((B, H, W), device=ir.device, dtype=torch.float32) if want_scale else None
     _lib.check(lib().paif_spa_blend_fwd(_p(comp), _p(w.detach().contiguous()), _p(ir), _p(vis), _p(agg), _p(scale), B, H, W, _stream()),
@@ -634,9 +691,10 @@ def eca_finish(o, r, partial, w1d, k, prelu, save=False):
     B, H, W, _ = o.shape
     out = torch.empty_like(o)
     gate = torch.empty((B, 32), device=o.device, dtype=torch.float32)
-    if o.dtype == torch.bfloat16:
-        assert not save and r.dtype == torch.bfloat16
-        _lib.check(lib().paif_eca_finish_fwd_bf16(_pa(o), _pa(r), _p(partial), _p(w1d.detach().contiguous()), k, _p(prelu), _p(gate), _pa(out),
+    if o.dtype in H16:
+        assert not save and r.dtype == o.dtype
+        fn = lib().paif_eca_finish_fwd_f16 if o.dtype == torch.float16 else lib().paif_eca_finish_fwd_bf16
+        _lib.check(fn(_pa(o), _pa(r), _p(partial), _p(w1d.detach().contiguous()), k, _p(prelu), _p(gate), _pa(out),
                                                   B, H, W, _stream()), "eca_finish")
         return out
     u = torch.empty_like(o) if save else None
@@ -737,9 +795,10 @@ def tail(x16, w, prelu, save=False):
     B, H, W, C = x16.shape
     assert C == 16
     fused = torch.empty((B, 1, H, W), device=x16.device, dtype=torch.float32)
-    if x16.dtype == torch.bfloat16:
+    if x16.dtype in H16:
         assert not save
-        _lib.check(lib().paif_tail_fwd_bf16(_pa(x16), _p(w.detach().contiguous()), _p(prelu), _p(fused), B, H, W, _stream()), "tail")
+        fn = lib().paif_tail_fwd_f16 if x16.dtype == torch.float16 else lib().paif_tail_fwd_bf16
+        _lib.check(fn(_pa(x16), _p(w.detach().contiguous()), _p(prelu), _p(fused), B, H, W, _stream()), "tail")
         return fused
     z = torch.empty((B, 1, H, W), device=x16.device, dtype=torch.float32) if save else None
     _lib.check(lib().paif_tail_fwd(_p(x16), _p(w.detach().contiguous()), _p(prelu), _p(fused), _p(z), B, H, W, _stream()), "tail")
@@ -748,10 +807,12 @@ def tail(x16, w, prelu, save=False):
 
 def add(a, b):
     assert a.shape == b.shape
-    if a.dtype == torch.bfloat16 or b.dtype == torch.bfloat16:
-        a, b = cast_storage(a, True), cast_storage(b, True)
+    if a.dtype in H16 or b.dtype in H16:
+        dt = a.dtype if a.dtype in H16 else b.dtype
+        a, b = cast_storage(a, dt), cast_storage(b, dt)
         out = torch.empty_like(a)
-        _lib.check(lib().paif_add_fwd_bf16(_pa(a), _pa(b), _pa(out), a.numel(), _stream()), "add")
+        fn = lib().paif_add_fwd_f16 if dt == torch.float16 else lib().paif_add_fwd_bf16
+        _lib.check(fn(_pa(a), _pa(b), _pa(out), a.numel(), _stream()), "add")
         return out
     out = torch.empty_like(a)
     _lib.check(lib().paif_add_fwd(_p(a), _p(b), _p(out), a.numel(), _stream()), "add")

@@ -147,7 +147,7 @@ def test_conv3x3_bf16_dma_kernel(nsrc, nres, act, shape):
     ref = ops.conv2d(xs32, wpk, 3, res=tuple(rs32), **kw)
     ops.set_storage("bf16")
     d = _lib_desc(xsb, wpk, rsb)
-    assert ops.conv2d_kernel_name(d, B, H, W) == "conv3x3_bf16_dma<%d, %d>" % (nsrc, nres)
+    assert ops.conv2d_kernel_name(d, B, H, W) == "conv3x3_bf16_dma<%d, %d, 1>" % (nsrc, nres)
     out = ops.conv2d(xsb, wpk, 3, res=tuple(rsb), **kw)
     torch.cuda.synchronize()
     assert out.dtype == torch.bfloat16
@@ -176,7 +176,7 @@ def test_conv7x7_bf16_dma_kernel(act, shape):
     ops.set_storage("bf16")
     d = _lib_desc([xb], wpk, [])
     d.kh = 7
-    assert ops.conv2d_kernel_name(d, B, H, W) == "conv7x7_bf16_dma"
+    assert ops.conv2d_kernel_name(d, B, H, W) == "conv7x7_bf16_dma<1>"
     out = ops.conv2d([xb], wpk, 7, **kw)
     torch.cuda.synchronize()
     err = (out.float() - ref).abs()
@@ -351,7 +351,7 @@ def test_fusion_forward_bf16_storage_tolerance_clause(golden):
     rng = float(g["logits"].max() - g["logits"].min())
     miou_ref = float(np.nanmean(compute_results(g["conf"])[2]))
     res = {}
-    for mode in ops.STORAGE_MODES:
+    for mode in ("f32", "bf16", "bf16_split"):        # (the fp16 configuration: tests/test_f16_storage_gpu.py)
         ops.set_storage(mode)
         with torch.no_grad():
             fused, seg = m(irt, vist)
@@ -387,11 +387,12 @@ def test_fusion_forward_bf16_storage_tolerance_clause(golden):
         # mIoU within 0.1 pt: HOLDS for the bf16 configuration BASELINE names (0.04-0.09 pt across this round's builds); bf16_split (a mode
         # nothing ships with: slower than bf16 and no more accurate) sits AT the clause's edge (0.07-0.10 pt): asserted with its measured head-room
         assert abs(r["miou_delta_vs_reference"]) <= lim["miou"], report
-        # argmax agreement >= 99.9 %: DOES NOT HOLD on this map (99.25 % / 98.1 %) and cannot for any 16-bit storage: with a median
-        # top-2 margin of 1.6 % of the logit range, ~1 % of the pixels are decided by less than the bf16 logit error (mean 0.04-0.06 %,
-        # max 0.7-0.8 % of the range).  What is asserted: the measured agreement (with head-room) and that ONLY such near-tie pixels move.
+        # argmax agreement >= 99.9 %: DOES NOT HOLD for bf16 maps on this map (99.25 % / 98.1 %): with a median top-2 margin of 1.6 % of
+        # the logit range, ~1 % of the pixels are decided by less than the bf16 logit error (mean 0.04-0.06 %, max 0.7-0.8 % of the
+        # range).  What is asserted here: the measured agreement (with head-room) and that ONLY such near-tie pixels move; the clause
+        # itself is test_bf16_storage_argmax_clause (expected to fail) and, for the 16-bit configuration that meets it,
+        # tests/test_f16_storage_gpu.py::test_fusion_forward_f16_storage_tolerance_clause.
         assert r["argmax_agreement_vs_reference"] >= lim["agree"], report
-        assert r["argmax_agreement_vs_reference"] < 0.999, "the bf16 argmax clause now holds: make bf16 the bench default again"
         # a pixel moves only where the reference itself decides by less than twice the largest logit error
         assert r["largest_reference_margin_of_a_moved_pixel_over_range"] <= 2.0 * r["logits_max_abs_over_range"], report
 
@@ -403,6 +404,26 @@ BF16_CLAUSE = {
     "bf16": dict(fused_max=1.7e-2, fused_mean=9.5e-4, logits_max=1e-2, logits_mean=7e-4, agree=0.985, miou=1e-3),
     "bf16_split": dict(fused_max=1.8e-2, fused_mean=8e-4, logits_max=1e-2, logits_mean=7.5e-4, agree=0.975, miou=1.5e-3),
 }
+
+
+@pytest.mark.xfail(strict=False, reason="SURVEY 8(d) argmax clause (>= 99.9 %) with bf16 maps: measured 99.25 % (8 significant bits per stored "
+                                        "value); the fp16 configuration is the 16-bit one that meets it")
+def test_bf16_storage_argmax_clause(golden):
+    from paif_amd.core.model_fusion_auto import Network_MM_Searched
+    from paif_amd.genotypes import FUSION_AT
+    from paif_amd.util.util import ConfusionMeter
+
+    g = golden("gf_model_b3_1x480x640")
+    dev = _dev()
+    m = Network_MM_Searched(32, FUSION_AT, None, None, "mit_b3", num_classes=9).eval()
+    S.load_formula_weights(m, head=Hh.HEAD480)
+    m = m.to(dev)
+    ir, vis, lab = S.make_batch(1, 480, 640)
+    ops.set_storage("bf16")
+    with torch.no_grad():
+        _, seg = m(t(ir).to(dev), t(vis).to(dev))
+    pred = ConfusionMeter(9, dev).update(seg, t(lab).to(dev)).cpu().numpy()
+    assert float((pred == g["pred"]).mean()) >= 0.999
 
 
 def test_bf16_storage_is_inference_only():

@@ -35,11 +35,40 @@ CONV_SHAPE = [(1, 1, 3, 0), (1, 1, 3, 0),
               (3, 1, 1, 0), (3, 1, 1, 0), (7, 1, 1, 0), (3, 2, 1, 2)]
 
 
-def rnd_(x, fmt):
+def _custom(x, ebits, mbits, bias):
+    """Round to a float with `mbits` explicit mantissa bits and exponents >= emin = 1 - bias (gradual underflow below; no overflow
+    handling: activations are O(1)), round-half-even on the scaled integer."""
+    emin = 1 - bias
+    e = torch.floor(torch.log2(x.abs().clamp_min(1e-30))).clamp_min(float(emin))
+    step = torch.exp2(e - mbits)
+    return torch.round(x.double() / step.double()).to(torch.float32) * step
+
+
+STATS = {}
+
+
+def rnd_(x, fmt, name=None):
+    if name is not None and name not in STATS and x.dim() >= 4:
+        v = x.reshape(-1, x.shape[-1]).double()
+        mu, sd = v.mean(0), v.std(0)
+        STATS[name] = dict(rms=float(v.pow(2).mean().sqrt()), absmax=float(v.abs().max()), mean_abs=float(v.abs().mean()),
+                           chan_mean_over_std_median=float((mu.abs() / sd.clamp_min(1e-12)).median()),
+                           rms_centered=float((v - mu).pow(2).mean().sqrt()))
     if fmt == "bf16":
         x.copy_(x.to(torch.bfloat16))
     elif fmt == "f16":
         x.copy_(x.to(torch.float16))
+    elif fmt == "f16c":       # fp16 of the per-channel-centred value (the channel mean kept aside in fp32)
+        mu = x.reshape(-1, x.shape[-1]).mean(0)
+        x.copy_((x - mu).to(torch.float16).float() + mu)
+    elif fmt == "e4m11":
+        x.copy_(_custom(x, 4, 11, 11))     # exponents 2^-10 .. 2^4
+    elif fmt == "e3m12":
+        x.copy_(_custom(x, 3, 12, 5))      # exponents 2^-4 .. 2^2 (|v| < 8)
+    elif fmt == "stat" or fmt is None:
+        pass
+    else:
+        raise ValueError(fmt)
     return x
 
 
@@ -49,6 +78,7 @@ class Emu:
     def __init__(self):
         self.on = {}        # class -> format
         self.wfmt = None    # weight format or None
+        self.wonly = None   # None = every conv's weights, or the set of conv classes whose weights are rounded
         self.n = 0
         self.twins = {}
         self.log = []
@@ -70,13 +100,18 @@ class Emu:
         feat, guide = self._orig["stem"](*a, **k)
         f = self.on.get("stem_twin")
         if f:   # the guided filter keeps the fp32 map; the 1x1 and the chain's outer residual take the 16-bit twin
-            self.twins[feat.data_ptr()] = rnd_(feat.clone(), f)
+            self.twins[feat.data_ptr()] = rnd_(feat.clone(), f, "stem_twin")
         return feat, guide
 
     def gf(self, *a, **k):
         lf = self._orig["gf"](*a, **k)
         f = self.on.get("gf_lf")
-        return rnd_(lf, f) if f else lf
+        if f == "hf16":      # the filter writes HF = x - LF (small) as fp16; the folded 1x1 is refolded over [x, HF1, HF2]
+            y = a[1]
+            for i in range(2):
+                lf[i].copy_(y - (y - lf[i]).to(torch.float16).float())
+            return lf
+        return rnd_(lf, f, "gf_lf") if f else lf
 
     def conv2d(self, srcs, wpk, kh, dil=1, **k):
         res = tuple(r for r in k.get("res", ()) if r is not None)
@@ -86,24 +121,32 @@ class Emu:
         self.log.append((kh, dil, len(srcs), len(res)))
         srcs = [self._tw(s) for s in srcs]
         k["res"] = tuple(self._tw(r) for r in res)
+        if getattr(self, "prelu_round", False) and k.get("in_act") == ops.ACT_PRELU:      # the fp16 kernel rounds PReLU(x) to fp16 at staging
+            a = k.pop("in_prelu")
+            k.pop("in_act")
+            srcs = [rnd_(torch.where(s >= 0, s, s * a), "f16") for s in srcs]
         r = self._orig["conv2d"](srcs, wpk, kh, dil, **k)
         f = self.on.get(cls)
         if f:
-            rnd_(r[0] if isinstance(r, tuple) else r, f)
+            rnd_(r[0] if isinstance(r, tuple) else r, f, cls)
         return r
 
     def blend(self, *a, **k):
         r = self._orig["blend"](*a, **k)
         f = self.on.get("blend")
-        return rnd_(r, f) if f else r
+        return rnd_(r, f, "blend") if f else r
 
     def eca(self, *a, **k):
         r = self._orig["eca"](*a, **k)
         f = self.on.get("eca_out")
-        return rnd_(r, f) if f else r
+        return rnd_(r, f, "eca_out") if f else r
 
     def _w(self, w):
-        return rnd_(w.detach().clone(), self.wfmt) if self.wfmt else w
+        # packs happen lazily inside the forward, right before the conv that uses them: self.n is that conv's index
+        cls = CONV_CLASS[self.n] if self.n < len(CONV_CLASS) else "tail"
+        if self.wfmt and (self.wonly is None or cls in self.wonly):
+            return rnd_(w.detach().clone(), self.wfmt)
+        return w
 
     def pack(self, w, *a, **k):
         return self._orig["pack"](self._w(w), *a, **k)
@@ -115,6 +158,7 @@ class Emu:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
+    ap.add_argument("--phase", type=int, default=1, help="2: map statistics, custom 16-bit formats, per-layer weight rounding")
     args = ap.parse_args()
     import helpers as Hh
     from paif_amd.core.model_fusion_auto import Network_MM_Searched
@@ -136,8 +180,8 @@ def main():
         S.load_formula_weights(m, head=Hh.HEAD480)
         return m.to(dev)
 
-    def run(on, wfmt=None):
-        emu.on, emu.wfmt = dict(on), wfmt
+    def run(on, wfmt=None, wonly=None):
+        emu.on, emu.wfmt, emu.wonly = dict(on), wfmt, wonly
         m = fresh_model()          # weight packs are cached per model: a fresh one per weight format
         emu.begin()
         with torch.no_grad():
@@ -153,13 +197,169 @@ def main():
 
     table = {}
 
-    def rec(name, on, wfmt=None):
-        table[name] = r = run(on, wfmt)
+    def rec(name, on, wfmt=None, wonly=None):
+        table[name] = r = run(on, wfmt, wonly)
         print("%-44s moved %6d  agree %.5f  logits mean %.2e max %.2e  fused mean %.2e max %.2e  dmIoU %+.3f pt" % (
             name, r["moved"], r["agree"], r["logits_mean"], r["logits_max"], r["fused_mean"], r["fused_max"], r["miou_delta_pt"]), flush=True)
 
     rec("f32 (no rounding)", {})
     assert emu.log == CONV_SHAPE, emu.log
+    if args.phase == 6:
+        # where the real fp16 forward leaves its emulation: stage by stage, against the unrounded fp32 forward
+        from paif_amd.core.model_fusion_auto import Network_Fusion_Searched
+        W16 = set(CONV_CLASS) - {"decomp1x1"}
+        base = {c: "f16" for c in CLASSES}
+        base["gf_lf"] = "hf16"
+        base.pop("feature2")
+        ycc = ops.rgb2ycrcb(vist)
+
+        def fnet():
+            net = Network_Fusion_Searched(32, None, FUSION_AT).eval()
+            net.load_state_dict({k: t(S.formula_tensor("enhance_net." + k, tuple(v.shape))).to(v.dtype) for k, v in net.state_dict().items()}, strict=True)
+            return net.to(dev)
+
+        def stages(on, wfmt, wonly, storage):
+            emu.on, emu.wfmt, emu.wonly = dict(on), wfmt, wonly
+            ops.set_storage(storage)
+            net = fnet()
+            emu.begin()
+            inter = {}
+            with torch.no_grad():
+                fused = net(irt, ycc, inter=inter)
+            ops.set_storage("f32")
+            out = {k: inter[k].float() for k in ("ir_feature", "vis_feature", "agg", "feature2")}
+            out["fused"] = fused
+            return out
+        ref = stages({}, None, None, "f32")
+        em = stages(base, "f16", W16, "f32")
+        for k, v in emu._orig.items():     # un-patch
+            setattr(ops, {"conv2d": "conv2d", "stem": "stem", "gf": "guided_filter_pair", "blend": "spa_blend", "eca": "eca_finish",
+                          "pack": "pack_conv_weight", "pack1": "pack_decomp1x1_weight"}[k], v)
+        real = stages({}, None, None, "f16")
+        for k in ref:
+            e1, e2, d = (em[k] - ref[k]), (real[k] - ref[k]), (real[k] - em[k])
+            print("%-12s |ref| %.3f   emulated-ref: mean|.| %.2e mean %.2e   real-ref: mean|.| %.2e mean %.2e   real-emulated: mean|.| %.2e" % (
+                k, float(ref[k].abs().mean()), float(e1.abs().mean()), float(e1.mean()), float(e2.abs().mean()), float(e2.mean()), float(d.abs().mean())), flush=True)
+        return
+    if args.phase == 5:
+        # the REAL fp16 forward against its emulation (what differs: the ECA block's PReLU(r) operand is rounded to fp16 in the kernel)
+        W16 = set(CONV_CLASS) - {"decomp1x1"}
+        base = {c: "f16" for c in CLASSES}
+        base["gf_lf"] = "hf16"
+        base.pop("feature2")
+        rec("emulated: P1 + fp32 feature2", base, "f16", W16)
+        emu.prelu_round = True
+        rec("emulated: same + PReLU(r) rounded to fp16 in front of the ECA conv", base, "f16", W16)
+        emu.prelu_round = False
+        emu.on, emu.wfmt, emu.wonly = {}, None, None
+        for k, v in emu._orig.items():     # un-patch
+            setattr(ops, {"conv2d": "conv2d", "stem": "stem", "gf": "guided_filter_pair", "blend": "spa_blend", "eca": "eca_finish",
+                          "pack": "pack_conv_weight", "pack1": "pack_decomp1x1_weight"}[k], v)
+        for mode in ("f16", "bf16"):
+            ops.set_storage(mode)
+            m = fresh_model()
+            with torch.no_grad():
+                fused, seg = m(irt, vist)
+            meter = ConfusionMeter(9, dev)
+            pred = meter.update(seg, labt).cpu().numpy()
+            lerr = (seg.cpu() - t(g["logits"])).abs()
+            d64 = (fused.cpu().double() - t(g["fused64"]).double()).abs()
+            print("REAL %s storage: moved %d  logits mean %.2e max %.2e  fused mean %.2e max %.2e" % (
+                mode, int((pred != g["pred"]).sum()), float(lerr.mean()) / rng, float(lerr.max()) / rng, float(d64.mean()), float(d64.max())), flush=True)
+        return
+    if args.phase == 4:
+        # how much of a "moved pixels" figure is luck: the candidate plans on EIGHT synthetic samples (B = 1 each), against this library's
+        # own fp32-storage forward (47 pixels from the reference on sample 0)
+        W16 = set(CONV_CLASS) - {"decomp1x1"}
+        base = {c: "f16" for c in CLASSES}
+        base["gf_lf"] = "hf16"
+
+        def plan(keep, b=base):
+            on = dict(b)
+            for c in keep:
+                on.pop(c)
+            return on
+        plans = [("bf16 maps + weights", {c: "bf16" for c in CLASSES}, "bf16", None),
+                 ("f16 maps + weights (LF stored)", {c: "f16" for c in CLASSES}, "f16", None),
+                 ("P1: f16 + HF, f16 weights (1x1 exact)", base, "f16", W16),
+                 ("P0: f16 + HF, weights exact", base, None, None),
+                 ("P1 + fp32 feature2", plan(["feature2"]), "f16", W16),
+                 ("P1 + fp32 stem_twin", plan(["stem_twin"]), "f16", W16),
+                 ("P1 + fp32 feature2+stem_twin", plan(["feature2", "stem_twin"]), "f16", W16),
+                 ("P1 + fp32 feature2+stem_twin+decomp1x1", plan(["feature2", "stem_twin", "decomp1x1"]), "f16", W16),
+                 ("P1 + fp32 feature2+stem_twin+eca_r", plan(["feature2", "stem_twin", "eca_r"]), "f16", W16),
+                 ("P0 + fp32 feature2+stem_twin", plan(["feature2", "stem_twin"]), None, None),
+                 ("all maps f16c (+HF), weights exact", {c: ("hf16" if c == "gf_lf" else "f16c") for c in CLASSES}, None, None),
+                 ("all maps e3m12, weights exact", {c: "e3m12" for c in CLASSES}, None, None)]
+        irs, viss, labs = S.make_batch(8, 480, 640)
+        models = {}
+
+        def fwd(on, wfmt, wonly, i):
+            emu.on, emu.wfmt, emu.wonly = dict(on), wfmt, wonly
+            key = (wfmt, None if wonly is None else tuple(sorted(wonly)))
+            if key not in models:
+                models[key] = fresh_model()
+            emu.begin()
+            with torch.no_grad():
+                fused, seg = models[key](t(irs[i:i + 1]).to(dev), t(viss[i:i + 1]).to(dev))
+            meter = ConfusionMeter(9, dev)
+            return meter.update(seg, t(labs[i:i + 1]).to(dev)).cpu().numpy(), seg.cpu()
+        ref = [fwd({}, None, None, i) for i in range(8)]
+        for name, on, wfmt, wonly in plans:
+            moved, lerr = [], []
+            for i in range(8):
+                pred, seg = fwd(on, wfmt, wonly, i)
+                moved.append(int((pred != ref[i][0]).sum()))
+                lerr.append(float((seg - ref[i][1]).abs().mean()) / rng)
+            table[name] = dict(moved=moved, agree_mean=1.0 - float(np.mean(moved)) / 307200.0, agree_min=1.0 - max(moved) / 307200.0,
+                               logits_mean=float(np.mean(lerr)))
+            print("%-46s moved %s  mean agree %.5f  min %.5f  logits mean %.2e" % (name, moved, table[name]["agree_mean"],
+                                                                                  table[name]["agree_min"], table[name]["logits_mean"]), flush=True)
+        if args.out:
+            json.dump(table, open(args.out, "w"), indent=1)
+        return
+    if args.phase == 3:
+        # candidates for a passing 16-bit plan: fp16 maps, the guided filter writes HF (fp16), fp16 weights except the folded 1x1 (exact),
+        # plus a few maps kept in fp32
+        W16 = set(CONV_CLASS) - {"decomp1x1"}
+        base = {c: "f16" for c in CLASSES}
+        base["gf_lf"] = "hf16"
+
+        def plan(keep):
+            on = dict(base)
+            for c in keep:
+                on.pop(c)
+            return on
+        rec("P0: f16 + HF, weights exact", base)
+        rec("P1: f16 + HF, f16 weights (1x1 exact)", base, "f16", W16)
+        for keep in (["feature2"], ["eca_r"], ["decomp1x1"], ["feature2", "eca_r"], ["feature2", "eca_r", "decomp1x1"],
+                     ["feature2", "eca_r", "decomp1x1", "stem_twin"], ["feature2", "eca_r", "blend"], ["feature2", "eca_r", "res7x7"],
+                     ["feature2", "eca_r", "stream_out"], ["feature2", "eca_r", "stream_out", "blend"]):
+            rec("P1 + fp32 kept: %s" % "+".join(keep), plan(keep), "f16", W16)
+        for c in ("feature2", "eca_r", "decomp1x1"):
+            on = dict(base); on[c] = "f16c"
+            rec("P1 + %s centred" % c, on, "f16", W16)
+        if args.out:
+            json.dump(table, open(args.out, "w"), indent=1)
+        return
+    if args.phase == 2:
+        rec("stats pass", {c: "stat" for c in CLASSES})
+        for k, v in STATS.items():
+            print("  %-12s rms %.3f  mean|v| %.3f  max|v| %.2f  rms centred %.3f  median |chan mean|/std %.2f" % (
+                k, v["rms"], v["mean_abs"], v["absmax"], v["rms_centered"], v["chan_mean_over_std_median"]), flush=True)
+        allf = lambda f: {c: f for c in CLASSES}
+        for fmt in ("f16", "f16c", "e4m11", "e3m12"):
+            rec("all maps %s, weights exact" % fmt, allf(fmt))
+        on = allf("f16"); on["gf_lf"] = "hf16"
+        rec("all maps f16, GF writes HF (f16), weights exact", on)
+        rec("only gf HF in f16", {"gf_lf": "hf16"})
+        for c in sorted(set(CONV_CLASS)):
+            rec("weights f16 only in %s convs" % c, {}, "f16", {c})
+        rec("weights f16 only in the tail", {}, "f16", {"tail"})
+        table["_stats"] = STATS
+        if args.out:
+            json.dump(table, open(args.out, "w"), indent=1)
+        return
     for fmt in ("bf16", "f16"):
         rec("weights only %s" % fmt, {}, fmt)
         rec("all maps %s, weights exact" % fmt, {c: fmt for c in CLASSES})
