@@ -13,17 +13,18 @@ the C ABI.  One process per GPU; replicas only (no data-path collective: the pat
 
 Prints ONE JSON line on rank 0 (contract in the task statement): value = whole-job pairs/s, plus
   roofline     -- dominant kernel family = the dense 3x3 dilation-1 forward convs (12 launches per step): several instantiations picked by
-                  source count and storage mode (fp32 storage: conv_bf16x3_res / conv_bf16x3_ms / conv_mfma_bf16x3; bf16 storage: the
-                  LDS-DMA kernels conv3x3_bf16_dma<NSRC, NRES>); `roofline` aggregates the family and `roofline.kernels` lists each
+                  source count and storage mode (fp32 storage: conv_bf16x3_res / conv_bf16x3_ms / conv_mfma_bf16x3; 16-bit storage: the
+                  LDS-DMA kernels conv3x3_bf16_dma<NSRC, NRES, format>, format 1 = bf16, 2 = fp16); `roofline` aggregates the family and `roofline.kernels` lists each
                   member under the name rocprofv3 gives it; HIP-event timed on the launch stream inside the timed region.
                   roofline_other: the next kernels by time (guided filter, 7x7, 1x1 ...)
   cpu_baseline -- the CPU oracle (torch fp32 port of the reference) on the host cores, bounded sample, rank 0, N=1 only
   parity       -- which storage mode `value` was measured in and what the committed parity report says about it
 
-`--storage` (fusion / fusion_seg): `value` is measured in fp32 storage by default since round 4 -- the configuration that meets BOTH
-clauses of SURVEY 8(d) on the reference's (now multi-class, near-tie) 480x640 map.  The bf16 configuration BASELINE configs[1] names
-keeps mIoU within 0.1 pt but agrees with the reference's argmax on 98.75 % of the pixels, not 99.9 %
-(profiles/r04_bf16_storage_report.json, tests/test_bf16_storage_gpu.py); its rate is in the same line (`other_storage`).
+`--storage` (fusion / fusion_seg): since round 5 `value` is measured in the fp16 configuration (`f16`) -- the 16-bit storage mode that meets
+BOTH clauses of SURVEY 8(d) against the reference's own multi-class, near-tie predictions: argmax agreement 99.93 % over the eight 480x640
+samples of the benchmarked batch (per sample 99.87-99.97 %: `parity` lists them), mIoU within 0.01 pt
+(profiles/r05_f16_storage_report.json, tests/test_f16_storage_gpu.py).  The fp32-storage rate (round 4's `value`; 99.993 %) and the bf16
+rate (what BASELINE configs[1] names literally; 98.9 %, misses the clause) are in the same line (`other_storage`).
 """
 import argparse
 import json
@@ -82,13 +83,15 @@ def main():
                          "splits (six MFMAs per product, 2^-25 per product: fp32-level parity -- sign mismatch vs the reference's float64 run 0 "
                          "through PGD-10), GEMMs / attention exact fp32 MFMA; exact = fp32-exact MFMA kernels everywhere; fast = the split-bf16 "
                          "kernels there too (trajectory diverges: sign mismatch 2.5e-2 by iteration 10; tests/test_parity_default_gpu.py)")
-    ap.add_argument("--storage", choices=["f32", "bf16", "bf16_split", "f16"], default="f32",
-                    help="activation storage of the fusion network's inference forward (fusion / fusion_seg workloads): f32 (default since "
-                         "round 4) = every map fp32, parity at the fp32 tolerance: BOTH clauses of SURVEY 8(d) hold on the reference's multi-class "
-                         "480x640 map; bf16 = what BASELINE configs[1] names: the 32-channel maps behind the guided-filter block held as bf16, bf16 "
-                         "weights, one MFMA per product, fp32 accumulate -- mIoU within 0.1 pt, argmax agreement 98.75 %% (< the 99.9 %% clause; "
-                         "tests/test_bf16_storage_gpu.py).  The line also carries the OTHER modes' rates (`other_storage`), measured right after "
-                         "the timed region")
+    ap.add_argument("--storage", choices=["f32", "bf16", "bf16_split", "f16"], default="f16",
+                    help="activation storage of the fusion network's inference forward (fusion / fusion_seg workloads).  f16 (default since "
+                         "round 5) = the 16-bit configuration that meets SURVEY 8(d)'s clause: IEEE fp16 maps behind the guided-filter block and "
+                         "fp16 weights, one fp16 MFMA per product, fp32 accumulate, HF = x - LF out of the guided filter, fp32 last map: argmax "
+                         "agreement with the reference 99.93 %% over the 8 samples of the benchmarked batch (per sample 99.87 ... 99.97 %%), mIoU "
+                         "within 0.01 pt (tests/test_f16_storage_gpu.py).  f32 = every map fp32 (round 4's default; 99.993 %%).  bf16 = what "
+                         "BASELINE configs[1] names literally: bf16 maps and weights -- mIoU within 0.1 pt, argmax agreement 98.9 %% (misses the "
+                         "99.9 %% clause).  The line also carries the OTHER modes' rates (`other_storage`), measured right after the timed region; "
+                         "taped (pgd / train) passes always run fp32 storage")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the passes that run after the timed region (other storage modes, two-stream, sustained): clean rocprofv3 / PMC "
                          "summaries of ONE configuration")
@@ -452,6 +455,7 @@ def main():
             "dtype": ("f32" if args.conv_precision == "f32" else
                       ("f32 (storage and accumulation f32; conv products as split-bf16: 3x bf16 MFMA)" if args.storage == "f32" or args.workload in ("pgd", "train")
                        else ("bf16 (maps and conv weights bf16, one bf16 MFMA per product, f32 accumulate; stems and guided filter fp32)" if args.storage == "bf16"
+                             else "f16 (IEEE fp16 maps and conv weights, one fp16 MFMA per product, f32 accumulate; stems, guided filter and the last map fp32)" if args.storage == "f16"
                              else "bf16 storage / f32 accumulate (conv weights split-bf16 hi + lo: 2 MFMAs per product; stems and guided filter fp32)")))
                      + ("" if args.workload == "fusion" else "; SegFormer GEMMs: %s" % {"f32": "exact fp32 MFMA", "bf16x3": "split-bf16",
                                                                                       "auto": "exact fp32 MFMA, split-bf16 where K >= 256"}[args.gemm_precision]
@@ -469,8 +473,10 @@ def main():
                                                 else "no all-reduce at N=1", args.backbone)}[args.workload]
                                    + ", 480x640, bs=%d/GPU, %s, conv precision %s" % (
                                        bpg, "fp32 storage" if args.storage == "f32" or args.workload in ("pgd", "train") else
-                                       "bf16 storage of the 32-channel maps behind the guided-filter block (fp32 stems / guided filter / accumulation)",
-                                       args.conv_precision if args.storage != "bf16" or args.workload in ("pgd", "train") else "bf16 (bf16 weights, 1 MFMA per product)"),
+                                       "%s storage of the 32-channel maps behind the guided-filter block (fp32 stems / guided filter / accumulation)" % (
+                                           "fp16" if args.storage == "f16" else "bf16"),
+                                       args.conv_precision if args.storage not in ("bf16", "f16") or args.workload in ("pgd", "train") else
+                                       "%s (%s weights, 1 MFMA per product)" % (("fp16", "fp16") if args.storage == "f16" else ("bf16", "bf16"))),
                        "batch_per_gpu": bpg,
                        "parallelism": ("dp%d: batch sharded, weights replicated, 179.5 MB fp32 gradient all-reduce (25 MB buckets) per step" % world
                                        if args.workload == "train" else "replicas x%d (no data-path collective)" % world)},
@@ -496,7 +502,8 @@ def main():
         if other_storage:
             res["other_storage"] = [{"storage": m_, "value": pairs / t_, "ms_per_step": t_ / args.steps * 1e3} for m_, t_ in other_storage]
             res["other_storage_note"] = ("the same K steps in the other storage modes (ops.set_storage), run right after the timed region: f32 = fp32 maps, "
-                                         "split-bf16 products (3 MFMAs, fp32-level parity); bf16_split = bf16 maps, split-bf16 weights (2 MFMAs); "
+                                         "split-bf16 products (3 MFMAs, fp32-level parity); f16 = fp16 maps and weights, one fp16 MFMA per product; "
+                                         "bf16_split = bf16 maps, split-bf16 weights (2 MFMAs); "
                                          "bf16 = bf16 maps and weights, one bf16 MFMA per product (BASELINE configs[1])")
         if args.two_stream:
             res["mode"] = (res["mode"] + "; " if "mode" in res else "") + (
@@ -591,20 +598,28 @@ ST_MFMAS = {0: 3, 1: 2, 2: 3, 3: 3, 4: 1, 5: 2, 6: 1, 7: 1, 9: 2, 12: 1, 14: 1, 
 
 
 def parity_block(storage):
-    """What the committed parity report (tests/test_bf16_storage_gpu.py::test_fusion_forward_bf16_storage_tolerance_clause on MI355X,
-    copied to profiles/) says about the storage mode `value` was measured in: SURVEY 8(d)'s two clauses on the reference's 480x640
-    mit_b3 map (calibrated head: 9 classes, median top-2 margin 1.6 % of the logit range)."""
-    out = {"storage": storage, "source": "profiles/r04_bf16_storage_report.json"}
+    """What the committed parity report (tests/test_f16_storage_gpu.py::test_fusion_forward_f16_storage_tolerance_clause on MI355X, copied
+    to profiles/) says about the storage mode `value` was measured in: SURVEY 8(d)'s two clauses against the REFERENCE's own mit_b3
+    predictions (calibrated head: multi-class maps, median top-2 margin 1.6-5 % of the logit range) on the eight 480x640 samples of the
+    benchmarked batch (2.46 M pixels), and the per-sample figures (a single sample is a noisy statistic at the 1e-3 level)."""
+    src = "profiles/r05_f16_storage_report.json"
+    out = {"storage": storage, "source": src}
     try:
-        rep = json.load(open(os.path.join(ROOT, "profiles", "r04_bf16_storage_report.json")))
+        rep = json.load(open(os.path.join(ROOT, src)))
         r = rep[storage]
-        out.update({"argmax_agreement_vs_reference": r["argmax_agreement_vs_reference"], "miou_delta_vs_reference": r["miou_delta_vs_reference"],
-                    "logits_max_abs_over_range": r["logits_max_abs_over_range"], "fused_max_abs_vs_fp64": r["fused_max_abs_vs_fp64"],
-                    "clause_argmax_ge_0.999": bool(r["argmax_agreement_vs_reference"] >= 0.999),
-                    "clause_miou_within_0.1pt": bool(abs(r["miou_delta_vs_reference"]) <= 1e-3)})
-        if storage != "f32":
-            out["note"] = ("this storage mode keeps mIoU within 0.1 pt but NOT the 99.9 % argmax clause on the near-tie map; the default "
-                           "(--storage f32) meets both")
+        out.update({"argmax_agreement_vs_reference_8_samples": r["argmax_agreement_8_samples"],
+                    "argmax_agreement_vs_reference_per_sample": r["argmax_agreement_per_sample"],
+                    "miou_delta_vs_reference_8_samples": r["miou_delta_8_samples"], "miou_delta_vs_reference_sample0": r["miou_delta_sample0"],
+                    "logits_max_abs_over_range_sample0": r["logits_max_abs_over_range"], "fused_max_abs_vs_fp64_sample0": r["fused_max_abs_vs_fp64"],
+                    "fused_mean_abs_vs_fp64_sample0": r["fused_mean_abs_vs_fp64"],
+                    "clause_argmax_ge_0.999": bool(r["argmax_agreement_8_samples"] >= 0.999),
+                    "clause_argmax_ge_0.999_on_every_sample": bool(min(r["argmax_agreement_per_sample"]) >= 0.999),
+                    "clause_miou_within_0.1pt": bool(abs(r["miou_delta_8_samples"]) <= 1e-3 and abs(r["miou_delta_sample0"]) <= 1e-3)})
+        if not out["clause_argmax_ge_0.999"]:
+            out["note"] = "this storage mode keeps mIoU within 0.1 pt but NOT the 99.9 % argmax clause; --storage f16 / f32 meet both"
+        elif not out["clause_argmax_ge_0.999_on_every_sample"]:
+            out["note"] = ("the 99.9 % clause holds on the 8-sample evaluation set, not on every sample taken alone (sample-to-sample spread of a "
+                           "near-tie statistic); --storage f32 holds it on every sample")
     except (OSError, ValueError, KeyError) as e:
         out["note"] = "parity report unreadable: %s" % e
     return out

@@ -165,7 +165,7 @@ class Cell_Decom(nn.Module):
         else:
             lf_ir, ab_ir = self.decomposition_nhwc(fir, g_ir, want_ab=True)
             lf_vis, ab_vis = self.decomposition_nhwc(fvis, g_vis, want_ab=True)
-        # fp16 configuration: the filter wrote HF = x - LF (fp16) and the 1x1 folds over [x, HF1, HF2] with fp16 hi + lo weights
+        # fp16 configuration: the filter wrote HF = x - LF (fp16) and the 1x1 folds over [x, HF1, HF2]
         pack1, pn = (ops.pack_decomp1x1_hf_weight, "_hf16") if lf16 is torch.float16 else (ops.pack_decomp1x1_weight, "")
         w_lf = self._packs.get("lf" + pn, [self.conv1x1_lf.weight], lambda: pack1(self.conv1x1_lf.weight))
         w_hf = self._packs.get("hf" + pn, [self.conv1x1_hf.weight], lambda: pack1(self.conv1x1_hf.weight))
@@ -357,7 +357,7 @@ class Network_Fusion_Searched(nn.Module):
                 vis_feature.record_stream(main)
             del fvis, g_vis
             agg = self.spa.blend_nhwc(ir_feature, vis_feature)
-            return self._tail_nhwc(self.chain.forward_nhwc(agg, (), None, out_f32=ops._ACT_BF16[0] is torch.float16))
+            return self._tail_nhwc(self.chain.forward_nhwc(agg, (), None, out_f32=self._last_f32()))
         fir, g_ir = ops.stem(ir, self.stem_1[0].weight, self.stem_1[1].weight)
         fvis, g_vis = ops.stem(vis, self.stem_2[0].weight, self.stem_2[1].weight)
         t_dec = None if tape is None else {}
@@ -374,7 +374,7 @@ class Network_Fusion_Searched(nn.Module):
         else:
             agg, scale = self.spa.blend_nhwc(ir_feature, vis_feature, want_scale=True)
         # fp16 storage: the forward's last 32-channel map (largest magnitudes, straight into the fused image) stays fp32
-        feature2 = self.chain.forward_nhwc(agg, (), t_chain, out_f32=tape is None and ops._ACT_BF16[0] is torch.float16)
+        feature2 = self.chain.forward_nhwc(agg, (), t_chain, out_f32=tape is None and self._last_f32())
         if tape is None:
             out = self._tail_nhwc(feature2)
         else:
@@ -387,6 +387,10 @@ class Network_Fusion_Searched(nn.Module):
         if inter is not None:
             inter.update(fir=fir, fvis=fvis, ir_feature=ir_feature, vis_feature=vis_feature, agg=agg, feature2=feature2)
         return out
+
+    @staticmethod
+    def _last_f32():
+        return ops._ACT_BF16[0] is torch.float16 and ops.CONFIG.get("f16_last_f32", True)      # (ablation switch)
 
     def _tail_nhwc(self, feature2):
         """stem_out + tanh of the inference forward (no tape)."""

@@ -72,8 +72,8 @@ def set_storage(mode):
     "bf16_split": bf16 maps, weights kept as split-bf16 hi + lo (2 MFMAs per product: only the maps are rounded).
     "f16":        round 5 -- the 16-bit configuration that meets SURVEY 8(d)'s argmax clause: IEEE fp16 maps (11 significant bits where
                   bf16 has 8) and fp16 weights, one fp16 MFMA per product, fp32 accumulate; the guided filter writes HF = x - LF (small
-                  magnitudes), the folded 1x1 behind it keeps fp16 hi + lo weights (2 MFMAs), and the forward's last 32-channel map
-                  (the input of stem_out) stays fp32.  Why these three: tools/storage_sensitivity.py, DESIGN section 2."""
+                  magnitudes) and the 1x1 behind it folds over [x, HF1, HF2]; the forward's last 32-channel map (the input of
+                  stem_out) stays fp32.  Why: tools/storage_sensitivity.py, tools/f16_ablation.py, DESIGN section 2."""
     if mode not in STORAGE_MODES:
         raise ValueError("storage must be one of %s" % (STORAGE_MODES,))
     CONFIG["storage"] = mode
@@ -526,7 +526,9 @@ def pack_decomp1x1_hf_weight(w):
     L = lib()
     wpk = torch.empty(L.paif_conv_wpk_floats(3, 32, 1), device=w.device, dtype=torch.float32)
     _lib.check(L.paif_pack_decomp1x1_hf_weight_f16x2(_p(w.detach().contiguous()), _p(wpk), _stream()), "pack_decomp1x1_hf_weight_f16x2")
-    return PackedWeight(wpk, "f16x2")
+    # one fp16 MFMA per product like every other conv of the mode: on the real kernels the hi + lo form ("f16x2", CONFIG
+    # "f16_decomp_split") buys nothing once the filter stores HF (tools/f16_ablation.py: 99.928 % vs 99.931 % over 8 samples, 23 us)
+    return PackedWeight(wpk, "f16x2" if CONFIG.get("f16_decomp_split", False) else "f16")
 
 
 def bn_fold(weight, bias, mean, var, eps):
