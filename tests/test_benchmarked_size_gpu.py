@@ -1,0 +1,133 @@
+"""GPU tests AT THE BENCHMARKED SIZE of BASELINE configs[3] / configs[4]: `attack_both` and the adversarial-
+training step at B = 8, 480x640, mit_b3 -- the shapes `bench.py --workload pgd | train` time.  The persistent kernels' tile ranges
+straddle images only when B > 1 at full size, and the taped passes keep ~25-40 GB of activations: nothing at 2x64x96 exercises that.
+
+Oracle-free properties (an fp32 torch-CPU PGD iteration at this size takes minutes): sample-wise equality with the B = 1 run on a
+batch of identical samples (every op of the path is per-sample except the glue's batch-global min/max, which a batch of copies
+leaves unchanged; the loss's 1/#valid factor scales by exactly 1/8), the eps-ball / [0, 1] box of the reference's update rule
+(attack/attack.py:504-512) on eight different samples, a growing loss, finite values; for the training step: a finite loss, a
+gradient on every parameter that has one in the reference (two never do), full coverage of the gradient arena, every
+such parameter moved by the optimizer."""
+import numpy as np
+import pytest
+import torch
+
+from paif_amd import ops, synthetic as S
+from tests.helpers import t
+
+pytestmark = pytest.mark.gpu
+EPS, ALPHA = 8 / 255., 2 / 255.
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _model(train=False):
+    from paif_amd.core.loss import Fusionloss_grad2
+    from paif_amd.core.model_fusion_auto import Network_MM_Searched
+    from paif_amd.genotypes import FUSION_AT
+
+    m = Network_MM_Searched(32, FUSION_AT, Fusionloss_grad2(), torch.nn.CrossEntropyLoss(ignore_index=255), "mit_b3", num_classes=9)
+    S.load_formula_weights(m)
+    return (m.train() if train else m.eval()).to(_dev())
+
+
+def test_attack_both_pgd2_at_b8_480x640_mit_b3():
+    from paif_amd.attack.attack import attack_both
+
+    dev = _dev()
+    m = _model()
+    ir, vis, lab = S.make_batch(8, 480, 640)
+    d0i, d0v = S.make_delta0(3, ir.shape, EPS), S.make_delta0(103, vis.shape, EPS)
+    kw = dict(epsilon=EPS, alpha=ALPHA, attack_iters=2, attack_loss="l_seg", attack_way="PGD")
+    # (a) eight DIFFERENT samples, the default attack arithmetic (what bench.py --workload pgd runs)
+    trace = []
+    with torch.no_grad():
+        d_ir, d_vis = attack_both(m, t(vis).to(dev), t(ir).to(dev), t(lab).to(dev), delta0_ir=t(d0i).to(dev), delta0_vis=t(d0v).to(dev),
+                                  trace=trace, **kw)
+    for d, x in ((d_ir, ir), (d_vis, vis)):
+        a = d.detach().cpu().numpy()
+        assert np.isfinite(a).all() and np.abs(a).max() <= EPS + 1e-7
+        assert (x + a).min() >= -1e-7 and (x + a).max() <= 1.0 + 1e-7                   # clamp(delta, 0 - X, 1 - X)
+        assert float((np.abs(a) > 0.5 * ALPHA).mean()) > 0.5                             # the attack moved most pixels
+    assert len(trace) == 2 and all(np.isfinite(s["loss"]) for s in trace) and trace[1]["loss"] > trace[0]["loss"]
+    for b in range(8):                                                                   # every sample of the batch received a gradient
+        assert float(d_ir.grad[b].abs().sum()) > 0 and float(d_vis.grad[b].abs().sum()) > 0
+    del d_ir, d_vis, trace
+    # (b) a batch of eight COPIES of sample 0 against the B = 1 run: per-sample arithmetic must not depend on the batch position
+    rep = lambda a: np.repeat(a[:1], 8, axis=0)
+    with torch.no_grad():
+        d8_ir, d8_vis = attack_both(m, t(rep(vis)).to(dev), t(rep(ir)).to(dev), t(rep(lab)).to(dev), delta0_ir=t(rep(d0i)).to(dev),
+                                    delta0_vis=t(rep(d0v)).to(dev), **kw)
+        d1_ir, d1_vis = attack_both(m, t(vis[:1]).to(dev), t(ir[:1]).to(dev), t(lab[:1]).to(dev), delta0_ir=t(d0i[:1]).to(dev),
+                                    delta0_vis=t(d0v[:1]).to(dev), **kw)
+    for d8, d1 in ((d8_ir, d1_ir), (d8_vis, d1_vis)):
+        for b in range(8):
+            diff = float((d8[b:b + 1].detach() != d1.detach()).float().mean())
+            # bit-equal up to the two min / max pixels of the glue (their gradient share is a sum over the batch: 8 x a value is not
+            # always that value's fp32 sum) and whatever sign flips they seed in the second iteration
+            assert diff <= 1e-5, (b, diff)
+    assert torch.equal(d8_ir[0].detach(), d8_ir[7].detach()) and torch.equal(d8_vis[0].detach(), d8_vis[5].detach())
+
+
+def test_training_step_at_b8_480x640_mit_b3():
+    """What `bench.py --workload train` times: PGD-2 attack (eval mode) + `_loss_coupled` forward / backward (train mode: BatchNorm batch
+    statistics, DropPath, Dropout2d) + one PolyWarmupAdamW step, B = 8 at 480x640."""
+    from paif_amd.attack.attack import attack_both
+    from paif_amd.utils.optimizer import PolyWarmupAdamW
+
+    dev = _dev()
+    m = _model()
+    pg = m.denoise_net.get_param_groups()
+    opt = PolyWarmupAdamW(params=[dict(params=pg[0], lr=8e-5, weight_decay=0.01), dict(params=pg[1], lr=8e-5, weight_decay=0.0),
+                                  dict(params=pg[2], lr=8e-4, weight_decay=0.01),
+                                  dict(params=list(m.enhance_net.parameters()), lr=8e-5, weight_decay=0.01)],
+                          lr=8e-5, weight_decay=0.01, betas=(0.9, 0.999), warmup_iter=3000, max_iter=160000, warmup_ratio=1e-5, power=1.0)
+    arena = opt.arena()
+    ir, vis, lab = S.make_batch(8, 480, 640)
+    irt, vist, labt = t(ir).to(dev), t(vis).to(dev), t(lab).to(dev)
+    mask = t(np.maximum(ir, vis[:, :1]).astype(np.float32)).to(dev)
+    before = arena.param.clone()
+    with torch.no_grad():
+        d_ir, d_vis = attack_both(m, vist, irt, labt, epsilon=EPS, alpha=ALPHA, attack_iters=2, attack_loss="l_seg", attack_way="PGD",
+                                  delta0_ir=t(S.make_delta0(0, ir.shape, EPS)).to(dev), delta0_vis=t(S.make_delta0(100, vis.shape, EPS)).to(dev))
+    assert all(p.grad is None for p in m.parameters())                 # the attack differentiates w.r.t. the input only
+    m.train()
+    ops.DROP_RNG.reseed(20261003, rank=0, step=0)
+    opt.zero_grad()
+    loss = m._loss_coupled((ops.add(irt, d_ir.detach()), irt), (ops.add(vist, d_vis.detach()), vist), mask, labt)
+    loss.backward()
+    assert np.isfinite(float(loss)) and float(loss) > 0
+    dead = {"denoise_net.classifier.weight", "enhance_net.decompation.relu.weight"}      # never receive a gradient in the reference either
+    covered = torch.zeros(arena.total, dtype=torch.bool, device=dev)
+    n_grad = 0
+    for k, p in m.named_parameters():
+        if k in dead:
+            assert p.grad is None or float(p.grad.abs().sum()) == 0.0, k
+            continue
+        assert p.grad is not None, k
+        assert p.grad.data_ptr() == p._paif_grad_view.data_ptr(), k                        # written in place into the arena, no copy
+        assert bool(torch.isfinite(p.grad).all()), k
+        assert float(p.grad.abs().sum()) > 0.0, k
+        o, _ = arena.range_of[id(p)]
+        covered[o:o + p.numel()] = True
+        n_grad += 1
+    assert n_grad == 623
+    # arena coverage: every element of the gradient arena outside the parameters' slots (chunk padding, dead tail) is still zero, and
+    # the slots of the live parameters hold the gradients asserted above
+    assert float(arena.grad[~covered].abs().sum()) == 0.0
+    assert int(covered.sum()) == sum(p.numel() for k, p in m.named_parameters() if k not in dead)
+    opt.global_step = 3000             # past the warm-up: at step 0 the schedule's factor is 1e-5 and lr * sign(g) = 8e-10 is below an ulp of most weights
+    opt.step()
+    torch.cuda.synchronize()
+    after = arena.param
+    assert bool(torch.isfinite(after).all())
+    for k, p in m.named_parameters():
+        o, _ = arena.range_of[id(p)]
+        moved = bool((after[o:o + p.numel()] != before[o:o + p.numel()]).any())
+        assert moved == (k not in dead), k
+    # BatchNorm running statistics moved (train-mode forward), num_batches_tracked counted one batch
+    sd = m.state_dict()
+    assert all(int(v) == 1 for k, v in sd.items() if k.endswith("num_batches_tracked"))
