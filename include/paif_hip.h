@@ -152,6 +152,10 @@ typedef struct {
   int storage;           /* PAIF_ST_*: storage of the 32-channel activation maps (src / res / out are then `unsigned short` bf16 data behind
                             the float* fields).  BASELINE configs[1] "bf16": fp32 accumulate, bf16 maps, round-to-nearest-even on store.
                             Built for the split-bf16 kernels of the inference forward (no gradient hooks) */
+  float* cpool;          /* optional (round 5; cout = 32): ChannelPool of the OUTPUT map fused into the epilogue (core/model_fusion_auto.py:1352-1355):
+                            cpool[4 * pixel + 0] = max_c out, cpool[4 * pixel + 1] = mean_c out (fp32, from the un-rounded fp32 values).  The pointer is
+                            pre-offset by 0 (infrared map) or 2 (visible map) floats into the [B,H,W,4] plane spatial_attn_layer_M reads.  Only the
+                            kernels paif_conv2d_can_cpool() reports; paif_channel_pool1_fwd* is the stand-alone pass otherwise.  LAST field */
 } paif_conv_desc;
 #define PAIF_ST_F32 0          /* fp32 maps in, fp32 maps out (default) */
 #define PAIF_ST_BF16 1         /* bf16 in, bf16 out */
@@ -200,6 +204,13 @@ int paif_add_fwd_f16(const float* a, const float* b, float* out, size_t n, paif_
 
 int paif_conv2d_blocks(int B, int H, int W);
 int paif_conv2d_fwd(const paif_conv_desc* d, int B, int H, int W, paif_stream_t stream);
+/* 1 if the kernel paif_conv2d_fwd runs for this descriptor / shape writes d->cpool (the fused ChannelPool of its output), else 0. */
+int paif_conv2d_can_cpool(const paif_conv_desc* d, int B, int H, int W);
+/* ChannelPool of ONE NHWC-32 map into the interleaved [B,H,W,4] plane (comp_off = comp + 0 or + 2): comp_off[4 p] = max_c x, comp_off[4 p + 1] =
+ * mean_c x -- the stand-alone pass for producers whose epilogue does not pool (core/model_fusion_auto.py:1352-1355).  fp32 / bf16 / fp16 maps. */
+int paif_channel_pool1_fwd(const float* x, float* comp_off, int B, int H, int W, paif_stream_t stream);
+int paif_channel_pool1_fwd_bf16(const float* x, float* comp_off, int B, int H, int W, paif_stream_t stream);
+int paif_channel_pool1_fwd_f16(const float* x, float* comp_off, int B, int H, int W, paif_stream_t stream);
 /* 1 if paif_conv2d_fwd would run this descriptor on the persistent wave-specialised kernel (conv_bf16x3_ws),
  * 0 for the tile-per-workgroup kernel (conv_mfma_*): lets a profiler-side caller name the kernel it times. */
 int paif_conv2d_is_persistent(const paif_conv_desc* d, int B, int H, int W);

@@ -21,7 +21,7 @@ class ConvDesc(Structure):
         ("in_act", c_int), ("in_prelu", F), ("scale", F), ("shift", F), ("act", c_int), ("prelu", F),
         ("alpha", c_float), ("res", F * 3), ("out", F), ("cout", c_int), ("pool_partial", F),
         ("precision", c_int), ("aux_out", F), ("in_aux", F), ("in_scale", F), ("in_alpha", c_float), ("epi_aux", F),
-        ("epi_dact", c_int), ("reverse_tiles", c_int), ("storage", c_int),
+        ("epi_dact", c_int), ("reverse_tiles", c_int), ("storage", c_int), ("cpool", F),
     ]
 
 
@@ -49,6 +49,10 @@ SIGNATURES = {
     "paif_conv2d_blocks": (c_int, [c_int, c_int, c_int]),
     "paif_conv2d_fwd": (c_int, [POINTER(ConvDesc), c_int, c_int, c_int, F]),
     "paif_conv2d_is_persistent": (c_int, [POINTER(ConvDesc), c_int, c_int, c_int]),
+    "paif_conv2d_can_cpool": (c_int, [POINTER(ConvDesc), c_int, c_int, c_int]),
+    "paif_channel_pool1_fwd": (c_int, [F, F, c_int, c_int, c_int, F]),
+    "paif_channel_pool1_fwd_bf16": (c_int, [F, F, c_int, c_int, c_int, F]),
+    "paif_channel_pool1_fwd_f16": (c_int, [F, F, c_int, c_int, c_int, F]),
     "paif_conv2d_kernel_name": (c_int, [POINTER(ConvDesc), c_int, c_int, c_int, c_char_p, c_int]),
     "paif_conv_wpk_floats": (c_size_t, [c_int, c_int, c_int]),
     "paif_pack_conv_weight": (c_int, [F, F, c_int, c_int, c_int, c_int, F]),

@@ -50,9 +50,18 @@ class MixedOp(nn.Module):
     def forward(self, x):
         return self._op(x)
 
-    def forward_nhwc(self, x, res=(), tape=None, out_f32=False):
+    def forward_nhwc(self, x, res=(), tape=None, out_f32=False, cpool=None):
+        """out_f32 / cpool: requests of the inference forward to the LAST op of a chain -- an fp32 output map from fp16 sources; the
+        ChannelPool of the output written into cpool = (comp, offset).  Honoured inside the op where its last conv can (one launch
+        less), by a cast / a stand-alone pooling pass here otherwise."""
         if out_f32 and getattr(self._op, "takes_out_f32", False):
             return self._op.forward_nhwc(x, res, tape, out_f32=True)
+        if cpool is not None and tape is None:
+            if getattr(self._op, "takes_cpool", False):
+                return self._op.forward_nhwc(x, res, tape, cpool=cpool)
+            y = self._op.forward_nhwc(x, res, tape)
+            ops.channel_pool1(y, *cpool)
+            return y
         return self._op.forward_nhwc(x, res, tape)
 
     def backward_nhwc(self, g, t, wgrad=False, res=()):
@@ -86,12 +95,14 @@ class Cell_Chain(_HipOp):
             self._ops += [MixedOp(C, name)]
         self._indices = indices
 
-    def forward_nhwc(self, inp, res=(), tape=None, out_f32=False):
-        """out_f32 (fp16-storage inference forward): ask the last op for an fp32 output map (honoured where its kernel exists)."""
+    def forward_nhwc(self, inp, res=(), tape=None, out_f32=False, cpool=None):
+        """out_f32 (fp16-storage inference forward): ask the last op for an fp32 output map (honoured where its kernel exists);
+        cpool = (comp, offset): the ChannelPool of the chain's output goes into comp[..., offset:offset+2] (MixedOp.forward_nhwc)."""
         s1 = inp
         for i in range(self._steps):
             last = i == self._steps - 1
-            s1 = self._ops[i].forward_nhwc(s1, ((inp,) + tuple(res)) if last else (), tape, out_f32=out_f32 and last)
+            s1 = self._ops[i].forward_nhwc(s1, ((inp,) + tuple(res)) if last else (), tape, out_f32=out_f32 and last,
+                                           cpool=cpool if last else None)
         return s1
 
     def backward_nhwc(self, g, tape, wgrad=False):
@@ -150,8 +161,9 @@ class Cell_Decom(nn.Module):
         xn = ops.to_nhwc(x)
         return self._cat_lf_hf(xn, self.decomposition_nhwc(xn))
 
-    def forward_nhwc(self, fir, fvis, g_ir=None, g_vis=None, tape=None, feats=None):
-        """feats (dict): receives the decomposition intermediates (LF maps, residues) for the visualisation path."""
+    def forward_nhwc(self, fir, fvis, g_ir=None, g_vis=None, tape=None, feats=None, comp=None):
+        """feats (dict): receives the decomposition intermediates (LF maps, residues) for the visualisation path.
+        comp ([B,H,W,4] fp32, inference): receives ChannelPool(ir_feature, vis_feature) (:1352-1355) from the two chains' last convs."""
         if g_ir is None:
             g_ir = ops.channel_residue(fir)
         if g_vis is None:
@@ -176,15 +188,16 @@ class Cell_Decom(nn.Module):
         hf = ops.conv2d([x_vis, lf_vis[0], lf_vis[1]], w_hf, 1, 1, shift=self.conv1x1_hf.bias)
         t1 = None if tape is None else []
         t2 = None if tape is None else []
-        ir_feature = self.chain.forward_nhwc(lf, (fir,), t1)      # lf_re + inp_ir
-        vis_feature = self.chain2.forward_nhwc(hf, (fvis,), t2)   # hf_re + inp_vis
+        cp = comp if tape is None else None
+        ir_feature = self.chain.forward_nhwc(lf, (fir,), t1, cpool=None if cp is None else (cp, 0))      # lf_re + inp_ir
+        vis_feature = self.chain2.forward_nhwc(hf, (fvis,), t2, cpool=None if cp is None else (cp, 2))   # hf_re + inp_vis
         if tape is not None:
             tape.update(fir=fir, fvis=fvis, g_ir=g_ir, g_vis=g_vis, ab_ir=ab_ir, ab_vis=ab_vis, chain=t1, chain2=t2)
             if ops.taping_wgrad():
                 tape.update(lf_ir=lf_ir, lf_vis=lf_vis)
         return ir_feature, vis_feature
 
-    def branch_nhwc(self, f, g, which):
+    def branch_nhwc(self, f, g, which, comp=None):
         """One stream of forward_nhwc (inference, no tape): guided-filter decomposition of the stem map f with guide g, the folded 1x1,
         the stream's chain (+ f).  which: 0 = infrared (conv1x1_lf, chain), 1 = visible (conv1x1_hf, chain2).  The two streams are
         independent up to the spatial blend: Network_Fusion_Searched runs them on two HIP streams (ops.CONFIG["two_stream"])."""
@@ -195,7 +208,7 @@ class Cell_Decom(nn.Module):
         w = self._packs.get(("lf" if which == 0 else "hf") + pn, [conv.weight], lambda: pack1(conv.weight))
         x = ops.cast_storage(f, True) if lf16 else f
         y = ops.conv2d([x, lf[0], lf[1]], w, 1, 1, shift=conv.bias)
-        return (self.chain if which == 0 else self.chain2).forward_nhwc(y, (f,), None)
+        return (self.chain if which == 0 else self.chain2).forward_nhwc(y, (f,), None, cpool=None if comp is None else (comp, 2 * which))
 
     def _stream_backward(self, d_feat, chain, chain_tape, conv, name, feat, guide, ab, lf=None):
         """One stream: d/d(ir_feature) -> d/d(stem feature).  lf (the stream's two LF maps): also the 1x1's parameter gradients."""
@@ -275,8 +288,10 @@ class spatial_attn_layer_M(nn.Module):
         self.compress = ChannelPool()
         self.spatial = BasicConv(4, 1, kernel_size, relu=False)
 
-    def blend_nhwc(self, ir, vis, want_scale=False, want_comp=False):
-        comp = ops.channel_pool2(ir, vis)
+    def blend_nhwc(self, ir, vis, want_scale=False, want_comp=False, comp=None):
+        """comp: ChannelPool(ir, vis) already written by the producers of ir / vis (paif_conv_desc.cpool); None = pooled here."""
+        if comp is None:
+            comp = ops.channel_pool2(ir, vis)
         r = ops.spa_blend(comp, self.spatial.conv.weight, ir, vis, want_scale)
         return (r + (comp,)) if want_comp else r
 
@@ -343,12 +358,13 @@ class Network_Fusion_Searched(nn.Module):
             side = self.__dict__.get("_side_stream")
             if side is None or side.device != ir.device:
                 side = self.__dict__["_side_stream"] = torch.cuda.Stream(device=ir.device)
+            comp = self._new_comp(ir)
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 fvis, g_vis = ops.stem(vis, self.stem_2[0].weight, self.stem_2[1].weight)
-                vis_feature = self.decompation.branch_nhwc(fvis, g_vis, 1)
+                vis_feature = self.decompation.branch_nhwc(fvis, g_vis, 1, comp)
             fir, g_ir = ops.stem(ir, self.stem_1[0].weight, self.stem_1[1].weight)
-            ir_feature = self.decompation.branch_nhwc(fir, g_ir, 0)
+            ir_feature = self.decompation.branch_nhwc(fir, g_ir, 0, comp)
             main.wait_stream(side)
             # vis_feature lives in the side stream's allocator pool and is consumed here.  Its block can only be handed out again to a
             # side-stream allocation, i.e. after the next forward's side.wait_stream(main) -- behind everything this stream does with it;
@@ -356,19 +372,19 @@ class Network_Fusion_Searched(nn.Module):
             if not torch.cuda.is_current_stream_capturing():
                 vis_feature.record_stream(main)
             del fvis, g_vis
-            agg = self.spa.blend_nhwc(ir_feature, vis_feature)
+            agg = self.spa.blend_nhwc(ir_feature, vis_feature, comp=comp)
             return self._tail_nhwc(self.chain.forward_nhwc(agg, (), None, out_f32=self._last_f32()))
         fir, g_ir = ops.stem(ir, self.stem_1[0].weight, self.stem_1[1].weight)
         fvis, g_vis = ops.stem(vis, self.stem_2[0].weight, self.stem_2[1].weight)
         t_dec = None if tape is None else {}
         feats = {} if (inter is not None and inter.get("want_decomposition")) else None
-        ir_feature, vis_feature = self.decompation.forward_nhwc(fir, fvis, g_ir, g_vis, t_dec, feats)
+        comp = self._new_comp(ir) if tape is None else None
+        ir_feature, vis_feature = self.decompation.forward_nhwc(fir, fvis, g_ir, g_vis, t_dec, feats, comp=comp)
         if feats is not None:
             inter.update(feats)
         t_chain = None if tape is None else []
-        comp = None
         if tape is None:
-            agg = self.spa.blend_nhwc(ir_feature, vis_feature)
+            agg = self.spa.blend_nhwc(ir_feature, vis_feature, comp=comp)
         elif ops.taping_wgrad():
             agg, scale, comp = self.spa.blend_nhwc(ir_feature, vis_feature, want_scale=True, want_comp=True)
         else:
@@ -387,6 +403,14 @@ class Network_Fusion_Searched(nn.Module):
         if inter is not None:
             inter.update(fir=fir, fvis=fvis, ir_feature=ir_feature, vis_feature=vis_feature, agg=agg, feature2=feature2)
         return out
+
+    @staticmethod
+    def _new_comp(img):
+        """The [B,H,W,4] plane ChannelPool(ir_feature, vis_feature) is written into by the two chains' last convs (inference forward)."""
+        if not ops.CONFIG.get("cpool_fused", True):
+            return None
+        B, _, H, W = img.shape
+        return torch.empty((B, H, W, 4), device=img.device, dtype=torch.float32)
 
     @staticmethod
     def _last_f32():

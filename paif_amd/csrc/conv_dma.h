@@ -16,6 +16,7 @@ struct Args {
   int nsrc, nres, act, kh;   // kh: 3 or 7
   int cout;                  // 32, or 16 (3x3, one source, no residual maps)
   int B, H, W, reverse;
+  float* cpool;              // optional: fused ChannelPool of the output (paif_conv_desc.cpool); built for (3 sources, 1 or 3 residual maps)
   int f16;                   // 1: the maps and weights are IEEE fp16 (PAIF_ST_F16 / PAIF_CONV_F16; the fp16 hi pieces of the F16X2 pack), else bf16
 };
 
@@ -23,6 +24,7 @@ struct Args {
 bool eligible(int nsrc, int nres, int B, int H, int W, float alpha);
 bool eligible16(int nsrc, int nres, int B, int H, int W, float alpha);  // 3x3 with 16 output channels: one source, no residual maps
 bool eligible7(int nsrc, int nres, int B, int H, int W, float alpha);   // the 7x7 form: one source, no residual maps
+bool can_cpool(int nsrc, int nres, int kh, int cout);   // the instantiations that write Args::cpool
 int launch(const Args& a, hipStream_t st);
 
 }  // namespace paif_conv_dma

@@ -85,7 +85,9 @@ struct Sched {
 };
 
 // F: 16-bit format of maps and weights (1 bf16, 2 fp16 -- round 5: same data path, v_mfma_f32_32x32x16_f16, fp16 conversions in the epilogue)
-template <int NSRC, int NRES, int F>
+// CP: also write the ChannelPool of the output map (max_c, mean_c of the un-rounded fp32 values) to a.cpool: the 4 lanes of a pixel are a
+// DPP quad -- two quad permutes finish the reduction of a lane's 8 channels; lane 0 of the quad stores 8 bytes
+template <int NSRC, int NRES, int F, bool CP = false>
 __global__ __launch_bounds__(256, 1) void conv3x3_bf16_dma(Args a, int ntiles, int tilesX, int tilesY) {
   typedef Sched<NSRC, NRES> SC;
   constexpr int U = SC::U, D = SC::D;
@@ -132,6 +134,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_dma(Args a, int ntiles, i
   const int opitch = a.cout * 2;                         // bytes per output pixel: 32 channels, or 16 (stem_out.0; one source, no residual maps)
   const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.B * H * W * opitch, RSRC_W3);
   const __amdgpu_buffer_rsrc_t rs_null = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, 0, RSRC_W3);
+  const __amdgpu_buffer_rsrc_t rs_cp = __builtin_amdgcn_make_buffer_rsrc(CP ? (void*)a.cpool : a.out, 0, CP ? a.B * H * W * 16 - 8 : 0, RSRC_W3);   // [B,H,W,4] fp32 plane, pre-offset
 
   // ---- B operand: [source][tap][k-step], lane (n = l & 31, k = 8 (l >> 5) + j) -- the hi halves of the split-bf16 pack ----
   u32x4 bw[NSRC][9][2];
@@ -243,6 +246,20 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_dma(Args a, int ntiles, i
       u32x4 od = {o0.x, o0.y, o1.x, o1.y};
       __builtin_amdgcn_raw_buffer_store_b128(od, rs_out, (!(CD_EXP & 1) && pok && y < H && x < W) ? o_lane : OOB, soff, 2);
       asm volatile("s_nop 2" : "+v"(od));                 // 128-bit store data: WAR hazard hipcc does not pad (gf_mfma.hip)
+      if constexpr (CP) {
+        // same summation tree as channel_pool2_kernel: quads, pairs of quads (in lane), then lanes ^1, ^2 of the DPP quad
+        float mx = fmaxf(fmaxf(fmaxf(ev[0], ev[1]), fmaxf(ev[2], ev[3])), fmaxf(fmaxf(ev[4], ev[5]), fmaxf(ev[6], ev[7])));
+        float sm = ((ev[0] + ev[1]) + (ev[2] + ev[3])) + ((ev[4] + ev[5]) + (ev[6] + ev[7]));
+        mx = fmaxf(mx, __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(mx), 0xB1, 0xF, 0xF, true)));   // quad_perm [1,0,3,2]
+        sm += __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(sm), 0xB1, 0xF, 0xF, true));
+        mx = fmaxf(mx, __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(mx), 0x4E, 0xF, 0xF, true)));   // quad_perm [2,3,0,1]
+        sm += __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(sm), 0x4E, 0xF, 0xF, true));
+        typedef float f32x2v __attribute__((ext_vector_type(2)));
+        const f32x2v pv = {mx, sm * (1.0f / 32.0f)};
+        const unsigned poff = (unsigned)(((pb * H + y) * W + px0 + (it & 1) * 16) * 16);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(unsigned __attribute__((ext_vector_type(2))), pv), rs_cp,
+                                              (pok && y < H && x < W && (l & 3) == 0) ? (unsigned)((l >> 2) * 16) : OOB, poff, 0);
+      }
     }
   };
 
@@ -675,7 +692,15 @@ int launch_7(const Args& a, hipStream_t st) {
 template <int NSRC, int NRES>
 int launch_n(const Args& a, hipStream_t st) {
   const int tilesX = (a.W + TW - 1) / TW, tilesY = (a.H + TH - 1) / TH;
-  if (a.f16) hipLaunchKernelGGL((conv3x3_bf16_dma<NSRC, NRES, 2>), dim3(256), dim3(256), 0, st, a, a.B * tilesX * tilesY, tilesX, tilesY);
+  if (a.cpool) {
+    if constexpr (NSRC == 3 && (NRES == 1 || NRES == 3)) {      // can_cpool(): the last conv of a ResidualDenseBlock, inside a chain or closing it
+      if (a.f16) hipLaunchKernelGGL((conv3x3_bf16_dma<NSRC, NRES, 2, true>), dim3(256), dim3(256), 0, st, a, a.B * tilesX * tilesY, tilesX, tilesY);
+      else hipLaunchKernelGGL((conv3x3_bf16_dma<NSRC, NRES, 1, true>), dim3(256), dim3(256), 0, st, a, a.B * tilesX * tilesY, tilesX, tilesY);
+    } else {
+      paif::set_error("conv2d(dma): the fused ChannelPool is built for 3 sources with 1 or 3 residual maps");
+      return PAIF_ENOSUP;
+    }
+  } else if (a.f16) hipLaunchKernelGGL((conv3x3_bf16_dma<NSRC, NRES, 2>), dim3(256), dim3(256), 0, st, a, a.B * tilesX * tilesY, tilesX, tilesY);
   else hipLaunchKernelGGL((conv3x3_bf16_dma<NSRC, NRES, 1>), dim3(256), dim3(256), 0, st, a, a.B * tilesX * tilesY, tilesX, tilesY);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -702,7 +727,13 @@ bool eligible(int nsrc, int nres, int B, int H, int W, float alpha) {
 bool eligible16(int nsrc, int nres, int B, int H, int W, float alpha) { return nsrc == 1 && nres == 0 && eligible(1, 0, B, H, W, alpha); }
 bool eligible7(int nsrc, int nres, int B, int H, int W, float alpha) { return nsrc == 1 && nres == 0 && eligible(1, 0, B, H, W, alpha); }
 
+bool can_cpool(int nsrc, int nres, int kh, int cout) { return kh == 3 && cout == 32 && nsrc == 3 && (nres == 1 || nres == 3); }
+
 int launch(const Args& a, hipStream_t st) {
+  if (a.cpool && !can_cpool(a.nsrc, a.nres, a.kh, a.cout)) {
+    paif::set_error("conv2d(dma): no fused ChannelPool for this form");
+    return PAIF_ENOSUP;
+  }
   if (a.kh == 7) return launch_7(a, st);
   switch (a.nsrc * 10 + a.nres) {
     case 10: return launch_n<1, 0>(a, st);

@@ -52,6 +52,7 @@ struct ConvArgs {
   const float* prelu;
   float* out;
   float* pool_partial;
+  float* cpool;            // optional: fused ChannelPool of the output map (paif_conv_desc.cpool; cout = 32), pre-offset, 4 floats per pixel
   float* aux_out;          // optional: pre-activation z = acc*scale+shift (saved for the backward pass)
   const float* in_aux;     // in_act 3/4: pre-activation of the layer whose gradient is being propagated
   const float* in_scale;   // in_act 3/4/5: per-input-channel factor (folded BN scale of that layer) or NULL
@@ -220,6 +221,14 @@ __device__ __forceinline__ float4 epilogue_lds_n(const ConvArgs& a, const EpiPar
     if (ok) {
       paif::stq_nt<BFO>(a.out, off, v);
       psum.x += v.x; psum.y += v.y; psum.z += v.z; psum.w += v.w;
+    }
+    if (a.cpool) {     // launch-uniform: ChannelPool of the output (the 8 lanes of a pixel; channel_pool2_kernel's summation tree)
+      float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)), sm = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+      for (int m = 1; m < 8; m <<= 1) {
+        mx = fmaxf(mx, __shfl_xor(mx, m)); sm += __shfl_xor(sm, m);
+      }
+      if (ok && q == 0) *reinterpret_cast<float2*>(a.cpool + (off >> 5) * 4) = make_float2(mx, sm * (1.0f / 32.0f));     // cout = 32: off / 32 = the pixel
     }
   }
   }
@@ -1527,6 +1536,15 @@ __device__ __forceinline__ void conv_ws_body(const ConvArgs& a, int ntiles) {
               for (int k = 0; k < NR; ++k) { v.x += r[k][j].x; v.y += r[k][j].y; v.z += r[k][j].z; v.w += r[k][j].w; }
               if (colok && y0 + j < a.H)
                 paif::stq_nt<BFO>(a.out, base + (size_t)j * a.W * 32 + lane_off, v);
+              if (a.cpool) {   // launch-uniform: the fused ChannelPool of the output (8 lanes per pixel, channel_pool2_kernel's tree)
+                float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)), sm = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+                for (int m = 1; m < 8; m <<= 1) {
+                  mx = fmaxf(mx, __shfl_xor(mx, m)); sm += __shfl_xor(sm, m);
+                }
+                if (colok && y0 + j < a.H && q == 0)
+                  *reinterpret_cast<float2*>(a.cpool + ((base + (size_t)j * a.W * 32) >> 5) * 4 + (size_t)px * 4) = make_float2(mx, sm * (1.0f / 32.0f));
+              }
             }
             if (NR > 0) request(i2 + 1);
           }
@@ -1660,6 +1678,14 @@ static inline ConvVariant bf16x3_variant(const ConvArgs& a, int kh, int dil) {
   return CV_PLAIN;
 }
 
+// the fused ChannelPool (ConvArgs::cpool): every tile kernel of this file through the shared LDS epilogue / the persistent form's storers
+// (cout = 32, no gradient hooks); the LDS-DMA kernel for the source / residual counts it instantiates
+static inline bool variant_can_cpool(const ConvArgs& a, int kh, int dil) {
+  if (a.cout != 32 || needs_hooks(a)) return false;
+  if (bf16x3_variant(a, kh, dil) == CV_DMA) return paif_conv_dma::can_cpool(a.nsrc, res_count(a), kh, a.cout);
+  return true;
+}
+
 template <int KH, int DIL, int ST>
 int launch_bf16x3_st(const ConvArgs& a, hipStream_t st) {
   switch (bf16x3_variant(a, KH, DIL)) {
@@ -1669,6 +1695,7 @@ int launch_bf16x3_st(const ConvArgs& a, hipStream_t st) {
       d.wpk = a.wpk; d.scale = a.scale; d.shift = a.shift; d.prelu = a.prelu; d.out = a.out; d.alpha = a.alpha;
       d.nsrc = a.nsrc; d.nres = res_count(a); d.act = a.act; d.B = a.B; d.H = a.H; d.W = a.W; d.reverse = a.reverse; d.kh = KH; d.cout = a.cout;
       d.f16 = paif::st_f16(ST) ? 1 : 0;
+      d.cpool = a.cpool;
       return paif_conv_dma::launch(d, st);
     }
     case CV_HOOKS:
@@ -1983,6 +2010,18 @@ int paif_conv2d_is_persistent(const paif_conv_desc* d, int B, int H, int W) {
   return takes_ws(a, d->kh, d->dil) ? 1 : 0;
 }
 
+int paif_conv2d_can_cpool(const paif_conv_desc* d, int B, int H, int W) {
+  if (!d || d->cout != 32 || d->cin != 32 || B <= 0 || H <= 0 || W <= 0 || d->precision == PAIF_CONV_F32 || d->precision == PAIF_CONV_BF16X6) return 0;
+  ConvArgs a{};
+  for (int s = 0; s < 3; ++s) a.res[s] = d->res[s];
+  a.pool_partial = d->pool_partial; a.nsrc = d->nsrc; a.in_act = d->in_act; a.cout = d->cout;
+  a.aux_out = d->aux_out; a.epi_dact = d->epi_dact;
+  a.B = B; a.H = H; a.W = W;
+  a.nblk = B * ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
+  a.st = d->storage; a.wl0 = (d->precision == PAIF_CONV_BF16 || d->precision == PAIF_CONV_F16) ? 1 : 0; a.alpha = d->alpha;
+  return variant_can_cpool(a, d->kh, d->dil) ? 1 : 0;
+}
+
 int paif_conv2d_kernel_name(const paif_conv_desc* d, int B, int H, int W, char* buf, int buflen) {
   PAIF_REQUIRE(d && buf && buflen > 0 && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "conv2d_kernel_name: bad arguments");
   ConvArgs a{};
@@ -2035,7 +2074,7 @@ int paif_conv2d_fwd(const paif_conv_desc* d, int B, int H, int W, paif_stream_t 
   }
   a.wpk = reinterpret_cast<const float4*>(d->wpk);
   a.in_prelu = d->in_prelu; a.scale = d->scale; a.shift = d->shift; a.prelu = d->prelu;
-  a.out = d->out; a.pool_partial = d->pool_partial; a.alpha = d->alpha;
+  a.out = d->out; a.pool_partial = d->pool_partial; a.cpool = d->cpool; a.alpha = d->alpha;
   a.nsrc = d->nsrc; a.in_act = d->in_act; a.act = d->act; a.cout = d->cout;
   a.aux_out = d->aux_out; a.in_aux = d->in_aux; a.in_scale = d->in_scale; a.in_alpha = d->in_alpha;
   a.epi_aux = d->epi_aux; a.epi_dact = d->epi_dact;
@@ -2061,6 +2100,7 @@ int paif_conv2d_fwd(const paif_conv_desc* d, int B, int H, int W, paif_stream_t 
                "conv2d: precision fp16 is built for fp16-stored maps only");
   PAIF_REQUIRE(d->storage != PAIF_ST_F16_F32 || d->precision == PAIF_CONV_F16, PAIF_ENOSUP, "conv2d: fp16 in / fp32 out takes plain fp16 weights");
   hipStream_t st = paif::as_stream(stream);
+  PAIF_REQUIRE(!d->cpool || paif_conv2d_can_cpool(d, B, H, W), PAIF_ENOSUP, "conv2d: no fused ChannelPool for this descriptor (paif_conv2d_can_cpool)");
   PAIF_REQUIRE(d->cin == 32 || d->cin == 16, PAIF_ENOSUP, "conv2d: cin=%d", d->cin);
   PAIF_REQUIRE(d->precision == PAIF_CONV_F32 || d->precision == PAIF_CONV_BF16X3 || d->precision == PAIF_CONV_BF16 ||
                    d->precision == PAIF_CONV_BF16X6 || d->precision == PAIF_CONV_F16 || d->precision == PAIF_CONV_F16X2, PAIF_EINVAL,

@@ -305,6 +305,22 @@ __global__ __launch_bounds__(256) void channel_pool2_kernel(const float* __restr
   }
 }
 
+// ChannelPool of ONE map into its half of the interleaved [B,H,W,4] plane (comp pre-offset by 0 or 2): the stand-alone pass behind a
+// producer whose epilogue does not pool (paif_conv_desc.cpool); same lane mapping and summation order as channel_pool2_kernel
+template <int BF = 0>
+__global__ __launch_bounds__(256) void channel_pool1_kernel(const float* __restrict__ x, float* __restrict__ comp, size_t npix) {
+  const int q = threadIdx.x & 7;
+  for (size_t pix = (size_t)blockIdx.x * 32 + (threadIdx.x >> 3); pix < npix; pix += (size_t)gridDim.x * 32) {
+    const float4 a = paif::ldq_nt<BF>(x, pix * 32 + q * 4);
+    float mxa = fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), sa = (a.x + a.y) + (a.z + a.w);
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) {
+      mxa = fmaxf(mxa, __shfl_xor(mxa, m)); sa += __shfl_xor(sa, m);
+    }
+    if (q == 0) *reinterpret_cast<float2*>(comp + pix * 4) = make_float2(mxa, sa * (1.0f / 32.0f));
+  }
+}
+
 // Cell_Decom.get_residue on an existing feature map: max_c - min_c
 __global__ __launch_bounds__(256) void channel_residue_kernel(const float* __restrict__ x, float* __restrict__ g, size_t npix) {
   const int q = threadIdx.x & 7;
@@ -841,6 +857,21 @@ int add16(const float* a, const float* b, float* out, size_t n, paif_stream_t st
 }  // namespace
 
 extern "C" {
+
+static int channel_pool1_launch(const float* x, float* comp_off, int B, int H, int W, int fmt, paif_stream_t stream) {
+  PAIF_REQUIRE(x && comp_off && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "channel_pool1: bad arguments");
+  const size_t npix = (size_t)B * H * W;
+  const dim3 g(grid_for(npix, 32)), blk(256);
+  hipStream_t st = paif::as_stream(stream);
+  if (fmt == 0) hipLaunchKernelGGL(channel_pool1_kernel<0>, g, blk, 0, st, x, comp_off, npix);
+  else if (fmt == 1) hipLaunchKernelGGL(channel_pool1_kernel<1>, g, blk, 0, st, x, comp_off, npix);
+  else hipLaunchKernelGGL(channel_pool1_kernel<2>, g, blk, 0, st, x, comp_off, npix);
+  PAIF_LAUNCH_CHECK("channel_pool1");
+  return 0;
+}
+int paif_channel_pool1_fwd(const float* x, float* comp_off, int B, int H, int W, paif_stream_t stream) { return channel_pool1_launch(x, comp_off, B, H, W, 0, stream); }
+int paif_channel_pool1_fwd_bf16(const float* x, float* comp_off, int B, int H, int W, paif_stream_t stream) { return channel_pool1_launch(x, comp_off, B, H, W, 1, stream); }
+int paif_channel_pool1_fwd_f16(const float* x, float* comp_off, int B, int H, int W, paif_stream_t stream) { return channel_pool1_launch(x, comp_off, B, H, W, 2, stream); }
 
 int paif_dwconv_fwd_bf16(const float* x, const float* w, float* out, int k, int dil, int in_relu, int B, int H, int W, paif_stream_t stream) {
   return dwconv16<1>(x, w, out, k, dil, in_relu, B, H, W, stream);

@@ -222,7 +222,9 @@ class ResidualDenseBlock(_HipOp):
         self.conv3 = BasicConv(in_channels * 3, in_channels, kernel_size, dilation=dialtions, relu=False)
         self.lrelu = PReLUParams()
 
-    def forward_nhwc(self, x, res=(), tape=None):
+    takes_cpool = True      # forward_nhwc(..., cpool=(comp, off)): ChannelPool of the block's output from its last conv's epilogue (inference)
+
+    def forward_nhwc(self, x, res=(), tape=None, cpool=None):
         a = self.lrelu.weight
         k, d = self.k, self.d
         kw = dict(act=ops.ACT_PRELU, prelu=a)
@@ -235,7 +237,7 @@ class ResidualDenseBlock(_HipOp):
         x1 = ops.conv2d([x], self.conv1.wpk(1, 32), k, d, **kw)
         x2 = ops.conv2d([x, x1], self.conv2.wpk(2, 32), k, d, **kw)
         if tape is None:
-            return ops.conv2d([x, x1, x2], self.conv3.wpk(3, 32), k, d, alpha=0.333333, res=(x,) + tuple(res), **kw)
+            return ops.conv2d([x, x1, x2], self.conv3.wpk(3, 32), k, d, alpha=0.333333, res=(x,) + tuple(res), cpool=cpool, **kw)
         out, z3 = ops.conv2d([x, x1, x2], self.conv3.wpk(3, 32), k, d, alpha=0.333333, res=(x,) + tuple(res), want_aux=True, **kw)
         tape.append(dict(x1=x1, x2=x2, z3=z3))
         return out
@@ -356,7 +358,9 @@ class DilConv(_HipOp):
             BatchNormParams(C_out, affine=affine),
         )
 
-    def forward_nhwc(self, x, res=(), tape=None):
+    takes_cpool = True
+
+    def forward_nhwc(self, x, res=(), tape=None, cpool=None):
         op = self.op
         dense = ops.CONFIG.get("dilconv_dense", True) if x.dtype in ops.H16 else ops.CONFIG.get("dilconv_dense_f32", True)
         if self.k == 3 and tape is None and not op[3].training and dense:
@@ -366,7 +370,7 @@ class DilConv(_HipOp):
             wc = self._packs.get("wc", [op[1].conv.weight, op[2].weight],
                                  lambda: ops.pack_conv_weight(ops.compose_dw_pw_weight(op[1].conv.weight, op[2].weight), 1, 32, self.k))
             scale, shift = _bn_scale_shift(op[3], self._packs)
-            return ops.conv2d([x], wc, self.k, self.d, in_act=ops.ACT_RELU, scale=scale, shift=shift, res=(x,) + tuple(res))
+            return ops.conv2d([x], wc, self.k, self.d, in_act=ops.ACT_RELU, scale=scale, shift=shift, res=(x,) + tuple(res), cpool=cpool)
         t = ops.dwconv(x, op[1].conv.weight, self.k, self.d, in_relu=True)
         w = self._packs.get("w", [op[2].weight], lambda: ops.pack_conv_weight(op[2].weight, 1, 32, 1))
         if op[3].training or (tape is not None and ops.taping_wgrad()):
@@ -374,11 +378,13 @@ class DilConv(_HipOp):
             out, stats = _bn_split(op[3], c, ops.ACT_NONE, None, (x,) + tuple(res))
             if tape is not None:
                 tape.append(dict(x=x, t=t, c=c, stats=stats, bn_training=op[3].training))
+            if cpool is not None:            # (train-mode forward without a tape: the split BatchNorm form has no pooling epilogue)
+                ops.channel_pool1(out, *cpool)
             return out
         scale, shift = _bn_scale_shift(op[3], self._packs)
         if tape is not None:
             tape.append(dict(x=x))
-        return ops.conv2d([t], w, 1, 1, scale=scale, shift=shift, res=(x,) + tuple(res))
+        return ops.conv2d([t], w, 1, 1, scale=scale, shift=shift, res=(x,) + tuple(res), cpool=cpool)
 
     def backward_nhwc(self, g, t, wgrad=False):
         op = self.op

@@ -55,7 +55,10 @@ ACT_GELU = 1  # paif_gemm_fwd's act code 1 is GELU (the conv's code 1 is PReLU)
 CONFIG = {"conv_precision": "bf16x3", "gemm_precision": "auto", "serpentine": True, "attack_precision": "bf16x6", "storage": "f32",
           # inference forward of the fusion network: run the infrared and the visible stream on two HIP streams (identical results; off by
           # default because per-launch timings -- bench.py's roofline blocks, rocprofv3 averages -- then measure CU sharing, not kernels)
-          "two_stream": False}
+          "two_stream": False,
+          # round 5: ChannelPool(ir_feature, vis_feature) from the producing convs' epilogues (paif_conv_desc.cpool) instead of a pass of its own;
+          # fp16 storage: the forward's last 32-channel map as fp32 / the folded 1x1 with fp16 hi + lo weights (ablation switches)
+          "cpool_fused": True, "f16_last_f32": True, "f16_decomp_split": False}
 # falsy, or the torch dtype (torch.bfloat16 / torch.float16) of the 32-channel maps while an inference forward of the fusion network
 # runs in a 16-bit storage mode (set by the model through `bf16_activations`)
 _ACT_BF16 = [False]
@@ -552,10 +555,12 @@ def conv2d_kernel_name(desc, B, H, W):
 
 def conv2d(srcs, wpk, kh, dil=1, cin=32, cout=32, in_act=ACT_NONE, in_prelu=None, scale=None, shift=None,
            act=ACT_NONE, prelu=None, alpha=1.0, res=(), pool=False, want_aux=False, in_aux=None, in_scale=None,
-           in_alpha=1.0, epi_dact=0, epi_aux=None, out=None, out_f32=False):
+           in_alpha=1.0, epi_dact=0, epi_aux=None, out=None, out_f32=False, cpool=None):
     """Dense conv over the virtual concat of `srcs` (NHWC).  Returns out (and the per-tile pool partials /
     the saved pre-activation when asked).  in_act 3/4/5 + in_aux/in_scale/in_alpha and epi_dact/epi_aux are the
-    activation-derivative hooks used when the same kernel runs a dgrad (include/paif_hip.h)."""
+    activation-derivative hooks used when the same kernel runs a dgrad (include/paif_hip.h).
+    cpool = (comp [B,H,W,4] fp32, offset 0 | 2): also write ChannelPool(out) = (max_c, mean_c) into comp[..., offset:offset+2] -- fused into
+    the conv's epilogue where the kernel can (paif_conv2d_can_cpool), by the stand-alone pass behind it otherwise."""
     B, H, W, C = srcs[0].shape
     assert C == cin and 1 <= len(srcs) <= 3
     res = [r for r in res if r is not None]
@@ -620,6 +625,14 @@ def conv2d(srcs, wpk, kh, dil=1, cin=32, cout=32, in_act=ACT_NONE, in_prelu=None
     aux = torch.empty_like(out) if want_aux else None
     d.aux_out, d.in_aux, d.in_scale, d.in_alpha = _p(aux), _p(in_aux), _p(in_scale), in_alpha
     d.epi_aux, d.epi_dact = _p(epi_aux), epi_dact
+    pool_after = None
+    if cpool is not None:
+        comp, coff = cpool
+        assert cout == 32 and comp.dtype == torch.float32 and tuple(comp.shape) == (B, H, W, 4) and comp.is_contiguous() and coff in (0, 2)
+        if not extra and CONFIG.get("cpool_fused", True) and L.paif_conv2d_can_cpool(ctypes.byref(d), B, H, W):
+            d.cpool = ctypes.c_void_p(comp.data_ptr() + 4 * coff)
+        else:
+            pool_after = (comp, coff)
     if CONFIG.get("serpentine", True):     # consecutive dense-conv launches walk their tiles in opposite directions (paif_hip.h)
         _SERP[0] ^= 1
         d.reverse_tiles = _SERP[0]
@@ -635,6 +648,8 @@ def conv2d(srcs, wpk, kh, dil=1, cin=32, cout=32, in_act=ACT_NONE, in_prelu=None
         TIMER.stop(tag, e0, 2 * px * kh * kh * cin * len(srcs) * cout, px * (eb_in * cin * len(srcs) + eb_out * cout * (1 + len(res))))
     for r in extra:  # more than 3 fused residuals: plain adds
         out = add(out, r)
+    if pool_after is not None:
+        channel_pool1(out, *pool_after)
     if pool and want_aux:
         return out, partial, aux
     if want_aux:
@@ -672,6 +687,15 @@ def channel_pool2(ir, vis):
     assert ir.dtype == vis.dtype
     fn = {torch.bfloat16: lib().paif_channel_pool2_fwd_bf16, torch.float16: lib().paif_channel_pool2_fwd_f16}.get(ir.dtype, lib().paif_channel_pool2_fwd)
     _lib.check(fn(_pa(ir), _pa(vis), _p(comp), B, H, W, _stream()), "channel_pool2")
+    return comp
+
+
+def channel_pool1(x, comp, coff):
+    """ChannelPool of ONE map into comp[..., coff:coff+2] (comp [B,H,W,4] fp32; coff 0 = the infrared half, 2 = the visible half)."""
+    B, H, W, C = x.shape
+    assert C == 32 and tuple(comp.shape) == (B, H, W, 4) and comp.dtype == torch.float32 and coff in (0, 2)
+    fn = {torch.bfloat16: lib().paif_channel_pool1_fwd_bf16, torch.float16: lib().paif_channel_pool1_fwd_f16}.get(x.dtype, lib().paif_channel_pool1_fwd)
+    _lib.check(fn(_pa(x), ctypes.c_void_p(comp.data_ptr() + 4 * coff), B, H, W, _stream()), "channel_pool1")
     return comp
 
 

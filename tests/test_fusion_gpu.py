@@ -688,3 +688,99 @@ def test_guided_filter_round4_engine_long_runs_of_rows():
             os.environ["PAIF_GF_ENGINE"] = old
     assert torch.isfinite(b).all()
     assert maxabs(a, b) <= 5e-6
+
+
+@pytest.mark.parametrize("storage,kh,dil,nsrc,nres,in_act,shape,kernel", [
+    ("f32", 3, 1, 3, 1, 0, (2, 333, 517), "conv_bf16x3_ms<3, 1, 3, 0>"),           # RDB conv3 closing a block inside a chain
+    ("f32", 3, 1, 3, 3, 0, (1, 64, 96), "conv_bf16x3_ms<3, 1, 3, 0>"),             # ... closing a chain (+ its residuals), small ragged grid
+    ("f32", 3, 2, 1, 3, 2, (2, 333, 517), "conv_mfma_bf16x3<3, 2, false, 0, 2>"),  # DilConv as one dense conv (ReLU input), tile-per-workgroup
+    ("f32", 3, 1, 1, 1, 0, (2, 333, 517), "conv_bf16x3_res<3, 1, 1, 4, 0>"),       # resident-weights persistent form
+    ("f32", 1, 1, 1, 0, 0, (2, 333, 517), "conv_bf16x3_ws<1, 1, 0>"),              # wave-specialised persistent form (storers pool)
+    ("f16", 3, 1, 3, 3, 0, (2, 333, 517), "conv3x3_bf16_dma<3, 3, 2>"),            # LDS-DMA kernel, the shipped genotype's visible chain
+    ("f16", 3, 1, 3, 1, 0, (1, 480, 640), "conv3x3_bf16_dma<3, 1, 2>"),
+    ("bf16", 3, 1, 3, 3, 0, (2, 333, 517), "conv3x3_bf16_dma<3, 3, 1>"),
+    ("f16", 3, 2, 1, 3, 2, (2, 333, 517), "conv_bf16x3_wsr<3, 2, 12>"),            # the shipped genotype's infrared chain (DilConv)
+    ("f16", 3, 1, 2, 0, 0, (2, 333, 517), None),                                   # a DMA form without the fused pool: stand-alone pass behind it
+    ("f16", 3, 1, 1, 0, 0, (1, 37, 53), "conv_mfma_bf16x3<3, 1, false, 12, 2>"),
+])
+def test_channel_pool_fused_into_the_conv_epilogue(storage, kh, dil, nsrc, nres, in_act, shape, kernel):
+    """paif_conv_desc.cpool: ChannelPool of a conv's OUTPUT (max_c, mean_c; core/model_fusion_auto.py:1352-1355) from
+    its epilogue, in every kernel form that produces ir_feature / vis_feature, against the stand-alone pooling of the fp32 result.  fp32
+    maps: bit-equal (same values, same summation tree).  16-bit maps: the pool is formed from the un-rounded fp32 values -- equal to the
+    pool of the stored map up to that rounding."""
+    from paif_amd import ops, _lib
+
+    B, H, W = shape
+    dev = _dev()
+    g = torch.Generator().manual_seed(77 + kh + nsrc + nres)
+    dt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[storage]
+    mk = lambda: ops.cast_storage(ops.to_nhwc(torch.randn(B, 32, H, W, generator=g).to(dev)), dt)
+    xs, rs = [mk() for _ in range(nsrc)], [mk() for _ in range(nres)]
+    w = (torch.randn(32, 32 * nsrc, kh, kh, generator=g) * 0.05).to(dev)
+    prec = "f16" if storage == "f16" else "bf16x3"
+    old = dict(ops.CONFIG)
+    try:
+        ops.set_storage(storage)
+        wpk = ops.pack_conv_weight(w, nsrc, 32, kh, precision=prec)
+        slope = torch.tensor([0.2], device=dev)
+        kw = dict(dil=dil, in_act=in_act, act=ops.ACT_PRELU, prelu=slope, alpha=0.5, res=tuple(rs))
+        ref = ops.conv2d(xs, wpk, kh, **kw)
+        comp = torch.full((B, H, W, 4), float("nan"), device=dev)
+        seen = []
+        orig = ops.channel_pool1
+        ops.channel_pool1 = lambda *a, **k: (seen.append(1), orig(*a, **k))[1]
+        try:
+            out = ops.conv2d(xs, wpk, kh, cpool=(comp, 2), **kw)
+        finally:
+            ops.channel_pool1 = orig
+        torch.cuda.synchronize()
+        assert bool(seen) == (kernel is None), "fused where the kernel can, the stand-alone pass otherwise"
+        assert torch.equal(out, ref)
+        assert bool(torch.isnan(comp[..., :2]).all()), "only the addressed half of the plane is written"
+        r32 = ref.float()
+        want = torch.stack([r32.max(-1).values, r32.mean(-1)], -1)
+        got = comp[..., 2:]
+        if storage == "f32":
+            pooled = torch.empty((B, H, W, 4), device=dev)
+            ops.channel_pool1(ref, pooled, 2)
+            assert torch.equal(got, pooled[..., 2:])
+        if kernel is None:
+            assert float((got - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max()))
+        else:   # from the un-rounded values: within the output format's rounding of the pooled stored map
+            eps = {"f32": 1e-6, "f16": 2.0 ** -11, "bf16": 2.0 ** -8}[storage]
+            assert float((got - want).abs().max()) <= 1.01 * eps * float(r32.abs().max()) + 1e-6
+    finally:
+        ops.CONFIG.update(old)
+
+
+@pytest.mark.parametrize("storage", ["f32", "f16", "bf16"])
+def test_fusion_forward_with_and_without_the_fused_channel_pool(storage):
+    """The inference forward with ChannelPool(ir_feature, vis_feature) fused into the two chains' last convs vs the stand-alone
+    channel_pool2 pass (ops.CONFIG['cpool_fused'] = False): fp32 storage bit-equal, 16-bit storage equal up to the pool's use of un-rounded
+    values (the blend weight sigmoid(conv5x5(pool)) moves by ~1e-4)."""
+    from paif_amd import ops
+
+    net = _fusion_net()
+    ir, vis, _ = S.make_batch(2, 64, 96)
+    irt, ycc = t(ir).to(_dev()), ops.rgb2ycrcb(t(vis).to(_dev()))
+    old = dict(ops.CONFIG)
+    try:
+        ops.set_storage(storage)
+        calls = []
+        orig = ops.channel_pool2
+        ops.channel_pool2 = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            with torch.no_grad():
+                fused = net(irt, ycc)
+                assert not calls, "channel_pool2 still launched in the inference forward"
+                ops.CONFIG["cpool_fused"] = False
+                plain = net(irt, ycc)
+                assert calls
+        finally:
+            ops.channel_pool2 = orig
+        if storage == "f32":
+            assert torch.equal(fused, plain)
+        else:
+            assert float((fused - plain).abs().max()) <= (5e-4 if storage == "f16" else 4e-3)
+    finally:
+        ops.CONFIG.update(old)
