@@ -219,6 +219,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_dma(Args a, int ntiles, i
 #pragma unroll
   for (int it = 0; it < 4; ++it) t[it][0] = t[it][1] = u32x4{0, 0, 0, 0};
   float ev[8];
+  float pmx = 0.f, psm = 0.f;   // CP: running (max, sum) of the lane's 8 channels of one pixel
   int cur = NSLOT - PF;    // ring slot of the current stage; the prologue's virtual stages -PF .. -1 bring it to 0
 
   // Epilogue micro-step m = 9 it + j of the tile in `t` (coordinates pb, py0, px0; residual set SETP): j < 8 one channel of the
@@ -238,6 +239,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_dma(Args a, int ntiles, i
         else v += __uint_as_float((j & 1) ? (u & 0xffff0000u) : (u << 16));
       }
       ev[j] = v;
+      if constexpr (CP) {                  // the fused ChannelPool accumulates with the micro-steps (two instructions each)
+        pmx = j == 0 ? v : fmaxf(pmx, v);
+        psm = j == 0 ? v : psm + v;
+      }
     } else {
       const uint2 o0 = paif::f32_to_h4<F>(make_float4(ev[0], ev[1], ev[2], ev[3]));
       const uint2 o1 = paif::f32_to_h4<F>(make_float4(ev[4], ev[5], ev[6], ev[7]));
@@ -247,13 +252,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_dma(Args a, int ntiles, i
       __builtin_amdgcn_raw_buffer_store_b128(od, rs_out, (!(CD_EXP & 1) && pok && y < H && x < W) ? o_lane : OOB, soff, 2);
       asm volatile("s_nop 2" : "+v"(od));                 // 128-bit store data: WAR hazard hipcc does not pad (gf_mfma.hip)
       if constexpr (CP) {
-        // same summation tree as channel_pool2_kernel: quads, pairs of quads (in lane), then lanes ^1, ^2 of the DPP quad
-        float mx = fmaxf(fmaxf(fmaxf(ev[0], ev[1]), fmaxf(ev[2], ev[3])), fmaxf(fmaxf(ev[4], ev[5]), fmaxf(ev[6], ev[7])));
-        float sm = ((ev[0] + ev[1]) + (ev[2] + ev[3])) + ((ev[4] + ev[5]) + (ev[6] + ev[7]));
-        mx = fmaxf(mx, __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(mx), 0xB1, 0xF, 0xF, true)));   // quad_perm [1,0,3,2]
-        sm += __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(sm), 0xB1, 0xF, 0xF, true));
-        mx = fmaxf(mx, __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(mx), 0x4E, 0xF, 0xF, true)));   // quad_perm [2,3,0,1]
-        sm += __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(sm), 0x4E, 0xF, 0xF, true));
+        // the lane's 8 channels are in (pmx, psm); the pixel's other three channel groups sit in the other lanes of the DPP quad
+        float mx = pmx, sm = psm;
+        mx = fmaxf(mx, paif::dpp_f<0xB1>(mx)); sm += paif::dpp_f<0xB1>(sm);       // quad_perm [1,0,3,2]
+        mx = fmaxf(mx, paif::dpp_f<0x4E>(mx)); sm += paif::dpp_f<0x4E>(sm);       // quad_perm [2,3,0,1]
         typedef float f32x2v __attribute__((ext_vector_type(2)));
         const f32x2v pv = {mx, sm * (1.0f / 32.0f)};
         const unsigned poff = (unsigned)(((pb * H + y) * W + px0 + (it & 1) * 16) * 16);

@@ -224,10 +224,7 @@ __device__ __forceinline__ float4 epilogue_lds_n(const ConvArgs& a, const EpiPar
     }
     if (a.cpool) {     // launch-uniform: ChannelPool of the output (the 8 lanes of a pixel; channel_pool2_kernel's summation tree)
       float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)), sm = (v.x + v.y) + (v.z + v.w);
-#pragma unroll
-      for (int m = 1; m < 8; m <<= 1) {
-        mx = fmaxf(mx, __shfl_xor(mx, m)); sm += __shfl_xor(sm, m);
-      }
+      paif::pix8_max_sum(mx, sm);
       if (ok && q == 0) *reinterpret_cast<float2*>(a.cpool + (off >> 5) * 4) = make_float2(mx, sm * (1.0f / 32.0f));     // cout = 32: off / 32 = the pixel
     }
   }
@@ -1538,10 +1535,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvArgs& a, int ntiles) {
                 paif::stq_nt<BFO>(a.out, base + (size_t)j * a.W * 32 + lane_off, v);
               if (a.cpool) {   // launch-uniform: the fused ChannelPool of the output (8 lanes per pixel, channel_pool2_kernel's tree)
                 float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)), sm = (v.x + v.y) + (v.z + v.w);
-#pragma unroll
-                for (int m = 1; m < 8; m <<= 1) {
-                  mx = fmaxf(mx, __shfl_xor(mx, m)); sm += __shfl_xor(sm, m);
-                }
+                paif::pix8_max_sum(mx, sm);
                 if (colok && y0 + j < a.H && q == 0)
                   *reinterpret_cast<float2*>(a.cpool + ((base + (size_t)j * a.W * 32) >> 5) * 4 + (size_t)px * 4) = make_float2(mx, sm * (1.0f / 32.0f));
               }

@@ -197,6 +197,19 @@ template <int BF> __device__ __forceinline__ void stq_nt(float* base, size_t eof
   }
 }
 
+// (max, sum) of a value over the 8 CONSECUTIVE lanes that hold one pixel's channel quads (lane & 7 = quad), result in all 8 lanes, on
+// the DPP path (no LDS traffic, unlike __shfl_xor's ds_bpermute): lanes ^1 and ^2 by quad permutes; after those every lane of a quad
+// holds its quad's result, so the mirror of the 8-lane half row (lane i <-> 7 - i) supplies the other quad's.  The summation tree is
+// channel_pool2_kernel's ((q0 + q1) + (q2 + q3)) + ((q4 + q5) + (q6 + q7)) up to commutation: bit-equal.
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
+  return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ void pix8_max_sum(float& mx, float& sm) {
+  mx = fmaxf(mx, dpp_f<0xB1>(mx)); sm += dpp_f<0xB1>(sm);       // quad_perm [1,0,3,2]
+  mx = fmaxf(mx, dpp_f<0x4E>(mx)); sm += dpp_f<0x4E>(sm);       // quad_perm [2,3,0,1]
+  mx = fmaxf(mx, dpp_f<0x141>(mx)); sm += dpp_f<0x141>(sm);     // row_half_mirror
+}
+
 // One 32x32x16 MFMA on 16-bit operands in format F (1 bf16, 2 fp16); operands travel as 8 packed 16-bit values (uint4 bits)
 typedef float mf32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 mbf16x8 __attribute__((ext_vector_type(8)));
