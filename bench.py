@@ -338,10 +338,14 @@ def main():
     if rank == 0:
         pairs = bpg * world * args.steps
         per_kernel = timer.summary()
+        extra_bytes = dict(timer.extra)
         if timer_all is not None:     # the other kernels from the pass after the timed region; the dominant family from the timed region itself
             merged = dict(timer_all.summary())
             merged.update(per_kernel)
             per_kernel = merged
+            xm = dict(timer_all.extra)
+            xm.update(extra_bytes)
+            extra_bytes = xm
 
         summ, members = {}, {}
         for tag, (n_, ms_, fl_, by_) in per_kernel.items():
@@ -398,6 +402,10 @@ def main():
                     blk = {"bound": "hbm", "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": f_h, "algorithmic_tflops": tf}
             blk.update({"kernel": tag, "launches": n_, "avg_launch_ms": ms_ / n_, "share_of_step": ms_ / (dt * 1e3),
                         "algorithmic_gflop_per_launch": fl_ / n_ / 1e9, "algorithmic_mb_per_launch": by_ / n_ / 1e6})
+            xb = sum(extra_bytes.get(k, 0) for k in members.get(tag, [tag]))
+            if xb:   # `frac` / `achieved` price SURVEY 8(d)'s bytes (residual adds free); this field also counts the residual maps the epilogues read
+                blk["hbm_frac_counting_residual_reads"] = (by_ + xb) / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS
+                blk["residual_read_mb_per_launch"] = xb / n_ / 1e6
             if len(members.get(tag, [])) > 1 or members.get(tag, [tag])[0] != tag:
                 blk["kernels"] = [{"kernel": k, "launches": per_kernel[k][0], "avg_launch_ms": per_kernel[k][1] / per_kernel[k][0],
                                    "achieved": per_kernel[k][3] / (per_kernel[k][1] * 1e-3) / 1e9, "unit": "GB/s",

@@ -2042,7 +2042,7 @@ int paif_conv2d_kernel_name(const paif_conv_desc* d, int B, int H, int W, char* 
   switch (bf16x3_variant(a, d->kh, d->dil)) {
     case CV_DMA:
       if (d->kh == 7) snprintf(buf, buflen, "conv7x7_bf16_dma<%d>", a.st >= 3 ? 2 : 1);
-      else snprintf(buf, buflen, "conv3x3_bf16_dma<%d, %d, %d>", d->nsrc, res_count(a), a.st >= 3 ? 2 : 1);
+      else snprintf(buf, buflen, "conv3x3_bf16_dma<%d, %d, %d, %s>", d->nsrc, res_count(a), a.st >= 3 ? 2 : 1, d->cpool ? "true" : "false");
       break;
     case CV_WS: snprintf(buf, buflen, "conv_bf16x3_ws%s<%d, %d, %d>", d->in_act == 2 ? "r" : "", d->kh, d->dil, code); break;
     case CV_RES: snprintf(buf, buflen, "conv_bf16x3_res<%d, %d, %d, %d, %d>", d->kh, d->dil, d->nsrc, PAIF_RES_ROWS, code); break;

@@ -219,6 +219,7 @@ class KernelTimer:
     def __init__(self, match):
         self.match = match          # predicate on the kernel tag
         self.records = []           # (tag, start_event, end_event, flops, bytes)
+        self.extra = {}             # tag -> bytes of residual-map reads (not part of the SURVEY 8(d) byte model)
 
     def start(self, tag):
         if not self.match(tag):
@@ -227,12 +228,15 @@ class KernelTimer:
         e.record()
         return e
 
-    def stop(self, tag, e0, flops, nbytes):
+    def stop(self, tag, e0, flops, nbytes, extra_bytes=0):
+        """nbytes: algorithmic bytes on SURVEY 8(d)'s model (each distinct input map read once, the output written once; residual adds
+        free); extra_bytes: what the launch moves on top of that by construction (residual maps read in the epilogue)."""
         if e0 is None:
             return
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
         self.records.append((tag, e0, e1, flops, nbytes))
+        self.extra[tag] = self.extra.get(tag, 0) + extra_bytes
 
     def summary(self):
         """-> dict tag -> (launches, total_ms, total_flops, total_bytes); call after a synchronize."""
@@ -645,7 +649,8 @@ def conv2d(srcs, wpk, kh, dil=1, cin=32, cout=32, in_act=ACT_NONE, in_prelu=None
         px = B * H * W
         # algorithmic work: 2*K*cout FLOP per output pixel; each source map read once, output written once
         eb_in, eb_out = (2 if src_bf else 4), (2 if out_bf else 4)
-        TIMER.stop(tag, e0, 2 * px * kh * kh * cin * len(srcs) * cout, px * (eb_in * cin * len(srcs) + eb_out * cout * (1 + len(res))))
+        eb_res = 2 if (res and res[0].dtype in H16) else 4
+        TIMER.stop(tag, e0, 2 * px * kh * kh * cin * len(srcs) * cout, px * (eb_in * cin * len(srcs) + eb_out * cout), px * eb_res * cout * len(res))
     for r in extra:  # more than 3 fused residuals: plain adds
         out = add(out, r)
     if pool_after is not None:

@@ -80,12 +80,12 @@ def _conv_case(kh, dil, nsrc, nres, cout, B, H, W, seed, wscale=0.05):
 
 
 @pytest.mark.parametrize("kh,dil,nsrc,nres,act,cout,kernel", [
-    (3, 1, 1, 0, 1, 32, "conv3x3_bf16_dma<1, 0, 2>"),
-    (3, 1, 1, 1, 0, 32, "conv3x3_bf16_dma<1, 1, 2>"),
-    (3, 1, 2, 0, 1, 32, "conv3x3_bf16_dma<2, 0, 2>"),
-    (3, 1, 3, 1, 1, 32, "conv3x3_bf16_dma<3, 1, 2>"),
-    (3, 1, 3, 3, 2, 32, "conv3x3_bf16_dma<3, 3, 2>"),
-    (3, 1, 1, 0, 0, 16, "conv3x3_bf16_dma<1, 0, 2>"),          # 32 -> 16 (stem_out.0 of the two-kernel tail)
+    (3, 1, 1, 0, 1, 32, "conv3x3_bf16_dma<1, 0, 2, false>"),
+    (3, 1, 1, 1, 0, 32, "conv3x3_bf16_dma<1, 1, 2, false>"),
+    (3, 1, 2, 0, 1, 32, "conv3x3_bf16_dma<2, 0, 2, false>"),
+    (3, 1, 3, 1, 1, 32, "conv3x3_bf16_dma<3, 1, 2, false>"),
+    (3, 1, 3, 3, 2, 32, "conv3x3_bf16_dma<3, 3, 2, false>"),
+    (3, 1, 1, 0, 0, 16, "conv3x3_bf16_dma<1, 0, 2, false>"),          # 32 -> 16 (stem_out.0 of the two-kernel tail)
     (7, 1, 1, 0, 1, 32, "conv7x7_bf16_dma<2>"),
     (1, 1, 1, 0, 0, 32, "conv_bf16x3_ws<1, 1, 12>"),           # 1x1 stream (wave-specialised)
     (1, 1, 1, 2, 1, 32, "conv_mfma_bf16x3<1, 1, false, 12, 2>"),   # 1x1 with residual maps (tile-per-workgroup kernel)
@@ -413,8 +413,8 @@ def _clause_eval(modes, golden):
     return report
 
 
-# measured on MI355X (profiles/r05_f16_storage_report.json); bounds = the measurement + 25 %
-F16_CLAUSE = dict(fused_max=2.5e-3, fused_mean=1.2e-4, logits_max=1.2e-3, logits_mean=8e-5, miou=1e-3)
+# measured on MI355X (profiles/r05_f16_storage_report.json: fused 1.8e-3 / 6.3e-5, logits 8.0e-4 / 3.9e-5 of the range); bounds = + 25-50 %
+F16_CLAUSE = dict(fused_max=2.5e-3, fused_mean=1.0e-4, logits_max=1.2e-3, logits_mean=8e-5, miou=1e-3)
 
 
 def test_fusion_forward_f16_storage_tolerance_clause(golden):
@@ -434,7 +434,7 @@ def test_fusion_forward_f16_storage_tolerance_clause(golden):
     assert r["largest_reference_margin_of_a_moved_pixel_over_range"] <= 2.0 * r["logits_max_abs_over_range"], r
     assert abs(r["miou_delta_8_samples"]) <= lim["miou"] and abs(r["miou_delta_sample0"]) <= lim["miou"], r      # within 0.1 pt
     assert r["argmax_agreement_8_samples"] >= 0.999, r                                                         # >= 99.9 %
-    assert min(r["argmax_agreement_per_sample"]) >= 0.998, r
+    assert min(r["argmax_agreement_per_sample"]) >= 0.9975, r                    # measured per sample 0.9982 ... 0.9997 across builds
     # the same evaluation of the other modes, for the record: fp32 storage sits at the reference's own noise; bf16 maps miss the clause
     assert report["f32"]["argmax_agreement_8_samples"] >= 0.9998, report["f32"]
     assert report["bf16"]["argmax_agreement_8_samples"] < r["argmax_agreement_8_samples"], report["bf16"]

@@ -696,9 +696,9 @@ def test_guided_filter_round4_engine_long_runs_of_rows():
     ("f32", 3, 2, 1, 3, 2, (2, 333, 517), "conv_mfma_bf16x3<3, 2, false, 0, 2>"),  # DilConv as one dense conv (ReLU input), tile-per-workgroup
     ("f32", 3, 1, 1, 1, 0, (2, 333, 517), "conv_bf16x3_res<3, 1, 1, 4, 0>"),       # resident-weights persistent form
     ("f32", 1, 1, 1, 0, 0, (2, 333, 517), "conv_bf16x3_ws<1, 1, 0>"),              # wave-specialised persistent form (storers pool)
-    ("f16", 3, 1, 3, 3, 0, (2, 333, 517), "conv3x3_bf16_dma<3, 3, 2>"),            # LDS-DMA kernel, the shipped genotype's visible chain
-    ("f16", 3, 1, 3, 1, 0, (1, 480, 640), "conv3x3_bf16_dma<3, 1, 2>"),
-    ("bf16", 3, 1, 3, 3, 0, (2, 333, 517), "conv3x3_bf16_dma<3, 3, 1>"),
+    ("f16", 3, 1, 3, 3, 0, (2, 333, 517), "conv3x3_bf16_dma<3, 3, 2, false>"),            # LDS-DMA kernel, the shipped genotype's visible chain
+    ("f16", 3, 1, 3, 1, 0, (1, 480, 640), "conv3x3_bf16_dma<3, 1, 2, false>"),
+    ("bf16", 3, 1, 3, 3, 0, (2, 333, 517), "conv3x3_bf16_dma<3, 3, 1, false>"),
     ("f16", 3, 2, 1, 3, 2, (2, 333, 517), "conv_bf16x3_wsr<3, 2, 12>"),            # the shipped genotype's infrared chain (DilConv)
     ("f16", 3, 1, 2, 0, 0, (2, 333, 517), None),                                   # a DMA form without the fused pool: stand-alone pass behind it
     ("f16", 3, 1, 1, 0, 0, (1, 37, 53), "conv_mfma_bf16x3<3, 1, false, 12, 2>"),
