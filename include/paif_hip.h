@@ -242,6 +242,18 @@ int paif_compose_dw_pw_weight(const float* dw, const float* pw, float* out, int 
  * paif_conv2d_fwd with the BN / PReLU / residual epilogue instead of two launches; the 32-channel map between them never goes to HBM. */
 int paif_compose_pw_conv_weight(const float* pw, const float* w, float* out, int cout, int cmid, int cin, int kh, paif_stream_t stream);
 
+/* ResidualDenseBlock (operations_m.py:435-449: x1 = P(c1(x)), x2 = P(c2([x, x1])), out = P(c3([x, x1, x2])) * alpha + x, one shared PReLU
+ * slope, k = 3, dilation 1, 32 channels) of the 16-bit inference forward as ONE kernel (round 5, csrc/rdb_fused.hip): x read once, out
+ * written once, x1 / x2 never leave LDS.  x / res0 / res1 / out: NHWC-32 16-bit maps (bf16, or IEEE fp16 when f16 != 0) behind the
+ * float*; res0, res1 (optional, packed from res0): further residual maps added to the output (a block closing a Cell_Chain,
+ * core/model_fusion_auto.py:445); cpool (optional): fused ChannelPool of the output as in paif_conv_desc.cpool.  wpk: the three convs'
+ * weights as 16x16x32-MFMA operands (paif_rdb_fused_pack from w1 [32,32,3,3], w2 [32,64,3,3], w3 [32,96,3,3];
+ * paif_rdb_fused_wpk_floats() floats).  Intermediate maps are rounded to the storage format like the three-launch form's. */
+size_t paif_rdb_fused_wpk_floats(void);
+int paif_rdb_fused_pack(const float* w1, const float* w2, const float* w3, float* wpk, int f16, paif_stream_t stream);
+int paif_rdb_fused_fwd(const float* x, const float* wpk, const float* prelu, float alpha, const float* res0, const float* res1, float* out,
+                       float* cpool, int f16, int reverse_tiles, int B, int H, int W, paif_stream_t stream);
+
 /* stem_out of the fusion network (core/model_fusion_auto.py:616-620, :640: conv3x3 32->16, conv3x3 16->1, PReLU, tanh) on a bf16-stored
  * NHWC-32 map as one launch pair: the two linear convs composed into a 5x5 32->1 conv evaluated on the matrix cores with the TAPS as the
  * M dimension (three-piece bf16 weights: fp32-level products), and the outermost pixel ring -- where the reference's zero padding of the

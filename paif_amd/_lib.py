@@ -50,6 +50,9 @@ SIGNATURES = {
     "paif_conv2d_fwd": (c_int, [POINTER(ConvDesc), c_int, c_int, c_int, F]),
     "paif_conv2d_is_persistent": (c_int, [POINTER(ConvDesc), c_int, c_int, c_int]),
     "paif_conv2d_can_cpool": (c_int, [POINTER(ConvDesc), c_int, c_int, c_int]),
+    "paif_rdb_fused_wpk_floats": (c_size_t, []),
+    "paif_rdb_fused_pack": (c_int, [F, F, F, F, c_int, F]),
+    "paif_rdb_fused_fwd": (c_int, [F, F, F, c_float, F, F, F, F, c_int, c_int, c_int, c_int, c_int, F]),
     "paif_channel_pool1_fwd": (c_int, [F, F, c_int, c_int, c_int, F]),
     "paif_channel_pool1_fwd_bf16": (c_int, [F, F, c_int, c_int, c_int, F]),
     "paif_channel_pool1_fwd_f16": (c_int, [F, F, c_int, c_int, c_int, F]),

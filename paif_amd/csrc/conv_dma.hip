@@ -41,6 +41,9 @@ constexpr int SLOT = 4 * DPW * 1024;
 #ifndef CD_PF
 #define CD_PF 4
 #endif
+#ifndef CD_ST_AUX
+#define CD_ST_AUX 2   // cache policy of the output stores: 2 = streaming (nt); 0 = default (A/B: tools/build_variant1.sh ... -DCD_ST_AUX=0)
+#endif
 #ifndef CD_EXP
 #define CD_EXP 0      // experiments (timing only, wrong results): 1 no stores, 2 no MFMAs, 4 no HBM reads (every DMA lane out of range)
 #endif
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_dma(Args a, int ntiles, i
       const int y = py0 + 2 * w + (it >> 1), x = px0 + (it & 1) * 16 + (l >> 2);
       const unsigned soff = (unsigned)(((pb * H + y) * W + px0 + (it & 1) * 16) * opitch);
       u32x4 od = {o0.x, o0.y, o1.x, o1.y};
-      __builtin_amdgcn_raw_buffer_store_b128(od, rs_out, (!(CD_EXP & 1) && pok && y < H && x < W) ? o_lane : OOB, soff, 2);
+      __builtin_amdgcn_raw_buffer_store_b128(od, rs_out, (!(CD_EXP & 1) && pok && y < H && x < W) ? o_lane : OOB, soff, CD_ST_AUX);
       asm volatile("s_nop 2" : "+v"(od));                 // 128-bit store data: WAR hazard hipcc does not pad (gf_mfma.hip)
       if constexpr (CP) {
         // the lane's 8 channels are in (pmx, psm); the pixel's other three channel groups sit in the other lanes of the DPP quad
@@ -563,7 +566,7 @@ __global__ __launch_bounds__(256, 1) void conv7x7_bf16_dma(Args a, int ntiles, i
       const int y = py0 + 2 * w + (it >> 1), x = px0 + (it & 1) * 16 + (l >> 2);
       const unsigned soff = (unsigned)(((pb * H + y) * W + px0 + (it & 1) * 16) * 64);
       u32x4 od = {o0.x, o0.y, o1.x, o1.y};
-      __builtin_amdgcn_raw_buffer_store_b128(od, rs_out, (pok && y < H && x < W) ? e_lane : OOB, soff, 2);
+      __builtin_amdgcn_raw_buffer_store_b128(od, rs_out, (pok && y < H && x < W) ? e_lane : OOB, soff, CD_ST_AUX);
       asm volatile("s_nop 2" : "+v"(od));
     }
   };

@@ -234,6 +234,12 @@ class ResidualDenseBlock(_HipOp):
             out, z3 = ops.conv2d([x, x1, x2], self.conv3.wpk(3, 32), k, d, alpha=0.333333, res=(x,) + tuple(res), want_aux=True, **kw)
             tape.append(dict(x=x, x1=x1, x2=x2, z1=z1, z2=z2, z3=z3))
             return out
+        if (tape is None and x.dtype in ops.H16 and k == 3 and d == 1 and len(res) <= 2 and ops.CONFIG.get("rdb_fused", False)
+                and x.shape[0] * ((x.shape[1] + 7) // 8) * ((x.shape[2] + 27) // 28) >= 512):
+            # 16-bit inference forward: the whole block as one kernel -- x read once, out written once, x1 / x2 stay in LDS
+            ws = [self.conv1.conv.weight, self.conv2.conv.weight, self.conv3.conv.weight]
+            wpk = self._packs.get("rdb_" + str(x.dtype), ws, lambda: ops.rdb_fused_pack(ws[0], ws[1], ws[2], x.dtype))
+            return ops.rdb_fused(x, wpk, a, alpha=0.333333, res=tuple(res), cpool=cpool)
         x1 = ops.conv2d([x], self.conv1.wpk(1, 32), k, d, **kw)
         x2 = ops.conv2d([x, x1], self.conv2.wpk(2, 32), k, d, **kw)
         if tape is None:

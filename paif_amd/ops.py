@@ -58,7 +58,11 @@ CONFIG = {"conv_precision": "bf16x3", "gemm_precision": "auto", "serpentine": Tr
           "two_stream": False,
           # round 5: ChannelPool(ir_feature, vis_feature) from the producing convs' epilogues (paif_conv_desc.cpool) instead of a pass of its own;
           # fp16 storage: the forward's last 32-channel map as fp32 / the folded 1x1 with fp16 hi + lo weights (ablation switches)
-          "cpool_fused": True, "f16_last_f32": True, "f16_decomp_split": False}
+          "cpool_fused": True, "f16_last_f32": True, "f16_decomp_split": False,
+          # 16-bit inference forward: a ResidualDenseBlock (k = 3, dilation 1) as ONE kernel (csrc/rdb_fused.hip) on maps of >= 512 tiles.
+          # OFF by default: correct (tests/test_f16_storage_gpu.py) and 2 map passes instead of 9, but matrix-pipe bound at the clock the chip
+          # sustains under that load -- 400 us per block inside the forward against 355 for the three bandwidth-bound launches
+          "rdb_fused": False}
 # falsy, or the torch dtype (torch.bfloat16 / torch.float16) of the 32-channel maps while an inference forward of the fusion network
 # runs in a 16-bit storage mode (set by the model through `bf16_activations`)
 _ACT_BF16 = [False]
@@ -524,6 +528,42 @@ def pack_decomp1x1_weight(w, precision=None):
     else:
         _lib.check(L.paif_pack_decomp1x1_weight(_p(wc), _p(wpk), _stream()), "pack_decomp1x1_weight")
     return PackedWeight(wpk, precision)
+
+
+def rdb_fused_pack(w1, w2, w3, dtype):
+    """Weights of a ResidualDenseBlock (k = 3) for the one-kernel form (paif_rdb_fused_fwd): 16-bit 16x16x32-MFMA operands."""
+    assert tuple(w1.shape) == (32, 32, 3, 3) and tuple(w2.shape) == (32, 64, 3, 3) and tuple(w3.shape) == (32, 96, 3, 3) and dtype in H16
+    L = lib()
+    wpk = torch.empty(L.paif_rdb_fused_wpk_floats(), device=w1.device, dtype=torch.float32)
+    _lib.check(L.paif_rdb_fused_pack(_p(w1.detach().contiguous()), _p(w2.detach().contiguous()), _p(w3.detach().contiguous()), _p(wpk),
+                                     int(dtype == torch.float16), _stream()), "rdb_fused_pack")
+    return PackedWeight(wpk, "rdb_f16" if dtype == torch.float16 else "rdb_bf16")
+
+
+def rdb_fused(x, wpk, prelu, alpha=0.333333, res=(), cpool=None):
+    """ResidualDenseBlock forward on a 16-bit NHWC-32 map as ONE launch: out = P(c3([x, P(c1(x)), P(c2([x, x1]))])) * alpha + x + res...
+    (operations_m.py:435-449); res: up to two more residual maps; cpool = (comp, offset) as in conv2d."""
+    B, H, W, C = x.shape
+    assert C == 32 and x.dtype in H16 and x.is_contiguous() and len(res) <= 2
+    assert wpk.precision == ("rdb_f16" if x.dtype == torch.float16 else "rdb_bf16")
+    res = [cast_storage(r, x.dtype) for r in res]
+    out = torch.empty_like(x)
+    cp = None
+    if cpool is not None:
+        comp, coff = cpool
+        assert comp.dtype == torch.float32 and tuple(comp.shape) == (B, H, W, 4) and comp.is_contiguous() and coff in (0, 2)
+        cp = ctypes.c_void_p(comp.data_ptr() + 4 * coff)
+    if CONFIG.get("serpentine", True):
+        _SERP[0] ^= 1
+    tag = "rdb_fused_kernel"
+    e0 = TIMER.start(tag) if TIMER is not None else None
+    _lib.check(lib().paif_rdb_fused_fwd(_pa(x), _p(wpk.data), _p(prelu), float(alpha), _pa(res[0]) if len(res) > 0 else None,
+                                        _pa(res[1]) if len(res) > 1 else None, _pa(out), cp, int(x.dtype == torch.float16),
+                                        _SERP[0] if CONFIG.get("serpentine", True) else 0, B, H, W, _stream()), "rdb_fused")
+    if e0 is not None:     # SURVEY 8(d) bytes of the three convs it replaces: x read by each (3), x1 twice, x2 once, three maps written
+        px = B * H * W
+        TIMER.stop(tag, e0, 2 * px * 9 * 32 * 32 * 6, px * 2 * 32 * 9, px * 2 * 32 * len(res))
+    return out
 
 
 def pack_decomp1x1_hf_weight(w):

@@ -452,3 +452,74 @@ def test_fusion_f16_storage_b8_is_samplewise_the_b1_forward():
         for i in (0, 3, 7):
             one = net(irt[i:i + 1].contiguous(), ycc[i:i + 1].contiguous())
             assert torch.equal(full[i:i + 1], one), i
+
+
+@pytest.mark.parametrize("fmt", ["f16", "bf16"])
+@pytest.mark.parametrize("shape,nres,pool", [((2, 333, 517), 0, False), ((1, 480, 640), 2, True), ((1, 37, 53), 1, False), ((3, 8, 28), 0, False),
+                                             ((2, 64, 96), 2, True), ((1, 9, 29), 0, True), ((8, 480, 640), 0, False)])
+def test_residual_dense_block_as_one_kernel(fmt, shape, nres, pool):
+    """csrc/rdb_fused.hip: ResidualDenseBlock (operations_m.py:435-449) of the 16-bit forward as ONE launch (x1, x2 in LDS, halo recompute,
+    16x16x32 MFMAs, 8 x 28 output tiles) against the three-launch form in the same storage.  Both round x1 and x2 to the storage format;
+    the accumulation orders differ, so a pre-rounding value next to a rounding boundary may land on the other neighbour -- a full ulp of
+    x1 / x2 on a vanishing fraction of elements, which reaches the output attenuated by the next conv's weights.  Ragged sizes, images
+    smaller than a tile, tile ranges that straddle images (B = 8), extra residual maps, the fused ChannelPool."""
+    from paif_amd.operations_m import ResidualDenseBlock
+
+    B, H, W = shape
+    dev = _dev()
+    dt = F16 if fmt == "f16" else torch.bfloat16
+    eps = H_EPS if fmt == "f16" else 2.0 ** -8
+    g = torch.Generator().manual_seed(B * 1000 + H + nres)
+    m = ResidualDenseBlock(32, 3, 1).eval()
+    sd = m.state_dict()
+    for k_, v in sd.items():
+        sd[k_] = torch.randn(v.shape, generator=g) * 0.06 if v.dim() == 4 else torch.full(v.shape, 0.2)
+    m.load_state_dict(sd)
+    m = m.to(dev)
+    mk = lambda: ops.cast_storage(ops.to_nhwc(torch.randn(B, 32, H, W, generator=g).to(dev)), dt)
+    x, res = mk(), tuple(mk() for _ in range(nres))
+    ops.set_storage(fmt)
+    with ops.bf16_activations():
+        c3 = torch.full((B, H, W, 4), float("nan"), device=dev)
+        ref = m.forward_nhwc(x, res, None, cpool=(c3, 2) if pool else None)
+        wpk = ops.rdb_fused_pack(m.conv1.conv.weight, m.conv2.conv.weight, m.conv3.conv.weight, dt)
+        c1 = torch.full((B, H, W, 4), float("nan"), device=dev)
+        out = ops.rdb_fused(x, wpk, m.lrelu.weight, alpha=0.333333, res=res, cpool=(c1, 2) if pool else None)
+    torch.cuda.synchronize()
+    assert out.dtype == dt and ref.dtype == dt and bool(torch.isfinite(out.float()).all())
+    d = (out.float() - ref.float()).abs()
+    scale = float(ref.float().abs().max())
+    assert float(d.max()) <= 4.0 * eps * scale, (float(d.max()), scale)
+    assert float((d > 1.01 * eps * ref.float().abs() + 1e-6).float().mean()) < 2e-2          # measured 0.5 %: elsewhere the same 16-bit value or its neighbour
+    assert float(d.mean()) <= 0.1 * eps * float(ref.float().abs().mean()) + 1e-7
+    if pool:
+        assert bool(torch.isnan(c1[..., :2]).all()) and bool(torch.isfinite(c1[..., 2:]).all())
+        assert float((c1[..., 2:] - c3[..., 2:]).abs().max()) <= 2.0 * eps * scale + 1e-6
+    # and against the block in fp32 storage (exact-level arithmetic): the distance is the storage format's
+    ops.set_storage("f32")
+    ref32 = m.forward_nhwc(x.float(), tuple(r.float() for r in res), None)
+    assert float((out.float() - ref32).abs().max()) <= (6.0 if fmt == "f16" else 8.0) * eps * max(1.0, float(ref32.abs().max()))
+
+
+def test_fusion_forward_takes_the_one_kernel_block_at_full_size():
+    """With ops.CONFIG["rdb_fused"] = True (opt-in: measured slower than the three launches) the fp16 inference forward
+    at the benchmarked shape launches the three ResidualDenseBlocks of the shipped genotype as one kernel each, and the result stays
+    within the storage mode's own noise of the three-launch form."""
+    net = _fusion_net()
+    ir, vis, _ = S.make_batch(1, 480, 640)
+    irt, ycc = t(ir).to(_dev()), ops.rgb2ycrcb(t(vis).to(_dev()))
+    ops.set_storage("f16")
+    calls = []
+    orig = ops.rdb_fused
+    ops.rdb_fused = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            three = net(irt, ycc)
+            assert len(calls) == 0                 # the default
+            ops.CONFIG["rdb_fused"] = True
+            one = net(irt, ycc)
+            assert len(calls) == 3
+    finally:
+        ops.rdb_fused = orig
+        ops.CONFIG["rdb_fused"] = False
+    assert float((one - three).abs().max()) <= 1.5e-3 and float((one - three).abs().mean()) <= 6e-5
