@@ -269,11 +269,16 @@ BOUNDS = {
     # bench.py's default configuration (B=8, 480x640, bf16 storage): measured on MI355X in round 4 (+20 %)
     # measured: bf16 fused 1.35e-2 / 7.8e-4, uint8 image max 8 grey levels, 5.4 % of the values > 1 level, 12.4 % != 0;
     #           bf16_split 1.46e-2 / 6.4e-4, max 9 levels, 5.2 % > 1 level
-    "b8_bf16": {"bf16": dict(fused_max=1.7e-2, fused_mean=9.5e-4, lev_max=10, lev_gt1=0.065),
+    # f16 (bench.py's default since round 5): fused 1.8e-3 / 6.3e-5 vs float64; the uint8 image: 99.5 % of the values identical to the
+    # reference's, max 3 grey levels (bf16: 88 % identical, max 9)
+    "b8_bf16": {"f16": dict(fused_max=2.5e-3, fused_mean=1.0e-4, lev_max=4, lev_gt1=0.008),
+                "bf16": dict(fused_max=1.7e-2, fused_mean=9.5e-4, lev_max=10, lev_gt1=0.065),
                 "bf16_split": dict(fused_max=1.8e-2, fused_mean=8e-4, lev_max=11, lev_gt1=0.063)},
     # configs[2] at B=16 vs the oracle on the host.  measured: f32 fused 1.8e-4, logits 4.9e-5 of the range, 408 of 4,915,200 pixels
     # (agreement 0.99992; each decided by the oracle by < 2.2e-5 of the range); bf16 fused 2.2e-2, logits 8.3e-3, agreement 0.99518
-    "b16": {"f32": dict(fused=2.2e-4, logits=1e-4, agree=0.9998), "bf16": dict(fused=2.6e-2, logits=1e-2, agree=0.994)},
+    # f16 (16 samples = 4.9 M pixels): SURVEY 8(d)'s 99.9 % asserted on the batch
+    "b16": {"f32": dict(fused=2.2e-4, logits=1e-4, agree=0.9998), "f16": dict(fused=3e-3, logits=1.5e-3, agree=0.999),
+            "bf16": dict(fused=2.6e-2, logits=1.2e-2, agree=0.985)},
 }
 
 
@@ -323,7 +328,7 @@ def _fusion_net_in_model():
     return net.to(_dev())
 
 
-@pytest.mark.parametrize("mode", ["bf16", "bf16_split"])
+@pytest.mark.parametrize("mode", ["f16", "bf16", "bf16_split"])
 def test_fusion_b8_480x640_bf16_storage_is_what_bench_runs(golden, mode):
     """THE BENCHMARKED CONFIGURATION END TO END: `bench.py` default = fusion forward, B=8, 480x640,
     `--storage bf16`.  (a) sample i of the B=8 launch equals the B=1 launch of sample i bit for bit in the same storage mode;
@@ -366,7 +371,7 @@ def test_fusion_b8_480x640_bf16_storage_is_what_bench_runs(golden, mode):
     assert rec["grey_level_max"] <= lim["lev_max"] and rec["grey_level_frac_gt1"] <= lim["lev_gt1"], rec
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("mode", ["f32", "f16", "bf16"])
 def test_fusion_seg_b16_480x640_vs_oracle(golden, mode):
     """configs[2] as bench.py runs it (B=16, 480x640, mit_b3, default arithmetic; `mode` = fp32 storage, the parity configuration,
     and bf16 storage, `bench.py --workload fusion_seg`'s default) against the CPU oracle on the same 16 pairs (the glue's min/max
