@@ -337,6 +337,29 @@ int paif_gemm_splitk_fwd_p(const float* A, int lda, const float* W, const float*
                          const float* res, int ldres, float* C, int ldc, int M, int N, int K, int splits,
                          float* workspace, int precision, paif_stream_t stream);
 
+/* Strided conv as a GEMM whose A operand is GATHERED from the NHWC map: paif_im2col_fwd + paif_gemm_fwd (OverlapPatchEmbed.proj
+ * core/mix_transformer.py:168-169 for Cin % 32 == 0, Attention.sr :74) without materialising the im2col matrix; bit-identical to that
+ * pair.  x [B,H,W,Cin]; Wt [N, k*k*Cin] (paif_pack_conv_gemm_weight); out [B*OH*OW, >= N], row stride ldc.  precision: PAIF_CONV_BF16X3 or
+ * PAIF_CONV_BF16X6 (PAIF_ENOSUP otherwise: callers keep the im2col pair for the exact fp32 MFMA).  splits = paif_gemm_splitk_plan(B*OH*OW,
+ * N, k*k*Cin); splits > 1 needs workspace[splits * M * N] floats. */
+int paif_gemm_conv_fwd(const float* x, int B, int H, int W, int Cin, int k, int stride, int pad, const float* Wt,
+                       const float* scale, const float* shift, int act, const float* res, int ldres, float* out, int ldc,
+                       int N, int precision, int splits, float* workspace, paif_stream_t stream);
+
+/* Wide-tile form of the split-bf16 paif_gemm_fwd (csrc/gemm_split2.hip) for the same nn.Linear sites (core/mix_transformer.py:22-25,
+ * 66-69,74; core/segformer_head.py:19): workgroup tile 128 x 64*nt, wave tile 64 x 32*nt.  paif_gemm2_plan returns nt (1, 2, 4 or 5
+ * column tiles per wave) for a shape it is built for, 0 otherwise (the caller then takes paif_gemm_fwd).  precision: PAIF_CONV_BF16X3 or
+ * PAIF_CONV_BF16X6.  N % (64*nt) == 0; ldc, ldres % 4 == 0; 16-byte aligned A, C, res, scale, shift.  Same arithmetic per product and
+ * the same k order as paif_gemm_fwd: results are bit-identical to it. */
+int paif_gemm2_plan(int M, int N, int K, int precision);
+/* W of paif_gemm2_fwd is the PRE-SPLIT image of the nn.Linear weight [N, K]: [K/32][N][pieces][32] bf16 (pieces = 2 for BF16X3, 3 for
+ * BF16X6; paif_gemm2_packed_bytes bytes), written by paif_gemm2_pack_weight -- once per weight version, not per call. */
+size_t paif_gemm2_packed_bytes(int N, int K, int precision);
+int paif_gemm2_pack_weight(const float* W, void* out, int N, int K, int precision, paif_stream_t stream);
+int paif_gemm2_fwd(const float* A, int lda, const void* W, const float* scale, const float* shift, int act,
+                   const float* res, int ldres, float* C, int ldc, int M, int N, int K, int precision, int nt,
+                   paif_stream_t stream);
+
 /* nn.LayerNorm over the last dim (core/mix_transformer.py:75,122,127,172,232-253). x,y [M,C]; C % 4 == 0. */
 int paif_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, int M, int C, float eps,
                        paif_stream_t stream);

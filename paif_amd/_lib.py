@@ -81,6 +81,11 @@ SIGNATURES = {
     "paif_add_fwd": (c_int, [F, F, F, c_size_t, F]),
     "paif_gemm_fwd": (c_int, [F, c_int, F, F, F, c_int, F, c_int, F, c_int, c_int, c_int, c_int, c_int, F]),
     "paif_gemm_splitk_plan": (c_int, [c_int, c_int, c_int]),
+    "paif_gemm_conv_fwd": (c_int, [F, c_int, c_int, c_int, c_int, c_int, c_int, c_int, F, F, F, c_int, F, c_int, F, c_int, c_int, c_int, c_int, F, F]),
+    "paif_gemm2_plan": (c_int, [c_int, c_int, c_int, c_int]),
+    "paif_gemm2_packed_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "paif_gemm2_pack_weight": (c_int, [F, F, c_int, c_int, c_int, F]),
+    "paif_gemm2_fwd": (c_int, [F, c_int, F, F, F, c_int, F, c_int, F, c_int, c_int, c_int, c_int, c_int, c_int, F]),
     "paif_conv2d_wgrad_workspace_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "paif_conv2d_wgrad": (c_int, [POINTER(c_void_p), c_int, F, F, F, F, c_int, c_float, c_int, c_int, F, F, c_int, c_int, c_int, c_int, c_int, F]),
     "paif_gemm_wgrad_splits": (c_int, [c_int, c_int, c_int]),

@@ -182,8 +182,7 @@ class Attention(nn.Module):
         if self.sr_ratio > 1:
             sr = self.sr_ratio
             wsr = self._packs.get("sr", [self.sr.weight], lambda: ops.pack_conv_gemm_weight(self.sr.weight))
-            col = ops.im2col(x.view(B, H, W, C), sr, sr, 0, wsr.shape[1])
-            x_sr = ops.gemm(col.view(B, -1, wsr.shape[1]), wsr, shift=self.sr.bias)
+            x_sr, _, _ = ops.conv_gemm(x.view(B, H, W, C), wsr, sr, sr, 0, shift=self.sr.bias)   # the im2col matrix is gathered in the GEMM's loader
             x_ = ops.layernorm(x_sr, self.norm.weight, self.norm.bias, self.norm.eps)
         else:
             x_ = x
@@ -308,9 +307,7 @@ class OverlapPatchEmbed(nn.Module):
         """x NHWC [B,H,W,Cin] -> tokens [B, OH*OW, D], OH, OW."""
         k = self.patch_size[0]
         w = self._packs.get("w", [self.proj.weight], lambda: ops.pack_conv_gemm_weight(self.proj.weight))
-        col = ops.im2col(x, k, self.stride, k // 2, w.shape[1])
-        B, OH, OW, _ = col.shape
-        t = ops.gemm(col.view(B, OH * OW, -1), w, shift=self.proj.bias)
+        t, OH, OW = ops.conv_gemm(x, w, k, self.stride, k // 2, shift=self.proj.bias)
         if tape is not None:
             tape.append(dict(pre=t, in_shape=tuple(x.shape), x_in=x if ops.taping_wgrad() else None))
         return ops.layernorm(t, self.norm.weight, self.norm.bias, self.norm.eps), OH, OW

@@ -30,6 +30,9 @@ struct GemmArgs {
   int kper;            // k extent of one split (= K without split-K); blockIdx.y selects the split
   float* partial;      // split-K: raw accumulators go to partial[split][M][N] (no epilogue); else NULL
   int wide;            // 1: N, ldc, ldres multiples of 4 and C / res 16-byte aligned -> float4 epilogue through LDS
+  // GATHER form (paif_gemm_conv_fwd): A is an NHWC map [gB, gH, gW, gC]; row m = output pixel (b, oy, ox) of a gk x gk conv with
+  // stride gs and padding gpad, column index (ky * gk + kx) * gC + c -- the im2col matrix, never materialised
+  int gk, gs, gpad, gH, gW, gC, gOH, gOW;
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return paif::gelu_erf_fast(x); }   // paif_common.h: x * Phi(x), one polynomial + v_exp_f32
@@ -325,8 +328,9 @@ __device__ __forceinline__ void split_store3(char* dst, float4 t4) {
   *reinterpret_cast<uint2*>(dst + 128) = make_uint2(pk(lx, ly), pk(lz, lw));
 }
 
-template <bool MASKED, int NP = 2>
+template <bool MASKED, int NP = 2, bool GATHER = false>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16x3(GemmArgs a) {
+  static_assert(!(MASKED && GATHER), "the dgrad prologue reads a mask with A's own layout");
   constexpr int RB = NP == 3 ? 208 : 144;   // bytes per staged row of a 32-wide K tile (shadows the two-piece constant)
   __shared__ __align__(16) char sA[BM * RB];
   __shared__ __align__(16) char sW[BN * RB];
@@ -353,11 +357,32 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16x3(GemmArgs a) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) woff[i] = (unsigned)min(n0 + srow + 32 * i, a.N - 1) * (unsigned)a.K + sq * 4;
   const bool masked = MASKED && a.a_mask != nullptr, scaled = MASKED && a.a_scale != nullptr;   // launch-uniform
+  int iy0[GATHER ? 4 : 1], ix0[GATHER ? 4 : 1];   // GATHER: top-left input pixel of the row's patch; aoff = pixel index of its image
+  if constexpr (GATHER) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = min(m0 + srow + 32 * i, a.M - 1);
+      const int ox = m % a.gOW, t = m / a.gOW, oy = t % a.gOH, b = t / a.gOH;
+      iy0[i] = oy * a.gs - a.gpad; ix0[i] = ox * a.gs - a.gpad;
+      aoff[i] = (unsigned)b * (unsigned)(a.gH * a.gW);
+    }
+  }
 
   float4 va[4], vw[2], vm[MASKED ? 4 : 1], vs;
   auto gload = [&](int k0) {
+    if constexpr (GATHER) {   // a 32-wide k tile lies inside one tap (gC % 32 == 0): 128 contiguous bytes of one input pixel, or padding
+      const int kk = k0 / a.gC, c0 = k0 - kk * a.gC, ky = kk / a.gk, kx = kk - ky * a.gk;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) va[i] = *reinterpret_cast<const float4*>(a.A + (aoff[i] + (unsigned)k0));
+      for (int i = 0; i < 4; ++i) {
+        const int iy = iy0[i] + ky, ix = ix0[i] + kx;
+        const bool ok = (unsigned)iy < (unsigned)a.gH && (unsigned)ix < (unsigned)a.gW;
+        const unsigned off = (aoff[i] + (unsigned)(iy * a.gW + ix)) * (unsigned)a.gC + (unsigned)(c0 + sq * 4);
+        va[i] = ok ? *reinterpret_cast<const float4*>(a.A + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) va[i] = *reinterpret_cast<const float4*>(a.A + (aoff[i] + (unsigned)k0));
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) vw[i] = *reinterpret_cast<const float4*>(a.W + (woff[i] + (unsigned)k0));
     if constexpr (MASKED) {
@@ -490,6 +515,7 @@ extern "C" int paif_gemm_masked_fwd(const float* A, int lda, const float* a_mask
   PAIF_REQUIRE(lda >= K && ldc >= N && (lda % 4) == 0, PAIF_EINVAL, "gemm: bad leading dimensions lda=%d ldc=%d", lda, ldc);
   PAIF_REQUIRE(act >= 0 && act <= 2, PAIF_EINVAL, "gemm: act=%d", act);
   GemmArgs a;
+  a.gk = 0;
   a.a_mask = a_mask; a.a_scale = a_scale;
   a.A = A; a.W = W; a.scale = scale; a.shift = shift; a.res = res; a.C = C;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldres = res ? ldres : 0; a.act = act;
@@ -555,6 +581,7 @@ extern "C" int paif_gemm_splitk_fwd_p(const float* A, int lda, const float* W, c
   PAIF_REQUIRE(lda >= K && ldc >= N && (lda % 4) == 0, PAIF_EINVAL, "gemm_splitk: bad leading dimensions lda=%d ldc=%d", lda, ldc);
   PAIF_REQUIRE(act >= 0 && act <= 2, PAIF_EINVAL, "gemm_splitk: act=%d", act);
   GemmArgs a;
+  a.gk = 0;
   a.a_mask = nullptr; a.a_scale = nullptr;
   a.A = A; a.W = W; a.scale = nullptr; a.shift = nullptr; a.res = nullptr; a.C = C;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldres = 0; a.act = 0;
@@ -575,5 +602,52 @@ extern "C" int paif_gemm_splitk_fwd_p(const float* A, int lda, const float* W, c
   hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(rblocks), dim3(256), 0, st, workspace, splits, scale, shift, act, res,
                      res ? ldres : 0, C, ldc, M, N);
   PAIF_LAUNCH_CHECK("gemm_splitk_reduce");
+  return 0;
+}
+
+// Strided conv as a GEMM whose A operand is gathered from the NHWC map (OverlapPatchEmbed.proj core/mix_transformer.py:168-169 for the
+// stages with Cin % 32 == 0, Attention.sr :74): the im2col matrix of paif_im2col_fwd + paif_gemm_fwd without writing and re-reading it.
+// Same k order, same arithmetic: bit-identical to that pair.  x [B,H,W,Cin]; Wt [N, k*k*Cin] (paif_pack_conv_gemm_weight);
+// out [B*OH*OW, >= N] row stride ldc.  precision: PAIF_CONV_BF16X3 / PAIF_CONV_BF16X6.  splits > 1 (paif_gemm_splitk_plan of the
+// im2col shape): workspace[splits * M * N] floats, partial sums added in split order by the reduction pass.
+extern "C" int paif_gemm_conv_fwd(const float* x, int B, int H, int W, int Cin, int k, int stride, int pad, const float* Wt,
+                                  const float* scale, const float* shift, int act, const float* res, int ldres, float* out, int ldc,
+                                  int N, int precision, int splits, float* workspace, paif_stream_t stream) {
+  PAIF_REQUIRE(precision == 1 || precision == 3, PAIF_ENOSUP, "gemm_conv: precision=%d (the gathered form is built for the split-bf16 kernels)", precision);
+  PAIF_REQUIRE(x && Wt && out, PAIF_EINVAL, "gemm_conv: null pointer");
+  PAIF_REQUIRE(B > 0 && H > 0 && W > 0 && N > 0 && k > 0 && stride > 0 && pad >= 0, PAIF_EINVAL, "gemm_conv: bad shape");
+  PAIF_REQUIRE(Cin % 32 == 0, PAIF_ENOSUP, "gemm_conv: Cin=%d must be a multiple of 32 (a k tile inside one tap)", Cin);
+  const int OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;
+  PAIF_REQUIRE(OH > 0 && OW > 0, PAIF_EINVAL, "gemm_conv: empty output");
+  const int M = B * OH * OW, K = k * k * Cin;
+  PAIF_REQUIRE(ldc >= N && act >= 0 && act <= 2, PAIF_EINVAL, "gemm_conv: ldc=%d act=%d", ldc, act);
+  PAIF_REQUIRE(splits >= 1 && (K / BK) % splits == 0 && (splits == 1 || workspace), PAIF_EINVAL, "gemm_conv: splits=%d, %d k tiles", splits, K / BK);
+  PAIF_REQUIRE((size_t)B * H * W * Cin < ((size_t)1 << 32) && (size_t)N * K < ((size_t)1 << 32), PAIF_ENOSUP, "gemm_conv: operands exceed the 32-bit element offsets");
+  GemmArgs a;
+  a.a_mask = nullptr; a.a_scale = nullptr;
+  a.A = x; a.W = Wt; a.C = out;
+  a.M = M; a.N = N; a.K = K; a.lda = K; a.ldc = ldc;
+  a.tilesN = (N + BN - 1) / BN;
+  a.nblk = a.tilesN * ((M + BM - 1) / BM);
+  a.kper = K / splits;
+  a.gk = k; a.gs = stride; a.gpad = pad; a.gH = H; a.gW = W; a.gC = Cin; a.gOH = OH; a.gOW = OW;
+  hipStream_t st = paif::as_stream(stream);
+  if (splits > 1) {
+    a.scale = nullptr; a.shift = nullptr; a.res = nullptr; a.ldres = 0; a.act = 0; a.partial = workspace; a.wide = 0;
+  } else {
+    a.scale = scale; a.shift = shift; a.res = res; a.ldres = res ? ldres : 0; a.act = act; a.partial = nullptr;
+    a.wide = (N % 4 == 0) && (ldc % 4 == 0) && ((uintptr_t)out % 16 == 0) && (!res || (ldres % 4 == 0 && (uintptr_t)res % 16 == 0)) &&
+             (!scale || (uintptr_t)scale % 16 == 0) && (!shift || (uintptr_t)shift % 16 == 0);
+  }
+  if (precision == 3) hipLaunchKernelGGL((gemm_mfma_bf16x3<false, 3, true>), dim3(a.nblk, splits), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((gemm_mfma_bf16x3<false, 2, true>), dim3(a.nblk, splits), dim3(256), 0, st, a);
+  PAIF_LAUNCH_CHECK("gemm_conv");
+  if (splits > 1) {
+    const size_t total = (size_t)M * N;
+    const int rblocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(rblocks), dim3(256), 0, st, workspace, splits, scale, shift, act, res,
+                       res ? ldres : 0, out, ldc, M, N);
+    PAIF_LAUNCH_CHECK("gemm_conv_reduce");
+  }
   return 0;
 }

@@ -13,6 +13,7 @@ boundary: an NHWC tensor viewed as [B,C,H,W] is exactly torch's channels_last fo
 is kept without copies between our own ops.
 """
 import ctypes
+import weakref
 import os
 
 import torch
@@ -52,7 +53,7 @@ ACT_GELU = 1  # paif_gemm_fwd's act code 1 is GELU (the conv's code 1 is PReLU)
 # and every 1-channel plane stay fp32 (SURVEY hard part 1).  Taped (gradient) passes always run fp32 storage.  Tolerance of this
 # mode: SURVEY 8(d) bf16 clause (max / mean |fused - reference| reported, argmax agreement >= 99.9 %, mIoU within 0.1 pt):
 # tests/test_bf16_storage_gpu.py.
-CONFIG = {"conv_precision": "bf16x3", "gemm_precision": "auto", "serpentine": True, "attack_precision": "bf16x6", "storage": "f32",
+CONFIG = {"conv_precision": "bf16x3", "gemm_precision": os.environ.get("PAIF_GEMM_PRECISION", "auto"), "serpentine": True, "attack_precision": "bf16x6", "storage": "f32",
           # inference forward of the fusion network: run the infrared and the visible stream on two HIP streams (identical results; off by
           # default because per-launch timings -- bench.py's roofline blocks, rocprofv3 averages -- then measure CU sharing, not kernels)
           "two_stream": False,
@@ -62,7 +63,7 @@ CONFIG = {"conv_precision": "bf16x3", "gemm_precision": "auto", "serpentine": Tr
           # 16-bit inference forward: a ResidualDenseBlock (k = 3, dilation 1) as ONE kernel (csrc/rdb_fused.hip) on maps of >= 512 tiles.
           # OFF by default: correct (tests/test_f16_storage_gpu.py) and 2 map passes instead of 9, but matrix-pipe bound at the clock the chip
           # sustains under that load -- 400 us per block inside the forward against 355 for the three bandwidth-bound launches
-          "rdb_fused": False}
+          "rdb_fused": False, "gemm2": False, "gemm_gather": os.environ.get("PAIF_GEMM_GATHER", "1") != "0"}
 # falsy, or the torch dtype (torch.bfloat16 / torch.float16) of the 32-channel maps while an inference forward of the fusion network
 # runs in a 16-bit storage mode (set by the model through `bf16_activations`)
 _ACT_BF16 = [False]
@@ -893,6 +894,32 @@ def add(a, b):
 # ---------------------------------------------------------------------------------------------
 # segmentation network (token tensors [B,N,C] = NHWC)
 # ---------------------------------------------------------------------------------------------
+_GEMM2_PACKS = {}   # id(weight tensor) -> (weakref, validity key, {precision: packed image})
+
+
+def _gemm2_pack(w, prec):
+    """The pre-split image of a Linear weight for csrc/gemm_split2.hip, built once per (tensor object, data_ptr, version, weights
+    generation) and precision.  Keyed on the tensor OBJECT (weak reference): a temporary's address can be reused by another tensor
+    with the same version counter, an object cannot while it is alive.  Callers on a hot path pass the same object every call
+    (module parameters, the cached transposes of the backward)."""
+    key = (w.data_ptr(), w._version, tuple(w.shape), str(w.device), CONFIG.get("weights_generation", 0))
+    ent = _GEMM2_PACKS.get(id(w))
+    if ent is None or ent[0]() is not w or ent[1] != key:
+        ent = (weakref.ref(w, lambda _, i=id(w): _GEMM2_PACKS.pop(i, None)), key, {})
+        _GEMM2_PACKS[id(w)] = ent
+    pk = ent[2].get(prec)
+    if pk is None:
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the pre-split image of a %s GEMM weight (%s) is missing while a hipGraph is being captured: run one eager "
+                               "step in this arithmetic first" % (tuple(w.shape), prec))
+        N, K = w.shape
+        L = lib()
+        pk = torch.empty(L.paif_gemm2_packed_bytes(N, K, _PREC_CODE[prec]), device=w.device, dtype=torch.uint8)
+        _lib.check(L.paif_gemm2_pack_weight(_p(w.detach()), ctypes.c_void_p(pk.data_ptr()), N, K, _PREC_CODE[prec], _stream()), "gemm2_pack")
+        ent[2][prec] = pk
+    return pk
+
+
 def gemm(a, w, scale=None, shift=None, act=ACT_NONE, res=None, out=None, out_cols=None, col_offset=0,
          a_cols=None, a_mask=None, a_scale=None):
     """a [..., K] x w [N, K]^T -> [..., N].  scale/shift per output column (bias = shift).
@@ -932,7 +959,15 @@ def gemm(a, w, scale=None, shift=None, act=ACT_NONE, res=None, out=None, out_col
         prec = "bf16x6" if (K >= 256 and M >= 2048) else "f32"
     tag = "gemm_mfma_%s" % prec
     e0 = TIMER.start(tag) if TIMER is not None else None
-    if splits > 1:
+    nt = 0
+    if CONFIG["gemm2"] and splits == 1 and a_mask is None and a_scale is None and prec in ("bf16x3", "bf16x6") and ldc % 4 == 0:
+        nt = L.paif_gemm2_plan(M, N, K, _PREC_CODE[prec])
+        if CONFIG["gemm2"] is not True and nt:      # A/B: a forced tile width (tools/gemm_shapes_b16.py)
+            nt = int(CONFIG["gemm2"]) if N % (64 * int(CONFIG["gemm2"])) == 0 else nt
+    if nt:
+        _lib.check(L.paif_gemm2_fwd(aptr, lda, ctypes.c_void_p(_gemm2_pack(w, prec).data_ptr()), _p(scale), _p(shift), act, _p(res), N, cptr, ldc, M, N, K,
+                                    _PREC_CODE[prec], nt, _stream()), "gemm2")
+    elif splits > 1:
         ws = torch.empty(splits * M * N, device=a.device, dtype=torch.float32)
         _lib.check(L.paif_gemm_splitk_fwd_p(aptr, lda, _p(w), _p(scale), _p(shift), act, _p(res), N, cptr, ldc, M, N, K, splits,
                                             _p(ws), _PREC_CODE[prec], _stream()), "gemm_splitk")
@@ -1536,6 +1571,36 @@ def im2col(x, k, stride, pad, kpad):
     col = torch.empty((B, OH, OW, kpad), device=x.device, dtype=torch.float32)
     _lib.check(lib().paif_im2col_fwd(_p(x), _p(col), B, H, W, Cin, k, stride, pad, kpad, _stream()), "im2col")
     return col
+
+
+def conv_gemm(x, wp, k, stride, pad, shift=None, scale=None, act=ACT_NONE):
+    """Strided k x k conv of an NHWC map as ONE GEMM: x [B,H,W,Cin], wp [N, Kpad] (pack_conv_gemm_weight) -> tokens [B, OH*OW, N], OH, OW.
+    With Cin % 32 == 0 and a split-bf16 GEMM arithmetic the A operand is gathered from the map inside the GEMM's loader
+    (paif_gemm_conv_fwd: no im2col matrix in HBM; bit-identical to the pair); otherwise im2col + gemm (the exact fp32 MFMA, 3-channel
+    inputs)."""
+    B, H, W, Cin = x.shape
+    N, kpad = wp.shape
+    OH, OW = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
+    M, K = B * OH * OW, k * k * Cin
+    prec = CONFIG["gemm_precision"]
+    if prec == "auto":
+        prec = "bf16x3" if (K >= 256 and M >= 2048) else "f32"
+    elif prec == "auto6":
+        prec = "bf16x6" if (K >= 256 and M >= 2048) else "f32"
+    if not CONFIG["gemm_gather"] or Cin % 32 != 0 or prec not in ("bf16x3", "bf16x6") or kpad != K:
+        col = im2col(x, k, stride, pad, kpad)
+        return gemm(col.view(B, OH * OW, kpad), wp, scale=scale, shift=shift, act=act), OH, OW
+    L = lib()
+    splits = L.paif_gemm_splitk_plan(M, N, K)
+    out = torch.empty((B, OH * OW, N), device=x.device, dtype=torch.float32)
+    ws = torch.empty(splits * M * N, device=x.device, dtype=torch.float32) if splits > 1 else None
+    tag = "gemm_mfma_%s" % prec
+    e0 = TIMER.start(tag) if TIMER is not None else None
+    _lib.check(L.paif_gemm_conv_fwd(_p(x), B, H, W, Cin, k, stride, pad, _p(wp), _p(scale), _p(shift), act, None, 0, _p(out), N, N,
+                                    _PREC_CODE[prec], splits, _p(ws), _stream()), "gemm_conv")
+    if e0 is not None:
+        TIMER.stop(tag, e0, 2 * M * N * K, 4 * (M * K + N * K + M * N))
+    return out, OH, OW
 
 
 def pack_conv_gemm_weight(w):
