@@ -383,9 +383,13 @@ int paif_dwconv3_bias_gelu_fwd(const float* x, const float* w, const float* bias
  * PAIF_ENOSUP when Nk*(C/heads)*8 B > 160 KiB or the head dim is not 32/64. */
 int paif_sr_attention_fwd(const float* q, const float* kv, float* out, float* lse, int B, int N, int Nk, int C, int heads,
                           paif_stream_t stream);
-/* Same contract, split-bf16 products (hi*hi + hi*lo + lo*hi on the bf16 MFMA, fp32 accumulate and softmax; ~1e-5 relative on
- * the products): 5.3x less matrix-pipe time than the exact-fp32 kernel.  Holds up to 316 keys at head dim 64 in LDS; with more (the exact
- * kernel takes 320) it runs the exact kernel. */
+/* Same contract, split-bf16 products on the bf16 MFMA (fp32 accumulate and softmax).  precision PAIF_CONV_BF16X3: operands as two bf16
+ * pieces, hi*hi + hi*lo + lo*hi (~1e-5 relative on the products, 5.3x less matrix-pipe time than the exact-fp32 kernel);
+ * PAIF_CONV_BF16X6: three pieces, six products (2^-25: fp32-level -- the attack loops' arithmetic, 2.7x less matrix-pipe time).  K and
+ * V^T are staged in LDS in chunks of keys (the online softmax carries over chunks): two pieces x 300 keys x 64 dims fit at once, three
+ * pieces take chunks of 160 keys; any Nk.  paif_sr_attention_bf16x3_fwd = precision PAIF_CONV_BF16X3. */
+int paif_sr_attention_split_fwd(const float* q, const float* kv, float* out, float* lse, int B, int N, int Nk, int C, int heads,
+                                int precision, paif_stream_t stream);
 int paif_sr_attention_bf16x3_fwd(const float* q, const float* kv, float* out, float* lse, int B, int N, int Nk, int C, int heads,
                           paif_stream_t stream);
 
@@ -433,7 +437,8 @@ int paif_sr_attention_bwd_input(const float* q, const float* kv, const float* o,
                                 float* delta, float* dq, float* dkv, float* dkv_partial, int B, int N, int Nk, int C,
                                 int heads, paif_stream_t stream);
 /* Same, with the arithmetic of the matrix products selectable: precision 0 = exact fp32 MFMA (= paif_sr_attention_bwd_input),
- * 1 = split-bf16 (hi*hi + hi*lo + lo*hi on the bf16 MFMA, fp32 accumulate; softmax statistics, delta and the slab reduction stay fp32). */
+ * 1 = split-bf16 (hi*hi + hi*lo + lo*hi on the bf16 MFMA, fp32 accumulate; softmax statistics, delta and the slab reduction stay fp32),
+ * 3 = three bf16 pieces per operand, six products (fp32-level; keys in LDS chunks of 128 at head dim 64). */
 int paif_sr_attention_bwd_input_p(const float* q, const float* kv, const float* o, const float* dout, const float* lse,
                                 float* delta, float* dq, float* dkv, float* dkv_partial, int B, int N, int Nk, int C,
                                 int heads, int precision, paif_stream_t stream);

@@ -107,6 +107,7 @@ SIGNATURES = {
     "paif_dwconv3_bias_gelu_fwd": (c_int, [F, F, F, F, c_int, c_int, c_int, c_int, F]),
     "paif_sr_attention_fwd": (c_int, [F, F, F, F, c_int, c_int, c_int, c_int, c_int, F]),
     "paif_sr_attention_bf16x3_fwd": (c_int, [F, F, F, F, c_int, c_int, c_int, c_int, c_int, F]),
+    "paif_sr_attention_split_fwd": (c_int, [F, F, F, F, c_int, c_int, c_int, c_int, c_int, c_int, F]),
     "paif_resize_bilinear_into_fwd": (c_int, [F, F, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, F]),
     "paif_nhwc_to_nchw_fwd": (c_int, [F, F, c_int, c_int, c_int, F]),
     "paif_nchw_to_nhwc_fwd": (c_int, [F, F, c_int, c_int, c_int, F]),

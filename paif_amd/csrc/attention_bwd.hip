@@ -10,6 +10,8 @@
 //                 walks a chunk of query tiles staged in LDS: S and dP tiles, then dV^T += dO^T . P and
 //                 dK^T += Q^T . dS with the accumulator registers as B operands.  Partial dK/dV per query
 //                 chunk go to a slab that a fixed-order reduction sums (deterministic, no float atomics).
+#include <type_traits>
+
 #include "paif_common.h"
 
 namespace {
@@ -126,24 +128,25 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnBwdArgs a) {
 // key-slot permutation: the dS^T accumulator registers are the B operand as they stand.
 // ---------------------------------------------------------------------------------------------
 typedef __bf16 bbf16x8 __attribute__((ext_vector_type(8)));
+using paif::splitN;
+using paif::mfma_pieces;
 
-__device__ __forceinline__ void bsplit8(const float (&v)[8], bbf16x8& hi, bbf16x8& lo) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const __bf16 hx = (__bf16)v[i];
-    hi[i] = hx;
-    lo[i] = (__bf16)(v[i] - (float)hx);
-  }
-}
+// NP: bf16 pieces per operand (2: "bf16x3", three products; 3: "bf16x6", six products -- fp32-level, the attack loops' arithmetic)
+template <int D, int NP>
+struct DqCfg {
+  static constexpr int KC = D == 64 ? (NP == 3 ? 128 : 160) : (NP == 3 ? 160 : 320);   // keys per LDS chunk
+  static constexpr int KREC = D * 2 * NP;                  // row-major record: NP pieces of D bf16
+  static constexpr int TREC = KC * 2 * NP + 16;            // transposed record: NP x KC slots | pad
+  static constexpr size_t lds_bytes = (size_t)2 * KC * KREC + (size_t)D * TREC;
+  static_assert(lds_bytes <= 160 * 1024, "dq(split): key chunk does not fit LDS");
+};
 
-template <int D>
-__global__ __launch_bounds__(512) void attn_bwd_dq_bf16x3_kernel(AttnBwdArgs a) {
+template <int D, int NP>
+__global__ __launch_bounds__(512) void attn_bwd_dq_split_kernel(AttnBwdArgs a) {
   extern __shared__ __align__(16) char ldsc[];
   constexpr int NT = 512;
   constexpr int NO = D / 16, DT = D / 32;
-  constexpr int KC = D == 64 ? 160 : 320;   // keys per LDS chunk
-  constexpr int KREC = D * 4;               // row-major record: hi | lo
-  constexpr int TREC = KC * 4 + 16;         // transposed record: KC slots hi | KC slots lo | pad
+  constexpr int KC = DqCfg<D, NP>::KC, KREC = DqCfg<D, NP>::KREC, TREC = DqCfg<D, NP>::TREC;
   char* Kr = ldsc;
   char* Vr = ldsc + KC * KREC;
   char* Kt = ldsc + 2 * KC * KREC;
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_bf16x3_kernel(AttnBwdArgs a) 
   const bool wave_live = q0 < a.N;          // dead waves still stage and hit the barriers
   const int qi = min(q0 + p, a.N - 1);
   const size_t rowoff = ((size_t)b * a.N + qi) * C + hd * D;
-  bbf16x8 qh[NO], ql[NO], doh[NO], dol[NO];
+  bbf16x8 qp[NO][NP], dop[NO][NP];
   float dpart = 0.f;
 #pragma unroll
   for (int o = 0; o < NO; ++o) {
@@ -170,8 +173,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_bf16x3_kernel(AttnBwdArgs a) 
       d8[4 * j] = dv.x; d8[4 * j + 1] = dv.y; d8[4 * j + 2] = dv.z; d8[4 * j + 3] = dv.w;
       dpart += (dv.x * ov.x + dv.y * ov.y) + (dv.z * ov.z + dv.w * ov.w);
     }
-    bsplit8(q8, qh[o], ql[o]);
-    bsplit8(d8, doh[o], dol[o]);
+    splitN<NP>(q8, qp[o]);
+    splitN<NP>(d8, dop[o]);
   }
   const float delta = dpart + __shfl_xor(dpart, 32);
   const size_t stat = ((size_t)b * a.heads + hd) * a.N + qi;
@@ -197,15 +200,16 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_bf16x3_kernel(AttnBwdArgs a) 
       const float4 v0 = *reinterpret_cast<const float4*>(krow + C), v1 = *reinterpret_cast<const float4*>(krow + C + 4);
       const float k8[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
       const float v8[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-      bbf16x8 kh, kl, vh, vl;
-      bsplit8(k8, kh, kl);
-      bsplit8(v8, vh, vl);
+      bbf16x8 kp[NP], vp[NP];
+      splitN<NP>(k8, kp);
+      splitN<NP>(v8, vp);
       if (live) {
         const int sw = key & (D / 8 - 1);
-        *reinterpret_cast<bbf16x8*>(Kr + key * KREC + ((c ^ sw) << 4)) = kh;
-        *reinterpret_cast<bbf16x8*>(Kr + key * KREC + D * 2 + ((c ^ sw) << 4)) = kl;
-        *reinterpret_cast<bbf16x8*>(Vr + key * KREC + ((c ^ sw) << 4)) = vh;
-        *reinterpret_cast<bbf16x8*>(Vr + key * KREC + D * 2 + ((c ^ sw) << 4)) = vl;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+          *reinterpret_cast<bbf16x8*>(Kr + key * KREC + q * D * 2 + ((c ^ sw) << 4)) = kp[q];
+          *reinterpret_cast<bbf16x8*>(Vr + key * KREC + q * D * 2 + ((c ^ sw) << 4)) = vp[q];
+        }
       }
       const int kk = key & 31, tt = key >> 5;
       const int hh = (kk >> 2) & 1, r = (kk & 3) + 4 * (kk >> 3);
@@ -213,8 +217,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_bf16x3_kernel(AttnBwdArgs a) 
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int dim = c * 8 + i;
-        *reinterpret_cast<__bf16*>(Kt + dim * TREC + slot * 2) = live ? kh[i] : (__bf16)0.f;
-        *reinterpret_cast<__bf16*>(Kt + dim * TREC + KC * 2 + slot * 2) = live ? kl[i] : (__bf16)0.f;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) *reinterpret_cast<__bf16*>(Kt + dim * TREC + q * KC * 2 + slot * 2) = live ? kp[q][i] : (__bf16)0.f;
       }
     }
     __syncthreads();
@@ -231,16 +235,14 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_bf16x3_kernel(AttnBwdArgs a) 
 #pragma unroll
       for (int o = 0; o < NO; ++o) {
         const int cc = ((2 * o + h) ^ sw) << 4;
-        const bbf16x8 kh = *reinterpret_cast<const bbf16x8*>(krow + cc);
-        const bbf16x8 kl = *reinterpret_cast<const bbf16x8*>(krow + D * 2 + cc);
-        const bbf16x8 vh = *reinterpret_cast<const bbf16x8*>(vrow + cc);
-        const bbf16x8 vl = *reinterpret_cast<const bbf16x8*>(vrow + D * 2 + cc);
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[o], st, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, doh[o], dp, 0, 0, 0);
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[o], st, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, dol[o], dp, 0, 0, 0);
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[o], st, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, doh[o], dp, 0, 0, 0);
+        bbf16x8 kp[NP], vp[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+          kp[q] = *reinterpret_cast<const bbf16x8*>(krow + q * D * 2 + cc);
+          vp[q] = *reinterpret_cast<const bbf16x8*>(vrow + q * D * 2 + cc);
+        }
+        mfma_pieces<NP>(st, kp, qp[o]);
+        mfma_pieces<NP>(dp, vp, dop[o]);
       }
       // dS^T = P^T o (dP^T - delta) * scale     (register r <-> key c0 + t*32 + (r&3)+8(r>>2)+4h)
 #pragma unroll
@@ -255,17 +257,16 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_bf16x3_kernel(AttnBwdArgs a) 
         float d8[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) d8[i] = st[8 * s2 + i];
-        bbf16x8 dsh, dsl;
-        bsplit8(d8, dsh, dsl);
+        bbf16x8 dsp[NP];
+        splitN<NP>(d8, dsp);
         const int soff = (t * 32 + s2 * 16 + 8 * h) * 2;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
           const int dim = 32 * dt + p;
-          const bbf16x8 th = *reinterpret_cast<const bbf16x8*>(Kt + dim * TREC + soff);
-          const bbf16x8 tl = *reinterpret_cast<const bbf16x8*>(Kt + dim * TREC + KC * 2 + soff);
-          dqacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tl, dsh, dqacc[dt], 0, 0, 0);
-          dqacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th, dsl, dqacc[dt], 0, 0, 0);
-          dqacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th, dsh, dqacc[dt], 0, 0, 0);
+          bbf16x8 tp[NP];
+#pragma unroll
+          for (int q = 0; q < NP; ++q) tp[q] = *reinterpret_cast<const bbf16x8*>(Kt + dim * TREC + q * KC * 2 + soff);
+          mfma_pieces<NP>(dqacc[dt], tp, dsp);
         }
       }
     }
@@ -281,15 +282,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_bf16x3_kernel(AttnBwdArgs a) 
   }
 }
 
-template <int D>
-int launch_dq_bf16x3(const AttnBwdArgs& a, hipStream_t st) {
-  constexpr int KC = D == 64 ? 160 : 320;
-  constexpr size_t lds_bytes = (size_t)2 * KC * D * 4 + (size_t)D * (KC * 4 + 16);
-  static_assert(lds_bytes <= 160 * 1024, "dq(bf16x3): key chunk does not fit LDS");
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_bf16x3_kernel<D>),
+template <int D, int NP>
+int launch_dq_split(const AttnBwdArgs& a, hipStream_t st) {
+  constexpr size_t lds_bytes = DqCfg<D, NP>::lds_bytes;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_split_kernel<D, NP>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  if (e != hipSuccess) { paif::set_error("sr_attention_bwd(dq bf16x3): LDS %zu: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
-  hipLaunchKernelGGL(attn_bwd_dq_bf16x3_kernel<D>, dim3((a.N + 255) / 256, a.heads, a.B), dim3(512), lds_bytes, st, a);
+  if (e != hipSuccess) { paif::set_error("sr_attention_bwd(dq split): LDS %zu: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
+  hipLaunchKernelGGL((attn_bwd_dq_split_kernel<D, NP>), dim3((a.N + 255) / 256, a.heads, a.B), dim3(512), lds_bytes, st, a);
   return 0;
 }
 
@@ -406,11 +405,11 @@ __global__ __launch_bounds__(64 * KG_TILES) void attn_bwd_dkv_kernel(AttnBwdArgs
 // S = Q . K^T and dP = dO . V^T) and transposed with the query-slot permutation (A operands of dK^T += Q^T . dS and
 // dV^T += dO^T . P), so that the P / dS accumulator registers are the B operands as they stand.
 // ---------------------------------------------------------------------------------------------
-template <int D>
-__global__ __launch_bounds__(64 * KG_TILES) void attn_bwd_dkv_bf16x3_kernel(AttnBwdArgs a) {
+template <int D, int NP>
+__global__ __launch_bounds__(64 * KG_TILES) void attn_bwd_dkv_split_kernel(AttnBwdArgs a) {
   constexpr int NO = D / 16, DT = D / 32;
-  constexpr int KREC = D * 4;              // row-major record: hi | lo
-  constexpr int TREC = 32 * 4 + 16;        // transposed record: 32 slots hi | 32 slots lo | pad
+  constexpr int KREC = D * 2 * NP;         // row-major record: NP pieces of D bf16
+  constexpr int TREC = 32 * 2 * NP + 16;   // transposed record: NP x 32 slots | pad
   __shared__ __align__(16) char Qr[32 * KREC];
   __shared__ __align__(16) char Dr[32 * KREC];
   __shared__ __align__(16) char Qt[D * TREC];
@@ -427,7 +426,7 @@ __global__ __launch_bounds__(64 * KG_TILES) void attn_bwd_dkv_bf16x3_kernel(Attn
   // this wave's key tile: K and V fragments as B operands (lane (h, j) = key j, dims 16o + 8h + i), split once
   const int key_b = min(wave * 32 + p, Nk - 1);
   const float* krow = a.kv + ((size_t)b * Nk + key_b) * 2 * C + hd * D;
-  bbf16x8 kh[NO], kl[NO], vh[NO], vl[NO];
+  bbf16x8 kp[NO][NP], vp[NO][NP];
 #pragma unroll
   for (int o = 0; o < NO; ++o) {
     float k8[8], v8[8];
@@ -438,8 +437,8 @@ __global__ __launch_bounds__(64 * KG_TILES) void attn_bwd_dkv_bf16x3_kernel(Attn
       k8[4 * j] = kv4.x; k8[4 * j + 1] = kv4.y; k8[4 * j + 2] = kv4.z; k8[4 * j + 3] = kv4.w;
       v8[4 * j] = vv4.x; v8[4 * j + 1] = vv4.y; v8[4 * j + 2] = vv4.z; v8[4 * j + 3] = vv4.w;
     }
-    bsplit8(k8, kh[o], kl[o]);
-    bsplit8(v8, vh[o], vl[o]);
+    splitN<NP>(k8, kp[o]);
+    splitN<NP>(v8, vp[o]);
   }
   const bool keyvalid = wave * 32 + p < Nk;
 
@@ -461,20 +460,20 @@ __global__ __launch_bounds__(64 * KG_TILES) void attn_bwd_dkv_bf16x3_kernel(Attn
       const float* src = (which ? a.dout : a.q) + ((size_t)b * N + qi) * C + hd * D + c * 8;
       const float4 x0 = *reinterpret_cast<const float4*>(src), x1 = *reinterpret_cast<const float4*>(src + 4);
       const float x8[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-      bbf16x8 xh, xl;
-      bsplit8(x8, xh, xl);
+      bbf16x8 xp[NP];
+      splitN<NP>(x8, xp);
       char* rm = which ? Dr : Qr;
       char* tr = which ? Dt : Qt;
       const int sw = row & (D / 8 - 1);
-      *reinterpret_cast<bbf16x8*>(rm + row * KREC + ((c ^ sw) << 4)) = xh;
-      *reinterpret_cast<bbf16x8*>(rm + row * KREC + D * 2 + ((c ^ sw) << 4)) = xl;
+#pragma unroll
+      for (int q = 0; q < NP; ++q) *reinterpret_cast<bbf16x8*>(rm + row * KREC + q * D * 2 + ((c ^ sw) << 4)) = xp[q];
       const int hh = (row >> 2) & 1, r = (row & 3) + 4 * (row >> 3);
       const int slot = (r >> 3) * 16 + 8 * hh + (r & 7);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int dim = c * 8 + i;
-        *reinterpret_cast<__bf16*>(tr + dim * TREC + slot * 2) = xh[i];
-        *reinterpret_cast<__bf16*>(tr + dim * TREC + 64 + slot * 2) = xl[i];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) *reinterpret_cast<__bf16*>(tr + dim * TREC + q * 64 + slot * 2) = xp[q][i];
       }
     }
     if (tid < 64) {
@@ -494,16 +493,14 @@ __global__ __launch_bounds__(64 * KG_TILES) void attn_bwd_dkv_bf16x3_kernel(Attn
 #pragma unroll
     for (int o = 0; o < NO; ++o) {
       const int cc = ((2 * o + h) ^ sw) << 4;
-      const bbf16x8 qh = *reinterpret_cast<const bbf16x8*>(Qr + p * KREC + cc);
-      const bbf16x8 ql = *reinterpret_cast<const bbf16x8*>(Qr + p * KREC + D * 2 + cc);
-      const bbf16x8 dh = *reinterpret_cast<const bbf16x8*>(Dr + p * KREC + cc);
-      const bbf16x8 dl = *reinterpret_cast<const bbf16x8*>(Dr + p * KREC + D * 2 + cc);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ql, kh[o], s, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dl, vh[o], dp, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh, kl[o], s, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh, vl[o], dp, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh, kh[o], s, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh, vh[o], dp, 0, 0, 0);
+      bbf16x8 qp[NP], dop[NP];
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        qp[q] = *reinterpret_cast<const bbf16x8*>(Qr + p * KREC + q * D * 2 + cc);
+        dop[q] = *reinterpret_cast<const bbf16x8*>(Dr + p * KREC + q * D * 2 + cc);
+      }
+      mfma_pieces<NP>(s, qp, kp[o]);
+      mfma_pieces<NP>(dp, dop, vp[o]);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -518,23 +515,21 @@ __global__ __launch_bounds__(64 * KG_TILES) void attn_bwd_dkv_bf16x3_kernel(Attn
       float p8[8], d8[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) { p8[i] = s[8 * s2 + i]; d8[i] = dp[8 * s2 + i]; }
-      bbf16x8 ph, pl, dsh, dsl;
-      bsplit8(p8, ph, pl);
-      bsplit8(d8, dsh, dsl);
+      bbf16x8 pp[NP], dsp[NP];
+      splitN<NP>(p8, pp);
+      splitN<NP>(d8, dsp);
       const int soff = (s2 * 16 + 8 * h) * 2;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
         const int dim = 32 * dt + p;
-        const bbf16x8 oh = *reinterpret_cast<const bbf16x8*>(Dt + dim * TREC + soff);
-        const bbf16x8 ol = *reinterpret_cast<const bbf16x8*>(Dt + dim * TREC + 64 + soff);
-        const bbf16x8 th = *reinterpret_cast<const bbf16x8*>(Qt + dim * TREC + soff);
-        const bbf16x8 tl = *reinterpret_cast<const bbf16x8*>(Qt + dim * TREC + 64 + soff);
-        dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ol, ph, dvacc[dt], 0, 0, 0);
-        dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tl, dsh, dkacc[dt], 0, 0, 0);
-        dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oh, pl, dvacc[dt], 0, 0, 0);
-        dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th, dsl, dkacc[dt], 0, 0, 0);
-        dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oh, ph, dvacc[dt], 0, 0, 0);
-        dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th, dsh, dkacc[dt], 0, 0, 0);
+        bbf16x8 op[NP], tp[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+          op[q] = *reinterpret_cast<const bbf16x8*>(Dt + dim * TREC + q * 64 + soff);
+          tp[q] = *reinterpret_cast<const bbf16x8*>(Qt + dim * TREC + q * 64 + soff);
+        }
+        mfma_pieces<NP>(dvacc[dt], op, pp);
+        mfma_pieces<NP>(dkacc[dt], tp, dsp);
       }
     }
   }
@@ -592,12 +587,12 @@ int paif_sr_attention_bwd_input(const float* q, const float* kv, const float* o,
 int paif_sr_attention_bwd_input_p(const float* q, const float* kv, const float* o, const float* dout, const float* lse,
                                   float* delta, float* dq, float* dkv, float* dkv_partial, int B, int N, int Nk, int C, int heads,
                                   int precision, paif_stream_t stream) {
-  PAIF_REQUIRE(precision == 0 || precision == 1, PAIF_EINVAL, "sr_attention_bwd: precision=%d", precision);
+  PAIF_REQUIRE(precision == 0 || precision == 1 || precision == 3, PAIF_EINVAL, "sr_attention_bwd: precision=%d", precision);
   PAIF_REQUIRE(q && kv && o && dout && lse && delta && dq && dkv && dkv_partial, PAIF_EINVAL, "sr_attention_bwd: null pointer");
   PAIF_REQUIRE(B > 0 && N > 0 && Nk > 0 && heads > 0 && C % heads == 0, PAIF_EINVAL, "sr_attention_bwd: bad shape");
   const int D = C / heads;
   PAIF_REQUIRE(D == 64 || D == 32, PAIF_ENOSUP, "sr_attention_bwd: head dim %d not built", D);
-  PAIF_REQUIRE(Nk <= 320, PAIF_ENOSUP, "sr_attention_bwd: Nk=%d > 320 keys not built", Nk);
+  PAIF_REQUIRE(precision != 0 || Nk <= 320, PAIF_ENOSUP, "sr_attention_bwd: Nk=%d > 320 keys not built for the exact kernels (the split forms chunk the keys)", Nk);
   AttnBwdArgs a;
   a.q = q; a.kv = kv; a.o = o; a.dout = dout; a.lse = lse; a.delta = delta; a.dq = dq; a.dkv_partial = dkv_partial;
   a.B = B; a.N = N; a.Nk = Nk; a.C = C; a.heads = heads; a.scale = 1.0f / sqrtf((float)D);
@@ -609,29 +604,28 @@ int paif_sr_attention_bwd_input_p(const float* q, const float* kv, const float* 
   const int ntile = (Nk + 31) / 32;
   const int ngroups = (ntile + KG_TILES - 1) / KG_TILES;
   const int wpb = ntile < KG_TILES ? ntile : KG_TILES;
-  if (D == 64) {
-    if (lds_bytes > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<64>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-      if (e != hipSuccess) { paif::set_error("sr_attention_bwd: LDS %zu: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
+  const dim3 kvgrid(a.nchunk * ngroups, heads, B), kvblk(64 * wpb);
+  auto run = [&](auto dtag) -> int {
+    constexpr int DD = decltype(dtag)::value;
+    if (precision == 0) {
+      if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<DD>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) { paif::set_error("sr_attention_bwd: LDS %zu: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
+      }
+      hipLaunchKernelGGL(attn_bwd_dq_kernel<DD>, dim3((N + 255) / 256, heads, B), dim3(512), lds_bytes, st, a);
+    } else {
+      const int rc = precision == 3 ? launch_dq_split<DD, 3>(a, st) : launch_dq_split<DD, 2>(a, st);
+      if (rc) return rc;
     }
-    if (precision == 1) { const int rc = launch_dq_bf16x3<64>(a, st); if (rc) return rc; }
-    else hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, dim3((N + 255) / 256, heads, B), dim3(512), lds_bytes, st, a);
     PAIF_LAUNCH_CHECK("sr_attention_bwd(dq)");
-    if (precision == 1) hipLaunchKernelGGL(attn_bwd_dkv_bf16x3_kernel<64>, dim3(a.nchunk * ngroups, heads, B), dim3(64 * wpb), 0, st, a);
-    else hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, dim3(a.nchunk * ngroups, heads, B), dim3(64 * wpb), 0, st, a);
-  } else {
-    if (lds_bytes > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<32>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-      if (e != hipSuccess) { paif::set_error("sr_attention_bwd: LDS %zu: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
-    }
-    if (precision == 1) { const int rc = launch_dq_bf16x3<32>(a, st); if (rc) return rc; }
-    else hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, dim3((N + 255) / 256, heads, B), dim3(512), lds_bytes, st, a);
-    PAIF_LAUNCH_CHECK("sr_attention_bwd(dq)");
-    if (precision == 1) hipLaunchKernelGGL(attn_bwd_dkv_bf16x3_kernel<32>, dim3(a.nchunk * ngroups, heads, B), dim3(64 * wpb), 0, st, a);
-    else hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, dim3(a.nchunk * ngroups, heads, B), dim3(64 * wpb), 0, st, a);
-  }
+    if (precision == 3) hipLaunchKernelGGL((attn_bwd_dkv_split_kernel<DD, 3>), kvgrid, kvblk, 0, st, a);
+    else if (precision == 1) hipLaunchKernelGGL((attn_bwd_dkv_split_kernel<DD, 2>), kvgrid, kvblk, 0, st, a);
+    else hipLaunchKernelGGL(attn_bwd_dkv_kernel<DD>, kvgrid, kvblk, 0, st, a);
+    return 0;
+  };
+  const int rc = D == 64 ? run(std::integral_constant<int, 64>{}) : run(std::integral_constant<int, 32>{});
+  if (rc) return rc;
   PAIF_LAUNCH_CHECK("sr_attention_bwd(dkv)");
   const size_t n4 = (size_t)B * Nk * 2 * C / 4;
   size_t g = (n4 + 255) / 256;

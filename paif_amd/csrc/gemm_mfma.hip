@@ -300,7 +300,6 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 4))) 
 // than the exact fp32 MFMA.  LDS row record (144 B): 32 x bf16 hi | 32 x bf16 lo | 16 B pad (conflict-free b128).
 // ---------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int RB = 144;  // bytes per staged row of a 32-wide K tile
 
 __device__ __forceinline__ void split_store(char* dst, float4 t4) {
   const __bf16 hx = (__bf16)t4.x, hy = (__bf16)t4.y, hz = (__bf16)t4.z, hw = (__bf16)t4.w;

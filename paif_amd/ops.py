@@ -63,7 +63,7 @@ CONFIG = {"conv_precision": "bf16x3", "gemm_precision": os.environ.get("PAIF_GEM
           # 16-bit inference forward: a ResidualDenseBlock (k = 3, dilation 1) as ONE kernel (csrc/rdb_fused.hip) on maps of >= 512 tiles.
           # OFF by default: correct (tests/test_f16_storage_gpu.py) and 2 map passes instead of 9, but matrix-pipe bound at the clock the chip
           # sustains under that load -- 400 us per block inside the forward against 355 for the three bandwidth-bound launches
-          "rdb_fused": False, "gemm2": False, "gemm_gather": os.environ.get("PAIF_GEMM_GATHER", "1") != "0"}
+          "rdb_fused": False, "gemm2": False, "attn_x6": os.environ.get("PAIF_ATTN_X6", "1") != "0", "gemm_gather": os.environ.get("PAIF_GEMM_GATHER", "1") != "0"}
 # falsy, or the torch dtype (torch.bfloat16 / torch.float16) of the 32-channel maps while an inference forward of the fusion network
 # runs in a 16-bit storage mode (set by the model through `bf16_activations`)
 _ACT_BF16 = [False]
@@ -1023,6 +1023,18 @@ def resize_bilinear_adjoint(dout, coff, C, IH, IW):
     return dx
 
 
+def _attn_precision():
+    """Arithmetic of the attention products, following the GEMMs: 0 = exact fp32 MFMA under set_gemm_precision("f32") (all gradient-
+    parity tests), 3 = three-piece bf16 splits (fp32-level, six MFMAs per product) inside the attack loops ("bf16x6" / "auto6";
+    CONFIG["attn_x6"] = False keeps the exact kernels there: round 4's form), 1 = split-bf16 (three MFMAs) otherwise."""
+    g = CONFIG["gemm_precision"]
+    if g == "f32":
+        return 0
+    if g in ("bf16x6", "auto6"):
+        return 3 if CONFIG["attn_x6"] else 0
+    return 1
+
+
 def sr_attention_bwd(q, kv, o, dout, lse, heads):
     B, N, C = q.shape
     Nk = kv.shape[1]
@@ -1032,7 +1044,7 @@ def sr_attention_bwd(q, kv, o, dout, lse, heads):
     dq = torch.empty_like(q)
     dkv = torch.empty_like(kv)
     partial = torch.empty((nchunk, B, Nk, 2 * C), device=q.device, dtype=torch.float32)
-    split = 0 if CONFIG["gemm_precision"] in ("f32", "bf16x6", "auto6") else 1     # arithmetic follows the GEMMs (sr_attention); exact where they are fp32-level
+    split = _attn_precision()     # arithmetic follows the GEMMs (sr_attention)
     _lib.check(L.paif_sr_attention_bwd_input_p(_p(q), _p(kv), _p(o), _p(dout.contiguous()), _p(lse), _p(delta), _p(dq), _p(dkv), _p(partial),
                                                B, N, Nk, C, heads, split, _stream()), "sr_attention_bwd")
     return dq, dkv
@@ -1627,12 +1639,13 @@ def sr_attention(q, kv, heads, want_lse=False):
     assert kv.shape[2] == 2 * C
     out = torch.empty_like(q)
     lse = torch.empty((B, heads, N), device=q.device, dtype=torch.float32) if want_lse else None
-    # arithmetic follows the GEMMs: exact fp32 MFMA under set_gemm_precision("f32") (all gradient-parity tests), split-bf16 otherwise
-    split = CONFIG["gemm_precision"] not in ("f32", "bf16x6", "auto6")
-    tag = "sr_attention_bf16x3" if split else "sr_attention"
+    split = _attn_precision()
+    tag = {0: "sr_attention", 1: "sr_attention_bf16x3", 3: "sr_attention_bf16x6"}[split]
     e0 = TIMER.start(tag) if TIMER is not None else None
-    fn = lib().paif_sr_attention_bf16x3_fwd if split else lib().paif_sr_attention_fwd
-    _lib.check(fn(_p(q), _p(kv), _p(out), _p(lse), B, N, Nk, C, heads, _stream()), "sr_attention")
+    if split:
+        _lib.check(lib().paif_sr_attention_split_fwd(_p(q), _p(kv), _p(out), _p(lse), B, N, Nk, C, heads, split, _stream()), "sr_attention")
+    else:
+        _lib.check(lib().paif_sr_attention_fwd(_p(q), _p(kv), _p(out), _p(lse), B, N, Nk, C, heads, _stream()), "sr_attention")
     if e0 is not None:
         TIMER.stop(tag, e0, 4 * B * N * Nk * C, 4 * (2 * B * N * C + 2 * B * Nk * C))
     return (out, lse) if want_lse else out

@@ -35,7 +35,7 @@ def _exact_convs():
     (1, 300, 300, 512, 8),      # stage 4: sr = 1, keys = queries
     (2, 777, 77, 64, 2),        # ragged: head_dim 32, N and Nk not multiples of 32, partial last workgroup
     (1, 1000, 45, 128, 2),      # ragged, head_dim 64, fewer keys than two tiles
-    (1, 640, 320, 64, 1),       # 320 keys x 64 dims: the split-bf16 forward does not fit LDS and runs the exact kernel
+    (1, 640, 320, 64, 1),       # 320 keys x 64 dims: K and V^T of all keys do not fit LDS in any split form -> two key chunks
 ])
 def test_sr_attention_forward_backward_at_480x640_token_counts(B, N, Nk, C, heads):
     """core/mix_transformer.py:93-115 (softmax(q k^T * hd^-0.5) v) and its autograd, vs torch in float64: the exact-fp32 kernels
@@ -57,7 +57,8 @@ def test_sr_attention_forward_backward_at_480x640_token_counts(B, N, Nk, C, head
     (ref * dout.double()).sum().backward()
     prev = ops.CONFIG["gemm_precision"]
     try:
-        for mode, tol_out, tol_grad in (("f32", 2e-6, 2e-5), ("auto", 3e-5, 1e-4)):
+        # "auto6" = the attack loops' arithmetic: three bf16 pieces per operand, six products (2^-25) -- held to the exact kernels' bounds
+        for mode, tol_out, tol_grad in (("f32", 2e-6, 2e-5), ("auto", 3e-5, 1e-4), ("auto6", 2e-6, 2e-5)):
             ops.set_gemm_precision(mode)
             timer = ops.KernelTimer(lambda tag: tag.startswith("sr_attention"))
             ops.TIMER = timer
@@ -66,11 +67,41 @@ def test_sr_attention_forward_backward_at_480x640_token_counts(B, N, Nk, C, head
             finally:
                 ops.TIMER = None
             torch.cuda.synchronize()
-            assert list(timer.summary()) == ["sr_attention" if mode == "f32" else "sr_attention_bf16x3"]   # the entry point taken
+            assert list(timer.summary()) == [{"f32": "sr_attention", "auto": "sr_attention_bf16x3", "auto6": "sr_attention_bf16x6"}[mode]]   # the entry point taken
             dq, dkv = ops.sr_attention_bwd(qd, kvd, out, dout.to(dev), lse, heads)
             assert maxabs(out.cpu().double(), ref.detach()) <= tol_out * float(ref.abs().max()), (mode, B, N, Nk, C, heads)
             for mine, r in ((dq, q64.grad), (dkv, kv64.grad)):
                 assert maxabs(mine.cpu().double(), r) <= tol_grad * float(r.abs().max()), (mode, B, N, Nk, C, heads)
+    finally:
+        ops.set_gemm_precision(prev)
+
+
+@pytest.mark.parametrize("mode,tol_out,tol_grad", [("auto", 3e-5, 1e-4), ("auto6", 2e-6, 2e-5)])
+def test_sr_attention_split_forms_chunk_any_key_count(mode, tol_out, tol_grad):
+    """More keys than one LDS chunk holds (700 at head dim 64: three chunks with two pieces, five with three; the backward's dq kernel
+    five / six): the online softmax carries over chunk boundaries, the backward's chunks are independent.  The exact kernels keep all
+    keys in LDS and refuse this shape (PAIF_ENOSUP), as before."""
+    B, N, Nk, C, heads = 2, 300, 700, 128, 2
+    g = torch.Generator().manual_seed(77)
+    q, kv, dout = torch.randn(B, N, C, generator=g), torch.randn(B, Nk, 2 * C, generator=g), torch.randn(B, N, C, generator=g)
+    dev = _dev()
+    hd = C // heads
+    q64, kv64 = q.double().requires_grad_(True), kv.double().requires_grad_(True)
+    qh = q64.reshape(B, N, heads, hd).permute(0, 2, 1, 3)
+    kvh = kv64.reshape(B, Nk, 2, heads, hd).permute(2, 0, 3, 1, 4)
+    ref = (((qh @ kvh[0].transpose(-2, -1)) * hd ** -0.5).softmax(dim=-1) @ kvh[1]).transpose(1, 2).reshape(B, N, C)
+    (ref * dout.double()).sum().backward()
+    prev = ops.CONFIG["gemm_precision"]
+    try:
+        ops.set_gemm_precision(mode)
+        out, lse = ops.sr_attention(q.to(dev), kv.to(dev), heads, want_lse=True)
+        dq, dkv = ops.sr_attention_bwd(q.to(dev), kv.to(dev), out, dout.to(dev), lse, heads)
+        assert maxabs(out.cpu().double(), ref.detach()) <= tol_out * float(ref.abs().max())
+        for mine, r in ((dq, q64.grad), (dkv, kv64.grad)):
+            assert maxabs(mine.cpu().double(), r) <= tol_grad * float(r.abs().max())
+        ops.set_gemm_precision("f32")
+        with pytest.raises(RuntimeError, match="LDS|320 keys"):
+            ops.sr_attention(q.to(dev), kv.to(dev), heads)
     finally:
         ops.set_gemm_precision(prev)
 
@@ -227,7 +258,7 @@ def test_sr_attention_seeded_shape_sweep():
             attn = ((qh @ kvh[0].transpose(-2, -1)) * hd ** -0.5).softmax(dim=-1)
             ref = (attn @ kvh[1]).transpose(1, 2).reshape(B, N, C)
             (ref * dout.double()).sum().backward()
-            for mode, tol_out, tol_grad in (("f32", 3e-6, 3e-5), ("auto", 4e-5, 2e-4)):
+            for mode, tol_out, tol_grad in (("f32", 3e-6, 3e-5), ("auto", 4e-5, 2e-4), ("auto6", 3e-6, 3e-5)):
                 ops.set_gemm_precision(mode)
                 out, lse = ops.sr_attention(q.to(dev), kv.to(dev), heads, want_lse=True)
                 dq, dkv = ops.sr_attention_bwd(q.to(dev), kv.to(dev), out, dout.to(dev), lse, heads)
