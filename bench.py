@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--attack-precision", choices=["exact", "bf16x6", "fast"], default="bf16x6",
                     help="pgd / train: arithmetic INSIDE the attack loop.  bf16x6 (default, the product default) = convs as three-piece bf16 "
                          "splits (six MFMAs per product, 2^-25 per product: fp32-level parity -- sign mismatch vs the reference's float64 run 0 "
-                         "through PGD-10), GEMMs / attention exact fp32 MFMA; exact = fp32-exact MFMA kernels everywhere; fast = the split-bf16 "
+                         "through PGD-10), the K >= 256 GEMMs and the attention products likewise, the other GEMMs exact fp32 MFMA; exact = fp32-exact MFMA kernels everywhere; fast = the split-bf16 "
                          "kernels there too (trajectory diverges: sign mismatch 2.5e-2 by iteration 10; tests/test_parity_default_gpu.py)")
     ap.add_argument("--storage", choices=["f32", "bf16", "bf16_split", "f16"], default="f16",
                     help="activation storage of the fusion network's inference forward (fusion / fusion_seg workloads).  f16 (default since "
@@ -473,7 +473,7 @@ def main():
                         + "; attention products: %s" % ("exact fp32 MFMA" if args.gemm_precision == "f32" else "split-bf16")
                         + ("" if args.workload not in ("pgd", "train") else
                            "; INSIDE the attack loop: %s" % ("exact fp32 MFMA for convs, GEMMs and attention (attack precision 'exact')"
-                                                            if args.attack_precision == "exact" else ("convs, and GEMMs with K >= 256, as three-piece bf16 splits (6 MFMAs per product, 2^-25); the other GEMMs and attention exact fp32 MFMA (attack precision 'bf16x6')" if args.attack_precision == "bf16x6" else "the same split-bf16 kernels (attack precision 'fast')")))),
+                                                            if args.attack_precision == "exact" else ("convs, GEMMs with K >= 256 and the attention products as three-piece bf16 splits (6 MFMAs per product, 2^-25); the other GEMMs exact fp32 MFMA (attack precision 'bf16x6')" if args.attack_precision == "bf16x6" else "the same split-bf16 kernels (attack precision 'fast')")))),
             "data": "synthetic",
             "config": {"workload": {"fusion": "configs[1]: fusion-net forward (RGB2YCrCb + Network_Fusion_Searched, C=32, shipped genotype)",
                                     "fusion_seg": "configs[2]: fusion + mit_b3 SegFormer end-to-end inference",

@@ -338,10 +338,12 @@ int paif_gemm_splitk_fwd_p(const float* A, int lda, const float* W, const float*
                          float* workspace, int precision, paif_stream_t stream);
 
 /* Strided conv as a GEMM whose A operand is GATHERED from the NHWC map: paif_im2col_fwd + paif_gemm_fwd (OverlapPatchEmbed.proj
- * core/mix_transformer.py:168-169 for Cin % 32 == 0, Attention.sr :74) without materialising the im2col matrix; bit-identical to that
- * pair.  x [B,H,W,Cin]; Wt [N, k*k*Cin] (paif_pack_conv_gemm_weight); out [B*OH*OW, >= N], row stride ldc.  precision: PAIF_CONV_BF16X3 or
- * PAIF_CONV_BF16X6 (PAIF_ENOSUP otherwise: callers keep the im2col pair for the exact fp32 MFMA).  splits = paif_gemm_splitk_plan(B*OH*OW,
- * N, k*k*Cin); splits > 1 needs workspace[splits * M * N] floats. */
+ * core/mix_transformer.py:168-169, Attention.sr :74) without materialising the im2col matrix; bit-identical to that pair.
+ * x [B,H,W,Cin]; Wt [N, Kpad], Kpad = k*k*Cin rounded up to a multiple of 32 (paif_pack_conv_gemm_weight); out [B*OH*OW, >= N], row
+ * stride ldc.  precision PAIF_CONV_BF16X3 / PAIF_CONV_BF16X6: Cin % 32 == 0 (a 32-wide k tile = 128 contiguous bytes of one input pixel);
+ * splits = paif_gemm_splitk_plan(B*OH*OW, N, Kpad), splits > 1 needs workspace[splits * M * N] floats.  precision PAIF_CONV_F32 (exact
+ * fp32 MFMA): any Cin, element-wise gather through a column table, Kpad <= 160 (the 3-channel 7x7 stride-4 patch embed), splits = 1.
+ * PAIF_ENOSUP for other combinations: callers keep the im2col pair. */
 int paif_gemm_conv_fwd(const float* x, int B, int H, int W, int Cin, int k, int stride, int pad, const float* Wt,
                        const float* scale, const float* shift, int act, const float* res, int ldres, float* out, int ldc,
                        int N, int precision, int splits, float* workspace, paif_stream_t stream);

@@ -122,10 +122,22 @@ __device__ __forceinline__ void gemm_finish(const GemmArgs& a, const f32x16 (&ac
 // Serial form (load -> wait -> LDS -> MFMA per k tile), kept for short k loops (K <= 160: at most 5 tiles): those GEMMs
 // are bound by the A / C streams, what matters is that every resident workgroup has its loads out as early as possible,
 // and the 88-register serial body measured 10-20 % faster there than the pipelined one (which wins 20-45 % at K >= 320).
+// GATHER (paif_gemm_conv_fwd, exact arithmetic): A is gathered element-wise from an NHWC map with ANY channel count (the 3-channel
+// input of OverlapPatchEmbed 1, core/mix_transformer.py:168: 7x7 taps, stride 4): column k = (ky * gk + kx) * gC + c decoded once per
+// workgroup into an LDS table; columns >= gk*gk*gC (the padding up to K) and taps outside the map read as 0.
+template <bool GATHER = false>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_serial(GemmArgs a) {
   __shared__ __align__(16) float sA[BM * LDS_STRIDE];
   __shared__ __align__(16) float sW[BN * LDS_STRIDE];
+  __shared__ int ktab[GATHER ? 160 : 1];   // (ky << 20) | (kx << 10) | c, or -1 for a padding column
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p = lane & 31;
+  if constexpr (GATHER) {
+    if (tid < a.K) {
+      const int kk = tid / a.gC, c = tid - kk * a.gC, ky = kk / a.gk, kx = kk - ky * a.gk;
+      ktab[tid] = ky < a.gk ? (ky << 20) | (kx << 10) | c : -1;
+    }
+    __syncthreads();
+  }
   // consecutive workgroups share the same rows of A (same m-tile, different n-tile) -> L2 reuse of A
   // XCD-aware tile order (round 4): the tilesN tiles that share 128 rows of A run on ONE XCD, so its L2 serves the re-reads
   // (round-robin dispatch put them on tilesN different XCDs: A came out of the Infinity Cache tilesN times).  Measured on the
@@ -145,21 +157,52 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_serial(GemmArgs a) {
   const int abase = (wave * 32 + p) * LDS_STRIDE + 4 * h;
   const int wbase = p * LDS_STRIDE + 4 * h;
 
+  int giy[GATHER ? 4 : 1], gix[GATHER ? 4 : 1];
+  unsigned gpix[GATHER ? 4 : 1];
+  if constexpr (GATHER) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = min(m0 + srow + 32 * i, a.M - 1);
+      const int ox = m % a.gOW, t = m / a.gOW, oy = t % a.gOH, b = t / a.gOH;
+      giy[i] = oy * a.gs - a.gpad; gix[i] = ox * a.gs - a.gpad;
+      gpix[i] = (unsigned)b * (unsigned)(a.gH * a.gW);
+    }
+  }
   const int kbeg = blockIdx.y * a.kper, kend = kbeg + a.kper;
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
     float4 va[4], vw[2];
+    if constexpr (GATHER) {
+      int kt[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m0 + srow + 32 * i;
-      va[i] = (m < a.M) ? *reinterpret_cast<const float4*>(a.A + (size_t)m * a.lda + k0 + sq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-      if (a.a_mask && m < a.M) {  // dgrad prologue: ReLU mask and per-column scale (folded BatchNorm)
-        const float4 mk = *reinterpret_cast<const float4*>(a.a_mask + (size_t)m * a.lda + k0 + sq * 4);
-        va[i].x = mk.x > 0.f ? va[i].x : 0.f; va[i].y = mk.y > 0.f ? va[i].y : 0.f;
-        va[i].z = mk.z > 0.f ? va[i].z : 0.f; va[i].w = mk.w > 0.f ? va[i].w : 0.f;
+      for (int j = 0; j < 4; ++j) kt[j] = ktab[k0 + sq * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {   // unconditional load of a clamped address, then select (no load under a data-dependent branch)
+          const int iy = giy[i] + (kt[j] >> 20), ix = gix[i] + ((kt[j] >> 10) & 1023);
+          const bool ok = kt[j] >= 0 && (unsigned)iy < (unsigned)a.gH && (unsigned)ix < (unsigned)a.gW;
+          const unsigned off = ok ? (gpix[i] + (unsigned)(iy * a.gW + ix)) * (unsigned)a.gC + (unsigned)(kt[j] & 1023) : 0u;
+          const float v = a.A[off];
+          e[j] = ok ? v : 0.f;
+        }
+        va[i] = make_float4(e[0], e[1], e[2], e[3]);
       }
-      if (a.a_scale) {
-        const float4 sc4 = *reinterpret_cast<const float4*>(a.a_scale + k0 + sq * 4);
-        va[i].x *= sc4.x; va[i].y *= sc4.y; va[i].z *= sc4.z; va[i].w *= sc4.w;
+    }
+    if constexpr (!GATHER) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + srow + 32 * i;
+        va[i] = (m < a.M) ? *reinterpret_cast<const float4*>(a.A + (size_t)m * a.lda + k0 + sq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.a_mask && m < a.M) {  // dgrad prologue: ReLU mask and per-column scale (folded BatchNorm)
+          const float4 mk = *reinterpret_cast<const float4*>(a.a_mask + (size_t)m * a.lda + k0 + sq * 4);
+          va[i].x = mk.x > 0.f ? va[i].x : 0.f; va[i].y = mk.y > 0.f ? va[i].y : 0.f;
+          va[i].z = mk.z > 0.f ? va[i].z : 0.f; va[i].w = mk.w > 0.f ? va[i].w : 0.f;
+        }
+        if (a.a_scale) {
+          const float4 sc4 = *reinterpret_cast<const float4*>(a.a_scale + k0 + sq * 4);
+          va[i].x *= sc4.x; va[i].y *= sc4.y; va[i].z *= sc4.z; va[i].w *= sc4.w;
+        }
       }
     }
 #pragma unroll
@@ -536,7 +579,7 @@ extern "C" int paif_gemm_masked_fwd(const float* A, int lda, const float* a_mask
     if (pro) hipLaunchKernelGGL(gemm_mfma_bf16x3<true>, grid, blk, 0, st, a);
     else hipLaunchKernelGGL(gemm_mfma_bf16x3<false>, grid, blk, 0, st, a);
   } else {
-    if (K <= 160) hipLaunchKernelGGL(gemm_mfma_f32_serial, grid, blk, 0, st, a);
+    if (K <= 160) hipLaunchKernelGGL(gemm_mfma_f32_serial<false>, grid, blk, 0, st, a);
     else if (pro) hipLaunchKernelGGL(gemm_mfma_f32<true>, grid, blk, 0, st, a);
     else hipLaunchKernelGGL(gemm_mfma_f32<false>, grid, blk, 0, st, a);
   }
@@ -612,13 +655,20 @@ extern "C" int paif_gemm_splitk_fwd_p(const float* A, int lda, const float* W, c
 extern "C" int paif_gemm_conv_fwd(const float* x, int B, int H, int W, int Cin, int k, int stride, int pad, const float* Wt,
                                   const float* scale, const float* shift, int act, const float* res, int ldres, float* out, int ldc,
                                   int N, int precision, int splits, float* workspace, paif_stream_t stream) {
-  PAIF_REQUIRE(precision == 1 || precision == 3, PAIF_ENOSUP, "gemm_conv: precision=%d (the gathered form is built for the split-bf16 kernels)", precision);
+  PAIF_REQUIRE(precision == 0 || precision == 1 || precision == 3, PAIF_EINVAL, "gemm_conv: precision=%d", precision);
   PAIF_REQUIRE(x && Wt && out, PAIF_EINVAL, "gemm_conv: null pointer");
-  PAIF_REQUIRE(B > 0 && H > 0 && W > 0 && N > 0 && k > 0 && stride > 0 && pad >= 0, PAIF_EINVAL, "gemm_conv: bad shape");
-  PAIF_REQUIRE(Cin % 32 == 0, PAIF_ENOSUP, "gemm_conv: Cin=%d must be a multiple of 32 (a k tile inside one tap)", Cin);
+  PAIF_REQUIRE(B > 0 && H > 0 && W > 0 && N > 0 && k > 0 && stride > 0 && pad >= 0 && Cin > 0, PAIF_EINVAL, "gemm_conv: bad shape");
   const int OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;
   PAIF_REQUIRE(OH > 0 && OW > 0, PAIF_EINVAL, "gemm_conv: empty output");
-  const int M = B * OH * OW, K = k * k * Cin;
+  const int M = B * OH * OW;
+  const int K = (k * k * Cin + 31) / 32 * 32;   // Wt's row length: the taps padded up to a multiple of 32 (paif_pack_conv_gemm_weight)
+  if (precision == 0) {
+    // exact fp32 MFMA, element-wise gather through a column table: the short-k form (K <= 160: the 3-channel 7x7 patch embed)
+    PAIF_REQUIRE(K <= 160 && k < 1024 && Cin < 1024, PAIF_ENOSUP, "gemm_conv: the exact gathered form is built for K <= 160 (got %d)", K);
+    PAIF_REQUIRE(splits == 1, PAIF_EINVAL, "gemm_conv: the exact gathered form does not split k");
+  } else {
+    PAIF_REQUIRE(Cin % 32 == 0, PAIF_ENOSUP, "gemm_conv: Cin=%d must be a multiple of 32 (a k tile inside one tap)", Cin);
+  }
   PAIF_REQUIRE(ldc >= N && act >= 0 && act <= 2, PAIF_EINVAL, "gemm_conv: ldc=%d act=%d", ldc, act);
   PAIF_REQUIRE(splits >= 1 && (K / BK) % splits == 0 && (splits == 1 || workspace), PAIF_EINVAL, "gemm_conv: splits=%d, %d k tiles", splits, K / BK);
   PAIF_REQUIRE((size_t)B * H * W * Cin < ((size_t)1 << 32) && (size_t)N * K < ((size_t)1 << 32), PAIF_ENOSUP, "gemm_conv: operands exceed the 32-bit element offsets");
@@ -639,7 +689,8 @@ extern "C" int paif_gemm_conv_fwd(const float* x, int B, int H, int W, int Cin, 
              (!scale || (uintptr_t)scale % 16 == 0) && (!shift || (uintptr_t)shift % 16 == 0);
   }
   if (precision == 3) hipLaunchKernelGGL((gemm_mfma_bf16x3<false, 3, true>), dim3(a.nblk, splits), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((gemm_mfma_bf16x3<false, 2, true>), dim3(a.nblk, splits), dim3(256), 0, st, a);
+  else if (precision == 1) hipLaunchKernelGGL((gemm_mfma_bf16x3<false, 2, true>), dim3(a.nblk, splits), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(gemm_mfma_f32_serial<true>, dim3(a.nblk), dim3(256), 0, st, a);
   PAIF_LAUNCH_CHECK("gemm_conv");
   if (splits > 1) {
     const size_t total = (size_t)M * N;

@@ -1587,9 +1587,10 @@ def im2col(x, k, stride, pad, kpad):
 
 def conv_gemm(x, wp, k, stride, pad, shift=None, scale=None, act=ACT_NONE):
     """Strided k x k conv of an NHWC map as ONE GEMM: x [B,H,W,Cin], wp [N, Kpad] (pack_conv_gemm_weight) -> tokens [B, OH*OW, N], OH, OW.
-    With Cin % 32 == 0 and a split-bf16 GEMM arithmetic the A operand is gathered from the map inside the GEMM's loader
-    (paif_gemm_conv_fwd: no im2col matrix in HBM; bit-identical to the pair); otherwise im2col + gemm (the exact fp32 MFMA, 3-channel
-    inputs)."""
+    The A operand is gathered from the map inside the GEMM's loader (paif_gemm_conv_fwd: no im2col matrix in HBM; bit-identical to
+    the pair) in two forms: 128-byte segments for Cin % 32 == 0 under a split-bf16 GEMM arithmetic (the SR convs, patch embeds 2-4), and
+    element-wise through a column table for the exact fp32 MFMA at Kpad <= 160 (the 3-channel 7x7 patch embed 1).  Anything else:
+    im2col + gemm."""
     B, H, W, Cin = x.shape
     N, kpad = wp.shape
     OH, OW = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
@@ -1599,11 +1600,13 @@ def conv_gemm(x, wp, k, stride, pad, shift=None, scale=None, act=ACT_NONE):
         prec = "bf16x3" if (K >= 256 and M >= 2048) else "f32"
     elif prec == "auto6":
         prec = "bf16x6" if (K >= 256 and M >= 2048) else "f32"
-    if not CONFIG["gemm_gather"] or Cin % 32 != 0 or prec not in ("bf16x3", "bf16x6") or kpad != K:
+    split_form = prec in ("bf16x3", "bf16x6") and Cin % 32 == 0 and kpad == K
+    exact_form = prec == "f32" and kpad <= 160 and kpad == (K + 31) // 32 * 32      # element-wise gather, any Cin (the 3-channel patch embed)
+    if not CONFIG["gemm_gather"] or not (split_form or exact_form):
         col = im2col(x, k, stride, pad, kpad)
         return gemm(col.view(B, OH * OW, kpad), wp, scale=scale, shift=shift, act=act), OH, OW
     L = lib()
-    splits = L.paif_gemm_splitk_plan(M, N, K)
+    splits = L.paif_gemm_splitk_plan(M, N, K) if split_form else 1
     out = torch.empty((B, OH * OW, N), device=x.device, dtype=torch.float32)
     ws = torch.empty(splits * M * N, device=x.device, dtype=torch.float32) if splits > 1 else None
     tag = "gemm_mfma_%s" % prec
@@ -1611,7 +1614,7 @@ def conv_gemm(x, wp, k, stride, pad, shift=None, scale=None, act=ACT_NONE):
     _lib.check(L.paif_gemm_conv_fwd(_p(x), B, H, W, Cin, k, stride, pad, _p(wp), _p(scale), _p(shift), act, None, 0, _p(out), N, N,
                                     _PREC_CODE[prec], splits, _p(ws), _stream()), "gemm_conv")
     if e0 is not None:
-        TIMER.stop(tag, e0, 2 * M * N * K, 4 * (M * K + N * K + M * N))
+        TIMER.stop(tag, e0, 2 * M * N * kpad, 4 * (M * kpad + N * kpad + M * N))
     return out, OH, OW
 
 

@@ -69,12 +69,41 @@ def test_conv_gemm_gather_bit_identical_to_im2col_gemm(case, prec):
     assert err <= (3e-5 if prec == "bf16x3" else 2e-6), err
 
 
-def test_conv_gemm_keeps_the_exact_path_and_refuses_unsupported_forms():
+@pytest.mark.parametrize("case", [(2, 64, 96, 3, 64, 7, 4, 3), (1, 61, 83, 3, 32, 7, 4, 3), (3, 33, 47, 3, 64, 5, 2, 2), (2, 20, 28, 5, 24, 3, 2, 1),
+                                  (16, 120, 160, 3, 64, 7, 4, 3)], ids=lambda c: "x".join(map(str, c)))
+def test_conv_gemm_exact_gather_of_the_3_channel_patch_embed(case):
+    """OverlapPatchEmbed 1 (core/mix_transformer.py:168: Conv2d(3, 64, 7, stride 4, padding 3)) in the exact fp32 MFMA: the gathered form
+    decodes the columns through a table (147 taps padded to 160) -- bit-identical to im2col + gemm, ragged maps and other small forms."""
+    B, H, W, Cin, N, k, s, p = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, H, W, Cin, generator=g).to(_dev())
+    w = (torch.randn(N, Cin, k, k, generator=g) * 0.05).to(_dev())
+    bias = torch.randn(N, generator=g).to(_dev())
+    wp = ops.pack_conv_gemm_weight(w)
+    assert wp.shape[1] <= 160
+    for prec in ("f32", "auto", "auto6"):                  # "auto" / "auto6" resolve to the exact MFMA at K < 256
+        with _cfg(gemm_precision=prec, gemm_gather=False):
+            ref, OH, OW = ops.conv_gemm(x, wp, k, s, p, shift=bias)
+        with _cfg(gemm_precision=prec, gemm_gather=True):
+            timer = ops.KernelTimer(lambda tag: True)
+            ops.TIMER = timer
+            try:
+                got, _, _ = ops.conv_gemm(x, wp, k, s, p, shift=bias)
+            finally:
+                ops.TIMER = None
+        assert torch.equal(got, ref), prec
+        assert list(timer.summary()) == ["gemm_mfma_f32"]       # one launch: no im2col, no second GEMM
+    want = torch.nn.functional.conv2d(x.cpu().double().permute(0, 3, 1, 2), w.cpu().double(), bias.cpu().double(), stride=s, padding=p)
+    want = want.permute(0, 2, 3, 1).reshape(B, OH * OW, N)
+    assert float((got.cpu().double() - want).abs().max() / want.abs().max()) <= 2e-6
+
+
+def test_conv_gemm_keeps_the_pair_where_no_gathered_form_is_built_and_refuses_bad_calls():
     dev = _dev()
     x = torch.randn(8, 16, 24, 64, device=dev)
     w = torch.randn(64, 64, 2, 2, device=dev) * 0.05
     wp = ops.pack_conv_gemm_weight(w)
-    with _cfg(gemm_precision="f32"):                       # exact fp32 MFMA: the im2col pair, not the gathered kernel
+    with _cfg(gemm_precision="f32"):                       # exact fp32 MFMA at K = 256 > 160: the im2col pair
         y32, _, _ = ops.conv_gemm(x, wp, 2, 2, 0)
         col = ops.im2col(x, 2, 2, 0, wp.shape[1])
         assert torch.equal(y32, ops.gemm(col.view(8, -1, wp.shape[1]), wp))
@@ -83,6 +112,8 @@ def test_conv_gemm_keeps_the_exact_path_and_refuses_unsupported_forms():
     out = torch.empty(8 * 8 * 12, 64, device=dev)
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     rc = L.paif_gemm_conv_fwd(p(x), 8, 16, 24, 64, 2, 2, 0, p(wp), None, None, 0, None, 0, p(out), 64, 64, 0, 1, None, None)
+    assert rc != 0 and "K <= 160" in err()
+    rc = L.paif_gemm_conv_fwd(p(x), 8, 16, 24, 64, 2, 2, 0, p(wp), None, None, 0, None, 0, p(out), 64, 64, 2, 1, None, None)
     assert rc != 0 and "precision" in err()
     x3 = torch.randn(2, 16, 24, 3, device=dev)
     rc = L.paif_gemm_conv_fwd(p(x3), 2, 16, 24, 3, 7, 4, 3, p(wp), None, None, 0, None, 0, p(out), 64, 64, 1, 1, None, None)
