@@ -107,7 +107,8 @@ def _attack_loop(model, X_vis, X_ir, label, lab64, epsilon, alpha, attack_iters,
         for i in range(attack_iters):
             if fast:
                 with torch.no_grad():
-                    _, logits, tape = model.forward_taped(ops.add(X_ir, d_ir), ops.add(X_vis, d_vis))
+                    with ops.attack_forward_arithmetic():
+                        _, logits, tape = model.forward_taped(ops.add(X_ir, d_ir), ops.add(X_vis, d_vis))
                     way, wt, wf = ops.attack_loss_weights(attack_way, i, attack_iters)
                     coef = ops.attack_loss_fwd(logits, lab64, way, wt, wf)    # loss + the backward's scalars, on the device
                     d32 = ops.attack_loss_bwd(logits, lab64, coef, way, wt, wf)

@@ -370,9 +370,27 @@ __device__ __forceinline__ void split_store3(char* dst, float4 t4) {
   *reinterpret_cast<uint2*>(dst + 128) = make_uint2(pk(lx, ly), pk(lz, lw));
 }
 
-template <bool MASKED, int NP = 2, bool GATHER = false>
+// PF = 1 ("f16x3"): the two pieces are IEEE fp16 (11 significant bits each: 22 bits per operand, against 16 for two bf16 pieces), the
+// three products hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16: ~2^-21.5 per product -- fp32-level for O(1) data at HALF the MFMAs of the
+// three-piece bf16 form.  fp16's narrow exponent is handled by an exact power-of-two scale on the W side (x 2^8, undone on the
+// accumulator): the lo piece of a weight of magnitude >= 5e-4 stays a normal fp16; activations are split unscaled (lo pieces of values
+// below 0.125 are subnormal: absolute error <= 3e-8 on an operand of an O(1) sum).  |x| must stay below 65504 (it does by orders of
+// magnitude on this path; an overflow shows up as inf / NaN, never silently).
+constexpr float F16X3_WSCALE = 256.f;
+__device__ __forceinline__ void split_store_h(char* dst, float4 t4) {
+  const _Float16 hx = (_Float16)t4.x, hy = (_Float16)t4.y, hz = (_Float16)t4.z, hw = (_Float16)t4.w;
+  const _Float16 lx = (_Float16)(t4.x - (float)hx), ly = (_Float16)(t4.y - (float)hy), lz = (_Float16)(t4.z - (float)hz),
+                 lw = (_Float16)(t4.w - (float)hw);
+  auto pk = [](_Float16 a, _Float16 b) { return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16); };
+  *reinterpret_cast<uint2*>(dst) = make_uint2(pk(hx, hy), pk(hz, hw));
+  *reinterpret_cast<uint2*>(dst + 64) = make_uint2(pk(lx, ly), pk(lz, lw));
+}
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <bool MASKED, int NP = 2, bool GATHER = false, int PF = 0>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16x3(GemmArgs a) {
   static_assert(!(MASKED && GATHER), "the dgrad prologue reads a mask with A's own layout");
+  static_assert(PF == 0 || NP == 2, "fp16 pieces come in pairs");
   constexpr int RB = NP == 3 ? 208 : 144;   // bytes per staged row of a 32-wide K tile (shadows the two-piece constant)
   __shared__ __align__(16) char sA[BM * RB];
   __shared__ __align__(16) char sW[BN * RB];
@@ -451,12 +469,16 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16x3(GemmArgs a) {
         if (scaled) { t.x *= vs.x; t.y *= vs.y; t.z *= vs.z; t.w *= vs.w; }
       }
       if constexpr (NP == 3) split_store3(sA + (srow + 32 * i) * RB + sq * 8, t);
+      else if constexpr (PF == 1) split_store_h(sA + (srow + 32 * i) * RB + sq * 8, t);
       else split_store(sA + (srow + 32 * i) * RB + sq * 8, t);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       if constexpr (NP == 3) split_store3(sW + (srow + 32 * i) * RB + sq * 8, vw[i]);
-      else split_store(sW + (srow + 32 * i) * RB + sq * 8, vw[i]);
+      else if constexpr (PF == 1) {
+        const float4 w4 = vw[i];
+        split_store_h(sW + (srow + 32 * i) * RB + sq * 8, make_float4(w4.x * F16X3_WSCALE, w4.y * F16X3_WSCALE, w4.z * F16X3_WSCALE, w4.w * F16X3_WSCALE));
+      } else split_store(sW + (srow + 32 * i) * RB + sq * 8, vw[i]);
     }
     __syncthreads();
     if (k0 + BK < kend) gload(k0 + BK);   // block-uniform
@@ -497,22 +519,32 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16x3(GemmArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       continue;
     }
+    auto mm = [&](const bf16x8& x, const bf16x8& y, f32x16 c) {
+      if constexpr (PF == 1) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), c, 0, 0, 0);
+      else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
+    };
 #pragma unroll
-    for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o0.al, o0.wh[t], acc[t], 0, 0, 0);
+    for (int t = 0; t < 2; ++t) acc[t] = mm(o0.al, o0.wh[t], acc[t]);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o0.ah, o0.wl[t], acc[t], 0, 0, 0);
+    for (int t = 0; t < 2; ++t) acc[t] = mm(o0.ah, o0.wl[t], acc[t]);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o0.ah, o0.wh[t], acc[t], 0, 0, 0);
+    for (int t = 0; t < 2; ++t) acc[t] = mm(o0.ah, o0.wh[t], acc[t]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o1.al, o1.wh[t], acc[t], 0, 0, 0);
+    for (int t = 0; t < 2; ++t) acc[t] = mm(o1.al, o1.wh[t], acc[t]);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o1.ah, o1.wl[t], acc[t], 0, 0, 0);
+    for (int t = 0; t < 2; ++t) acc[t] = mm(o1.ah, o1.wl[t], acc[t]);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o1.ah, o1.wh[t], acc[t], 0, 0, 0);
+    for (int t = 0; t < 2; ++t) acc[t] = mm(o1.ah, o1.wh[t], acc[t]);
     __builtin_amdgcn_sched_barrier(0);
   }
 
+  if constexpr (PF == 1) {   // undo the W-side scale (exact: a power of two)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] *= 1.0f / F16X3_WSCALE;
+  }
   __syncthreads();   // every wave has finished reading the last k tile: its A region becomes the epilogue park
   gemm_finish(a, acc, reinterpret_cast<float*>(sA), m0, n0, wave, hh, p);
 }
@@ -550,7 +582,7 @@ extern "C" int paif_gemm_fwd(const float* A, int lda, const float* W, const floa
 extern "C" int paif_gemm_masked_fwd(const float* A, int lda, const float* a_mask, const float* a_scale, const float* W,
                                     const float* scale, const float* shift, int act, const float* res, int ldres, float* C,
                                     int ldc, int M, int N, int K, int precision, paif_stream_t stream) {
-  PAIF_REQUIRE(precision == 0 || precision == 1 || precision == 3, PAIF_EINVAL, "gemm: precision=%d", precision);
+  PAIF_REQUIRE(precision == 0 || precision == 1 || precision == 3 || precision == 6, PAIF_EINVAL, "gemm: precision=%d", precision);
   PAIF_REQUIRE(A && W && C, PAIF_EINVAL, "gemm: null pointer");
   PAIF_REQUIRE(M > 0 && N > 0 && K > 0, PAIF_EINVAL, "gemm: empty shape %dx%dx%d", M, N, K);
   PAIF_REQUIRE(K % 32 == 0, PAIF_ENOSUP, "gemm: K=%d must be a multiple of 32 (pad the operands)", K);
@@ -575,6 +607,9 @@ extern "C" int paif_gemm_masked_fwd(const float* A, int lda, const float* a_mask
   if (precision == 3) {
     if (pro) hipLaunchKernelGGL((gemm_mfma_bf16x3<true, 3>), grid, blk, 0, st, a);
     else hipLaunchKernelGGL((gemm_mfma_bf16x3<false, 3>), grid, blk, 0, st, a);
+  } else if (precision == 6) {
+    PAIF_REQUIRE(!pro, PAIF_ENOSUP, "gemm: the fp16-pair arithmetic has no dgrad prologue (gradients need the bf16 exponent range)");
+    hipLaunchKernelGGL((gemm_mfma_bf16x3<false, 2, false, 1>), grid, blk, 0, st, a);
   } else if (precision == 1) {
     if (pro) hipLaunchKernelGGL(gemm_mfma_bf16x3<true>, grid, blk, 0, st, a);
     else hipLaunchKernelGGL(gemm_mfma_bf16x3<false>, grid, blk, 0, st, a);
@@ -615,7 +650,7 @@ extern "C" int paif_gemm_splitk_fwd(const float* A, int lda, const float* W, con
 extern "C" int paif_gemm_splitk_fwd_p(const float* A, int lda, const float* W, const float* scale, const float* shift, int act,
                                       const float* res, int ldres, float* C, int ldc, int M, int N, int K, int splits,
                                       float* workspace, int precision, paif_stream_t stream) {
-  PAIF_REQUIRE(precision == 0 || precision == 1 || precision == 3, PAIF_EINVAL, "gemm_splitk: precision=%d", precision);
+  PAIF_REQUIRE(precision == 0 || precision == 1 || precision == 3 || precision == 6, PAIF_EINVAL, "gemm_splitk: precision=%d", precision);
   PAIF_REQUIRE(A && W && C && workspace, PAIF_EINVAL, "gemm_splitk: null pointer");
   PAIF_REQUIRE(M > 0 && N > 0 && K > 0 && K % 32 == 0, PAIF_EINVAL, "gemm_splitk: shape %dx%dx%d", M, N, K);
   PAIF_REQUIRE(splits >= 2 && (K / BK) % splits == 0, PAIF_EINVAL, "gemm_splitk: splits=%d does not divide %d k-tiles", splits,
@@ -636,6 +671,7 @@ extern "C" int paif_gemm_splitk_fwd_p(const float* A, int lda, const float* W, c
   PAIF_REQUIRE((size_t)M * lda < ((size_t)1 << 32) && (size_t)N * K < ((size_t)1 << 32), PAIF_ENOSUP,
                "gemm_splitk: operands exceed the 32-bit element offsets");
   if (precision == 3) hipLaunchKernelGGL((gemm_mfma_bf16x3<false, 3>), dim3(a.nblk, splits), dim3(256), 0, st, a);
+  else if (precision == 6) hipLaunchKernelGGL((gemm_mfma_bf16x3<false, 2, false, 1>), dim3(a.nblk, splits), dim3(256), 0, st, a);
   else if (precision == 1) hipLaunchKernelGGL(gemm_mfma_bf16x3<false>, dim3(a.nblk, splits), dim3(256), 0, st, a);
   else hipLaunchKernelGGL(gemm_mfma_f32<false>, dim3(a.nblk, splits), dim3(256), 0, st, a);
   PAIF_LAUNCH_CHECK("gemm_splitk");
@@ -655,7 +691,7 @@ extern "C" int paif_gemm_splitk_fwd_p(const float* A, int lda, const float* W, c
 extern "C" int paif_gemm_conv_fwd(const float* x, int B, int H, int W, int Cin, int k, int stride, int pad, const float* Wt,
                                   const float* scale, const float* shift, int act, const float* res, int ldres, float* out, int ldc,
                                   int N, int precision, int splits, float* workspace, paif_stream_t stream) {
-  PAIF_REQUIRE(precision == 0 || precision == 1 || precision == 3, PAIF_EINVAL, "gemm_conv: precision=%d", precision);
+  PAIF_REQUIRE(precision == 0 || precision == 1 || precision == 3 || precision == 6, PAIF_EINVAL, "gemm_conv: precision=%d", precision);
   PAIF_REQUIRE(x && Wt && out, PAIF_EINVAL, "gemm_conv: null pointer");
   PAIF_REQUIRE(B > 0 && H > 0 && W > 0 && N > 0 && k > 0 && stride > 0 && pad >= 0 && Cin > 0, PAIF_EINVAL, "gemm_conv: bad shape");
   const int OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;
@@ -689,6 +725,7 @@ extern "C" int paif_gemm_conv_fwd(const float* x, int B, int H, int W, int Cin, 
              (!scale || (uintptr_t)scale % 16 == 0) && (!shift || (uintptr_t)shift % 16 == 0);
   }
   if (precision == 3) hipLaunchKernelGGL((gemm_mfma_bf16x3<false, 3, true>), dim3(a.nblk, splits), dim3(256), 0, st, a);
+  else if (precision == 6) hipLaunchKernelGGL((gemm_mfma_bf16x3<false, 2, true, 1>), dim3(a.nblk, splits), dim3(256), 0, st, a);
   else if (precision == 1) hipLaunchKernelGGL((gemm_mfma_bf16x3<false, 2, true>), dim3(a.nblk, splits), dim3(256), 0, st, a);
   else hipLaunchKernelGGL(gemm_mfma_f32_serial<true>, dim3(a.nblk), dim3(256), 0, st, a);
   PAIF_LAUNCH_CHECK("gemm_conv");

@@ -63,7 +63,7 @@ CONFIG = {"conv_precision": "bf16x3", "gemm_precision": os.environ.get("PAIF_GEM
           # 16-bit inference forward: a ResidualDenseBlock (k = 3, dilation 1) as ONE kernel (csrc/rdb_fused.hip) on maps of >= 512 tiles.
           # OFF by default: correct (tests/test_f16_storage_gpu.py) and 2 map passes instead of 9, but matrix-pipe bound at the clock the chip
           # sustains under that load -- 400 us per block inside the forward against 355 for the three bandwidth-bound launches
-          "rdb_fused": False, "gemm2": False, "attn_x6": os.environ.get("PAIF_ATTN_X6", "1") != "0", "gemm_gather": os.environ.get("PAIF_GEMM_GATHER", "1") != "0"}
+          "rdb_fused": False, "gemm2": False, "gemm_split_min_m": 2048, "attack_fwd_f16x3": os.environ.get("PAIF_ATTACK_FWD_F16X3", "0") == "1", "attn_x6": os.environ.get("PAIF_ATTN_X6", "1") != "0", "gemm_gather": os.environ.get("PAIF_GEMM_GATHER", "1") != "0"}
 # falsy, or the torch dtype (torch.bfloat16 / torch.float16) of the 32-channel maps while an inference forward of the fusion network
 # runs in a 16-bit storage mode (set by the model through `bf16_activations`)
 _ACT_BF16 = [False]
@@ -111,15 +111,15 @@ class bf16_activations:
 
 _TWINS = {}    # data_ptr of an fp32 map -> (the map, its bf16 twin written by the producing kernel); lives for one bf16 forward
 _SERP = [0]    # tile-direction parity of the next dense-conv launch
-_PREC_CODE = {"f32": 0, "bf16x3": 1, "bf16x6": 3, "f16": 4, "f16x2": 5}    # include/paif_hip.h PAIF_CONV_*
+_PREC_CODE = {"f32": 0, "bf16x3": 1, "bf16x6": 3, "f16": 4, "f16x2": 5, "f16x3": 6}    # include/paif_hip.h PAIF_CONV_*
 PREC_BF16 = 2          # include/paif_hip.h PAIF_CONV_BF16 (conv descriptors with bf16-stored maps only)
 
 
 def set_gemm_precision(mode):
     """Arithmetic of the SegFormer GEMMs: "f32" (exact fp32 MFMA), "bf16x3" (split-bf16: 3 bf16 MFMAs, ~1e-5 relative),
-    or "auto": split-bf16 where the GEMM is matrix-pipe bound at fp32 (K >= 256 and M >= 2048), exact fp32 elsewhere."""
-    if mode not in ("f32", "bf16x3", "auto", "bf16x6", "auto6"):
-        raise ValueError("gemm precision must be 'f32', 'bf16x3', 'auto', 'bf16x6' or 'auto6'")
+    or "auto": split-bf16 where the GEMM is matrix-pipe bound at fp32 (K >= 256 and M >= CONFIG["gemm_split_min_m"]), exact fp32 elsewhere."""
+    if mode not in ("f32", "bf16x3", "auto", "bf16x6", "auto6", "f16x3", "auto6h"):
+        raise ValueError("gemm precision must be 'f32', 'bf16x3', 'auto', 'bf16x6', 'auto6', 'f16x3' or 'auto6h'")
     CONFIG["gemm_precision"] = mode
 
 
@@ -153,6 +153,20 @@ class attack_arithmetic:
 
     def __exit__(self, *a):
         CONFIG["conv_precision"], CONFIG["gemm_precision"] = self.old
+
+
+class attack_forward_arithmetic:
+    """Inside an attack loop, around the FORWARD pass only (CONFIG["attack_fwd_f16x3"]): the K >= 256 GEMMs as fp16 pairs (two 11-bit
+    pieces per operand, three fp16 MFMAs per product, ~2^-21.5) instead of three bf16 pieces (six MFMAs, 2^-25).  The backward keeps
+    the three-piece form: gradients span the bf16 exponent range."""
+
+    def __enter__(self):
+        self.old = CONFIG["gemm_precision"]
+        if CONFIG["attack_fwd_f16x3"] and self.old == "auto6":
+            CONFIG["gemm_precision"] = "auto6h"
+
+    def __exit__(self, *a):
+        CONFIG["gemm_precision"] = self.old
 
 
 # ---- what a taped forward records: "dgrad" = enough for the input-gradient pass (PGD attacks); "wgrad" = also what the
@@ -954,9 +968,13 @@ def gemm(a, w, scale=None, shift=None, act=ACT_NONE, res=None, out=None, out_col
     if a_mask is None and a_scale is None:
         splits = L.paif_gemm_splitk_plan(M, N, K)   # small grid + long k loop (small batch): spread k over the idle CUs
     if prec == "auto":   # with or without split-K (its partial products take the same arithmetic, the reduction is fp32)
-        prec = "bf16x3" if (K >= 256 and M >= 2048) else "f32"
+        prec = "bf16x3" if (K >= 256 and M >= CONFIG["gemm_split_min_m"]) else "f32"
     elif prec == "auto6":  # the attack loops: three-piece splits (fp32-level parity) where the exact GEMM is matrix-pipe bound
-        prec = "bf16x6" if (K >= 256 and M >= 2048) else "f32"
+        prec = "bf16x6" if (K >= 256 and M >= CONFIG["gemm_split_min_m"]) else "f32"
+    elif prec == "auto6h":  # the attack loops' FORWARD passes: fp16 pairs (22 bits per operand, three MFMAs) there instead
+        prec = "f16x3" if (K >= 256 and M >= CONFIG["gemm_split_min_m"]) else "f32"
+    if prec == "f16x3" and (a_mask is not None or a_scale is not None):
+        prec = "bf16x6"     # dgrad prologue: gradients keep the bf16 exponent range
     tag = "gemm_mfma_%s" % prec
     e0 = TIMER.start(tag) if TIMER is not None else None
     nt = 0
@@ -1030,7 +1048,7 @@ def _attn_precision():
     g = CONFIG["gemm_precision"]
     if g == "f32":
         return 0
-    if g in ("bf16x6", "auto6"):
+    if g in ("bf16x6", "auto6", "f16x3", "auto6h"):
         return 3 if CONFIG["attn_x6"] else 0
     return 1
 
@@ -1597,10 +1615,12 @@ def conv_gemm(x, wp, k, stride, pad, shift=None, scale=None, act=ACT_NONE):
     M, K = B * OH * OW, k * k * Cin
     prec = CONFIG["gemm_precision"]
     if prec == "auto":
-        prec = "bf16x3" if (K >= 256 and M >= 2048) else "f32"
+        prec = "bf16x3" if (K >= 256 and M >= CONFIG["gemm_split_min_m"]) else "f32"
     elif prec == "auto6":
-        prec = "bf16x6" if (K >= 256 and M >= 2048) else "f32"
-    split_form = prec in ("bf16x3", "bf16x6") and Cin % 32 == 0 and kpad == K
+        prec = "bf16x6" if (K >= 256 and M >= CONFIG["gemm_split_min_m"]) else "f32"
+    elif prec == "auto6h":
+        prec = "f16x3" if (K >= 256 and M >= CONFIG["gemm_split_min_m"]) else "f32"
+    split_form = prec in ("bf16x3", "bf16x6", "f16x3") and Cin % 32 == 0 and kpad == K
     exact_form = prec == "f32" and kpad <= 160 and kpad == (K + 31) // 32 * 32      # element-wise gather, any Cin (the 3-channel patch embed)
     if not CONFIG["gemm_gather"] or not (split_form or exact_form):
         col = im2col(x, k, stride, pad, kpad)

@@ -111,7 +111,7 @@ def test_attack_both_pgd3_trajectory(golden, precision):
     assert float(d_ir.detach().abs().max()) <= EPS + 1e-7 and float(d_vis.detach().abs().max()) <= EPS + 1e-7
 
 
-def test_attack_both_pgd10_trajectory_and_attacked_miou(golden, precision):
+def test_attack_both_pgd10_trajectory_and_attacked_miou(golden, precision, tag=None):
     """H2 at the iteration count configs[3] uses: TEN accumulated-gradient iterations (the reference never zeroes delta.grad,
     attack/attack.py:501-512), then the harness forward on the attacked pair (robust_test.py:143-166), vs the reference's own
     run (gn_attack_PGD10).  Stated per iteration against the reference's float32-vs-float64 disagreement (`floor_*`)."""
@@ -148,7 +148,7 @@ def test_attack_both_pgd10_trajectory_and_attacked_miou(golden, precision):
     Hh.assert_multiclass(g["pred"], min_classes=3)
     miou_clean_ref = float(np.mean(np.nan_to_num(compute_results(g["conf_clean"])[2])))
     assert miou_clean_ref - miou_ref >= 0.2, (miou_clean_ref, miou_ref)
-    _record("pgd10_2x64x96_mit_b0[%s]" % precision, loss_rel=loss_rel, sign_mismatch_vs_ref32=sm32, sign_mismatch_vs_ref64=sm64,
+    _record("pgd10_2x64x96_mit_b0[%s]" % (tag or precision), loss_rel=loss_rel, sign_mismatch_vs_ref32=sm32, sign_mismatch_vs_ref64=sm64,
             delta_mismatch_vs_ref32=dm32, delta_mismatch_vs_ref64=dm64, moved_pixels=moved, miou=miou, miou_ref=miou_ref,
             miou_clean_ref=miou_clean_ref, ref_moved_pixels_f32_vs_f64=int((g["pred"] != g["pred64"]).sum()),
             ref_floor_sign=g["floor_sign"], ref_floor_loss=g["floor_loss"], ref_floor_delta=g["floor_delta"])
@@ -170,6 +170,32 @@ def test_attack_both_pgd10_trajectory_and_attacked_miou(golden, precision):
     assert (sm64 <= lim["sign_k"] * g["floor_sign"] + 1e-3).all(), (sm64, g["floor_sign"])
     assert max(dm64) <= lim["sign_k"] * float(g["floor_delta"].max()) + 1e-3, (dm64, g["floor_delta"])
     assert float(d_ir.detach().abs().max()) <= EPS + 1e-7 and float(d_vis.detach().abs().max()) <= EPS + 1e-7
+
+
+@pytest.mark.parametrize("mode", ["x6_gemms_at_every_size", "f16x3_forward"])
+def test_pgd10_gate_with_the_split_gemms_forced_at_this_size(golden, mode):
+    """The "auto6" rule sends a GEMM to the split kernels only from 2,048 rows up: at 2x64x96 (768 tokens at most) the gate above runs
+    every GEMM on the exact fp32 MFMA and says nothing about the arithmetic configs[3] actually uses at 480x640.  Here the threshold is
+    lowered to 1 row, so the SAME gate (the bounds of "default") is run with (a) three-piece bf16 GEMMs everywhere K >= 256 and
+    (b) the fp16-pair forward GEMMs of CONFIG["attack_fwd_f16x3"] (two 11-bit pieces, three MFMAs; the backward stays three-piece)."""
+    old = dict(ops.CONFIG)
+    try:
+        ops.set_conv_precision("bf16x3")
+        ops.set_gemm_precision("auto")
+        ops.set_attack_precision("bf16x6")
+        ops.CONFIG["gemm_split_min_m"] = 1
+        ops.CONFIG["attack_fwd_f16x3"] = mode == "f16x3_forward"
+        timer = ops.KernelTimer(lambda tag: tag.startswith("gemm_mfma"))
+        ops.TIMER = timer
+        try:
+            test_attack_both_pgd10_trajectory_and_attacked_miou(golden, "default", tag=mode)
+        finally:
+            ops.TIMER = None
+        seen = set(timer.summary())
+        assert ("gemm_mfma_f16x3" in seen) == (mode == "f16x3_forward") and "gemm_mfma_bf16x6" in seen, seen
+    finally:
+        ops.CONFIG.clear()
+        ops.CONFIG.update(old)
 
 
 def test_one_pgd_iteration_at_480x640_mit_b3(precision):
