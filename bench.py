@@ -371,12 +371,12 @@ def main():
                 # on bf16 maps) / 2 (bf16 maps: the stored operand's low half is zero; or plain bf16 weights on fp32 maps) / 1 (bf16 maps and
                 # plain bf16 weights: --storage bf16) -> 2500/n TF algorithmic peak
                 m_ = re.search(r", (\d+)>$", tag)
-                m5 = re.match(r"conv_mfma_bf16x3<\d, \d, (?:true|false), (\d+), (\d)>$", tag)   # <KH, DIL, HOOKS, storage code, pieces>
+                m5 = re.match(r"conv_mfma_bf16x3<\d, \d, (?:true|false), (\d+), (\d), (\d)>$", tag)   # <KH, DIL, HOOKS, storage code, pieces, fp16 pairs>
                 if tag == DOMINANT:
                     nm = {"f32": 3, "bf16_split": 2, "bf16": 1, "f16": 1}[args.storage] if args.workload in ("fusion", "fusion_seg") else 3
                 else:
                     if m5:
-                        nm = 6 if m5.group(2) == "3" else ST_MFMAS[int(m5.group(1))]
+                        nm = 6 if m5.group(2) == "3" else (3 if m5.group(3) == "1" else ST_MFMAS[int(m5.group(1))])
                     else:
                         nm = 1 if "bf16_dma" in tag else (ST_MFMAS[int(m_.group(1))] if m_ else 3)
                 peak_tf = 2500.0 / nm
@@ -473,7 +473,7 @@ def main():
                         + "; attention products: %s" % ("exact fp32 MFMA" if args.gemm_precision == "f32" else "split-bf16")
                         + ("" if args.workload not in ("pgd", "train") else
                            "; INSIDE the attack loop: %s" % ("exact fp32 MFMA for convs, GEMMs and attention (attack precision 'exact')"
-                                                            if args.attack_precision == "exact" else ("convs, GEMMs with K >= 256 and the attention products as three-piece bf16 splits (6 MFMAs per product, 2^-25); the other GEMMs exact fp32 MFMA (attack precision 'bf16x6')" if args.attack_precision == "bf16x6" else "the same split-bf16 kernels (attack precision 'fast')")))),
+                                                            if args.attack_precision == "exact" else ("backward passes: convs, GEMMs with K >= 256 and the attention products as three-piece bf16 splits (6 MFMAs per product, 2^-25); forward passes: the convs and those GEMMs as fp16 pairs (two 11-bit pieces per operand, 3 fp16 MFMAs per product, ~2^-21.5; measured error vs float64 at or below the exact fp32 MFMA's), attention three-piece; the other GEMMs exact fp32 MFMA (attack precision 'bf16x6')" if args.attack_precision == "bf16x6" else "the same split-bf16 kernels (attack precision 'fast')")))),
             "data": "synthetic",
             "config": {"workload": {"fusion": "configs[1]: fusion-net forward (RGB2YCrCb + Network_Fusion_Searched, C=32, shipped genotype)",
                                     "fusion_seg": "configs[2]: fusion + mit_b3 SegFormer end-to-end inference",
@@ -620,7 +620,7 @@ def also_block(args, dev, rank):
             tag = max(summ, key=lambda k: summ[k][1])
             n_, ms_, fl_, by_ = summ[tag]
             tf, gb = fl_ / (ms_ * 1e-3) / 1e12, by_ / (ms_ * 1e-3) / 1e9
-            peak_tf = (2500.0 / 6 if "bf16x6" in tag or tag.endswith(", 3>") else SPLIT_BF16_PEAK_TFLOPS if "bf16x3" in tag else
+            peak_tf = (2500.0 / 6 if "bf16x6" in tag or tag.endswith(", 3, 0>") else SPLIT_BF16_PEAK_TFLOPS if "bf16x3" in tag else
                        2500.0 if "bf16_dma" in tag else MFMA_F32_PEAK_TFLOPS)
             out[name] = {"config": cfg, "value": pairs * steps / dt, "unit": "pairs/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
                          "dominant_kernel": {"kernel": tag, "launches_per_step": n_ / steps, "share_of_step": ms_ / (dt * 1e3),

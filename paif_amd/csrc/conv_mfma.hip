@@ -399,7 +399,10 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 
 // NP = 3 ("bf16x6", fp32 storage only): every operand as THREE bf16 pieces (hi + mid + lo = the fp32 value to 2^-27) and the six
 // products down to 2^-25 relative -- fp32-level parity at 6 bf16 MFMAs per product (the exact fp32 MFMA costs 16 of their cycles).
-template <int KH, int DIL, bool HOOKS, int ST = 0, int NP = 2>
+// PF = 1 ("f16x3", fp32 storage, forward descriptors): the two pieces are IEEE fp16 (22 significant bits per operand instead of 16), the
+// weight pack carries fp16 pieces of 2^8 * w (exact scale, undone on the accumulators): ~2^-21.5 per product for O(1) data at three
+// MFMAs -- the forward passes of the attack loops (gemm_mfma.hip has the same form and the reasoning about fp16's exponent range).
+template <int KH, int DIL, bool HOOKS, int ST = 0, int NP = 2, int PF = 0>
 #ifndef PAIF_LB
 #define PAIF_LB 3
 #endif
@@ -411,7 +414,8 @@ __global__ __launch_bounds__(NTHREADS, (HOOKS || KH >= 5 || DIL == 2 || NP == 3)
   constexpr int TWH = TW + 2 * P;
   constexpr int THH = TH + 2 * P;
   static_assert(NP == 2 || (NP == 3 && ST == 0), "the three-piece split is built for fp32 storage");
-  constexpr int FM = paif::st_fmt16(ST);     // 16-bit format of the MFMA operands (1 bf16, 2 fp16)
+  static_assert(PF == 0 || (NP == 2 && ST == 0), "fp16 pairs: fp32 storage (forward descriptors: the launcher refuses the dgrad staging modes)");
+  constexpr int FM = PF == 1 ? 2 : paif::st_fmt16(ST);     // 16-bit format of the MFMA operands (1 bf16, 2 fp16)
   constexpr int PSB = NP == 3 ? 208 : 144;   // pixel record in bytes: NP x 64 + 16 (13 / 9 sixteen-byte slots: odd -> conflict-free b128)
   constexpr int QPP = CIN / 4;
   constexpr int NKS = CIN / 16;        // K=16 steps per tap
@@ -487,6 +491,13 @@ __global__ __launch_bounds__(NTHREADS, (HOOKS || KH >= 5 || DIL == 2 || NP == 3)
           const float4 t4 = stage_xform<HOOKS>(a, v[u], xa[u], in_slope, (dst[u] % PSB) >> 3);
           if constexpr (paif::st_f16(ST)) {   // fp16 maps: the staged operand is ONE fp16 value (stored as such, or rounded after the input PReLU)
             *reinterpret_cast<uint2*>(ldsb + dst[u]) = paif::f32_to_f16x4(t4);
+            continue;
+          }
+          if constexpr (PF == 1) {             // fp16 hi | lo pieces of the fp32 value
+            const uint2 hi = paif::f32_to_f16x4(t4);
+            const float4 hf = paif::f16x4_to_f32(hi);
+            *reinterpret_cast<uint2*>(ldsb + dst[u]) = hi;
+            *reinterpret_cast<uint2*>(ldsb + dst[u] + 64) = paif::f32_to_f16x4(make_float4(t4.x - hf.x, t4.y - hf.y, t4.z - hf.z, t4.w - hf.w));
             continue;
           }
           const __bf16 hx = (__bf16)t4.x, hy = (__bf16)t4.y, hz = (__bf16)t4.z, hw = (__bf16)t4.w;
@@ -623,6 +634,12 @@ __global__ __launch_bounds__(NTHREADS, (HOOKS || KH >= 5 || DIL == 2 || NP == 3)
     }
   }
 
+  if constexpr (PF == 1) {   // undo the 2^8 of the weight pack (exact)
+#pragma unroll
+    for (int s = 0; s < SEGS_PER_WAVE; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[s][r] *= 1.0f / 256.f;
+  }
   const bool full = (y0 + TH <= a.H) && (x0 + TW <= a.W) && (a.cout == 32);  // block-uniform
   const EpiParams ep_par = load_epi_params<HOOKS>(a, lane);   // in flight across the barrier
   __syncthreads();  // every wave has finished reading the staged tile: its LDS is reused by the epilogue
@@ -643,7 +660,7 @@ __global__ __launch_bounds__(NTHREADS, (HOOKS || KH >= 5 || DIL == 2 || NP == 3)
   }
 }
 
-template <int KH, int DIL, bool HOOKS, int ST = 0, int NP = 2>
+template <int KH, int DIL, bool HOOKS, int ST = 0, int NP = 2, int PF = 0>
 int launch_bf16x3_h(const ConvArgs& a, hipStream_t st) {
   constexpr int P = DIL * (KH - 1) / 2;
   constexpr size_t tile_bytes = (size_t)(TH + 2 * P) * (TW + 2 * P) * (NP == 3 ? 208 : 144);
@@ -651,14 +668,14 @@ int launch_bf16x3_h(const ConvArgs& a, hipStream_t st) {
   constexpr size_t lds_bytes = tile_bytes > epi_bytes ? tile_bytes : epi_bytes;
   static_assert(lds_bytes <= 160 * 1024, "tile does not fit LDS");
   if (lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_bf16x3<KH, DIL, HOOKS, ST, NP>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_bf16x3<KH, DIL, HOOKS, ST, NP, PF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) {
       paif::set_error("conv2d(bf16x3): cannot raise dynamic LDS to %zu: %s", lds_bytes, hipGetErrorString(e));
       return (int)e;
     }
   }
-  hipLaunchKernelGGL((conv_mfma_bf16x3<KH, DIL, HOOKS, ST, NP>), dim3(a.nblk), dim3(NTHREADS), lds_bytes, st, a);
+  hipLaunchKernelGGL((conv_mfma_bf16x3<KH, DIL, HOOKS, ST, NP, PF>), dim3(a.nblk), dim3(NTHREADS), lds_bytes, st, a);
   PAIF_LAUNCH_CHECK("conv2d(bf16x3)");
   return 0;
 }
@@ -1739,6 +1756,17 @@ int launch_bf16x6(const ConvArgs& a, hipStream_t st) {
   return needs_hooks(a) ? launch_bf16x3_h<KH, DIL, true, 0, 3>(a, st) : launch_bf16x3_h<KH, DIL, false, 0, 3>(a, st);
 }
 
+// fp16 pairs (PAIF_CONV_F16X3): the tile-per-workgroup kernel, forward form, fp32 storage
+template <int KH, int DIL>
+int launch_f16x3(const ConvArgs& a, hipStream_t st) {
+  if (a.st != 0 || a.in_act >= 3 || a.epi_dact) {
+    paif::set_error("conv2d: precision f16x3 is built for fp32-stored maps and forward descriptors (no dgrad staging / epilogue modes: gradients need the bf16 exponent range)");
+    return PAIF_ENOSUP;
+  }
+  // (a saved pre-activation -- aux_out, the taped forward -- takes the hook kernel's epilogue)
+  return needs_hooks(a) ? launch_bf16x3_h<KH, DIL, true, 0, 2, 1>(a, st) : launch_bf16x3_h<KH, DIL, false, 0, 2, 1>(a, st);
+}
+
 template <int KH, int DIL>
 int launch_bf16x3(const ConvArgs& a, hipStream_t st) {
   const int code = kernel_st(a);
@@ -2005,7 +2033,7 @@ int paif_conv2d_is_persistent(const paif_conv_desc* d, int B, int H, int W) {
 }
 
 int paif_conv2d_can_cpool(const paif_conv_desc* d, int B, int H, int W) {
-  if (!d || d->cout != 32 || d->cin != 32 || B <= 0 || H <= 0 || W <= 0 || d->precision == PAIF_CONV_F32 || d->precision == PAIF_CONV_BF16X6) return 0;
+  if (!d || d->cout != 32 || d->cin != 32 || B <= 0 || H <= 0 || W <= 0 || d->precision == PAIF_CONV_F32 || d->precision == PAIF_CONV_BF16X6 || d->precision == PAIF_CONV_F16X3) return 0;
   ConvArgs a{};
   for (int s = 0; s < 3; ++s) a.res[s] = d->res[s];
   a.pool_partial = d->pool_partial; a.nsrc = d->nsrc; a.in_act = d->in_act; a.cout = d->cout;
@@ -2027,7 +2055,11 @@ int paif_conv2d_kernel_name(const paif_conv_desc* d, int B, int H, int W, char* 
   a.st = d->storage; a.wl0 = (d->precision == PAIF_CONV_BF16 || d->precision == PAIF_CONV_F16) ? 1 : 0; a.alpha = d->alpha;
   const int code = kernel_st(a);
   if (d->precision == PAIF_CONV_BF16X6 && d->cin == 32) {
-    snprintf(buf, buflen, "conv_mfma_bf16x3<%d, %d, %s, 0, 3>", d->kh, d->dil, needs_hooks(a) ? "true" : "false");
+    snprintf(buf, buflen, "conv_mfma_bf16x3<%d, %d, %s, 0, 3, 0>", d->kh, d->dil, needs_hooks(a) ? "true" : "false");
+    return 0;
+  }
+  if (d->precision == PAIF_CONV_F16X3 && d->cin == 32) {
+    snprintf(buf, buflen, "conv_mfma_bf16x3<%d, %d, %s, 0, 2, 1>", d->kh, d->dil, needs_hooks(a) ? "true" : "false");
     return 0;
   }
   if (d->precision != PAIF_CONV_BF16X3 && d->precision != PAIF_CONV_BF16 && d->precision != PAIF_CONV_F16 && d->precision != PAIF_CONV_F16X2) {
@@ -2047,8 +2079,8 @@ int paif_conv2d_kernel_name(const paif_conv_desc* d, int B, int H, int W, char* 
     case CV_WS: snprintf(buf, buflen, "conv_bf16x3_ws%s<%d, %d, %d>", d->in_act == 2 ? "r" : "", d->kh, d->dil, code); break;
     case CV_RES: snprintf(buf, buflen, "conv_bf16x3_res<%d, %d, %d, %d, %d>", d->kh, d->dil, d->nsrc, PAIF_RES_ROWS, code); break;
     case CV_MS: snprintf(buf, buflen, "conv_bf16x3_ms<%d, %d, %d, %d>", d->kh, d->dil, d->nsrc, code); break;
-    case CV_HOOKS: snprintf(buf, buflen, "conv_mfma_bf16x3<%d, %d, true, %d, 2>", d->kh, d->dil, code); break;
-    default: snprintf(buf, buflen, "conv_mfma_bf16x3<%d, %d, false, %d, 2>", d->kh, d->dil, code); break;
+    case CV_HOOKS: snprintf(buf, buflen, "conv_mfma_bf16x3<%d, %d, true, %d, 2, 0>", d->kh, d->dil, code); break;
+    default: snprintf(buf, buflen, "conv_mfma_bf16x3<%d, %d, false, %d, 2, 0>", d->kh, d->dil, code); break;
   }
   return 0;
 }
@@ -2097,10 +2129,23 @@ int paif_conv2d_fwd(const paif_conv_desc* d, int B, int H, int W, paif_stream_t 
   PAIF_REQUIRE(!d->cpool || paif_conv2d_can_cpool(d, B, H, W), PAIF_ENOSUP, "conv2d: no fused ChannelPool for this descriptor (paif_conv2d_can_cpool)");
   PAIF_REQUIRE(d->cin == 32 || d->cin == 16, PAIF_ENOSUP, "conv2d: cin=%d", d->cin);
   PAIF_REQUIRE(d->precision == PAIF_CONV_F32 || d->precision == PAIF_CONV_BF16X3 || d->precision == PAIF_CONV_BF16 ||
-                   d->precision == PAIF_CONV_BF16X6 || d->precision == PAIF_CONV_F16 || d->precision == PAIF_CONV_F16X2, PAIF_EINVAL,
+                   d->precision == PAIF_CONV_BF16X6 || d->precision == PAIF_CONV_F16 || d->precision == PAIF_CONV_F16X2 ||
+                   d->precision == PAIF_CONV_F16X3, PAIF_EINVAL,
                "conv2d: precision=%d", d->precision);
-  PAIF_REQUIRE(d->precision != PAIF_CONV_BF16X6 || d->cin == 32, PAIF_ENOSUP, "conv2d: bf16x6 needs 32-channel sources");
+  PAIF_REQUIRE((d->precision != PAIF_CONV_BF16X6 && d->precision != PAIF_CONV_F16X3) || d->cin == 32, PAIF_ENOSUP, "conv2d: bf16x6 / f16x3 need 32-channel sources");
   const int key = d->kh * 100 + d->dil * 10 + (d->cin == 32 ? 0 : 1);
+  if (d->precision == PAIF_CONV_F16X3) {
+    switch (key) {
+      case 110: return launch_f16x3<1, 1>(a, st);
+      case 310: return launch_f16x3<3, 1>(a, st);
+      case 320: return launch_f16x3<3, 2>(a, st);
+      case 510: return launch_f16x3<5, 1>(a, st);
+      case 710: return launch_f16x3<7, 1>(a, st);
+      default: break;
+    }
+    paif::set_error("conv2d(f16x3): kernel %dx%d dil %d cin %d not built", d->kh, d->kh, d->dil, d->cin);
+    return PAIF_ENOSUP;
+  }
   if (d->precision == PAIF_CONV_BF16X6) {
     switch (key) {
       case 110: return launch_bf16x6<1, 1>(a, st);

@@ -35,10 +35,14 @@ ACT_GELU = 1  # paif_gemm_fwd's act code 1 is GELU (the conv's code 1 is PReLU)
 # configs[2]); "auto" keeps K < 256 exact because that is what keeps the default inside the reference's own fp32 noise floor.
 #
 # Arithmetic of the ATTACKS (attack_both / attack_vis / attack_ir and the single-modality variants), CONFIG["attack_precision"]:
-#   "bf16x6" (DEFAULT) -- the whole attack loop (taped forward AND input-gradient reverse pass) at fp32-level precision: convs and the
-#              K >= 256 GEMMs as three-piece bf16 splits (six MFMAs per product, 2^-25 per product), the other GEMMs and attention on the
-#              exact-fp32 kernels, whatever the two settings above say.  SURVEY 8(a) A1 (sign mismatch <= 1e-3 per iteration) HOLDS:
-#              measured sign mismatch against the reference's float64 run 0 in every iteration through PGD-10;
+#   "bf16x6" (DEFAULT) -- the whole attack loop (taped forward AND input-gradient reverse pass) at fp32-level precision, whatever the two
+#              settings above say.  Reverse pass: convs, the K >= 256 GEMMs and (round 5) the attention products as three-piece bf16
+#              splits (six MFMAs per product, 2^-25 per product).  Forward pass (round 5, CONFIG["attack_fwd_f16x3"]): the convs and those
+#              GEMMs as fp16 PAIRS -- two 11-bit pieces per operand, three fp16 MFMAs per product, the weight side pre-scaled by 2^8 --
+#              whose error against float64 measures at or below the exact fp32 MFMA's on O(1) data (tools/f16x3_check.py); attention
+#              three-piece.  The other GEMMs on the exact-fp32 kernel.  SURVEY 8(a) A1 (sign mismatch <= 1e-3 per iteration) HOLDS:
+#              measured sign mismatch against the reference's float64 run 0 in every iteration through PGD-10 (also with the split
+#              GEMMs forced at the test's small size: tests/test_parity_default_gpu.py);
 #   "exact"  -- opt-in: every kernel of the loop fp32-exact (fp32 MFMA, 157 TF): A1 holds (0 ... 8e-5 at iteration 10), 20 % slower;
 #   "fast"   -- opt-in: the settings above stay in force inside the loop (split-bf16 conv products, ~1e-5 relative): sign(running
 #              gradient sum) is a chaotic map and 2.4e-4 of the elements sit on the other side of zero in iteration 1, 2.5e-2 by
@@ -63,7 +67,7 @@ CONFIG = {"conv_precision": "bf16x3", "gemm_precision": os.environ.get("PAIF_GEM
           # 16-bit inference forward: a ResidualDenseBlock (k = 3, dilation 1) as ONE kernel (csrc/rdb_fused.hip) on maps of >= 512 tiles.
           # OFF by default: correct (tests/test_f16_storage_gpu.py) and 2 map passes instead of 9, but matrix-pipe bound at the clock the chip
           # sustains under that load -- 400 us per block inside the forward against 355 for the three bandwidth-bound launches
-          "rdb_fused": False, "gemm2": False, "gemm_split_min_m": 2048, "attack_fwd_f16x3": os.environ.get("PAIF_ATTACK_FWD_F16X3", "0") == "1", "attn_x6": os.environ.get("PAIF_ATTN_X6", "1") != "0", "gemm_gather": os.environ.get("PAIF_GEMM_GATHER", "1") != "0"}
+          "rdb_fused": False, "gemm2": False, "gemm_split_min_m": 2048, "attack_fwd_f16x3": {"0": False, "1": True, "gemm": "gemm"}[os.environ.get("PAIF_ATTACK_FWD_F16X3", "1")], "attn_x6": os.environ.get("PAIF_ATTN_X6", "1") != "0", "gemm_gather": os.environ.get("PAIF_GEMM_GATHER", "1") != "0"}
 # falsy, or the torch dtype (torch.bfloat16 / torch.float16) of the 32-channel maps while an inference forward of the fusion network
 # runs in a 16-bit storage mode (set by the model through `bf16_activations`)
 _ACT_BF16 = [False]
@@ -111,6 +115,7 @@ class bf16_activations:
 
 _TWINS = {}    # data_ptr of an fp32 map -> (the map, its bf16 twin written by the producing kernel); lives for one bf16 forward
 _SERP = [0]    # tile-direction parity of the next dense-conv launch
+F16X3_WSCALE = 256.0    # csrc/gemm_mfma.hip / conv_mfma.hip: the exact power of two on the weight side of the fp16-pair arithmetic
 _PREC_CODE = {"f32": 0, "bf16x3": 1, "bf16x6": 3, "f16": 4, "f16x2": 5, "f16x3": 6}    # include/paif_hip.h PAIF_CONV_*
 PREC_BF16 = 2          # include/paif_hip.h PAIF_CONV_BF16 (conv descriptors with bf16-stored maps only)
 
@@ -156,17 +161,19 @@ class attack_arithmetic:
 
 
 class attack_forward_arithmetic:
-    """Inside an attack loop, around the FORWARD pass only (CONFIG["attack_fwd_f16x3"]): the K >= 256 GEMMs as fp16 pairs (two 11-bit
-    pieces per operand, three fp16 MFMAs per product, ~2^-21.5) instead of three bf16 pieces (six MFMAs, 2^-25).  The backward keeps
-    the three-piece form: gradients span the bf16 exponent range."""
+    """Inside an attack loop, around the FORWARD pass only (CONFIG["attack_fwd_f16x3"]): the 32-channel convs and the K >= 256 GEMMs as fp16
+    pairs (two 11-bit pieces per operand, three fp16 MFMAs per product, ~2^-21.5) instead of three bf16 pieces (six MFMAs, 2^-25).  The
+    backward keeps the three-piece form: gradients span the bf16 exponent range."""
 
     def __enter__(self):
-        self.old = CONFIG["gemm_precision"]
-        if CONFIG["attack_fwd_f16x3"] and self.old == "auto6":
+        self.old = (CONFIG["gemm_precision"], CONFIG["conv_precision"])
+        if CONFIG["attack_fwd_f16x3"] and self.old[0] == "auto6":
             CONFIG["gemm_precision"] = "auto6h"
+        if CONFIG["attack_fwd_f16x3"] in (True, "conv") and self.old[1] == "bf16x6":
+            CONFIG["conv_precision"] = "f16x3"
 
     def __exit__(self, *a):
-        CONFIG["gemm_precision"] = self.old
+        CONFIG["gemm_precision"], CONFIG["conv_precision"] = self.old
 
 
 # ---- what a taped forward records: "dgrad" = enough for the input-gradient pass (PGD attacks); "wgrad" = also what the
@@ -497,6 +504,8 @@ def pack_conv_weight(w, nsrc, cin, kh, precision=None):
     wc = w.detach().contiguous()
     if precision in ("f16", "f16x2"):      # fp16 hi | lo pieces; "f16" reads the hi pieces only (one MFMA per product)
         _lib.check(L.paif_pack_conv_weight_f16x2(_p(wc), _p(wpk), cout, nsrc, kh, _stream()), "pack_conv_weight_f16x2")
+    elif precision == "f16x3":             # fp16 pairs on fp32 maps: the pieces of 2^8 * w (exact scale; the kernel undoes it on the accumulators)
+        _lib.check(L.paif_pack_conv_weight_f16x2(_p(wc * F16X3_WSCALE), _p(wpk), cout, nsrc, kh, _stream()), "pack_conv_weight_f16x2")
     elif precision == "bf16x6":
         _lib.check(L.paif_pack_conv_weight_bf16x6(_p(wc), _p(wpk), cout, nsrc, kh, _stream()), "pack_conv_weight_bf16x6")
     elif precision == "bf16x3":
@@ -536,7 +545,12 @@ def pack_decomp1x1_weight(w, precision=None):
     nfl = L.paif_conv_wpk_floats(3, 32, 1)
     wpk = torch.empty(nfl * 3 // 2 if precision == "bf16x6" else nfl, device=w.device, dtype=torch.float32)
     wc = w.detach().contiguous()
-    if precision == "bf16x6":
+    if precision == "f16x3":
+        # the same fold as paif_pack_decomp1x1_weight_bf16x3 (one fp32 add / subtract per weight), then the fp16 pieces of 2^8 * w
+        w2 = wc.view(32, 128)
+        fold = torch.cat([w2[:, 64:96] + w2[:, 96:128], w2[:, 0:32] - w2[:, 64:96], w2[:, 32:64] - w2[:, 96:128]], dim=1).contiguous()
+        _lib.check(L.paif_pack_conv_weight_f16x2(_p(fold * F16X3_WSCALE), _p(wpk), 32, 3, 1, _stream()), "pack_conv_weight_f16x2")
+    elif precision == "bf16x6":
         _lib.check(L.paif_pack_decomp1x1_weight_bf16x6(_p(wc), _p(wpk), _stream()), "pack_decomp1x1_weight_bf16x6")
     elif precision == "bf16x3":
         _lib.check(L.paif_pack_decomp1x1_weight_bf16x3(_p(wc), _p(wpk), _stream()), "pack_decomp1x1_weight_bf16x3")
@@ -651,6 +665,8 @@ def conv2d(srcs, wpk, kh, dil=1, cin=32, cout=32, in_act=ACT_NONE, in_prelu=None
             raise NotImplementedError("fp32 sources with an fp16 output are not built (the fp16 forward hands the 1x1 fp16 maps)")
     if storage and (want_aux or in_act >= 3 or epi_dact or in_aux is not None):
         raise NotImplementedError("16-bit activation storage is built for the inference forward (no gradient hooks)")
+    if wpk.precision == "f16x3" and (storage or in_act >= 3 or epi_dact or in_aux is not None):
+        raise NotImplementedError("the fp16-pair conv arithmetic is built for fp32 maps and forward descriptors (gradients need the bf16 exponent range)")
     if (sdt == torch.float16) != (wpk.precision in ("f16", "f16x2")):
         raise RuntimeError("conv2d: fp16 maps need an fp16 weight pack and vice versa (sources %s, pack %s)" % (sdt, wpk.precision))
     if out is None:
