@@ -1,0 +1,146 @@
+"""GPU tests of the fp16-pair arithmetic ("f16x3", PAIF_CONV_F16X3; round 5): every operand as TWO IEEE fp16 pieces (hi = rn(v),
+lo = rn(v - hi): 22 significant bits), three fp16 MFMAs per product (hi*hi + hi*lo + lo*hi), fp32 accumulate; the weight side carries an
+exact 2^8 so that its lo pieces stay normal fp16 numbers, undone on the accumulators.  It is the arithmetic of the FORWARD passes of the
+attack loops (ops.attack_forward_arithmetic, CONFIG["attack_fwd_f16x3"]): half the MFMAs of the three-piece bf16 form.  It must sit as
+close to float64 as the exact fp32-MFMA kernels do on the data of this path; the trajectory-level statement (PGD-10 sign mismatch vs the
+reference's float64 run, with the split GEMMs forced at the small size) is tests/test_parity_default_gpu.py."""
+import ctypes
+
+import pytest
+import torch
+
+from paif_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _restore():
+    old = dict(ops.CONFIG)
+    yield
+    ops.CONFIG.clear()
+    ops.CONFIG.update(old)
+
+
+@pytest.mark.parametrize("kh,dil,nsrc,cout", [(3, 1, 1, 32), (3, 1, 3, 32), (1, 1, 2, 32), (7, 1, 1, 32), (3, 2, 1, 32), (5, 1, 1, 32), (3, 1, 1, 16)])
+def test_conv_f16x3_is_fp32_level(kh, dil, nsrc, cout):
+    """The full epilogue (affine, PReLU, alpha, residual, saved pre-activation) on ragged maps, against float64; bound = the bf16x6 test's."""
+    dev = _dev()
+    B, H, W = 2, 70, 101
+    g = torch.Generator().manual_seed(kh * 10 + dil + nsrc)
+    xs = [ops.to_nhwc(torch.randn(B, 32, H, W, generator=g).to(dev)) for _ in range(nsrc)]
+    w = (torch.randn(cout, 32 * nsrc, kh, kh, generator=g) * 0.05).to(dev)
+    res = ops.to_nhwc(torch.randn(B, cout, H, W, generator=g).to(dev)) if cout == 32 else None
+    scale, shift = (torch.rand(cout, generator=g) + 0.5).to(dev), (torch.randn(cout, generator=g) * 0.1).to(dev)
+    slope = torch.tensor([0.2], device=dev)
+    x64 = torch.cat([ops.to_nchw_view(x) for x in xs], 1).double()
+    z = torch.nn.functional.conv2d(x64, w.double(), padding=dil * (kh - 1) // 2, dilation=dil) * scale.double()[None, :, None, None] + shift.double()[None, :, None, None]
+    ref = torch.where(z >= 0, z, z * 0.2) * 0.5
+    if res is not None:
+        ref = ref + ops.to_nchw_view(res).double()
+    err, aux_err = {}, {}
+    for prec in ("f32", "f16x3"):
+        wpk = ops.pack_conv_weight(w, nsrc, 32, kh, precision=prec)
+        out, aux = ops.conv2d(xs, wpk, kh, dil=dil, cout=cout, scale=scale, shift=shift, act=ops.ACT_PRELU, prelu=slope, alpha=0.5,
+                              res=(res,) if res is not None else (), want_aux=True)
+        err[prec] = float((ops.to_nchw_view(out).double() - ref).abs().max() / ref.abs().max())
+        aux_err[prec] = float((ops.to_nchw_view(aux).double() - z).abs().max() / z.abs().max())      # the taped forward's pre-activation
+    assert err["f16x3"] <= max(2.0 * err["f32"], 5e-7), err
+    assert aux_err["f16x3"] <= max(2.0 * aux_err["f32"], 5e-7), aux_err
+
+
+@pytest.mark.parametrize("scale_x,scale_w,bound", [(1.0, 0.05, 1.0), (30.0, 0.3, 1.0), (0.02, 0.05, 4.0), (1.0, 2e-4, 4.0)])
+def test_conv_f16x3_over_the_magnitudes_of_the_path(scale_x, scale_w, bound):
+    """fp16's narrow exponent: activations below 0.125 and weights below 5e-4 have SUBNORMAL lo pieces (absolute error <= 3e-8 per
+    operand) -- the relative error of an output may then exceed the exact kernel's, by a small factor (bound), never the split-bf16 level."""
+    dev = _dev()
+    g = torch.Generator().manual_seed(int(scale_x * 1000) + int(scale_w * 1e6))
+    x = ops.to_nhwc((torch.randn(2, 32, 48, 64, generator=g) * scale_x).to(dev))
+    w = (torch.randn(32, 32, 3, 3, generator=g) * scale_w).to(dev)
+    ref = torch.nn.functional.conv2d(ops.to_nchw_view(x).double(), w.double(), padding=1)
+    err = {}
+    for prec in ("f32", "f16x3", "bf16x3"):
+        out = ops.conv2d([x], ops.pack_conv_weight(w, 1, 32, 3, precision=prec), 3)
+        err[prec] = float((ops.to_nchw_view(out).double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    assert err["f16x3"] <= bound * max(err["f32"], 3e-7), err
+    assert err["f16x3"] <= 0.5 * err["bf16x3"], err
+
+
+def test_conv_f16x3_refuses_gradient_descriptors_and_16_bit_maps():
+    dev = _dev()
+    x = ops.to_nhwc(torch.randn(1, 32, 16, 24, device=dev))
+    w = torch.randn(32, 32, 3, 3, device=dev) * 0.05
+    wpk = ops.pack_conv_weight(w, 1, 32, 3, precision="f16x3")
+    with pytest.raises(NotImplementedError, match="forward descriptors"):
+        ops.conv2d([x], wpk, 3, in_act=ops.IN_DRELU, in_aux=x)
+    with pytest.raises(NotImplementedError, match="forward descriptors"):
+        ops.conv2d([x], wpk, 3, epi_aux=x, epi_dact=2)
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        ops.conv2d([x.half()], wpk, 3)
+    d = ops._lib.ConvDesc()                                  # the C ABI refuses the same things itself
+    out = torch.empty_like(x)
+    d.src[0], d.nsrc, d.cin, d.wpk, d.kh, d.dil, d.precision = ops._p(x), 1, 32, ops._p(wpk.data), 3, 1, 6
+    d.out, d.cout, d.alpha, d.in_act, d.in_aux = ops._p(out), 32, 1.0, 4, ops._p(x)
+    assert ops.lib().paif_conv2d_fwd(ctypes.byref(d), 1, 16, 24, None) != 0
+    assert "f16x3" in ops.lib().paif_last_error().decode()
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 320, 320), (3000, 1280, 320), (2500, 64, 4096), (2049, 72, 256), (100, 512, 512)])
+def test_gemm_f16x3_is_fp32_level(M, N, K):
+    """The GEMM form (plain and split-K, bias + GELU + residual epilogue) against float64; the dgrad prologue keeps the three-piece form."""
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dev)
+    bias, res = torch.randn(N, generator=g).to(dev), torch.randn(M, N, generator=g).to(dev)
+    ref = torch.nn.functional.gelu(a.double() @ w.double().t() + bias.double()) + res.double()
+    err = {}
+    for prec in ("f32", "bf16x6", "f16x3"):
+        ops.set_gemm_precision(prec)
+        timer = ops.KernelTimer(lambda tag: tag.startswith("gemm_mfma"))
+        ops.TIMER = timer
+        try:
+            y = ops.gemm(a, w, shift=bias, act=ops.ACT_GELU, res=res)
+        finally:
+            ops.TIMER = None
+        torch.cuda.synchronize()
+        assert list(timer.summary()) == ["gemm_mfma_" + prec]
+        err[prec] = float((y.double() - ref).abs().max() / ref.abs().max())
+    assert err["f16x3"] <= max(2.0 * err["f32"], 1e-6), err
+    ops.set_gemm_precision("f16x3")
+    mask = (torch.randn(M, K, generator=g) > 0).float().to(dev)
+    timer = ops.KernelTimer(lambda tag: tag.startswith("gemm_mfma"))
+    ops.TIMER = timer
+    try:
+        ops.gemm(a, w, a_mask=mask)
+    finally:
+        ops.TIMER = None
+    torch.cuda.synchronize()
+    assert list(timer.summary()) == ["gemm_mfma_bf16x6"]
+
+
+def test_attack_forward_arithmetic_switches_only_the_forward():
+    """The context the attack loop puts around forward_taped: conv packs "f16x3", GEMM rule "auto6h"; outside it (the reverse pass) the
+    three-piece forms; nothing changes outside an attack loop or with the switch off."""
+    assert ops.CONFIG["attack_fwd_f16x3"] is True                      # the product default
+    seen = []
+    with ops.attack_arithmetic():
+        seen.append((ops.CONFIG["conv_precision"], ops.CONFIG["gemm_precision"]))
+        with ops.attack_forward_arithmetic():
+            seen.append((ops.CONFIG["conv_precision"], ops.CONFIG["gemm_precision"], ops.pack_precision()))
+        seen.append((ops.CONFIG["conv_precision"], ops.CONFIG["gemm_precision"]))
+    assert seen == [("bf16x6", "auto6"), ("f16x3", "auto6h", "f16x3"), ("bf16x6", "auto6")]
+    with ops.attack_forward_arithmetic():                                # not inside an attack loop: untouched
+        assert (ops.CONFIG["conv_precision"], ops.CONFIG["gemm_precision"]) == ("bf16x3", "auto")
+    ops.CONFIG["attack_fwd_f16x3"] = False
+    with ops.attack_arithmetic(), ops.attack_forward_arithmetic():
+        assert (ops.CONFIG["conv_precision"], ops.CONFIG["gemm_precision"]) == ("bf16x6", "auto6")
+    ops.set_attack_precision("exact")
+    ops.CONFIG["attack_fwd_f16x3"] = True
+    with ops.attack_arithmetic(), ops.attack_forward_arithmetic():
+        assert (ops.CONFIG["conv_precision"], ops.CONFIG["gemm_precision"]) == ("f32", "f32")

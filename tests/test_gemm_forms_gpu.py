@@ -91,6 +91,7 @@ def test_conv_gemm_exact_gather_of_the_3_channel_patch_embed(case):
                 got, _, _ = ops.conv_gemm(x, wp, k, s, p, shift=bias)
             finally:
                 ops.TIMER = None
+            torch.cuda.synchronize()
         assert torch.equal(got, ref), prec
         assert list(timer.summary()) == ["gemm_mfma_f32"]       # one launch: no im2col, no second GEMM
     want = torch.nn.functional.conv2d(x.cpu().double().permute(0, 3, 1, 2), w.cpu().double(), bias.cpu().double(), stride=s, padding=p)

@@ -191,6 +191,7 @@ def test_pgd10_gate_with_the_split_gemms_forced_at_this_size(golden, mode):
             test_attack_both_pgd10_trajectory_and_attacked_miou(golden, "default", tag=mode)
         finally:
             ops.TIMER = None
+        torch.cuda.synchronize()
         seen = set(timer.summary())
         assert ("gemm_mfma_f16x3" in seen) == (mode == "f16x3_forward") and "gemm_mfma_bf16x6" in seen, seen
     finally:
