@@ -171,10 +171,11 @@ typedef struct {
 #define PAIF_CONV_F16 4         /* PAIF_ST_F16 / PAIF_ST_F16_F32 only: one fp16 MFMA per product; wpk = the F16X2 pack (its hi pieces are read) */
 #define PAIF_CONV_F16X2 5       /* PAIF_ST_F16 only, 1x1: weights as fp16 hi + lo (two MFMAs per product, 22-bit weights): the folded
                                    decomposition 1x1, whose weight rounding is the one that moves the segmentation argmax */
-#define PAIF_CONV_F16X3 6       /* paif_gemm_fwd / paif_gemm_splitk_fwd_p / paif_gemm_conv_fwd only (fp32 operands): each operand as TWO IEEE fp16 pieces (22
-                                   significant bits), hi*hi + hi*lo + lo*hi on the fp16 MFMA, W pre-scaled by 2^8 (undone on the accumulator): ~2^-21.5
-                                   per product for O(1) data at half the MFMAs of BF16X6 -- the FORWARD passes of the attack loops; no dgrad prologue
-                                   (gradients need the bf16 exponent range) */
+#define PAIF_CONV_F16X3 6       /* fp32 storage, cin = 32 (paif_conv2d_fwd: wpk = paif_pack_conv_weight_f16x2 of 2^8 * w) and paif_gemm_fwd /
+                                   paif_gemm_masked_fwd / paif_gemm_splitk_fwd_p / paif_gemm_conv_fwd: each operand as TWO IEEE fp16 pieces (22
+                                   significant bits), hi*hi + hi*lo + lo*hi on the fp16 MFMA, the weight side scaled by 2^8 (undone on the
+                                   accumulator): ~2^-21.5 per product for O(1) data at half the MFMAs of BF16X6 -- the attack loops' arithmetic.
+                                   Operands must lie inside fp16's exponent range: a caller that sends gradients through it scales them first */
 #define PAIF_CONV_BF16X6 3      /* fp32 storage, cin = 32: three bf16 pieces per operand, six MFMAs per product: fp32-level parity (2^-25 per
                                    product) at 6/16 of the exact fp32 MFMA's matrix-pipe time; the arithmetic of the attack loops */
 

@@ -399,7 +399,7 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 
 // NP = 3 ("bf16x6", fp32 storage only): every operand as THREE bf16 pieces (hi + mid + lo = the fp32 value to 2^-27) and the six
 // products down to 2^-25 relative -- fp32-level parity at 6 bf16 MFMAs per product (the exact fp32 MFMA costs 16 of their cycles).
-// PF = 1 ("f16x3", fp32 storage, forward descriptors): the two pieces are IEEE fp16 (22 significant bits per operand instead of 16), the
+// PF = 1 ("f16x3", fp32 storage): the two pieces are IEEE fp16 (22 significant bits per operand instead of 16), the
 // weight pack carries fp16 pieces of 2^8 * w (exact scale, undone on the accumulators): ~2^-21.5 per product for O(1) data at three
 // MFMAs -- the forward passes of the attack loops (gemm_mfma.hip has the same form and the reasoning about fp16's exponent range).
 template <int KH, int DIL, bool HOOKS, int ST = 0, int NP = 2, int PF = 0>
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(NTHREADS, (HOOKS || KH >= 5 || DIL == 2 || NP == 3)
   constexpr int TWH = TW + 2 * P;
   constexpr int THH = TH + 2 * P;
   static_assert(NP == 2 || (NP == 3 && ST == 0), "the three-piece split is built for fp32 storage");
-  static_assert(PF == 0 || (NP == 2 && ST == 0), "fp16 pairs: fp32 storage (forward descriptors: the launcher refuses the dgrad staging modes)");
+  static_assert(PF == 0 || (NP == 2 && ST == 0), "fp16 pairs: fp32 storage");
   constexpr int FM = PF == 1 ? 2 : paif::st_fmt16(ST);     // 16-bit format of the MFMA operands (1 bf16, 2 fp16)
   constexpr int PSB = NP == 3 ? 208 : 144;   // pixel record in bytes: NP x 64 + 16 (13 / 9 sixteen-byte slots: odd -> conflict-free b128)
   constexpr int QPP = CIN / 4;
@@ -1759,11 +1759,12 @@ int launch_bf16x6(const ConvArgs& a, hipStream_t st) {
 // fp16 pairs (PAIF_CONV_F16X3): the tile-per-workgroup kernel, forward form, fp32 storage
 template <int KH, int DIL>
 int launch_f16x3(const ConvArgs& a, hipStream_t st) {
-  if (a.st != 0 || a.in_act >= 3 || a.epi_dact) {
-    paif::set_error("conv2d: precision f16x3 is built for fp32-stored maps and forward descriptors (no dgrad staging / epilogue modes: gradients need the bf16 exponent range)");
+  if (a.st != 0) {
+    paif::set_error("conv2d: precision f16x3 is built for fp32-stored maps");
     return PAIF_ENOSUP;
   }
-  // (a saved pre-activation -- aux_out, the taped forward -- takes the hook kernel's epilogue)
+  // (a saved pre-activation -- aux_out, the taped forward -- and the dgrad staging / epilogue modes take the hook kernel; a caller that
+  // sends GRADIENTS through this arithmetic scales them into fp16's exponent range first: ops.attack_grad_scale)
   return needs_hooks(a) ? launch_bf16x3_h<KH, DIL, true, 0, 2, 1>(a, st) : launch_bf16x3_h<KH, DIL, false, 0, 2, 1>(a, st);
 }
 

@@ -608,8 +608,8 @@ extern "C" int paif_gemm_masked_fwd(const float* A, int lda, const float* a_mask
     if (pro) hipLaunchKernelGGL((gemm_mfma_bf16x3<true, 3>), grid, blk, 0, st, a);
     else hipLaunchKernelGGL((gemm_mfma_bf16x3<false, 3>), grid, blk, 0, st, a);
   } else if (precision == 6) {
-    PAIF_REQUIRE(!pro, PAIF_ENOSUP, "gemm: the fp16-pair arithmetic has no dgrad prologue (gradients need the bf16 exponent range)");
-    hipLaunchKernelGGL((gemm_mfma_bf16x3<false, 2, false, 1>), grid, blk, 0, st, a);
+    if (pro) hipLaunchKernelGGL((gemm_mfma_bf16x3<true, 2, false, 1>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((gemm_mfma_bf16x3<false, 2, false, 1>), grid, blk, 0, st, a);
   } else if (precision == 1) {
     if (pro) hipLaunchKernelGGL(gemm_mfma_bf16x3<true>, grid, blk, 0, st, a);
     else hipLaunchKernelGGL(gemm_mfma_bf16x3<false>, grid, blk, 0, st, a);

@@ -67,7 +67,9 @@ CONFIG = {"conv_precision": "bf16x3", "gemm_precision": os.environ.get("PAIF_GEM
           # 16-bit inference forward: a ResidualDenseBlock (k = 3, dilation 1) as ONE kernel (csrc/rdb_fused.hip) on maps of >= 512 tiles.
           # OFF by default: correct (tests/test_f16_storage_gpu.py) and 2 map passes instead of 9, but matrix-pipe bound at the clock the chip
           # sustains under that load -- 400 us per block inside the forward against 355 for the three bandwidth-bound launches
-          "rdb_fused": False, "gemm2": False, "gemm_split_min_m": 2048, "attack_fwd_f16x3": {"0": False, "1": True, "gemm": "gemm"}[os.environ.get("PAIF_ATTACK_FWD_F16X3", "1")], "attn_x6": os.environ.get("PAIF_ATTN_X6", "1") != "0", "gemm_gather": os.environ.get("PAIF_GEMM_GATHER", "1") != "0"}
+          "rdb_fused": False, "gemm2": False, "gemm_split_min_m": 2048, "attack_bwd_f16x3": {"0": False, "1": True, "gemm": "gemm"}[os.environ.get("PAIF_ATTACK_BWD_F16X3", "1")],
+          "attack_grad_scale_log2": (int(os.environ["PAIF_ATTACK_GSCALE"]) if "PAIF_ATTACK_GSCALE" in os.environ else None),
+          "attack_fwd_f16x3": {"0": False, "1": True, "gemm": "gemm"}[os.environ.get("PAIF_ATTACK_FWD_F16X3", "1")], "attn_x6": os.environ.get("PAIF_ATTN_X6", "1") != "0", "gemm_gather": os.environ.get("PAIF_GEMM_GATHER", "1") != "0"}
 # falsy, or the torch dtype (torch.bfloat16 / torch.float16) of the 32-channel maps while an inference forward of the fusion network
 # runs in a 16-bit storage mode (set by the model through `bf16_activations`)
 _ACT_BF16 = [False]
@@ -174,6 +176,33 @@ class attack_forward_arithmetic:
 
     def __exit__(self, *a):
         CONFIG["gemm_precision"], CONFIG["conv_precision"] = self.old
+
+
+class attack_backward_arithmetic:
+    """Inside an attack loop, around the REVERSE pass (CONFIG["attack_bwd_f16x3"]): fp16 pairs there too.  The reverse pass is linear in
+    the upstream gradient, so the loop multiplies d(loss)/d(logits) by an exact power of two (attack_grad_scale: ~ the number of
+    pixels the loss averages over, which brings the gradients to O(1)) and divides the input gradient by it -- bit-neutral in fp32
+    arithmetic, and what puts the gradients inside fp16's exponent range."""
+
+    def __enter__(self):
+        self.old = (CONFIG["gemm_precision"], CONFIG["conv_precision"])
+        if CONFIG["attack_bwd_f16x3"] and self.old[0] == "auto6":
+            CONFIG["gemm_precision"] = "auto6h"
+        if CONFIG["attack_bwd_f16x3"] in (True, "conv") and self.old[1] == "bf16x6":
+            CONFIG["conv_precision"] = "f16x3"
+
+    def __exit__(self, *a):
+        CONFIG["gemm_precision"], CONFIG["conv_precision"] = self.old
+
+
+def attack_grad_scale(label):
+    """The power of two the attack loops scale the reverse pass by (1.0 when the reverse pass stays on three-piece bf16 splits)."""
+    if not CONFIG["attack_bwd_f16x3"] or CONFIG.get("attack_precision", "bf16x6") != "bf16x6":
+        return 1.0
+    k = CONFIG["attack_grad_scale_log2"]
+    if k is None:
+        k = max(0, int(label.numel()).bit_length() - 1 - 4)      # 2^floor(log2(pixels)) / 16: |d logits| <= 1/16 after scaling
+    return float(2 ** k)
 
 
 # ---- what a taped forward records: "dgrad" = enough for the input-gradient pass (PGD attacks); "wgrad" = also what the
@@ -665,8 +694,8 @@ def conv2d(srcs, wpk, kh, dil=1, cin=32, cout=32, in_act=ACT_NONE, in_prelu=None
             raise NotImplementedError("fp32 sources with an fp16 output are not built (the fp16 forward hands the 1x1 fp16 maps)")
     if storage and (want_aux or in_act >= 3 or epi_dact or in_aux is not None):
         raise NotImplementedError("16-bit activation storage is built for the inference forward (no gradient hooks)")
-    if wpk.precision == "f16x3" and (storage or in_act >= 3 or epi_dact or in_aux is not None):
-        raise NotImplementedError("the fp16-pair conv arithmetic is built for fp32 maps and forward descriptors (gradients need the bf16 exponent range)")
+    if wpk.precision == "f16x3" and storage:
+        raise NotImplementedError("the fp16-pair conv arithmetic is built for fp32 maps")
     if (sdt == torch.float16) != (wpk.precision in ("f16", "f16x2")):
         raise RuntimeError("conv2d: fp16 maps need an fp16 weight pack and vice versa (sources %s, pack %s)" % (sdt, wpk.precision))
     if out is None:
@@ -989,8 +1018,6 @@ def gemm(a, w, scale=None, shift=None, act=ACT_NONE, res=None, out=None, out_col
         prec = "bf16x6" if (K >= 256 and M >= CONFIG["gemm_split_min_m"]) else "f32"
     elif prec == "auto6h":  # the attack loops' FORWARD passes: fp16 pairs (22 bits per operand, three MFMAs) there instead
         prec = "f16x3" if (K >= 256 and M >= CONFIG["gemm_split_min_m"]) else "f32"
-    if prec == "f16x3" and (a_mask is not None or a_scale is not None):
-        prec = "bf16x6"     # dgrad prologue: gradients keep the bf16 exponent range
     tag = "gemm_mfma_%s" % prec
     e0 = TIMER.start(tag) if TIMER is not None else None
     nt = 0

@@ -71,23 +71,33 @@ def test_conv_f16x3_over_the_magnitudes_of_the_path(scale_x, scale_w, bound):
     assert err["f16x3"] <= 0.5 * err["bf16x3"], err
 
 
-def test_conv_f16x3_refuses_gradient_descriptors_and_16_bit_maps():
+def test_conv_f16x3_gradient_hooks_match_exact_kernel_and_16_bit_maps_are_refused():
+    """The dgrad staging / epilogue modes (activation-derivative transforms) in the fp16-pair arithmetic, on gradients scaled to O(1)
+    the way the attack loop does it; fp16-STORED maps are another configuration (precision "f16") and refused."""
     dev = _dev()
-    x = ops.to_nhwc(torch.randn(1, 32, 16, 24, device=dev))
-    w = torch.randn(32, 32, 3, 3, device=dev) * 0.05
+    B, H, W = 2, 50, 77
+    g = torch.Generator().manual_seed(5)
+    dy = ops.to_nhwc(torch.randn(B, 32, H, W, generator=g).to(dev))
+    aux = ops.to_nhwc(torch.randn(B, 32, H, W, generator=g).to(dev))
+    w = (torch.randn(32, 32, 3, 3, generator=g) * 0.05).to(dev)
+    slope = torch.tensor([0.25], device=dev)
+    outs = {}
+    for prec in ("f32", "f16x3"):
+        wpk = ops.pack_conv_weight(w, 1, 32, 3, precision=prec)
+        o1 = ops.conv2d([dy], wpk, 3, in_act=ops.IN_DPRELU, in_prelu=slope, in_aux=aux)
+        o2 = ops.conv2d([dy], wpk, 3, in_act=ops.IN_DRELU, in_aux=aux, epi_aux=aux, epi_dact=2)
+        outs[prec] = (o1, o2)
+    for a, b in zip(outs["f32"], outs["f16x3"]):
+        assert float((a - b).abs().max() / a.abs().max()) <= 1e-6
     wpk = ops.pack_conv_weight(w, 1, 32, 3, precision="f16x3")
-    with pytest.raises(NotImplementedError, match="forward descriptors"):
-        ops.conv2d([x], wpk, 3, in_act=ops.IN_DRELU, in_aux=x)
-    with pytest.raises(NotImplementedError, match="forward descriptors"):
-        ops.conv2d([x], wpk, 3, epi_aux=x, epi_dact=2)
     with pytest.raises((NotImplementedError, RuntimeError)):
-        ops.conv2d([x.half()], wpk, 3)
-    d = ops._lib.ConvDesc()                                  # the C ABI refuses the same things itself
-    out = torch.empty_like(x)
-    d.src[0], d.nsrc, d.cin, d.wpk, d.kh, d.dil, d.precision = ops._p(x), 1, 32, ops._p(wpk.data), 3, 1, 6
-    d.out, d.cout, d.alpha, d.in_act, d.in_aux = ops._p(out), 32, 1.0, 4, ops._p(x)
-    assert ops.lib().paif_conv2d_fwd(ctypes.byref(d), 1, 16, 24, None) != 0
-    assert "f16x3" in ops.lib().paif_last_error().decode()
+        ops.conv2d([dy.half()], wpk, 3)
+    d = ops._lib.ConvDesc()                                  # the C ABI refuses 16-bit storage itself
+    out = torch.empty_like(dy)
+    d.src[0], d.nsrc, d.cin, d.wpk, d.kh, d.dil, d.precision = ops._p(dy), 1, 32, ops._p(wpk.data), 3, 1, 6
+    d.out, d.cout, d.alpha, d.storage = ops._p(out), 32, 1.0, 3
+    assert ops.lib().paif_conv2d_fwd(ctypes.byref(d), B, H, W, None) != 0
+    assert "f16x3" in ops.lib().paif_last_error().decode() or "fp16" in ops.lib().paif_last_error().decode()
 
 
 @pytest.mark.parametrize("M,N,K", [(4096, 320, 320), (3000, 1280, 320), (2500, 64, 4096), (2049, 72, 256), (100, 512, 512)])
@@ -112,22 +122,23 @@ def test_gemm_f16x3_is_fp32_level(M, N, K):
         assert list(timer.summary()) == ["gemm_mfma_" + prec]
         err[prec] = float((y.double() - ref).abs().max() / ref.abs().max())
     assert err["f16x3"] <= max(2.0 * err["f32"], 1e-6), err
-    ops.set_gemm_precision("f16x3")
+    # the dgrad prologue (ReLU mask, per-column scale) in the same arithmetic
     mask = (torch.randn(M, K, generator=g) > 0).float().to(dev)
-    timer = ops.KernelTimer(lambda tag: tag.startswith("gemm_mfma"))
-    ops.TIMER = timer
-    try:
-        ops.gemm(a, w, a_mask=mask)
-    finally:
-        ops.TIMER = None
-    torch.cuda.synchronize()
-    assert list(timer.summary()) == ["gemm_mfma_bf16x6"]
+    colscale = (torch.rand(K, generator=g) + 0.5).to(dev)
+    ref2 = (a.double() * mask.double() * colscale.double()) @ w.double().t()
+    ops.set_gemm_precision("f16x3")
+    y2 = ops.gemm(a, w, a_mask=mask, a_scale=colscale)
+    ops.set_gemm_precision("f32")
+    y2e = ops.gemm(a, w, a_mask=mask, a_scale=colscale)
+    e2, e2e = float((y2.double() - ref2).abs().max() / ref2.abs().max()), float((y2e.double() - ref2).abs().max() / ref2.abs().max())
+    assert e2 <= max(2.0 * e2e, 1e-6), (e2, e2e)
 
 
 def test_attack_forward_arithmetic_switches_only_the_forward():
     """The context the attack loop puts around forward_taped: conv packs "f16x3", GEMM rule "auto6h"; outside it (the reverse pass) the
     three-piece forms; nothing changes outside an attack loop or with the switch off."""
     assert ops.CONFIG["attack_fwd_f16x3"] is True                      # the product default
+    ops.CONFIG["attack_bwd_f16x3"] = False
     seen = []
     with ops.attack_arithmetic():
         seen.append((ops.CONFIG["conv_precision"], ops.CONFIG["gemm_precision"]))

@@ -172,20 +172,23 @@ def test_attack_both_pgd10_trajectory_and_attacked_miou(golden, precision, tag=N
     assert float(d_ir.detach().abs().max()) <= EPS + 1e-7 and float(d_vis.detach().abs().max()) <= EPS + 1e-7
 
 
-@pytest.mark.parametrize("mode", ["x6_gemms_at_every_size", "f16x3_forward"])
+@pytest.mark.parametrize("mode", ["x6_everywhere", "f16x3_forward", "f16x3_forward_and_backward"])
 def test_pgd10_gate_with_the_split_gemms_forced_at_this_size(golden, mode):
     """The "auto6" rule sends a GEMM to the split kernels only from 2,048 rows up: at 2x64x96 (768 tokens at most) the gate above runs
     every GEMM on the exact fp32 MFMA and says nothing about the arithmetic configs[3] actually uses at 480x640.  Here the threshold is
-    lowered to 1 row, so the SAME gate (the bounds of "default") is run with (a) three-piece bf16 GEMMs everywhere K >= 256 and
-    (b) the fp16-pair forward GEMMs of CONFIG["attack_fwd_f16x3"] (two 11-bit pieces, three MFMAs; the backward stays three-piece)."""
+    lowered to 1 row, and the SAME gate (the bounds of "default") is run with
+      x6_everywhere               three-piece bf16 convs / K >= 256 GEMMs in both passes (round 4's attack arithmetic),
+      f16x3_forward               fp16 pairs (two 11-bit pieces, three MFMAs) in the forward pass, three-piece bf16 in the reverse pass,
+      f16x3_forward_and_backward  fp16 pairs in both, the reverse pass scaled by ops.attack_grad_scale (an exact power of two)."""
     old = dict(ops.CONFIG)
     try:
         ops.set_conv_precision("bf16x3")
         ops.set_gemm_precision("auto")
         ops.set_attack_precision("bf16x6")
         ops.CONFIG["gemm_split_min_m"] = 1
-        ops.CONFIG["attack_fwd_f16x3"] = mode == "f16x3_forward"
-        timer = ops.KernelTimer(lambda tag: tag.startswith("gemm_mfma"))
+        ops.CONFIG["attack_fwd_f16x3"] = mode != "x6_everywhere"
+        ops.CONFIG["attack_bwd_f16x3"] = mode == "f16x3_forward_and_backward"
+        timer = ops.KernelTimer(lambda tag: tag.startswith("gemm_mfma") or tag.startswith("conv_mfma"))
         ops.TIMER = timer
         try:
             test_attack_both_pgd10_trajectory_and_attacked_miou(golden, "default", tag=mode)
@@ -193,7 +196,14 @@ def test_pgd10_gate_with_the_split_gemms_forced_at_this_size(golden, mode):
             ops.TIMER = None
         torch.cuda.synchronize()
         seen = set(timer.summary())
-        assert ("gemm_mfma_f16x3" in seen) == (mode == "f16x3_forward") and "gemm_mfma_bf16x6" in seen, seen
+        x6 = {t for t in seen if t == "gemm_mfma_bf16x6" or t.endswith(", 0, 3, 0>")}
+        h3 = {t for t in seen if t == "gemm_mfma_f16x3" or t.endswith(", 0, 2, 1>")}
+        if mode == "x6_everywhere":
+            assert x6 and not h3, seen
+        elif mode == "f16x3_forward":
+            assert "gemm_mfma_f16x3" in h3 and "gemm_mfma_bf16x6" in x6 and len(h3) > 1 and len(x6) > 1, seen
+        else:                                   # the three-piece form is left only where a kernel has no fp16-pair form
+            assert "gemm_mfma_f16x3" in h3 and len(h3) > 1, seen
     finally:
         ops.CONFIG.clear()
         ops.CONFIG.update(old)
