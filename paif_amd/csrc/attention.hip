@@ -149,7 +149,7 @@ using paif::mfma_pieces;
 // NP: bf16 pieces per operand.  KC (multiple of 32): keys per LDS chunk -- K (krows = min(KC, Nk) row records of NP x D bf16) and
 // V^T (D records of NP x KC slots) of a chunk are staged together; the online softmax carries over chunk boundaries as it does
 // over key tiles.  Two pieces x 300 keys x 64 dims fit at once (159,744 B); three pieces take chunks of 160 keys.
-template <int D, int NP>
+template <int D, int NP, int PF = 0>
 __global__ __launch_bounds__(512) void sr_attention_split_kernel(AttnArgs a, int KC, int krows) {
   extern __shared__ __align__(16) char ldsc[];
   constexpr int NT = 512;
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(512) void sr_attention_split_kernel(AttnArgs a, int
     const float4 q0v = *reinterpret_cast<const float4*>(qrow + 16 * o + 8 * h);
     const float4 q1v = *reinterpret_cast<const float4*>(qrow + 16 * o + 8 * h + 4);
     const float q8[8] = {q0v.x, q0v.y, q0v.z, q0v.w, q1v.x, q1v.y, q1v.z, q1v.w};
-    splitN<NP>(q8, qp[o]);
+    splitN<NP, PF>(q8, qp[o]);
   }
 
   f32x16 oacc[DT];
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(512) void sr_attention_split_kernel(AttnArgs a, int
       const float4 k1 = *reinterpret_cast<const float4*>(src + 4);
       const float kv8[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
       abf16x8 pc[NP];
-      splitN<NP>(kv8, pc);
+      splitN<NP, PF>(kv8, pc);
       // record: piece q at q * 2D bytes; 16-byte chunks swizzled inside each piece (D/8 is 4 or 8 chunks: key & (D/8 - 1))
       const int sw = key & (D / 8 - 1);
 #pragma unroll
@@ -216,9 +216,9 @@ __global__ __launch_bounds__(512) void sr_attention_split_kernel(AttnArgs a, int
         float rr = vf[i];
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
-          const __bf16 hx = (__bf16)rr;
-          *reinterpret_cast<__bf16*>(Vt + (size_t)dim * VREC + q * KC * 2 + slot * 2) = hx;
-          if (q + 1 < NP) rr -= (float)hx;
+          float back;
+          *reinterpret_cast<__bf16*>(Vt + (size_t)dim * VREC + q * KC * 2 + slot * 2) = paif::piece16<PF>(rr, back);
+          if (q + 1 < NP) rr -= back;
         }
       }
     }
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(512) void sr_attention_split_kernel(AttnArgs a, int
         abf16x8 kp[NP];
 #pragma unroll
         for (int q = 0; q < NP; ++q) kp[q] = *reinterpret_cast<const abf16x8*>(krow + q * D * 2 + ((c ^ sw) << 4));
-        mfma_pieces<NP>(st, kp, qp[o]);
+        mfma_pieces<NP, PF>(st, kp, qp[o]);
       }
       // ---- online softmax over this tile's keys (register r <-> key c0 + t*32 + (r&3)+8(r>>2)+4h) ----
       float mt = -INFINITY;
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(512) void sr_attention_split_kernel(AttnArgs a, int
 #pragma unroll
         for (int i = 0; i < 8; ++i) p8[i] = st[8 * s2 + i];
         abf16x8 pp[NP];
-        splitN<NP>(p8, pp);
+        splitN<NP, PF>(p8, pp);
         const int soff = (t * 32 + s2 * 16 + 8 * h) * 2;   // byte offset of this lane half's 8 slots
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(512) void sr_attention_split_kernel(AttnArgs a, int
           abf16x8 vp[NP];
 #pragma unroll
           for (int q = 0; q < NP; ++q) vp[q] = *reinterpret_cast<const abf16x8*>(Vt + (size_t)dim * VREC + q * KC * 2 + soff);
-          mfma_pieces<NP>(oacc[dt], vp, pp);
+          mfma_pieces<NP, PF>(oacc[dt], vp, pp);
         }
       }
     }
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(512) void sr_attention_split_kernel(AttnArgs a, int
   }
 }
 
-template <int D, int NP>
+template <int D, int NP, int PF = 0>
 int launch_attn_split(const AttnArgs& a, hipStream_t st) {
   // the largest chunk (multiple of 32 keys, at most ceil32(Nk)) whose K rows + V^T records fit the 160 KiB of LDS
   int KC = (a.Nk + 31) & ~31;
@@ -314,14 +314,14 @@ int launch_attn_split(const AttnArgs& a, hipStream_t st) {
   }
   if (KC < 32) { paif::set_error("sr_attention(split): no key chunk fits LDS"); return PAIF_ENOSUP; }
   if (lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sr_attention_split_kernel<D, NP>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sr_attention_split_kernel<D, NP, PF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) {
       paif::set_error("sr_attention(split): cannot raise dynamic LDS to %zu: %s", lds_bytes, hipGetErrorString(e));
       return (int)e;
     }
   }
-  hipLaunchKernelGGL((sr_attention_split_kernel<D, NP>), dim3((a.N + 255) / 256, a.heads, a.B), dim3(512), lds_bytes, st, a, KC,
+  hipLaunchKernelGGL((sr_attention_split_kernel<D, NP, PF>), dim3((a.N + 255) / 256, a.heads, a.B), dim3(512), lds_bytes, st, a, KC,
                      KC < a.Nk ? KC : a.Nk);
   PAIF_LAUNCH_CHECK("sr_attention(split)");
   return 0;
@@ -357,14 +357,14 @@ extern "C" int paif_sr_attention_split_fwd(const float* q, const float* kv, floa
                                           int heads, int precision, paif_stream_t stream) {
   PAIF_REQUIRE(q && kv && out && B > 0 && N > 0 && Nk > 0 && heads > 0, PAIF_EINVAL, "sr_attention(split): bad arguments");
   PAIF_REQUIRE(C % heads == 0, PAIF_EINVAL, "sr_attention(split): C=%d not divisible by heads=%d", C, heads);
-  PAIF_REQUIRE(precision == 1 || precision == 3, PAIF_EINVAL, "sr_attention(split): precision=%d", precision);
+  PAIF_REQUIRE(precision == 1 || precision == 3 || precision == 6, PAIF_EINVAL, "sr_attention(split): precision=%d", precision);
   const int D = C / heads;
   AttnArgs a;
   a.q = q; a.kv = kv; a.out = out; a.lse = lse; a.B = B; a.N = N; a.Nk = Nk; a.C = C; a.heads = heads;
   a.scale = 1.0f / sqrtf((float)D);
   hipStream_t st = paif::as_stream(stream);
-  if (D == 64) return precision == 3 ? launch_attn_split<64, 3>(a, st) : launch_attn_split<64, 2>(a, st);
-  if (D == 32) return precision == 3 ? launch_attn_split<32, 3>(a, st) : launch_attn_split<32, 2>(a, st);
+  if (D == 64) return precision == 3 ? launch_attn_split<64, 3>(a, st) : precision == 6 ? launch_attn_split<64, 2, 1>(a, st) : launch_attn_split<64, 2>(a, st);
+  if (D == 32) return precision == 3 ? launch_attn_split<32, 3>(a, st) : precision == 6 ? launch_attn_split<32, 2, 1>(a, st) : launch_attn_split<32, 2>(a, st);
   paif::set_error("sr_attention(split): head dim %d not built (32 and 64 are)", D);
   return PAIF_ENOSUP;
 }

@@ -141,7 +141,7 @@ struct DqCfg {
   static_assert(lds_bytes <= 160 * 1024, "dq(split): key chunk does not fit LDS");
 };
 
-template <int D, int NP>
+template <int D, int NP, int PF = 0>
 __global__ __launch_bounds__(512) void attn_bwd_dq_split_kernel(AttnBwdArgs a) {
   extern __shared__ __align__(16) char ldsc[];
   constexpr int NT = 512;
@@ -173,8 +173,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_split_kernel(AttnBwdArgs a) {
       d8[4 * j] = dv.x; d8[4 * j + 1] = dv.y; d8[4 * j + 2] = dv.z; d8[4 * j + 3] = dv.w;
       dpart += (dv.x * ov.x + dv.y * ov.y) + (dv.z * ov.z + dv.w * ov.w);
     }
-    splitN<NP>(q8, qp[o]);
-    splitN<NP>(d8, dop[o]);
+    splitN<NP, PF>(q8, qp[o]);
+    splitN<NP, PF>(d8, dop[o]);
   }
   const float delta = dpart + __shfl_xor(dpart, 32);
   const size_t stat = ((size_t)b * a.heads + hd) * a.N + qi;
@@ -201,8 +201,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_split_kernel(AttnBwdArgs a) {
       const float k8[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
       const float v8[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
       bbf16x8 kp[NP], vp[NP];
-      splitN<NP>(k8, kp);
-      splitN<NP>(v8, vp);
+      splitN<NP, PF>(k8, kp);
+      splitN<NP, PF>(v8, vp);
       if (live) {
         const int sw = key & (D / 8 - 1);
 #pragma unroll
@@ -241,8 +241,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_split_kernel(AttnBwdArgs a) {
           kp[q] = *reinterpret_cast<const bbf16x8*>(krow + q * D * 2 + cc);
           vp[q] = *reinterpret_cast<const bbf16x8*>(vrow + q * D * 2 + cc);
         }
-        mfma_pieces<NP>(st, kp, qp[o]);
-        mfma_pieces<NP>(dp, vp, dop[o]);
+        mfma_pieces<NP, PF>(st, kp, qp[o]);
+        mfma_pieces<NP, PF>(dp, vp, dop[o]);
       }
       // dS^T = P^T o (dP^T - delta) * scale     (register r <-> key c0 + t*32 + (r&3)+8(r>>2)+4h)
 #pragma unroll
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_split_kernel(AttnBwdArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) d8[i] = st[8 * s2 + i];
         bbf16x8 dsp[NP];
-        splitN<NP>(d8, dsp);
+        splitN<NP, PF>(d8, dsp);
         const int soff = (t * 32 + s2 * 16 + 8 * h) * 2;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_split_kernel(AttnBwdArgs a) {
           bbf16x8 tp[NP];
 #pragma unroll
           for (int q = 0; q < NP; ++q) tp[q] = *reinterpret_cast<const bbf16x8*>(Kt + dim * TREC + q * KC * 2 + soff);
-          mfma_pieces<NP>(dqacc[dt], tp, dsp);
+          mfma_pieces<NP, PF>(dqacc[dt], tp, dsp);
         }
       }
     }
@@ -282,13 +282,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_split_kernel(AttnBwdArgs a) {
   }
 }
 
-template <int D, int NP>
+template <int D, int NP, int PF = 0>
 int launch_dq_split(const AttnBwdArgs& a, hipStream_t st) {
   constexpr size_t lds_bytes = DqCfg<D, NP>::lds_bytes;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_split_kernel<D, NP>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_split_kernel<D, NP, PF>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e != hipSuccess) { paif::set_error("sr_attention_bwd(dq split): LDS %zu: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
-  hipLaunchKernelGGL((attn_bwd_dq_split_kernel<D, NP>), dim3((a.N + 255) / 256, a.heads, a.B), dim3(512), lds_bytes, st, a);
+  hipLaunchKernelGGL((attn_bwd_dq_split_kernel<D, NP, PF>), dim3((a.N + 255) / 256, a.heads, a.B), dim3(512), lds_bytes, st, a);
   return 0;
 }
 
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(64 * KG_TILES) void attn_bwd_dkv_kernel(AttnBwdArgs
 // S = Q . K^T and dP = dO . V^T) and transposed with the query-slot permutation (A operands of dK^T += Q^T . dS and
 // dV^T += dO^T . P), so that the P / dS accumulator registers are the B operands as they stand.
 // ---------------------------------------------------------------------------------------------
-template <int D, int NP>
+template <int D, int NP, int PF = 0>
 __global__ __launch_bounds__(64 * KG_TILES) void attn_bwd_dkv_split_kernel(AttnBwdArgs a) {
   constexpr int NO = D / 16, DT = D / 32;
   constexpr int KREC = D * 2 * NP;         // row-major record: NP pieces of D bf16
@@ -437,8 +437,8 @@ __global__ __launch_bounds__(64 * KG_TILES) void attn_bwd_dkv_split_kernel(AttnB
       k8[4 * j] = kv4.x; k8[4 * j + 1] = kv4.y; k8[4 * j + 2] = kv4.z; k8[4 * j + 3] = kv4.w;
       v8[4 * j] = vv4.x; v8[4 * j + 1] = vv4.y; v8[4 * j + 2] = vv4.z; v8[4 * j + 3] = vv4.w;
     }
-    splitN<NP>(k8, kp[o]);
-    splitN<NP>(v8, vp[o]);
+    splitN<NP, PF>(k8, kp[o]);
+    splitN<NP, PF>(v8, vp[o]);
   }
   const bool keyvalid = wave * 32 + p < Nk;
 
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(64 * KG_TILES) void attn_bwd_dkv_split_kernel(AttnB
       const float4 x0 = *reinterpret_cast<const float4*>(src), x1 = *reinterpret_cast<const float4*>(src + 4);
       const float x8[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
       bbf16x8 xp[NP];
-      splitN<NP>(x8, xp);
+      splitN<NP, PF>(x8, xp);
       char* rm = which ? Dr : Qr;
       char* tr = which ? Dt : Qt;
       const int sw = row & (D / 8 - 1);
@@ -499,8 +499,8 @@ __global__ __launch_bounds__(64 * KG_TILES) void attn_bwd_dkv_split_kernel(AttnB
         qp[q] = *reinterpret_cast<const bbf16x8*>(Qr + p * KREC + q * D * 2 + cc);
         dop[q] = *reinterpret_cast<const bbf16x8*>(Dr + p * KREC + q * D * 2 + cc);
       }
-      mfma_pieces<NP>(s, qp, kp[o]);
-      mfma_pieces<NP>(dp, dop, vp[o]);
+      mfma_pieces<NP, PF>(s, qp, kp[o]);
+      mfma_pieces<NP, PF>(dp, dop, vp[o]);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -516,8 +516,8 @@ __global__ __launch_bounds__(64 * KG_TILES) void attn_bwd_dkv_split_kernel(AttnB
 #pragma unroll
       for (int i = 0; i < 8; ++i) { p8[i] = s[8 * s2 + i]; d8[i] = dp[8 * s2 + i]; }
       bbf16x8 pp[NP], dsp[NP];
-      splitN<NP>(p8, pp);
-      splitN<NP>(d8, dsp);
+      splitN<NP, PF>(p8, pp);
+      splitN<NP, PF>(d8, dsp);
       const int soff = (s2 * 16 + 8 * h) * 2;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
@@ -528,8 +528,8 @@ __global__ __launch_bounds__(64 * KG_TILES) void attn_bwd_dkv_split_kernel(AttnB
           op[q] = *reinterpret_cast<const bbf16x8*>(Dt + dim * TREC + q * 64 + soff);
           tp[q] = *reinterpret_cast<const bbf16x8*>(Qt + dim * TREC + q * 64 + soff);
         }
-        mfma_pieces<NP>(dvacc[dt], op, pp);
-        mfma_pieces<NP>(dkacc[dt], tp, dsp);
+        mfma_pieces<NP, PF>(dvacc[dt], op, pp);
+        mfma_pieces<NP, PF>(dkacc[dt], tp, dsp);
       }
     }
   }
@@ -587,7 +587,7 @@ int paif_sr_attention_bwd_input(const float* q, const float* kv, const float* o,
 int paif_sr_attention_bwd_input_p(const float* q, const float* kv, const float* o, const float* dout, const float* lse,
                                   float* delta, float* dq, float* dkv, float* dkv_partial, int B, int N, int Nk, int C, int heads,
                                   int precision, paif_stream_t stream) {
-  PAIF_REQUIRE(precision == 0 || precision == 1 || precision == 3, PAIF_EINVAL, "sr_attention_bwd: precision=%d", precision);
+  PAIF_REQUIRE(precision == 0 || precision == 1 || precision == 3 || precision == 6, PAIF_EINVAL, "sr_attention_bwd: precision=%d", precision);
   PAIF_REQUIRE(q && kv && o && dout && lse && delta && dq && dkv && dkv_partial, PAIF_EINVAL, "sr_attention_bwd: null pointer");
   PAIF_REQUIRE(B > 0 && N > 0 && Nk > 0 && heads > 0 && C % heads == 0, PAIF_EINVAL, "sr_attention_bwd: bad shape");
   const int D = C / heads;
@@ -615,11 +615,12 @@ int paif_sr_attention_bwd_input_p(const float* q, const float* kv, const float* 
       }
       hipLaunchKernelGGL(attn_bwd_dq_kernel<DD>, dim3((N + 255) / 256, heads, B), dim3(512), lds_bytes, st, a);
     } else {
-      const int rc = precision == 3 ? launch_dq_split<DD, 3>(a, st) : launch_dq_split<DD, 2>(a, st);
+      const int rc = precision == 3 ? launch_dq_split<DD, 3>(a, st) : precision == 6 ? launch_dq_split<DD, 2, 1>(a, st) : launch_dq_split<DD, 2>(a, st);
       if (rc) return rc;
     }
     PAIF_LAUNCH_CHECK("sr_attention_bwd(dq)");
     if (precision == 3) hipLaunchKernelGGL((attn_bwd_dkv_split_kernel<DD, 3>), kvgrid, kvblk, 0, st, a);
+    else if (precision == 6) hipLaunchKernelGGL((attn_bwd_dkv_split_kernel<DD, 2, 1>), kvgrid, kvblk, 0, st, a);
     else if (precision == 1) hipLaunchKernelGGL((attn_bwd_dkv_split_kernel<DD, 2>), kvgrid, kvblk, 0, st, a);
     else hipLaunchKernelGGL(attn_bwd_dkv_kernel<DD>, kvgrid, kvblk, 0, st, a);
     return 0;

@@ -224,29 +224,47 @@ template <int F, typename AV, typename BV> __device__ __forceinline__ mf32x16 mf
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
-// v -> NP bf16 pieces: piece 0 = rn(v), piece q = rn(v - the pieces before it).  Two pieces carry 16 significant bits, three 24.
-template <int NP>
+// v -> NP pieces: piece 0 = rn(v), piece q = rn(v - the pieces before it).  PF = 0: bf16 pieces (two carry 16 significant bits, three
+// 24); PF = 1: IEEE fp16 pieces (two carry 22 bits; operands must lie inside fp16's exponent range), kept in the same 16-byte container.
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+template <int PF>
+__device__ __forceinline__ __bf16 piece16(float r, float& back) {
+  if constexpr (PF == 1) {
+    const _Float16 h = (_Float16)r;
+    back = (float)h;
+    return __builtin_bit_cast(__bf16, h);
+  } else {
+    const __bf16 h = (__bf16)r;
+    back = (float)h;
+    return h;
+  }
+}
+template <int NP, int PF = 0>
 __device__ __forceinline__ void splitN(const float (&v)[8], bf16x8_t (&pc)[NP]) {
+  static_assert(PF == 0 || NP == 2, "fp16 pieces come in pairs");
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     float r = v[i];
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
-      const __bf16 hx = (__bf16)r;
-      pc[q][i] = hx;
-      if (q + 1 < NP) r -= (float)hx;
+      float back;
+      pc[q][i] = piece16<PF>(r, back);
+      if (q + 1 < NP) r -= back;
     }
   }
 }
 
-// acc += A . B over the kept piece products, smallest first (gemm_mfma.hip's order): NP = 2 -> a1 b0 + a0 b1 + a0 b0 (2^-16);
-// NP = 3 -> a0 b2 + a2 b0 + a1 b1 + a0 b1 + a1 b0 + a0 b0 (2^-25: fp32-level, the attack loops' arithmetic)
-template <int NP>
+// acc += A . B over the kept piece products, smallest first (gemm_mfma.hip's order): NP = 2 -> a1 b0 + a0 b1 + a0 b0 (2^-16 with bf16
+// pieces, ~2^-21.5 with fp16 pieces); NP = 3 -> a0 b2 + a2 b0 + a1 b1 + a0 b1 + a1 b0 + a0 b0 (2^-25)
+template <int NP, int PF = 0>
 __device__ __forceinline__ void mfma_pieces(f32x16_t& acc, const bf16x8_t (&pa)[NP], const bf16x8_t (&pb)[NP]) {
   constexpr int QA3[6] = {0, 2, 1, 0, 1, 0}, QB3[6] = {2, 0, 1, 1, 0, 0}, QA2[3] = {1, 0, 0}, QB2[3] = {0, 1, 0};
 #pragma unroll
-  for (int qi = 0; qi < (NP == 3 ? 6 : 3); ++qi)
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[NP == 3 ? QA3[qi] : QA2[qi % 3]], pb[NP == 3 ? QB3[qi] : QB2[qi % 3]], acc, 0, 0, 0);
+  for (int qi = 0; qi < (NP == 3 ? 6 : 3); ++qi) {
+    const bf16x8_t x = pa[NP == 3 ? QA3[qi] : QA2[qi % 3]], y = pb[NP == 3 ? QB3[qi] : QB2[qi % 3]];
+    if constexpr (PF == 1) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, x), __builtin_bit_cast(f16x8_t, y), acc, 0, 0, 0);
+    else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc, 0, 0, 0);
+  }
 }
 
 }  // namespace paif

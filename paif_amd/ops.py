@@ -69,7 +69,7 @@ CONFIG = {"conv_precision": "bf16x3", "gemm_precision": os.environ.get("PAIF_GEM
           # sustains under that load -- 400 us per block inside the forward against 355 for the three bandwidth-bound launches
           "rdb_fused": False, "gemm2": False, "gemm_split_min_m": 2048, "attack_bwd_f16x3": {"0": False, "1": True, "gemm": "gemm"}[os.environ.get("PAIF_ATTACK_BWD_F16X3", "1")],
           "attack_grad_scale_log2": (int(os.environ["PAIF_ATTACK_GSCALE"]) if "PAIF_ATTACK_GSCALE" in os.environ else None),
-          "attack_fwd_f16x3": {"0": False, "1": True, "gemm": "gemm"}[os.environ.get("PAIF_ATTACK_FWD_F16X3", "1")], "attn_x6": os.environ.get("PAIF_ATTN_X6", "1") != "0", "gemm_gather": os.environ.get("PAIF_GEMM_GATHER", "1") != "0"}
+          "attack_fwd_f16x3": {"0": False, "1": True, "gemm": "gemm"}[os.environ.get("PAIF_ATTACK_FWD_F16X3", "1")], "attn_x6": os.environ.get("PAIF_ATTN_X6", "1") != "0", "attn_f16x3": os.environ.get("PAIF_ATTN_F16X3", "1") != "0", "gemm_gather": os.environ.get("PAIF_GEMM_GATHER", "1") != "0"}
 # falsy, or the torch dtype (torch.bfloat16 / torch.float16) of the 32-channel maps while an inference forward of the fusion network
 # runs in a 16-bit storage mode (set by the model through `bf16_activations`)
 _ACT_BF16 = [False]
@@ -1086,11 +1086,14 @@ def resize_bilinear_adjoint(dout, coff, C, IH, IW):
 
 def _attn_precision():
     """Arithmetic of the attention products, following the GEMMs: 0 = exact fp32 MFMA under set_gemm_precision("f32") (all gradient-
-    parity tests), 3 = three-piece bf16 splits (fp32-level, six MFMAs per product) inside the attack loops ("bf16x6" / "auto6";
-    CONFIG["attn_x6"] = False keeps the exact kernels there: round 4's form), 1 = split-bf16 (three MFMAs) otherwise."""
+    parity tests), 6 = fp16 pairs (three fp16 MFMAs, ~2^-21.5) where the attack loops run their GEMMs on them ("auto6h"), 3 = three-piece
+    bf16 splits (fp32-level, six MFMAs per product) under "bf16x6" / "auto6" (CONFIG["attn_x6"] = False keeps the exact kernels there:
+    round 4's form), 1 = split-bf16 (three MFMAs) otherwise."""
     g = CONFIG["gemm_precision"]
     if g == "f32":
         return 0
+    if g in ("f16x3", "auto6h") and CONFIG["attn_f16x3"]:
+        return 6
     if g in ("bf16x6", "auto6", "f16x3", "auto6h"):
         return 3 if CONFIG["attn_x6"] else 0
     return 1
@@ -1706,7 +1709,7 @@ def sr_attention(q, kv, heads, want_lse=False):
     out = torch.empty_like(q)
     lse = torch.empty((B, heads, N), device=q.device, dtype=torch.float32) if want_lse else None
     split = _attn_precision()
-    tag = {0: "sr_attention", 1: "sr_attention_bf16x3", 3: "sr_attention_bf16x6"}[split]
+    tag = {0: "sr_attention", 1: "sr_attention_bf16x3", 3: "sr_attention_bf16x6", 6: "sr_attention_f16x3"}[split]
     e0 = TIMER.start(tag) if TIMER is not None else None
     if split:
         _lib.check(lib().paif_sr_attention_split_fwd(_p(q), _p(kv), _p(out), _p(lse), B, N, Nk, C, heads, split, _stream()), "sr_attention")

@@ -58,7 +58,8 @@ def test_sr_attention_forward_backward_at_480x640_token_counts(B, N, Nk, C, head
     prev = ops.CONFIG["gemm_precision"]
     try:
         # "auto6" = the attack loops' arithmetic: three bf16 pieces per operand, six products (2^-25) -- held to the exact kernels' bounds
-        for mode, tol_out, tol_grad in (("f32", 2e-6, 2e-5), ("auto", 3e-5, 1e-4), ("auto6", 2e-6, 2e-5)):
+        # "auto6h" = fp16 pairs (two 11-bit pieces, three MFMAs): the arithmetic the attack loops run since round 5, same bounds
+        for mode, tol_out, tol_grad in (("f32", 2e-6, 2e-5), ("auto", 3e-5, 1e-4), ("auto6", 2e-6, 2e-5), ("auto6h", 2e-6, 2e-5)):
             ops.set_gemm_precision(mode)
             timer = ops.KernelTimer(lambda tag: tag.startswith("sr_attention"))
             ops.TIMER = timer
@@ -67,7 +68,7 @@ def test_sr_attention_forward_backward_at_480x640_token_counts(B, N, Nk, C, head
             finally:
                 ops.TIMER = None
             torch.cuda.synchronize()
-            assert list(timer.summary()) == [{"f32": "sr_attention", "auto": "sr_attention_bf16x3", "auto6": "sr_attention_bf16x6"}[mode]]   # the entry point taken
+            assert list(timer.summary()) == [{"f32": "sr_attention", "auto": "sr_attention_bf16x3", "auto6": "sr_attention_bf16x6", "auto6h": "sr_attention_f16x3"}[mode]]   # the entry point taken
             dq, dkv = ops.sr_attention_bwd(qd, kvd, out, dout.to(dev), lse, heads)
             assert maxabs(out.cpu().double(), ref.detach()) <= tol_out * float(ref.abs().max()), (mode, B, N, Nk, C, heads)
             for mine, r in ((dq, q64.grad), (dkv, kv64.grad)):
@@ -76,7 +77,7 @@ def test_sr_attention_forward_backward_at_480x640_token_counts(B, N, Nk, C, head
         ops.set_gemm_precision(prev)
 
 
-@pytest.mark.parametrize("mode,tol_out,tol_grad", [("auto", 3e-5, 1e-4), ("auto6", 2e-6, 2e-5)])
+@pytest.mark.parametrize("mode,tol_out,tol_grad", [("auto", 3e-5, 1e-4), ("auto6", 2e-6, 2e-5), ("auto6h", 2e-6, 2e-5)])
 def test_sr_attention_split_forms_chunk_any_key_count(mode, tol_out, tol_grad):
     """More keys than one LDS chunk holds (700 at head dim 64: three chunks with two pieces, five with three; the backward's dq kernel
     five / six): the online softmax carries over chunk boundaries, the backward's chunks are independent.  The exact kernels keep all
@@ -258,7 +259,7 @@ def test_sr_attention_seeded_shape_sweep():
             attn = ((qh @ kvh[0].transpose(-2, -1)) * hd ** -0.5).softmax(dim=-1)
             ref = (attn @ kvh[1]).transpose(1, 2).reshape(B, N, C)
             (ref * dout.double()).sum().backward()
-            for mode, tol_out, tol_grad in (("f32", 3e-6, 3e-5), ("auto", 4e-5, 2e-4), ("auto6", 3e-6, 3e-5)):
+            for mode, tol_out, tol_grad in (("f32", 3e-6, 3e-5), ("auto", 4e-5, 2e-4), ("auto6", 3e-6, 3e-5), ("auto6h", 3e-6, 3e-5)):
                 ops.set_gemm_precision(mode)
                 out, lse = ops.sr_attention(q.to(dev), kv.to(dev), heads, want_lse=True)
                 dq, dkv = ops.sr_attention_bwd(q.to(dev), kv.to(dev), out, dout.to(dev), lse, heads)
