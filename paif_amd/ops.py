@@ -67,7 +67,7 @@ CONFIG = {"conv_precision": "bf16x3", "gemm_precision": os.environ.get("PAIF_GEM
           # 16-bit inference forward: a ResidualDenseBlock (k = 3, dilation 1) as ONE kernel (csrc/rdb_fused.hip) on maps of >= 512 tiles.
           # OFF by default: correct (tests/test_f16_storage_gpu.py) and 2 map passes instead of 9, but matrix-pipe bound at the clock the chip
           # sustains under that load -- 400 us per block inside the forward against 355 for the three bandwidth-bound launches
-          "rdb_fused": False, "gemm2": False, "gemm_split_min_m": 2048, "attack_bwd_f16x3": {"0": False, "1": True, "gemm": "gemm"}[os.environ.get("PAIF_ATTACK_BWD_F16X3", "1")],
+          "rdb_fused": False, "gemm2": False, "gemm_split_min_m": 2048, "f16x3_min_k": int(os.environ.get("PAIF_F16X3_MIN_K", "32")), "attack_bwd_f16x3": {"0": False, "1": True, "gemm": "gemm"}[os.environ.get("PAIF_ATTACK_BWD_F16X3", "1")],
           "attack_grad_scale_log2": (int(os.environ["PAIF_ATTACK_GSCALE"]) if "PAIF_ATTACK_GSCALE" in os.environ else None),
           "attack_fwd_f16x3": {"0": False, "1": True, "gemm": "gemm"}[os.environ.get("PAIF_ATTACK_FWD_F16X3", "1")], "attn_x6": os.environ.get("PAIF_ATTN_X6", "1") != "0", "attn_f16x3": os.environ.get("PAIF_ATTN_F16X3", "1") != "0", "gemm_gather": os.environ.get("PAIF_GEMM_GATHER", "1") != "0"}
 # falsy, or the torch dtype (torch.bfloat16 / torch.float16) of the 32-channel maps while an inference forward of the fusion network
@@ -1016,8 +1016,9 @@ def gemm(a, w, scale=None, shift=None, act=ACT_NONE, res=None, out=None, out_col
         prec = "bf16x3" if (K >= 256 and M >= CONFIG["gemm_split_min_m"]) else "f32"
     elif prec == "auto6":  # the attack loops: three-piece splits (fp32-level parity) where the exact GEMM is matrix-pipe bound
         prec = "bf16x6" if (K >= 256 and M >= CONFIG["gemm_split_min_m"]) else "f32"
-    elif prec == "auto6h":  # the attack loops' FORWARD passes: fp16 pairs (22 bits per operand, three MFMAs) there instead
-        prec = "f16x3" if (K >= 256 and M >= CONFIG["gemm_split_min_m"]) else "f32"
+    elif prec == "auto6h":  # the attack loops since round 5: fp16 pairs (22 bits per operand, three MFMAs) -- for every k extent: at a
+        # fifth of the exact MFMA's matrix-pipe time the short-k GEMMs are faster on them too (CONFIG["f16x3_min_k"])
+        prec = "f16x3" if (K >= CONFIG["f16x3_min_k"] and M >= CONFIG["gemm_split_min_m"]) else "f32"
     tag = "gemm_mfma_%s" % prec
     e0 = TIMER.start(tag) if TIMER is not None else None
     nt = 0
@@ -1665,7 +1666,7 @@ def conv_gemm(x, wp, k, stride, pad, shift=None, scale=None, act=ACT_NONE):
     elif prec == "auto6":
         prec = "bf16x6" if (K >= 256 and M >= CONFIG["gemm_split_min_m"]) else "f32"
     elif prec == "auto6h":
-        prec = "f16x3" if (K >= 256 and M >= CONFIG["gemm_split_min_m"]) else "f32"
+        prec = "f16x3" if (K >= CONFIG["f16x3_min_k"] and M >= CONFIG["gemm_split_min_m"]) else "f32"
     split_form = prec in ("bf16x3", "bf16x6", "f16x3") and Cin % 32 == 0 and kpad == K
     exact_form = prec == "f32" and kpad <= 160 and kpad == (K + 31) // 32 * 32      # element-wise gather, any Cin (the 3-channel patch embed)
     if not CONFIG["gemm_gather"] or not (split_form or exact_form):
