@@ -136,6 +136,8 @@ def _attack_loop(model, X_vis, X_ir, label, lab64, epsilon, alpha, attack_iters,
                     ops.pgd_step_(d_vis, g_vis, X_vis, alpha, epsilon)
             if trace is not None:
                 trace.append(dict(loss=float(loss.detach()), g_ir=g_ir.clone(), g_vis=g_vis.clone()))
+    if fast:
+        ops.check_attack_range(g_ir, g_vis)      # fp16 pairs: an operand outside fp16's exponent range shows up here, loudly
     # the reference returns Variables that carry the accumulated .grad
     d_ir.requires_grad_(True)
     d_vis.requires_grad_(True)

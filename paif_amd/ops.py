@@ -195,6 +195,26 @@ class attack_backward_arithmetic:
         CONFIG["gemm_precision"], CONFIG["conv_precision"] = self.old
 
 
+def check_attack_range(*grads):
+    """The fp16-pair arithmetic of the attack loops needs every matrix operand inside fp16's exponent range (|v| < 65504): activations
+    are, by orders of magnitude, and the scaled gradients are for any sane model -- but nothing in the kernels enforces it, and an
+    overflow becomes inf / NaN in the accumulated input gradient.  One reduction + host read per attack call (skipped while a hipGraph
+    is being captured: run one eager call first); raises with the way out instead of returning a garbage perturbation."""
+    if not (CONFIG["attack_fwd_f16x3"] or CONFIG["attack_bwd_f16x3"]) or CONFIG.get("attack_precision", "bf16x6") != "bf16x6":
+        return
+    if torch.cuda.is_current_stream_capturing():
+        return
+    ok = None
+    for g in grads:
+        f = torch.isfinite(g).all()
+        ok = f if ok is None else ok & f
+    if ok is not None and not bool(ok):
+        raise FloatingPointError("attack loop: non-finite input gradient -- an operand left fp16's exponent range in the fp16-pair arithmetic "
+                                 "(CONFIG['attack_grad_scale_log2'] = %r).  Lower that scale, or run the loop on three-piece bf16 splits: "
+                                 "ops.CONFIG.update(attack_fwd_f16x3=False, attack_bwd_f16x3=False, attn_f16x3=False)"
+                                 % (CONFIG["attack_grad_scale_log2"],))
+
+
 def attack_grad_scale(label):
     """The power of two the attack loops scale the reverse pass by (1.0 when the reverse pass stays on three-piece bf16 splits)."""
     if not CONFIG["attack_bwd_f16x3"] or CONFIG.get("attack_precision", "bf16x6") != "bf16x6":

@@ -155,3 +155,34 @@ def test_attack_forward_arithmetic_switches_only_the_forward():
     ops.CONFIG["attack_fwd_f16x3"] = True
     with ops.attack_arithmetic(), ops.attack_forward_arithmetic():
         assert (ops.CONFIG["conv_precision"], ops.CONFIG["gemm_precision"]) == ("f32", "f32")
+
+
+def test_attack_loop_reports_an_fp16_range_overflow_instead_of_returning_garbage():
+    """A gradient scale far too large (2^60 instead of ~2^9 at this size) pushes the scaled gradients past 65504: the loop raises and
+    names the switches; with the product scale the same call returns a finite perturbation inside the eps-ball."""
+    from paif_amd import synthetic as S
+    from paif_amd.attack.attack import attack_both
+    from paif_amd.core.model_fusion_auto import Network_MM_Searched
+    from paif_amd.genotypes import FUSION_AT
+    from tests import helpers as Hh
+    from tests.helpers import t
+
+    dev = _dev()
+    m = Network_MM_Searched(32, FUSION_AT, None, None, "mit_b0", num_classes=9).eval()
+    S.load_formula_weights(m, head=Hh.HEAD64["mit_b0"])
+    m = m.to(dev)
+    ir, vis, lab = S.make_batch(2, 64, 96)
+    args = (m, t(vis).to(dev), t(ir).to(dev), t(lab).to(dev))
+    kw = dict(epsilon=8 / 255., alpha=2 / 255., attack_iters=2, attack_loss="l_seg", attack_way="PGD",
+              delta0_ir=t(S.make_delta0(1, ir.shape, 8 / 255.)).to(dev), delta0_vis=t(S.make_delta0(2, vis.shape, 8 / 255.)).to(dev))
+    with torch.no_grad():
+        d_ir, d_vis = attack_both(*args, **kw)
+    assert bool(torch.isfinite(d_ir).all()) and float(d_ir.abs().max()) <= 8 / 255. + 1e-7
+    ops.CONFIG["attack_grad_scale_log2"] = 60
+    with torch.no_grad(), pytest.raises(FloatingPointError, match="fp16's exponent range"):
+        attack_both(*args, **kw)
+    ops.CONFIG["attack_grad_scale_log2"] = None
+    ops.CONFIG.update(attack_fwd_f16x3=False, attack_bwd_f16x3=False, attn_f16x3=False)      # the way out the message names
+    with torch.no_grad():
+        d2_ir, _ = attack_both(*args, **kw)
+    assert float((d2_ir != d_ir).float().mean()) <= 2e-3                       # same trajectory up to near-zero gradient elements
