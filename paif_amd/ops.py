@@ -1687,6 +1687,8 @@ def conv_gemm(x, wp, k, stride, pad, shift=None, scale=None, act=ACT_NONE):
         prec = "bf16x6" if (K >= 256 and M >= CONFIG["gemm_split_min_m"]) else "f32"
     elif prec == "auto6h":
         prec = "f16x3" if (K >= CONFIG["f16x3_min_k"] and M >= CONFIG["gemm_split_min_m"]) else "f32"
+    if Cin % 32 != 0 and kpad <= 160 and prec == "f16x3" and CONFIG["gemm_precision"] == "auto6h":
+        prec = "f32"      # the 3-channel patch embed inside an attack loop: the exact gathered form beats im2col + a split GEMM
     split_form = prec in ("bf16x3", "bf16x6", "f16x3") and Cin % 32 == 0 and kpad == K
     exact_form = prec == "f32" and kpad <= 160 and kpad == (K + 31) // 32 * 32      # element-wise gather, any Cin (the 3-channel patch embed)
     if not CONFIG["gemm_gather"] or not (split_form or exact_form):
