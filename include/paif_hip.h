@@ -353,6 +353,13 @@ int paif_gemm_conv_fwd(const float* x, int B, int H, int W, int Cin, int k, int 
                        const float* scale, const float* shift, int act, const float* res, int ldres, float* out, int ldc,
                        int N, int precision, int splits, float* workspace, paif_stream_t stream);
 
+/* The input gradient of a NON-OVERLAPPING strided conv (Attention.sr, core/mix_transformer.py:74: kernel = stride = sr_ratio) as ONE GEMM:
+ * paif_gemm_fwd(dY, Wt) + paif_col2im_fwd with the col2im done by the GEMM epilogue's addresses (every column of the [M, sr*sr*C]
+ * product lands on exactly one input pixel); bit-identical to that pair.  dY [B*(H/sr)*(W/sr), >= K] row stride lda; Wt [sr*sr*C, K]
+ * (the transposed packed conv weight); dx [B,H,W,C]; H, W multiples of sr (PAIF_ENOSUP otherwise).  precision as paif_gemm_fwd. */
+int paif_gemm_col2im_fwd(const float* dY, int lda, const float* Wt, float* dx, int B, int H, int W, int C, int sr, int K,
+                         int precision, paif_stream_t stream);
+
 /* Wide-tile form of the split-bf16 paif_gemm_fwd (csrc/gemm_split2.hip) for the same nn.Linear sites (core/mix_transformer.py:22-25,
  * 66-69,74; core/segformer_head.py:19): workgroup tile 128 x 64*nt, wave tile 64 x 32*nt.  paif_gemm2_plan returns nt (1, 2, 4 or 5
  * column tiles per wave) for a shape it is built for, 0 otherwise (the caller then takes paif_gemm_fwd).  precision: PAIF_CONV_BF16X3 or

@@ -82,6 +82,7 @@ SIGNATURES = {
     "paif_gemm_fwd": (c_int, [F, c_int, F, F, F, c_int, F, c_int, F, c_int, c_int, c_int, c_int, c_int, F]),
     "paif_gemm_splitk_plan": (c_int, [c_int, c_int, c_int]),
     "paif_gemm_conv_fwd": (c_int, [F, c_int, c_int, c_int, c_int, c_int, c_int, c_int, F, F, F, c_int, F, c_int, F, c_int, c_int, c_int, c_int, F, F]),
+    "paif_gemm_col2im_fwd": (c_int, [F, c_int, F, F, c_int, c_int, c_int, c_int, c_int, c_int, c_int, F]),
     "paif_gemm2_plan": (c_int, [c_int, c_int, c_int, c_int]),
     "paif_gemm2_packed_bytes": (c_size_t, [c_int, c_int, c_int]),
     "paif_gemm2_pack_weight": (c_int, [F, F, c_int, c_int, c_int, F]),

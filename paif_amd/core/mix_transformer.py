@@ -219,8 +219,7 @@ class Attention(nn.Module):
             d_sr = ops.layernorm_bwd(tape["x_sr"], self.norm.weight, d_xkv, self.norm.eps)
             if wgrad:   # the SR conv's im2col columns are rebuilt from the saved input (cheaper than keeping them)
                 _conv_as_gemm_wgrad(self.sr, d_sr, ops.im2col(tape["x"].view(B, H, W, C), sr, sr, 0, wsr.shape[1]))
-            d_col = ops.gemm(d_sr, wsrt)
-            d_xkv = ops.col2im(d_col, B, H, W, C, sr, sr, 0).view(B, N, C)
+            d_xkv = ops.gemm_col2im(d_sr.reshape(-1, d_sr.shape[-1]), wsrt, B, H, W, C, sr).view(B, N, C)   # col2im by the GEMM epilogue's addresses
         return ops.gemm(dq, qt, res=d_xkv)
 
 

@@ -33,7 +33,18 @@ struct GemmArgs {
   // GATHER form (paif_gemm_conv_fwd): A is an NHWC map [gB, gH, gW, gC]; row m = output pixel (b, oy, ox) of a gk x gk conv with
   // stride gs and padding gpad, column index (ky * gk + kx) * gC + c -- the im2col matrix, never materialised
   int gk, gs, gpad, gH, gW, gC, gOH, gOW;
+  // SCATTER form (paif_gemm_col2im_fwd): C is an NHWC map [B, sH, sW, sC]; row m = patch (b, oy, ox) of a NON-OVERLAPPING sk x sk / stride sk
+  // tiling, column n = (ky * sk + kx) * sC + c -- the col2im of the dgrad GEMM's output, written by the epilogue (0 = off)
+  int sk, sH, sW, sC, sOH, sOW;
 };
+
+// address of output element (m, n): row-major, or its pixel / channel in the SCATTER form (n .. n + 3 share a tap: sC % 4 == 0)
+__device__ __forceinline__ float* c_addr(const GemmArgs& a, int m, int n) {
+  if (!a.sk) return a.C + (size_t)m * a.ldc + n;
+  const int ox = m % a.sOW, t = m / a.sOW, oy = t % a.sOH, b = t / a.sOH;
+  const int tap = n / a.sC, cc = n - tap * a.sC, ky = tap / a.sk, kx = tap - ky * a.sk;
+  return a.C + ((size_t)(b * a.sH + oy * a.sk + ky) * a.sW + ox * a.sk + kx) * a.sC + cc;
+}
 
 __device__ __forceinline__ float gelu_erf(float x) { return paif::gelu_erf_fast(x); }   // paif_common.h: x * Phi(x), one polynomial + v_exp_f32
 
@@ -86,7 +97,7 @@ __device__ __forceinline__ void gemm_finish(const GemmArgs& a, const f32x16 (&ac
         if (a.act == 1) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
         else if (a.act == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         if (a.res) { v.x += rv[it].x; v.y += rv[it].y; v.z += rv[it].z; v.w += rv[it].w; }
-        if (nok && m < a.M) *reinterpret_cast<float4*>(a.C + (size_t)m * a.ldc + n) = v;
+        if (nok && m < a.M) *reinterpret_cast<float4*>(c_addr(a, m, n)) = v;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the tile's reads are done before the next one is parked
     }
@@ -113,7 +124,7 @@ __device__ __forceinline__ void gemm_finish(const GemmArgs& a, const f32x16 (&ac
         if (a.act == 1) v = gelu_erf(v);
         else if (a.act == 2) v = fmaxf(v, 0.f);
         if (a.res) v += rv[r];
-        a.C[(size_t)m * a.ldc + n] = v;
+        *c_addr(a, m, n) = v;
       }
     }
   }
@@ -589,7 +600,7 @@ extern "C" int paif_gemm_masked_fwd(const float* A, int lda, const float* a_mask
   PAIF_REQUIRE(lda >= K && ldc >= N && (lda % 4) == 0, PAIF_EINVAL, "gemm: bad leading dimensions lda=%d ldc=%d", lda, ldc);
   PAIF_REQUIRE(act >= 0 && act <= 2, PAIF_EINVAL, "gemm: act=%d", act);
   GemmArgs a;
-  a.gk = 0;
+  a.gk = 0; a.sk = 0;
   a.a_mask = a_mask; a.a_scale = a_scale;
   a.A = A; a.W = W; a.scale = scale; a.shift = shift; a.res = res; a.C = C;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldres = res ? ldres : 0; a.act = act;
@@ -658,7 +669,7 @@ extern "C" int paif_gemm_splitk_fwd_p(const float* A, int lda, const float* W, c
   PAIF_REQUIRE(lda >= K && ldc >= N && (lda % 4) == 0, PAIF_EINVAL, "gemm_splitk: bad leading dimensions lda=%d ldc=%d", lda, ldc);
   PAIF_REQUIRE(act >= 0 && act <= 2, PAIF_EINVAL, "gemm_splitk: act=%d", act);
   GemmArgs a;
-  a.gk = 0;
+  a.gk = 0; a.sk = 0;
   a.a_mask = nullptr; a.a_scale = nullptr;
   a.A = A; a.W = W; a.scale = nullptr; a.shift = nullptr; a.res = nullptr; a.C = C;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldres = 0; a.act = 0;
@@ -715,6 +726,7 @@ extern "C" int paif_gemm_conv_fwd(const float* x, int B, int H, int W, int Cin, 
   a.tilesN = (N + BN - 1) / BN;
   a.nblk = a.tilesN * ((M + BM - 1) / BM);
   a.kper = K / splits;
+  a.sk = 0;
   a.gk = k; a.gs = stride; a.gpad = pad; a.gH = H; a.gW = W; a.gC = Cin; a.gOH = OH; a.gOW = OW;
   hipStream_t st = paif::as_stream(stream);
   if (splits > 1) {
@@ -736,5 +748,38 @@ extern "C" int paif_gemm_conv_fwd(const float* x, int B, int H, int W, int Cin, 
                        res ? ldres : 0, out, ldc, M, N);
     PAIF_LAUNCH_CHECK("gemm_conv_reduce");
   }
+  return 0;
+}
+
+// The dgrad of a NON-OVERLAPPING strided conv (Attention.sr core/mix_transformer.py:74: kernel = stride = sr_ratio) as ONE GEMM:
+// d_col[M, sr*sr*C] = dY[M, K] . Wt[sr*sr*C, K]^T with the col2im of paif_col2im_fwd done by the epilogue's addresses -- every
+// column lands on exactly one input pixel.  dx [B,H,W,C] (H, W multiples of sr: every pixel is written); bit-identical to
+// paif_gemm_fwd + paif_col2im_fwd.  precision: any of paif_gemm_fwd's.
+extern "C" int paif_gemm_col2im_fwd(const float* dY, int lda, const float* Wt, float* dx, int B, int H, int W, int C, int sr, int K,
+                                    int precision, paif_stream_t stream) {
+  PAIF_REQUIRE(precision == 0 || precision == 1 || precision == 3 || precision == 6, PAIF_EINVAL, "gemm_col2im: precision=%d", precision);
+  PAIF_REQUIRE(dY && Wt && dx, PAIF_EINVAL, "gemm_col2im: null pointer");
+  PAIF_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && sr >= 1 && K > 0, PAIF_EINVAL, "gemm_col2im: bad shape");
+  PAIF_REQUIRE(H % sr == 0 && W % sr == 0, PAIF_ENOSUP, "gemm_col2im: %dx%d is not a multiple of the stride %d (pixels without a patch: use paif_col2im_fwd)", H, W, sr);
+  PAIF_REQUIRE(C % 4 == 0 && K % 32 == 0 && lda >= K && (lda % 4) == 0 && (uintptr_t)dx % 16 == 0, PAIF_EINVAL, "gemm_col2im: C=%d K=%d lda=%d", C, K, lda);
+  const int OH = H / sr, OW = W / sr, M = B * OH * OW, N = sr * sr * C;
+  PAIF_REQUIRE((size_t)M * lda < ((size_t)1 << 32) && (size_t)N * K < ((size_t)1 << 32), PAIF_ENOSUP, "gemm_col2im: operands exceed the 32-bit element offsets");
+  GemmArgs a;
+  a.gk = 0;
+  a.a_mask = nullptr; a.a_scale = nullptr;
+  a.A = dY; a.W = Wt; a.scale = nullptr; a.shift = nullptr; a.res = nullptr; a.C = dx;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = N; a.ldres = 0; a.act = 0;
+  a.tilesN = (N + BN - 1) / BN;
+  a.nblk = a.tilesN * ((M + BM - 1) / BM);
+  a.kper = K; a.partial = nullptr; a.wide = 1;
+  a.sk = sr; a.sH = H; a.sW = W; a.sC = C; a.sOH = OH; a.sOW = OW;
+  const dim3 grid(a.nblk), blk(256);
+  hipStream_t st = paif::as_stream(stream);
+  if (precision == 3) hipLaunchKernelGGL((gemm_mfma_bf16x3<false, 3>), grid, blk, 0, st, a);
+  else if (precision == 6) hipLaunchKernelGGL((gemm_mfma_bf16x3<false, 2, false, 1>), grid, blk, 0, st, a);
+  else if (precision == 1) hipLaunchKernelGGL(gemm_mfma_bf16x3<false>, grid, blk, 0, st, a);
+  else if (K <= 160) hipLaunchKernelGGL(gemm_mfma_f32_serial<false>, grid, blk, 0, st, a);
+  else hipLaunchKernelGGL(gemm_mfma_f32<false>, grid, blk, 0, st, a);
+  PAIF_LAUNCH_CHECK("gemm_col2im");
   return 0;
 }

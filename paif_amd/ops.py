@@ -1096,6 +1096,34 @@ def col2im(dcol, B, H, W, Cin, k, stride, pad):
     return dx
 
 
+def gemm_col2im(dy, wt, B, H, W, C, sr):
+    """Input gradient of a non-overlapping sr x sr / stride-sr conv (Attention.sr): dy [B*(H/sr)*(W/sr), K] . wt [sr*sr*C, K]^T scattered
+    to dx [B,H,W,C] by the GEMM's epilogue (paif_gemm_col2im_fwd) -- bit-identical to gemm + col2im, which it falls back to on maps
+    whose size is not a multiple of sr (pixels without a patch must be zeroed) or with CONFIG["gemm_gather"] off."""
+    K = dy.shape[-1]
+    N = wt.shape[0]
+    assert N == sr * sr * C and wt.shape[1] == K
+    M = dy.numel() // K
+    if not CONFIG["gemm_gather"] or H % sr or W % sr or C % 4:
+        return col2im(gemm(dy, wt), B, H, W, C, sr, sr, 0)
+    assert M == B * (H // sr) * (W // sr)
+    prec = CONFIG["gemm_precision"]
+    big = M >= CONFIG["gemm_split_min_m"]
+    if prec == "auto":
+        prec = "bf16x3" if (K >= 256 and big) else "f32"
+    elif prec == "auto6":
+        prec = "bf16x6" if (K >= 256 and big) else "f32"
+    elif prec == "auto6h":
+        prec = "f16x3" if (K >= CONFIG["f16x3_min_k"] and big) else "f32"
+    dx = torch.empty((B, H, W, C), device=dy.device, dtype=torch.float32)
+    tag = "gemm_mfma_%s" % prec
+    e0 = TIMER.start(tag) if TIMER is not None else None
+    _lib.check(lib().paif_gemm_col2im_fwd(_p(dy), K, _p(wt), _p(dx), B, H, W, C, sr, K, _PREC_CODE[prec], _stream()), "gemm_col2im")
+    if e0 is not None:
+        TIMER.stop(tag, e0, 2 * M * N * K, 4 * (M * K + N * K + M * N))
+    return dx
+
+
 def resize_bilinear_adjoint(dout, coff, C, IH, IW):
     """dout [B,OH,OW,ldo] -> dx [B,IH,IW,C] (adjoint of resize_bilinear_into on channels [coff,coff+C))."""
     B, OH, OW, ldo = dout.shape

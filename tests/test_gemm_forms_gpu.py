@@ -165,3 +165,27 @@ def test_wide_tile_gemm_pack_follows_weight_updates():
     del w
     import gc
     gc.collect()
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3", "bf16x6", "f16x3"])
+@pytest.mark.parametrize("case", [(2, 64, 96, 64, 8), (3, 32, 48, 128, 4), (9, 30, 40, 320, 2), (1, 16, 24, 32, 2), (2, 30, 41, 64, 2)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_gemm_col2im_scatter_bit_identical_to_gemm_then_col2im(case, prec):
+    """The input gradient of the spatial-reduction conv (kernel = stride = sr_ratio, core/mix_transformer.py:74): the col2im done by the
+    dgrad GEMM's epilogue addresses (`paif_gemm_col2im_fwd`) against `ops.gemm` + `ops.col2im`; the last case (W not a multiple of sr)
+    takes the pair itself."""
+    B, H, W, C, sr = case
+    g = torch.Generator().manual_seed(sum(case))
+    M = B * ((H - sr) // sr + 1) * ((W - sr) // sr + 1)
+    dy = torch.randn(M, C, generator=g).to(_dev())
+    wt = (torch.randn(sr * sr * C, C, generator=g) * 0.05).to(_dev())
+    with _cfg(gemm_precision=prec, gemm_gather=False):
+        ref = ops.gemm_col2im(dy, wt, B, H, W, C, sr)
+    with _cfg(gemm_precision=prec, gemm_gather=True):
+        got = ops.gemm_col2im(dy, wt, B, H, W, C, sr)
+    assert got.shape == ref.shape == (B, H, W, C) and torch.equal(got, ref)
+    if H % sr == 0 and W % sr == 0:          # and the definition: the transposed conv of the gradient, float64 on the host
+        want = torch.nn.functional.conv_transpose2d(dy.cpu().double().view(B, H // sr, W // sr, C).permute(0, 3, 1, 2),
+                                                    wt.cpu().double().view(sr, sr, C, C).permute(3, 2, 0, 1), stride=sr).permute(0, 2, 3, 1)
+        err = float((got.cpu().double() - want).abs().max() / want.abs().max())
+        assert err <= (3e-5 if prec == "bf16x3" else 3e-6), err
