@@ -582,6 +582,11 @@ int paif_conv2d_wgrad(const float* const* src, int nsrc, const float* dout, cons
 int paif_gemm_wgrad_splits(int M, int N, int K);
 int paif_gemm_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, float* db, int M, int N, int K, int splits,
                     float* workspace, int accumulate, paif_stream_t stream);
+/* Same with the arithmetic selectable: precision PAIF_CONV_F32 = paif_gemm_wgrad (exact fp32 MFMA); PAIF_CONV_F16X3 = fp16 pairs (dY and x
+ * as two IEEE fp16 pieces each, three fp16 MFMAs per 16 tokens instead of eight fp32 ones), dY multiplied by the exact power of two gscale
+ * before the split and the result by its inverse: |dY| * gscale and |x| must stay below 65504. */
+int paif_gemm_wgrad_p(const float* dy, int lddy, const float* x, int ldx, float* dw, float* db, int M, int N, int K, int splits,
+                      float* workspace, int accumulate, int precision, float gscale, paif_stream_t stream);
 
 /* LayerNorm affine gradients: dgamma[c] = sum_rows dy * xhat, dbeta[c] = sum_rows dy (x, dy [M, C] dense).
  * workspace: paif_layernorm_wgrad_blocks(M) * 2 * C floats (per-workgroup partials, summed in block order). */

@@ -91,6 +91,7 @@ SIGNATURES = {
     "paif_conv2d_wgrad": (c_int, [POINTER(c_void_p), c_int, F, F, F, F, c_int, c_float, c_int, c_int, F, F, c_int, c_int, c_int, c_int, c_int, F]),
     "paif_gemm_wgrad_splits": (c_int, [c_int, c_int, c_int]),
     "paif_gemm_wgrad": (c_int, [F, c_int, F, c_int, F, F, c_int, c_int, c_int, c_int, F, c_int, F]),
+    "paif_gemm_wgrad_p": (c_int, [F, c_int, F, c_int, F, F, c_int, c_int, c_int, c_int, F, c_int, c_int, c_float, F]),
     "paif_layernorm_wgrad_blocks": (c_int, [c_int]),
     "paif_layernorm_wgrad": (c_int, [F, F, F, F, F, c_int, c_int, c_float, c_int, F]),
     "paif_channel_affine_nchw_fwd": (c_int, [F, F, F, F, c_int, c_int, c_int, c_int, F]),

@@ -774,7 +774,11 @@ class _CompositeFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_fused, d_seg):
         d32 = ops.nchw_to_nhwc_pad(d_seg, 32)
-        d_ir, d_vis = ctx.module.backward_taped(d32, ctx.tape, d_fused.contiguous(), ctx.wgrad)
+        if ctx.wgrad:      # the training step: weight-gradient GEMMs on fp16 pairs, dY scaled by ~ the pixel count inside the kernels
+            with ops.wgrad_scale(d_fused.numel()):
+                d_ir, d_vis = ctx.module.backward_taped(d32, ctx.tape, d_fused.contiguous(), ctx.wgrad)
+        else:
+            d_ir, d_vis = ctx.module.backward_taped(d32, ctx.tape, d_fused.contiguous(), ctx.wgrad)
         ctx.tape = None
         return d_ir, d_vis, None, None, None, None
 

@@ -67,7 +67,7 @@ CONFIG = {"conv_precision": "bf16x3", "gemm_precision": os.environ.get("PAIF_GEM
           # 16-bit inference forward: a ResidualDenseBlock (k = 3, dilation 1) as ONE kernel (csrc/rdb_fused.hip) on maps of >= 512 tiles.
           # OFF by default: correct (tests/test_f16_storage_gpu.py) and 2 map passes instead of 9, but matrix-pipe bound at the clock the chip
           # sustains under that load -- 400 us per block inside the forward against 355 for the three bandwidth-bound launches
-          "rdb_fused": False, "gemm2": False, "gemm_split_min_m": 2048, "f16x3_min_k": int(os.environ.get("PAIF_F16X3_MIN_K", "32")), "attack_bwd_f16x3": {"0": False, "1": True, "gemm": "gemm"}[os.environ.get("PAIF_ATTACK_BWD_F16X3", "1")],
+          "rdb_fused": False, "gemm2": False, "wgrad_f16x3": os.environ.get("PAIF_WGRAD_F16X3", "1") != "0", "_wgrad_scale": None, "gemm_split_min_m": 2048, "f16x3_min_k": int(os.environ.get("PAIF_F16X3_MIN_K", "32")), "attack_bwd_f16x3": {"0": False, "1": True, "gemm": "gemm"}[os.environ.get("PAIF_ATTACK_BWD_F16X3", "1")],
           "attack_grad_scale_log2": (int(os.environ["PAIF_ATTACK_GSCALE"]) if "PAIF_ATTACK_GSCALE" in os.environ else None),
           "attack_fwd_f16x3": {"0": False, "1": True, "gemm": "gemm"}[os.environ.get("PAIF_ATTACK_FWD_F16X3", "1")], "attn_x6": os.environ.get("PAIF_ATTN_X6", "1") != "0", "attn_f16x3": os.environ.get("PAIF_ATTN_F16X3", "1") != "0", "gemm_gather": os.environ.get("PAIF_GEMM_GATHER", "1") != "0"}
 # falsy, or the torch dtype (torch.bfloat16 / torch.float16) of the 32-channel maps while an inference forward of the fusion network
@@ -1248,8 +1248,30 @@ def gemm_wgrad(dy, x, want_bias=True, out_w=None, out_b=None, n=None, k=None, dy
         db = torch.empty(N, device=dy.device, dtype=torch.float32) if want_bias else None
     _p(dy)
     dyp = ctypes.c_void_p(dy.data_ptr() + 4 * dy_col0)
-    _lib.check(L.paif_gemm_wgrad(dyp, lddy, _p(x), ldx, _p(dw), _p(db), M, N, K, splits, _p(ws), int(acc), _stream()), "gemm_wgrad")
+    gs = CONFIG["_wgrad_scale"] if CONFIG["wgrad_f16x3"] else None
+    if gs:      # the training step's reverse pass (wgrad_scale context): fp16 pairs, dY scaled into fp16's exponent range
+        _lib.check(L.paif_gemm_wgrad_p(dyp, lddy, _p(x), ldx, _p(dw), _p(db), M, N, K, splits, _p(ws), int(acc), _PREC_CODE["f16x3"], gs,
+                                       _stream()), "gemm_wgrad")
+    else:
+        _lib.check(L.paif_gemm_wgrad(dyp, lddy, _p(x), ldx, _p(dw), _p(db), M, N, K, splits, _p(ws), int(acc), _stream()), "gemm_wgrad")
     return dw, db
+
+
+class wgrad_scale:
+    """Around the reverse pass of a training step over `pixels` image pixels: the Linear-layer weight-gradient kernels run on fp16 pairs
+    (CONFIG["wgrad_f16x3"]) with dY multiplied by 2^(floor(log2 pixels) - 6) inside the kernel (and the result divided by it): losses
+    averaged over the pixels put |dY| around 1 / pixels, far below fp16's exponent range.  Outside this context (stand-alone calls, the
+    gradient-parity tests of the kernels) the exact fp32-MFMA kernels run."""
+
+    def __init__(self, pixels):
+        self.k = max(0, int(pixels).bit_length() - 1 - 6)
+
+    def __enter__(self):
+        self.old = CONFIG["_wgrad_scale"]
+        CONFIG["_wgrad_scale"] = float(2 ** self.k)
+
+    def __exit__(self, *a):
+        CONFIG["_wgrad_scale"] = self.old
 
 
 def layernorm_wgrad(x, dy, eps, out_g=None, out_b=None):

@@ -186,3 +186,27 @@ def test_attack_loop_reports_an_fp16_range_overflow_instead_of_returning_garbage
     with torch.no_grad():
         d2_ir, _ = attack_both(*args, **kw)
     assert float((d2_ir != d_ir).float().mean()) <= 2e-3                       # same trajectory up to near-zero gradient elements
+
+
+@pytest.mark.parametrize("M,N,K", [(19200, 320, 320), (4097, 64, 256), (2400, 512, 2048), (1000, 9, 256), (5000, 40, 72)])
+def test_gemm_wgrad_f16x3_is_fp32_level_on_gradient_magnitudes(M, N, K):
+    """dW = dY^T X and db = sum dY of a Linear layer (core/mix_transformer.py:22-25) in the fp16-pair arithmetic the training step's
+    reverse pass uses (ops.wgrad_scale): dY of the magnitude a pixel-averaged loss produces (1e-7 ... 1e-5, with a long tail), scaled by
+    a power of two inside the kernel; against float64 and against the exact fp32-MFMA kernel (ragged N / K, accumulation into .grad)."""
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + N)
+    dy = (torch.randn(M, N, generator=g) * 3e-7 * torch.exp(torch.randn(M, 1, generator=g))).to(dev)
+    x = torch.randn(M, K, generator=g).to(dev)
+    refw, refb = dy.double().t() @ x.double(), dy.double().sum(0)
+    w_e, b_e = ops.gemm_wgrad(dy, x)                                   # outside the context: the exact kernel
+    with ops.wgrad_scale(8 * 480 * 640):
+        w_h, b_h = ops.gemm_wgrad(dy, x)
+        acc_w, acc_b = torch.ones(N, K, device=dev), torch.ones(N, device=dev)
+        ops.gemm_wgrad(dy, x, out_w=acc_w, out_b=acc_b)                # accumulating form
+    assert ops.CONFIG["_wgrad_scale"] is None
+    e_e = float((w_e.double() - refw).abs().max() / refw.abs().max())
+    e_h = float((w_h.double() - refw).abs().max() / refw.abs().max())
+    assert e_h <= max(3.0 * e_e, 2e-6), (e_h, e_e)
+    assert not torch.equal(w_h, w_e)                                    # (it is the other kernel)
+    assert float((b_h.double() - refb).abs().max() / refb.abs().max()) <= 2e-6
+    assert float((acc_w - 1.0 - w_h).abs().max()) <= 1e-6 * float(w_h.abs().max()) + 1e-7 and float((acc_b - 1.0 - b_h).abs().max()) <= 1e-7
