@@ -57,6 +57,14 @@ ACT_GELU = 1  # paif_gemm_fwd's act code 1 is GELU (the conv's code 1 is PReLU)
 # and every 1-channel plane stay fp32 (SURVEY hard part 1).  Taped (gradient) passes always run fp32 storage.  Tolerance of this
 # mode: SURVEY 8(d) bf16 clause (max / mean |fused - reference| reported, argmax agreement >= 99.9 %, mIoU within 0.1 pt):
 # tests/test_bf16_storage_gpu.py.
+def _env_switch(name, default="1"):
+    """A/B switch from the environment: 0 / 1, or "gemm" (the GEMMs only) for the attack loops' fp16-pair arithmetic."""
+    v = os.environ.get(name, default)
+    if v not in ("0", "1", "gemm"):
+        raise ValueError("%s=%r: expected 0, 1 or gemm" % (name, v))
+    return {"0": False, "1": True, "gemm": "gemm"}[v]
+
+
 CONFIG = {"conv_precision": "bf16x3", "gemm_precision": os.environ.get("PAIF_GEMM_PRECISION", "auto"), "serpentine": True, "attack_precision": "bf16x6", "storage": "f32",
           # inference forward of the fusion network: run the infrared and the visible stream on two HIP streams (identical results; off by
           # default because per-launch timings -- bench.py's roofline blocks, rocprofv3 averages -- then measure CU sharing, not kernels)
@@ -67,9 +75,9 @@ CONFIG = {"conv_precision": "bf16x3", "gemm_precision": os.environ.get("PAIF_GEM
           # 16-bit inference forward: a ResidualDenseBlock (k = 3, dilation 1) as ONE kernel (csrc/rdb_fused.hip) on maps of >= 512 tiles.
           # OFF by default: correct (tests/test_f16_storage_gpu.py) and 2 map passes instead of 9, but matrix-pipe bound at the clock the chip
           # sustains under that load -- 400 us per block inside the forward against 355 for the three bandwidth-bound launches
-          "rdb_fused": False, "gemm2": False, "wgrad_f16x3": os.environ.get("PAIF_WGRAD_F16X3", "1") != "0", "_wgrad_scale": None, "gemm_split_min_m": 2048, "f16x3_min_k": int(os.environ.get("PAIF_F16X3_MIN_K", "32")), "attack_bwd_f16x3": {"0": False, "1": True, "gemm": "gemm"}[os.environ.get("PAIF_ATTACK_BWD_F16X3", "1")],
+          "rdb_fused": False, "gemm2": False, "wgrad_f16x3": os.environ.get("PAIF_WGRAD_F16X3", "1") != "0", "_wgrad_scale": None, "gemm_split_min_m": 2048, "f16x3_min_k": int(os.environ.get("PAIF_F16X3_MIN_K", "32")), "attack_bwd_f16x3": _env_switch("PAIF_ATTACK_BWD_F16X3"),
           "attack_grad_scale_log2": (int(os.environ["PAIF_ATTACK_GSCALE"]) if "PAIF_ATTACK_GSCALE" in os.environ else None),
-          "attack_fwd_f16x3": {"0": False, "1": True, "gemm": "gemm"}[os.environ.get("PAIF_ATTACK_FWD_F16X3", "1")], "attn_x6": os.environ.get("PAIF_ATTN_X6", "1") != "0", "attn_f16x3": os.environ.get("PAIF_ATTN_F16X3", "1") != "0", "gemm_gather": os.environ.get("PAIF_GEMM_GATHER", "1") != "0"}
+          "attack_fwd_f16x3": _env_switch("PAIF_ATTACK_FWD_F16X3"), "attn_x6": os.environ.get("PAIF_ATTN_X6", "1") != "0", "attn_f16x3": os.environ.get("PAIF_ATTN_F16X3", "1") != "0", "gemm_gather": os.environ.get("PAIF_GEMM_GATHER", "1") != "0"}
 # falsy, or the torch dtype (torch.bfloat16 / torch.float16) of the 32-channel maps while an inference forward of the fusion network
 # runs in a 16-bit storage mode (set by the model through `bf16_activations`)
 _ACT_BF16 = [False]
