@@ -55,7 +55,7 @@ def main():
                     help="fusion = BASELINE configs[1] (the headline line); fusion_seg = configs[2] (bs=16, + mit_b3 SegFormer); "
                          "pgd = configs[3] (PGD-10 attack + final forward, bs=8); train = configs[4] (adversarial-training step: "
                          "PGD-k attack, _loss_coupled forward + full backward, gradient all-reduce over RCCL when N > 1, AdamW; bs=8/GPU)")
-    ap.add_argument("--gemm-precision", choices=["f32", "bf16x3", "auto"], default="auto",
+    ap.add_argument("--gemm-precision", choices=["f32", "bf16x3", "auto", "f16x3", "auto6h"], default="auto",
                     help="arithmetic of the SegFormer GEMMs (workloads with the segmentation net): auto (default) = split-bf16 only where "
                          "the exact-fp32 GEMM is matrix-pipe bound (K >= 256), exact fp32 MFMA elsewhere; f32 = exact everywhere; bf16x3")
     ap.add_argument("--force-allreduce", action="store_true",
@@ -242,7 +242,8 @@ def main():
     # launches (GEMMs, attention, guided filter, the remaining convs: `roofline_other`) are instrumented in a pass of the same K steps
     # right AFTER the timed region: two events around each of fusion_seg's ~150 tagged launches per step cost ~5 % of `value`
     # (measured: 569 pairs/s instrumented everywhere, 597 un-instrumented), the measurement must not price the product.
-    DOM_PRIOR = {"fusion": DOMINANT, "fusion_seg": "gemm_mfma_bf16x3",
+    DOM_PRIOR = {"fusion": DOMINANT,
+                 "fusion_seg": "gemm_mfma_f16x3" if (args.gemm_precision == "auto" and ops.CONFIG["infer_f16x3"]) or args.gemm_precision in ("f16x3", "auto6h") else "gemm_mfma_bf16x3",
                  "pgd": "gemm_mfma_f16x3" if args.attack_precision == "bf16x6" else None,
                  "train": "gemm_mfma_f16x3" if args.attack_precision == "bf16x6" else None}[args.workload]
     timer = ops.KernelTimer((lambda tag: family(tag) == DOM_PRIOR) if DOM_PRIOR else (lambda tag: True))
@@ -469,11 +470,13 @@ def main():
                              else "f16 (IEEE fp16 maps and conv weights, one fp16 MFMA per product, f32 accumulate; stems, guided filter and the last map fp32)" if args.storage == "f16"
                              else "bf16 storage / f32 accumulate (conv weights split-bf16 hi + lo: 2 MFMAs per product; stems and guided filter fp32)")))
                      + ("" if args.workload == "fusion" else "; SegFormer GEMMs: %s" % {"f32": "exact fp32 MFMA", "bf16x3": "split-bf16",
-                                                                                      "auto": "exact fp32 MFMA, split-bf16 where K >= 256"}[args.gemm_precision]
-                        + "; attention products: %s" % ("exact fp32 MFMA" if args.gemm_precision == "f32" else "split-bf16")
+                                                                                      "auto": ("inference forward: fp16 pairs (3 fp16 MFMAs per product, fp32-level) from 2,048 rows up, exact fp32 MFMA below; taped passes outside the attack loops: exact fp32 MFMA, split-bf16 where K >= 256" if ops.CONFIG["infer_f16x3"] else "exact fp32 MFMA, split-bf16 where K >= 256"), "f16x3": "fp16 pairs (3 fp16 MFMAs, fp32-level)",
+                                                                                      "auto6h": "fp16 pairs (3 fp16 MFMAs, fp32-level) from 2,048 rows up, exact fp32 MFMA below"}[args.gemm_precision]
+                        + "; attention products: %s" % ("exact fp32 MFMA" if args.gemm_precision == "f32" else
+                                                        "fp16 pairs" if args.gemm_precision in ("f16x3", "auto6h") or (args.gemm_precision == "auto" and ops.CONFIG["infer_f16x3"] and args.workload == "fusion_seg") else "split-bf16")
                         + ("" if args.workload not in ("pgd", "train") else
                            "; INSIDE the attack loop: %s" % ("exact fp32 MFMA for convs, GEMMs and attention (attack precision 'exact')"
-                                                            if args.attack_precision == "exact" else ("the convs and the GEMMs with K >= 256 as fp16 pairs (two 11-bit pieces per operand, 3 fp16 MFMAs per product, ~2^-21.5: measured error vs float64 at or below the exact fp32 MFMA's; the weight side pre-scaled by 2^8, the reverse pass by a power of two ~ the pixel count -- both exact), the attention products as three-piece bf16 splits (6 MFMAs, 2^-25), the other GEMMs exact fp32 MFMA (attack precision 'bf16x6')" if args.attack_precision == "bf16x6" else "the same split-bf16 kernels (attack precision 'fast')")))),
+                                                            if args.attack_precision == "exact" else ("the 32-channel convs, the GEMMs (from 2,048 rows up) and the attention products as fp16 pairs (two 11-bit pieces per operand, 3 fp16 MFMAs per product, ~2^-21.5: measured error vs float64 at or below the exact fp32 MFMA's; the weight side pre-scaled by 2^8, the reverse pass by a power of two ~ the pixel count -- both exact), smaller GEMMs exact fp32 MFMA (attack precision 'bf16x6')" if args.attack_precision == "bf16x6" else "the same split-bf16 kernels (attack precision 'fast')")))),
             "data": "synthetic",
             "config": {"workload": {"fusion": "configs[1]: fusion-net forward (RGB2YCrCb + Network_Fusion_Searched, C=32, shipped genotype)",
                                     "fusion_seg": "configs[2]: fusion + mit_b3 SegFormer end-to-end inference",

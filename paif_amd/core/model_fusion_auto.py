@@ -576,6 +576,9 @@ class WeTr(nn.Module):
         """x NHWC [B,H,W,3] (normalised) -> logits NHWC [B,H/4,W/4,num_classes]."""
         enc_tape = None if tape is None else []
         head_tape = None if tape is None else {}
+        if tape is None:       # inference: the GEMMs / attention on fp16 pairs (ops.inference_gemm_arithmetic)
+            with ops.inference_gemm_arithmetic():
+                return self.decoder.forward_nhwc(self.encoder.forward_features_nhwc(x, None), None)
         out = self.decoder.forward_nhwc(self.encoder.forward_features_nhwc(x, enc_tape), head_tape)
         if tape is not None:
             tape.update(enc=enc_tape, head=head_tape)

@@ -75,7 +75,7 @@ CONFIG = {"conv_precision": "bf16x3", "gemm_precision": os.environ.get("PAIF_GEM
           # 16-bit inference forward: a ResidualDenseBlock (k = 3, dilation 1) as ONE kernel (csrc/rdb_fused.hip) on maps of >= 512 tiles.
           # OFF by default: correct (tests/test_f16_storage_gpu.py) and 2 map passes instead of 9, but matrix-pipe bound at the clock the chip
           # sustains under that load -- 400 us per block inside the forward against 355 for the three bandwidth-bound launches
-          "rdb_fused": False, "gemm2": False, "wgrad_f16x3": os.environ.get("PAIF_WGRAD_F16X3", "1") != "0", "_wgrad_scale": None, "gemm_split_min_m": 2048, "f16x3_min_k": int(os.environ.get("PAIF_F16X3_MIN_K", "32")), "attack_bwd_f16x3": _env_switch("PAIF_ATTACK_BWD_F16X3"),
+          "rdb_fused": False, "gemm2": False, "infer_f16x3": os.environ.get("PAIF_INFER_F16X3", "1") != "0", "wgrad_f16x3": os.environ.get("PAIF_WGRAD_F16X3", "1") != "0", "_wgrad_scale": None, "gemm_split_min_m": 2048, "f16x3_min_k": int(os.environ.get("PAIF_F16X3_MIN_K", "32")), "attack_bwd_f16x3": _env_switch("PAIF_ATTACK_BWD_F16X3"),
           "attack_grad_scale_log2": (int(os.environ["PAIF_ATTACK_GSCALE"]) if "PAIF_ATTACK_GSCALE" in os.environ else None),
           "attack_fwd_f16x3": _env_switch("PAIF_ATTACK_FWD_F16X3"), "attn_x6": os.environ.get("PAIF_ATTN_X6", "1") != "0", "attn_f16x3": os.environ.get("PAIF_ATTN_F16X3", "1") != "0", "gemm_gather": os.environ.get("PAIF_GEMM_GATHER", "1") != "0"}
 # falsy, or the torch dtype (torch.bfloat16 / torch.float16) of the 32-channel maps while an inference forward of the fusion network
@@ -184,6 +184,24 @@ class attack_forward_arithmetic:
 
     def __exit__(self, *a):
         CONFIG["gemm_precision"], CONFIG["conv_precision"] = self.old
+
+
+class inference_gemm_arithmetic:
+    """Around the segmentation network's inference forward (no tape; CONFIG["infer_f16x3"]): the "auto" rule of the GEMMs / attention /
+    strided convs becomes "auto6h" -- fp16 pairs (two 11-bit pieces per operand, three fp16 MFMAs per product) from 2,048 rows up, for every
+    k extent, instead of split-bf16 for K >= 256 and the exact fp32 MFMA below.  Error against float64 at the exact kernels' level (20x
+    below split-bf16), and faster: the fp16 split is two conversion instructions per value where the bf16 split needs its rounding done by
+    hand, and the GEMM's staging is vector-issue bound; the short-k GEMMs leave the fp32 matrix rate.  Activations of the path are O(1)-O(100),
+    orders of magnitude inside fp16's range.  Taped forwards / reverse passes outside an attack loop keep "auto": unscaled gradients
+    need the bf16 exponent range."""
+
+    def __enter__(self):
+        self.old = CONFIG["gemm_precision"]
+        if CONFIG["infer_f16x3"] and self.old == "auto":
+            CONFIG["gemm_precision"] = "auto6h"
+
+    def __exit__(self, *a):
+        CONFIG["gemm_precision"] = self.old
 
 
 class attack_backward_arithmetic:

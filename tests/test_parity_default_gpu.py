@@ -188,6 +188,7 @@ def test_pgd10_gate_with_the_split_gemms_forced_at_this_size(golden, mode):
         ops.CONFIG["gemm_split_min_m"] = 1
         ops.CONFIG["attack_fwd_f16x3"] = mode != "x6_everywhere"
         ops.CONFIG["attack_bwd_f16x3"] = mode == "f16x3_forward_and_backward"
+        ops.CONFIG["infer_f16x3"] = mode != "x6_everywhere"        # (the harness forward on the attacked pair after the loop)
         timer = ops.KernelTimer(lambda tag: tag.startswith("gemm_mfma") or tag.startswith("conv_mfma"))
         ops.TIMER = timer
         try:
