@@ -439,8 +439,23 @@ def main():
                 return None
             names = [tag.split(" (")[0]] + (["gf_guide_stats_kernel"] if "gf_guide_stats_kernel" in tag else [])
             total = 0.0
+
+            def is_kernel_of(nm, k):
+                if k == nm or k.startswith(nm + "<"):
+                    return True
+                # timer tags that name an ARITHMETIC of a templated kernel: gemm_mfma_bf16x3<MASKED, NP, GATHER, PF> and the split attention <D, NP, PF>
+                m = re.match(r"gemm_mfma_bf16x3<(?:true|false), (\d), (?:true|false), (\d)>$", k)
+                if m and nm.startswith("gemm_mfma_"):
+                    return nm == {("2", "0"): "gemm_mfma_bf16x3", ("3", "0"): "gemm_mfma_bf16x6", ("2", "1"): "gemm_mfma_f16x3"}.get((m.group(1), m.group(2)))
+                if nm == "gemm_mfma_f32" and k.startswith("gemm_mfma_f32_serial<"):
+                    return True
+                m = re.match(r"sr_attention_split_kernel<\d+, (\d), (\d)>$", k)
+                if m and nm.startswith("sr_attention_"):
+                    return nm == {("2", "0"): "sr_attention_bf16x3", ("3", "0"): "sr_attention_bf16x6", ("2", "1"): "sr_attention_f16x3"}.get((m.group(1), m.group(2)))
+                return nm == "sr_attention" and k.startswith("sr_attention_kernel<")
+
             for nm in names:
-                hits = [v for k, v in pmc_sec.items() if not k.startswith("_") and (k == nm or k.startswith(nm + "<"))]
+                hits = [v for k, v in pmc_sec.items() if not k.startswith("_") and is_kernel_of(nm, k)]
                 if not hits:
                     return None
                 total += sum(h["traffic_bytes"] * h["launches_fetch_pass"] for h in hits) / sum(h["launches_fetch_pass"] for h in hits)

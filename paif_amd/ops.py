@@ -190,9 +190,8 @@ class inference_gemm_arithmetic:
     """Around the segmentation network's inference forward (no tape; CONFIG["infer_f16x3"]): the "auto" rule of the GEMMs / attention /
     strided convs becomes "auto6h" -- fp16 pairs (two 11-bit pieces per operand, three fp16 MFMAs per product) from 2,048 rows up, for every
     k extent, instead of split-bf16 for K >= 256 and the exact fp32 MFMA below.  Error against float64 at the exact kernels' level (20x
-    below split-bf16), and faster: the fp16 split is two conversion instructions per value where the bf16 split needs its rounding done by
-    hand, and the GEMM's staging is vector-issue bound; the short-k GEMMs leave the fp32 matrix rate.  Activations of the path are O(1)-O(100),
-    orders of magnitude inside fp16's range.  Taped forwards / reverse passes outside an attack loop keep "auto": unscaled gradients
+    below split-bf16) at the same speed (configs[2] 746 vs 747 pairs/s on one box).  Activations of the path are O(1)-O(100), orders of
+    magnitude inside fp16's range.  Taped forwards / reverse passes outside an attack loop keep "auto": unscaled gradients
     need the bf16 exponent range."""
 
     def __enter__(self):
