@@ -95,6 +95,9 @@ def main():
     ap.add_argument("--no-also", action="store_true",
                     help="fusion workload at N=1: skip the bounded `also` block (configs[2]-[4] -- fusion + SegFormer, PGD-10 evaluation, "
                          "adversarial-training step -- measured in this same process after the headline's timed region, ~30 s)")
+    ap.add_argument("--event-sample", type=int, default=1,
+                    help="time one launch in N of the dominant kernel inside the timed region (HIP events around a launch keep the GPU idle "
+                         "for ~3 us; N = 1: every launch)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the passes that run after the timed region (other storage modes, two-stream, sustained): clean rocprofv3 / PMC "
                          "summaries of ONE configuration")
@@ -246,7 +249,7 @@ def main():
                  "fusion_seg": "gemm_mfma_f16x3" if (args.gemm_precision == "auto" and ops.CONFIG["infer_f16x3"]) or args.gemm_precision in ("f16x3", "auto6h") else "gemm_mfma_bf16x3",
                  "pgd": "gemm_mfma_f16x3" if args.attack_precision == "bf16x6" else None,
                  "train": "gemm_mfma_f16x3" if args.attack_precision == "bf16x6" else None}[args.workload]
-    timer = ops.KernelTimer((lambda tag: family(tag) == DOM_PRIOR) if DOM_PRIOR else (lambda tag: True))
+    timer = ops.KernelTimer((lambda tag: family(tag) == DOM_PRIOR) if DOM_PRIOR else (lambda tag: True), every=args.event_sample)
     timer_all = None
     if args.graph:
         if args.workload not in ("fusion", "fusion_seg", "pgd"):
