@@ -360,6 +360,14 @@ int paif_gemm_conv_fwd(const float* x, int B, int H, int W, int Cin, int k, int 
 int paif_gemm_col2im_fwd(const float* dY, int lda, const float* Wt, float* dx, int B, int H, int W, int C, int sr, int K,
                          int precision, paif_stream_t stream);
 
+/* Measurement helpers (bench.py's live roofline, BASELINE.json metric / SURVEY 8(d); not on the product path): HIP events created with
+ * hipEventDisableSystemFence -- timing-only events: no system-scope fence between the kernels they bracket -- recorded on the launch
+ * stream.  paif_timing_event_elapsed_ms needs both events completed (synchronise the stream first). */
+int paif_timing_event_create(void** ev);
+int paif_timing_event_record(void* ev, paif_stream_t stream);
+int paif_timing_event_elapsed_ms(void* start, void* stop, float* ms);
+int paif_timing_event_destroy(void* ev);
+
 /* Wide-tile form of the split-bf16 paif_gemm_fwd (csrc/gemm_split2.hip) for the same nn.Linear sites (core/mix_transformer.py:22-25,
  * 66-69,74; core/segformer_head.py:19): workgroup tile 128 x 64*nt, wave tile 64 x 32*nt.  paif_gemm2_plan returns nt (1, 2, 4 or 5
  * column tiles per wave) for a shape it is built for, 0 otherwise (the caller then takes paif_gemm_fwd).  precision: PAIF_CONV_BF16X3 or

@@ -83,6 +83,10 @@ SIGNATURES = {
     "paif_gemm_splitk_plan": (c_int, [c_int, c_int, c_int]),
     "paif_gemm_conv_fwd": (c_int, [F, c_int, c_int, c_int, c_int, c_int, c_int, c_int, F, F, F, c_int, F, c_int, F, c_int, c_int, c_int, c_int, F, F]),
     "paif_gemm_col2im_fwd": (c_int, [F, c_int, F, F, c_int, c_int, c_int, c_int, c_int, c_int, c_int, F]),
+    "paif_timing_event_create": (c_int, [POINTER(c_void_p)]),
+    "paif_timing_event_record": (c_int, [c_void_p, F]),
+    "paif_timing_event_elapsed_ms": (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
+    "paif_timing_event_destroy": (c_int, [c_void_p]),
     "paif_gemm2_plan": (c_int, [c_int, c_int, c_int, c_int]),
     "paif_gemm2_packed_bytes": (c_size_t, [c_int, c_int, c_int]),
     "paif_gemm2_pack_weight": (c_int, [F, F, c_int, c_int, c_int, F]),

@@ -75,7 +75,7 @@ CONFIG = {"conv_precision": "bf16x3", "gemm_precision": os.environ.get("PAIF_GEM
           # 16-bit inference forward: a ResidualDenseBlock (k = 3, dilation 1) as ONE kernel (csrc/rdb_fused.hip) on maps of >= 512 tiles.
           # OFF by default: correct (tests/test_f16_storage_gpu.py) and 2 map passes instead of 9, but matrix-pipe bound at the clock the chip
           # sustains under that load -- 400 us per block inside the forward against 355 for the three bandwidth-bound launches
-          "rdb_fused": False, "gemm2": False, "infer_f16x3": os.environ.get("PAIF_INFER_F16X3", "1") != "0", "wgrad_f16x3": os.environ.get("PAIF_WGRAD_F16X3", "1") != "0", "_wgrad_scale": None, "gemm_split_min_m": 2048, "f16x3_min_k": int(os.environ.get("PAIF_F16X3_MIN_K", "32")), "attack_bwd_f16x3": _env_switch("PAIF_ATTACK_BWD_F16X3"),
+          "rdb_fused": False, "gemm2": False, "timer_torch_events": os.environ.get("PAIF_TIMER_TORCH_EVENTS", "0") == "1", "infer_f16x3": os.environ.get("PAIF_INFER_F16X3", "1") != "0", "wgrad_f16x3": os.environ.get("PAIF_WGRAD_F16X3", "1") != "0", "_wgrad_scale": None, "gemm_split_min_m": 2048, "f16x3_min_k": int(os.environ.get("PAIF_F16X3_MIN_K", "32")), "attack_bwd_f16x3": _env_switch("PAIF_ATTACK_BWD_F16X3"),
           "attack_grad_scale_log2": (int(os.environ["PAIF_ATTACK_GSCALE"]) if "PAIF_ATTACK_GSCALE" in os.environ else None),
           "attack_fwd_f16x3": _env_switch("PAIF_ATTACK_FWD_F16X3"), "attn_x6": os.environ.get("PAIF_ATTN_X6", "1") != "0", "attn_f16x3": os.environ.get("PAIF_ATTN_F16X3", "1") != "0", "gemm_gather": os.environ.get("PAIF_GEMM_GATHER", "1") != "0"}
 # falsy, or the torch dtype (torch.bfloat16 / torch.float16) of the 32-channel maps while an inference forward of the fusion network
@@ -321,6 +321,7 @@ class KernelTimer:
         self.every = max(1, int(every))   # time one matching launch in `every` (a pair of event records between two kernels costs
         self.seen = 0                     # ~3 us of idle GPU: 22 of them are ~2-3 % of a 3.5 ms step)
         self.records = []           # (tag, start_event, end_event, flops, bytes)
+        self._events = []           # fence-less HIP events owned by this timer
         self.extra = {}             # tag -> bytes of residual-map reads (not part of the SURVEY 8(d) byte model)
 
     def start(self, tag):
@@ -329,17 +330,41 @@ class KernelTimer:
         self.seen += 1
         if (self.seen - 1) % self.every:
             return None
-        e = torch.cuda.Event(enable_timing=True)
-        e.record()
-        return e
+        return self._record()
+
+    def _record(self):
+        """One timing event on the current stream: a fence-less HIP event (csrc/timing.hip) unless CONFIG["timer_torch_events"]."""
+        if CONFIG["timer_torch_events"]:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            return e
+        ev = ctypes.c_void_p()
+        _lib.check(lib().paif_timing_event_create(ctypes.byref(ev)), "timing_event_create")
+        _lib.check(lib().paif_timing_event_record(ev, _stream()), "timing_event_record")
+        self._events.append(ev)
+        return ev
+
+    @staticmethod
+    def _elapsed(e0, e1):
+        if isinstance(e0, torch.cuda.Event):
+            return e0.elapsed_time(e1)
+        ms = ctypes.c_float()
+        _lib.check(lib().paif_timing_event_elapsed_ms(e0, e1, ctypes.byref(ms)), "timing_event_elapsed_ms")
+        return ms.value
+
+    def __del__(self):
+        try:
+            for ev in self._events:
+                lib().paif_timing_event_destroy(ev)
+        except Exception:
+            pass
 
     def stop(self, tag, e0, flops, nbytes, extra_bytes=0):
         """nbytes: algorithmic bytes on SURVEY 8(d)'s model (each distinct input map read once, the output written once; residual adds
         free); extra_bytes: what the launch moves on top of that by construction (residual maps read in the epilogue)."""
         if e0 is None:
             return
-        e1 = torch.cuda.Event(enable_timing=True)
-        e1.record()
+        e1 = self._record()
         self.records.append((tag, e0, e1, flops, nbytes))
         self.extra[tag] = self.extra.get(tag, 0) + extra_bytes
 
@@ -348,7 +373,7 @@ class KernelTimer:
         out = {}
         for tag, e0, e1, fl, nb in self.records:
             n, ms, f, b = out.get(tag, (0, 0.0, 0, 0))
-            out[tag] = (n + 1, ms + e0.elapsed_time(e1), f + fl, b + nb)
+            out[tag] = (n + 1, ms + self._elapsed(e0, e1), f + fl, b + nb)
         return out
 
 
