@@ -21,10 +21,11 @@ Prints ONE JSON line on rank 0 (contract in the task statement): value = whole-j
   parity       -- which storage mode `value` was measured in and what the committed parity report says about it
 
 `--storage` (fusion / fusion_seg): since round 5 `value` is measured in the fp16 configuration (`f16`) -- the 16-bit storage mode that meets
-BOTH clauses of SURVEY 8(d) against the reference's own multi-class, near-tie predictions: argmax agreement 99.93 % over the eight 480x640
-samples of the benchmarked batch (per sample 99.87-99.97 %: `parity` lists them), mIoU within 0.01 pt
-(profiles/r05_f16_storage_report.json, tests/test_f16_storage_gpu.py).  The fp32-storage rate (round 4's `value`; 99.993 %) and the bf16
-rate (what BASELINE configs[1] names literally; 98.9 %, misses the clause) are in the same line (`other_storage`).
+BOTH clauses of SURVEY 8(d) against the reference's own multi-class, near-tie predictions, evaluated (round 6) on THIRTY-TWO 480x640
+samples with a bootstrap interval over samples: `parity` carries the aggregate, the interval, the per-sample values (a single sample is a
+noisy statistic at the 1e-3 level: individual samples fall on either side of 99.9 %) and the mIoU delta, read from the committed report
+(profiles/r06_f16_storage_report.json, written by tests/test_f16_storage_gpu.py on MI355X).  The fp32-storage rate (round 4's `value`)
+and the bf16 rate (what BASELINE configs[1] names literally; misses the argmax clause) are in the same line (`other_storage`).
 """
 import argparse
 import json
@@ -78,23 +79,27 @@ def main():
                          "network on two HIP streams; bit-identical output, ~+6 %%).  `value` is then the co-scheduled rate and every per-launch "
                          "duration (roofline blocks, rocprofv3) measures CU sharing as well as the kernel -- the line says so.  Without the flag the "
                          "two-stream rate is reported beside `value` as `two_stream`")
-    ap.add_argument("--attack-precision", choices=["exact", "bf16x6", "fast"], default="bf16x6",
-                    help="pgd / train: arithmetic INSIDE the attack loop.  bf16x6 (default, the product default) = convs as three-piece bf16 "
-                         "splits (six MFMAs per product, 2^-25 per product: fp32-level parity -- sign mismatch vs the reference's float64 run 0 "
-                         "through PGD-10): round 5 -- convs and K >= 256 GEMMs as fp16 pairs (3 fp16 MFMAs, ~2^-21.5), attention three-piece bf16 (6 MFMAs), the other GEMMs exact fp32 MFMA; exact = fp32-exact MFMA kernels everywhere; fast = the split-bf16 "
-                         "kernels there too (trajectory diverges: sign mismatch 2.5e-2 by iteration 10; tests/test_parity_default_gpu.py)")
+    ap.add_argument("--attack-precision", choices=["exact", "fp32level", "bf16x6", "fast"], default="fp32level",
+                    help="pgd / train: arithmetic INSIDE the attack loop.  fp32level (default; `bf16x6` is its pre-round-6 name, still accepted) = "
+                         "fp32-level parity at a fraction of the exact kernels' matrix time: the 32-channel convs, the GEMMs from 2,048 rows up and "
+                         "the attention products as fp16 PAIRS (two fp16 pieces per operand, 3 fp16 MFMAs per product, ~2^-21.5; weights pre-scaled "
+                         "by 2^8 and the reverse pass by a power of two, both exact), smaller GEMMs on the exact fp32 MFMA -- sign mismatch of the "
+                         "running gradient sum vs the reference's float64 run: 0 through PGD-10 (tests/test_parity_default_gpu.py).  exact = "
+                         "fp32-exact MFMA kernels everywhere.  fast = split-bf16 (two bf16 pieces, 3 MFMAs, ~2^-16): the trajectory diverges "
+                         "(sign mismatch 2.5e-2 by iteration 10)")
     ap.add_argument("--storage", choices=["f32", "bf16", "bf16_split", "f16"], default="f16",
                     help="activation storage of the fusion network's inference forward (fusion / fusion_seg workloads).  f16 (default since "
                          "round 5) = the 16-bit configuration that meets SURVEY 8(d)'s clause: IEEE fp16 maps behind the guided-filter block and "
                          "fp16 weights, one fp16 MFMA per product, fp32 accumulate, HF = x - LF out of the guided filter, fp32 last map: argmax "
-                         "agreement with the reference 99.93 %% over the 8 samples of the benchmarked batch (per sample 99.87 ... 99.97 %%), mIoU "
-                         "within 0.01 pt (tests/test_f16_storage_gpu.py).  f32 = every map fp32 (round 4's default; 99.993 %%).  bf16 = what "
+                         "agreement with the reference evaluated on 32 samples with a bootstrap interval (the `parity` block of the line; "
+                         "tests/test_f16_storage_gpu.py), mIoU within 0.01 pt.  f32 = every map fp32 (round 4's default; 99.993 %%).  bf16 = what "
                          "BASELINE configs[1] names literally: bf16 maps and weights -- mIoU within 0.1 pt, argmax agreement 98.9 %% (misses the "
                          "99.9 %% clause).  The line also carries the OTHER modes' rates (`other_storage`), measured right after the timed region; "
                          "taped (pgd / train) passes always run fp32 storage")
     ap.add_argument("--no-also", action="store_true",
                     help="fusion workload at N=1: skip the bounded `also` block (configs[2]-[4] -- fusion + SegFormer, PGD-10 evaluation, "
                          "adversarial-training step -- measured in this same process after the headline's timed region, ~30 s)")
+    ap.add_argument("--also-child", action="store_true", help=argparse.SUPPRESS)     # internal: the process that measures the `also` block
     ap.add_argument("--event-sample", type=int, default=1,
                     help="time one launch in N of the dominant kernel inside the timed region (HIP events around a launch keep the GPU idle "
                          "for ~3 us; N = 1: every launch)")
@@ -104,9 +109,13 @@ def main():
     ap.add_argument("--conv-precision", choices=["f32", "bf16x3"], default="bf16x3",
                     help="arithmetic of the dense convs: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs, fp32 accumulate)")
     args = ap.parse_args()
+    if args.attack_precision == "fp32level":
+        args.attack_precision = "bf16x6"      # ops.set_attack_precision's name of the same mode
     if args.workload == "pgd" and not args.no_graph:
         args.graph = True          # the whole PGD-10 evaluation step as one hipGraph is the default
 
+    if args.also_child:
+        raise SystemExit(also_child_main(args))
     if (args.gpus > 1 or os.environ.get("PAIF_BENCH_FORCE_LAUNCH") == "1") and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: this process has made NO GPU call yet (importing torch and counting devices does not
         # initialise HIP) -- it starts the N ranks as CHILD processes (never an exec of a GPU-initialised process), relays rank 0's
@@ -118,6 +127,18 @@ def main():
     if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, world, args.gpus))
+    also_proc = None
+    if world == 1 and args.workload == "fusion" and not (args.no_also or args.no_extras or args.graph or args.two_stream):
+        # the `also` block (three more workloads, a training step among them) used to run in THIS process before the one JSON
+        # line was printed -- a GPU fault there lost the headline.  It now runs in a child process that is started HERE, before this
+        # process has made any GPU call (a GPU-initialised process must not start programs on this pool), imports torch and then waits
+        # on its stdin; it is told to go after the headline's timed region and answers with one JSON object.  Its failure costs `also`.
+        import subprocess
+        also_proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--also-child", "--backbone", args.backbone,
+                                      "--attack-iters", str(args.attack_iters), "--attack-precision", args.attack_precision,
+                                      "--gemm-precision", args.gemm_precision, "--conv-precision", args.conv_precision],
+                                     stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True,
+                                     env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
     dev = torch.device("cuda", local_rank)
     dist = None
     rccl_ranks_seen = None
@@ -141,7 +162,12 @@ def main():
     ops.set_gemm_precision(args.gemm_precision)
     ops.set_attack_precision(args.attack_precision)
     ops.set_storage(args.storage)
-    DOMINANT = "dense conv 3x3 dil 1, forward (%s)" % args.conv_precision   # family tag of the 12 dense 3x3 convs of a step
+    # family tag of the dense 3x3 dilation-1 convs of a step, named after the arithmetic that RUNS
+    DOMINANT = "dense conv 3x3 dil 1, forward (%s)" % (
+        "exact fp32 MFMA" if args.conv_precision == "f32" else
+        {"f32": "fp32 maps, split-bf16: 3 bf16 MFMAs per product", "bf16_split": "bf16 maps, split-bf16 weights: 2 MFMAs per product",
+         "bf16": "bf16 maps and weights: 1 bf16 MFMA per product", "f16": "fp16 maps and weights: 1 fp16 MFMA per product"}[
+             args.storage if args.workload in ("fusion", "fusion_seg") else "f32"])
     bpg = 16 if args.workload == "fusion_seg" else B_PER_GPU
     if args.workload == "fusion":
         net = Network_Fusion_Searched(32, None, FUSION_AT).eval()
@@ -351,6 +377,7 @@ def main():
             xm.update(extra_bytes)
             extra_bytes = xm
 
+        sampled_families = {family(tag) for tag in timer.summary()} if timer.every > 1 else set()
         summ, members = {}, {}
         for tag, (n_, ms_, fl_, by_) in per_kernel.items():
             f = family(tag)
@@ -365,7 +392,8 @@ def main():
         def roof_block(tag):
             n_, ms_, fl_, by_ = summ[tag]
             tf, gb = fl_ / (ms_ * 1e-3) / 1e12, by_ / (ms_ * 1e-3) / 1e9
-            if (tag.startswith("conv_") or tag.startswith("dense conv") or tag.startswith("conv3x3_bf16_dma") or tag.startswith("conv7x7_bf16_dma")) and ("bf16x3" in tag or "bf16_dma" in tag):
+            if (tag == DOMINANT and args.conv_precision != "f32") or (
+                    (tag.startswith("conv_") or tag.startswith("conv3x3_bf16_dma") or tag.startswith("conv7x7_bf16_dma")) and ("bf16x3" in tag or "bf16_dma" in tag)):
                 # split-bf16 convs: 3 bf16 MFMA passes -> effective matrix peak 2500/3 = 833 TF algorithmic; at 72-108 FLOP/B
                 # (fp32 storage, k <= 3) the HBM roof binds (833e12 / 8e12 = 104 FLOP/B); the 5x5 / 7x7 convs (K = 800 / 1568:
                 # 200-390 FLOP/B) are matrix-pipe bound and are priced against the 833 TF algorithmic peak
@@ -387,7 +415,7 @@ def main():
                 if fl_ / max(by_, 1) > peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9):
                     blk = {"bound": "mfma", "achieved": tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": tf / peak_tf, "algorithmic_gbs": gb,
                            "hbm_frac": gb / HBM_PEAK_GBS,
-                           "note": "%d bf16 MFMA%s per product -> 2500/%d TF algorithmic peak" % (nm, "" if nm == 1 else "s", nm)}
+                           "note": "%d 16-bit MFMA%s per product -> 2500/%d TF algorithmic peak" % (nm, "" if nm == 1 else "s", nm)}
                 else:
                     blk = {"bound": "hbm", "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS, "algorithmic_tflops": tf}
             elif tag.startswith("gf_") or tag.startswith("gf2_"):
@@ -404,9 +432,12 @@ def main():
                     blk = {"bound": "mfma", "achieved": tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": f_m, "algorithmic_gbs": gb}
                 else:
                     blk = {"bound": "hbm", "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": f_h, "algorithmic_tflops": tf}
-            blk.update({"kernel": tag, "launches": n_, "avg_launch_ms": ms_ / n_, "share_of_step": ms_ / (dt * 1e3),
+            ev_ = timer.every if (tag in sampled_families) else 1      # --event-sample N timed one launch in N inside the timed region
+            blk.update({"kernel": tag, "launches": n_ * ev_, "avg_launch_ms": ms_ / n_, "share_of_step": ms_ * ev_ / (dt * 1e3),
                         "algorithmic_gflop_per_launch": fl_ / n_ / 1e9, "algorithmic_mb_per_launch": by_ / n_ / 1e6})
             xb = sum(extra_bytes.get(k, 0) for k in members.get(tag, [tag]))
+            if ev_ > 1:
+                blk["timed_launches"] = n_
             if xb:   # `frac` / `achieved` price SURVEY 8(d)'s bytes (residual adds free); this field also counts the residual maps the epilogues read
                 blk["hbm_frac_counting_residual_reads"] = (by_ + xb) / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS
                 blk["residual_read_mb_per_launch"] = xb / n_ / 1e6
@@ -502,7 +533,8 @@ def main():
                                     "train": "configs[4]: adversarial-training step = PGD-%d attack_both (eval mode) + _loss_coupled forward/backward with "
                                              "all parameter gradients (train mode) + %s + PolyWarmupAdamW (one AdamW kernel over the flat arena), %s"
                                              % (args.attack_iters, "bucketed RCCL gradient all-reduce overlapped with the backward" if world > 1
-                                                else "no all-reduce at N=1", args.backbone)}[args.workload]
+                                                else ("bucketed gradient all-reduce on a 1-rank RCCL group (--force-allreduce)" if args.force_allreduce
+                                                      else "no all-reduce at N=1"), args.backbone)}[args.workload]
                                    + ", 480x640, bs=%d/GPU, %s, conv precision %s" % (
                                        bpg, "fp32 storage" if args.storage == "f32" or args.workload in ("pgd", "train") else
                                        "%s storage of the 32-channel maps behind the guided-filter block (fp32 stems / guided filter / accumulation)" % (
@@ -515,6 +547,12 @@ def main():
             "roofline": roof,
             "roofline_other": others,
         }
+        if args.workload == "fusion":
+            # SURVEY 8(d)'s layer-boundary traffic model of the whole fusion forward: 703.8 M elements per pair (each conv-level op reads
+            # each distinct input map once and writes its output once; residual adds free) x the storage width, against the 8 TB/s spec
+            gbp = 0.7038 * (4 if args.storage == "f32" else 2)
+            res["whole_step_survey_hbm_frac"] = gbp * (pairs / dt) / HBM_PEAK_GBS
+            res["whole_step_survey_gb_per_pair"] = gbp
         if rccl_ranks_seen is not None:
             res["rccl_ranks_seen"] = rccl_ranks_seen      # all-reduce of ones over the process group (= world size when RCCL connected every rank)
         if args.workload in ("fusion", "fusion_seg"):
@@ -550,18 +588,49 @@ def main():
             res["sustained_value"] = bpg * world * sustained[0] / sustained[1]
             res["sustained"] = {"steps": sustained[0], "seconds": sustained[1], "ms_per_step": sustained[1] / sustained[0] * 1e3,
                                 "note": "the same step looped for >= %.0f s right after the timed region; `value` is the K-step figure" % args.sustain_seconds}
-        if world == 1 and args.workload == "fusion" and not (args.no_also or args.no_extras or args.graph or args.two_stream):
-            # the other BASELINE configurations as DRIVER-OBSERVED figures -- a bounded pass of each after the headline
+        if also_proc is not None:
+            # the other BASELINE configurations as DRIVER-OBSERVED figures -- a bounded pass of each after the headline,
+            # measured by the waiting child process while this one idles (its tensors stay resident: a few GB of the 288)
             del out
             ops.TIMER = None
             torch.cuda.empty_cache()
-            res["also"] = also_block(args, dev, rank)
+            torch.cuda.synchronize()
+            try:
+                reply, _ = also_proc.communicate("go\n", timeout=600)
+                last = [ln for ln in reply.splitlines() if ln.startswith("{")]
+                res["also"] = json.loads(last[-1]) if last else {"error": "the also-child exited %s without a JSON object" % also_proc.returncode}
+            except Exception as e:                 # timeout, broken pipe, bad JSON: the headline line survives
+                also_proc.kill()
+                res["also"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline and args.workload in ("fusion", "fusion_seg", "pgd"):
-            res["cpu_baseline"] = cpu_baseline(args.workload, ir_np, vis_np, lab_np, args.cpu_baseline_full, args.backbone)
+            # BASELINE.md 3b's protocol (3 warm-up + 5 timed forwards, at B=1 and at B=8) whenever the run is a full-length one
+            # (--steps >= 20, the default); shorter runs take the bounded sample
+            res["cpu_baseline"] = cpu_baseline(args.workload, ir_np, vis_np, lab_np, args.cpu_baseline_full or args.steps >= 20, args.backbone)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def also_child_main(args):
+    """`bench.py --also-child`: started by the headline process before it touches the GPU.  Waits for one line on stdin (EOF = the parent
+    is gone: exit quietly), THEN initialises the GPU, measures the `also` block and prints it as one JSON object."""
+    line = sys.stdin.readline()
+    if not line.strip():
+        return 0
+    if not torch.cuda.is_available():
+        print(json.dumps({"error": "no GPU in the also-child"}), flush=True)
+        return 1
+    from paif_amd import ops
+    if args.attack_precision == "fp32level":
+        args.attack_precision = "bf16x6"
+    torch.cuda.set_device(0)
+    ops.set_conv_precision(args.conv_precision)
+    ops.set_gemm_precision(args.gemm_precision)
+    ops.set_attack_precision(args.attack_precision)
+    ops.set_storage("f16")
+    print(json.dumps(also_block(args, torch.device("cuda", 0), 0)), flush=True)
+    return 0
 
 
 def also_block(args, dev, rank):
@@ -652,8 +721,9 @@ def also_block(args, dev, rank):
             out[name] = {"config": cfg, "error": "%s: %s" % (type(e).__name__, e)}
         net.eval()
     out["seconds"] = time.perf_counter() - t_begin
-    out["note"] = ("bounded passes in the headline's process after its timed region (fp32 storage in the taped passes, the attack loop in "
-                   "bf16x6 arithmetic); two HIP events around every tagged launch")
+    out["note"] = ("bounded passes right after the headline's timed region, in a child process the headline process started before it touched "
+                   "the GPU (a fault here cannot lose the headline); fusion_seg in fp16 storage, fp32 storage in the taped passes, the attack "
+                   "loop in the fp32-level fp16-pair arithmetic; two HIP events around every tagged launch")
     return out
 
 
@@ -731,26 +801,33 @@ ST_MFMAS = {0: 3, 1: 2, 2: 3, 3: 3, 4: 1, 5: 2, 6: 1, 7: 1, 9: 2, 12: 1, 14: 1, 
 def parity_block(storage):
     """What the committed parity report (tests/test_f16_storage_gpu.py::test_fusion_forward_f16_storage_tolerance_clause on MI355X, copied
     to profiles/) says about the storage mode `value` was measured in: SURVEY 8(d)'s two clauses against the REFERENCE's own mit_b3
-    predictions (calibrated head: multi-class maps, median top-2 margin 1.6-5 % of the logit range) on the eight 480x640 samples of the
-    benchmarked batch (2.46 M pixels), and the per-sample figures (a single sample is a noisy statistic at the 1e-3 level)."""
-    src = "profiles/r05_f16_storage_report.json"
+    predictions (calibrated head: multi-class maps, median top-2 margin 1.6-5 % of the logit range) on 32 synthetic 480x640 samples
+    (9.83 M pixels; samples 0-7 = the benchmarked batch), the 95 % bootstrap interval over samples of the aggregate, and the per-sample
+    figures (a single sample is a noisy statistic at the 1e-3 level)."""
+    src = "profiles/r06_f16_storage_report.json"
     out = {"storage": storage, "source": src}
     try:
         rep = json.load(open(os.path.join(ROOT, src)))
         r = rep[storage]
-        out.update({"argmax_agreement_vs_reference_8_samples": r["argmax_agreement_8_samples"],
-                    "argmax_agreement_vs_reference_per_sample": r["argmax_agreement_per_sample"],
-                    "miou_delta_vs_reference_8_samples": r["miou_delta_8_samples"], "miou_delta_vs_reference_sample0": r["miou_delta_sample0"],
+        per = r["argmax_agreement_per_sample"]
+        out.update({"samples": len(per), "argmax_agreement_vs_reference": r["argmax_agreement_32_samples"],
+                    "argmax_agreement_bootstrap_95": r["argmax_agreement_bootstrap_95"],
+                    "argmax_agreement_vs_reference_8_samples_of_the_benchmarked_batch": r["argmax_agreement_8_samples"],
+                    "argmax_agreement_vs_reference_per_sample_min_max": [min(per), max(per)], "samples_below_0.999": r["samples_below_999"],
+                    "miou_delta_vs_reference": r["miou_delta_32_samples"], "miou_delta_vs_reference_sample0": r["miou_delta_sample0"],
                     "logits_max_abs_over_range_sample0": r["logits_max_abs_over_range"], "fused_max_abs_vs_fp64_sample0": r["fused_max_abs_vs_fp64"],
                     "fused_mean_abs_vs_fp64_sample0": r["fused_mean_abs_vs_fp64"],
-                    "clause_argmax_ge_0.999": bool(r["argmax_agreement_8_samples"] >= 0.999),
-                    "clause_argmax_ge_0.999_on_every_sample": bool(min(r["argmax_agreement_per_sample"]) >= 0.999),
-                    "clause_miou_within_0.1pt": bool(abs(r["miou_delta_8_samples"]) <= 1e-3 and abs(r["miou_delta_sample0"]) <= 1e-3)})
+                    "clause_argmax_ge_0.999": bool(r["argmax_agreement_32_samples"] >= 0.999),
+                    "clause_argmax_ge_0.999_at_the_lower_end_of_the_interval": bool(r["argmax_agreement_bootstrap_95"][0] >= 0.999),
+                    "clause_argmax_ge_0.999_on_every_sample": bool(min(per) >= 0.999),
+                    "clause_miou_within_0.1pt": bool(abs(r["miou_delta_32_samples"]) <= 1e-3 and abs(r["miou_delta_sample0"]) <= 1e-3)})
         if not out["clause_argmax_ge_0.999"]:
             out["note"] = "this storage mode keeps mIoU within 0.1 pt but NOT the 99.9 % argmax clause; --storage f16 / f32 meet both"
         elif not out["clause_argmax_ge_0.999_on_every_sample"]:
-            out["note"] = ("the 99.9 % clause holds on the 8-sample evaluation set, not on every sample taken alone (sample-to-sample spread of a "
-                           "near-tie statistic); --storage f32 holds it on every sample")
+            out["note"] = ("the 99.9 % clause holds on the 32-sample evaluation set%s, not on every sample taken alone (sample-to-sample spread "
+                           "of a near-tie statistic); --storage f32 holds it on every sample" % (
+                               " including the lower end of its bootstrap interval" if out["clause_argmax_ge_0.999_at_the_lower_end_of_the_interval"]
+                               else " in aggregate but NOT at the lower end of its bootstrap interval"))
     except (OSError, ValueError, KeyError) as e:
         out["note"] = "parity report unreadable: %s" % e
     return out

@@ -104,7 +104,8 @@ def _attack_loop(model, X_vis, X_ir, label, lab64, epsilon, alpha, attack_iters,
         d_vis = _init_delta(X_vis, epsilon, delta0_vis) if do_vis else torch.zeros_like(X_vis)
         g_ir = torch.zeros_like(X_ir)     # the never-zeroed delta.grad (:501): a running sum over iterations
         g_vis = torch.zeros_like(X_vis)
-        gs = 1.0
+        # exact power of two on the (linear) reverse pass, undone in the accumulation below; from the label's VALID pixels
+        gs = ops.attack_grad_scale(lab64) if fast else 1.0
         for i in range(attack_iters):
             if fast:
                 with torch.no_grad():
@@ -112,7 +113,6 @@ def _attack_loop(model, X_vis, X_ir, label, lab64, epsilon, alpha, attack_iters,
                         _, logits, tape = model.forward_taped(ops.add(X_ir, d_ir), ops.add(X_vis, d_vis))
                     way, wt, wf = ops.attack_loss_weights(attack_way, i, attack_iters)
                     coef = ops.attack_loss_fwd(logits, lab64, way, wt, wf)    # loss + the backward's scalars, on the device
-                    gs = ops.attack_grad_scale(lab64)                         # exact power of two on the (linear) reverse pass, undone below
                     d32 = ops.attack_loss_bwd(logits, lab64, coef, way, wt, wf, upstream=gs)
                     with ops.attack_backward_arithmetic():
                         gi, gv = model.backward_taped(d32, tape)

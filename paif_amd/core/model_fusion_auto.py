@@ -343,7 +343,10 @@ class Network_Fusion_Searched(nn.Module):
         if torch.is_grad_enabled() and (ir.requires_grad or vis.requires_grad or wg):
             return _FusionFn.apply(ir, vis, self, wg, grad_anchor(ir.device))
         # ops.set_storage("bf16"): bf16 maps behind the guided-filter block (eval mode: the train-mode BatchNorm path is fp32 only)
-        with torch.no_grad(), ops.bf16_activations(enable=not self.training):
+        # (a forward that returns the decomposition intermediates -- inter["want_decomposition"] -- keeps fp32 maps: the guided filter
+        # then writes fp32 LF maps, which the 16-bit chain kernels do not take)
+        want_feats = inter is not None and bool(inter.get("want_decomposition"))
+        with torch.no_grad(), ops.bf16_activations(enable=not self.training and not want_feats):
             return self.forward_impl(ir, vis, inter=inter)
 
     def forward_impl(self, ir, vis, inter=None, tape=None):

@@ -65,7 +65,17 @@ def _env_switch(name, default="1"):
     return {"0": False, "1": True, "gemm": "gemm"}[v]
 
 
-CONFIG = {"conv_precision": "bf16x3", "gemm_precision": os.environ.get("PAIF_GEMM_PRECISION", "auto"), "serpentine": True, "attack_precision": "bf16x6", "storage": "f32",
+GEMM_PRECISIONS = ("f32", "bf16x3", "auto", "bf16x6", "auto6", "f16x3", "auto6h")
+
+
+def _env_gemm_precision():
+    v = os.environ.get("PAIF_GEMM_PRECISION", "auto")
+    if v not in GEMM_PRECISIONS:
+        raise ValueError("PAIF_GEMM_PRECISION=%r: expected one of %s" % (v, GEMM_PRECISIONS))
+    return v
+
+
+CONFIG = {"conv_precision": "bf16x3", "gemm_precision": _env_gemm_precision(), "serpentine": True, "attack_precision": "bf16x6", "storage": "f32",
           # inference forward of the fusion network: run the infrared and the visible stream on two HIP streams (identical results; off by
           # default because per-launch timings -- bench.py's roofline blocks, rocprofv3 averages -- then measure CU sharing, not kernels)
           "two_stream": False,
@@ -133,8 +143,8 @@ PREC_BF16 = 2          # include/paif_hip.h PAIF_CONV_BF16 (conv descriptors wit
 def set_gemm_precision(mode):
     """Arithmetic of the SegFormer GEMMs: "f32" (exact fp32 MFMA), "bf16x3" (split-bf16: 3 bf16 MFMAs, ~1e-5 relative),
     or "auto": split-bf16 where the GEMM is matrix-pipe bound at fp32 (K >= 256 and M >= CONFIG["gemm_split_min_m"]), exact fp32 elsewhere."""
-    if mode not in ("f32", "bf16x3", "auto", "bf16x6", "auto6", "f16x3", "auto6h"):
-        raise ValueError("gemm precision must be 'f32', 'bf16x3', 'auto', 'bf16x6', 'auto6', 'f16x3' or 'auto6h'")
+    if mode not in GEMM_PRECISIONS:
+        raise ValueError("gemm precision must be one of %s" % (GEMM_PRECISIONS,))
     CONFIG["gemm_precision"] = mode
 
 
@@ -240,13 +250,29 @@ def check_attack_range(*grads):
                                  % (CONFIG["attack_grad_scale_log2"],))
 
 
-def attack_grad_scale(label):
-    """The power of two the attack loops scale the reverse pass by (1.0 when the reverse pass stays on three-piece bf16 splits)."""
+_VALID_PIXELS = {}     # (data_ptr, numel, version) of a label tensor -> pixels that are not ignore_index (one host read per label tensor)
+
+
+def attack_grad_scale(label, ignore_index=255):
+    """The power of two the attack loops scale the reverse pass by (1.0 when the reverse pass stays on three-piece bf16 splits):
+    2^(floor(log2 V) - 4) with V = the pixels the cross-entropy AVERAGES over -- the label's valid pixels, not its size (with
+    most labels at ignore_index the mean over the valid pixels makes d(logits) 1 / V, not 1 / numel; scaling by numel would overflow).
+    One small reduction + host read per label tensor (cached; while a hipGraph is being captured the cached value of the eager call that
+    must precede a capture is used, the label's size if there is none)."""
     if not CONFIG["attack_bwd_f16x3"] or CONFIG.get("attack_precision", "bf16x6") != "bf16x6":
         return 1.0
     k = CONFIG["attack_grad_scale_log2"]
     if k is None:
-        k = max(0, int(label.numel()).bit_length() - 1 - 4)      # 2^floor(log2(pixels)) / 16: |d logits| <= 1/16 after scaling
+        key = (label.data_ptr(), label.numel(), label._version)
+        v = _VALID_PIXELS.get(key)
+        if v is None:
+            if torch.cuda.is_current_stream_capturing():
+                v = label.numel()
+            else:
+                if len(_VALID_PIXELS) > 64:
+                    _VALID_PIXELS.clear()
+                v = _VALID_PIXELS[key] = max(1, int((label != ignore_index).sum()))
+        k = max(0, int(v).bit_length() - 1 - 4)      # 2^floor(log2 V) / 16: |d logits| <= 1/16 after scaling
     return float(2 ** k)
 
 

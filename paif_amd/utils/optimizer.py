@@ -216,6 +216,16 @@ class PolyWarmupAdamW(torch.optim.AdamW):
             if g['betas'] != g0['betas'] or g['eps'] != g0['eps'] or g.get('amsgrad') or g.get('maximize'):
                 raise NotImplementedError("PolyWarmupAdamW: per-group betas / eps, amsgrad and maximize are not built")
         has_grad = np.array([p.grad is not None for p, _, _, _ in A.entries], dtype=bool)
+        if ops.CONFIG["wgrad_f16x3"] and ops.CONFIG.get("wgrad_guard", True) and has_grad.any() and not torch.cuda.is_current_stream_capturing():
+            # the Linear weight gradients of a training step run on fp16 pairs with dY pre-scaled by a power of two
+            # guessed from the pixel count (ops.wgrad_scale).  A loss multiplier / sum reduction / GradScaler-style scaling can push
+            # |dY| * scale past 65504: the kernel then accumulates inf / NaN.  One pass over the gradient arena and one host read per
+            # step, BEFORE anything is written: a non-finite gradient raises instead of reaching the weights and the Adam moments
+            if not bool(torch.isfinite(A.grad).all()):
+                raise FloatingPointError(
+                    "PolyWarmupAdamW.step: non-finite gradient in the arena; nothing was updated.  If the loss is scaled (multiplier, "
+                    "sum reduction, GradScaler) the fp16-pair weight-gradient GEMMs may have left fp16's exponent range: set "
+                    "ops.CONFIG['wgrad_f16x3'] = False (or PAIF_WGRAD_F16X3=0) to run them on the exact fp32 MFMA kernels")
         self._steps[has_grad] += 1                      # torch: state['step'] += 1 for the parameters updated now
         beta1, beta2 = g0['betas']
         ng = len(self.param_groups)

@@ -52,3 +52,36 @@ def test_bucketed_allreduce_on_a_one_rank_rccl_group():
     assert o["delta_equal"] and o["loss_a"] == o["loss_b"], o
     assert o["grad_max_abs_diff"] == 0.0, o                           # AVG over one rank: bit-identical gradients
     assert o["global_minmax_equals_plain_forward"], o                 # the 2-float MIN all-reduce of the optional global_minmax mode
+
+
+def test_bench_self_launch_path_on_one_gpu():
+    """the path the driver takes at N = 8 -- `python bench.py --gpus N` -> bench.self_launch ->
+    `python -m torch.distributed.run` child -> RCCL process group -> bucketed gradient all-reduce -> rank 0's JSON line relayed by
+    the parent -- run end to end on the one GPU of this box (PAIF_BENCH_FORCE_LAUNCH=1 takes the launcher path at N = 1, a 1-rank
+    RCCL group runs the real collective).  Everything short of the 8-GPU node: exit status, exactly one JSON line, the number of ranks
+    RCCL connected, the exposed all-reduce time of configs[4].  The parent of the launcher is a plain subprocess of a pytest process
+    that has not initialised the GPU."""
+    import torch
+
+    if torch.cuda.is_initialized():
+        msg = "the launcher is only started from a parent that has not touched the GPU"
+        if os.environ.get("PAIF_REQUIRE_RCCL_TEST") == "1":
+            pytest.fail(msg)
+        pytest.skip(msg)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PAIF_BENCH_FORCE_LAUNCH="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "train", "--force-allreduce",
+                        "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--sustain-seconds", "0"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert len(lines) == 1, r.stdout[-2000:]
+    o = json.loads(lines[0])
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        open(os.path.join(out_dir, "bench_selflaunch.json"), "w").write(lines[0] + "\n")
+    assert o["n_gpus"] == 1 and o["rccl_ranks_seen"] == 1, o
+    assert o["steps"] == 1 and o["value"] > 0 and o["unit"] == "pairs/s" and o["scaling"] == "weak", o
+    assert "configs[4]" in o["config"]["workload"], o["config"]
+    assert o["allreduce_exposed_ms_per_step"] >= 0.0, o            # the bucketed all-reduce ran and its exposed tail was timed
+    assert o["roofline"]["frac"] > 0 and o["roofline"]["launches"] > 0, o["roofline"]

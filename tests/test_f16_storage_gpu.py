@@ -359,44 +359,60 @@ def test_two_stream_and_graph_replay_are_bit_identical_in_f16_storage():
     assert torch.equal(two, ref) and torch.equal(gout, ref)
 
 
+NS = 32       # evaluation set of SURVEY 8(d)'s 16-bit clause: tests/golden/gq_model_b3_32x480x640.npz (oracle/make_golden_r6.py)
+
+
+def _bootstrap_interval(moved, reps=20000, seed=20261004):
+    """Percentile bootstrap over SAMPLES (the pixels that move come in spatial clusters: pixels are not independent draws, samples are) of
+    the aggregate argmax agreement: (2.5 %, 50 %, 97.5 %)."""
+    rs = np.random.RandomState(seed)
+    mv = np.asarray(moved, np.float64)
+    idx = rs.randint(0, len(mv), size=(reps, len(mv)))
+    agg = 1.0 - mv[idx].mean(axis=1) / 307200.0
+    return [float(v) for v in np.percentile(agg, [2.5, 50.0, 97.5])]
+
+
 def _clause_eval(modes, golden):
     """SURVEY 8(d)'s bf16-clause numbers of the storage modes `modes` against the REFERENCE: (a) the 1x480x640 golden (sample 0: fused
-    plane vs its float64 run, logits, argmax, mIoU), (b) the argmax maps / confusion matrices of the reference on all EIGHT samples of the
-    benchmarked batch (gp_model_b3_8x480x640, B = 1 forwards like the reference harness)."""
+    plane vs its float64 run, logits, argmax, mIoU), (b) the argmax maps / confusion matrices of the reference on THIRTY-TWO synthetic
+    480x640 samples (gq_model_b3_32x480x640: samples 0-7 are the benchmarked batch; B = 1 forwards like the reference harness), with a
+    bootstrap interval over samples of the aggregate agreement."""
     from paif_amd.core.model_fusion_auto import Network_MM_Searched
     from paif_amd.genotypes import FUSION_AT
     from paif_amd.util.util import ConfusionMeter, compute_results
 
-    g, g8 = golden("gf_model_b3_1x480x640"), golden("gp_model_b3_8x480x640")
+    g, g8, gq = golden("gf_model_b3_1x480x640"), golden("gp_model_b3_8x480x640"), golden("gq_model_b3_32x480x640")
     Hh.assert_multiclass(g["pred"], min_classes=9)
-    for i in range(8):
-        Hh.assert_multiclass(g8["pred"][i], min_classes=3, min_share=0.04)
-    assert np.array_equal(g8["pred"][0], g["pred"][0])
+    for i in range(NS):
+        Hh.assert_multiclass(gq["pred"][i], min_classes=3, min_share=0.04)
+    assert np.array_equal(gq["pred"][0], g["pred"][0]) and np.array_equal(gq["pred"][:8], g8["pred"]) and gq["pred"].shape[0] == NS
     dev = _dev()
     m = Network_MM_Searched(32, FUSION_AT, None, None, "mit_b3", num_classes=9).eval()
     S.load_formula_weights(m, head=Hh.HEAD480)
     m = m.to(dev)
-    ir, vis, lab = S.make_batch(8, 480, 640)
     up = lambda x: torch.nn.functional.interpolate(x, size=(480, 640), mode="bilinear", align_corners=False).numpy()
     srt = np.sort(up(t(g["logits"])), axis=1)
     margin_ref = srt[:, -1] - srt[:, -2]
     rng = float(g["logits"].max() - g["logits"].min())
     miou = lambda conf: float(np.nanmean(compute_results(conf)[2]))
-    miou_ref0, miou_ref8 = miou(g["conf"]), miou(g8["conf"].sum(0))
-    report = dict(logit_range=rng, miou_reference_sample0=miou_ref0, miou_reference_8_samples=miou_ref8,
-                  reference_median_margin_over_range=[float(v) for v in g8["median_margin_over_range"]],
-                  reference_f32_vs_f64_pixels=[int((g8["pred"][i] != g8["pred64"][i]).sum()) for i in range(8)])
+    miou_ref0, miou_ref8, miou_refq = miou(g["conf"]), miou(gq["conf"][:8].sum(0)), miou(gq["conf"].sum(0))
+    report = dict(logit_range=rng, samples=NS, miou_reference_sample0=miou_ref0, miou_reference_8_samples=miou_ref8, miou_reference_32_samples=miou_refq,
+                  reference_median_margin_over_range=[float(v) for v in gq["median_margin_over_range"]],
+                  reference_f32_vs_f64_pixels=[int((gq["pred"][i] != gq["pred64"][i]).sum()) for i in range(NS)])
     for mode in modes:
         ops.set_storage(mode)
-        moved, conf = [], np.zeros((9, 9), np.int64)
-        for i in range(8):
+        moved, conf, conf8 = [], np.zeros((9, 9), np.int64), np.zeros((9, 9), np.int64)
+        for i in range(NS):
+            ir, vis, lab = S.make_batch(1, 480, 640, start=i)
             with torch.no_grad():
-                fused, seg = m(t(ir[i:i + 1]).to(dev), t(vis[i:i + 1]).to(dev))
+                fused, seg = m(t(ir).to(dev), t(vis).to(dev))
             meter = ConfusionMeter(9, dev)
-            pred = meter.update(seg, t(lab[i:i + 1]).to(dev)).cpu().numpy()
+            pred = meter.update(seg, t(lab).to(dev)).cpu().numpy()
             c = meter.conf.cpu().numpy()
             conf += c
-            moved.append(int((pred[0] != g8["pred"][i]).sum()))
+            if i < 8:
+                conf8 += c
+            moved.append(int((pred[0] != gq["pred"][i]).sum()))
             if i == 0:
                 d64 = (fused.cpu().double() - t(g["fused64"]).double()).abs()
                 lerr = (seg.cpu() - t(g["logits"])).abs()
@@ -405,9 +421,13 @@ def _clause_eval(modes, golden):
                          logits_max_abs_over_range=float(lerr.max()) / rng, logits_mean_abs_over_range=float(lerr.mean()) / rng,
                          largest_reference_margin_of_a_moved_pixel_over_range=float(margin_ref[dis].max() / rng) if dis.any() else 0.0,
                          miou_delta_sample0=miou(c) - miou_ref0)
+        lo, med, hi = _bootstrap_interval(moved)
         r.update(moved_pixels=moved, argmax_agreement_per_sample=[1.0 - v / 307200.0 for v in moved],
-                 argmax_agreement_8_samples=1.0 - sum(moved) / (8 * 307200.0), argmax_agreement_sample0=1.0 - moved[0] / 307200.0,
-                 miou_delta_8_samples=miou(conf) - miou_ref8)
+                 argmax_agreement_32_samples=1.0 - sum(moved) / (NS * 307200.0), argmax_agreement_8_samples=1.0 - sum(moved[:8]) / (8 * 307200.0),
+                 argmax_agreement_bootstrap_95=[lo, hi], argmax_agreement_bootstrap_median=med,
+                 samples_below_999=int(sum(1 for v in moved if 1.0 - v / 307200.0 < 0.999)),
+                 argmax_agreement_sample0=1.0 - moved[0] / 307200.0, miou_delta_8_samples=miou(conf8) - miou_ref8,
+                 miou_delta_32_samples=miou(conf) - miou_refq)
         report[mode] = r
     ops.set_storage("f32")
     return report
@@ -420,9 +440,10 @@ F16_CLAUSE = dict(fused_max=2.5e-3, fused_mean=1.0e-4, logits_max=1.2e-3, logits
 def test_fusion_forward_f16_storage_tolerance_clause(golden):
     """SURVEY 8(d)'s bf16-clause for the fp16 configuration, against the reference (mit_b3, calibrated head: multi-class maps with
     near-ties on every class boundary): max / mean |fused - reference| and the logit error reported and bounded; only near-tie pixels
-    move; mIoU within 0.1 pt; ARGMAX AGREEMENT >= 99.9 % over the eight 480x640 samples of the benchmarked batch (2.46 M pixels).  On a
-    single sample the figure is a noisy statistic at this level (the pixels that move are near-ties in spatial clusters): the per-sample
-    values are reported and floor-bounded, not held to 99.9 % one by one (tools/storage_sensitivity.py --phase 4)."""
+    move; mIoU within 0.1 pt; ARGMAX AGREEMENT >= 99.9 % over THIRTY-TWO 480x640 samples (9.83 M pixels) -- asserted on the LOWER end of
+    a 95 % bootstrap interval over samples (round 6; round 5 evaluated eight samples and held the mean).  On a single sample the figure
+    is a noisy statistic at this level (the pixels that move are near-ties in spatial clusters): the per-sample values are reported and
+    floor-bounded, not held to 99.9 % one by one (tools/storage_sensitivity.py --phase 4)."""
     report = _clause_eval(("f16", "bf16", "bf16_split", "f32"), golden)
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out_dir):
@@ -432,12 +453,13 @@ def test_fusion_forward_f16_storage_tolerance_clause(golden):
     assert r["fused_max_abs_vs_fp64"] <= lim["fused_max"] and r["fused_mean_abs_vs_fp64"] <= lim["fused_mean"], r
     assert r["logits_max_abs_over_range"] <= lim["logits_max"] and r["logits_mean_abs_over_range"] <= lim["logits_mean"], r
     assert r["largest_reference_margin_of_a_moved_pixel_over_range"] <= 2.0 * r["logits_max_abs_over_range"], r
-    assert abs(r["miou_delta_8_samples"]) <= lim["miou"] and abs(r["miou_delta_sample0"]) <= lim["miou"], r      # within 0.1 pt
-    assert r["argmax_agreement_8_samples"] >= 0.999, r                                                         # >= 99.9 %
+    assert abs(r["miou_delta_32_samples"]) <= lim["miou"] and abs(r["miou_delta_8_samples"]) <= lim["miou"] and abs(r["miou_delta_sample0"]) <= lim["miou"], r
+    assert r["argmax_agreement_32_samples"] >= 0.999, r                                                        # >= 99.9 %
+    assert r["argmax_agreement_bootstrap_95"][0] >= 0.999, r                     # ... with the sampling uncertainty on the safe side
     assert min(r["argmax_agreement_per_sample"]) >= 0.9975, r                    # measured per sample 0.9982 ... 0.9997 across builds
     # the same evaluation of the other modes, for the record: fp32 storage sits at the reference's own noise; bf16 maps miss the clause
-    assert report["f32"]["argmax_agreement_8_samples"] >= 0.9998, report["f32"]
-    assert report["bf16"]["argmax_agreement_8_samples"] < r["argmax_agreement_8_samples"], report["bf16"]
+    assert report["f32"]["argmax_agreement_bootstrap_95"][0] >= 0.9998, report["f32"]
+    assert report["bf16"]["argmax_agreement_bootstrap_95"][1] < 0.999, report["bf16"]
 
 
 def test_fusion_f16_storage_b8_is_samplewise_the_b1_forward():

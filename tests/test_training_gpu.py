@@ -216,6 +216,33 @@ def test_adamw_kernel_vs_torch_adamw():
 
 
 @pytest.mark.gpu
+def test_adamw_refuses_a_non_finite_gradient_arena():
+    """with the fp16-pair weight-gradient GEMMs on (ops.CONFIG["wgrad_f16x3"], the default), a loss scaled past fp16's
+    range would put inf / NaN into the gradient arena; step() checks the arena BEFORE the AdamW launch and raises -- weights, moments and
+    step counts untouched.  With the switch off the optimizer behaves like torch's (no check)."""
+    from paif_amd.utils.optimizer import PolyWarmupAdamW
+
+    g = torch.Generator().manual_seed(5)
+    ps = [torch.nn.Parameter(torch.randn(s, generator=g).to(_dev())) for s in [(64, 64), (9,)]]
+    opt = PolyWarmupAdamW([dict(params=ps, lr=1e-3, weight_decay=0.01)], lr=1e-3, weight_decay=0.01, betas=(0.9, 0.999), warmup_iter=2, max_iter=10,
+                          warmup_ratio=0.1, power=1.0)
+    opt.zero_grad()
+    for p in ps:
+        ops.grad_of(p).copy_(torch.randn(p.shape, generator=g).to(_dev()))
+    opt.step()
+    before = [p.detach().clone() for p in ps]
+    opt.zero_grad()
+    for p in ps:
+        ops.grad_of(p).copy_(torch.randn(p.shape, generator=g).to(_dev()))
+    ops.grad_of(ps[0])[3, 5] = float("inf")
+    assert ops.CONFIG["wgrad_f16x3"]
+    with pytest.raises(FloatingPointError, match="wgrad_f16x3"):
+        opt.step()
+    assert all(torch.equal(a, p.detach()) for a, p in zip(before, ps)) and opt.global_step == 1
+    assert bool(torch.isfinite(opt.arena().m).all()) and bool(torch.isfinite(opt.arena().v).all())
+
+
+@pytest.mark.gpu
 def test_adamw_checkpoint_resume_and_per_parameter_steps():
     """ The moments live in the arenas, not in `self.state`: state_dict() must export them in torch.optim.AdamW's layout
     and load_state_dict() must restore them -- checked BOTH ways against torch's own AdamW (ours -> torch and torch -> ours), with a
