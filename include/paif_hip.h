@@ -75,7 +75,9 @@ int paif_stem_fwd(const float* img, size_t img_bstride, const float* w, const fl
  * the fp32 map feeds the fp32 guided-filter block, its bf16 twin the residual inputs of the bf16-stored layers. */
 int paif_stem_fwd_twin(const float* img, size_t img_bstride, const float* w, const float* prelu, float* feat, float* feat_bf16,
                        float* guide, int B, int H, int W, paif_stream_t stream);
-/* the same with the twin as IEEE fp16 (the fp16 storage mode, round 5) */
+/* the same with the twin as IEEE fp16 (the fp16 storage mode, round 5).  Round 6: `feat` may be NULL -- the fp16 forward then keeps the
+ * 16-bit map only (the guided filter reads it through paif_guided_filter_fused_fwd_hf16_y16); the guide is formed from the fp32 values
+ * either way. */
 int paif_stem_fwd_twin_f16(const float* img, size_t img_bstride, const float* w, const float* prelu, float* feat, float* feat_f16,
                            float* guide, int B, int H, int W, paif_stream_t stream);
 /* Cell_Decom.get_residue on an existing NHWC [B,H,W,32] map (:517-521): guide = max_c - min_c. */
@@ -106,6 +108,12 @@ int paif_guided_filter_fused_fwd_bf16(const float* guide, const float* y, float*
  * folds that conv over [x, HF1, HF2]).  Statistics, A, b, every sum and y - LF itself are fp32. */
 int paif_guided_filter_fused_fwd_hf16(const float* guide, const float* y, float* hf, float eps0, float eps1, float* workspace, int B,
                                       int H, int W, paif_stream_t stream);
+
+/* Round 6: the same with y READ as IEEE fp16 (`y16`: [B,H,W,32] `unsigned short` data -- the 16-bit twin the stem writes, the same map the
+ * folded 1x1 takes as its first source): HF_e = y16 - LF_e(y16); the fp16 forward then has no fp32 stem map at all (replaces the same
+ * reference lines, core/model_fusion_auto.py:522-535). */
+int paif_guided_filter_fused_fwd_hf16_y16(const float* guide, const float* y16, float* hf, float eps0, float eps1, float* workspace,
+                                          int B, int H, int W, paif_stream_t stream);
 
 /* Dense k x k convolution, stride 1, "same" zero padding (pad = dil*(k-1)/2), Cout <= 32, inputs =
  * virtual concat of up to 3 NHWC sources of `cin` channels each, fp32 MFMA (v_mfma_f32_32x32x2_f32)

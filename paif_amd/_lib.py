@@ -46,6 +46,7 @@ SIGNATURES = {
     "paif_guided_filter_fused_fwd": (c_int, [F, F, F, c_float, c_float, F, c_int, c_int, c_int, F]),
     "paif_guided_filter_fused_fwd_bf16": (c_int, [F, F, F, c_float, c_float, F, c_int, c_int, c_int, F]),
     "paif_guided_filter_fused_fwd_hf16": (c_int, [F, F, F, c_float, c_float, F, c_int, c_int, c_int, F]),
+    "paif_guided_filter_fused_fwd_hf16_y16": (c_int, [F, F, F, c_float, c_float, F, c_int, c_int, c_int, F]),
     "paif_conv2d_blocks": (c_int, [c_int, c_int, c_int]),
     "paif_conv2d_fwd": (c_int, [POINTER(ConvDesc), c_int, c_int, c_int, F]),
     "paif_conv2d_is_persistent": (c_int, [POINTER(ConvDesc), c_int, c_int, c_int]),

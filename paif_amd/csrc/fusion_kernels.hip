@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
   }
   __syncthreads();   // the only barrier of an item: a wave that writes buffer p again (two items later) has passed the NEXT item's barrier,
                      // which every wave reaches only after its reads of p
-  float* frow = feat + (size_t)row * W * 32;
+  float* frow = feat ? feat + (size_t)row * W * 32 : nullptr;   // (NULL with a 16-bit twin, round 6: the fp16 forward keeps the twin only)
   unsigned short* frow16 = feat16 ? feat16 + (size_t)row * W * 32 : nullptr;   // optional 16-bit twin of the map (bf16 / fp16 storage modes)
   float* grow = guide ? guide + (size_t)row * W : nullptr;
 #pragma unroll
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
       for (int k = 0; k < 9; ++k) s = fmaf(v[k], wr[c][k], s);
       o[c] = paif::prelu_f(s, slope);
     }
-    if (x < W) paif::store_nt(frow + (size_t)x * 32 + q * 4, make_float4(o[0], o[1], o[2], o[3]));
+    if (frow && x < W) paif::store_nt(frow + (size_t)x * 32 + q * 4, make_float4(o[0], o[1], o[2], o[3]));
     if (frow16 && x < W)      // the 16-bit twin: bf16, or IEEE fp16 (launch-uniform)
       *reinterpret_cast<uint2*>(frow16 + (size_t)x * 32 + q * 4) = twin_f16 ? paif::f32_to_f16x4(make_float4(o[0], o[1], o[2], o[3]))
                                                                              : paif::f32_to_bf16x4(make_float4(o[0], o[1], o[2], o[3]));
@@ -665,7 +665,7 @@ int paif_ycrcb2rgb_fwd(const float* ycc, float* rgb, int B, int H, int W, paif_s
 
 static int stem_launch(const float* img, size_t img_bstride, const float* w, const float* prelu, float* feat, float* guide,
                        unsigned short* feat16, int twin_f16, int B, int H, int W, paif_stream_t stream) {
-  PAIF_REQUIRE(img && w && prelu && feat && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "stem: bad arguments");
+  PAIF_REQUIRE(img && w && prelu && (feat || feat16) && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "stem: bad arguments");
   PAIF_REQUIRE(img_bstride >= (size_t)H * W, PAIF_EINVAL, "stem: batch stride %zu < H*W", img_bstride);
   const int chunks = (W + STEM_CHUNK - 1) / STEM_CHUNK;
   PAIF_REQUIRE((size_t)B * H * chunks < ((size_t)1 << 31), PAIF_EINVAL, "stem: %dx%dx%d is too large for one launch", B, H, W);

@@ -122,6 +122,8 @@ __device__ __forceinline__ f32x2 ring_push(Ring& rg, f32x2 x) {
 // HIGH-frequency maps HF_e = y - LF_e as IEEE fp16, same store path: |HF| << |LF| ~ |y|, so the fp16 rounding of what the folded 1x1
 // behind this block reads is ~8x smaller (core/model_fusion_auto.py:531-532 forms x - LF anyway).  y(r - 9) comes from an in-lane delay
 // line (a 6-deep and a 3-deep ring, both statically indexed by the unrolled step: 18 registers, 4 moves per row).
+// OM 3 (round 6): as OM 2, with y READ as IEEE fp16 -- the stem's 16-bit twin of its map (the only form of that map the fp16 forward then
+// keeps: the stem writes no fp32 map at all).  HF = x16 - LF(x16): the same x16 the folded 1x1 behind the filter takes as its first source.
 template <int OM>
 __global__ __launch_bounds__(64 * NW, NW / 4) void gf2_kernel(const float* __restrict__ guide, const float* __restrict__ y,
                                                      const float* __restrict__ planes, float* __restrict__ lf,
@@ -175,6 +177,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gf2_kernel(const float* __res
   }
   const bool outcol = lc0 >= 2 * R && lc0 < SC - 2 * R;          // the strip's 48 output columns
   constexpr bool BFO = OM != 0;                                    // 16-bit output (bf16 LF or fp16 HF)
+  constexpr bool HFO = OM >= 2;                                    // the output is the high-frequency map y - LF as fp16
+  constexpr bool Y16 = OM == 3;                                    // y is an fp16 map
   const bool odd = (c & 1) != 0;                                   // BFO: even lanes store column 0, odd lanes column 1 of the channel pair
   const u32x2 a_own = band_operand(l & 15, 2 * (l >> 4));
   const u32x2 a_halo = band_operand(l & 15, (l >> 4) < 2 ? -4 + 2 * (l >> 4) : 8 + 2 * ((l >> 4) - 2));
@@ -187,13 +191,15 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gf2_kernel(const float* __res
   // are range-checked away by the buffer hardware (loads return 0, stores are dropped).  The round-4 first cut computed clamped row
   // offsets and descriptor selects on the scalar unit -- 44 scalar instructions per wave and row, ONE scalar unit per CU for 8 waves:
   // 0.15 ms of the 0.49 ms launch (ablation builds).  Requires every per-image byte size < 2^31 - 2^20 (host check).
-  const unsigned rowbytes_pl = (unsigned)W * 4u, rowbytes = (unsigned)W * 128u;
+  constexpr unsigned YES = Y16 ? 2u : 4u;                          // bytes per y element
+  const unsigned rowbytes_pl = (unsigned)W * 4u, rowbytes = (unsigned)W * 32u * YES;
   const int pl_bytes = (int)((size_t)H * rowbytes_pl);
   const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(guide + img), 0, pl_bytes, RSRC_W3);
   const __amdgpu_buffer_rsrc_t rs_mg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(planes + img), 0, pl_bytes, RSRC_W3);
   const __amdgpu_buffer_rsrc_t rs_r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(planes + npix + img), 0, pl_bytes, RSRC_W3);
   const __amdgpu_buffer_rsrc_t rs_r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(planes + 2 * npix + img), 0, pl_bytes, RSRC_W3);
-  const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(y + img * 32), 0, (int)((size_t)H * rowbytes), RSRC_W3);
+  const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(y) + img * 32 * YES), 0, (int)((size_t)H * rowbytes), RSRC_W3);
   constexpr unsigned OES = BFO ? 2u : 4u;                 // bytes per stored output element
   const unsigned rowbytes_o = (unsigned)W * 32u * OES;
   // output descriptors cover the SEGMENT's rows only: a warm-up / tail row lies outside and its stores are dropped
@@ -220,15 +226,15 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gf2_kernel(const float* __res
   for (int k = 0; k < PF; ++k) { ry.p[k] = zero2; rgy.p[k] = zero2; rA0.p[k] = zero2; rB0.p[k] = zero2; rA1.p[k] = zero2; rB1.p[k] = zero2; }
   ry.a1 = ry.a2 = rgy.a1 = rgy.a2 = rA0.a1 = rA0.a2 = rB0.a1 = rB0.a2 = rA1.a1 = rA1.a2 = rB1.a1 = rB1.a2 = zero2;
   f32x2 wA0 = zero2, wB0 = zero2, wA1 = zero2, wB1 = zero2;           // vertical (A, b) window sums of the previous iteration
-  f32x2 yd6[OM == 2 ? PF : 1], yd3[OM == 2 ? 3 : 1];                    // OM 2: y delayed by 6 and by 6 + 3 iterations (the output row's y)
+  f32x2 yd6[OM >= 2 ? PF : 1], yd3[OM >= 2 ? 3 : 1];                    // OM 2: y delayed by 6 and by 6 + 3 iterations (the output row's y)
 #pragma unroll
-  for (int k = 0; k < (OM == 2 ? PF : 1); ++k) yd6[k] = zero2;
+  for (int k = 0; k < (OM >= 2 ? PF : 1); ++k) yd6[k] = zero2;
 #pragma unroll
-  for (int k = 0; k < (OM == 2 ? 3 : 1); ++k) yd3[k] = zero2;
+  for (int k = 0; k < (OM >= 2 ? 3 : 1); ++k) yd3[k] = zero2;
 
   // running offsets (wrapping 32-bit arithmetic on purpose)
   constexpr unsigned NEVER = 0x80000000u;                // + any row offset of the image stays out of range
-  const unsigned lane_y = (unsigned)(((col0) * 32 + 16 * chh + c) * 4);
+  const unsigned lane_y = (unsigned)(((col0) * 32 + 16 * chh + c) * (int)YES);
   unsigned vy = cin[0] ? lane_y + (unsigned)r0 * rowbytes : NEVER + (unsigned)r0 * rowbytes;       // input row of the prefetch target
   const float m1 = cin[1] ? 1.f : 0.f;                   // a lane whose second column lies outside the image (odd W) reads the next row's first pixel there
   // ---- per-pixel planes: loaded ONCE per workgroup and row by the strip's two halo waves (which skip stage 2) and handed to the
@@ -281,8 +287,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gf2_kernel(const float* __res
 #ifdef GF2_NOY         // diagnostic build: no input loads
     py0[slot] = __builtin_bit_cast(float, vy); py1[slot] = __builtin_bit_cast(float, vy ^ 77u);
 #else
-    py0[slot] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_y, vy, 0, 0));
-    py1[slot] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_y, vy + 128u, 0, 0));
+    if constexpr (Y16) {       // two 16-bit loads (the raw fp16 bits wait in the ring; converted where the row is consumed)
+      py0[slot] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs_y, vy, 0, 0));
+      py1[slot] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs_y, vy + 64u, 0, 0));
+    } else {
+      py0[slot] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_y, vy, 0, 0));
+      py1[slot] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_y, vy + 128u, 0, 0));
+    }
 #endif
     vy += rowbytes;
   };
@@ -311,9 +322,16 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gf2_kernel(const float* __res
     constexpr int par = k & 1;                           // PF is even: the iteration's parity is static
     const int it = itb + k;
     GF2_ST(0);
-    const f32x2 yy = {py0[slot], py1[slot] * m1};        // zero outside the image (range-checked loads)
+    f32x2 yy;                                            // zero outside the image (range-checked loads)
+    if constexpr (Y16) {
+      const _Float16 h0 = __builtin_bit_cast(_Float16, (unsigned short)__builtin_bit_cast(unsigned, py0[slot]));
+      const _Float16 h1 = __builtin_bit_cast(_Float16, (unsigned short)__builtin_bit_cast(unsigned, py1[slot]));
+      yy = f32x2{(float)h0, (float)h1 * m1};
+    } else {
+      yy = f32x2{py0[slot], py1[slot] * m1};
+    }
     f32x2 y9 = yy;
-    if constexpr (OM == 2) {                              // y of the row stage 2 outputs in this iteration (r - 9)
+    if constexpr (HFO) {                                  // y of the row stage 2 outputs in this iteration (r - 9)
       const f32x2 y6 = yd6[k];
       yd6[k] = yy;
       y9 = yd3[k % 3];
@@ -365,13 +383,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gf2_kernel(const float* __res
       if constexpr (BFO) {
         auto pair_store = [&](const f32x2& lfv, const __amdgpu_buffer_rsrc_t& rs) {
           typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-          const f32x2 ov = OM == 2 ? y9 - lfv : lfv;     // OM 2: the high-frequency map
+          const f32x2 ov = HFO ? y9 - lfv : lfv;         // OM 2 / 3: the high-frequency map
           // even lane keeps its column 0 and takes the partner's (channel c + 1) column 0; odd lane its column 1 and the partner's
           const float give = odd ? ov[0] : ov[1];        // what the partner needs from me: my value of ITS column
           const float got = __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(give), 0xB1, 0xF, 0xF, true));
           const f32x2 v = {odd ? got : ov[0], odd ? ov[1] : got};     // (channel c & ~1, channel c | 1) of the lane's stored column
           unsigned bits;
-          if constexpr (OM == 2) bits = __builtin_bit_cast(unsigned, __builtin_convertvector(v, paif::f16x2_t));
+          if constexpr (HFO) bits = __builtin_bit_cast(unsigned, __builtin_convertvector(v, paif::f16x2_t));
           else bits = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
           __builtin_amdgcn_raw_buffer_store_b32(bits, rs, vo0, 0, 2);
         };
@@ -432,5 +450,6 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gf2_kernel(const float* __res
 template __global__ void gf2_kernel<0>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
 template __global__ void gf2_kernel<1>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
 template __global__ void gf2_kernel<2>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
+template __global__ void gf2_kernel<3>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
 
 }  // namespace paif_gf2

@@ -318,6 +318,10 @@ __global__ __launch_bounds__(FC * NL) void gf_fused_kernel(const float* __restri
                                                            const float* __restrict__ gs, const unsigned* __restrict__ only_if, float* __restrict__ lf,
                                                            int B, int H, int W, int nstrip, int nseg, int frows, int out_bf16) {
   constexpr int VW = VecOps<V>::VW;
+  // out_bf16 == 3 (round 6): as 2 (fp16 high-frequency output), with y an IEEE fp16 map (the stem's 16-bit twin)
+  const bool y_f16 = out_bf16 == 3;
+  if (y_f16) out_bf16 = 2;
+  const unsigned short* const y16 = reinterpret_cast<const unsigned short*>(y) + (blockIdx.z * NL + threadIdx.x % NL) * VW;
   unsigned short* const lf16 = reinterpret_cast<unsigned short*>(lf);   // out_bf16 (1 bf16 LF, 2 fp16 HF = y - LF): the same element indices in a 16-bit buffer
   if (only_if != nullptr && *only_if == 0u) return;      // fallback launch behind the matrix-core kernel: runs only when it raised the flag
   __shared__ V s_a[2][FC][NL];
@@ -326,6 +330,16 @@ __global__ __launch_bounds__(FC * NL) void gf_fused_kernel(const float* __restri
   const int ql = threadIdx.x - xi * NL;                       // vector slot in the LDS rows; channel = (blockIdx.z * NL + ql) * VW
   y += (blockIdx.z * NL + ql) * VW;
   lf += (blockIdx.z * NL + ql) * VW;
+  auto ldy = [&](size_t px) -> V {                            // the lane's VW channels of pixel px (launch-uniform branch)
+    if (y_f16) {
+      V r;
+      float* pr = reinterpret_cast<float*>(&r);
+#pragma unroll
+      for (int i = 0; i < VW; ++i) pr[i] = (float)__builtin_bit_cast(_Float16, y16[px * 32 + i]);
+      return r;
+    }
+    return *reinterpret_cast<const V*>(y + px * 32);
+  };
   int t = blockIdx.x;
   const int strip = t % nstrip; t /= nstrip;
   const int seg = t % nseg;
@@ -372,7 +386,7 @@ __global__ __launch_bounds__(FC * NL) void gf_fused_kernel(const float* __restri
 #pragma unroll
   for (int p = 0; p < PF; ++p) {
     const size_t px = img + (size_t)min(max(r0 + p, 0), H - 1) * W + colc;
-    pv[p] = *reinterpret_cast<const V*>(y + px * 32);
+    pv[p] = ldy(px);
     pg[p] = guide[px];
     const size_t sx = img + (size_t)min(max(r0 + p - R, 0), H - 1) * W + colc;
     ps[p] = make_float2(gmean[sx], grden[sx]);
@@ -388,7 +402,7 @@ __global__ __launch_bounds__(FC * NL) void gf_fused_kernel(const float* __restri
       const float2 st = ps[k % PF];             // (mean_g, 1/(var_g + eps)) of (row - R, col)
       {
         const size_t px = img + (size_t)min(max(row + PF, 0), H - 1) * W + colc;
-        pv[k % PF] = *reinterpret_cast<const V*>(y + px * 32);
+        pv[k % PF] = ldy(px);
         pg[k % PF] = guide[px];
         const size_t sx = img + (size_t)min(max(row + PF - R, 0), H - 1) * W + colc;
         ps[k % PF] = make_float2(gmean[sx], grden[sx]);
@@ -459,7 +473,7 @@ __global__ __launch_bounds__(FC * NL) void gf_fused_kernel(const float* __restri
 #pragma unroll
         for (int i = 0; i < VW; ++i) po[i] = fmaf(pa[i] * rn, g0, pb[i] * rn);
         if (out_bf16 == 2) {   // launch-uniform: the fp16 configuration's high-frequency map (y re-read: this is the rare fallback path)
-          const V yv = *reinterpret_cast<const V*>(y + px * 32);
+          const V yv = ldy(px);
           const float* py_ = reinterpret_cast<const float*>(&yv);
 #pragma unroll
           for (int i = 0; i < VW; ++i) out16[px * 32 + i] = __builtin_bit_cast(unsigned short, (_Float16)(py_[i] - po[i]));
@@ -494,6 +508,7 @@ __global__ void gf2_kernel(const float* __restrict__ guide, const float* __restr
 extern template __global__ void gf2_kernel<0>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
 extern template __global__ void gf2_kernel<1>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
 extern template __global__ void gf2_kernel<2>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
+extern template __global__ void gf2_kernel<3>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
 }
 
 // workspace: four per-pixel planes + one 256-byte line holding the f16-range flag
@@ -511,8 +526,8 @@ static int gf_fused_launch(const float* guide, const float* y, float* lf, float 
   int engine = (eng && !strcmp(eng, "valu")) ? 0 : (eng && !strcmp(eng, "mfma")) ? 1 : 2;
   // the round-4 engine addresses rows with wrapping 32-bit per-lane offsets that the buffer range check filters: every per-image
   // byte size must stay below 2^31 - 2^20
-  if (engine == 2 && ((size_t)(B + 1) * H * W * 128 >= 0x7FF00000ull || (size_t)B * nstrip * H >= 0x7FFFFFFFull)) engine = out_bf16 == 2 ? 0 : 1;
-  if (out_bf16 == 2 && engine == 1) engine = 2;     // the fp16 high-frequency output is built for the round-4 engine and the VALU kernel
+  if (engine == 2 && ((size_t)(B + 1) * H * W * 128 >= 0x7FF00000ull || (size_t)B * nstrip * H >= 0x7FFFFFFFull)) engine = out_bf16 >= 2 ? 0 : 1;
+  if (out_bf16 >= 2 && engine == 1) engine = 2;     // the fp16 high-frequency output is built for the round-4 engine and the VALU kernel
   static const int form = [] {
     const char* e = getenv("PAIF_GF_FORM");
     if (!e) return 0;
@@ -551,7 +566,10 @@ static int gf_fused_launch(const float* guide, const float* y, float* lf, float 
     nslots = nslots < 1 ? 1 : (nslots > cus / 2 ? cus / 2 : nslots);
     const int rows_per_slot = (int)((total_rows + nslots - 1) / nslots);
     const int grid = (nslots + 7) / 8 * 16;
-    if (out_bf16 == 2)
+    if (out_bf16 == 3)
+      hipLaunchKernelGGL((paif_gf2::gf2_kernel<3>), dim3(grid), dim3(512), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip, nslots,
+                         rows_per_slot, (int)total_rows);
+    else if (out_bf16 == 2)
       hipLaunchKernelGGL((paif_gf2::gf2_kernel<2>), dim3(grid), dim3(512), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip, nslots,
                          rows_per_slot, (int)total_rows);
     else if (out_bf16)
@@ -613,6 +631,12 @@ extern "C" int paif_guided_filter_fused_fwd(const float* guide, const float* y, 
 extern "C" int paif_guided_filter_fused_fwd_hf16(const float* guide, const float* y, float* hf, float eps0, float eps1, float* workspace, int B,
                                                  int H, int W, paif_stream_t stream) {
   return gf_fused_launch(guide, y, hf, eps0, eps1, workspace, B, H, W, 2, stream);
+}
+
+// round 6: as paif_guided_filter_fused_fwd_hf16 with y READ as IEEE fp16 (`y16`: [B,H,W,32] unsigned short data, the stem's 16-bit twin)
+extern "C" int paif_guided_filter_fused_fwd_hf16_y16(const float* guide, const float* y16, float* hf, float eps0, float eps1, float* workspace,
+                                                     int B, int H, int W, paif_stream_t stream) {
+  return gf_fused_launch(guide, y16, hf, eps0, eps1, workspace, B, H, W, 3, stream);
 }
 
 // same, the two low-frequency maps written as bf16 (`lf`: [2][B,H,W,32] unsigned short data): the bf16 configuration

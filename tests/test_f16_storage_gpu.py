@@ -250,21 +250,49 @@ def test_elementwise_kernels_f16_storage():
     assert maxabs(ops.tail(th, wt, slope), ops.tail(t32, wt, slope)) == 0.0                    # fp32 output from identical values
 
 
+@pytest.mark.parametrize("twin_only", [True, False])
 @pytest.mark.parametrize("shape", [(2, 64, 96), (1, 37, 53), (1, 480, 640)])
-def test_stem_writes_an_fp16_twin(shape):
+def test_stem_writes_an_fp16_twin(shape, twin_only, monkeypatch):
+    """fp16 storage: the stem's map as IEEE fp16, written by the stem kernel itself.  Round 6 (CONFIG["gf_in_f16"], the default): ONLY that
+    map -- the guided filter reads it -- and the guide still formed from the fp32 values; with the switch off: the fp32 map and its twin."""
     B, H, W = shape
     dev = _dev()
     ir, _, _ = S.make_batch(B, H, W)
     g = torch.Generator().manual_seed(8)
     w, slope = (torch.randn(32, 1, 3, 3, generator=g) * 0.4).to(dev), torch.tensor([0.2], device=dev)
     ref, gref = ops.stem(t(ir).to(dev), w, slope)
+    monkeypatch.setitem(ops.CONFIG, "gf_in_f16", twin_only)
     ops.set_storage("f16")
     with ops.bf16_activations():
         feat, guide = ops.stem(t(ir).to(dev), w, slope)
         twin = ops.cast_storage(feat, True)
-        assert ops._TWINS[feat.data_ptr()][1] is twin           # written by the stem kernel, not by a cast pass
-    assert torch.equal(feat, ref) and torch.equal(guide, gref)
+        if twin_only:
+            assert twin is feat and feat.dtype == F16
+        else:
+            assert ops._TWINS[feat.data_ptr()][1] is twin           # written by the stem kernel, not by a cast pass
+            assert torch.equal(feat, ref)
+    assert torch.equal(guide, gref)
     assert twin.dtype == F16 and torch.equal(twin, ref.to(F16))
+
+
+@pytest.mark.parametrize("shape", [(1, 24, 32), (2, 64, 96), (1, 37, 53), (1, 480, 640), (3, 100, 201)])
+@pytest.mark.parametrize("engine", ["mfma2", "valu"])
+def test_guided_filter_reads_the_fp16_map(shape, engine, monkeypatch):
+    """paif_guided_filter_fused_fwd_hf16_y16 (round 6): y read as IEEE fp16.  Same result as the fp32-input entry on the map
+    y16.float() (fp16 -> fp32 is exact, the kernels run the same arithmetic): bit-equal fp16 outputs, both engines; odd widths too."""
+    B, H, W = shape
+    dev = _dev()
+    monkeypatch.setenv("PAIF_GF_ENGINE", engine)
+    y = torch.from_numpy(S.make_smooth_feature(11, B, 32, H, W)).permute(0, 2, 3, 1).contiguous().to(dev)
+    y16 = y.to(F16)
+    guide = ops.channel_residue(y)
+    a = ops.guided_filter_pair(guide, y16.float(), out_bf16=F16)
+    b = ops.guided_filter_pair(guide, y16, out_bf16=F16)
+    torch.cuda.synchronize()
+    assert b.dtype == F16 and tuple(b.shape) == (2, B, H, W, 32)
+    assert torch.equal(a, b)
+    with pytest.raises(NotImplementedError):
+        ops.guided_filter_pair(guide, y16)                            # fp32 LF output from an fp16 map is not built
 
 
 @pytest.mark.parametrize("shape", [(1, 24, 32), (2, 64, 96), (1, 37, 53), (1, 480, 640), (3, 100, 200)])
@@ -298,6 +326,23 @@ def _fusion_net():
     net.load_state_dict({k: t(S.formula_tensor("enhance_net." + k, tuple(v.shape))).to(v.dtype) for k, v in net.state_dict().items()},
                         strict=True)
     return net.to(_dev())
+
+
+def test_decomposition_intermediates_forward_under_f16_storage():
+    """forward(ir, vis, inter={"want_decomposition": True}) under set_storage("f16") used to raise (fp32 LF maps handed to fp16
+    packs).  A forward that returns the decomposition intermediates keeps fp32 maps in every storage mode: same result as fp32 storage."""
+    net = _fusion_net()
+    ir, vis, _ = S.make_batch(2, 64, 96)
+    irt, ycc = t(ir).to(_dev()), ops.rgb2ycrcb(t(vis).to(_dev()))
+    a, b = {"want_decomposition": True}, {"want_decomposition": True}
+    with torch.no_grad():
+        ref = net(irt, ycc, inter=a)
+        ops.set_storage("f16")
+        try:
+            out = net(irt, ycc, inter=b)
+        finally:
+            ops.set_storage("f32")
+    assert torch.equal(out, ref) and b["lf_ir"].dtype == torch.float32 and torch.equal(b["lf_ir"], a["lf_ir"]) and torch.equal(b["fir"], a["fir"])
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 96), (1, 48, 64), (1, 480, 640)])
