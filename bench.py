@@ -824,7 +824,7 @@ def parity_block(storage):
         if not out["clause_argmax_ge_0.999"]:
             out["note"] = "this storage mode keeps mIoU within 0.1 pt but NOT the 99.9 % argmax clause; --storage f16 / f32 meet both"
         elif not out["clause_argmax_ge_0.999_on_every_sample"]:
-            out["note"] = ("the 99.9 % clause holds on the 32-sample evaluation set%s, not on every sample taken alone (sample-to-sample spread "
+            out["note"] = ("the 99.9 %% clause holds on the 32-sample evaluation set%s, not on every sample taken alone (sample-to-sample spread "
                            "of a near-tie statistic); --storage f32 holds it on every sample" % (
                                " including the lower end of its bootstrap interval" if out["clause_argmax_ge_0.999_at_the_lower_end_of_the_interval"]
                                else " in aggregate but NOT at the lower end of its bootstrap interval"))
