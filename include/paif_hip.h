@@ -278,6 +278,11 @@ int paif_stem_out_fwd_bf16(const float* x, const float* wpk, const float* prelu,
 /* the same on an fp32 NHWC-32 map (the fp32-storage forward, round 4): x as bf16 hi + lo (2^-17), five MFMAs per k-step -- the operand
  * split of every dense conv of that path; same packed weights. */
 int paif_stem_out_fwd_f32(const float* x, const float* wpk, const float* prelu, float* fused, int B, int H, int W, paif_stream_t stream);
+/* Round 6, range guard of the fp16 storage mode: the same launches (f32in != 0: paif_stem_out_fwd_f32, else _bf16) and `*flag |= 1` when a
+ * pre-tanh value is inf / NaN -- an fp16 map of the forward overflowed (|v| >= 65520 stores inf; convs and residual adds carry it to this
+ * kernel's input; tanh alone would turn it into a finite, wrong +-1).  flag: one 32-bit device word the caller clears and reads. */
+int paif_stem_out_fwd_guard(const float* x, int f32in, const float* wpk, const float* prelu, float* fused, unsigned* flag, int B, int H, int W,
+                            paif_stream_t stream);
 int paif_pack_decomp1x1_weight_bf16x6(const float* w, float* wpk, paif_stream_t stream);
 int paif_pack_decomp1x1_weight_bf16x3(const float* w, float* wpk, paif_stream_t stream);
 /* fp16 forward (round 5): the guided filter writes HF_i = x - LF_i (small magnitudes: 8x less fp16 rounding than LF_i), and the same 1x1

@@ -70,6 +70,7 @@ SIGNATURES = {
     "paif_stem_out_pack": (c_int, [F, F, F, F]),
     "paif_stem_out_fwd_bf16": (c_int, [F, F, F, F, c_int, c_int, c_int, F]),
     "paif_stem_out_fwd_f32": (c_int, [F, F, F, F, c_int, c_int, c_int, F]),
+    "paif_stem_out_fwd_guard": (c_int, [F, c_int, F, F, F, F, c_int, c_int, c_int, F]),
     "paif_pack_decomp1x1_weight_bf16x3": (c_int, [F, F, F]),
     "paif_pack_decomp1x1_hf_weight_f16x2": (c_int, [F, F, F]),
     "paif_pack_decomp1x1_weight_bf16x6": (c_int, [F, F, F]),

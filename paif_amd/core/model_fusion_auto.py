@@ -434,6 +434,8 @@ class Network_Fusion_Searched(nn.Module):
             # inference forward (bf16 maps; since round 4 fp32 maps too): both stem_out convs + PReLU + tanh as one launch pair (csrc/stem_out.hip)
             wso = self._packs.get("so_fused", [so[0].weight, so[1].weight], lambda: ops.stem_out_pack(so[0].weight, so[1].weight))
             return ops.stem_out_fused(feature2, wso, so[2].weight)
+        if ops._ACT_BF16[0] is torch.float16:  # the fp16 range guard rides on the one-kernel form; on this two-launch path a torch reduction feeds it
+            ops.f16_guard_flag(feature2.device).bitwise_or_((~torch.isfinite(feature2).all()).to(torch.int32))
         if feature2.dtype == torch.float32:   # (also the fp32 last map of an fp16-storage forward: a split-bf16 pack whatever the forward's packs are)
             prec = ops.CONFIG["conv_precision"]
             w0 = self._packs.get("so0_" + prec, [so[0].weight], lambda: ops.pack_conv_weight(so[0].weight, 1, 32, 3, precision=prec))

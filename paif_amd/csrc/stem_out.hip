@@ -95,7 +95,7 @@ __global__ void stem_out_ring_pack_kernel(const float* __restrict__ w1, const fl
 template <bool F32IN>
 __global__ __launch_bounds__(256) void stem_out_fused_kernel(const void* __restrict__ xv, const uint4* __restrict__ wpk,
                                                              const float* __restrict__ prelu, float* __restrict__ fused, int B, int H,
-                                                             int W, int tilesX, int tilesY) {
+                                                             int W, int tilesX, int tilesY, unsigned* __restrict__ flag) {
   typedef typename std::conditional<F32IN, float, unsigned short>::type XT;
   const XT* __restrict__ x = reinterpret_cast<const XT*>(xv);
   __shared__ float G[NTAP * GS];
@@ -192,13 +192,17 @@ __global__ __launch_bounds__(256) void stem_out_fused_kernel(const void* __restr
   const int py = y0 + oy, px = x0 + ox;
   const bool ring = py == 0 || py == H - 1 || px == 0 || px == W - 1;           // finished by stem_out_ring_kernel
   if (py < H && px < W) fused[((size_t)b * H + py) * W + px] = ring ? z : tanhf(paif::prelu_f(z, *prelu));
+  // range guard of the fp16 storage mode (paif_stem_out_fwd_f32_guard): tanh maps an overflowed trunk to a FINITE +-1, so the
+  // pre-activation is tested here -- one compare per pixel, an atomic only on the first non-finite value a wave sees
+  if (flag != nullptr && py < H && px < W && !(fabsf(z) <= 3.0e38f)) atomicOr(flag, 1u);
 }
 
 // The outermost pixel ring: raw 5x5 sum (left in `fused` by the kernel above) minus the surplus terms, then PReLU + tanh.
 // 8 lanes per pixel, lane q = channels 4q .. 4q + 3.
 template <bool F32IN>
 __global__ __launch_bounds__(256) void stem_out_ring_kernel(const void* __restrict__ xv, const float* __restrict__ wr,
-                                                            const float* __restrict__ prelu, float* __restrict__ fused, int B, int H, int W) {
+                                                            const float* __restrict__ prelu, float* __restrict__ fused, int B, int H, int W,
+                                                            unsigned* __restrict__ flag) {
   typedef typename std::conditional<F32IN, float, unsigned short>::type XT;
   const XT* __restrict__ x = reinterpret_cast<const XT*>(xv);
   const int q = threadIdx.x & 7;
@@ -240,7 +244,9 @@ __global__ __launch_bounds__(256) void stem_out_ring_kernel(const void* __restri
   c += __shfl_xor(c, 4);
   if (live && q == 0) {
     float* o = fused + ((size_t)b * H + py) * W + px;
-    *o = tanhf(paif::prelu_f(*o - c, *prelu));
+    const float z = *o - c;
+    if (flag != nullptr && !(fabsf(z) <= 3.0e38f)) atomicOr(flag, 1u);
+    *o = tanhf(paif::prelu_f(z, *prelu));
   }
 }
 
@@ -259,7 +265,8 @@ int paif_stem_out_pack(const float* w1, const float* w2, float* wpk, paif_stream
   return 0;
 }
 
-static int stem_out_launch(const void* x, bool f32in, const float* wpk, const float* prelu, float* fused, int B, int H, int W, paif_stream_t stream) {
+static int stem_out_launch(const void* x, bool f32in, const float* wpk, const float* prelu, float* fused, int B, int H, int W, paif_stream_t stream,
+                           unsigned* flag = nullptr) {
   PAIF_REQUIRE(x && wpk && prelu && fused && B > 0, PAIF_EINVAL, "stem_out: bad arguments");
   PAIF_REQUIRE(H >= 3 && W >= 3, PAIF_ENOSUP, "stem_out: %dx%d is smaller than 3x3", H, W);
   const int tilesX = (W + TW - 1) / TW, tilesY = (H + TH - 1) / TH;
@@ -269,13 +276,13 @@ static int stem_out_launch(const void* x, bool f32in, const float* wpk, const fl
   const int ring = B * (2 * W + 2 * (H - 2));
   const dim3 rgrid((unsigned)((ring + 31) / 32));
   if (f32in) {
-    hipLaunchKernelGGL(stem_out_fused_kernel<true>, grid, dim3(256), 0, st, x, reinterpret_cast<const uint4*>(wpk), prelu, fused, B, H, W, tilesX, tilesY);
+    hipLaunchKernelGGL(stem_out_fused_kernel<true>, grid, dim3(256), 0, st, x, reinterpret_cast<const uint4*>(wpk), prelu, fused, B, H, W, tilesX, tilesY, flag);
     PAIF_LAUNCH_CHECK("stem_out(f32)");
-    hipLaunchKernelGGL(stem_out_ring_kernel<true>, rgrid, dim3(256), 0, st, x, wpk + 1536, prelu, fused, B, H, W);
+    hipLaunchKernelGGL(stem_out_ring_kernel<true>, rgrid, dim3(256), 0, st, x, wpk + 1536, prelu, fused, B, H, W, flag);
   } else {
-    hipLaunchKernelGGL(stem_out_fused_kernel<false>, grid, dim3(256), 0, st, x, reinterpret_cast<const uint4*>(wpk), prelu, fused, B, H, W, tilesX, tilesY);
+    hipLaunchKernelGGL(stem_out_fused_kernel<false>, grid, dim3(256), 0, st, x, reinterpret_cast<const uint4*>(wpk), prelu, fused, B, H, W, tilesX, tilesY, flag);
     PAIF_LAUNCH_CHECK("stem_out(bf16)");
-    hipLaunchKernelGGL(stem_out_ring_kernel<false>, rgrid, dim3(256), 0, st, x, wpk + 1536, prelu, fused, B, H, W);
+    hipLaunchKernelGGL(stem_out_ring_kernel<false>, rgrid, dim3(256), 0, st, x, wpk + 1536, prelu, fused, B, H, W, flag);
   }
   PAIF_LAUNCH_CHECK("stem_out ring");
   return 0;
@@ -287,6 +294,15 @@ int paif_stem_out_fwd_bf16(const float* x, const float* wpk, const float* prelu,
 
 int paif_stem_out_fwd_f32(const float* x, const float* wpk, const float* prelu, float* fused, int B, int H, int W, paif_stream_t stream) {
   return stem_out_launch(x, true, wpk, prelu, fused, B, H, W, stream);
+}
+
+// fp16 storage mode's range guard (round 6): as paif_stem_out_fwd_f32 / _bf16 (f32in selects), and *flag |= 1 when any pre-tanh value is
+// inf / NaN.  Every 16-bit map of the forward reaches this kernel's input through convs and residual adds, which keep a non-finite
+// value non-finite; tanh would hide it (tanh(inf) = 1).  flag: one 32-bit word in device memory, cleared by the caller.
+int paif_stem_out_fwd_guard(const float* x, int f32in, const float* wpk, const float* prelu, float* fused, unsigned* flag, int B, int H, int W,
+                            paif_stream_t stream) {
+  PAIF_REQUIRE(flag, PAIF_EINVAL, "stem_out_guard: null flag");
+  return stem_out_launch(x, f32in != 0, wpk, prelu, fused, B, H, W, stream, flag);
 }
 
 }  // extern "C"

@@ -131,10 +131,74 @@ class bf16_activations:
         on = self.enable and CONFIG["storage"] in ("bf16", "bf16_split", "f16") and CONFIG["conv_precision"] == "bf16x3"
         _ACT_BF16[0] = (torch.float16 if CONFIG["storage"] == "f16" else torch.bfloat16) if on else False
 
-    def __exit__(self, *a):
+    def __exit__(self, et, *a):
+        was_f16 = _ACT_BF16[0] is torch.float16
         _ACT_BF16[0] = self.old
         if not self.old:
             _TWINS.clear()
+        if was_f16 and et is None and _F16_GUARD and not torch.cuda.is_current_stream_capturing():
+            _f16_guard_poll(torch.cuda.current_device())
+
+
+# ---- range guard of the fp16 storage mode ----
+# IEEE fp16 stores |v| >= 65520 as inf.  Every 16-bit map of the inference forward reaches the forward's last map through convs and
+# residual adds (`inp + ops(inp)` in every chain), which keep a non-finite value non-finite; the forward ends in tanh, which would turn it
+# into a finite, wrong +-1.  The kernel in front of that tanh (stem_out) ORs one device word when its pre-activation is inf / NaN.
+# The word is read WITHOUT stalling the stream: a forward leaves an async copy + event behind, the next forward (or check_f16_overflow())
+# looks at it.  Formula weights keep every map O(1); a real checkpoint is not known to.
+_F16_GUARD = {}     # device index -> dict(flag=int32[1] device, host=int32[1] pinned, event=Event or None)
+
+
+def f16_guard_flag(device):
+    g = _F16_GUARD.get(device.index)
+    if g is None:
+        g = _F16_GUARD[device.index] = dict(flag=torch.zeros(1, device=device, dtype=torch.int32),
+                                            host=torch.zeros(1, dtype=torch.int32).pin_memory(), event=None, dirty=False)
+    g["dirty"] = True
+    return g["flag"]
+
+
+def _f16_overflow_error():
+    return FloatingPointError("fp16 storage: a 16-bit map of the fusion network's inference forward overflowed IEEE fp16's range (|v| >= 65520 "
+                              "is stored as inf): the fused image of that forward is wrong.  Run this model with ops.set_storage(\"f32\") "
+                              "(or \"bf16\": fp32's exponent range at 8 significant bits)")
+
+
+def _f16_guard_poll(device_index):
+    """End of an fp16-storage forward (not under graph capture): look at the previous forward's copy if it has landed, leave a new one."""
+    g = _F16_GUARD.get(device_index)
+    if g is None or not g["dirty"]:
+        return
+    ev = g["event"]
+    if ev is not None:
+        if not ev.query():
+            return                       # the previous copy is still in flight: no second one queued behind it
+        g["event"] = None
+        if int(g["host"][0]) != 0:
+            g["flag"].zero_()
+            g["host"].zero_()
+            raise _f16_overflow_error()
+    g["host"].copy_(g["flag"], non_blocking=True)
+    g["event"] = torch.cuda.Event()
+    g["event"].record()
+    g["dirty"] = False
+
+
+def check_f16_overflow(device=None):
+    """Synchronous form of the fp16 storage mode's range guard: waits for the stream, raises FloatingPointError if any fp16-storage forward
+    since the last check overflowed (and clears the word).  Call it after a hipGraph replay, at the end of an evaluation loop, in tests."""
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    g = _F16_GUARD.get(idx)
+    if g is None:
+        return
+    torch.cuda.synchronize(idx)
+    g["event"] = None
+    bad = int(g["flag"].item()) != 0 or int(g["host"][0]) != 0
+    g["flag"].zero_()
+    g["host"].zero_()
+    g["dirty"] = False
+    if bad:
+        raise _f16_overflow_error()
 
 
 _TWINS = {}    # data_ptr of an fp32 map -> (the map, its bf16 twin written by the producing kernel); lives for one bf16 forward
@@ -1033,6 +1097,11 @@ def stem_out_fused(x, wpk, prelu):
     B, H, W, C = x.shape
     assert C == 32 and x.dtype in (torch.bfloat16, torch.float32)
     fused = torch.empty((B, 1, H, W), device=x.device, dtype=torch.float32)
+    if _ACT_BF16[0] is torch.float16:     # fp16 storage: the range guard rides on this kernel (f16_guard_flag)
+        flag = f16_guard_flag(x.device)
+        _lib.check(lib().paif_stem_out_fwd_guard(_pa(x), int(x.dtype == torch.float32), _p(wpk), _p(prelu), _p(fused),
+                                                 ctypes.c_void_p(flag.data_ptr()), B, H, W, _stream()), "stem_out_fused")
+        return fused
     fn = lib().paif_stem_out_fwd_bf16 if x.dtype == torch.bfloat16 else lib().paif_stem_out_fwd_f32
     _lib.check(fn(_pa(x), _p(wpk), _p(prelu), _p(fused), B, H, W, _stream()), "stem_out_fused")
     return fused

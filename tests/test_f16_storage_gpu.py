@@ -328,6 +328,51 @@ def _fusion_net():
     return net.to(_dev())
 
 
+@pytest.mark.parametrize("fused_tail", [True, False])
+def test_f16_storage_overflow_guard(fused_tail, monkeypatch):
+    """an fp16 map that overflows (|v| >= 65520 -> inf) must not come out as a finite, wrong fused image (the forward
+    ends in tanh).  A stem weight scaled until the trunk leaves fp16's range:
+    ops.check_f16_overflow() raises FloatingPointError naming set_storage("f32"); the lazy form raises from a later forward without any
+    explicit call; fp32 storage of the same weights and an in-range fp16 forward raise nothing."""
+    net = _fusion_net()
+    ir, vis, _ = S.make_batch(1, 64, 96)
+    irt, ycc = t(ir).to(_dev()), ops.rgb2ycrcb(t(vis).to(_dev()))
+    monkeypatch.setitem(ops.CONFIG, "stem_out_fused_f32", fused_tail)
+    ops.check_f16_overflow()                                   # a clean slate
+    ops.set_storage("f16")
+    try:
+        with torch.no_grad():
+            net(irt, ycc)
+        ops.check_f16_overflow()                               # in range: silent
+        with torch.no_grad():
+            net.stem_1[0].weight.mul_(3e5)
+            out = net(irt, ycc)
+        del out       # (NaN here, +-1 where every overflowed sum keeps one sign: nothing in the output itself is a reliable signal)
+        with pytest.raises(FloatingPointError, match="set_storage"):
+            ops.check_f16_overflow()
+        ops.check_f16_overflow()                               # the word was cleared
+        # lazy form: the forward after the one that overflowed (or the one after that) raises on its own
+        with pytest.raises(FloatingPointError, match="set_storage"):
+            with torch.no_grad():
+                for _ in range(4):
+                    net(irt, ycc)
+                    torch.cuda.synchronize()
+        try:
+            ops.check_f16_overflow()
+        except FloatingPointError:
+            pass
+        ops.set_storage("f32")
+        with torch.no_grad():
+            net(irt, ycc)
+        ops.check_f16_overflow()                               # fp32 storage has the range
+    finally:
+        ops.set_storage("f32")
+        try:
+            ops.check_f16_overflow()
+        except FloatingPointError:
+            pass
+
+
 def test_decomposition_intermediates_forward_under_f16_storage():
     """forward(ir, vis, inter={"want_decomposition": True}) under set_storage("f16") used to raise (fp32 LF maps handed to fp16
     packs).  A forward that returns the decomposition intermediates keeps fp32 maps in every storage mode: same result as fp32 storage."""
