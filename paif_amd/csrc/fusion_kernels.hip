@@ -389,6 +389,93 @@ __global__ __launch_bounds__(256) void spa_blend_kernel(const float* __restrict_
   }
 }
 
+// Round 6, 16-bit maps: the same arithmetic (bit for bit: the 8 tap-subset partial sums of spa_blend_kernel's lanes and its shuffle
+// tree, formed by one thread) on a 4 x 64 pixel tile per workgroup iteration.  spa_blend_kernel has the 8 lanes of a pixel gather the
+// 25 taps of the pooled plane from global memory (4 clamped 16-byte gathers per lane) and move the maps 8 bytes per lane: 7 vector-memory
+// instructions per wave for 8 pixels -- bound by the address unit (139 us at B=8 480x640 for 511 MB: 3.7 TB/s).  Here the (4+4) x (64+4)
+// patch of the pooled plane goes through LDS once (zero padding written there), a thread convolves ONE pixel from it, and the maps
+// move 16 bytes per lane (4 lanes per pixel), all eight loads of a thread issued before the convolution.
+constexpr int SB_TW = 64, SB_TH = 4;
+template <int F>
+__global__ __launch_bounds__(256) void spa_blend_tile_kernel(const float* __restrict__ comp, const float* __restrict__ w,
+                                                             const float* __restrict__ ir, const float* __restrict__ vis,
+                                                             float* __restrict__ agg, int B, int H, int W, int tilesX, int tilesY, int ntiles) {
+  typedef unsigned u32x4_nt __attribute__((ext_vector_type(4)));
+  __shared__ float ws[100];
+  __shared__ float4 ct[SB_TH + 4][SB_TW + 4];
+  __shared__ float sc[SB_TH * SB_TW];
+  const int t = threadIdx.x;
+  if (t < 100) ws[t] = w[t];
+  const unsigned short* ir16 = reinterpret_cast<const unsigned short*>(ir);
+  const unsigned short* vis16 = reinterpret_cast<const unsigned short*>(vis);
+  unsigned short* agg16 = reinterpret_cast<unsigned short*>(agg);
+  const int pc = t >> 2, part = t & 3;                      // blend phase: pixel column of the tile, 8-channel part
+  const int cr = t >> 6, cc = t & 63;                       // convolution phase: this thread's pixel of the tile
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int tx = tile % tilesX;
+    const int r_ = tile / tilesX;
+    const int ty = r_ % tilesY, b = r_ / tilesY;
+    const int y0 = ty * SB_TH, x0 = tx * SB_TW;
+    // the maps: one 16-byte piece per row of the tile and map, all in flight across the convolution (clamped addresses, stores masked)
+    u32x4_nt av[SB_TH], bv[SB_TH];
+    size_t eo[SB_TH];
+    bool ok[SB_TH];
+#pragma unroll
+    for (int p = 0; p < SB_TH; ++p) {
+      const int yy = y0 + p, xx = x0 + pc;
+      ok[p] = yy < H && xx < W;
+      eo[p] = (((size_t)b * H + min(yy, H - 1)) * W + min(xx, W - 1)) * 32 + part * 8;
+      av[p] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt*>(ir16 + eo[p]));
+      bv[p] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt*>(vis16 + eo[p]));
+    }
+    const float* cbase = comp + (size_t)b * H * W * 4;
+    for (int i = t; i < (SB_TH + 4) * (SB_TW + 4); i += 256) {
+      const int r = i / (SB_TW + 4), c = i - r * (SB_TW + 4);
+      const int gy = y0 - 2 + r, gx = x0 - 2 + c;
+      const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+      const float4 v = *reinterpret_cast<const float4*>(cbase + ((size_t)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1)) * 4);
+      ct[r][c] = in ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();   // the patch is in (and every wave has left the previous tile's blend phase: `sc` may be rewritten)
+    {
+      float p8[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) p8[q] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int tap = q + 8 * i;
+          if (tap < 25) {                                    // lane q of spa_blend_kernel: taps q, q + 8, q + 16, (q + 24), in that order
+            const int dy = tap / 5, dx = tap - dy * 5;
+            const float4 c4 = ct[cr + dy][cc + dx];
+            float s_ = p8[q];
+            s_ = fmaf(c4.x, ws[tap], s_); s_ = fmaf(c4.y, ws[25 + tap], s_);
+            s_ = fmaf(c4.z, ws[50 + tap], s_); s_ = fmaf(c4.w, ws[75 + tap], s_);
+            p8[q] = s_;
+          }
+        }
+      const float s_ = ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));   // its xor-shuffle tree
+      sc[t] = 1.0f / (1.0f + expf(-s_));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < SB_TH; ++p) {
+      const float s_ = sc[p * SB_TW + pc], om = 1.0f - s_;
+      const float4 a0 = paif::h4_to_f32<F>(make_uint2(av[p].x, av[p].y)), a1 = paif::h4_to_f32<F>(make_uint2(av[p].z, av[p].w));
+      const float4 b0 = paif::h4_to_f32<F>(make_uint2(bv[p].x, bv[p].y)), b1 = paif::h4_to_f32<F>(make_uint2(bv[p].z, bv[p].w));
+      float4 o0, o1;
+      o0.x = __fadd_rn(__fmul_rn(s_, a0.x), __fmul_rn(om, b0.x)); o0.y = __fadd_rn(__fmul_rn(s_, a0.y), __fmul_rn(om, b0.y));
+      o0.z = __fadd_rn(__fmul_rn(s_, a0.z), __fmul_rn(om, b0.z)); o0.w = __fadd_rn(__fmul_rn(s_, a0.w), __fmul_rn(om, b0.w));
+      o1.x = __fadd_rn(__fmul_rn(s_, a1.x), __fmul_rn(om, b1.x)); o1.y = __fadd_rn(__fmul_rn(s_, a1.y), __fmul_rn(om, b1.y));
+      o1.z = __fadd_rn(__fmul_rn(s_, a1.z), __fmul_rn(om, b1.z)); o1.w = __fadd_rn(__fmul_rn(s_, a1.w), __fmul_rn(om, b1.w));
+      const uint2 u0 = paif::f32_to_h4<F>(o0), u1 = paif::f32_to_h4<F>(o1);
+      const u32x4_nt ov = {u0.x, u0.y, u1.x, u1.y};
+      if (ok[p]) __builtin_nontemporal_store(ov, reinterpret_cast<u32x4_nt*>(agg16 + eo[p]));
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // ECA tail: mean over HxW from the conv's per-tile partials -> conv1d(k) over channels -> sigmoid
 //           -> out = PReLU(o * s[c] + r)
@@ -816,6 +903,16 @@ int channel_pool2_16(const float* ir, const float* vis, float* comp, int B, int 
 template <int F>
 int spa_blend16(const float* comp, const float* w, const float* ir, const float* vis, float* agg, int B, int H, int W, paif_stream_t stream) {
   PAIF_REQUIRE(comp && w && ir && vis && agg && B > 0 && H > 0 && W > 0, PAIF_EINVAL, "spa_blend(16-bit): bad arguments");
+  const char* e_ = getenv("PAIF_SPA_TILED");       // PAIF_SPA_TILED=0: the pixel-per-8-lanes kernel (A/B runs and the bit-equality test; read per call)
+  const bool tiled = !(e_ && e_[0] == '0');
+  const int tilesX = (W + SB_TW - 1) / SB_TW, tilesY = (H + SB_TH - 1) / SB_TH;
+  const long long ntiles = (long long)B * tilesX * tilesY;
+  if (tiled && ntiles < (1ll << 31)) {
+    hipLaunchKernelGGL(spa_blend_tile_kernel<F>, dim3((unsigned)(ntiles < 4096 ? ntiles : 4096)), dim3(256), 0, paif::as_stream(stream), comp, w, ir,
+                       vis, agg, B, H, W, tilesX, tilesY, (int)ntiles);
+    PAIF_LAUNCH_CHECK("spa_blend(16-bit, tiled)");
+    return 0;
+  }
   hipLaunchKernelGGL(spa_blend_kernel<F>, dim3(grid_for((size_t)B * H * W, 32)), dim3(256), 0, paif::as_stream(stream), comp, w, ir, vis, agg,
                      (float*)nullptr, B, H, W);
   PAIF_LAUNCH_CHECK("spa_blend(16-bit)");

@@ -219,6 +219,26 @@ def test_storage_and_pack_precision_must_agree():
         ops.conv2d(xsh, ops.pack_conv_weight(w, 1, 32, 3, precision="f16"), 3, want_aux=True)
 
 
+@pytest.mark.parametrize("dt", [F16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 37, 53), (1, 480, 640), (3, 4, 64), (1, 5, 130), (2, 64, 96)])
+def test_spatial_blend_tiled_kernel_is_bit_equal(shape, dt, monkeypatch):
+    """Round 6: spa_blend on 16-bit maps as a 4 x 64 tile kernel (pooled patch through LDS, 16-byte map pieces) -- the same partial sums and
+    the same summation tree as the pixel-per-8-lanes kernel: bit-identical maps, including ragged tiles."""
+    B, H, W = shape
+    dev = _dev()
+    g = torch.Generator().manual_seed(17 + W)
+    a = ops.to_nhwc(torch.randn(B, 32, H, W, generator=g).to(dev)).to(dt)
+    b = ops.to_nhwc(torch.randn(B, 32, H, W, generator=g).to(dev)).to(dt)
+    comp = ops.channel_pool2(a.float(), b.float())
+    w5 = (torch.randn(1, 4, 5, 5, generator=g) * 0.2).to(dev)
+    monkeypatch.setenv("PAIF_SPA_TILED", "0")
+    ref = ops.spa_blend(comp, w5, a, b)
+    monkeypatch.setenv("PAIF_SPA_TILED", "1")
+    out = ops.spa_blend(comp, w5, a, b)
+    torch.cuda.synchronize()
+    assert out.dtype == dt and torch.equal(out, ref)
+
+
 def test_elementwise_kernels_f16_storage():
     dev = _dev()
     B, H, W = 2, 37, 53
