@@ -14,7 +14,7 @@ the C ABI.  One process per GPU; replicas only (no data-path collective: the pat
 Prints ONE JSON line on rank 0 (contract in the task statement): value = whole-job pairs/s, plus
   roofline     -- dominant kernel family = the dense 3x3 dilation-1 forward convs (12 launches per step): several instantiations picked by
                   source count and storage mode (fp32 storage: conv_bf16x3_res / conv_bf16x3_ms / conv_mfma_bf16x3; 16-bit storage: the
-                  LDS-DMA kernels conv3x3_bf16_dma<NSRC, NRES, format>, format 1 = bf16, 2 = fp16); `roofline` aggregates the family and `roofline.kernels` lists each
+                  LDS-DMA kernels conv3x3_h16_dma<NSRC, NRES, format, CP, DIL, IA>, format 1 = bf16, 2 = fp16; the family is DIL = 1); `roofline` aggregates the family and `roofline.kernels` lists each
                   member under the name rocprofv3 gives it; HIP-event timed on the launch stream inside the timed region.
                   roofline_other: the next kernels by time (guided filter, 7x7, 1x1 ...)
   cpu_baseline -- the CPU oracle (torch fp32 port of the reference) on the host cores, bounded sample, rank 0, N=1 only
@@ -259,8 +259,8 @@ def main():
 
     def family(tag):
         # the dense 3x3 dilation-1 forward convs are one kernel family (instantiations by source count / pool)
-        if tag.startswith("conv3x3_bf16_dma<"):      # the LDS-DMA form (bf16 maps + bf16 weights)
-            return DOMINANT
+        if tag.startswith("conv3x3_h16_dma<"):      # the LDS-DMA form (16-bit maps and weights): dilation 1 is the family, dilation 2 its own row
+            return DOMINANT if re.search(r", 1, \d>$", tag) else tag
         m = re.match(r"conv_(mfma_bf16x3|bf16x3_ms|bf16x3_res|mfma_f32)<3, 1\b(.*)>$", tag)
         if m and "true" not in m.group(2) and not (m.group(1) == "mfma_f32" and ", 16," in tag):
             return DOMINANT
@@ -393,7 +393,7 @@ def main():
             n_, ms_, fl_, by_ = summ[tag]
             tf, gb = fl_ / (ms_ * 1e-3) / 1e12, by_ / (ms_ * 1e-3) / 1e9
             if (tag == DOMINANT and args.conv_precision != "f32") or (
-                    (tag.startswith("conv_") or tag.startswith("conv3x3_bf16_dma") or tag.startswith("conv7x7_bf16_dma")) and ("bf16x3" in tag or "bf16_dma" in tag)):
+                    (tag.startswith("conv_") or tag.startswith("conv3x3_h16_dma") or tag.startswith("conv7x7_h16_dma")) and ("bf16x3" in tag or "h16_dma" in tag)):
                 # split-bf16 convs: 3 bf16 MFMA passes -> effective matrix peak 2500/3 = 833 TF algorithmic; at 72-108 FLOP/B
                 # (fp32 storage, k <= 3) the HBM roof binds (833e12 / 8e12 = 104 FLOP/B); the 5x5 / 7x7 convs (K = 800 / 1568:
                 # 200-390 FLOP/B) are matrix-pipe bound and are priced against the 833 TF algorithmic peak
@@ -410,7 +410,7 @@ def main():
                     if m5:
                         nm = 6 if m5.group(2) == "3" else (3 if m5.group(3) == "1" else ST_MFMAS[int(m5.group(1))])
                     else:
-                        nm = 1 if "bf16_dma" in tag else (ST_MFMAS[int(m_.group(1))] if m_ else 3)
+                        nm = 1 if "h16_dma" in tag else (ST_MFMAS[int(m_.group(1))] if m_ else 3)
                 peak_tf = 2500.0 / nm
                 if fl_ / max(by_, 1) > peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9):
                     blk = {"bound": "mfma", "achieved": tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": tf / peak_tf, "algorithmic_gbs": gb,
@@ -421,7 +421,7 @@ def main():
             elif tag.startswith("gf_") or tag.startswith("gf2_"):
                 blk = {"bound": "hbm", "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS, "algorithmic_tflops": tf,
                        "note": "gf2_kernel (round 4): two columns per lane, two waves per SIMD, horizontal box sums on the matrix cores, vector-issue "
-                               "bound; gf_mfma_kernel (PAIF_GF_ENGINE=mfma): the round-3 engine; gf_fused_kernel (=valu): all-VALU form -- DESIGN.md 7.1"}
+                               "bound; gf_fused_kernel (PAIF_GF_ENGINE=valu): the all-VALU form, also its out-of-range fallback"}
             elif tag.startswith("conv_") or tag.startswith("dense conv"):
                 blk = {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS}
             else:
@@ -711,7 +711,7 @@ def also_block(args, dev, rank):
             n_, ms_, fl_, by_ = summ[tag]
             tf, gb = fl_ / (ms_ * 1e-3) / 1e12, by_ / (ms_ * 1e-3) / 1e9
             peak_tf = (2500.0 / 6 if "bf16x6" in tag or tag.endswith(", 3, 0>") else SPLIT_BF16_PEAK_TFLOPS if ("bf16x3" in tag or "f16x3" in tag) else
-                       2500.0 if "bf16_dma" in tag else MFMA_F32_PEAK_TFLOPS)
+                       2500.0 if "h16_dma" in tag else MFMA_F32_PEAK_TFLOPS)
             out[name] = {"config": cfg, "value": pairs * steps / dt, "unit": "pairs/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
                          "dominant_kernel": {"kernel": tag, "launches_per_step": n_ / steps, "share_of_step": ms_ / (dt * 1e3),
                                              "achieved_tflops": tf, "mfma_peak_tflops": peak_tf, "mfma_frac": tf / peak_tf,

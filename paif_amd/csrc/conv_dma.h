@@ -18,13 +18,16 @@ struct Args {
   int B, H, W, reverse;
   float* cpool;              // optional: fused ChannelPool of the output (paif_conv_desc.cpool); built for (3 sources, 1 or 3 residual maps)
   int f16;                   // 1: the maps and weights are IEEE fp16 (PAIF_ST_F16 / PAIF_CONV_F16; the fp16 hi pieces of the F16X2 pack), else bf16
+  int dil;                   // 1, or 2 (3x3, one source, input ReLU: the composed DilConv)
+  int in_relu;               // 1: ReLU on the source as it is read (dilation 2 only)
 };
 
 // true if the kernel is built for this source / residual count and the tensors fit its 32-bit addressing
 bool eligible(int nsrc, int nres, int B, int H, int W, float alpha);
 bool eligible16(int nsrc, int nres, int B, int H, int W, float alpha);  // 3x3 with 16 output channels: one source, no residual maps
 bool eligible7(int nsrc, int nres, int B, int H, int W, float alpha);   // the 7x7 form: one source, no residual maps
-bool can_cpool(int nsrc, int nres, int kh, int cout);   // the instantiations that write Args::cpool
+bool eligible_d2(int nsrc, int nres, int B, int H, int W, float alpha);  // 3x3 dilation 2 behind an input ReLU: one source, 1 or 3 residual maps
+bool can_cpool(int nsrc, int nres, int kh, int cout, int dil);   // the instantiations that write Args::cpool
 int launch(const Args& a, hipStream_t st);
 
 }  // namespace paif_conv_dma

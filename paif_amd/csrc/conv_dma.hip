@@ -34,10 +34,6 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int TW = 32, TH = 8;          // output tile
-constexpr int TWH = TW + 2, THH = TH + 2;
-constexpr int NPIX = TWH * THH;         // 340 halo pixels x 64 B
-constexpr int DPW = 6;                  // DMA instructions per wave and stage: 4 x 6 x 1 KB = 24 KB >= 21,760 B
-constexpr int SLOT = 4 * DPW * 1024;
 #ifndef CD_PF
 #define CD_PF 4
 #endif
@@ -47,13 +43,26 @@ constexpr int SLOT = 4 * DPW * 1024;
 #ifndef CD_EXP
 #define CD_EXP 0      // experiments (timing only, wrong results): 1 no stores, 2 no MFMAs, 4 no HBM reads (every DMA lane out of range)
 #endif
-constexpr int PF = CD_PF;               // stages in flight ahead of the MFMAs
-constexpr int NSLOT = PF + 1;
-constexpr int ROWB = TWH * 64;          // one halo row in LDS
-constexpr int PARK_OFF = NSLOT * SLOT;  // per-wave [64 px][32 ch] fp32 transposition buffers
-constexpr int PARK_WAVE = 2 * 32 * 32 * 4;
-constexpr int LDS_BYTES = PARK_OFF + 4 * PARK_WAVE;
-static_assert(LDS_BYTES <= 160 * 1024, "ring + transposition buffers exceed LDS");
+constexpr int PARK_WAVE = 2 * 32 * 32 * 4;   // per-wave [64 px][32 ch] fp32 transposition buffer
+// Geometry of the 3x3 kernel by dilation (round 6: DIL = 2 for the composed DilConv of operations_m.py:494-506).  DIL 1: 10 x 34 halo
+// pixels = 21,760 B -> 6 DMAs per wave and stage, 5 ring slots (4 stages ahead).  DIL 2: 12 x 36 = 27,648 B -> 7 DMAs, 4 slots (3 ahead).
+template <int DIL>
+struct Geo {
+  static constexpr int TWH = TW + 2 * DIL, THH = TH + 2 * DIL;
+  static constexpr int NPIX = TWH * THH;                      // halo pixels x 64 B
+  static constexpr int DPW = (NPIX * 4 + 255) / 256;          // DMA instructions per wave and stage (4 waves x 64 lanes x 16 B each)
+  static constexpr int SLOT = 4 * DPW * 1024;
+  static constexpr int PF = DIL == 1 ? CD_PF : 3;             // stages in flight ahead of the MFMAs
+  static constexpr int NSLOT = PF + 1;
+  static constexpr int ROWB = TWH * 64;                       // one halo row in LDS
+  static constexpr int PARK_OFF = NSLOT * SLOT;               // the transposition buffers behind the ring
+  static constexpr int LDS_BYTES = PARK_OFF + 4 * PARK_WAVE;
+  static_assert(LDS_BYTES <= 160 * 1024, "ring + transposition buffers exceed LDS");
+  static_assert(4 * DPW * 64 >= NPIX * 4, "DMA instructions do not cover the halo tile");
+  // the wave's two output rows are `base` and `base + DIL`: their 3 vertical taps read input rows base + DIL * {0, 1, 2, 3} -- four
+  // fragments feed six MFMAs at either dilation (rows 2 w, 2 w + 1 would need six fragments at dilation 2)
+  static __device__ __forceinline__ int base_row(int w) { return DIL == 1 ? 2 * w : (w >> 1) * 4 + (w & 1); }
+};
 constexpr unsigned RSRC_W3 = 0x00020000u;
 constexpr unsigned OOB = 0x80000000u;   // a byte offset no map reaches (checked at launch): the hardware returns 0 / drops the store
 constexpr int NSTORE = 4;               // 16-byte stores per wave and tile (2 rows x 32 px x 64 B)
@@ -71,7 +80,7 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff
 //   (a) s == R_STAGE: 4 x NRES residual loads of tile t + D     (b) 6 DMAs of stage g + PF     (c) s == 0: 4 stores of tile t - 1
 // (the epilogue of a tile runs in the MFMA shadow of the next tile's first stage).  Residual loads are issued just early enough
 // that, by the time they are waited for (stage (t + 1, 0)), every DMA in front of them in the queue has been waited for anyway.
-template <int NSRC, int NRES>
+template <int NSRC, int NRES, int PF, int DPW>
 struct Sched {
   static constexpr int RL = 4 * NRES;
   static constexpr int smod(int x) { return ((x % NSRC) + NSRC) % NSRC; }
@@ -90,16 +99,22 @@ struct Sched {
 // F: 16-bit format of maps and weights (1 bf16, 2 fp16 -- round 5: same data path, v_mfma_f32_32x32x16_f16, fp16 conversions in the epilogue)
 // CP: also write the ChannelPool of the output map (max_c, mean_c of the un-rounded fp32 values) to a.cpool: the 4 lanes of a pixel are a
 // DPP quad -- two quad permutes finish the reduction of a lane's 8 channels; lane 0 of the quad stores 8 bytes
-template <int NSRC, int NRES, int F, bool CP = false>
-__global__ __launch_bounds__(256, 1) void conv3x3_bf16_dma(Args a, int ntiles, int tilesX, int tilesY) {
-  typedef Sched<NSRC, NRES> SC;
+// DIL: dilation (1, 2).  IA: input activation on the A fragments as they arrive from LDS (0 none; 2 ReLU -- max(x, 0) of a stored 16-bit
+// value is a 16-bit value: one v_pk_max_i16 per register, issued behind the MFMA in front of the fragment's first use): the composed
+// DilConv (ReLU -> depthwise 3x3 dilation 2 -> 1x1 -> BN, operations_m.py:494-506, as ONE dense dilated conv) is <1, NRES, F, CP, 2, 2>.
+template <int NSRC, int NRES, int F, bool CP = false, int DIL = 1, int IA = 0>
+__global__ __launch_bounds__(256, 1) void conv3x3_h16_dma(Args a, int ntiles, int tilesX, int tilesY) {
+  typedef Geo<DIL> G;
+  constexpr int TWH = G::TWH, NPIX = G::NPIX, DPW = G::DPW, SLOT = G::SLOT, PF = G::PF, NSLOT = G::NSLOT, ROWB = G::ROWB, PARK_OFF = G::PARK_OFF;
+  typedef Sched<NSRC, NRES, PF, DPW> SC;
   constexpr int U = SC::U, D = SC::D;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS_BYTES];
   asm volatile("" ::"v"((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem) : "memory");   // only asm touches it
 
   const int tid = threadIdx.x, l = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = l & 31, hh = l >> 5;
+  const int wb = G::base_row(w);        // this wave's output rows: wb and wb + DIL
 
   // this workgroup's tiles: XCD x owns the contiguous range [x * tpx, (x + 1) * tpx); its workgroups interleave over it
   const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, nwg = gridDim.x >> 3;
@@ -178,10 +193,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_dma(Args a, int ntiles, i
   auto target = [&](int k) {
     int b, y0, x0;
     const bool ok = tile_of(k, b, y0, x0);
-    const int org = ((b * H + y0 - 1) * W + x0 - 1) * 64;
+    const int org = ((b * H + y0 - DIL) * W + x0 - DIL) * 64;
 #pragma unroll
     for (int i = 0; i < DPW; ++i) {
-      const int gy = y0 - 1 + (d_rc[i] & 0xff), gx = x0 - 1 + (d_rc[i] >> 8);
+      const int gy = y0 - DIL + (d_rc[i] & 0xff), gx = x0 - DIL + (d_rc[i] >> 8);
       const bool in = !(CD_EXP & 4) && ok && d_rc[i] >= 0 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
       d_voff[i] = in ? (unsigned)(org + d_rel[i]) : OOB;
     }
@@ -192,8 +207,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_dma(Args a, int ntiles, i
   for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const int c = p + dx;
-      a_rd[dx][ks] = (unsigned)(2 * w * ROWB + c * 64 + (((2 * ks + hh) ^ ((c >> 2) & 3)) * 16));
+      const int c = p + dx * DIL;
+      a_rd[dx][ks] = (unsigned)(wb * ROWB + c * 64 + (((2 * ks + hh) ^ ((c >> 2) & 3)) * 16));
     }
   // ---- epilogue geometry ----
   const unsigned a_pw = PARK_OFF + w * PARK_WAVE + (4 * hh * 32 + p) * 4;          // + (sg * 32 + (r & 3) + 8 * (r >> 2)) * 128
@@ -209,7 +224,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_dma(Args a, int ntiles, i
     const bool ok = tile_of(k, b, y0, x0);
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-      const int y = y0 + 2 * w + (it >> 1), x = x0 + (it & 1) * 16 + (l >> 2);
+      const int y = y0 + wb + (it >> 1) * DIL, x = x0 + (it & 1) * 16 + (l >> 2);
       const bool in = ok && y < H && x < W;
       const unsigned soff = (unsigned)(((b * H + y) * W + x0 + (it & 1) * 16) * 64);
 #pragma unroll
@@ -217,6 +232,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_dma(Args a, int ntiles, i
     }
   };
 
+  auto relu_frag = [](u32x4& f) {      // max(x, 0) on 8 stored 16-bit values: negative floats are negative int16 (bf16 and fp16 alike)
+    // (one whole-vector max: a per-dword loop over f[d] made hipcc 7.2 form ONE v_pk_max_i16 and splat it over the fragment)
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    f = __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(s16x8, f), z));
+  };
   f32x16 acc[2];
   u32x4 t[4][2];          // a finished tile, transposed: [16-pixel group][channels 0-3 | 4-7 of the lane's 8] fp32 bits
 #pragma unroll
@@ -249,11 +270,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_dma(Args a, int ntiles, i
     } else {
       const uint2 o0 = paif::f32_to_h4<F>(make_float4(ev[0], ev[1], ev[2], ev[3]));
       const uint2 o1 = paif::f32_to_h4<F>(make_float4(ev[4], ev[5], ev[6], ev[7]));
-      const int y = py0 + 2 * w + (it >> 1), x = px0 + (it & 1) * 16 + (l >> 2);
+      const int y = py0 + wb + (it >> 1) * DIL, x = px0 + (it & 1) * 16 + (l >> 2);
       const unsigned soff = (unsigned)(((pb * H + y) * W + px0 + (it & 1) * 16) * opitch);
       u32x4 od = {o0.x, o0.y, o1.x, o1.y};
       __builtin_amdgcn_raw_buffer_store_b128(od, rs_out, (!(CD_EXP & 1) && pok && y < H && x < W) ? o_lane : OOB, soff, CD_ST_AUX);
-      asm volatile("s_nop 2" : "+v"(od));                 // 128-bit store data: WAR hazard hipcc does not pad (gf_mfma.hip)
+      asm volatile("s_nop 2" : "+v"(od));                 // 128-bit store data: WAR hazard hipcc does not pad
       if constexpr (CP) {
         // the lane's 8 channels are in (pmx, psm); the pixel's other three channel groups sit in the other lanes of the DPP quad
         float mx = pmx, sm = psm;
@@ -292,7 +313,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_dma(Args a, int ntiles, i
         }
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) CD_RD128(A[0][r], ad[0][0], r * ROWB);
+      for (int r = 0; r < 4; ++r) CD_RD128(A[0][r], ad[0][0], r * DIL * ROWB);
     }
     // (a) residual maps, D tiles ahead
     if constexpr (NRES > 0 && S == SC::R_STAGE) issue_res(std::integral_constant<int, (K + D) % U>{}, k + D);
@@ -325,6 +346,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_dma(Args a, int ntiles, i
           }
         }
         if constexpr (S == 0) epi(std::integral_constant<int, gi * 6 + dy * 2 + j>{}, std::integral_constant<int, SETP>{}, pok, pb, py0, px0);
+        if constexpr (IA == 2) {      // the fragment the NEXT product reads first: (dy, j) = (0,0) (0,1) (1,0) (1,1) (2,0) (2,1) use fragments 0 1 1 2 2 3
+          constexpr int call = dy * 2 + j;
+          if constexpr (call == 0) relu_frag(A[gi & 1][1]);
+          if constexpr (call == 2) relu_frag(A[gi & 1][2]);
+          if constexpr (call == 4) relu_frag(A[gi & 1][3]);
+        }
         __builtin_amdgcn_sched_barrier(0);
       };
       auto group = [&](auto gitag) {
@@ -332,7 +359,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_dma(Args a, int ntiles, i
         if constexpr (gi + 1 < 6) {
           constexpr int ks1 = (gi + 1) / 3, dx1 = (gi + 1) % 3;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) CD_RD128(A[(gi + 1) & 1][r], ad[dx1][ks1], r * ROWB);
+          for (int r = 0; r < 4; ++r) CD_RD128(A[(gi + 1) & 1][r], ad[dx1][ks1], r * DIL * ROWB);
         }
         if constexpr (S == 0 && gi == 0) {   // LDS operations complete in order: the read-back issued in front of A[0] is in `t` too
           asm volatile("s_waitcnt lgkmcnt(4)"
@@ -343,6 +370,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_dma(Args a, int ntiles, i
         } else {
           asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[gi & 1][0]), "+v"(A[gi & 1][1]), "+v"(A[gi & 1][2]), "+v"(A[gi & 1][3])::"memory");
         }
+        if constexpr (IA == 2) relu_frag(A[gi & 1][0]);
         __builtin_amdgcn_sched_barrier(0);
         typedef std::integral_constant<int, 0> I0;
         typedef std::integral_constant<int, 1> I1;
@@ -457,7 +485,7 @@ static_assert(4 * DPW * 64 >= NPIX * 4, "7x7: DMA instructions do not cover the 
 #define CD_WR128(addr, val, off) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(val), "n"(off) : "memory")
 
 template <int F>
-__global__ __launch_bounds__(256, 1) void conv7x7_bf16_dma(Args a, int ntiles, int tilesX, int tilesY) {
+__global__ __launch_bounds__(256, 1) void conv7x7_h16_dma(Args a, int ntiles, int tilesX, int tilesY) {
   constexpr int P = k7::P, TWH = k7::TWH, NPIX = k7::NPIX, DPW = k7::DPW, SLOT = k7::SLOT, ROWB = k7::ROWB, WB_OFF = k7::WB_OFF,
                 PARK_OFF = k7::PARK_OFF;   // shadow the 3x3 kernel's file-scope constants
   __shared__ __attribute__((aligned(16))) unsigned char smem[k7::LDS_BYTES];
@@ -684,8 +712,8 @@ __global__ __launch_bounds__(256, 1) void conv7x7_bf16_dma(Args a, int ntiles, i
 
 int launch_7(const Args& a, hipStream_t st) {
   const int tilesX = (a.W + TW - 1) / TW, tilesY = (a.H + TH - 1) / TH;
-  if (a.f16) hipLaunchKernelGGL(conv7x7_bf16_dma<2>, dim3(256), dim3(256), 0, st, a, a.B * tilesX * tilesY, tilesX, tilesY);
-  else hipLaunchKernelGGL(conv7x7_bf16_dma<1>, dim3(256), dim3(256), 0, st, a, a.B * tilesX * tilesY, tilesX, tilesY);
+  if (a.f16) hipLaunchKernelGGL(conv7x7_h16_dma<2>, dim3(256), dim3(256), 0, st, a, a.B * tilesX * tilesY, tilesX, tilesY);
+  else hipLaunchKernelGGL(conv7x7_h16_dma<1>, dim3(256), dim3(256), 0, st, a, a.B * tilesX * tilesY, tilesX, tilesY);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     paif::set_error("conv2d(bf16 dma 7x7): launch failed: %s", hipGetErrorString(e));
@@ -699,17 +727,32 @@ int launch_n(const Args& a, hipStream_t st) {
   const int tilesX = (a.W + TW - 1) / TW, tilesY = (a.H + TH - 1) / TH;
   if (a.cpool) {
     if constexpr (NSRC == 3 && (NRES == 1 || NRES == 3)) {      // can_cpool(): the last conv of a ResidualDenseBlock, inside a chain or closing it
-      if (a.f16) hipLaunchKernelGGL((conv3x3_bf16_dma<NSRC, NRES, 2, true>), dim3(256), dim3(256), 0, st, a, a.B * tilesX * tilesY, tilesX, tilesY);
-      else hipLaunchKernelGGL((conv3x3_bf16_dma<NSRC, NRES, 1, true>), dim3(256), dim3(256), 0, st, a, a.B * tilesX * tilesY, tilesX, tilesY);
+      if (a.f16) hipLaunchKernelGGL((conv3x3_h16_dma<NSRC, NRES, 2, true>), dim3(256), dim3(256), 0, st, a, a.B * tilesX * tilesY, tilesX, tilesY);
+      else hipLaunchKernelGGL((conv3x3_h16_dma<NSRC, NRES, 1, true>), dim3(256), dim3(256), 0, st, a, a.B * tilesX * tilesY, tilesX, tilesY);
     } else {
       paif::set_error("conv2d(dma): the fused ChannelPool is built for 3 sources with 1 or 3 residual maps");
       return PAIF_ENOSUP;
     }
-  } else if (a.f16) hipLaunchKernelGGL((conv3x3_bf16_dma<NSRC, NRES, 2>), dim3(256), dim3(256), 0, st, a, a.B * tilesX * tilesY, tilesX, tilesY);
-  else hipLaunchKernelGGL((conv3x3_bf16_dma<NSRC, NRES, 1>), dim3(256), dim3(256), 0, st, a, a.B * tilesX * tilesY, tilesX, tilesY);
+  } else if (a.f16) hipLaunchKernelGGL((conv3x3_h16_dma<NSRC, NRES, 2>), dim3(256), dim3(256), 0, st, a, a.B * tilesX * tilesY, tilesX, tilesY);
+  else hipLaunchKernelGGL((conv3x3_h16_dma<NSRC, NRES, 1>), dim3(256), dim3(256), 0, st, a, a.B * tilesX * tilesY, tilesX, tilesY);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
-    paif::set_error("conv2d(bf16 dma): launch failed: %s", hipGetErrorString(e));
+    paif::set_error("conv2d(h16 dma): launch failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+// dilation 2, one source, input ReLU: the composed DilConv (1 residual map = its own `+ x`; 3 = closing a chain: + the chain's input and
+// the caller's residual, with the fused ChannelPool when asked)
+template <int NRES, bool CP>
+int launch_d2(const Args& a, hipStream_t st) {
+  const int tilesX = (a.W + TW - 1) / TW, tilesY = (a.H + TH - 1) / TH;
+  if (a.f16) hipLaunchKernelGGL((conv3x3_h16_dma<1, NRES, 2, CP, 2, 2>), dim3(256), dim3(256), 0, st, a, a.B * tilesX * tilesY, tilesX, tilesY);
+  else hipLaunchKernelGGL((conv3x3_h16_dma<1, NRES, 1, CP, 2, 2>), dim3(256), dim3(256), 0, st, a, a.B * tilesX * tilesY, tilesX, tilesY);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    paif::set_error("conv2d(h16 dma, dilation 2): launch failed: %s", hipGetErrorString(e));
     return (int)e;
   }
   return 0;
@@ -729,17 +772,38 @@ bool eligible(int nsrc, int nres, int B, int H, int W, float alpha) {
   return tiles >= 1024 && tiles <= 128 * 256 && B < 1024 && H < 2048 * TH && W < 2048 * TW && (long long)B * H * W * 64 < (1ll << 31);
 }
 
+// dilation 2 with an input ReLU: one source, 1 or 3 residual maps (the register file holds the 3 residual sets of PF = 3 next to the pipeline)
+bool eligible_d2(int nsrc, int nres, int B, int H, int W, float alpha) {
+  static const bool on = [] {
+    const char* e = getenv("PAIF_CONV_DMA_D2");   // PAIF_CONV_DMA_D2=0: the register-staged persistent kernel (conv_mfma.hip) for A/B runs
+    return !(e && e[0] == '0');
+  }();
+  return on && nsrc == 1 && (nres == 1 || nres == 3) && eligible(1, 1, B, H, W, alpha);
+}
+
 bool eligible16(int nsrc, int nres, int B, int H, int W, float alpha) { return nsrc == 1 && nres == 0 && eligible(1, 0, B, H, W, alpha); }
 bool eligible7(int nsrc, int nres, int B, int H, int W, float alpha) { return nsrc == 1 && nres == 0 && eligible(1, 0, B, H, W, alpha); }
 
-bool can_cpool(int nsrc, int nres, int kh, int cout) { return kh == 3 && cout == 32 && nsrc == 3 && (nres == 1 || nres == 3); }
+bool can_cpool(int nsrc, int nres, int kh, int cout, int dil) {
+  return kh == 3 && cout == 32 && ((dil == 1 && nsrc == 3 && (nres == 1 || nres == 3)) || (dil == 2 && nsrc == 1 && (nres == 1 || nres == 3)));
+}
 
 int launch(const Args& a, hipStream_t st) {
-  if (a.cpool && !can_cpool(a.nsrc, a.nres, a.kh, a.cout)) {
+  if (a.cpool && !can_cpool(a.nsrc, a.nres, a.kh, a.cout, a.dil)) {
     paif::set_error("conv2d(dma): no fused ChannelPool for this form");
     return PAIF_ENOSUP;
   }
   if (a.kh == 7) return launch_7(a, st);
+  if (a.dil == 2) {
+    if (a.nsrc == 1 && a.in_relu && a.nres == 1) return a.cpool ? launch_d2<1, true>(a, st) : launch_d2<1, false>(a, st);
+    if (a.nsrc == 1 && a.in_relu && a.nres == 3) return a.cpool ? launch_d2<3, true>(a, st) : launch_d2<3, false>(a, st);
+    paif::set_error("conv2d(h16 dma): dilation 2 is built for one source behind an input ReLU with 1 or 3 residual maps");
+    return PAIF_ENOSUP;
+  }
+  if (a.in_relu) {
+    paif::set_error("conv2d(h16 dma): the input ReLU is built for the dilation-2 form");
+    return PAIF_ENOSUP;
+  }
   switch (a.nsrc * 10 + a.nres) {
     case 10: return launch_n<1, 0>(a, st);
     case 11: return launch_n<1, 1>(a, st);

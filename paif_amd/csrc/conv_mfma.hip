@@ -1679,6 +1679,10 @@ static inline ConvVariant bf16x3_variant(const ConvArgs& a, int kh, int dil) {
        (kh == 3 && a.cout == 16 && paif_conv_dma::eligible16(a.nsrc, res_count(a), a.B, a.H, a.W, a.alpha)) ||
        (kh == 7 && a.cout == 32 && paif_conv_dma::eligible7(a.nsrc, res_count(a), a.B, a.H, a.W, a.alpha))))
     return CV_DMA;
+  // round 6: 3x3 dilation 2 behind an input ReLU (the composed DilConv), 16-bit maps in and out, one source, 1 or 3 residual maps
+  if (kh == 3 && dil == 2 && st_h16(a) && a.wl0 && a.in_act == 2 && !a.pool_partial && a.cout == 32 &&
+      paif_conv_dma::eligible_d2(a.nsrc, res_count(a), a.B, a.H, a.W, a.alpha))
+    return CV_DMA;
   if (takes_ws(a, kh, dil)) return CV_WS;
   if (kh == 3 && dil == 1 && !st_is_f16(a)) {    // (fp16 maps: LDS-DMA, persistent or tile-per-workgroup kernel only)
     if (res_eligible(a)) return CV_RES;
@@ -1693,7 +1697,7 @@ static inline ConvVariant bf16x3_variant(const ConvArgs& a, int kh, int dil) {
 // (cout = 32, no gradient hooks); the LDS-DMA kernel for the source / residual counts it instantiates
 static inline bool variant_can_cpool(const ConvArgs& a, int kh, int dil) {
   if (a.cout != 32 || needs_hooks(a)) return false;
-  if (bf16x3_variant(a, kh, dil) == CV_DMA) return paif_conv_dma::can_cpool(a.nsrc, res_count(a), kh, a.cout);
+  if (bf16x3_variant(a, kh, dil) == CV_DMA) return paif_conv_dma::can_cpool(a.nsrc, res_count(a), kh, a.cout, dil);
   return true;
 }
 
@@ -1707,6 +1711,7 @@ int launch_bf16x3_st(const ConvArgs& a, hipStream_t st) {
       d.nsrc = a.nsrc; d.nres = res_count(a); d.act = a.act; d.B = a.B; d.H = a.H; d.W = a.W; d.reverse = a.reverse; d.kh = KH; d.cout = a.cout;
       d.f16 = paif::st_f16(ST) ? 1 : 0;
       d.cpool = a.cpool;
+      d.dil = DIL; d.in_relu = a.in_act == 2 ? 1 : 0;
       return paif_conv_dma::launch(d, st);
     }
     case CV_HOOKS:
@@ -2074,8 +2079,9 @@ int paif_conv2d_kernel_name(const paif_conv_desc* d, int B, int H, int W, char* 
   // the names rocprofv3 prints: every template argument, the storage code last
   switch (bf16x3_variant(a, d->kh, d->dil)) {
     case CV_DMA:
-      if (d->kh == 7) snprintf(buf, buflen, "conv7x7_bf16_dma<%d>", a.st >= 3 ? 2 : 1);
-      else snprintf(buf, buflen, "conv3x3_bf16_dma<%d, %d, %d, %s>", d->nsrc, res_count(a), a.st >= 3 ? 2 : 1, d->cpool ? "true" : "false");
+      if (d->kh == 7) snprintf(buf, buflen, "conv7x7_h16_dma<%d>", a.st >= 3 ? 2 : 1);
+      else snprintf(buf, buflen, "conv3x3_h16_dma<%d, %d, %d, %s, %d, %d>", d->nsrc, res_count(a), a.st >= 3 ? 2 : 1, d->cpool ? "true" : "false",
+                    d->dil, d->dil == 2 ? 2 : 0);
       break;
     case CV_WS: snprintf(buf, buflen, "conv_bf16x3_ws%s<%d, %d, %d>", d->in_act == 2 ? "r" : "", d->kh, d->dil, code); break;
     case CV_RES: snprintf(buf, buflen, "conv_bf16x3_res<%d, %d, %d, %d, %d>", d->kh, d->dil, d->nsrc, PAIF_RES_ROWS, code); break;

@@ -389,6 +389,14 @@ __device__ __forceinline__ void split_store3(char* dst, float4 t4) {
 // magnitude on this path; an overflow shows up as inf / NaN, never silently).
 constexpr float F16X3_WSCALE = 256.f;
 __device__ __forceinline__ void split_store_h(char* dst, float4 t4) {
+#ifdef PAIF_GEMM_NOSPLIT   // timing build (wrong results): what the kernel would cost if its operands arrived pre-split (no split arithmetic)
+  {
+    const unsigned a0 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(t4.x, t4.y)), a1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(t4.z, t4.w));
+    *reinterpret_cast<uint2*>(dst) = make_uint2(a0, a1);
+    *reinterpret_cast<uint2*>(dst + 64) = make_uint2(a0 & 0x03ff03ffu, a1 & 0x03ff03ffu);     // tiny finite "lo" pieces
+    return;
+  }
+#endif
   const _Float16 hx = (_Float16)t4.x, hy = (_Float16)t4.y, hz = (_Float16)t4.z, hw = (_Float16)t4.w;
   const _Float16 lx = (_Float16)(t4.x - (float)hx), ly = (_Float16)(t4.y - (float)hy), lz = (_Float16)(t4.z - (float)hz),
                  lw = (_Float16)(t4.w - (float)hw);

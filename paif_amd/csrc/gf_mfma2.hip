@@ -2,7 +2,7 @@
 // Replaces the reference's two GuidedFilter(4, eps) calls of Cell_Decom.decomposition (core/model_fusion_auto.py:522-535;
 // third-party guided_filter_pytorch.GuidedFilter, algorithm per oracle/shims/guided_filter_pytorch).
 //
-// Same arithmetic as gf_mfma.hip (vertical 9-row windows as in-lane rings of 3-row partial sums, horizontal 9-column sums as f16
+// Same arithmetic as the round-3 engine (tools/parked/gf_mfma.hip: vertical 9-row windows as in-lane rings of 3-row partial sums, horizontal 9-column sums as f16
 // hi/lo band-matrix products on the matrix cores, A / b never touch HBM, both eps in one pass) with a different mapping.  The
 // round-3 kernel ran ONE wave per SIMD (a lane owned 4 columns: 192 registers of ring state, 320 VGPRs + 64 AGPRs) and was bound by
 // that wave's own instruction issue and LDS round trips: 333 instructions per row at ~4 cycles each with nothing else to issue,
@@ -19,7 +19,7 @@
 //     workgroup; entry 0 = 0 serves every out-of-image row and column), so the row loop has no branches;
 //   * masks are buffer range checks: an out-of-image row loads through a zero-length descriptor, an out-of-image column through an
 //     out-of-range offset (both return 0); invalid outputs are dropped the same way.
-// f16 range: as in gf_mfma.hip -- max |v| is tracked, *flag raised, the host wrapper's predicated VALU launch rewrites the output.
+// f16 range: max |v| is tracked, *flag raised, the host wrapper's predicated VALU launch rewrites the output.
 #include <stdint.h>
 #include <type_traits>
 

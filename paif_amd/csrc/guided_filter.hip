@@ -236,7 +236,7 @@ __device__ __forceinline__ void lds_barrier() {
 // its VALU instructions, a fifth of its LDS operations and one of its three divisions per row).
 constexpr int GT = 32, GH = GT + 2 * R;   // 32 x 32 output tile, 40 x 40 halo tile
 // Output: four [B*H*W] planes -- mean_g, 1/(var_g + eps0), 1/(var_g + eps1), 1/n -- each read as 16-byte column groups by the
-// matrix-core kernel (gf_mfma.hip); block 0 also clears the f16-range flag behind the planes.
+// matrix-core kernel (gf_mfma2.hip); block 0 also clears the f16-range flag behind the planes.
 __global__ __launch_bounds__(256) void gf_guide_stats_kernel(const float* __restrict__ guide, float* __restrict__ gs, unsigned* __restrict__ flag,
                                                              float eps0, float eps1, int B, int H, int W, int tilesX, int tilesY) {
   __shared__ float sG[GH][GH + 1];
@@ -490,17 +490,6 @@ __global__ __launch_bounds__(FC * NL) void gf_fused_kernel(const float* __restri
 
 }  // namespace
 
-namespace paif_gf_mfma {
-template <bool AL4, bool BFO>
-__global__ void gf_mfma_kernel(const float* __restrict__ guide, const float* __restrict__ y, const float* __restrict__ planes,
-                               float* __restrict__ lf, unsigned* __restrict__ flag, int B, int H, int W, int nstrip, int nseg, int frows,
-                               int ntiles);
-extern template __global__ void gf_mfma_kernel<true, false>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
-extern template __global__ void gf_mfma_kernel<false, false>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
-extern template __global__ void gf_mfma_kernel<true, true>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
-extern template __global__ void gf_mfma_kernel<false, true>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
-}
-
 namespace paif_gf2 {
 template <int OM>
 __global__ void gf2_kernel(const float* __restrict__ guide, const float* __restrict__ y, const float* __restrict__ planes, float* __restrict__ lf,
@@ -519,15 +508,15 @@ static int gf_fused_launch(const float* guide, const float* y, float* lf, float 
   PAIF_REQUIRE(guide && y && lf && workspace && B > 0, PAIF_EINVAL, "guided_filter_fused: bad arguments");
   PAIF_REQUIRE(H > 2 * R + 1 && W > 2 * R + 1, PAIF_EINVAL, "guided_filter: H,W must exceed 2r+1 = %d (got %dx%d)", K, H, W);
   const int nstrip = (W + FO - 1) / FO;
-  // engine: "mfma" (default; horizontal box sums on the matrix cores, gf_mfma.hip) or "valu" (the all-VALU kernel below, also the
-  // fallback the mfma engine's f16-range flag selects).  PAIF_GF_ENGINE / PAIF_GF_FORM are A/B knobs.
+  // engine: "mfma2" (default; horizontal box sums on the matrix cores, gf_mfma2.hip) or "valu" (the all-VALU kernel below, also the
+  // fallback the matrix-core engine's f16-range flag selects).  PAIF_GF_ENGINE / PAIF_GF_FORM are A/B knobs.
   const char* eng = getenv("PAIF_GF_ENGINE");           // read per call: the tests run every engine in one process
-  // "mfma2" (default, round 4: gf_mfma2.hip, two waves per SIMD) | "mfma" (round 3: gf_mfma.hip, one wave per SIMD) | "valu"
-  int engine = (eng && !strcmp(eng, "valu")) ? 0 : (eng && !strcmp(eng, "mfma")) ? 1 : 2;
+  PAIF_REQUIRE(!(eng && !strcmp(eng, "mfma")), PAIF_ENOSUP,
+               "guided_filter: the round-3 matrix-core engine (PAIF_GF_ENGINE=mfma) left the library in round 6 (tools/parked/gf_mfma.hip)");
+  int engine = (eng && !strcmp(eng, "valu")) ? 0 : 2;
   // the round-4 engine addresses rows with wrapping 32-bit per-lane offsets that the buffer range check filters: every per-image
   // byte size must stay below 2^31 - 2^20
-  if (engine == 2 && ((size_t)(B + 1) * H * W * 128 >= 0x7FF00000ull || (size_t)B * nstrip * H >= 0x7FFFFFFFull)) engine = out_bf16 >= 2 ? 0 : 1;
-  if (out_bf16 >= 2 && engine == 1) engine = 2;     // the fp16 high-frequency output is built for the round-4 engine and the VALU kernel
+  if (engine == 2 && ((size_t)(B + 1) * H * W * 128 >= 0x7FF00000ull || (size_t)B * nstrip * H >= 0x7FFFFFFFull)) engine = 0;   // the all-VALU kernel takes any size
   static const int form = [] {
     const char* e = getenv("PAIF_GF_FORM");
     if (!e) return 0;
@@ -580,39 +569,10 @@ static int gf_fused_launch(const float* guide, const float* y, float* lf, float 
                          rows_per_slot, (int)total_rows);
     PAIF_LAUNCH_CHECK("guided_filter_fused(mfma2)");
   }
-  if (engine == 1) {
-    // one 4-wave workgroup (one wave per SIMD, the whole register file) per CU; a workgroup costs rows + 17 warm-up iterations
-    // (rounded up to 6); tiles x 2 channel halves, the halves of a tile 8 block ids apart (same XCD)
-    int nseg = 1;
-    long best = -1;
-    for (int n = 1; n <= 24 && n <= H; ++n) {
-      const int rows = (H + n - 1) / n;
-      const long blocks = (long)B * nstrip * n * 2;
-      const long cost = ((blocks + 255) / 256) * ((rows + 4 * R + 1 + 5) / 6 * 6);
-      if (best < 0 || cost < best) { best = cost; nseg = n; }
-    }
-    const int frows = (H + nseg - 1) / nseg;
-    const int ntiles = B * nstrip * nseg;
-    const int grid = (ntiles + 7) / 8 * 16;
-    const bool al4 = W % 4 == 0 && W >= 4;
-    if (al4 && !out_bf16)
-      hipLaunchKernelGGL((paif_gf_mfma::gf_mfma_kernel<true, false>), dim3(grid), dim3(256), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip,
-                         nseg, frows, ntiles);
-    else if (!out_bf16)
-      hipLaunchKernelGGL((paif_gf_mfma::gf_mfma_kernel<false, false>), dim3(grid), dim3(256), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip,
-                         nseg, frows, ntiles);
-    else if (al4)
-      hipLaunchKernelGGL((paif_gf_mfma::gf_mfma_kernel<true, true>), dim3(grid), dim3(256), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip,
-                         nseg, frows, ntiles);
-    else
-      hipLaunchKernelGGL((paif_gf_mfma::gf_mfma_kernel<false, true>), dim3(grid), dim3(256), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip,
-                         nseg, frows, ntiles);
-    PAIF_LAUNCH_CHECK("guided_filter_fused(mfma)");
-  }
   int nseg;
   pick(4 * R, resident, zgroups, nseg);
   const int frows = (H + nseg - 1) / nseg;
-  const unsigned* only_if = engine >= 1 ? flag : nullptr;
+  const unsigned* only_if = engine == 2 ? flag : nullptr;
   const dim3 grid(B * nstrip * nseg, 2, zgroups);
   if (form == 0) hipLaunchKernelGGL((gf_fused_kernel<float4, 8>), grid, dim3(FC * 8), 0, st, guide, y, workspace, only_if, lf, B, H, W, nstrip, nseg, frows, out_bf16);
   else if (form == 1) hipLaunchKernelGGL((gf_fused_kernel<float4, 4>), grid, dim3(FC * 4), 0, st, guide, y, workspace, only_if, lf, B, H, W, nstrip, nseg, frows, out_bf16);

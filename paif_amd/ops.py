@@ -681,7 +681,7 @@ def guided_filter_pair(guide, y, eps=(0.001, 0.0001), want_ab=False, out_bf16=Fa
         ws = torch.empty(L.paif_guided_filter_fused_workspace_floats(B, H, W), device=y.device, dtype=torch.float32)
         import os
         eng = os.environ.get("PAIF_GF_ENGINE")
-        tag = ("gf_fused_kernel" if eng == "valu" else "gf_mfma_kernel" if eng == "mfma" else "gf2_kernel") + " (+ gf_guide_stats_kernel)"
+        tag = ("gf_fused_kernel" if eng == "valu" else "gf2_kernel") + " (+ gf_guide_stats_kernel)"
         e0 = TIMER.start(tag) if TIMER is not None else None
         y16 = y.dtype == torch.float16
         if y16 and not hf16:

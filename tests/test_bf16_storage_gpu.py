@@ -147,7 +147,7 @@ def test_conv3x3_bf16_dma_kernel(nsrc, nres, act, shape):
     ref = ops.conv2d(xs32, wpk, 3, res=tuple(rs32), **kw)
     ops.set_storage("bf16")
     d = _lib_desc(xsb, wpk, rsb)
-    assert ops.conv2d_kernel_name(d, B, H, W) == "conv3x3_bf16_dma<%d, %d, 1, false>" % (nsrc, nres)
+    assert ops.conv2d_kernel_name(d, B, H, W) == "conv3x3_h16_dma<%d, %d, 1, false, 1, 0>" % (nsrc, nres)
     out = ops.conv2d(xsb, wpk, 3, res=tuple(rsb), **kw)
     torch.cuda.synchronize()
     assert out.dtype == torch.bfloat16
@@ -176,7 +176,7 @@ def test_conv7x7_bf16_dma_kernel(act, shape):
     ops.set_storage("bf16")
     d = _lib_desc([xb], wpk, [])
     d.kh = 7
-    assert ops.conv2d_kernel_name(d, B, H, W) == "conv7x7_bf16_dma<1>"
+    assert ops.conv2d_kernel_name(d, B, H, W) == "conv7x7_h16_dma<1>"
     out = ops.conv2d([xb], wpk, 7, **kw)
     torch.cuda.synchronize()
     err = (out.float() - ref).abs()

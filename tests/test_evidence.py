@@ -22,7 +22,7 @@ def test_pmc_traffic_record_matches_the_kernel_sources():
         assert v.get("_round") == 6, k
     # the default bench line's dominant family (the LDS-DMA 3x3 convs of the fp16 forward) has its traffic in the record
     f16 = secs["fusion/f16"]
-    dma = [k for k in f16 if k.startswith("conv3x3_bf16_dma<")]
+    dma = [k for k in f16 if k.startswith("conv3x3_h16_dma<")]
     assert len(dma) >= 4 and all(f16[k]["traffic_bytes"] > 0 for k in dma), dma
 
 

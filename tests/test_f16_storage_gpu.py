@@ -80,13 +80,13 @@ def _conv_case(kh, dil, nsrc, nres, cout, B, H, W, seed, wscale=0.05):
 
 
 @pytest.mark.parametrize("kh,dil,nsrc,nres,act,cout,kernel", [
-    (3, 1, 1, 0, 1, 32, "conv3x3_bf16_dma<1, 0, 2, false>"),
-    (3, 1, 1, 1, 0, 32, "conv3x3_bf16_dma<1, 1, 2, false>"),
-    (3, 1, 2, 0, 1, 32, "conv3x3_bf16_dma<2, 0, 2, false>"),
-    (3, 1, 3, 1, 1, 32, "conv3x3_bf16_dma<3, 1, 2, false>"),
-    (3, 1, 3, 3, 2, 32, "conv3x3_bf16_dma<3, 3, 2, false>"),
-    (3, 1, 1, 0, 0, 16, "conv3x3_bf16_dma<1, 0, 2, false>"),          # 32 -> 16 (stem_out.0 of the two-kernel tail)
-    (7, 1, 1, 0, 1, 32, "conv7x7_bf16_dma<2>"),
+    (3, 1, 1, 0, 1, 32, "conv3x3_h16_dma<1, 0, 2, false, 1, 0>"),
+    (3, 1, 1, 1, 0, 32, "conv3x3_h16_dma<1, 1, 2, false, 1, 0>"),
+    (3, 1, 2, 0, 1, 32, "conv3x3_h16_dma<2, 0, 2, false, 1, 0>"),
+    (3, 1, 3, 1, 1, 32, "conv3x3_h16_dma<3, 1, 2, false, 1, 0>"),
+    (3, 1, 3, 3, 2, 32, "conv3x3_h16_dma<3, 3, 2, false, 1, 0>"),
+    (3, 1, 1, 0, 0, 16, "conv3x3_h16_dma<1, 0, 2, false, 1, 0>"),          # 32 -> 16 (stem_out.0 of the two-kernel tail)
+    (7, 1, 1, 0, 1, 32, "conv7x7_h16_dma<2>"),
     (1, 1, 1, 0, 0, 32, "conv_bf16x3_ws<1, 1, 12>"),           # 1x1 stream (wave-specialised)
     (1, 1, 1, 2, 1, 32, "conv_mfma_bf16x3<1, 1, false, 12, 2, 0>"),   # 1x1 with residual maps (tile-per-workgroup kernel)
     (3, 2, 1, 0, 0, 32, "conv_bf16x3_ws<3, 2, 12>"),           # dilation 2 (wave-specialised)
@@ -110,6 +110,50 @@ def test_dense_conv_f16_storage_matches_fp32_storage(kh, dil, nsrc, nres, act, c
     torch.cuda.synchronize()
     assert out.dtype == F16 and ref.dtype == torch.float32
     _close(out, ref, frac=1e-4)
+
+
+@pytest.mark.parametrize("fmt", ["f16", "bf16"])
+@pytest.mark.parametrize("nres", [1, 3])
+@pytest.mark.parametrize("shape", [(2, 333, 517), (1, 480, 640), (4, 96, 100)])
+def test_dilated_conv_behind_a_relu_on_the_lds_dma_kernel(shape, nres, fmt):
+    """Round 6: the composed DilConv -- input ReLU, dense 3x3 dilation 2, affine, 1 or 3 residual maps
+    (operations_m.py:494-506 as one conv) -- on the LDS-DMA kernel conv3x3_h16_dma<1, NRES, F, CP, 2, 2>: 12 x 36 halo tiles, the wave's
+    two output rows two apart (four A fragments feed six MFMAs at dilation 2 as well), ReLU as v_pk_max_i16 on the fragments.  Against the
+    fp32-storage conv on the same (16-bit-representable) values; ragged tiles; both formats."""
+    B, H, W = shape
+    dt = F16 if fmt == "f16" else torch.bfloat16
+    g = torch.Generator().manual_seed(1000 + nres + W)
+    dev = _dev()
+    x32 = ops.cast_storage(ops.cast_storage(ops.to_nhwc(torch.randn(B, 32, H, W, generator=g).to(dev)), dt), torch.float32)
+    r32 = [ops.cast_storage(ops.cast_storage(ops.to_nhwc(torch.randn(B, 32, H, W, generator=g).to(dev)), dt), torch.float32) for _ in range(nres)]
+    xh, rh = ops.cast_storage(x32, dt), [ops.cast_storage(r, dt) for r in r32]
+    w = (torch.randn(32, 32, 3, 3, generator=g) * 0.05).to(dev).to(dt).float()
+    scale, shift = (torch.rand(32, generator=g) + 0.5).to(dev), (torch.randn(32, generator=g) * 0.1).to(dev)
+    kw = dict(dil=2, in_act=ops.ACT_RELU, scale=scale, shift=shift)
+    ref = ops.conv2d([x32], ops.pack_conv_weight(w, 1, 32, 3, precision="bf16x3"), 3, res=tuple(r32), **kw)
+    from paif_amd import _lib
+    old = dict(ops.CONFIG)
+    try:
+        ops.set_storage(fmt)
+        wpk = ops.pack_conv_weight(w, 1, 32, 3, precision="f16" if fmt == "f16" else "bf16x3")
+        d = _lib.ConvDesc()
+        d.storage, d.precision, d.nsrc, d.cin, d.kh, d.dil, d.cout, d.alpha, d.in_act = (3 if fmt == "f16" else 1), (4 if fmt == "f16" else 2), 1, 32, 3, 2, 32, 1.0, 2
+        for i, r in enumerate(rh):
+            d.res[i] = ops._pa(r)
+        big = B * ((H + 7) // 8) * ((W + 31) // 32) >= 1024
+        name = ops.conv2d_kernel_name(d, B, H, W)
+        assert name == ("conv3x3_h16_dma<1, %d, %d, false, 2, 2>" % (nres, 2 if fmt == "f16" else 1) if big else name), name
+        assert big or "h16_dma" not in name
+        out = ops.conv2d([xh], wpk, 3, res=tuple(rh), **kw)
+        torch.cuda.synchronize()
+    finally:
+        ops.CONFIG.update(old)
+    assert out.dtype == dt
+    eps = H_EPS if fmt == "f16" else 2.0 ** -8
+    err = (out.float() - ref).abs()
+    tol = eps * ref.abs() * 1.01 + 1e-5
+    bad = err > tol
+    assert float(bad.float().mean()) < 1e-4 and bool((err <= 2 * tol).all()), (int(bad.sum()), float(err.max()))
 
 
 @pytest.mark.parametrize("kh,dil,nsrc,nres,act,cout", [(3, 1, 1, 0, 1, 32), (3, 1, 2, 1, 1, 32), (3, 1, 3, 2, 0, 32), (1, 1, 3, 0, 0, 32),

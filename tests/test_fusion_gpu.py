@@ -531,12 +531,12 @@ def test_unknown_and_malformed_primitives():
         MixedOp(32, "DilConv_3")
 
 
-@pytest.mark.parametrize("mengine", ["mfma2", "mfma"])
+@pytest.mark.parametrize("mengine", ["mfma2"])
 @pytest.mark.parametrize("shape", [(1, 24, 32), (2, 64, 96), (1, 50, 131), (3, 37, 49), (2, 11, 10), (1, 100, 47), (1, 130, 200), (1, 480, 640),
                                    (1, 1100, 40), (1, 12, 700), (5, 97, 33)])
 def test_guided_filter_matrix_core_engine_vs_valu_engine_and_oracle(shape, mengine):
-    """The matrix-core engines -- csrc/gf_mfma2.hip (round 4, the default: two columns per lane, two waves per SIMD) and
-    csrc/gf_mfma.hip (round 3: four columns per lane, one wave per SIMD); horizontal box sums as f16 hi/lo band-matrix MFMAs --
+    """The matrix-core engine -- csrc/gf_mfma2.hip (round 4: two columns per lane, two waves per SIMD; the round-3 engine it superseded
+    left the library in round 6, tools/parked/gf_mfma.hip); horizontal box sums as f16 hi/lo band-matrix MFMAs --
     against the all-VALU kernel (PAIF_GF_ENGINE=valu) and the float64 oracle, incl. ragged and odd widths, strips hanging over
     the image edge, several row segments, B > 1, the bench shape, an image taller than one run of rows of the round-4 engine (its
     per-iteration 1 / ny table: pieces of <= 1000 rows) and one wider than ten strips.  Core/model_fusion_auto.py:522-535."""
@@ -573,7 +573,7 @@ def test_guided_filter_matrix_core_engine_vs_valu_engine_and_oracle(shape, mengi
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 96), (1, 50, 131), (3, 37, 49), (1, 100, 47), (1, 130, 200)])
-@pytest.mark.parametrize("engine", ["mfma2", "mfma", "valu"])
+@pytest.mark.parametrize("engine", ["mfma2", "valu"])
 def test_guided_filter_bf16_output_is_the_rounded_fp32_output(shape, engine):
     """The bf16-output form of the fused guided filter (paif_guided_filter_fused_fwd_bf16: the bf16 configuration's storage of the two
     low-frequency maps; channel pairs exchanged by DPP and stored as dwords) computes the same fp32 values and rounds them to nearest
@@ -599,7 +599,7 @@ def test_guided_filter_bf16_output_is_the_rounded_fp32_output(shape, engine):
             os.environ["PAIF_GF_ENGINE"] = old
 
 
-@pytest.mark.parametrize("mengine", ["mfma2", "mfma"])
+@pytest.mark.parametrize("mengine", ["mfma2"])
 def test_guided_filter_f16_range_fallback(mengine):
     """A 9-row vertical sum beyond the f16 range (65504) cannot be split into an f16 pair: the matrix-core kernels raise their
     flag and the predicated all-VALU launch behind it rewrites the output -- bit-identical to the VALU engine."""
@@ -665,7 +665,7 @@ def test_standalone_forwards_of_the_import_surface(shape):
 def test_guided_filter_round4_engine_long_runs_of_rows():
     """B = 20 at 480x640: 134,400 strip-rows over 128 workgroup pairs = 1,050 rows per run, more than one piece of the round-4 engine's
     per-iteration table (<= 1,000 rows): every run is walked as two or three pieces (strip boundary and table limit).  Against the
-    round-3 engine, all 20 images."""
+    all-VALU kernel, all 20 images."""
     import os
 
     from paif_amd import ops
@@ -677,7 +677,7 @@ def test_guided_filter_round4_engine_long_runs_of_rows():
     guide = ops.channel_residue(xn)
     old = os.environ.get("PAIF_GF_ENGINE")
     try:
-        os.environ["PAIF_GF_ENGINE"] = "mfma"
+        os.environ["PAIF_GF_ENGINE"] = "valu"
         a = ops.guided_filter_pair(guide, xn).clone()
         os.environ["PAIF_GF_ENGINE"] = "mfma2"
         b = ops.guided_filter_pair(guide, xn).clone()
@@ -696,10 +696,13 @@ def test_guided_filter_round4_engine_long_runs_of_rows():
     ("f32", 3, 2, 1, 3, 2, (2, 333, 517), "conv_mfma_bf16x3<3, 2, false, 0, 2, 0>"),  # DilConv as one dense conv (ReLU input), tile-per-workgroup
     ("f32", 3, 1, 1, 1, 0, (2, 333, 517), "conv_bf16x3_res<3, 1, 1, 4, 0>"),       # resident-weights persistent form
     ("f32", 1, 1, 1, 0, 0, (2, 333, 517), "conv_bf16x3_ws<1, 1, 0>"),              # wave-specialised persistent form (storers pool)
-    ("f16", 3, 1, 3, 3, 0, (2, 333, 517), "conv3x3_bf16_dma<3, 3, 2, false>"),            # LDS-DMA kernel, the shipped genotype's visible chain
-    ("f16", 3, 1, 3, 1, 0, (1, 480, 640), "conv3x3_bf16_dma<3, 1, 2, false>"),
-    ("bf16", 3, 1, 3, 3, 0, (2, 333, 517), "conv3x3_bf16_dma<3, 3, 1, false>"),
-    ("f16", 3, 2, 1, 3, 2, (2, 333, 517), "conv_bf16x3_wsr<3, 2, 12>"),            # the shipped genotype's infrared chain (DilConv)
+    ("f16", 3, 1, 3, 3, 0, (2, 333, 517), "conv3x3_h16_dma<3, 3, 2, false, 1, 0>"),            # LDS-DMA kernel, the shipped genotype's visible chain
+    ("f16", 3, 1, 3, 1, 0, (1, 480, 640), "conv3x3_h16_dma<3, 1, 2, false, 1, 0>"),
+    ("bf16", 3, 1, 3, 3, 0, (2, 333, 517), "conv3x3_h16_dma<3, 3, 1, false, 1, 0>"),
+    ("f16", 3, 2, 1, 3, 2, (2, 333, 517), "conv3x3_h16_dma<1, 3, 2, true, 2, 2>"),   # the shipped genotype's infrared chain (DilConv): LDS-DMA form, round 6
+    ("bf16", 3, 2, 1, 3, 2, (1, 480, 640), "conv3x3_h16_dma<1, 3, 1, true, 2, 2>"),
+    ("f16", 3, 2, 1, 1, 2, (2, 333, 517), "conv3x3_h16_dma<1, 1, 2, true, 2, 2>"),   # DilConv inside a chain
+    ("f16", 3, 2, 1, 3, 2, (1, 64, 96), "conv_bf16x3_wsr<3, 2, 12>"),              # below the LDS-DMA kernel's tile count: the persistent kernel's storers pool
     ("f16", 3, 1, 2, 0, 0, (2, 333, 517), None),                                   # a DMA form without the fused pool: stand-alone pass behind it
     ("f16", 3, 1, 1, 0, 0, (1, 37, 53), "conv_mfma_bf16x3<3, 1, false, 12, 2, 0>"),
 ])
