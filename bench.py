@@ -393,7 +393,7 @@ def main():
             n_, ms_, fl_, by_ = summ[tag]
             tf, gb = fl_ / (ms_ * 1e-3) / 1e12, by_ / (ms_ * 1e-3) / 1e9
             if (tag == DOMINANT and args.conv_precision != "f32") or (
-                    (tag.startswith("conv_") or tag.startswith("conv3x3_h16_dma") or tag.startswith("conv7x7_h16_dma")) and ("bf16x3" in tag or "h16_dma" in tag)):
+                    (tag.startswith("conv_") or tag.startswith("conv3x3_h16_dma") or tag.startswith("conv7x7_h16_dma")) and ("bf16x3" in tag or "bf16x6" in tag or "f16x3" in tag or "h16_dma" in tag)):
                 # split-bf16 convs: 3 bf16 MFMA passes -> effective matrix peak 2500/3 = 833 TF algorithmic; at 72-108 FLOP/B
                 # (fp32 storage, k <= 3) the HBM roof binds (833e12 / 8e12 = 104 FLOP/B); the 5x5 / 7x7 convs (K = 800 / 1568:
                 # 200-390 FLOP/B) are matrix-pipe bound and are priced against the 833 TF algorithmic peak
@@ -403,12 +403,12 @@ def main():
                 # on bf16 maps) / 2 (bf16 maps: the stored operand's low half is zero; or plain bf16 weights on fp32 maps) / 1 (bf16 maps and
                 # plain bf16 weights: --storage bf16) -> 2500/n TF algorithmic peak
                 m_ = re.search(r", (\d+)>$", tag)
-                m5 = re.match(r"conv_mfma_bf16x3<\d, \d, (?:true|false), (\d+), (\d), (\d)>$", tag)   # <KH, DIL, HOOKS, storage code, pieces, fp16 pairs>
+                m5 = re.match(r"conv_mfma_(bf16x3|bf16x6|f16x3)<\d, \d, (?:true|false), (\d+)>$", tag)   # arithmetic, <KH, DIL, HOOKS, storage code>
                 if tag == DOMINANT:
                     nm = {"f32": 3, "bf16_split": 2, "bf16": 1, "f16": 1}[args.storage] if args.workload in ("fusion", "fusion_seg") else 3
                 else:
                     if m5:
-                        nm = 6 if m5.group(2) == "3" else (3 if m5.group(3) == "1" else ST_MFMAS[int(m5.group(1))])
+                        nm = 6 if m5.group(1) == "bf16x6" else (3 if m5.group(1) == "f16x3" else ST_MFMAS[int(m5.group(2))])
                     else:
                         nm = 1 if "h16_dma" in tag else (ST_MFMAS[int(m_.group(1))] if m_ else 3)
                 peak_tf = 2500.0 / nm
@@ -475,17 +475,12 @@ def main():
             total = 0.0
 
             def is_kernel_of(nm, k):
-                if k == nm or k.startswith(nm + "<"):
+                # (round 6: every arithmetic of a templated kernel is a kernel of its own name -- gemm_mfma_{bf16x3,bf16x6,f16x3}<..>,
+                # sr_attention_{bf16x3,bf16x6,f16x3}_kernel<D> -- so a timer tag is a kernel name up to its template arguments)
+                if k == nm or k.startswith(nm + "<") or k.startswith(nm + "_kernel<"):
                     return True
-                # timer tags that name an ARITHMETIC of a templated kernel: gemm_mfma_bf16x3<MASKED, NP, GATHER, PF> and the split attention <D, NP, PF>
-                m = re.match(r"gemm_mfma_bf16x3<(?:true|false), (\d), (?:true|false), (\d)>$", k)
-                if m and nm.startswith("gemm_mfma_"):
-                    return nm == {("2", "0"): "gemm_mfma_bf16x3", ("3", "0"): "gemm_mfma_bf16x6", ("2", "1"): "gemm_mfma_f16x3"}.get((m.group(1), m.group(2)))
                 if nm == "gemm_mfma_f32" and k.startswith("gemm_mfma_f32_serial<"):
                     return True
-                m = re.match(r"sr_attention_split_kernel<\d+, (\d), (\d)>$", k)
-                if m and nm.startswith("sr_attention_"):
-                    return nm == {("2", "0"): "sr_attention_bf16x3", ("3", "0"): "sr_attention_bf16x6", ("2", "1"): "sr_attention_f16x3"}.get((m.group(1), m.group(2)))
                 return nm == "sr_attention" and k.startswith("sr_attention_kernel<")
 
             for nm in names:
@@ -710,7 +705,7 @@ def also_block(args, dev, rank):
             tag = max(summ, key=lambda k: summ[k][1])
             n_, ms_, fl_, by_ = summ[tag]
             tf, gb = fl_ / (ms_ * 1e-3) / 1e12, by_ / (ms_ * 1e-3) / 1e9
-            peak_tf = (2500.0 / 6 if "bf16x6" in tag or tag.endswith(", 3, 0>") else SPLIT_BF16_PEAK_TFLOPS if ("bf16x3" in tag or "f16x3" in tag) else
+            peak_tf = (2500.0 / 6 if "bf16x6" in tag else SPLIT_BF16_PEAK_TFLOPS if ("bf16x3" in tag or "f16x3" in tag) else
                        2500.0 if "h16_dma" in tag else MFMA_F32_PEAK_TFLOPS)
             out[name] = {"config": cfg, "value": pairs * steps / dt, "unit": "pairs/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
                          "dominant_kernel": {"kernel": tag, "launches_per_step": n_ / steps, "share_of_step": ms_ / (dt * 1e3),

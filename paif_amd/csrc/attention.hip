@@ -150,7 +150,7 @@ using paif::mfma_pieces;
 // V^T (D records of NP x KC slots) of a chunk are staged together; the online softmax carries over chunk boundaries as it does
 // over key tiles.  Two pieces x 300 keys x 64 dims fit at once (159,744 B); three pieces take chunks of 160 keys.
 template <int D, int NP, int PF = 0>
-__global__ __launch_bounds__(512) void sr_attention_split_kernel(AttnArgs a, int KC, int krows) {
+__device__ __forceinline__ void sr_attention_split_body(const AttnArgs& a, int KC, int krows) {
   extern __shared__ __align__(16) char ldsc[];
   constexpr int NT = 512;
   constexpr int NO = D / 16;       // K=16 steps of the QK^T contraction
@@ -302,8 +302,19 @@ __global__ __launch_bounds__(512) void sr_attention_split_kernel(AttnArgs a, int
   }
 }
 
+// one kernel name per arithmetic (round 6: rocprofv3 rows need no template-argument decoding): two bf16 pieces (3 MFMAs per product),
+// three bf16 pieces (6), two IEEE fp16 pieces (3, fp32-level)
+template <int D> __global__ __launch_bounds__(512) void sr_attention_bf16x3_kernel(AttnArgs a, int KC, int krows) { sr_attention_split_body<D, 2, 0>(a, KC, krows); }
+template <int D> __global__ __launch_bounds__(512) void sr_attention_bf16x6_kernel(AttnArgs a, int KC, int krows) { sr_attention_split_body<D, 3, 0>(a, KC, krows); }
+template <int D> __global__ __launch_bounds__(512) void sr_attention_f16x3_kernel(AttnArgs a, int KC, int krows) { sr_attention_split_body<D, 2, 1>(a, KC, krows); }
+
 template <int D, int NP, int PF = 0>
 int launch_attn_split(const AttnArgs& a, hipStream_t st) {
+  auto kern = [] {
+    if constexpr (PF == 1) return &sr_attention_f16x3_kernel<D>;
+    else if constexpr (NP == 3) return &sr_attention_bf16x6_kernel<D>;
+    else return &sr_attention_bf16x3_kernel<D>;
+  }();
   // the largest chunk (multiple of 32 keys, at most ceil32(Nk)) whose K rows + V^T records fit the 160 KiB of LDS
   int KC = (a.Nk + 31) & ~31;
   size_t lds_bytes = 0;
@@ -314,14 +325,14 @@ int launch_attn_split(const AttnArgs& a, hipStream_t st) {
   }
   if (KC < 32) { paif::set_error("sr_attention(split): no key chunk fits LDS"); return PAIF_ENOSUP; }
   if (lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sr_attention_split_kernel<D, NP, PF>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) {
       paif::set_error("sr_attention(split): cannot raise dynamic LDS to %zu: %s", lds_bytes, hipGetErrorString(e));
       return (int)e;
     }
   }
-  hipLaunchKernelGGL((sr_attention_split_kernel<D, NP, PF>), dim3((a.N + 255) / 256, a.heads, a.B), dim3(512), lds_bytes, st, a, KC,
+  hipLaunchKernelGGL(kern, dim3((a.N + 255) / 256, a.heads, a.B), dim3(512), lds_bytes, st, a, KC,
                      KC < a.Nk ? KC : a.Nk);
   PAIF_LAUNCH_CHECK("sr_attention(split)");
   return 0;

@@ -142,7 +142,7 @@ struct DqCfg {
 };
 
 template <int D, int NP, int PF = 0>
-__global__ __launch_bounds__(512) void attn_bwd_dq_split_kernel(AttnBwdArgs a) {
+__device__ __forceinline__ void attn_bwd_dq_split_body(const AttnBwdArgs& a) {
   extern __shared__ __align__(16) char ldsc[];
   constexpr int NT = 512;
   constexpr int NO = D / 16, DT = D / 32;
@@ -282,13 +282,23 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_split_kernel(AttnBwdArgs a) {
   }
 }
 
+// one kernel name per arithmetic (see attention.hip)
+template <int D> __global__ __launch_bounds__(512) void attn_bwd_dq_bf16x3_kernel(AttnBwdArgs a) { attn_bwd_dq_split_body<D, 2, 0>(a); }
+template <int D> __global__ __launch_bounds__(512) void attn_bwd_dq_bf16x6_kernel(AttnBwdArgs a) { attn_bwd_dq_split_body<D, 3, 0>(a); }
+template <int D> __global__ __launch_bounds__(512) void attn_bwd_dq_f16x3_kernel(AttnBwdArgs a) { attn_bwd_dq_split_body<D, 2, 1>(a); }
+
 template <int D, int NP, int PF = 0>
 int launch_dq_split(const AttnBwdArgs& a, hipStream_t st) {
   constexpr size_t lds_bytes = DqCfg<D, NP>::lds_bytes;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_split_kernel<D, NP, PF>),
+  auto kern = [] {
+    if constexpr (PF == 1) return &attn_bwd_dq_f16x3_kernel<D>;
+    else if constexpr (NP == 3) return &attn_bwd_dq_bf16x6_kernel<D>;
+    else return &attn_bwd_dq_bf16x3_kernel<D>;
+  }();
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e != hipSuccess) { paif::set_error("sr_attention_bwd(dq split): LDS %zu: %s", lds_bytes, hipGetErrorString(e)); return (int)e; }
-  hipLaunchKernelGGL((attn_bwd_dq_split_kernel<D, NP, PF>), dim3((a.N + 255) / 256, a.heads, a.B), dim3(512), lds_bytes, st, a);
+  hipLaunchKernelGGL(kern, dim3((a.N + 255) / 256, a.heads, a.B), dim3(512), lds_bytes, st, a);
   return 0;
 }
 
@@ -406,7 +416,7 @@ __global__ __launch_bounds__(64 * KG_TILES) void attn_bwd_dkv_kernel(AttnBwdArgs
 // dV^T += dO^T . P), so that the P / dS accumulator registers are the B operands as they stand.
 // ---------------------------------------------------------------------------------------------
 template <int D, int NP, int PF = 0>
-__global__ __launch_bounds__(64 * KG_TILES) void attn_bwd_dkv_split_kernel(AttnBwdArgs a) {
+__device__ __forceinline__ void attn_bwd_dkv_split_body(const AttnBwdArgs& a) {
   constexpr int NO = D / 16, DT = D / 32;
   constexpr int KREC = D * 2 * NP;         // row-major record: NP pieces of D bf16
   constexpr int TREC = 32 * 2 * NP + 16;   // transposed record: NP x 32 slots | pad
@@ -549,6 +559,10 @@ __global__ __launch_bounds__(64 * KG_TILES) void attn_bwd_dkv_split_kernel(AttnB
   }
 }
 
+template <int D> __global__ __launch_bounds__(64 * KG_TILES) void attn_bwd_dkv_bf16x3_kernel(AttnBwdArgs a) { attn_bwd_dkv_split_body<D, 2, 0>(a); }
+template <int D> __global__ __launch_bounds__(64 * KG_TILES) void attn_bwd_dkv_bf16x6_kernel(AttnBwdArgs a) { attn_bwd_dkv_split_body<D, 3, 0>(a); }
+template <int D> __global__ __launch_bounds__(64 * KG_TILES) void attn_bwd_dkv_f16x3_kernel(AttnBwdArgs a) { attn_bwd_dkv_split_body<D, 2, 1>(a); }
+
 __global__ void reduce_slabs_kernel(const float4* __restrict__ partial, float4* __restrict__ out, size_t n4, int nchunk) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     float4 s = partial[i];
@@ -619,9 +633,9 @@ int paif_sr_attention_bwd_input_p(const float* q, const float* kv, const float* 
       if (rc) return rc;
     }
     PAIF_LAUNCH_CHECK("sr_attention_bwd(dq)");
-    if (precision == 3) hipLaunchKernelGGL((attn_bwd_dkv_split_kernel<DD, 3>), kvgrid, kvblk, 0, st, a);
-    else if (precision == 6) hipLaunchKernelGGL((attn_bwd_dkv_split_kernel<DD, 2, 1>), kvgrid, kvblk, 0, st, a);
-    else if (precision == 1) hipLaunchKernelGGL((attn_bwd_dkv_split_kernel<DD, 2>), kvgrid, kvblk, 0, st, a);
+    if (precision == 3) hipLaunchKernelGGL(attn_bwd_dkv_bf16x6_kernel<DD>, kvgrid, kvblk, 0, st, a);
+    else if (precision == 6) hipLaunchKernelGGL(attn_bwd_dkv_f16x3_kernel<DD>, kvgrid, kvblk, 0, st, a);
+    else if (precision == 1) hipLaunchKernelGGL(attn_bwd_dkv_bf16x3_kernel<DD>, kvgrid, kvblk, 0, st, a);
     else hipLaunchKernelGGL(attn_bwd_dkv_kernel<DD>, kvgrid, kvblk, 0, st, a);
     return 0;
   };

@@ -408,7 +408,7 @@ template <int KH, int DIL, bool HOOKS, int ST = 0, int NP = 2, int PF = 0>
 #endif
 // two workgroups per CU (256 VGPRs) for the gradient-hook kernels and the wide halos (k >= 5, dilation 2: at three the
 // staging batch spills 84-220 B/lane and the kernels measure 5-25 % slower), three for the 1x1 / 3x3 dilation-1 kernels
-__global__ __launch_bounds__(NTHREADS, (HOOKS || KH >= 5 || DIL == 2 || NP == 3) ? 2 : PAIF_LB) void conv_mfma_bf16x3(ConvArgs a) {
+__device__ __forceinline__ void conv_mfma_split_body(const ConvArgs& a) {
   constexpr int CIN = 32;
   constexpr int P = DIL * (KH - 1) / 2;
   constexpr int TWH = TW + 2 * P;
@@ -660,6 +660,16 @@ __global__ __launch_bounds__(NTHREADS, (HOOKS || KH >= 5 || DIL == 2 || NP == 3)
   }
 }
 
+// One kernel name per arithmetic of the tile conv (round 6: rocprofv3 rows say what ran): two bf16 pieces (3 MFMAs per product), three
+// bf16 pieces (6), two IEEE fp16 pieces (3, fp32-level); ST = storage code (paif_common.h)
+#define PAIF_CONV_LB(HOOKS, KH, DIL, NP) __launch_bounds__(NTHREADS, ((HOOKS) || (KH) >= 5 || (DIL) == 2 || (NP) == 3) ? 2 : PAIF_LB)
+template <int KH, int DIL, bool HOOKS, int ST = 0>
+__global__ PAIF_CONV_LB(HOOKS, KH, DIL, 2) void conv_mfma_bf16x3(ConvArgs a) { conv_mfma_split_body<KH, DIL, HOOKS, ST, 2, 0>(a); }
+template <int KH, int DIL, bool HOOKS, int ST = 0>
+__global__ PAIF_CONV_LB(HOOKS, KH, DIL, 3) void conv_mfma_bf16x6(ConvArgs a) { conv_mfma_split_body<KH, DIL, HOOKS, ST, 3, 0>(a); }
+template <int KH, int DIL, bool HOOKS, int ST = 0>
+__global__ PAIF_CONV_LB(HOOKS, KH, DIL, 2) void conv_mfma_f16x3(ConvArgs a) { conv_mfma_split_body<KH, DIL, HOOKS, ST, 2, 1>(a); }
+
 template <int KH, int DIL, bool HOOKS, int ST = 0, int NP = 2, int PF = 0>
 int launch_bf16x3_h(const ConvArgs& a, hipStream_t st) {
   constexpr int P = DIL * (KH - 1) / 2;
@@ -667,15 +677,20 @@ int launch_bf16x3_h(const ConvArgs& a, hipStream_t st) {
   constexpr size_t epi_bytes = (size_t)TH * 32 * 32 * 4;
   constexpr size_t lds_bytes = tile_bytes > epi_bytes ? tile_bytes : epi_bytes;
   static_assert(lds_bytes <= 160 * 1024, "tile does not fit LDS");
+  auto kern = [] {
+    if constexpr (PF == 1) return &conv_mfma_f16x3<KH, DIL, HOOKS, ST>;
+    else if constexpr (NP == 3) return &conv_mfma_bf16x6<KH, DIL, HOOKS, ST>;
+    else return &conv_mfma_bf16x3<KH, DIL, HOOKS, ST>;
+  }();
   if (lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_bf16x3<KH, DIL, HOOKS, ST, NP, PF>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) {
       paif::set_error("conv2d(bf16x3): cannot raise dynamic LDS to %zu: %s", lds_bytes, hipGetErrorString(e));
       return (int)e;
     }
   }
-  hipLaunchKernelGGL((conv_mfma_bf16x3<KH, DIL, HOOKS, ST, NP, PF>), dim3(a.nblk), dim3(NTHREADS), lds_bytes, st, a);
+  hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(NTHREADS), lds_bytes, st, a);
   PAIF_LAUNCH_CHECK("conv2d(bf16x3)");
   return 0;
 }
@@ -2061,11 +2076,11 @@ int paif_conv2d_kernel_name(const paif_conv_desc* d, int B, int H, int W, char* 
   a.st = d->storage; a.wl0 = (d->precision == PAIF_CONV_BF16 || d->precision == PAIF_CONV_F16) ? 1 : 0; a.alpha = d->alpha;
   const int code = kernel_st(a);
   if (d->precision == PAIF_CONV_BF16X6 && d->cin == 32) {
-    snprintf(buf, buflen, "conv_mfma_bf16x3<%d, %d, %s, 0, 3, 0>", d->kh, d->dil, needs_hooks(a) ? "true" : "false");
+    snprintf(buf, buflen, "conv_mfma_bf16x6<%d, %d, %s, 0>", d->kh, d->dil, needs_hooks(a) ? "true" : "false");
     return 0;
   }
   if (d->precision == PAIF_CONV_F16X3 && d->cin == 32) {
-    snprintf(buf, buflen, "conv_mfma_bf16x3<%d, %d, %s, 0, 2, 1>", d->kh, d->dil, needs_hooks(a) ? "true" : "false");
+    snprintf(buf, buflen, "conv_mfma_f16x3<%d, %d, %s, 0>", d->kh, d->dil, needs_hooks(a) ? "true" : "false");
     return 0;
   }
   if (d->precision != PAIF_CONV_BF16X3 && d->precision != PAIF_CONV_BF16 && d->precision != PAIF_CONV_F16 && d->precision != PAIF_CONV_F16X2) {
@@ -2086,8 +2101,8 @@ int paif_conv2d_kernel_name(const paif_conv_desc* d, int B, int H, int W, char* 
     case CV_WS: snprintf(buf, buflen, "conv_bf16x3_ws%s<%d, %d, %d>", d->in_act == 2 ? "r" : "", d->kh, d->dil, code); break;
     case CV_RES: snprintf(buf, buflen, "conv_bf16x3_res<%d, %d, %d, %d, %d>", d->kh, d->dil, d->nsrc, PAIF_RES_ROWS, code); break;
     case CV_MS: snprintf(buf, buflen, "conv_bf16x3_ms<%d, %d, %d, %d>", d->kh, d->dil, d->nsrc, code); break;
-    case CV_HOOKS: snprintf(buf, buflen, "conv_mfma_bf16x3<%d, %d, true, %d, 2, 0>", d->kh, d->dil, code); break;
-    default: snprintf(buf, buflen, "conv_mfma_bf16x3<%d, %d, false, %d, 2, 0>", d->kh, d->dil, code); break;
+    case CV_HOOKS: snprintf(buf, buflen, "conv_mfma_bf16x3<%d, %d, true, %d>", d->kh, d->dil, code); break;
+    default: snprintf(buf, buflen, "conv_mfma_bf16x3<%d, %d, false, %d>", d->kh, d->dil, code); break;
   }
   return 0;
 }

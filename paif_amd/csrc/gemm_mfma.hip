@@ -407,7 +407,7 @@ __device__ __forceinline__ void split_store_h(char* dst, float4 t4) {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 template <bool MASKED, int NP = 2, bool GATHER = false, int PF = 0>
-__global__ __launch_bounds__(256, 2) void gemm_mfma_bf16x3(GemmArgs a) {
+__device__ __forceinline__ void gemm_split_body(const GemmArgs& a) {
   static_assert(!(MASKED && GATHER), "the dgrad prologue reads a mask with A's own layout");
   static_assert(PF == 0 || NP == 2, "fp16 pieces come in pairs");
   constexpr int RB = NP == 3 ? 208 : 144;   // bytes per staged row of a 32-wide K tile (shadows the two-piece constant)
@@ -568,6 +568,17 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16x3(GemmArgs a) {
   gemm_finish(a, acc, reinterpret_cast<float*>(sA), m0, n0, wave, hh, p);
 }
 
+// The three arithmetics of the split GEMM as kernels of their own (round 6: a rocprofv3 row names what ran, no template-argument decoding):
+//   gemm_mfma_bf16x3  two bf16 pieces per operand, 3 MFMAs per product (~2^-16)
+//   gemm_mfma_bf16x6  three bf16 pieces, 6 MFMAs (2^-25)
+//   gemm_mfma_f16x3   two IEEE fp16 pieces, 3 MFMAs (~2^-21.5; weight side x 2^8)
+template <bool MASKED, bool GATHER = false>
+__global__ __launch_bounds__(256, 2) void gemm_mfma_bf16x3(GemmArgs a) { gemm_split_body<MASKED, 2, GATHER, 0>(a); }
+template <bool MASKED, bool GATHER = false>
+__global__ __launch_bounds__(256, 2) void gemm_mfma_bf16x6(GemmArgs a) { gemm_split_body<MASKED, 3, GATHER, 0>(a); }
+template <bool MASKED, bool GATHER = false>
+__global__ __launch_bounds__(256, 2) void gemm_mfma_f16x3(GemmArgs a) { gemm_split_body<MASKED, 2, GATHER, 1>(a); }
+
 // split-K second pass: C[m][n] = act(scale[n] * sum_s partial[s][m][n] + shift[n]) (+ res), splits summed in index order
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ partial, int splits,
                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
@@ -624,11 +635,11 @@ extern "C" int paif_gemm_masked_fwd(const float* A, int lda, const float* a_mask
   const dim3 grid(a.nblk), blk(256);
   hipStream_t st = paif::as_stream(stream);
   if (precision == 3) {
-    if (pro) hipLaunchKernelGGL((gemm_mfma_bf16x3<true, 3>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((gemm_mfma_bf16x3<false, 3>), grid, blk, 0, st, a);
+    if (pro) hipLaunchKernelGGL((gemm_mfma_bf16x6<true>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((gemm_mfma_bf16x6<false>), grid, blk, 0, st, a);
   } else if (precision == 6) {
-    if (pro) hipLaunchKernelGGL((gemm_mfma_bf16x3<true, 2, false, 1>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((gemm_mfma_bf16x3<false, 2, false, 1>), grid, blk, 0, st, a);
+    if (pro) hipLaunchKernelGGL((gemm_mfma_f16x3<true>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((gemm_mfma_f16x3<false>), grid, blk, 0, st, a);
   } else if (precision == 1) {
     if (pro) hipLaunchKernelGGL(gemm_mfma_bf16x3<true>, grid, blk, 0, st, a);
     else hipLaunchKernelGGL(gemm_mfma_bf16x3<false>, grid, blk, 0, st, a);
@@ -689,8 +700,8 @@ extern "C" int paif_gemm_splitk_fwd_p(const float* A, int lda, const float* W, c
   hipStream_t st = paif::as_stream(stream);
   PAIF_REQUIRE((size_t)M * lda < ((size_t)1 << 32) && (size_t)N * K < ((size_t)1 << 32), PAIF_ENOSUP,
                "gemm_splitk: operands exceed the 32-bit element offsets");
-  if (precision == 3) hipLaunchKernelGGL((gemm_mfma_bf16x3<false, 3>), dim3(a.nblk, splits), dim3(256), 0, st, a);
-  else if (precision == 6) hipLaunchKernelGGL((gemm_mfma_bf16x3<false, 2, false, 1>), dim3(a.nblk, splits), dim3(256), 0, st, a);
+  if (precision == 3) hipLaunchKernelGGL((gemm_mfma_bf16x6<false>), dim3(a.nblk, splits), dim3(256), 0, st, a);
+  else if (precision == 6) hipLaunchKernelGGL((gemm_mfma_f16x3<false>), dim3(a.nblk, splits), dim3(256), 0, st, a);
   else if (precision == 1) hipLaunchKernelGGL(gemm_mfma_bf16x3<false>, dim3(a.nblk, splits), dim3(256), 0, st, a);
   else hipLaunchKernelGGL(gemm_mfma_f32<false>, dim3(a.nblk, splits), dim3(256), 0, st, a);
   PAIF_LAUNCH_CHECK("gemm_splitk");
@@ -744,9 +755,9 @@ extern "C" int paif_gemm_conv_fwd(const float* x, int B, int H, int W, int Cin, 
     a.wide = (N % 4 == 0) && (ldc % 4 == 0) && ((uintptr_t)out % 16 == 0) && (!res || (ldres % 4 == 0 && (uintptr_t)res % 16 == 0)) &&
              (!scale || (uintptr_t)scale % 16 == 0) && (!shift || (uintptr_t)shift % 16 == 0);
   }
-  if (precision == 3) hipLaunchKernelGGL((gemm_mfma_bf16x3<false, 3, true>), dim3(a.nblk, splits), dim3(256), 0, st, a);
-  else if (precision == 6) hipLaunchKernelGGL((gemm_mfma_bf16x3<false, 2, true, 1>), dim3(a.nblk, splits), dim3(256), 0, st, a);
-  else if (precision == 1) hipLaunchKernelGGL((gemm_mfma_bf16x3<false, 2, true>), dim3(a.nblk, splits), dim3(256), 0, st, a);
+  if (precision == 3) hipLaunchKernelGGL((gemm_mfma_bf16x6<false, true>), dim3(a.nblk, splits), dim3(256), 0, st, a);
+  else if (precision == 6) hipLaunchKernelGGL((gemm_mfma_f16x3<false, true>), dim3(a.nblk, splits), dim3(256), 0, st, a);
+  else if (precision == 1) hipLaunchKernelGGL((gemm_mfma_bf16x3<false, true>), dim3(a.nblk, splits), dim3(256), 0, st, a);
   else hipLaunchKernelGGL(gemm_mfma_f32_serial<true>, dim3(a.nblk), dim3(256), 0, st, a);
   PAIF_LAUNCH_CHECK("gemm_conv");
   if (splits > 1) {
@@ -783,8 +794,8 @@ extern "C" int paif_gemm_col2im_fwd(const float* dY, int lda, const float* Wt, f
   a.sk = sr; a.sH = H; a.sW = W; a.sC = C; a.sOH = OH; a.sOW = OW;
   const dim3 grid(a.nblk), blk(256);
   hipStream_t st = paif::as_stream(stream);
-  if (precision == 3) hipLaunchKernelGGL((gemm_mfma_bf16x3<false, 3>), grid, blk, 0, st, a);
-  else if (precision == 6) hipLaunchKernelGGL((gemm_mfma_bf16x3<false, 2, false, 1>), grid, blk, 0, st, a);
+  if (precision == 3) hipLaunchKernelGGL((gemm_mfma_bf16x6<false>), grid, blk, 0, st, a);
+  else if (precision == 6) hipLaunchKernelGGL((gemm_mfma_f16x3<false>), grid, blk, 0, st, a);
   else if (precision == 1) hipLaunchKernelGGL(gemm_mfma_bf16x3<false>, grid, blk, 0, st, a);
   else if (K <= 160) hipLaunchKernelGGL(gemm_mfma_f32_serial<false>, grid, blk, 0, st, a);
   else hipLaunchKernelGGL(gemm_mfma_f32<false>, grid, blk, 0, st, a);

@@ -223,11 +223,17 @@ def set_conv_precision(mode):
 
 
 def set_attack_precision(mode):
-    """Arithmetic of the attack loops: "exact" (fp32-exact MFMA kernels everywhere), "bf16x6" (convs as three-piece bf16 splits, six
-    MFMAs per product, 2^-25 per product: fp32-level parity at 6/16 of the fp32 MFMA's matrix-pipe time; GEMMs / attention exact) or
-    "fast" (whatever set_conv_precision / set_gemm_precision select -- split-bf16 by default; ~1.5x faster, trajectory diverges)."""
+    """Arithmetic of the attack loops:
+    "fp32level" (the default; stored as its pre-round-6 name "bf16x6", which is still accepted): fp32-level parity at a fraction of the
+        exact kernels' matrix time -- the 32-channel convs, the GEMMs from 2,048 rows up and the attention products on fp16 PAIRS (two
+        fp16 pieces per operand, 3 fp16 MFMAs per product, ~2^-21.5; CONFIG["attack_fwd_f16x3" / "attack_bwd_f16x3" / "attn_f16x3"];
+        with those switches off: three-piece bf16 splits, 6 MFMAs, 2^-25), the smaller GEMMs on the exact fp32 MFMA;
+    "exact": fp32-exact MFMA kernels everywhere;
+    "fast": whatever set_conv_precision / set_gemm_precision select -- split-bf16 by default; ~1.25x faster, the trajectory diverges."""
+    if mode == "fp32level":
+        mode = "bf16x6"
     if mode not in ("exact", "bf16x6", "fast"):
-        raise ValueError("attack precision must be 'exact', 'bf16x6' or 'fast'")
+        raise ValueError("attack precision must be 'exact', 'fp32level' (alias 'bf16x6') or 'fast'")
     CONFIG["attack_precision"] = mode
 
 

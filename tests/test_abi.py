@@ -69,20 +69,20 @@ def test_dense_conv_dispatch_rules_on_the_host():
     assert name(nsrc=1) == "conv_bf16x3_res<3, 1, 1, 4, 0>"
     assert name(nsrc=1, nres=3) == "conv_bf16x3_res<3, 1, 1, 4, 0>"
     assert name(nsrc=1, in_act=1) == "conv_bf16x3_res<3, 1, 1, 4, 0>"
-    assert name(nsrc=1, pool=True) == "conv_mfma_bf16x3<3, 1, false, 0, 2, 0>"
+    assert name(nsrc=1, pool=True) == "conv_mfma_bf16x3<3, 1, false, 0>"
     assert name(nsrc=2) == "conv_bf16x3_ms<3, 1, 2, 0>"
     assert name(nsrc=3, nres=3) == "conv_bf16x3_ms<3, 1, 3, 0>"
-    assert name(nsrc=3, in_act=1) == "conv_mfma_bf16x3<3, 1, false, 0, 2, 0>"        # multi-source form: no input activation
-    assert name(nsrc=1, hooks=True) == "conv_mfma_bf16x3<3, 1, true, 0, 2, 0>"       # dgrad hooks: tile-per-workgroup kernel
+    assert name(nsrc=3, in_act=1) == "conv_mfma_bf16x3<3, 1, false, 0>"        # multi-source form: no input activation
+    assert name(nsrc=1, hooks=True) == "conv_mfma_bf16x3<3, 1, true, 0>"       # dgrad hooks: tile-per-workgroup kernel
     assert name(kh=1, nsrc=3) == "conv_bf16x3_ws<1, 1, 0>"
-    assert name(kh=1, nsrc=3, nres=1) == "conv_mfma_bf16x3<1, 1, false, 0, 2, 0>"
-    assert name(kh=3, dil=2, nsrc=1) == "conv_mfma_bf16x3<3, 2, false, 0, 2, 0>"   # fp32 maps: tile-per-workgroup since round 4 (bf16 maps: below)
-    assert name(kh=3, dil=2, nsrc=2) == "conv_mfma_bf16x3<3, 2, false, 0, 2, 0>"
-    assert name(kh=7) == "conv_mfma_bf16x3<7, 1, false, 0, 2, 0>"
-    assert name(kh=5, dil=2) == "conv_mfma_bf16x3<5, 2, false, 0, 2, 0>"
+    assert name(kh=1, nsrc=3, nres=1) == "conv_mfma_bf16x3<1, 1, false, 0>"
+    assert name(kh=3, dil=2, nsrc=1) == "conv_mfma_bf16x3<3, 2, false, 0>"   # fp32 maps: tile-per-workgroup since round 4 (bf16 maps: below)
+    assert name(kh=3, dil=2, nsrc=2) == "conv_mfma_bf16x3<3, 2, false, 0>"
+    assert name(kh=7) == "conv_mfma_bf16x3<7, 1, false, 0>"
+    assert name(kh=5, dil=2) == "conv_mfma_bf16x3<5, 2, false, 0>"
     # small images: fewer than 1024 / 2048 tiles -> no persistent forms
-    assert name(nsrc=1, B=2, H=64, W=96) == "conv_mfma_bf16x3<3, 1, false, 0, 2, 0>"
-    assert name(kh=1, nsrc=3, B=2, H=64, W=96) == "conv_mfma_bf16x3<1, 1, false, 0, 2, 0>"
+    assert name(nsrc=1, B=2, H=64, W=96) == "conv_mfma_bf16x3<3, 1, false, 0>"
+    assert name(kh=1, nsrc=3, B=2, H=64, W=96) == "conv_mfma_bf16x3<1, 1, false, 0>"
     assert name(nsrc=2, B=2, H=64, W=96) == "conv_bf16x3_ms<3, 1, 2, 0>"      # the multi-source form has no size threshold
     # bf16 activation storage: the same dispatch, the storage code is the kernels' last template argument
     def name_st(st, **kw):
@@ -102,7 +102,7 @@ def test_dense_conv_dispatch_rules_on_the_host():
     assert name_st(2, kh=1, nsrc=3) == "conv_bf16x3_ws<1, 1, 2>"
     assert name_st(1, dil=2) == "conv_bf16x3_ws<3, 2, 1>"
     assert name_st(1, dil=2, in_act=2) == "conv_bf16x3_wsr<3, 2, 1>"            # input ReLU: the composed DilConv of the bf16 forward
-    assert name(kh=3, dil=2, nsrc=1, in_act=2) == "conv_mfma_bf16x3<3, 2, false, 0, 2, 0>"   # fp32 storage: no ReLU form of the persistent kernel
+    assert name(kh=3, dil=2, nsrc=1, in_act=2) == "conv_mfma_bf16x3<3, 2, false, 0>"   # fp32 storage: no ReLU form of the persistent kernel
     # exact arithmetic
     assert name(precision=0) == "conv_mfma_f32<3, 1, 32, false>"
     assert name(precision=0, cin=16, cout=16) == "conv_mfma_f32<3, 1, 16, false>"

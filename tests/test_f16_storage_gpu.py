@@ -88,7 +88,7 @@ def _conv_case(kh, dil, nsrc, nres, cout, B, H, W, seed, wscale=0.05):
     (3, 1, 1, 0, 0, 16, "conv3x3_h16_dma<1, 0, 2, false, 1, 0>"),          # 32 -> 16 (stem_out.0 of the two-kernel tail)
     (7, 1, 1, 0, 1, 32, "conv7x7_h16_dma<2>"),
     (1, 1, 1, 0, 0, 32, "conv_bf16x3_ws<1, 1, 12>"),           # 1x1 stream (wave-specialised)
-    (1, 1, 1, 2, 1, 32, "conv_mfma_bf16x3<1, 1, false, 12, 2, 0>"),   # 1x1 with residual maps (tile-per-workgroup kernel)
+    (1, 1, 1, 2, 1, 32, "conv_mfma_bf16x3<1, 1, false, 12>"),   # 1x1 with residual maps (tile-per-workgroup kernel)
     (3, 2, 1, 0, 0, 32, "conv_bf16x3_ws<3, 2, 12>"),           # dilation 2 (wave-specialised)
     (3, 2, 1, 2, 1, 32, "conv_bf16x3_ws<3, 2, 12>"),
 ])

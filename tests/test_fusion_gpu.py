@@ -166,7 +166,7 @@ def test_dense_conv_persistent_kernel_is_dispatched_and_correct(kh, dil, nsrc, n
     torch.cuda.synchronize()
     # fp32 maps: 1x1 -> the persistent form; dilation-2 3x3 -> the tile-per-workgroup kernel since round 4 (faster inside the forward;
     # the persistent dilation-2 form serves bf16-stored maps: tests/test_bf16_storage_gpu.py)
-    want = "conv_bf16x3_ws<1, 1, 0>" if kh == 1 else "conv_mfma_bf16x3<3, 2, false, 0, 2, 0>"
+    want = "conv_bf16x3_ws<1, 1, 0>" if kh == 1 else "conv_mfma_bf16x3<3, 2, false, 0>"
     assert list(timer.summary()) == [want], list(timer.summary())
     assert maxabs(y.permute(0, 3, 1, 2).cpu(), ref) <= 1e-4 * float(ref.abs().max())
 
@@ -209,7 +209,7 @@ def test_dense_conv_3x3_kernel_variants_are_dispatched_and_correct(nsrc, nres, a
         ops.TIMER = None
     torch.cuda.synchronize()
     y, partial = out if pool else (out, None)
-    want = ("conv_mfma_bf16x3<3, 1, false, 0, 2, 0>" if pool else "conv_bf16x3_res<3, 1, 1, 4, 0>") if nsrc == 1 else "conv_bf16x3_ms<3, 1, %d, 0>" % nsrc
+    want = ("conv_mfma_bf16x3<3, 1, false, 0>" if pool else "conv_bf16x3_res<3, 1, 1, 4, 0>") if nsrc == 1 else "conv_bf16x3_ms<3, 1, %d, 0>" % nsrc
     assert list(timer.summary()) == [want], list(timer.summary())
     sc = float(ref.abs().max())
     assert maxabs(y.permute(0, 3, 1, 2).cpu(), ref) <= 1e-4 * sc
@@ -693,7 +693,7 @@ def test_guided_filter_round4_engine_long_runs_of_rows():
 @pytest.mark.parametrize("storage,kh,dil,nsrc,nres,in_act,shape,kernel", [
     ("f32", 3, 1, 3, 1, 0, (2, 333, 517), "conv_bf16x3_ms<3, 1, 3, 0>"),           # RDB conv3 closing a block inside a chain
     ("f32", 3, 1, 3, 3, 0, (1, 64, 96), "conv_bf16x3_ms<3, 1, 3, 0>"),             # ... closing a chain (+ its residuals), small ragged grid
-    ("f32", 3, 2, 1, 3, 2, (2, 333, 517), "conv_mfma_bf16x3<3, 2, false, 0, 2, 0>"),  # DilConv as one dense conv (ReLU input), tile-per-workgroup
+    ("f32", 3, 2, 1, 3, 2, (2, 333, 517), "conv_mfma_bf16x3<3, 2, false, 0>"),  # DilConv as one dense conv (ReLU input), tile-per-workgroup
     ("f32", 3, 1, 1, 1, 0, (2, 333, 517), "conv_bf16x3_res<3, 1, 1, 4, 0>"),       # resident-weights persistent form
     ("f32", 1, 1, 1, 0, 0, (2, 333, 517), "conv_bf16x3_ws<1, 1, 0>"),              # wave-specialised persistent form (storers pool)
     ("f16", 3, 1, 3, 3, 0, (2, 333, 517), "conv3x3_h16_dma<3, 3, 2, false, 1, 0>"),            # LDS-DMA kernel, the shipped genotype's visible chain
@@ -704,7 +704,7 @@ def test_guided_filter_round4_engine_long_runs_of_rows():
     ("f16", 3, 2, 1, 1, 2, (2, 333, 517), "conv3x3_h16_dma<1, 1, 2, true, 2, 2>"),   # DilConv inside a chain
     ("f16", 3, 2, 1, 3, 2, (1, 64, 96), "conv_bf16x3_wsr<3, 2, 12>"),              # below the LDS-DMA kernel's tile count: the persistent kernel's storers pool
     ("f16", 3, 1, 2, 0, 0, (2, 333, 517), None),                                   # a DMA form without the fused pool: stand-alone pass behind it
-    ("f16", 3, 1, 1, 0, 0, (1, 37, 53), "conv_mfma_bf16x3<3, 1, false, 12, 2, 0>"),
+    ("f16", 3, 1, 1, 0, 0, (1, 37, 53), "conv_mfma_bf16x3<3, 1, false, 12>"),
 ])
 def test_channel_pool_fused_into_the_conv_epilogue(storage, kh, dil, nsrc, nres, in_act, shape, kernel):
     """paif_conv_desc.cpool: ChannelPool of a conv's OUTPUT (max_c, mean_c; core/model_fusion_auto.py:1352-1355) from

@@ -197,8 +197,8 @@ def test_pgd10_gate_with_the_split_gemms_forced_at_this_size(golden, mode):
             ops.TIMER = None
         torch.cuda.synchronize()
         seen = set(timer.summary())
-        x6 = {t for t in seen if t == "gemm_mfma_bf16x6" or t.endswith(", 0, 3, 0>")}
-        h3 = {t for t in seen if t == "gemm_mfma_f16x3" or t.endswith(", 0, 2, 1>")}
+        x6 = {t for t in seen if t == "gemm_mfma_bf16x6" or t.startswith("conv_mfma_bf16x6<")}
+        h3 = {t for t in seen if t == "gemm_mfma_f16x3" or t.startswith("conv_mfma_f16x3<")}
         if mode == "x6_everywhere":
             assert x6 and not h3, seen
         elif mode == "f16x3_forward":
