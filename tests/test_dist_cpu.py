@@ -190,3 +190,40 @@ def test_bench_self_launch_refuses_under_a_profiler_preload():
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 2, (r.returncode, r.stderr[-500:])
     assert "profiler" in r.stderr and '"metric"' not in r.stdout
+
+
+def test_bench_also_child_waits_for_its_parent_and_leaves_quietly():
+    """bench.py measures the `also` block (configs[2]-[4]) in a child process that the headline process starts BEFORE it touches the GPU
+    (a fault there must not lose the headline).  The child imports torch, then blocks on its stdin: end-of-file (the parent
+    died, or never asked) makes it exit 0 without a word and without initialising a GPU."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--also-child"], env=env, input="", capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "", (r.returncode, r.stdout[-300:], r.stderr[-300:])
+    # asked to go on a box without a GPU: one JSON object with the reason, exit 1 -- the parent turns that into also = {"error": ...}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--also-child"], env=env, input="go\n", capture_output=True, text=True,
+                       timeout=300)
+    import json
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode == 1 and "error" in json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_bootstrap_interval_of_the_argmax_clause_is_seeded_and_ordered():
+    """tests/test_f16_storage_gpu.py asserts SURVEY 8(d)'s 99.9 % argmax clause on the LOWER end of a percentile bootstrap over samples:
+    the interval is reproducible (seeded), ordered, contains the aggregate, and widens with the sample-to-sample spread."""
+    import importlib
+    m = importlib.import_module("tests.test_f16_storage_gpu")
+    moved = [280, 342, 104, 85, 169, 541, 100, 125, 64, 45, 289, 148, 147, 66, 277, 134, 196, 205, 155, 68, 67, 100, 376, 143, 124, 111, 292, 154,
+             189, 167, 105, 366]           # the fp16 configuration on MI355X, round 6 (profiles/r06_f16_storage_report.json)
+    lo, med, hi = m._bootstrap_interval(moved)
+    assert (lo, med, hi) == tuple(m._bootstrap_interval(moved))
+    agg = 1.0 - sum(moved) / (32 * 307200.0)
+    assert lo < agg < hi and lo <= med <= hi and abs(med - agg) < 2e-5
+    assert 0.9992 < lo < 0.9994 and 0.9995 < hi < 0.9996
+    lo2, _, hi2 = m._bootstrap_interval([v * 2 if i % 2 else v // 2 for i, v in enumerate(moved)])
+    assert hi2 - lo2 > hi - lo

@@ -22,7 +22,7 @@ def clean(name):
     """rocprofv3 kernel name -> `kernel<template args>` without return type, namespaces and the argument list."""
     n = re.sub(r"^void ", "", name)
     n = re.sub(r"\(anonymous namespace\)::", "", n)
-    n = re.sub(r"^paif_(gf_mfma|gf2|conv_dma)::", "", n)
+    n = re.sub(r"^paif_(gf2|conv_dma)::", "", n)
     m = re.match(r"([A-Za-z_0-9]+(?:<.*?>)?)\(", n)
     return m.group(1) if m else n.split("(")[0]
 
@@ -42,7 +42,7 @@ allrec["_note"] = ("HBM bytes per launch from rocprofv3 --pmc passes of `bench.p
                    "tools/pmc_traffic.py), gfx950 correction applied: traffic = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024, averaged over the launches of "
                    "the kernel; one section per workload key.  kernel_source_sha16 ties a section to the kernel sources it was measured on "
                    "(bench.py reports a stale one as such).")
-sec = {"_kernel_source_sha16": kernel_source_sha16(), "_round": 5}
+sec = {"_kernel_source_sha16": kernel_source_sha16(), "_round": 6}
 for k, d in tot.items():
     if not re.match(r"(conv_|conv3x3_|conv7x7_|gf_|gf2_|gemm_|sr_attention|attn_bwd|dwconv|layernorm|stem_|spa_|eca_|tail_|channel_|head_sum|im2col|col2im|upsample|resize)", k):
         continue
