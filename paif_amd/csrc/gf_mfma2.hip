@@ -98,6 +98,25 @@ __device__ __forceinline__ u32x2 band_operand(int m, int colbase) {
   return d;
 }
 
+// Round 6: TWO quantities per matrix instruction.  v_mfma_f32_16x16x32_f16: lane (n = l & 15, kg = l >> 4) holds B[8 kg + j][n], j = 0 .. 7 =
+// quantity P's fragment (hi c0, hi c1, lo c0, lo c1) then quantity Q's; the band rows i = 0, 1 of every 4-row group select P's four k
+// values, rows i = 2, 3 Q's -- D registers 0, 1 are P's two columns, 2, 3 are Q's (the 16x16x16 form left rows 2, 3 zero): 6 matrix
+// instructions and 6 LDS operations per wave-row instead of 12 + 12.
+#ifndef GF2_PAIRED
+#define GF2_PAIRED 1
+#endif
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ u32x4 band_operand2(int m, int colbase) {
+  const u32x2 d = band_operand((m & ~3) | (m & 1), colbase);       // the two-row pattern of output column 2 (m >> 2) + (m & 1)
+  return (m & 2) ? u32x4{0u, 0u, d[0], d[1]} : u32x4{d[0], d[1], 0u, 0u};
+}
+__device__ __forceinline__ f32x4 band_mfma2(u32x4 a_own, u32x4 b_own, u32x4 a_halo, u32x4 b_halo) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a_own), __builtin_bit_cast(half8, b_own), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a_halo), __builtin_bit_cast(half8, b_halo), acc, 0, 0, 0);
+  return acc;
+}
+
 struct Ring {
   f32x2 p[PF];
   f32x2 a1, a2;
@@ -130,7 +149,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gf2_kernel(const float* __res
                                                      unsigned* __restrict__ flag, int B, int H, int W, int nstrip, int nslots,
                                                      int rows_per_slot, int total_rows) {
   // halo fragments: [parity][quantity][slot = wave + 1; slots 0 and NW + 1 stay zero][lane]
+#if GF2_PAIRED
+  __shared__ u32x4 hbuf[2][NQ / 2][NW + 2][64];                    // pairs (y, g y), (A0, b0), (A1, b1)
+#else
   __shared__ u32x2 hbuf[2][NQ][NW + 2][64];
+#endif
   __shared__ float rny_tab[MAXIT + 8];                             // 1 / ny of the row each iteration outputs; 0 outside the image
   __shared__ float pbuf[2][5][SC];                                  // per-pixel planes of one iteration: g(r), mean_g / rden0 / rden1 (r - 4), g(r - 9)
   __shared__ float tbuf[NW][2][8][16];                              // wave-private output transposition [eps][column][channel]
@@ -153,10 +176,17 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gf2_kernel(const float* __res
   const int lc0 = 8 * q + 2 * g;                        // strip-local first column of this lane
   float vmax = 0.f;
   // zero the two permanent zero slots of both halo buffers
+#if GF2_PAIRED
+  for (int i = tid; i < 2 * (NQ / 2) * 2 * 64; i += 64 * NW) {
+    const int ln = i & 63, sl = (i >> 6) & 1, qq = (i >> 7) % (NQ / 2), par = i / (128 * (NQ / 2));
+    hbuf[par][qq][sl ? NW + 1 : 0][ln] = u32x4{0u, 0u, 0u, 0u};
+  }
+#else
   for (int i = tid; i < 2 * NQ * 2 * 64; i += 64 * NW) {
     const int ln = i & 63, sl = (i >> 6) & 1, qq = (i >> 7) % NQ, par = i / (128 * NQ);
     hbuf[par][qq][sl ? NW + 1 : 0][ln] = u32x2{0u, 0u};
   }
+#endif
   while (run_lo < run_hi) {                              // workgroup-uniform
   const int sidx = run_lo / H;
   const int ybeg = run_lo - sidx * H, yend = min(H, ybeg + min(run_hi - run_lo, MAXIT - 32));
@@ -180,8 +210,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gf2_kernel(const float* __res
   constexpr bool HFO = OM >= 2;                                    // the output is the high-frequency map y - LF as fp16
   constexpr bool Y16 = OM == 3;                                    // y is an fp16 map
   const bool odd = (c & 1) != 0;                                   // BFO: even lanes store column 0, odd lanes column 1 of the channel pair
+#if GF2_PAIRED
+  const u32x4 a_own = band_operand2(l & 15, 2 * (l >> 4));
+  const u32x4 a_halo = band_operand2(l & 15, (l >> 4) < 2 ? -4 + 2 * (l >> 4) : 8 + 2 * ((l >> 4) - 2));
+#else
   const u32x2 a_own = band_operand(l & 15, 2 * (l >> 4));
   const u32x2 a_halo = band_operand(l & 15, (l >> 4) < 2 ? -4 + 2 * (l >> 4) : 8 + 2 * ((l >> 4) - 2));
+#endif
   const int rd_slot = (g < 2 ? q - 1 : q + 1) + 1;                 // left neighbour's right half / right neighbour's left half
   const int rd_lane = l ^ 32;
   const bool has_out = __builtin_amdgcn_readfirstlane((q != 0 && q != NW - 1) ? 1 : 0) != 0;
@@ -355,12 +390,19 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gf2_kernel(const float* __res
     const u32x2 f_b1 = split2(wB1, vmax);
     GF2_ST(1);
 #ifndef GF2_NOLDS       // (diagnostic build without the halo exchange: -DGF2_NOLDS)
+#if GF2_PAIRED
+    const u32x4 p_yg = {f_y[0], f_y[1], f_gy[0], f_gy[1]}, p_0 = {f_a0[0], f_a0[1], f_b0[0], f_b0[1]}, p_1 = {f_a1[0], f_a1[1], f_b1[0], f_b1[1]};
+    hbuf[par][0][q + 1][l] = p_yg;
+    hbuf[par][1][q + 1][l] = p_0;
+    hbuf[par][2][q + 1][l] = p_1;
+#else
     hbuf[par][0][q + 1][l] = f_y;
     hbuf[par][1][q + 1][l] = f_gy;
     hbuf[par][2][q + 1][l] = f_a0;
     hbuf[par][3][q + 1][l] = f_b0;
     hbuf[par][4][q + 1][l] = f_a1;
     hbuf[par][5][q + 1][l] = f_b1;
+#endif
     GF2_ST(2);
     lds_barrier();
 #endif
@@ -370,13 +412,21 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gf2_kernel(const float* __res
 #ifdef GF2_NOLDS
       const u32x2 h_a0 = f_b1, h_b0 = f_a1, h_a1 = f_b0, h_b1 = f_a0;
 #else
+#if !GF2_PAIRED
       const u32x2 h_a0 = hbuf[par][2][rd_slot][rd_lane], h_b0 = hbuf[par][3][rd_slot][rd_lane];
       const u32x2 h_a1 = hbuf[par][4][rd_slot][rd_lane], h_b1 = hbuf[par][5][rd_slot][rd_lane];
 #endif
+#endif
+#if GF2_PAIRED
+      const u32x4 h_0 = hbuf[par][1][rd_slot][rd_lane], h_1 = hbuf[par][2][rd_slot][rd_lane];
+      const f32x4 s_0 = band_mfma2(a_own, p_0, a_halo, h_0), s_1 = band_mfma2(a_own, p_1, a_halo, h_1);
+      const f32x2 s_a0 = {s_0[0], s_0[1]}, s_b0 = {s_0[2], s_0[3]}, s_a1 = {s_1[0], s_1[1]}, s_b1 = {s_1[2], s_1[3]};
+#else
       const f32x2 s_a0 = band_mfma(a_own, f_a0, a_halo, h_a0);
       const f32x2 s_b0 = band_mfma(a_own, f_b0, a_halo, h_b0);
       const f32x2 s_a1 = band_mfma(a_own, f_a1, a_halo, h_a1);
       const f32x2 s_b1 = band_mfma(a_own, f_b1, a_halo, h_b1);
+#endif
       const f32x2 out0 = (s_a0 * g2 + s_b0) * rn2;
       const f32x2 out1 = (s_a1 * g2 + s_b1) * rn2;
 #ifndef GF2_NOSTORE    // (diagnostic build without the stores: -DGF2_NOSTORE)
@@ -415,10 +465,18 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gf2_kernel(const float* __res
 #ifdef GF2_NOLDS
       const u32x2 h_y = f_gy, h_gy = f_y;
 #else
+#if !GF2_PAIRED
       const u32x2 h_y = hbuf[par][0][rd_slot][rd_lane], h_gy = hbuf[par][1][rd_slot][rd_lane];
 #endif
+#endif
+#if GF2_PAIRED
+      const u32x4 h_yg = hbuf[par][0][rd_slot][rd_lane];
+      const f32x4 s_yg = band_mfma2(a_own, p_yg, a_halo, h_yg);
+      const f32x2 s_y = {s_yg[0], s_yg[1]}, s_gy = {s_yg[2], s_yg[3]};
+#else
       const f32x2 s_y = band_mfma(a_own, f_y, a_halo, h_y);
       const f32x2 s_gy = band_mfma(a_own, f_gy, a_halo, h_gy);
+#endif
       const f32x2 my = s_y * rn;                         // rn = 0 outside the image: the coefficients there are zero padding
       const f32x2 cov = s_gy * rn - mg1 * my;
       const f32x2 A0 = cov * rd0, A1 = cov * rd1;
