@@ -534,7 +534,10 @@ int paif_spa_blend_bwd_input(const float* dagg, const float* w, const float* ir,
                              const float* add_ir, const float* add_vis, float* dpre, float* d_ir, float* d_vis,
                              int B, int H, int W, paif_stream_t stream);
 /* backward of the guided-filter pair (+ get_residue): dlf [2][B,H,W,32] -> dy [B,H,W,32] (guide gradient routed to
- * the arg-max/arg-min channels; + optional add).  gstat [B,H,W,2], t_my/t_mgy [B,H,W,32], t_g [B,H,W,4]: scratch. */
+ * the arg-max/arg-min channels; + optional add).  Scratch: gstat = paif_guided_filter_fused_workspace_floats(B,H,W) floats
+ * (the forward's per-pixel guide statistics), t_my/t_mgy [B,H,W,32], t_g [B,H,W,4].  Round 6: both eps in one stage-1
+ * launch, 48-column strips walked as runs of rows (csrc/gf_backward.hip); environment PAIF_GF_BWD=v1 selects the round-1
+ * kernels (csrc/fusion_backward.hip), which also take the sizes whose row offsets do not fit 32 bits. */
 int paif_guided_filter_bwd_input(const float* guide, const float* y, const float* ab, const float* dlf, float eps0,
                                  float eps1, const float* add, float* gstat, float* t_my, float* t_mgy, float* t_g,
                                  float* dy, int B, int H, int W, paif_stream_t stream);

@@ -661,9 +661,12 @@ int paif_spa_blend_bwd_input(const float* dagg, const float* w, const float* ir,
   return 0;
 }
 
-int paif_guided_filter_bwd_input(const float* guide, const float* y, const float* ab, const float* dlf, float eps0, float eps1,
-                                 const float* add, float* gstat, float* t_my, float* t_mgy, float* t_g, float* dy, int B, int H,
-                                 int W, paif_stream_t stream) {
+// the round-1 form (32-column strips x 60-row segments, one eps per stage-1 launch); since round 6 the cross-check and the
+// any-size fallback of gf_backward.hip's paif_guided_filter_bwd_input (PAIF_GF_BWD=v1).  gstat: [B,H,W,2] of the caller's workspace.
+__attribute__((visibility("hidden"))) int paifi_gf_bwd_input_v1(const float* guide, const float* y, const float* ab, const float* dlf,
+                                                                float eps0, float eps1, const float* add, float* gstat, float* t_my,
+                                                                float* t_mgy, float* t_g, float* dy, int B, int H, int W,
+                                                                paif_stream_t stream) {
   PAIF_REQUIRE(guide && y && ab && dlf && gstat && t_my && t_mgy && t_g && dy && B > 0, PAIF_EINVAL, "guided_filter_bwd: bad arguments");
   PAIF_REQUIRE(H > 2 * R + 1 && W > 2 * R + 1, PAIF_EINVAL, "guided_filter_bwd: H,W must exceed 9");
   hipStream_t st = paif::as_stream(stream);

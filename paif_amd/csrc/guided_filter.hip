@@ -500,6 +500,17 @@ extern template __global__ void gf2_kernel<2>(const float*, const float*, const 
 extern template __global__ void gf2_kernel<3>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
 }
 
+// The statistics launch alone: the reverse pass (gf_backward.hip) reads the same planes.  workspace: as below.
+extern "C" __attribute__((visibility("hidden"))) int paifi_gf_guide_stats(const float* guide, float* workspace, float eps0, float eps1, int B,
+                                                                          int H, int W, paif_stream_t stream) {
+  const size_t npix = (size_t)B * H * W;
+  const int gtx = (W + GT - 1) / GT, gty = (H + GT - 1) / GT;
+  hipLaunchKernelGGL(gf_guide_stats_kernel, dim3(B * gtx * gty), dim3(256), 0, paif::as_stream(stream), guide, workspace,
+                     reinterpret_cast<unsigned*>(workspace + 4 * npix), eps0, eps1, B, H, W, gtx, gty);
+  PAIF_LAUNCH_CHECK("guided_filter(stats)");
+  return 0;
+}
+
 // workspace: four per-pixel planes + one 256-byte line holding the f16-range flag
 extern "C" size_t paif_guided_filter_fused_workspace_floats(int B, int H, int W) { return (size_t)4 * B * H * W + 64; }
 

@@ -1064,7 +1064,9 @@ def dwconv_bwd(dt, w, k, dil, aux=None, add=None):
 def guided_filter_bwd(guide, y, ab, dlf, eps=(0.001, 0.0001), add=None):
     B, H, W, _ = y.shape
     dev = y.device
-    gstat = torch.empty((B, H, W, 2), device=dev, dtype=torch.float32)
+    # per-pixel guide statistics: the fused forward's workspace (planes mean_g, 1/(var+eps_e), 1/n + the flag line); the round-1
+    # kernels (PAIF_GF_BWD=v1, sizes beyond the streaming form's 32-bit offsets) use its first 2 floats per pixel
+    gstat = torch.empty(lib().paif_guided_filter_fused_workspace_floats(B, H, W), device=dev, dtype=torch.float32)
     t_my, t_mgy = torch.empty_like(y), torch.empty_like(y)
     t_g = torch.empty((B, H, W, 4), device=dev, dtype=torch.float32)
     dy = torch.empty_like(y)

@@ -1,0 +1,7 @@
+cd $GRAFT_REPO_ROOT
+python -m pytest tests/test_fusion_gpu.py tests/test_f16_storage_gpu.py -x -q -m gpu -k "guided_filter" 2>&1 | tail -3
+for i in 1 2; do
+for v in "" base; do
+  if [ -z "$v" ]; then unset PAIF_LIB; else export PAIF_LIB=paif_amd/lib/libpaif_hip_$v.so; fi
+  python bench.py --no-cpu-baseline --no-extras --steps 40 --warmup 10 2>/dev/null | python -c "import sys,json; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('variant=[$v]', round(r['value'],1), round(r['ms_per_step'],4))"
+done; done
