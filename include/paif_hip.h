@@ -93,6 +93,14 @@ int paif_guided_filter_ab_fwd(const float* guide, const float* y, float* ab, flo
                               int B, int H, int W, paif_stream_t stream);
 int paif_guided_filter_lf_fwd(const float* guide, const float* ab, float* lf, int B, int H, int W,
                               paif_stream_t stream);
+/* Round 6, the taped forward the attack loops and the training step run (csrc/gf_taped.hip): the same two filters with the
+ * TWO-map tape mc [2][B,H,W,32] = (mean_y, cov) instead of ab's four -- A_e, b_e are re-formed where they are used from mc and
+ * the per-pixel guide statistics in `workspace` (paif_guided_filter_fused_workspace_floats(B,H,W) floats, filled here; the reverse
+ * pass paif_guided_filter_bwd_input_mc reads it again).  lf [2][B,H,W,32].  paif_guided_filter_taped_fits: 1 if the streaming
+ * kernels take the size (their row offsets are 32-bit), else the caller keeps paif_guided_filter_ab_fwd + _lf_fwd. */
+int paif_guided_filter_taped_fits(int B, int H, int W);
+int paif_guided_filter_taped_fwd(const float* guide, const float* y, float* mc, float* lf, float eps0, float eps1,
+                                 float* workspace, int B, int H, int W, paif_stream_t stream);
 /* Both stages fused (inference: the coefficient maps never reach HBM); same result as ab_fwd + lf_fwd.
  * workspace: paif_guided_filter_fused_workspace_floats(B,H,W) floats (per-pixel guide statistics for both eps). */
 size_t paif_guided_filter_fused_workspace_floats(int B, int H, int W);
@@ -541,6 +549,10 @@ int paif_spa_blend_bwd_input(const float* dagg, const float* w, const float* ir,
 int paif_guided_filter_bwd_input(const float* guide, const float* y, const float* ab, const float* dlf, float eps0,
                                  float eps1, const float* add, float* gstat, float* t_my, float* t_mgy, float* t_g,
                                  float* dy, int B, int H, int W, paif_stream_t stream);
+/* the same reverse pass over paif_guided_filter_taped_fwd's tape (mc, and the statistics workspace it filled) */
+int paif_guided_filter_bwd_input_mc(const float* guide, const float* y, const float* mc, const float* stats, const float* dlf,
+                                    const float* add, float* t_my, float* t_mgy, float* t_g, float* dy, int B, int H, int W,
+                                    paif_stream_t stream);
 
 /* ---- glue backward + PGD update ---- */
 /* backward of paif_recompose_clamp_fwd + paif_minmax_normalize_fwd: dseg NCHW [B,3,H,W] -> dfused [B,H,W]

@@ -42,6 +42,8 @@ SIGNATURES = {
     "paif_channel_residue_fwd": (c_int, [F, F, c_int, c_int, c_int, F]),
     "paif_guided_filter_ab_fwd": (c_int, [F, F, F, c_float, c_float, c_int, c_int, c_int, F]),
     "paif_guided_filter_lf_fwd": (c_int, [F, F, F, c_int, c_int, c_int, F]),
+    "paif_guided_filter_taped_fits": (c_int, [c_int, c_int, c_int]),
+    "paif_guided_filter_taped_fwd": (c_int, [F, F, F, F, c_float, c_float, F, c_int, c_int, c_int, F]),
     "paif_guided_filter_fused_workspace_floats": (c_size_t, [c_int, c_int, c_int]),
     "paif_guided_filter_fused_fwd": (c_int, [F, F, F, c_float, c_float, F, c_int, c_int, c_int, F]),
     "paif_guided_filter_fused_fwd_bf16": (c_int, [F, F, F, c_float, c_float, F, c_int, c_int, c_int, F]),
@@ -156,6 +158,7 @@ SIGNATURES = {
     "paif_eca_bwd_input": (c_int, [F, F, F, F, F, c_int, F, F, F, F, F, c_int, c_int, c_int, F]),
     "paif_spa_blend_bwd_input": (c_int, [F, F, F, F, F, F, F, F, F, F, c_int, c_int, c_int, F]),
     "paif_guided_filter_bwd_input": (c_int, [F, F, F, F, c_float, c_float, F, F, F, F, F, F, c_int, c_int, c_int, F]),
+    "paif_guided_filter_bwd_input_mc": (c_int, [F, F, F, F, F, F, F, F, F, F, c_int, c_int, c_int, F]),
     "paif_upsample_argmax_fwd": (c_int, [F, F, c_int, c_int, c_int, c_int, c_int, c_int, F]),
     "paif_confusion_matrix_accum": (c_int, [F, F, F, c_size_t, c_int, F]),
     "paif_spa1_fwd": (c_int, [F, F, F, c_int, F, F, F, F, F, c_int, c_int, c_int, F]),

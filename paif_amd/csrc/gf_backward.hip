@@ -24,7 +24,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "paif_common.h"
+#include "gf_stream.h"
 
 // fusion_backward.hip: the round-1 form
 extern "C" int paifi_gf_bwd_input_v1(const float* guide, const float* y, const float* ab, const float* dlf, float eps0, float eps1,
@@ -35,81 +35,14 @@ extern "C" int paifi_gf_guide_stats(const float* guide, float* workspace, float 
 
 namespace paif_gfb {
 
-constexpr int R = 4, KB = 2 * R + 1;
-constexpr int NC = 48;                 // columns per workgroup
-constexpr int NO = NC - 2 * R;         // 40 output columns
-constexpr int NT = NC * 16;            // threads: (column, channel pair)
-constexpr int MAXIT = 1035;            // iterations per piece (a multiple of KB); the host caps nothing: long runs are walked in pieces
-constexpr unsigned RSRC_W3 = 0x00020000u;
-constexpr unsigned NEVER = 0xC0000000u;   // + any row offset of an image (< 2^30 bytes, host check) stays out of range
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-__device__ __forceinline__ f32x2 ld2(const __amdgpu_buffer_rsrc_t& rs, unsigned off) {
-  return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0));
-}
-__device__ __forceinline__ float ld1(const __amdgpu_buffer_rsrc_t& rs, unsigned off) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
-}
-__device__ __forceinline__ void st2(f32x2 v, const __amdgpu_buffer_rsrc_t& rs, unsigned off) {
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rs, off, 0, 0);
-}
-
-// sum over the 16 lanes of a DPP row (= the 16 channel pairs of one pixel), fixed order, every lane ends with the total
-__device__ __forceinline__ float row_sum(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
-  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
-  return v;
-}
-template <int CTRL>
-__device__ __forceinline__ float dppf(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true)); }
-template <int CTRL>
-__device__ __forceinline__ int dppi(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true); }
-
-// LDS reads of the horizontal sums as ds_read_b64 with a 16-bit immediate offset from ONE address register (hipcc pairs the nine
-// column reads into ds_read2_b64, whose 8-bit offsets need an address register per quantity and column group: 10 VGPRs of a budget of
-// 168).  The compiler does not know these loads are in flight: lds_wait9 is the wait, and it carries the nine values as in / out
-// operands so that no use can be scheduled in front of it.
-template <int OFF>
-__device__ __forceinline__ f32x2 lds_rd(unsigned addr) {
-  f32x2 v;
-  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-  return v;
-}
-__device__ __forceinline__ void lds_wait9(f32x2 (&v)[9]) {
-  asm volatile("s_waitcnt lgkmcnt(0)"
-               : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]));
-}
-template <int QOFF>
-__device__ __forceinline__ f32x2 hsum9(unsigned addr) {       // addr: the thread's column - 4, its channel pair, the row's parity
-  f32x2 v[9];
-  v[0] = lds_rd<QOFF + 0 * 128>(addr); v[1] = lds_rd<QOFF + 1 * 128>(addr); v[2] = lds_rd<QOFF + 2 * 128>(addr);
-  v[3] = lds_rd<QOFF + 3 * 128>(addr); v[4] = lds_rd<QOFF + 4 * 128>(addr); v[5] = lds_rd<QOFF + 5 * 128>(addr);
-  v[6] = lds_rd<QOFF + 6 * 128>(addr); v[7] = lds_rd<QOFF + 7 * 128>(addr); v[8] = lds_rd<QOFF + 8 * 128>(addr);
-  lds_wait9(v);
-  return (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) + v[8];
-}
-
-template <int NQ>
-struct Rings {
-  f32x2 r[NQ][KB];
-};
-
-// The walk shared by both stages: which run of rows this workgroup owns and the pieces it is cut into.
-struct Piece {
-  int b, strip, ybeg, yend;
-};
+using namespace paif_gfs;
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // stage 1
 // ------------------------------------------------------------------------------------------------------------------------------
+// MC: the tape is (mean_y, cov) [2][B,H,W,32] of gf_taped.hip -- A_e = cov / (var + eps_e) is re-formed at the source pixel from the
+// per-pixel statistics (3 map streams with halo + 1 pointwise instead of 4 + 2); otherwise the round-1 tape (A_0, b_0, A_1, b_1).
+template <bool MC>
 __global__ __launch_bounds__(NT) void gf_bwd1_v2_kernel(const float* __restrict__ guide, const float* __restrict__ planes,
                                                         const float* __restrict__ ab, const float* __restrict__ dlf,
                                                         float* __restrict__ t_my, float* __restrict__ t_mgy, float* __restrict__ t_g,
@@ -141,10 +74,11 @@ __global__ __launch_bounds__(NT) void gf_bwd1_v2_kernel(const float* __restrict_
     // planes of ab / dlf cannot share one
     const __amdgpu_buffer_rsrc_t rs_d0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dlf + img * 32), 0, img_bytes, RSRC_W3);
     const __amdgpu_buffer_rsrc_t rs_d1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dlf + plane + img * 32), 0, img_bytes, RSRC_W3);
-    const __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ab + img * 32), 0, img_bytes, RSRC_W3);
-    const __amdgpu_buffer_rsrc_t rs_b0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ab + plane + img * 32), 0, img_bytes, RSRC_W3);
-    const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ab + 2 * plane + img * 32), 0, img_bytes, RSRC_W3);
-    const __amdgpu_buffer_rsrc_t rs_b1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ab + 3 * plane + img * 32), 0, img_bytes, RSRC_W3);
+    // MC: rs_a0 = cov (streamed), rs_b0 = mean_y (pointwise); rs_a1 / rs_b1 unused
+    const __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ab + (MC ? plane : 0) + img * 32), 0, img_bytes, RSRC_W3);
+    const __amdgpu_buffer_rsrc_t rs_b0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ab + (MC ? 0 : plane) + img * 32), 0, img_bytes, RSRC_W3);
+    const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ab + (MC ? 0 : 2 * plane) + img * 32), 0, img_bytes, RSRC_W3);
+    const __amdgpu_buffer_rsrc_t rs_b1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ab + (MC ? 0 : 3 * plane) + img * 32), 0, img_bytes, RSRC_W3);
     const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(guide + img), 0, img_bytes_g, RSRC_W3);
     const __amdgpu_buffer_rsrc_t rs_mg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(planes + img), 0, img_bytes_g, RSRC_W3);
     const __amdgpu_buffer_rsrc_t rs_r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(planes + npix + img), 0, img_bytes_g, RSRC_W3);
@@ -182,8 +116,9 @@ __global__ __launch_bounds__(NT) void gf_bwd1_v2_kernel(const float* __restrict_
       for (int k = 0; k < KB; ++k) rg.r[qn][k] = f32x2{0.f, 0.f};
 
     // one row ahead
-    f32x2 nd0 = ld2(rs_d0, vs), nd1 = ld2(rs_d1, vs), na0 = ld2(rs_a0, vs), na1 = ld2(rs_a1, vs);
-    float ng = ld1(rs_g, vg);
+    f32x2 nd0 = ld2(rs_d0, vs), nd1 = ld2(rs_d1, vs), na0 = ld2(rs_a0, vs), na1 = {0.f, 0.f};
+    float ng = ld1(rs_g, vg), nr0 = 0.f, nr1 = 0.f;           // MC: 1 / (var + eps_e) of the streamed pixel
+    if constexpr (MC) { nr0 = ld1(rs_r0, vg); nr1 = ld1(rs_r1, vg); } else na1 = ld2(rs_a1, vs);
     vs += rowbytes; vg += rowbytes_g;
 
     auto step = [&](auto ktag, int itb) {
@@ -191,27 +126,25 @@ __global__ __launch_bounds__(NT) void gf_bwd1_v2_kernel(const float* __restrict_
       const int it = itb + k;
       const float rn = rnx * rny_tab[it];           // 1 / N of the streamed pixel; 0 outside the image
       const f32x2 u20 = nd0 * rn, u21 = nd1 * rn;
-      rg.r[0][k] = u20 * ng; rg.r[1][k] = u20; rg.r[2][k] = na0;
-      rg.r[3][k] = u21 * ng; rg.r[4][k] = u21; rg.r[5][k] = na1;
+      rg.r[0][k] = u20 * ng; rg.r[1][k] = u20; rg.r[2][k] = MC ? na0 * nr0 : na0;
+      rg.r[3][k] = u21 * ng; rg.r[4][k] = u21; rg.r[5][k] = MC ? na0 * nr1 : na1;
       // this output row's pointwise loads, then the next row's streamed loads (vmcnt retires in order: the wait for the pointwise
       // values leaves the five streamed loads in flight)
-      const f32x2 b0 = ld2(rs_b0, vp), b1 = ld2(rs_b1, vp);
+      const f32x2 b0 = ld2(rs_b0, vp);                  // MC: mean_y
+      f32x2 b1 = {0.f, 0.f};
+      if constexpr (!MC) b1 = ld2(rs_b1, vp);
       const float mg = ld1(rs_mg, vp1), rd0 = ld1(rs_r0, vp1), rd1 = ld1(rs_r1, vp1);
       vp += rowbytes; vp1 += rowbytes_g;
       __builtin_amdgcn_sched_barrier(0);
-      nd0 = ld2(rs_d0, vs); nd1 = ld2(rs_d1, vs); na0 = ld2(rs_a0, vs); na1 = ld2(rs_a1, vs);
+      nd0 = ld2(rs_d0, vs); nd1 = ld2(rs_d1, vs); na0 = ld2(rs_a0, vs);
       ng = ld1(rs_g, vg);
+      if constexpr (MC) { nr0 = ld1(rs_r0, vg); nr1 = ld1(rs_r1, vg); } else na1 = ld2(rs_a1, vs);
       vs += rowbytes; vg += rowbytes_g;
       __builtin_amdgcn_sched_barrier(0);            // the loads stay HERE (hipcc sinks them to their first use: no prefetch at all)
       // vertical 9-row sums -> LDS
       f32x2* const sw = &sbuf[par][0][xi][cp];
 #pragma unroll
-      for (int qn = 0; qn < 6; ++qn) {
-        f32x2 v = rg.r[qn][0];
-#pragma unroll
-        for (int j = 1; j < KB; ++j) v = v + rg.r[qn][j];
-        sw[qn * NC * 16] = v;
-      }
+      for (int qn = 0; qn < 6; ++qn) sw[qn * NC * 16] = vsum9<k>(rg, qn);
       lds_barrier();
       if (xi >= R && xi < NC - R) {                 // wave-uniform (a wave = 4 columns): the strip's first and last wave hold halo columns only
         // horizontal 9-column sums
@@ -223,7 +156,7 @@ __global__ __launch_bounds__(NT) void gf_bwd1_v2_kernel(const float* __restrict_
         constexpr int kc = (k + KB - R) % KB;
         const f32x2 A0 = rg.r[2][kc], A1 = rg.r[5][kc], q20 = rg.r[1][kc], q21 = rg.r[4][kc];
         const f32x2 dcov0 = (hs[0] - hs[1] * mg) * rd0, dcov1 = (hs[3] - hs[4] * mg) * rd1;
-        const f32x2 my0 = b0 + A0 * mg, my1 = b1 + A1 * mg;
+        const f32x2 my0 = MC ? b0 : b0 + A0 * mg, my1 = MC ? b0 : b1 + A1 * mg;
         const f32x2 xv = (hs[1] * A0 + dcov0 * my0) + (hs[4] * A1 + dcov1 * my1);
         const f32x2 vv = dcov0 * A0 + dcov1 * A1;
         const f32x2 gv = q20 * hs[2] + q21 * hs[5];
@@ -335,9 +268,7 @@ __global__ __launch_bounds__(NT) void gf_bwd2_v2_kernel(const float* __restrict_
       n1 = ld2(rs_my, vs); n2 = ld2(rs_mgy, vs); n3 = ld2(rs_tg, vt);
       vs += rowbytes; vt += rowbytes_t;
       __builtin_amdgcn_sched_barrier(0);            // pointwise loads first, the next row's streamed loads behind them, all of them HERE
-      f32x2 v1 = rg.r[0][0], v2 = rg.r[1][0], v3 = rg.r[2][0];
-#pragma unroll
-      for (int j = 1; j < KB; ++j) { v1 = v1 + rg.r[0][j]; v2 = v2 + rg.r[1][j]; v3 = v3 + rg.r[2][j]; }
+      const f32x2 v1 = vsum9<k>(rg, 0), v2 = vsum9<k>(rg, 1), v3 = vsum9<k>(rg, 2);
       sbuf[par][0][xi][cp] = v1;
       sbuf[par][1][xi][cp] = v2;
       if (cp == 0) sg[par][xi] = v3;
@@ -395,6 +326,28 @@ __global__ __launch_bounds__(NT) void gf_bwd2_v2_kernel(const float* __restrict_
 
 }  // namespace paif_gfb
 
+static int gf_bwd_v2_launch(bool mc, const float* guide, const float* y, const float* tape, const float* stats, const float* dlf,
+                            const float* add, float* t_my, float* t_mgy, float* t_g, float* dy, int B, int H, int W, paif_stream_t stream) {
+  using namespace paif_gfb;
+  const Plan p = make_plan(B, H, W);
+  hipStream_t st = paif::as_stream(stream);
+  if (mc)
+    hipLaunchKernelGGL((gf_bwd1_v2_kernel<true>), dim3(p.grid), dim3(NT), 0, st, guide, stats, tape, dlf, t_my, t_mgy, t_g, B, H, W, p.nstrip,
+                       p.rows_per_slot, p.total_rows);
+  else
+    hipLaunchKernelGGL((gf_bwd1_v2_kernel<false>), dim3(p.grid), dim3(NT), 0, st, guide, stats, tape, dlf, t_my, t_mgy, t_g, B, H, W, p.nstrip,
+                       p.rows_per_slot, p.total_rows);
+  PAIF_LAUNCH_CHECK("guided_filter_bwd(1)");
+  if (add)
+    hipLaunchKernelGGL((gf_bwd2_v2_kernel<true>), dim3(p.grid), dim3(NT), 0, st, guide, y, t_my, t_mgy, t_g, add, dy, B, H, W, p.nstrip,
+                       p.rows_per_slot, p.total_rows);
+  else
+    hipLaunchKernelGGL((gf_bwd2_v2_kernel<false>), dim3(p.grid), dim3(NT), 0, st, guide, y, t_my, t_mgy, t_g, add, dy, B, H, W, p.nstrip,
+                       p.rows_per_slot, p.total_rows);
+  PAIF_LAUNCH_CHECK("guided_filter_bwd(2)");
+  return 0;
+}
+
 extern "C" int paif_guided_filter_bwd_input(const float* guide, const float* y, const float* ab, const float* dlf, float eps0, float eps1,
                                             const float* add, float* gstat, float* t_my, float* t_mgy, float* t_g, float* dy, int B, int H,
                                             int W, paif_stream_t stream) {
@@ -403,36 +356,20 @@ extern "C" int paif_guided_filter_bwd_input(const float* guide, const float* y, 
   PAIF_REQUIRE(H > 2 * R + 1 && W > 2 * R + 1, PAIF_EINVAL, "guided_filter_bwd: H,W must exceed 9");
   const char* e = getenv("PAIF_GF_BWD");           // read per call: the tests run both forms in one process
   PAIF_REQUIRE(!e || !strcmp(e, "v1") || !strcmp(e, "v2"), PAIF_EINVAL, "PAIF_GF_BWD must be v1 or v2 (got '%s')", e);
-  const int nstrip = (W + NO - 1) / NO;
-  // wrapping 32-bit row offsets + the range check: an image's bytes and the flattened row count must stay small
-  const bool fits = (size_t)H * W * 128 < 0x40000000ull && (size_t)W * 128 * 16 < 0x10000000ull && (size_t)B * nstrip * H < 0x7FFFFFFFull;
-  if ((e && !strcmp(e, "v1")) || !fits)
+  if ((e && !strcmp(e, "v1")) || !make_plan(B, H, W).fits)
     return paifi_gf_bwd_input_v1(guide, y, ab, dlf, eps0, eps1, add, gstat, t_my, t_mgy, t_g, dy, B, H, W, stream);
-  hipStream_t st = paif::as_stream(stream);
   int rc = paifi_gf_guide_stats(guide, gstat, eps0, eps1, B, H, W, stream);
   if (rc) return rc;
-  static const int cus = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    return n > 1 ? n : 2;
-  }();
-  // one 12-wave workgroup per CU, one round: runs of >= 48 rows; more rounds only where a run would exceed 1000 rows (the kernels' 1 / ny
-  // table holds one piece of a run; they cut longer runs into pieces themselves, a path no shipped size takes)
-  const long total_rows = (long)B * nstrip * H;
-  long nslots = total_rows / 48;
-  nslots = nslots < 1 ? 1 : (nslots > cus ? cus : nslots);
-  if ((total_rows + nslots - 1) / nslots > 1000) nslots = (total_rows + 999) / 1000;
-  const int rows_per_slot = (int)((total_rows + nslots - 1) / nslots);
-  const int grid = (int)((total_rows + rows_per_slot - 1) / rows_per_slot);
-  hipLaunchKernelGGL(gf_bwd1_v2_kernel, dim3(grid), dim3(NT), 0, st, guide, gstat, ab, dlf, t_my, t_mgy, t_g, B, H, W, nstrip, rows_per_slot,
-                     (int)total_rows);
-  PAIF_LAUNCH_CHECK("guided_filter_bwd(1)");
-  if (add)
-    hipLaunchKernelGGL((gf_bwd2_v2_kernel<true>), dim3(grid), dim3(NT), 0, st, guide, y, t_my, t_mgy, t_g, add, dy, B, H, W, nstrip,
-                       rows_per_slot, (int)total_rows);
-  else
-    hipLaunchKernelGGL((gf_bwd2_v2_kernel<false>), dim3(grid), dim3(NT), 0, st, guide, y, t_my, t_mgy, t_g, add, dy, B, H, W, nstrip,
-                       rows_per_slot, (int)total_rows);
-  PAIF_LAUNCH_CHECK("guided_filter_bwd(2)");
-  return 0;
+  return gf_bwd_v2_launch(false, guide, y, ab, gstat, dlf, add, t_my, t_mgy, t_g, dy, B, H, W, stream);
+}
+
+// The reverse pass over gf_taped.hip's tape: mc = (mean_y, cov) [2][B,H,W,32], stats = the workspace paif_guided_filter_taped_fwd filled.
+extern "C" int paif_guided_filter_bwd_input_mc(const float* guide, const float* y, const float* mc, const float* stats, const float* dlf,
+                                               const float* add, float* t_my, float* t_mgy, float* t_g, float* dy, int B, int H, int W,
+                                               paif_stream_t stream) {
+  using namespace paif_gfb;
+  PAIF_REQUIRE(guide && y && mc && stats && dlf && t_my && t_mgy && t_g && dy && B > 0, PAIF_EINVAL, "guided_filter_bwd_mc: bad arguments");
+  PAIF_REQUIRE(H > 2 * R + 1 && W > 2 * R + 1, PAIF_EINVAL, "guided_filter_bwd_mc: H,W must exceed 9");
+  PAIF_REQUIRE(make_plan(B, H, W).fits, PAIF_ENOSUP, "guided_filter_bwd_mc: %dx%dx%d exceeds the streaming kernels' 32-bit row offsets", B, H, W);
+  return gf_bwd_v2_launch(true, guide, y, mc, stats, dlf, add, t_my, t_mgy, t_g, dy, B, H, W, stream);
 }

@@ -37,9 +37,34 @@ constexpr int SO = SC - 4 * R;    // output columns per workgroup (48 of 64)
 constexpr int PF = 6;             // unroll factor = partial-sum ring size
 constexpr int NQ = 6;             // exchanged quantities: sum y, sum g*y, A0, b0, A1, b1
 #ifndef GF2_DP
-#define GF2_DP 3
+#define GF2_DP (GF2_NW >= 12 ? 2 : 3)
+#endif
+// Register diet of the 12-wave form (three waves per SIMD: <= 168 registers where the 8-wave form takes 207):
+//   GF2_YD_LDS: y(r - 9) of the high-frequency output modes waits in a wave-private LDS ring (9 slots x 8 bytes per lane, one read + one
+//               write per row at ONE address) instead of the 18-register in-lane delay line;
+//   GF2_OWN_LDS: a lane's own fragments are read back from the halo buffer behind the barrier (3 more 16-byte LDS reads per row)
+//               instead of staying live across it (12 registers).
+#ifndef GF2_MINW
+#define GF2_MINW (GF2_NW / 4)      // waves per SIMD the register allocation must allow
+#endif
+#ifndef GF2_YD_LDS
+#define GF2_YD_LDS (GF2_NW >= 12)
+#endif
+#ifndef GF2_OWN_LDS
+#define GF2_OWN_LDS (GF2_NW >= 12)
+#endif
+//   GF2_EARLY_AB: the (A, b) window sums are split and published at the END of the iteration that forms them, into the halo buffer of
+//               the next iteration (every wave is past this iteration's barrier, so nobody still reads that buffer), instead of
+//               waiting in 8 registers for the next iteration's publish;
+//   GF2_DPL:    rows of per-pixel planes the two loader waves keep in flight (a register ring of 3 x GF2_DPL)
+#ifndef GF2_EARLY_AB
+#define GF2_EARLY_AB (GF2_NW >= 12)
+#endif
+#ifndef GF2_DPL
+#define GF2_DPL (GF2_NW >= 12 ? 1 : GF2_DP)
 #endif
 constexpr int DP = GF2_DP;        // rows of input prefetch (register ring, static slots: PF % DP == 0)
+constexpr int DPL = GF2_DPL;      // the same for the loader waves' plane ring
 constexpr unsigned RSRC_W3 = 0x00020000u;
 constexpr int MAXIT = 1032;        // iterations per workgroup (the host caps the rows per segment at 1000)
 
@@ -105,6 +130,9 @@ __device__ __forceinline__ u32x2 band_operand(int m, int colbase) {
 #ifndef GF2_PAIRED
 #define GF2_PAIRED 1
 #endif
+#if GF2_EARLY_AB && !GF2_PAIRED
+#error "GF2_EARLY_AB is written for the paired form"
+#endif
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ u32x4 band_operand2(int m, int colbase) {
   const u32x2 d = band_operand((m & ~3) | (m & 1), colbase);       // the two-row pattern of output column 2 (m >> 2) + (m & 1)
@@ -144,7 +172,7 @@ __device__ __forceinline__ f32x2 ring_push(Ring& rg, f32x2 x) {
 // OM 3 (round 6): as OM 2, with y READ as IEEE fp16 -- the stem's 16-bit twin of its map (the only form of that map the fp16 forward then
 // keeps: the stem writes no fp32 map at all).  HF = x16 - LF(x16): the same x16 the folded 1x1 behind the filter takes as its first source.
 template <int OM>
-__global__ __launch_bounds__(64 * NW, NW / 4) void gf2_kernel(const float* __restrict__ guide, const float* __restrict__ y,
+__global__ __launch_bounds__(64 * NW, GF2_MINW) void gf2_kernel(const float* __restrict__ guide, const float* __restrict__ y,
                                                      const float* __restrict__ planes, float* __restrict__ lf,
                                                      unsigned* __restrict__ flag, int B, int H, int W, int nstrip, int nslots,
                                                      int rows_per_slot, int total_rows) {
@@ -157,6 +185,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gf2_kernel(const float* __res
   __shared__ float rny_tab[MAXIT + 8];                             // 1 / ny of the row each iteration outputs; 0 outside the image
   __shared__ float pbuf[2][5][SC];                                  // per-pixel planes of one iteration: g(r), mean_g / rden0 / rden1 (r - 4), g(r - 9)
   __shared__ float tbuf[NW][2][8][16];                              // wave-private output transposition [eps][column][channel]
+  constexpr bool YDL = GF2_YD_LDS && OM >= 2;
+  __shared__ f32x2 ydl[YDL ? 9 : 1][YDL ? 64 * NW : 1];             // GF2_YD_LDS: the y delay line, [slot][thread]
 
   const int tid = threadIdx.x, l = tid & 63;
   const int q = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave = 8-column group of the strip
@@ -261,11 +291,16 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gf2_kernel(const float* __res
   for (int k = 0; k < PF; ++k) { ry.p[k] = zero2; rgy.p[k] = zero2; rA0.p[k] = zero2; rB0.p[k] = zero2; rA1.p[k] = zero2; rB1.p[k] = zero2; }
   ry.a1 = ry.a2 = rgy.a1 = rgy.a2 = rA0.a1 = rA0.a2 = rB0.a1 = rB0.a2 = rA1.a1 = rA1.a2 = rB1.a1 = rB1.a2 = zero2;
   f32x2 wA0 = zero2, wB0 = zero2, wA1 = zero2, wB1 = zero2;           // vertical (A, b) window sums of the previous iteration
-  f32x2 yd6[OM >= 2 ? PF : 1], yd3[OM >= 2 ? 3 : 1];                    // OM 2: y delayed by 6 and by 6 + 3 iterations (the output row's y)
+  f32x2 yd6[(OM >= 2 && !YDL) ? PF : 1], yd3[(OM >= 2 && !YDL) ? 3 : 1];   // OM 2: y delayed by 6 and by 6 + 3 iterations (the output row's y)
 #pragma unroll
-  for (int k = 0; k < (OM >= 2 ? PF : 1); ++k) yd6[k] = zero2;
+  for (int k = 0; k < ((OM >= 2 && !YDL) ? PF : 1); ++k) yd6[k] = zero2;
 #pragma unroll
-  for (int k = 0; k < (OM >= 2 ? 3 : 1); ++k) yd3[k] = zero2;
+  for (int k = 0; k < ((OM >= 2 && !YDL) ? 3 : 1); ++k) yd3[k] = zero2;
+  int ys = 0;                                              // GF2_YD_LDS: the ring slot of this iteration (wave-uniform)
+  if constexpr (YDL) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) ydl[k][tid] = zero2;      // wave-private: no barrier
+  }
 
   // running offsets (wrapping 32-bit arithmetic on purpose)
   constexpr unsigned NEVER = 0x80000000u;                // + any row offset of the image stays out of range
@@ -278,24 +313,43 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gf2_kernel(const float* __res
   // wave 0: g(rr), g(rr - 9) -> planes 0, 4;   wave NW - 1: mean_g, 1/(var + eps0), 1/(var + eps1) at rr - 4 -> planes 1, 2, 3
   const bool loader = q == 0 || q == NW - 1;              // wave-uniform
   const bool ld_g = q == 0;
-  const int pcol = X0 + l;                                // the loader lane's column of the 64-column strip
-  const unsigned lane_pl = (pcol >= 0 && pcol < W) ? (unsigned)pcol * 4u : NEVER;
-  const __amdgpu_buffer_rsrc_t rsA = ld_g ? rs_g : rs_mg, rsB = ld_g ? rs_g : rs_r0;
-  unsigned vpa = lane_pl + (unsigned)(ld_g ? r0 : r0 - R) * rowbytes_pl;
-  unsigned vpb = lane_pl + (unsigned)(ld_g ? r0 - (2 * R + 1) : r0 - R) * rowbytes_pl;
+  // Strips wider than 64 columns (the 12-wave form: 96): each loader wave takes ALL five planes of one half of the strip's columns
+  // (lanes 0 .. SC / 2 - 1) instead of two / three planes of all 64.
+  constexpr bool PLH = SC > 64;
+  const int pcol = X0 + l + ((PLH && !ld_g) ? SC / 2 : 0);        // the loader lane's column
+  const unsigned lane_pl = (pcol >= 0 && pcol < W && (!PLH || l < SC / 2)) ? (unsigned)pcol * 4u : NEVER;
+  const int pl_l = l + ((PLH && !ld_g) ? SC / 2 : 0);               // its column of pbuf (lanes >= SC / 2 of the half form: duplicates of in-range columns' slots are avoided by the mask below)
+  const __amdgpu_buffer_rsrc_t rsA = (PLH || ld_g) ? rs_g : rs_mg, rsB = (PLH || ld_g) ? rs_g : rs_r0;
+  unsigned vpa = lane_pl + (unsigned)((PLH || ld_g) ? r0 : r0 - R) * rowbytes_pl;
+  unsigned vpb = lane_pl + (unsigned)((PLH || ld_g) ? r0 - (2 * R + 1) : r0 - R) * rowbytes_pl;
   unsigned vpc = lane_pl + (unsigned)(r0 - R) * rowbytes_pl;
-  const int plA = ld_g ? 0 : 1, plB = ld_g ? 4 : 2;
-  float pa[DP], pb[DP], pc[DP];                           // the loader's ring: rows of iterations it + 1 .. it + DP
+  const int plA = (PLH || ld_g) ? 0 : 1, plB = (PLH || ld_g) ? 4 : 2;
+  float pa[DPL], pb[DPL], pc[DPL];                        // the loader's ring: rows of iterations it + 1 .. it + DPL
+  float pd[PLH ? DPL : 1], pe[PLH ? DPL : 1];
   auto plane_load = [&](int slot) {
     if (loader) {
       pa[slot] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsA, vpa, 0, 0));
       pb[slot] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB, vpb, 0, 0));
-      if (!ld_g) pc[slot] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r1, vpc, 0, 0));
+      if constexpr (PLH) {
+        pc[slot] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_mg, vpc, 0, 0));
+        pd[slot] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r0, vpc, 0, 0));
+        pe[slot] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r1, vpc, 0, 0));
+      } else {
+        if (!ld_g) pc[slot] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r1, vpc, 0, 0));
+      }
       vpa += rowbytes_pl; vpb += rowbytes_pl; vpc += rowbytes_pl;
     }
   };
   auto plane_publish = [&](int slot, int par) {           // the loader's ring slot -> pbuf[par] (read by everyone after the next barrier)
-    if (loader) {
+    if constexpr (PLH) {
+      if (loader && l < SC / 2) {
+        pbuf[par][0][pl_l] = pa[slot];
+        pbuf[par][4][pl_l] = pb[slot];
+        pbuf[par][1][pl_l] = pc[slot];
+        pbuf[par][2][pl_l] = pd[slot];
+        pbuf[par][3][pl_l] = pe[slot];
+      }
+    } else if (loader) {
       pbuf[par][plA][l] = pa[slot];
       pbuf[par][plB][l] = pb[slot];
       if (!ld_g) pbuf[par][3][l] = pc[slot];
@@ -338,7 +392,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gf2_kernel(const float* __res
   plane_load(0);
   plane_publish(0, 0);
 #pragma unroll
-  for (int j = 1; j <= DP; ++j) plane_load(j % DP);
+  for (int j = 1; j <= DPL; ++j) plane_load(j % DPL);
+#if GF2_EARLY_AB
+  hbuf[0][1][q + 1][l] = u32x4{0u, 0u, 0u, 0u};            // iteration 0 reads the (A, b) fragments "of the iteration before": zeros
+  hbuf[0][2][q + 1][l] = u32x4{0u, 0u, 0u, 0u};
+#endif
 
   __syncthreads();                                       // the zero slots, the 1 / ny table and the first planes are visible
 
@@ -366,7 +424,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gf2_kernel(const float* __res
       yy = f32x2{py0[slot], py1[slot] * m1};
     }
     f32x2 y9 = yy;
-    if constexpr (HFO) {                                  // y of the row stage 2 outputs in this iteration (r - 9)
+    if constexpr (HFO && YDL) {                           // y of the row stage 2 outputs in this iteration (r - 9): written 9 iterations ago
+      y9 = ydl[ys][tid];
+      ydl[ys][tid] = yy;                                  // same address, a wave's LDS operations execute in issue order
+      ys = ys == 8 ? 0 : ys + 1;
+    } else if constexpr (HFO) {
       const f32x2 y6 = yd6[k];
       yd6[k] = yy;
       y9 = yd3[k % 3];
@@ -377,24 +439,29 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gf2_kernel(const float* __res
     const f32x2 g2 = *reinterpret_cast<const f32x2*>(&pbuf[par][4][lc0]);
     prefetch(slot);
     // the loader waves: planes of the NEXT iteration -> the other buffer (visible after this iteration's barrier), ring refilled
-    plane_publish((k + 1) % DP, par ^ 1);
-    plane_load((k + 1) % DP);
+    plane_publish((k + 1) % DPL, par ^ 1);
+    plane_load((k + 1) % DPL);
     // 1 / n of the stage-2 row (r - 9) and of the stage-1 row (r - 4): (1 / nx) * (1 / ny); zero outside the image
     const float ry2 = rny_tab[it], ry1 = rny_tab[it + (R + 1)];
     const f32x2 rn2 = f32x2{rnx[0] * ry2, rnx[1] * ry2}, rn = f32x2{rnx[0] * ry1, rnx[1] * ry1};
     const u32x2 f_y = split2(ring_push<k>(ry, yy), vmax);
     const u32x2 f_gy = split2(ring_push<k>(rgy, gv * yy), vmax);
+#if !GF2_EARLY_AB
     const u32x2 f_a0 = split2(wA0, vmax);
     const u32x2 f_b0 = split2(wB0, vmax);
     const u32x2 f_a1 = split2(wA1, vmax);
     const u32x2 f_b1 = split2(wB1, vmax);
+#endif
     GF2_ST(1);
 #ifndef GF2_NOLDS       // (diagnostic build without the halo exchange: -DGF2_NOLDS)
 #if GF2_PAIRED
-    const u32x4 p_yg = {f_y[0], f_y[1], f_gy[0], f_gy[1]}, p_0 = {f_a0[0], f_a0[1], f_b0[0], f_b0[1]}, p_1 = {f_a1[0], f_a1[1], f_b1[0], f_b1[1]};
+    const u32x4 p_yg = {f_y[0], f_y[1], f_gy[0], f_gy[1]};
     hbuf[par][0][q + 1][l] = p_yg;
+#if !GF2_EARLY_AB
+    const u32x4 p_0 = {f_a0[0], f_a0[1], f_b0[0], f_b0[1]}, p_1 = {f_a1[0], f_a1[1], f_b1[0], f_b1[1]};
     hbuf[par][1][q + 1][l] = p_0;
     hbuf[par][2][q + 1][l] = p_1;
+#endif
 #else
     hbuf[par][0][q + 1][l] = f_y;
     hbuf[par][1][q + 1][l] = f_gy;
@@ -419,7 +486,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gf2_kernel(const float* __res
 #endif
 #if GF2_PAIRED
       const u32x4 h_0 = hbuf[par][1][rd_slot][rd_lane], h_1 = hbuf[par][2][rd_slot][rd_lane];
-      const f32x4 s_0 = band_mfma2(a_own, p_0, a_halo, h_0), s_1 = band_mfma2(a_own, p_1, a_halo, h_1);
+#if GF2_OWN_LDS || GF2_EARLY_AB
+      const u32x4 o_0 = hbuf[par][1][q + 1][l], o_1 = hbuf[par][2][q + 1][l];
+#else
+      const u32x4 o_0 = p_0, o_1 = p_1;
+#endif
+      const f32x4 s_0 = band_mfma2(a_own, o_0, a_halo, h_0), s_1 = band_mfma2(a_own, o_1, a_halo, h_1);
       const f32x2 s_a0 = {s_0[0], s_0[1]}, s_b0 = {s_0[2], s_0[3]}, s_a1 = {s_1[0], s_1[1]}, s_b1 = {s_1[2], s_1[3]};
 #else
       const f32x2 s_a0 = band_mfma(a_own, f_a0, a_halo, h_a0);
@@ -471,7 +543,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gf2_kernel(const float* __res
 #endif
 #if GF2_PAIRED
       const u32x4 h_yg = hbuf[par][0][rd_slot][rd_lane];
-      const f32x4 s_yg = band_mfma2(a_own, p_yg, a_halo, h_yg);
+#if GF2_OWN_LDS
+      const u32x4 o_yg = hbuf[par][0][q + 1][l];
+#else
+      const u32x4 o_yg = p_yg;
+#endif
+      const f32x4 s_yg = band_mfma2(a_own, o_yg, a_halo, h_yg);
       const f32x2 s_y = {s_yg[0], s_yg[1]}, s_gy = {s_yg[2], s_yg[3]};
 #else
       const f32x2 s_y = band_mfma(a_own, f_y, a_halo, h_y);
@@ -484,10 +561,16 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gf2_kernel(const float* __res
       wB0 = ring_push<k>(rB0, my - A0 * mg1);
       wA1 = ring_push<k>(rA1, A1);
       wB1 = ring_push<k>(rB1, my - A1 * mg1);
+#if GF2_EARLY_AB
+      const u32x2 f_a0 = split2(wA0, vmax), f_b0 = split2(wB0, vmax);
+      hbuf[par ^ 1][1][q + 1][l] = u32x4{f_a0[0], f_a0[1], f_b0[0], f_b0[1]};
+      const u32x2 f_a1 = split2(wA1, vmax), f_b1 = split2(wB1, vmax);
+      hbuf[par ^ 1][2][q + 1][l] = u32x4{f_a1[0], f_a1[1], f_b1[0], f_b1[1]};
+#endif
     }
     GF2_ST(5);
   };
-  static_assert(PF == 6 && PF % DP == 0, "the unrolled body lists PF = 6 steps");
+  static_assert(PF == 6 && PF % DP == 0 && PF % DPL == 0, "the unrolled body lists PF = 6 steps");
   for (int itb = 0; itb < n_it; itb += PF) {
     step(std::integral_constant<int, 0>{}, itb);
     step(std::integral_constant<int, 1>{}, itb);
@@ -504,6 +587,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gf2_kernel(const float* __res
   for (int m = 32; m >= 1; m >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, m));
   if (l == 0 && !(vmax < 65000.f)) atomicOr(flag, 1u);
 }
+
+// what the host launcher (guided_filter.hip) needs to know about the build
+extern const int kStripOut = SO, kThreads = 64 * NW;
 
 template __global__ void gf2_kernel<0>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
 template __global__ void gf2_kernel<1>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);

@@ -494,6 +494,7 @@ namespace paif_gf2 {
 template <int OM>
 __global__ void gf2_kernel(const float* __restrict__ guide, const float* __restrict__ y, const float* __restrict__ planes, float* __restrict__ lf,
                            unsigned* __restrict__ flag, int B, int H, int W, int nstrip, int nslots, int rows_per_slot, int total_rows);
+extern const int kStripOut, kThreads;      // output columns per strip and threads per workgroup of the build (8 waves: 48, 512; 12 waves: 80, 768)
 extern template __global__ void gf2_kernel<0>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
 extern template __global__ void gf2_kernel<1>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
 extern template __global__ void gf2_kernel<2>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
@@ -527,7 +528,8 @@ static int gf_fused_launch(const float* guide, const float* y, float* lf, float 
   int engine = (eng && !strcmp(eng, "valu")) ? 0 : 2;
   // the round-4 engine addresses rows with wrapping 32-bit per-lane offsets that the buffer range check filters: every per-image
   // byte size must stay below 2^31 - 2^20
-  if (engine == 2 && ((size_t)(B + 1) * H * W * 128 >= 0x7FF00000ull || (size_t)B * nstrip * H >= 0x7FFFFFFFull)) engine = 0;   // the all-VALU kernel takes any size
+  const int nstrip2 = (W + paif_gf2::kStripOut - 1) / paif_gf2::kStripOut;      // the matrix-core engine's strips
+  if (engine == 2 && ((size_t)(B + 1) * H * W * 128 >= 0x7FF00000ull || (size_t)B * nstrip2 * H >= 0x7FFFFFFFull)) engine = 0;   // the all-VALU kernel takes any size
   static const int form = [] {
     const char* e = getenv("PAIF_GF_FORM");
     if (!e) return 0;
@@ -561,22 +563,22 @@ static int gf_fused_launch(const float* guide, const float* y, float* lf, float 
       if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
       return n > 1 ? n : 2;
     }();
-    const long total_rows = (long)B * nstrip * H;
+    const long total_rows = (long)B * nstrip2 * H;
     int nslots = (int)(total_rows / 96);
     nslots = nslots < 1 ? 1 : (nslots > cus / 2 ? cus / 2 : nslots);
     const int rows_per_slot = (int)((total_rows + nslots - 1) / nslots);
     const int grid = (nslots + 7) / 8 * 16;
     if (out_bf16 == 3)
-      hipLaunchKernelGGL((paif_gf2::gf2_kernel<3>), dim3(grid), dim3(512), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip, nslots,
+      hipLaunchKernelGGL((paif_gf2::gf2_kernel<3>), dim3(grid), dim3(paif_gf2::kThreads), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip2, nslots,
                          rows_per_slot, (int)total_rows);
     else if (out_bf16 == 2)
-      hipLaunchKernelGGL((paif_gf2::gf2_kernel<2>), dim3(grid), dim3(512), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip, nslots,
+      hipLaunchKernelGGL((paif_gf2::gf2_kernel<2>), dim3(grid), dim3(paif_gf2::kThreads), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip2, nslots,
                          rows_per_slot, (int)total_rows);
     else if (out_bf16)
-      hipLaunchKernelGGL((paif_gf2::gf2_kernel<1>), dim3(grid), dim3(512), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip, nslots,
+      hipLaunchKernelGGL((paif_gf2::gf2_kernel<1>), dim3(grid), dim3(paif_gf2::kThreads), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip2, nslots,
                          rows_per_slot, (int)total_rows);
     else
-      hipLaunchKernelGGL((paif_gf2::gf2_kernel<0>), dim3(grid), dim3(512), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip, nslots,
+      hipLaunchKernelGGL((paif_gf2::gf2_kernel<0>), dim3(grid), dim3(paif_gf2::kThreads), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip2, nslots,
                          rows_per_slot, (int)total_rows);
     PAIF_LAUNCH_CHECK("guided_filter_fused(mfma2)");
   }

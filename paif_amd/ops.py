@@ -670,7 +670,16 @@ def channel_residue(x):
     return g
 
 
-def guided_filter_pair(guide, y, eps=(0.001, 0.0001), want_ab=False, out_bf16=False):
+class GfTape:
+    """What the guided filter's taped forward leaves for its reverse pass: mc [2,B,H,W,32] = (mean_y, cov) and the per-pixel guide
+    statistics workspace (csrc/gf_taped.hip).  The round-1 kernels' tape is a plain [4,B,H,W,32] tensor (A_0, b_0, A_1, b_1)."""
+    __slots__ = ("mc", "stats")
+
+    def __init__(self, mc, stats):
+        self.mc, self.stats = mc, stats
+
+
+def guided_filter_pair(guide, y, eps=(0.001, 0.0001), want_ab=False, out_bf16=False, tape=None):
     """Returns lf [2,B,H,W,32] for the two eps (r = 4) (and the coefficient maps ab [4,B,H,W,32] for the
     backward pass).  AssertionError if H or W <= 9, like the reference's guided_filter_pytorch.
     out_bf16 (inference, fused form): the two maps as bf16 -- the bf16 configuration's storage of the maps behind this block;
@@ -700,6 +709,22 @@ def guided_filter_pair(guide, y, eps=(0.001, 0.0001), want_ab=False, out_bf16=Fa
         return lf
     assert not out_bf16, "bf16 low-frequency maps are an inference (fused-form) output"
     lf = torch.empty((2, B, H, W, 32), device=y.device, dtype=torch.float32)
+    import os
+    # tape: "mc" / "ab" force the round-6 streaming pair / the round-1 pair (tests, A/B runs); default: streaming wherever it fits
+    assert tape in (None, "mc", "ab"), tape
+    if tape is None:
+        tape = os.environ.get("PAIF_GF_TAPE")        # A/B knob: the round-1 pair and its four-map tape under the streaming reverse pass
+        if tape not in (None, "mc", "ab"):
+            raise ValueError("PAIF_GF_TAPE must be 'mc' or 'ab', got %r" % tape)
+    if tape is None:
+        tape = "mc" if os.environ.get("PAIF_GF_BWD") != "v1" and L.paif_guided_filter_taped_fits(B, H, W) else "ab"
+    if want_ab and tape == "mc":
+        # round 6: the streaming taped forward and its two-map tape (mean_y, cov) + the per-pixel guide statistics (csrc/gf_taped.hip)
+        mc = torch.empty((2, B, H, W, 32), device=y.device, dtype=torch.float32)
+        stats = torch.empty(L.paif_guided_filter_fused_workspace_floats(B, H, W), device=y.device, dtype=torch.float32)
+        _lib.check(L.paif_guided_filter_taped_fwd(_p(guide), _p(y), _p(mc), _p(lf), eps[0], eps[1], _p(stats), B, H, W, _stream()),
+                   "guided_filter_taped")
+        return lf, GfTape(mc, stats)
     ab = torch.empty((4, B, H, W, 32), device=y.device, dtype=torch.float32)
     _lib.check(L.paif_guided_filter_ab_fwd(_p(guide), _p(y), _p(ab), eps[0], eps[1], B, H, W, _stream()), "guided_filter_ab")
     _lib.check(L.paif_guided_filter_lf_fwd(_p(guide), _p(ab), _p(lf), B, H, W, _stream()), "guided_filter_lf")
@@ -1064,6 +1089,12 @@ def dwconv_bwd(dt, w, k, dil, aux=None, add=None):
 def guided_filter_bwd(guide, y, ab, dlf, eps=(0.001, 0.0001), add=None):
     B, H, W, _ = y.shape
     dev = y.device
+    if isinstance(ab, GfTape):
+        t_my, t_mgy, dy = torch.empty_like(y), torch.empty_like(y), torch.empty_like(y)
+        t_g = torch.empty((B, H, W, 4), device=dev, dtype=torch.float32)
+        _lib.check(lib().paif_guided_filter_bwd_input_mc(_p(guide), _p(y), _p(ab.mc), _p(ab.stats), _p(dlf), _p(add), _p(t_my), _p(t_mgy),
+                                                         _p(t_g), _p(dy), B, H, W, _stream()), "guided_filter_bwd_mc")
+        return dy
     # per-pixel guide statistics: the fused forward's workspace (planes mean_g, 1/(var+eps_e), 1/n + the flag line); the round-1
     # kernels (PAIF_GF_BWD=v1, sizes beyond the streaming form's 32-bit offsets) use its first 2 floats per pixel
     gstat = torch.empty(lib().paif_guided_filter_fused_workspace_floats(B, H, W), device=dev, dtype=torch.float32)

@@ -9,7 +9,7 @@ for (B, H, W, use_add) in [(1, 20, 24, False), (2, 33, 41, True), (1, 64, 96, Tr
     g = torch.Generator().manual_seed(B * 1000 + H + W)
     xn = torch.randn(B, H, W, 32, generator=g).to(dev)
     guide = ops.channel_residue(xn)
-    lf, ab = ops.guided_filter_pair(guide, xn, want_ab=True)
+    lf, ab = ops.guided_filter_pair(guide, xn, want_ab=True, tape="ab")
     dlf = torch.randn(2, B, H, W, 32, generator=g).to(dev)
     add = torch.randn(B, H, W, 32, generator=g).to(dev) if use_add else None
     out = {}
