@@ -19,6 +19,11 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+def _hip_includes(src):
+    import re
+    return [m for m in re.findall(r'^#include "([A-Za-z0-9_]+\.hip)"', open(src).read(), flags=re.M) if os.path.exists(os.path.join(CSRC, m))]
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True
@@ -44,7 +49,9 @@ def build(force=False, verbose=False):
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+        # a source that includes another .hip (gf_mfma2_w12.hip: the 12-wave build of gf_mfma2.hip) is as old as the newest of the two
+        src_t = max([os.path.getmtime(src)] + [os.path.getmtime(os.path.join(CSRC, inc)) for inc in _hip_includes(src)])
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(src_t, hdr_t):
             cmd = [hipcc] + flags + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))

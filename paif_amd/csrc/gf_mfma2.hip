@@ -25,7 +25,13 @@
 
 #include "paif_common.h"
 
-namespace paif_gf2 {
+// This file is compiled twice: as itself (8 waves per workgroup, namespace paif_gf2, every output mode) and through gf_mfma2_w12.hip
+// (GF2_NW = 12, namespace paif_gf2w12, the 16-bit high-frequency output modes 2 and 3 only: the modes whose 12-wave build keeps its
+// row loop free of scratch accesses).
+#ifndef GF2_NS
+#define GF2_NS paif_gf2
+#endif
+namespace GF2_NS {
 
 constexpr int R = 4;
 #ifndef GF2_NW
@@ -591,9 +597,11 @@ __global__ __launch_bounds__(64 * NW, GF2_MINW) void gf2_kernel(const float* __r
 // what the host launcher (guided_filter.hip) needs to know about the build
 extern const int kStripOut = SO, kThreads = 64 * NW;
 
+#if GF2_NW < 12
 template __global__ void gf2_kernel<0>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
 template __global__ void gf2_kernel<1>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
+#endif
 template __global__ void gf2_kernel<2>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
 template __global__ void gf2_kernel<3>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
 
-}  // namespace paif_gf2
+}  // namespace GF2_NS

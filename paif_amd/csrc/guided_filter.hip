@@ -500,6 +500,14 @@ extern template __global__ void gf2_kernel<1>(const float*, const float*, const 
 extern template __global__ void gf2_kernel<2>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
 extern template __global__ void gf2_kernel<3>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
 }
+namespace paif_gf2w12 {      // gf_mfma2_w12.hip: the 12-wave build, output modes 2 and 3
+template <int OM>
+__global__ void gf2_kernel(const float* __restrict__ guide, const float* __restrict__ y, const float* __restrict__ planes, float* __restrict__ lf,
+                           unsigned* __restrict__ flag, int B, int H, int W, int nstrip, int nslots, int rows_per_slot, int total_rows);
+extern const int kStripOut, kThreads;
+extern template __global__ void gf2_kernel<2>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
+extern template __global__ void gf2_kernel<3>(const float*, const float*, const float*, float*, unsigned*, int, int, int, int, int, int, int);
+}
 
 // The statistics launch alone: the reverse pass (gf_backward.hip) reads the same planes.  workspace: as below.
 extern "C" __attribute__((visibility("hidden"))) int paifi_gf_guide_stats(const float* guide, float* workspace, float eps0, float eps1, int B,
@@ -528,7 +536,12 @@ static int gf_fused_launch(const float* guide, const float* y, float* lf, float 
   int engine = (eng && !strcmp(eng, "valu")) ? 0 : 2;
   // the round-4 engine addresses rows with wrapping 32-bit per-lane offsets that the buffer range check filters: every per-image
   // byte size must stay below 2^31 - 2^20
-  const int nstrip2 = (W + paif_gf2::kStripOut - 1) / paif_gf2::kStripOut;      // the matrix-core engine's strips
+  // fp16 high-frequency outputs: the 12-wave build (96-column strips, three waves per SIMD); PAIF_GF_NW=8 keeps the 8-wave build (A/B runs)
+  const char* nwe = getenv("PAIF_GF_NW");
+  PAIF_REQUIRE(!nwe || !strcmp(nwe, "8") || !strcmp(nwe, "12"), PAIF_EINVAL, "PAIF_GF_NW must be 8 or 12 (got '%s')", nwe);
+  const bool w12 = out_bf16 >= 2 && !(nwe && !strcmp(nwe, "8"));
+  const int strip_out = w12 ? paif_gf2w12::kStripOut : paif_gf2::kStripOut, threads2 = w12 ? paif_gf2w12::kThreads : paif_gf2::kThreads;
+  const int nstrip2 = (W + strip_out - 1) / strip_out;      // the matrix-core engine's strips
   if (engine == 2 && ((size_t)(B + 1) * H * W * 128 >= 0x7FF00000ull || (size_t)B * nstrip2 * H >= 0x7FFFFFFFull)) engine = 0;   // the all-VALU kernel takes any size
   static const int form = [] {
     const char* e = getenv("PAIF_GF_FORM");
@@ -568,17 +581,23 @@ static int gf_fused_launch(const float* guide, const float* y, float* lf, float 
     nslots = nslots < 1 ? 1 : (nslots > cus / 2 ? cus / 2 : nslots);
     const int rows_per_slot = (int)((total_rows + nslots - 1) / nslots);
     const int grid = (nslots + 7) / 8 * 16;
-    if (out_bf16 == 3)
-      hipLaunchKernelGGL((paif_gf2::gf2_kernel<3>), dim3(grid), dim3(paif_gf2::kThreads), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip2, nslots,
+    if (w12 && out_bf16 == 3)
+      hipLaunchKernelGGL((paif_gf2w12::gf2_kernel<3>), dim3(grid), dim3(threads2), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip2, nslots,
+                         rows_per_slot, (int)total_rows);
+    else if (w12)
+      hipLaunchKernelGGL((paif_gf2w12::gf2_kernel<2>), dim3(grid), dim3(threads2), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip2, nslots,
+                         rows_per_slot, (int)total_rows);
+    else if (out_bf16 == 3)
+      hipLaunchKernelGGL((paif_gf2::gf2_kernel<3>), dim3(grid), dim3(threads2), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip2, nslots,
                          rows_per_slot, (int)total_rows);
     else if (out_bf16 == 2)
-      hipLaunchKernelGGL((paif_gf2::gf2_kernel<2>), dim3(grid), dim3(paif_gf2::kThreads), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip2, nslots,
+      hipLaunchKernelGGL((paif_gf2::gf2_kernel<2>), dim3(grid), dim3(threads2), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip2, nslots,
                          rows_per_slot, (int)total_rows);
     else if (out_bf16)
-      hipLaunchKernelGGL((paif_gf2::gf2_kernel<1>), dim3(grid), dim3(paif_gf2::kThreads), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip2, nslots,
+      hipLaunchKernelGGL((paif_gf2::gf2_kernel<1>), dim3(grid), dim3(threads2), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip2, nslots,
                          rows_per_slot, (int)total_rows);
     else
-      hipLaunchKernelGGL((paif_gf2::gf2_kernel<0>), dim3(grid), dim3(paif_gf2::kThreads), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip2, nslots,
+      hipLaunchKernelGGL((paif_gf2::gf2_kernel<0>), dim3(grid), dim3(threads2), 0, st, guide, y, workspace, lf, flag, B, H, W, nstrip2, nslots,
                          rows_per_slot, (int)total_rows);
     PAIF_LAUNCH_CHECK("guided_filter_fused(mfma2)");
   }
