@@ -420,8 +420,9 @@ def main():
                     blk = {"bound": "hbm", "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS, "algorithmic_tflops": tf}
             elif tag.startswith("gf_") or tag.startswith("gf2_"):
                 blk = {"bound": "hbm", "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS, "algorithmic_tflops": tf,
-                       "note": "gf2_kernel (round 4): two columns per lane, two waves per SIMD, horizontal box sums on the matrix cores, vector-issue "
-                               "bound; gf_fused_kernel (PAIF_GF_ENGINE=valu): the all-VALU form, also its out-of-range fallback"}
+                       "note": "gf2_kernel: two columns per lane, horizontal box sums on the matrix cores, vector-issue bound; fp16 high-frequency "
+                               "output (the fp16 configuration): the 12-wave build, three waves per SIMD (round 6), other outputs: 8 waves, two per "
+                               "SIMD; gf_fused_kernel (PAIF_GF_ENGINE=valu): the all-VALU form, also its out-of-range fallback"}
             elif tag.startswith("conv_") or tag.startswith("dense conv"):
                 blk = {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS}
             else:

@@ -12,14 +12,16 @@
 // What changed against the round-1 kernels (HBM-bound at ~4 TB/s on 14 + 6.5 map passes per stream):
 //   * both eps in one launch: t_my / t_mgy / t_g are written once (no read-modify-write pass), A_e and dLF_e of the output pixel come
 //     out of the register rings (the round-1 kernel re-read them);
-//   * a workgroup = 48 columns (40 outputs: halo x1.2, was 32 / 24: x1.33) x 16 channel PAIRS = 768 threads = 3 waves per SIMD; a wave
-//     load = 4 pixels x 128 B contiguous; 640 columns = 16 strips exactly;
-//   * gf_mfma2.hip's work distribution: the B x nstrip full-height strips laid end to end and cut into equal runs of rows, one per CU,
-//     one round (was 60-row segments + 8 warm-up rows: x1.13), and its addressing: per-lane byte offsets that advance by one row per
-//     iteration, rows / columns outside the image and rows outside the run are range-checked away by the buffer hardware (loads
-//     return 0, stores are dropped) -- no per-row branches, loads one row ahead;
-//   * the per-pixel guide statistics are the forward's planes (gf_guide_stats_kernel: mean_g, 1/(var+eps0), 1/(var+eps1)).
-// Map passes per stream: stage 1 = 4 x 1.2 (dLF_e, A_e) + 2 (b_e) + 2 (t_my, t_mgy) = 8.8, stage 2 = 2 x 1.2 + 3 (y, add, dy) = 5.4.
+//   * the streaming geometry of gf_stream.h: 48-column strips (40 outputs: halo x1.2, was 32 / 24: x1.33) x 16 channel PAIRS = 768
+//     threads = 3 waves per SIMD, 640 columns = 16 strips exactly; full-height strips cut into equal runs of rows, one per CU, one
+//     round (was 60-row segments + 8 warm-up rows: x1.13); per-lane byte offsets advancing one row per iteration with the buffer range
+//     check as the only mask; loads one row ahead;
+//   * the per-pixel guide statistics are the forward's planes (gf_guide_stats_kernel: mean_g, 1/(var+eps0), 1/(var+eps1));
+//   * MC form (the default of the taped networks): the tape is gf_taped.hip's (mean_y, cov), A_e = cov / (var + eps_e) re-formed where
+//     the ring is filled.
+// Map passes per stream: stage 1 = 4 x 1.2 (dLF_e, A_e) + 2 (b_e) + 2 (t_my, t_mgy) = 8.8 (MC: 3 x 1.2 + 1 + 2 = 6.6), stage 2 =
+// 2 x 1.2 + 3 (y, add, dy) = 5.4.  Measured at B=8 480x640: 2.31 ms (round 1) -> 1.02 ms (four-map tape) / 0.94 ms (MC) per stream,
+// ~4 TB/s.
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>

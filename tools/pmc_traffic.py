@@ -22,7 +22,7 @@ def clean(name):
     """rocprofv3 kernel name -> `kernel<template args>` without return type, namespaces and the argument list."""
     n = re.sub(r"^void ", "", name)
     n = re.sub(r"\(anonymous namespace\)::", "", n)
-    n = re.sub(r"^paif_(gf2|conv_dma)::", "", n)
+    n = re.sub(r"^paif_(gf2w12|gf2|gft|gfb|conv_dma)::", "", n)
     m = re.match(r"([A-Za-z_0-9]+(?:<.*?>)?)\(", n)
     return m.group(1) if m else n.split("(")[0]
 
