@@ -106,3 +106,16 @@ def test_dense_conv_dispatch_rules_on_the_host():
     # exact arithmetic
     assert name(precision=0) == "conv_mfma_f32<3, 1, 32, false>"
     assert name(precision=0, cin=16, cout=16) == "conv_mfma_f32<3, 1, 16, false>"
+
+
+def test_streaming_guided_filter_size_rule_on_the_host():
+    """paif_guided_filter_taped_fits is host-only logic (gf_stream.h make_plan): the streaming kernels address rows with wrapping 32-bit
+    offsets that the buffer range check filters, so an image's 32-channel map must stay under 2^30 bytes; anything else keeps the round-1
+    pair (ops.guided_filter_pair falls back by itself)."""
+    L = _lib.load()
+    assert L.paif_guided_filter_taped_fits(8, 480, 640) == 1
+    assert L.paif_guided_filter_taped_fits(1, 10, 10) == 1
+    assert L.paif_guided_filter_taped_fits(1, 9, 100) == 0 and L.paif_guided_filter_taped_fits(1, 100, 9) == 0      # H, W must exceed 2r + 1
+    assert L.paif_guided_filter_taped_fits(1, 2896, 2896) == 1          # 2896^2 * 128 B = 2^30 - 2.4 MB
+    assert L.paif_guided_filter_taped_fits(1, 2897, 2897) == 0
+    assert L.paif_guided_filter_taped_fits(0, 480, 640) == 0
