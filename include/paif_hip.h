@@ -93,7 +93,8 @@ int paif_guided_filter_ab_fwd(const float* guide, const float* y, float* ab, flo
                               int B, int H, int W, paif_stream_t stream);
 int paif_guided_filter_lf_fwd(const float* guide, const float* ab, float* lf, int B, int H, int W,
                               paif_stream_t stream);
-/* Round 6, the taped forward the attack loops and the training step run (csrc/gf_taped.hip): the same two filters with the
+/* Round 6, the taped forward the attack loops and the training step run (csrc/gf_taped.hip; replaces the same reference site,
+ * core/model_fusion_auto.py:522-535 Cell_Decom.decomposition's two GuidedFilter(4, eps) calls, under autograd): the same two filters with the
  * TWO-map tape mc [2][B,H,W,32] = (mean_y, cov) instead of ab's four -- A_e, b_e are re-formed where they are used from mc and
  * the per-pixel guide statistics in `workspace` (paif_guided_filter_fused_workspace_floats(B,H,W) floats, filled here; the reverse
  * pass paif_guided_filter_bwd_input_mc reads it again).  lf [2][B,H,W,32].  paif_guided_filter_taped_fits: 1 if the streaming
@@ -549,7 +550,8 @@ int paif_spa_blend_bwd_input(const float* dagg, const float* w, const float* ir,
 int paif_guided_filter_bwd_input(const float* guide, const float* y, const float* ab, const float* dlf, float eps0,
                                  float eps1, const float* add, float* gstat, float* t_my, float* t_mgy, float* t_g,
                                  float* dy, int B, int H, int W, paif_stream_t stream);
-/* the same reverse pass over paif_guided_filter_taped_fwd's tape (mc, and the statistics workspace it filled) */
+/* the same reverse pass (autograd of core/model_fusion_auto.py:517-535) over paif_guided_filter_taped_fwd's tape (mc, and the
+ * statistics workspace it filled) */
 int paif_guided_filter_bwd_input_mc(const float* guide, const float* y, const float* mc, const float* stats, const float* dlf,
                                     const float* add, float* t_my, float* t_mgy, float* t_g, float* dy, int B, int H, int W,
                                     paif_stream_t stream);
