@@ -382,6 +382,33 @@ def test_guided_filter_writes_high_frequency_maps_as_fp16(shape, engine, monkeyp
     assert float(ref.abs().mean()) < 0.5 * float(lf.abs().mean())
 
 
+@pytest.mark.parametrize("y16", [False, True])
+def test_guided_filter_12_wave_build_is_the_8_wave_build_bit_for_bit(y16, monkeypatch):
+    """csrc/gf_mfma2_w12.hip (round 6: 96-column strips, three waves per SIMD; what the fp16 forward runs) against the 8-wave build of the
+    same source (PAIF_GF_NW=8) on the fp16 high-frequency outputs: the two walk different strips in different runs of rows with a different
+    register / LDS allocation (y delay line and own fragments through LDS, (A, b) fragments published an iteration early, half-strip plane
+    loaders), but every output is formed by the same operations in the same order -- bit-identical, on ragged widths (one to three strips
+    of either width, rests of every size), odd widths, heights of one piece and of several, batches whose runs cross image boundaries, and
+    repeated calls (a race between waves would not repeat)."""
+    dev = _dev()
+    shapes = [(1, 10, 10), (1, 24, 32), (2, 33, 47), (1, 64, 96), (3, 40, 81), (1, 37, 161), (2, 100, 200), (1, 480, 640), (2, 1100, 50),
+              (5, 61, 97), (1, 12, 640), (4, 480, 79)]
+    for B, H, W in shapes:
+        y = torch.from_numpy(S.make_smooth_feature(100 + H + W, B, 32, H, W)).permute(0, 2, 3, 1).contiguous().to(dev)
+        guide = ops.channel_residue(y)
+        yy = y.to(torch.float16) if y16 else y
+        outs = {}
+        for nw in ("8", "12", "12"):
+            monkeypatch.setenv("PAIF_GF_NW", nw)
+            outs.setdefault(nw, []).append(ops.guided_filter_pair(guide, yy, out_bf16=F16).clone())
+        torch.cuda.synchronize()
+        assert torch.equal(outs["12"][0], outs["12"][1]), (B, H, W)
+        assert torch.equal(outs["8"][0], outs["12"][0]), (B, H, W, float((outs["8"][0].float() - outs["12"][0].float()).abs().max()))
+    monkeypatch.setenv("PAIF_GF_NW", "10")
+    with pytest.raises(RuntimeError, match="PAIF_GF_NW"):
+        ops.guided_filter_pair(guide, yy, out_bf16=F16)
+
+
 def _fusion_net():
     from paif_amd.core.model_fusion_auto import Network_Fusion_Searched
     from paif_amd.genotypes import FUSION_AT
